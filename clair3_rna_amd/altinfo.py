@@ -1,0 +1,70 @@
+"""Host-side reconstruction of the per-candidate alt_info field and of the create_tensor text line.
+
+The kernel emits, per candidate, what every covering read shows at the centre column in BAM order
+(c3r_token_t).  From that the ordered alternative-allele dictionary of the reference is rebuilt:
+    src/create_tensor_pileup.py:179     Counter(base_list)  -> first-seen order of distinct tokens
+    src/create_tensor_pileup.py:221-261 alt_dict keys  X<base> / I<ref><SEQ> / D<refseq> / R<ref>
+    src/create_tensor_pileup.py:595-605 line = ctg \t pos \t ref33 \t ints \t "<depth>-<k v k v ...>"
+Order matters: clair3_rna/call_variants.py:144,151,187,196 break ties with max(dict, key=dict.get)
+(first maximum wins).
+"""
+from collections import OrderedDict
+
+from .reads import NT16
+
+_ACGT = {1: "A", 2: "C", 4: "G", 8: "T"}
+
+
+def evc_base(b):
+    """evc_base_from (src/create_tensor_pileup.py:64-74) for an upper-case reference base."""
+    return b if b in "ACGT" else "A"
+
+
+def alt_dict_from_tokens(tokens, readset, ref_seq, ref_start, pos):
+    """tokens: TOKEN_DTYPE slice for one site (BAM order). ref_seq[0] is 1-based ref_start.
+    Returns (OrderedDict alt, depth)."""
+    ref_base = evc_base(ref_seq[pos - ref_start])
+    alt = OrderedDict()
+    depth = alt_count = ins_count = del_count = 0
+    for tk in tokens:
+        b = int(tk["base"])
+        if b in _ACGT:
+            depth += 1
+            u = _ACGT[b]
+            if u != ref_base:
+                alt["X" + u] = alt.get("X" + u, 0) + 1
+                alt_count += 1
+        elif b == 16:          # '*' / '#'
+            depth += 1
+            del_count += 1
+        ind = int(tk["indel"])
+        if ind > 0:
+            seq = readset.read_bases(int(tk["read_idx"]), int(tk["qpos"]), ind)
+            k = "I" + ref_base + seq
+            alt[k] = alt.get(k, 0) + 1
+            ins_count += 1
+        elif ind < 0:
+            a = pos - ref_start + 1
+            k = "D" + ref_seq[a:a + (-ind)]
+            alt[k] = alt.get(k, 0) + 1
+            del_count += 1
+    ref_count = max(0, depth - del_count - ins_count - alt_count)
+    if ref_count > 0:
+        alt["R" + ref_base] = alt.get("R" + ref_base, 0) + ref_count
+    return alt, depth
+
+
+def alt_info_string(depth, alt):
+    return "%d-%s" % (depth, " ".join("%s %d" % kv for kv in alt.items()))
+
+
+def format_lines(ctg, sites, tensors_raw, tokens, readset, ref_seq, ref_start):
+    """Reproduce the reference's create_tensor stdout lines (debug / parity only)."""
+    out = []
+    for i, s in enumerate(sites):
+        pos = int(s["pos"])
+        tk = tokens[int(s["tok_off"]):int(s["tok_off"]) + int(s["n_tok"])]
+        alt, _ = alt_dict_from_tokens(tk, readset, ref_seq, ref_start, pos)
+        ints = " ".join(str(v) for v in tensors_raw[i].reshape(-1).tolist())
+        out.append("%s\t%d\t%s\t%s\t%s" % (ctg, pos, s["ref33"].decode(), ints, alt_info_string(int(s["depth"]), alt)))
+    return out

@@ -1,0 +1,226 @@
+"""ctypes binding of libc3r.so (include/c3r.h).  There is no CPU fallback: if the HIP library is
+missing or no MI355X is visible, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .reads import READ_DTYPE, ReadSet
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libc3r.so")
+
+SITE_DTYPE = np.dtype([("pos", "<i4"), ("depth", "<i4"), ("ref33", "S36"), ("n_tok", "<i4"), ("tok_off", "<u4")], align=True)
+TOKEN_DTYPE = np.dtype([("read_idx", "<u4"), ("indel", "<i4"), ("qpos", "<u4"), ("base", "u1"), ("rev", "u1"), ("pad", "u1", (2,))],
+                       align=True)
+assert SITE_DTYPE.itemsize == 52 and TOKEN_DTYPE.itemsize == 16
+
+C3R_ERRORS = {-1: "EINVAL", -2: "ENODEVICE", -3: "EHIP", -4: "ENOMEM", -5: "EUNSUPPORTED", -6: "EOVERFLOW"}
+
+
+class Params(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("min_mq", C.c_int32), ("excl_flags", C.c_int32), ("min_coverage", C.c_int32),
+                ("snp_min_af", C.c_double), ("indel_min_af", C.c_double), ("head_tail", C.c_int32),
+                ("splice_padding", C.c_int32), ("genotyping_mode", C.c_int32), ("max_depth_rescale", C.c_int32)]
+
+
+class C3RError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libc3r: %s (%s)" % (msg, C3R_ERRORS.get(code, code)))
+        self.code = code
+
+
+EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
+           "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
+           "c3r_pileup_scan", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
+           "c3r_weight_count", "c3r_load_weights", "c3r_infer", "c3r_set_profiling", "c3r_reset_kernel_stats",
+           "c3r_get_kernel_stats"]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libc3r.so and declare prototypes.  Raises ImportError when the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libc3r.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.c3r_version.restype = C.c_char_p
+    L.c3r_create.argtypes = [i32, vp, C.POINTER(vp)]
+    L.c3r_destroy.argtypes = [vp]
+    L.c3r_destroy.restype = None
+    L.c3r_last_error.argtypes = [vp]
+    L.c3r_last_error.restype = C.c_char_p
+    L.c3r_synchronize.argtypes = [vp]
+    L.c3r_stream.argtypes = [vp]
+    L.c3r_stream.restype = vp
+    L.c3r_default_params.argtypes = [C.POINTER(Params)]
+    L.c3r_default_params.restype = None
+    L.c3r_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.c3r_load_reads.argtypes = [vp, vp, i64, vp, i64, vp, i64]
+    L.c3r_set_reference.argtypes = [vp, i64, C.c_char_p, i64]
+    L.c3r_set_bed.argtypes = [vp, i32, vp, i64]
+    L.c3r_set_sites.argtypes = [vp, vp, i64]
+    L.c3r_pileup_scan.argtypes = [vp, i64, i64, C.POINTER(i64)]
+    L.c3r_get_tensors.argtypes = [vp, i32, vp, i64]
+    L.c3r_get_sites.argtypes = [vp, vp, i64]
+    L.c3r_token_count.argtypes = [vp, C.POINTER(i64)]
+    L.c3r_get_tokens.argtypes = [vp, vp, i64]
+    L.c3r_get_columns.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), vp, vp, vp, i64]
+    L.c3r_weight_count.argtypes = [i32]
+    L.c3r_weight_count.restype = i64
+    L.c3r_load_weights.argtypes = [vp, vp, i64, i32]
+    L.c3r_infer.argtypes = [vp, vp, i64, vp]
+    L.c3r_set_profiling.argtypes = [vp, i32]
+    L.c3r_reset_kernel_stats.argtypes = [vp]
+    L.c3r_get_kernel_stats.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i64), i32, C.POINTER(i32)]
+    _lib = L
+    return L
+
+
+def default_params():
+    p = Params()
+    load_library().c3r_default_params(C.byref(p))
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine(object):
+    """One GPU context: tensor build (A1-A5) + network forward (A6/A7) on one MI355X."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.c3r_create(device, stream, C.byref(h))
+        if rc != 0:
+            raise C3RError(rc, "c3r_create(device=%d) failed: no usable MI355X/HIP device (no CPU fallback)" % device)
+        self.h = h
+        self.params = default_params()
+        self.n_candidates = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.c3r_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise C3RError(rc, self.L.c3r_last_error(self.h).decode())
+
+    # ---- configuration / inputs
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.params, k):
+                raise KeyError(k)
+            setattr(self.params, k, v)
+        self._chk(self.L.c3r_set_params(self.h, C.byref(self.params)))
+
+    def load_reads(self, rs):
+        assert isinstance(rs, ReadSet)
+        self.readset = rs
+        self._chk(self.L.c3r_load_reads(self.h, _ptr(rs.reads), len(rs.reads), _ptr(rs.cigar), len(rs.cigar), _ptr(rs.seq), len(rs.seq)))
+
+    def set_reference(self, ref_start, seq):
+        b = seq.encode() if isinstance(seq, str) else bytes(seq)
+        self.ref_start, self.ref_seq = ref_start, b.decode().upper()
+        self._chk(self.L.c3r_set_reference(self.h, ref_start, b, len(b)))
+
+    def set_bed(self, which, intervals):
+        a = np.ascontiguousarray(np.asarray(intervals if intervals is not None else [], dtype=np.int32).reshape(-1, 2))
+        self._chk(self.L.c3r_set_bed(self.h, which, _ptr(a), len(a)))
+
+    def set_sites(self, sites):
+        a = np.ascontiguousarray(np.asarray(sites, dtype=np.int32))
+        self._chk(self.L.c3r_set_sites(self.h, _ptr(a), len(a)))
+
+    # ---- tensor build
+    def scan(self, ctg_start, ctg_end):
+        n = C.c_int64(0)
+        self._chk(self.L.c3r_pileup_scan(self.h, ctg_start, ctg_end, C.byref(n)))
+        self.n_candidates = n.value
+        return n.value
+
+    def tensors(self, rescaled=True):
+        n, Cc = self.n_candidates, self.params.channels
+        out = np.zeros((n, 33, Cc), dtype=np.int32)
+        if n:
+            self._chk(self.L.c3r_get_tensors(self.h, int(rescaled), _ptr(out), n))
+        return out
+
+    def sites(self):
+        out = np.zeros(self.n_candidates, dtype=SITE_DTYPE)
+        if self.n_candidates:
+            self._chk(self.L.c3r_get_sites(self.h, _ptr(out), len(out)))
+        return out
+
+    def tokens(self):
+        n = C.c_int64(0)
+        self._chk(self.L.c3r_token_count(self.h, C.byref(n)))
+        out = np.zeros(n.value, dtype=TOKEN_DTYPE)
+        if n.value:
+            self._chk(self.L.c3r_get_tokens(self.h, _ptr(out), len(out)))
+        return out
+
+    def columns(self):
+        rs, n = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.c3r_get_columns(self.h, C.byref(rs), C.byref(n), None, None, None, 0))
+        Cc = self.params.channels
+        cols = np.zeros((n.value, Cc), dtype=np.int32)
+        depth = np.zeros(n.value, dtype=np.int32)
+        flags = np.zeros(n.value, dtype=np.uint8)
+        self._chk(self.L.c3r_get_columns(self.h, C.byref(rs), C.byref(n), _ptr(cols), _ptr(depth), _ptr(flags), n.value))
+        return dict(region_start=rs.value, cols=cols, depth=depth, flags=flags)
+
+    # ---- network
+    def load_weights(self, blob, channels=None):
+        channels = channels or self.params.channels
+        w = np.ascontiguousarray(blob, dtype=np.float32)
+        self._chk(self.L.c3r_load_weights(self.h, _ptr(w), w.size, channels))
+
+    def infer(self, tensors=None, n=None, fetch=True):
+        if tensors is None:
+            n = self.n_candidates if n is None else n
+            x = None
+        else:
+            x = np.ascontiguousarray(tensors, dtype=np.int32)
+            n = x.shape[0]
+        probs = np.zeros((n, 24), dtype=np.float32) if fetch else None
+        self._chk(self.L.c3r_infer(self.h, _ptr(x), n, _ptr(probs)))
+        return probs
+
+    # ---- measurement
+    def synchronize(self):
+        self._chk(self.L.c3r_synchronize(self.h))
+
+    def stream(self):
+        return self.L.c3r_stream(self.h)
+
+    def set_profiling(self, on):
+        self._chk(self.L.c3r_set_profiling(self.h, int(on)))
+
+    def reset_kernel_stats(self):
+        self._chk(self.L.c3r_reset_kernel_stats(self.h))
+
+    def kernel_stats(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        cnt = (C.c_int64 * cap)()
+        n = C.c_int(0)
+        self._chk(self.L.c3r_get_kernel_stats(self.h, names, ms, cnt, cap, C.byref(n)))
+        return {names[i].decode(): dict(total_ms=ms[i], launches=cnt[i]) for i in range(min(n.value, cap))}

@@ -1,0 +1,584 @@
+// c3r_lib.hip — host side of libc3r.so: the C-ABI of include/c3r.h over the gfx950 kernels.
+// No CPU fallback: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/c3r.h"
+#include "net_kernels.hpp"
+#include "pileup_kernels.hpp"
+
+using namespace c3r;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct KStat { double ms = 0; int64_t n = 0; };
+
+}  // namespace
+
+struct c3r_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string err;
+    c3r_params_t prm;
+    bool profiling = false;
+    std::map<std::string, KStat> kstats;
+    std::vector<std::string> kstat_names;   // stable storage for c3r_get_kernel_stats
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // ---- inputs
+    std::vector<DevRead> h_reads;          // normalised, kept for alt-info formatting
+    std::vector<uint32_t> h_cigar;
+    std::vector<uint8_t> h_seq;
+    int64_t n_indel_ops = 0;
+    DevBuf d_reads, d_cigar, d_seq, d_prefmax;
+    std::string h_ref; int64_t ref_start1 = 1;
+    DevBuf d_ref;
+    std::vector<int32_t> h_bed[2];
+    DevBuf d_bed[2];
+    bool has_bed[2] = {false, false};
+    std::vector<int32_t> h_sites;
+    DevBuf d_sites;
+
+    // ---- scan state
+    int32_t reg_beg0 = 0, reg_end0 = 0;
+    int64_t n_pos = 0;
+    DevBuf d_cols, d_depth, d_ncov, d_flags, d_ev, d_small /* cursor,last_row,totals */, d_blockcnt;
+    int64_t n_cand = 0, n_tok = 0;
+    DevBuf d_cand, d_tensors, d_raw, d_sites_out, d_tokcnt, d_tok;
+    bool tokens_ready = false;
+
+    // ---- network
+    NetState net;
+};
+
+namespace {
+
+int fail(c3r_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) return fail(ctx, C3R_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int ensure(c3r_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return C3R_OK;
+    size_t want = std::max(bytes, (size_t)256);
+    want = want + want / 4;   // grow-only with slack so steady-state steps never reallocate
+    if (b.p) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return C3R_OK;
+}
+
+template <typename T>
+int upload(c3r_ctx *ctx, DevBuf &b, const T *src, size_t n) {
+    int rc = ensure(ctx, b, std::max<size_t>(n * sizeof(T), 16));
+    if (rc) return rc;
+    if (n) HIPCHK(ctx, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return C3R_OK;
+}
+
+// Launch helper: optional per-kernel HIP-event timing on the context's stream.
+struct Launch {
+    c3r_ctx *ctx;
+    const char *name;
+    Launch(c3r_ctx *c, const char *n) : ctx(c), name(n) {
+        if (ctx->profiling) (void)hipEventRecord(ctx->ev0, ctx->stream);
+    }
+    ~Launch() {
+        if (ctx->profiling) {
+            (void)hipEventRecord(ctx->ev1, ctx->stream);
+            (void)hipEventSynchronize(ctx->ev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+            KStat &k = ctx->kstats[name];
+            k.ms += ms; k.n += 1;
+        }
+    }
+};
+
+void recompute_prefmax(c3r_ctx *ctx, std::vector<int32_t> &pm) {
+    pm.resize(ctx->h_reads.size());
+    int32_t m = INT_MIN;
+    for (size_t i = 0; i < ctx->h_reads.size(); ++i) {
+        const DevRead &r = ctx->h_reads[i];
+        const bool pass = !(r.flag & ctx->prm.excl_flags) && !(r.flag & 4) && r.mapq >= ctx->prm.min_mq && r.end > r.pos;
+        if (pass) m = std::max(m, r.end);
+        pm[i] = m;
+    }
+}
+
+int upload_prefmax(c3r_ctx *ctx) {
+    if (ctx->h_reads.empty()) return C3R_OK;
+    std::vector<int32_t> pm;
+    recompute_prefmax(ctx, pm);
+    int rc = upload(ctx, ctx->d_prefmax, pm.data(), pm.size());
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // pm is a temporary
+    return C3R_OK;
+}
+
+// sort + merge intervals into a disjoint union (the overlap test against the union equals the
+// reference's any-interval overlap, shared/interval_tree.py:77-87)
+void merge_intervals(std::vector<int32_t> &iv) {
+    std::vector<std::pair<int32_t, int32_t>> v;
+    for (size_t i = 0; i + 1 < iv.size(); i += 2) v.push_back({iv[i], iv[i + 1]});
+    std::sort(v.begin(), v.end());
+    iv.clear();
+    for (auto &x : v) {
+        if (x.second <= x.first) continue;
+        if (!iv.empty() && x.first <= iv.back()) iv.back() = std::max(iv.back(), x.second);
+        else { iv.push_back(x.first); iv.push_back(x.second); }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *c3r_version(void) { return "c3r 0.1 (gfx950, HIP)"; }
+
+void c3r_default_params(c3r_params_t *p) {
+    memset(p, 0, sizeof *p);
+    p->channels = C3R_CH;
+    p->min_mq = 5;
+    p->excl_flags = 2316;
+    p->min_coverage = 4;
+    p->snp_min_af = 0.08;
+    p->indel_min_af = 0.15;
+    p->max_depth_rescale = 144;
+}
+
+int c3r_create(int device_id, void *stream, c3r_ctx **out) {
+    if (!out) return C3R_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return C3R_ENODEVICE;
+    if (device_id < 0 || device_id >= n) return C3R_EINVAL;
+    if (hipSetDevice(device_id) != hipSuccess) return C3R_ENODEVICE;
+    c3r_ctx *ctx = new c3r_ctx();
+    ctx->device = device_id;
+    c3r_default_params(&ctx->prm);
+    if (stream) ctx->stream = (hipStream_t)stream;
+    else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return C3R_EHIP; }
+        ctx->owns_stream = true;
+    }
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return C3R_EHIP; }
+    *out = ctx;
+    return C3R_OK;
+}
+
+void c3r_destroy(c3r_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+                      &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_ev, &ctx->d_small,
+                      &ctx->d_blockcnt, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
+    for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    net_free(ctx->net);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *c3r_last_error(const c3r_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int c3r_synchronize(c3r_ctx *ctx) {
+    if (!ctx) return C3R_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
+void *c3r_stream(c3r_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int c3r_set_params(c3r_ctx *ctx, const c3r_params_t *p) {
+    if (!ctx || !p) return C3R_EINVAL;
+    if (p->channels != C3R_CH && p->channels != C3R_CH_PHASED) return fail(ctx, C3R_EINVAL, "channels must be 18 or 30");
+    if (p->splice_padding)
+        return fail(ctx, C3R_EUNSUPPORTED, "enable_padding_in_splice_junction_regions is not implemented on the GPU path");
+    const bool refilter = p->min_mq != ctx->prm.min_mq || p->excl_flags != ctx->prm.excl_flags;
+    ctx->prm = *p;
+    if (ctx->prm.max_depth_rescale <= 0) ctx->prm.max_depth_rescale = 144;
+    if (refilter) return upload_prefmax(ctx);
+    return C3R_OK;
+}
+
+int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const uint32_t *cigars, int64_t n_cigar_ops,
+                   const uint8_t *seq4, int64_t n_seq_bytes) {
+    if (!ctx || n_reads < 0 || (n_reads && (!reads || !cigars || !seq4))) return C3R_EINVAL;
+    if (n_reads > INT32_MAX) return fail(ctx, C3R_EINVAL, "too many reads");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->h_reads.clear(); ctx->h_cigar.clear();
+    ctx->h_reads.reserve((size_t)n_reads);
+    ctx->h_cigar.reserve((size_t)n_cigar_ops);
+    ctx->n_indel_ops = 0;
+    int32_t prev_pos = INT_MIN;
+    for (int64_t i = 0; i < n_reads; ++i) {
+        const c3r_read_t &r = reads[i];
+        if (r.pos < prev_pos) return fail(ctx, C3R_EINVAL, "reads must be sorted by pos (read %lld)", (long long)i);
+        prev_pos = r.pos;
+        if ((int64_t)r.cigar_off + r.n_cigar > n_cigar_ops) return fail(ctx, C3R_EINVAL, "cigar range of read %lld out of bounds", (long long)i);
+        if ((int64_t)r.seq_off + (r.l_seq + 1) / 2 > n_seq_bytes) return fail(ctx, C3R_EINVAL, "seq range of read %lld out of bounds", (long long)i);
+        DevRead d;
+        d.pos = r.pos; d.cig_off = (uint32_t)ctx->h_cigar.size(); d.seq_off = r.seq_off; d.flag = r.flag; d.mapq = r.mapq;
+        d.hp = r.hp; d.l_seq = r.l_seq;
+        int64_t rlen = 0;
+        // normalise: drop P/H/zero-length, fold =/X into M, merge adjacent equal ops (htslib merges runs of
+        // D and of I when it attaches an indel to a column, and skips pads)
+        for (uint32_t k = 0; k < r.n_cigar; ++k) {
+            uint32_t c = cigars[r.cigar_off + k];
+            uint32_t op = c & 15u, len = c >> 4;
+            if (op == C3R_CIG_EQ || op == C3R_CIG_X) op = C3R_CIG_M;
+            if (len == 0 || op == C3R_CIG_P || op == C3R_CIG_H) continue;
+            if (op > C3R_CIG_X) return fail(ctx, C3R_EINVAL, "bad cigar op in read %lld", (long long)i);
+            if (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) rlen += len;
+            if (ctx->h_cigar.size() > d.cig_off && (ctx->h_cigar.back() & 15u) == op) {
+                const uint64_t nl = (uint64_t)(ctx->h_cigar.back() >> 4) + len;
+                if (nl >= (1u << 28)) return fail(ctx, C3R_EINVAL, "cigar op too long in read %lld", (long long)i);
+                ctx->h_cigar.back() = (uint32_t)(nl << 4) | op;
+            } else {
+                ctx->h_cigar.push_back((len << 4) | op);
+            }
+        }
+        d.n_cig = (uint32_t)(ctx->h_cigar.size() - d.cig_off);
+        for (uint32_t k = 0; k < d.n_cig; ++k) {
+            const uint32_t op = ctx->h_cigar[d.cig_off + k] & 15u;
+            if (op == C3R_CIG_I || op == C3R_CIG_D) ctx->n_indel_ops++;
+        }
+        if ((int64_t)r.pos + rlen > INT32_MAX) return fail(ctx, C3R_EINVAL, "read %lld ends beyond 2^31", (long long)i);
+        d.end = (int32_t)(r.pos + rlen);
+        ctx->h_reads.push_back(d);
+    }
+    ctx->h_seq.assign(seq4, seq4 + n_seq_bytes);
+    int rc;
+    if ((rc = upload(ctx, ctx->d_reads, ctx->h_reads.data(), ctx->h_reads.size()))) return rc;
+    if ((rc = upload(ctx, ctx->d_cigar, ctx->h_cigar.data(), ctx->h_cigar.size()))) return rc;
+    if ((rc = upload(ctx, ctx->d_seq, ctx->h_seq.data(), ctx->h_seq.size()))) return rc;
+    if ((rc = upload_prefmax(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
+int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t len) {
+    if (!ctx || !ref || len < 0 || ref_start < 1) return C3R_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->h_ref.assign(ref, ref + len);
+    for (auto &ch : ctx->h_ref) if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+    ctx->ref_start1 = ref_start;
+    int rc = upload(ctx, ctx->d_ref, (const uint8_t *)ctx->h_ref.data(), ctx->h_ref.size());
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
+int c3r_set_bed(c3r_ctx *ctx, int which, const int32_t *pairs, int64_t n) {
+    if (!ctx || which < 0 || which > 1 || n < 0 || (n && !pairs)) return C3R_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->has_bed[which] = n > 0;
+    ctx->h_bed[which].assign(pairs, pairs + 2 * n);
+    merge_intervals(ctx->h_bed[which]);
+    int rc = upload(ctx, ctx->d_bed[which], ctx->h_bed[which].data(), ctx->h_bed[which].size());
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
+int c3r_set_sites(c3r_ctx *ctx, const int32_t *sites, int64_t n) {
+    if (!ctx || n < 0 || (n && !sites)) return C3R_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->h_sites.assign(sites, sites + n);
+    std::sort(ctx->h_sites.begin(), ctx->h_sites.end());
+    ctx->h_sites.erase(std::unique(ctx->h_sites.begin(), ctx->h_sites.end()), ctx->h_sites.end());
+    int rc = upload(ctx, ctx->d_sites, ctx->h_sites.data(), ctx->h_sites.size());
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int run_gather(c3r_ctx *ctx, int rescale, int32_t *dst, bool with_sites) {
+    GatherArgs g;
+    g.cols = (const int32_t *)ctx->d_cols.p; g.depth = (const int32_t *)ctx->d_depth.p; g.ncov = (const int32_t *)ctx->d_ncov.p;
+    g.flags = (const uint8_t *)ctx->d_flags.p; g.cand_idx = (const int32_t *)ctx->d_cand.p; g.n_cand = (int32_t)ctx->n_cand;
+    g.n_pos = (int32_t)ctx->n_pos; g.reg_beg0 = ctx->reg_beg0;
+    g.ref = (const uint8_t *)ctx->d_ref.p; g.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); g.ref_len = (int32_t)ctx->h_ref.size();
+    g.head_tail = ctx->prm.head_tail; g.last_row = (const int32_t *)((char *)ctx->d_small.p + 8);
+    g.rescale = rescale; g.max_depth = ctx->prm.max_depth_rescale;
+    g.tensors = dst;
+    g.sites = with_sites ? (c3r_site_t *)ctx->d_sites_out.p : nullptr;
+    g.tok_cnt = with_sites ? (int32_t *)ctx->d_tokcnt.p : nullptr;
+    const int blocks = (int)((ctx->n_cand * 64 + 255) / 256);
+    Launch L(ctx, "k_gather");
+    if (ctx->prm.channels == C3R_CH) hipLaunchKernelGGL(k_gather<C3R_CH>, dim3(blocks), dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL(k_gather<C3R_CH_PHASED>, dim3(blocks), dim3(256), 0, ctx->stream, g);
+    return C3R_OK;
+}
+
+int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n_candidates) {
+    if (!ctx || ctg_end < ctg_start) return C3R_EINVAL;
+    if (ctx->h_ref.empty()) return fail(ctx, C3R_EINVAL, "c3r_set_reference must be called before c3r_pileup_scan");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int C = ctx->prm.channels;
+    // rows: 1-based [max(1, ctg_start-33), ctg_end+33]  (src/create_tensor_pileup.py:411-415)
+    int64_t es = ctg_start - C3R_WINDOW, ee = ctg_end + C3R_WINDOW;
+    if (es < 1) es = 1;
+    if (ee > INT32_MAX - 1) return fail(ctx, C3R_EINVAL, "region beyond 2^31");
+    ctx->reg_beg0 = (int32_t)(es - 1);
+    ctx->reg_end0 = (int32_t)ee;
+    ctx->n_pos = ee - es + 1;
+    ctx->n_cand = 0; ctx->n_tok = 0; ctx->tokens_ready = false;
+    const int64_t n_pos = ctx->n_pos;
+    const int n_tiles = (int)((n_pos + TILE - 1) / TILE);
+    const int n_cblocks = (int)((n_pos + CMP_BLOCK - 1) / CMP_BLOCK);
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_cols, (size_t)n_pos * C * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d_depth, (size_t)n_pos * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ncov, (size_t)n_pos * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d_flags, (size_t)n_pos))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ev, ((size_t)ctx->n_indel_ops + 16 * (size_t)n_tiles + 16) * sizeof(EvRec)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_small, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_blockcnt, (size_t)(n_cblocks + 1) * 4))) return rc;
+    // d_small: [0..7] ev_cursor (u64), [8..11] last_row, [12..15] n_cand, [16..19] n_tok
+    int32_t init[5] = {0, 0, -1, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_small.p, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_flags.p, 0, (size_t)n_pos, ctx->stream));
+
+    ScanArgs a;
+    a.reads = (const DevRead *)ctx->d_reads.p; a.cigar = (const uint32_t *)ctx->d_cigar.p; a.seq = (const uint8_t *)ctx->d_seq.p;
+    a.prefmax_end = (const int32_t *)ctx->d_prefmax.p; a.n_reads = (int32_t)ctx->h_reads.size();
+    a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->h_ref.size();
+    a.reg_beg0 = ctx->reg_beg0; a.reg_end0 = ctx->reg_end0;
+    a.cols = (int32_t *)ctx->d_cols.p; a.depth = (int32_t *)ctx->d_depth.p; a.ncov = (int32_t *)ctx->d_ncov.p; a.flags = (uint8_t *)ctx->d_flags.p;
+    a.lbed = (const int32_t *)ctx->d_bed[0].p; a.n_lbed = (int32_t)(ctx->h_bed[0].size() / 2); a.has_lbed = ctx->has_bed[0];
+    a.cbed = (const int32_t *)ctx->d_bed[1].p; a.n_cbed = (int32_t)(ctx->h_bed[1].size() / 2); a.has_cbed = ctx->has_bed[1];
+    a.sites = (const int32_t *)ctx->d_sites.p; a.n_sites = (int32_t)ctx->h_sites.size(); a.genotyping = ctx->prm.genotyping_mode;
+    a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.min_cov = ctx->prm.min_coverage;
+    a.snp_af = ctx->prm.snp_min_af; a.indel_af = ctx->prm.indel_min_af;
+    a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)ctx->d_small.p; a.last_row = (int32_t *)((char *)ctx->d_small.p + 8);
+    if (a.n_reads > 0) {
+        Launch L(ctx, "k_scan_tiles");
+        if (C == C3R_CH) hipLaunchKernelGGL(k_scan_tiles<C3R_CH>, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_scan_tiles<C3R_CH_PHASED>, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
+    }
+    {
+        Launch L(ctx, "k_select");
+        hipLaunchKernelGGL(k_select, dim3((unsigned)((n_pos + 255) / 256)), dim3(256), 0, ctx->stream, (uint8_t *)ctx->d_flags.p,
+                           (int)n_pos, ctx->reg_beg0, ctx->prm.head_tail, (const int32_t *)((char *)ctx->d_small.p + 8));
+    }
+    {
+        Launch L(ctx, "k_compact_count");
+        hipLaunchKernelGGL(k_compact_count, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
+                           (int32_t *)ctx->d_blockcnt.p);
+    }
+    {
+        Launch L(ctx, "k_excl_scan");
+        hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)ctx->d_blockcnt.p, n_cblocks,
+                           (int32_t *)((char *)ctx->d_small.p + 12));
+    }
+    int32_t n_cand = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n_cand, (char *)ctx->d_small.p + 12, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    ctx->n_cand = n_cand;
+    if (n_candidates) *n_candidates = n_cand;
+    if (n_cand == 0) return C3R_OK;
+    if ((rc = ensure(ctx, ctx->d_cand, (size_t)n_cand * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tensors, (size_t)n_cand * C3R_WINDOW * C * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d_sites_out, (size_t)n_cand * sizeof(c3r_site_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tokcnt, (size_t)(n_cand + 1) * 4))) return rc;
+    {
+        Launch L(ctx, "k_compact_write");
+        hipLaunchKernelGGL(k_compact_write, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
+                           (const int32_t *)ctx->d_blockcnt.p, (int32_t *)ctx->d_cand.p);
+    }
+    if ((rc = run_gather(ctx, 1, (int32_t *)ctx->d_tensors.p, true))) return rc;
+    {
+        Launch L(ctx, "k_excl_scan");
+        hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)ctx->d_tokcnt.p, (int)n_cand,
+                           (int32_t *)((char *)ctx->d_small.p + 16));
+    }
+    int32_t n_tok = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n_tok, (char *)ctx->d_small.p + 16, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_tok = n_tok;
+    if ((rc = ensure(ctx, ctx->d_tok, std::max<size_t>((size_t)n_tok * sizeof(c3r_token_t), 16)))) return rc;
+    {
+        TokArgs t;
+        t.reads = a.reads; t.cigar = a.cigar; t.seq = a.seq; t.prefmax_end = a.prefmax_end; t.n_reads = a.n_reads;
+        t.cand_idx = (const int32_t *)ctx->d_cand.p; t.n_cand = n_cand; t.reg_beg0 = ctx->reg_beg0;
+        t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p; t.tok = (c3r_token_t *)ctx->d_tok.p;
+        t.min_mq = a.min_mq; t.excl_flags = a.excl_flags;
+        Launch L(ctx, "k_tokens");
+        hipLaunchKernelGGL(k_tokens, dim3((unsigned)(((int64_t)n_cand * 64 + 255) / 256)), dim3(256), 0, ctx->stream, t);
+    }
+    ctx->tokens_ready = true;
+    HIPCHK(ctx, hipGetLastError());
+    return C3R_OK;
+}
+
+int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_sites) {
+    if (!ctx || !tensors) return C3R_EINVAL;
+    if (cap_sites < ctx->n_cand) return fail(ctx, C3R_EOVERFLOW, "need room for %lld sites", (long long)ctx->n_cand);
+    if (ctx->n_cand == 0) return C3R_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->n_cand * C3R_WINDOW * ctx->prm.channels * 4;
+    const void *src = ctx->d_tensors.p;
+    if (!rescaled) {
+        int rc = ensure(ctx, ctx->d_raw, bytes);
+        if (rc) return rc;
+        if ((rc = run_gather(ctx, 0, (int32_t *)ctx->d_raw.p, false))) return rc;
+        src = ctx->d_raw.p;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(tensors, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
+int c3r_get_sites(c3r_ctx *ctx, c3r_site_t *sites, int64_t cap_sites) {
+    if (!ctx || !sites) return C3R_EINVAL;
+    if (cap_sites < ctx->n_cand) return fail(ctx, C3R_EOVERFLOW, "need room for %lld sites", (long long)ctx->n_cand);
+    if (ctx->n_cand == 0) return C3R_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(sites, ctx->d_sites_out.p, (size_t)ctx->n_cand * sizeof(c3r_site_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
+int c3r_token_count(c3r_ctx *ctx, int64_t *n_tokens) {
+    if (!ctx || !n_tokens) return C3R_EINVAL;
+    *n_tokens = ctx->n_tok;
+    return C3R_OK;
+}
+
+int c3r_get_tokens(c3r_ctx *ctx, c3r_token_t *tokens, int64_t cap_tokens) {
+    if (!ctx || !tokens) return C3R_EINVAL;
+    if (cap_tokens < ctx->n_tok) return fail(ctx, C3R_EOVERFLOW, "need room for %lld tokens", (long long)ctx->n_tok);
+    if (ctx->n_tok == 0) return C3R_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(tokens, ctx->d_tok.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
+int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t *cols, int32_t *depth, uint8_t *flags, int64_t cap_pos) {
+    if (!ctx) return C3R_EINVAL;
+    if (region_start) *region_start = (int64_t)ctx->reg_beg0 + 1;
+    if (n_pos) *n_pos = ctx->n_pos;
+    if (!cols && !depth && !flags) return C3R_OK;
+    if (cap_pos < ctx->n_pos) return fail(ctx, C3R_EOVERFLOW, "need room for %lld positions", (long long)ctx->n_pos);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->n_pos;
+    if (cols) HIPCHK(ctx, hipMemcpyAsync(cols, ctx->d_cols.p, n * ctx->prm.channels * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (depth) HIPCHK(ctx, hipMemcpyAsync(depth, ctx->d_depth.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (flags) HIPCHK(ctx, hipMemcpyAsync(flags, ctx->d_flags.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int64_t c3r_weight_count(int channels) { return net_weight_count(channels); }
+
+int c3r_load_weights(c3r_ctx *ctx, const float *blob, int64_t n_floats, int channels) {
+    if (!ctx || !blob) return C3R_EINVAL;
+    if (channels != C3R_CH && channels != C3R_CH_PHASED) return fail(ctx, C3R_EINVAL, "channels must be 18 or 30");
+    if (n_floats != net_weight_count(channels))
+        return fail(ctx, C3R_EINVAL, "weight blob has %lld floats, expected %lld", (long long)n_floats, (long long)net_weight_count(channels));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string e;
+    int rc = net_load(ctx->net, blob, channels, ctx->stream, e);
+    if (rc) return fail(ctx, rc, "%s", e.c_str());
+    return C3R_OK;
+}
+
+int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
+    if (!ctx || n < 0) return C3R_EINVAL;
+    if (!ctx->net.loaded) return fail(ctx, C3R_EINVAL, "c3r_load_weights must be called before c3r_infer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int C = ctx->net.channels;
+    const int32_t *d_x = nullptr;
+    if (tensors == nullptr) {
+        if (C != ctx->prm.channels) return fail(ctx, C3R_EINVAL, "weights are for %d channels, scan produced %d", C, ctx->prm.channels);
+        if (n != ctx->n_cand) return fail(ctx, C3R_EINVAL, "n=%lld but the last scan produced %lld candidates", (long long)n, (long long)ctx->n_cand);
+        d_x = (const int32_t *)ctx->d_tensors.p;
+    } else if (n > 0) {
+        int rc = ensure(ctx, ctx->d_raw, (size_t)n * C3R_WINDOW * C * 4);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_raw.p, tensors, (size_t)n * C3R_WINDOW * C * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_x = (const int32_t *)ctx->d_raw.p;
+    }
+    if (n == 0) return C3R_OK;
+    std::string e;
+    auto prof = [&](const char *name, int phase) {
+        if (!ctx->profiling) return;
+        if (phase == 0) (void)hipEventRecord(ctx->ev0, ctx->stream);
+        else {
+            (void)hipEventRecord(ctx->ev1, ctx->stream); (void)hipEventSynchronize(ctx->ev1);
+            float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+            KStat &k = ctx->kstats[name]; k.ms += ms; k.n += 1;
+        }
+    };
+    int rc = net_forward(ctx->net, d_x, n, ctx->stream, prof, e);
+    if (rc) return fail(ctx, rc, "%s", e.c_str());
+    if (probs) {
+        HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, (size_t)n * C3R_NPROB * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return C3R_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int c3r_set_profiling(c3r_ctx *ctx, int enabled) {
+    if (!ctx) return C3R_EINVAL;
+    ctx->profiling = enabled != 0;
+    return C3R_OK;
+}
+int c3r_reset_kernel_stats(c3r_ctx *ctx) {
+    if (!ctx) return C3R_EINVAL;
+    ctx->kstats.clear();
+    return C3R_OK;
+}
+int c3r_get_kernel_stats(c3r_ctx *ctx, const char **names, double *total_ms, int64_t *launches, int cap, int *n) {
+    if (!ctx || !n) return C3R_EINVAL;
+    ctx->kstat_names.clear();
+    for (auto &kv : ctx->kstats) ctx->kstat_names.push_back(kv.first);
+    int i = 0;
+    for (auto &kv : ctx->kstats) {
+        if (i < cap) {
+            if (names) names[i] = ctx->kstat_names[i].c_str();
+            if (total_ms) total_ms[i] = kv.second.ms;
+            if (launches) launches[i] = kv.second.n;
+        }
+        ++i;
+    }
+    *n = i;
+    return C3R_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,453 @@
+// net_kernels.hpp — gfx950 kernels for the Clair3-RNA pileup network (K2-K5) and their host driver.
+//
+// What it replaces: clair3_rna/model.py:126-216 (Clair3_P: BiLSTM(128) -> BiLSTM(160) -> flatten ->
+// Dense128 selu -> {Dense128 selu -> Dense21 selu -> softmax ; Dense128 selu -> Dense3 selu -> softmax})
+// as run by m.predict_on_batch (clair3_rna/call_variants.py:1505).  Keras LSTM conventions: gates
+// i,f,c,o; one bias; zero initial state; backward outputs stored at their original time index.
+//
+// Design.  fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact f32; the
+// 1e-4 probability tolerance rules out plain bf16).  One workgroup = 32 candidate sites x one
+// direction, persistent over the 33 time steps.  Per step it computes Z^T = W^T [4H x K] * act^T
+// [K x 32 sites] with K = input||hidden, so input projection and recurrence are ONE fused GEMM and
+// nothing but the layer output ever goes to HBM:
+//   * MFMA rows  = gate columns, permuted at pack time so that each lane's 16 accumulator rows of a
+//     32-row block are {4 gates} x {4 consecutive hidden units}  -> the LSTM cell update is lane-local
+//     (no cross-lane / LDS exchange of gates), cell state c stays in registers for all 33 steps;
+//   * MFMA cols  = sites; the B operand (activations) is one ds_read_b128 per lane per 8 k's from an
+//     LDS tile act[32][K+4] (row stride chosen conflict-free for b128 reads);
+//   * the A operand (weights) streams from L2 as one fully coalesced global_load_dwordx4 per lane per
+//     8 k's from a layout pre-packed on the host in exact fragment order;
+//   * 4 wavefronts split the 4H/32 row blocks evenly (H=128: 4 each, H=160: 5 each).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/c3r.h"
+
+namespace c3r {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int NET_H1 = 128;
+constexpr int NET_H2 = 160;
+constexpr int NET_T = C3R_WINDOW;          // 33 time steps
+constexpr int NET_SITES = 32;              // sites per workgroup (one MFMA column block)
+constexpr int NET_FLAT = NET_T * 2 * NET_H2;   // 10560
+constexpr int NET_L4 = 128;
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 1 - 2/(exp(2x)+1); exp overflow -> inf -> 1, underflow -> 0 -> -1
+    return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f);
+}
+__device__ __forceinline__ float selu(float x) {
+    const float scale = 1.0507009873554805f, alpha = 1.6732632423543772f;
+    return x > 0.f ? scale * x : scale * alpha * (__expf(x) - 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused bidirectional LSTM layer.  grid = (ceil(n/32), 2 directions), block = 256.
+//   INP   : input width padded to a multiple of 8 (zero columns / zero weight rows)
+//   CIN   : real input width in memory
+//   H     : hidden units
+//   INT_IN: input is int32 (the pileup tensor) instead of float
+// Wp: packed weights [dir][blk][g][64 lanes] float4, bp: packed bias [dir][blk][2][16]
+template <int INP, int CIN, int H, bool INT_IN>
+__global__ __launch_bounds__(256, 2) void k_lstm(const void *__restrict__ xin, const float4 *__restrict__ Wp,
+                                                 const float *__restrict__ bp, float *__restrict__ y, int n) {
+    constexpr int NGX = INP / 8;           // k-groups fed from the layer input (global memory)
+    constexpr int NGH = H / 8;             // k-groups fed from h_{t-1} (LDS)
+    constexpr int NG = NGX + NGH;
+    constexpr int HP = H + 4;              // LDS row stride: conflict-free for ds_read_b128 (H=128: 132, H=160: 164)
+    constexpr int NBLK = 4 * H / 32;
+    constexpr int NT = NBLK / 4;           // 32-row blocks per wave
+    static_assert(INP % 8 == 0 && H % 32 == 0, "shape");
+    __shared__ __attribute__((aligned(16))) float hbuf[2][NET_SITES][HP];   // h double buffer: one barrier per step
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y;
+    const int site0 = blockIdx.x * NET_SITES;
+    int sj = site0 + j; if (sj >= n) sj = n - 1;
+
+    const float4 *wl = Wp + ((size_t)dir * NBLK + wave * NT) * NG * 64 + lane;
+    const float *B = bp + ((size_t)dir * NBLK + wave * NT) * 32 + hh * 16;
+
+    float cst[NT][4];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cst[tt][q] = 0.f;
+
+    for (int step = 0; step < NET_T; ++step) {
+        const int t = dir ? NET_T - 1 - step : step;
+        const int cur = step & 1, nxt = cur ^ 1;
+
+        floatx16 acc[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const float4 *b4 = (const float4 *)(B + tt * 32);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = b4[q];
+                acc[tt][4 * q + 0] = v.x; acc[tt][4 * q + 1] = v.y; acc[tt][4 * q + 2] = v.z; acc[tt][4 * q + 3] = v.w;
+            }
+        }
+        // ---- input part: B operand = x_t[site j][8g + 4hh .. +3], straight from global (L1/L2 resident rows)
+        auto load_x = [&](int g) -> float4 {
+            if (INT_IN) {
+                const int32_t *xp = (const int32_t *)xin + ((size_t)sj * NET_T + t) * CIN;
+                float4 v;
+                const int k0 = 8 * g + 4 * hh;
+                v.x = (k0 + 0 < CIN) ? (float)xp[k0 + 0] : 0.f;
+                v.y = (k0 + 1 < CIN) ? (float)xp[k0 + 1] : 0.f;
+                v.z = (k0 + 2 < CIN) ? (float)xp[k0 + 2] : 0.f;
+                v.w = (k0 + 3 < CIN) ? (float)xp[k0 + 3] : 0.f;
+                return v;
+            } else {
+                return *(const float4 *)((const float *)xin + ((size_t)sj * NET_T + t) * CIN + 8 * g + 4 * hh);
+            }
+        };
+        float4 bnext = load_x(0);
+#pragma unroll 1
+        for (int g = 0; g < NGX; ++g) {
+            const float4 b = bnext;
+            if (g + 1 < NGX) bnext = load_x(g + 1);
+            float4 a[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) a[tt] = wl[((size_t)tt * NG + g) * 64];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].x, b.x, acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].y, b.y, acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].z, b.z, acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].w, b.w, acc[tt], 0, 0, 0);
+        }
+        // ---- recurrent part: B operand = h_{t-1}[site j][8g + 4hh .. +3] from LDS (zero at step 0: skipped)
+        if (step > 0) {
+            const float *hrow = &hbuf[cur][j][4 * hh];
+#pragma unroll 1
+            for (int g = 0; g < NGH; ++g) {
+                const float4 b = *(const float4 *)(hrow + 8 * g);
+                float4 a[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) a[tt] = wl[((size_t)tt * NG + NGX + g) * 64];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].x, b.x, acc[tt], 0, 0, 0);
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].y, b.y, acc[tt], 0, 0, 0);
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].z, b.z, acc[tt], 0, 0, 0);
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].w, b.w, acc[tt], 0, 0, 0);
+            }
+        }
+        // ---- lane-local cell update: acc row 4q+m <-> gate m (i,f,g,o) of unit 8*blk + 4*hh + q
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            float hq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float ig = fast_sigmoid(acc[tt][4 * q + 0]);
+                const float fg = fast_sigmoid(acc[tt][4 * q + 1]);
+                const float gg = fast_tanh(acc[tt][4 * q + 2]);
+                const float og = fast_sigmoid(acc[tt][4 * q + 3]);
+                const float c = fg * cst[tt][q] + ig * gg;
+                cst[tt][q] = c;
+                hq[q] = og * fast_tanh(c);
+            }
+            *(float4 *)&hbuf[nxt][j][8 * (wave * NT + tt) + 4 * hh] = make_float4(hq[0], hq[1], hq[2], hq[3]);
+        }
+        __syncthreads();   // h_t complete; everyone is done reading h_{t-1}
+        // ---- layer output y[site][t][dir*H + u]: coalesced 16-byte stores from the LDS copy of h_t
+        constexpr int HV = H / 4;
+        for (int f = tid; f < NET_SITES * HV; f += 256) {
+            const int row = f / HV, c4 = f % HV;
+            const int s = site0 + row;
+            if (s < n) {
+                const float4 v = *(const float4 *)&hbuf[nxt][row][4 * c4];
+                *(float4 *)(y + ((size_t)s * NET_T + t) * (2 * H) + dir * H + 4 * c4) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// L4: a4[n][128] = selu(y2[n][10560] * W4 + b4).  grid = ceil(n/32), block = 256 (wave = 32-row block
+// of output units).  Same transposed MFMA scheme; B operand straight from global (each site row is
+// streamed sequentially, 16 B per lane).
+__global__ __launch_bounds__(256) void k_fc4(const float *__restrict__ y2, const float4 *__restrict__ Wp,
+                                             const float *__restrict__ bias, float *__restrict__ a4, int n) {
+    constexpr int NG = NET_FLAT / 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int site0 = blockIdx.x * NET_SITES;
+    int s = site0 + j; if (s >= n) s = n - 1;
+    const float *xrow = y2 + (size_t)s * NET_FLAT + 4 * hh;
+    const float4 *wl = Wp + (size_t)wave * NG * 64 + lane;
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll 4
+    for (int g = 0; g < NG; g += 2) {
+        const float4 b0 = *(const float4 *)(xrow + 8 * g);
+        const float4 b1 = *(const float4 *)(xrow + 8 * g + 8);
+        const float4 a0 = wl[(size_t)g * 64];
+        const float4 a1 = wl[(size_t)(g + 1) * 64];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc1, 0, 0, 0);
+    }
+    if (site0 + j < n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u = 32 * wave + 8 * q + 4 * hh;   // acc row 4q+m <-> output unit 32*wave + 8q + 4hh + m
+            float4 v;
+            v.x = selu(acc0[4 * q + 0] + acc1[4 * q + 0] + bias[u + 0]);
+            v.y = selu(acc0[4 * q + 1] + acc1[4 * q + 1] + bias[u + 1]);
+            v.z = selu(acc0[4 * q + 2] + acc1[4 * q + 2] + bias[u + 2]);
+            v.w = selu(acc0[4 * q + 3] + acc1[4 * q + 3] + bias[u + 3]);
+            *(float4 *)(a4 + (size_t)(site0 + j) * NET_L4 + u) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Heads: L5_1 / L5_2 (128->128 selu each), Y_gt21 (128->21) / Y_genotype (128->3) with selu THEN
+// softmax (clair3_rna/model.py:150-152,196-198).  0.15 % of the flops: plain VALU, 8 sites per block.
+constexpr int HEAD_SITES = 8;
+__global__ __launch_bounds__(256) void k_heads(const float *__restrict__ a4, const float *__restrict__ w5 /* [128][256] */,
+                                               const float *__restrict__ b5 /* [256] */, const float *__restrict__ wo /* [128][24] */,
+                                               const float *__restrict__ bo /* [24] */, float *__restrict__ probs, int n) {
+    __shared__ float s_a4[HEAD_SITES][128];
+    __shared__ float s_a5[HEAD_SITES][256];
+    __shared__ float s_lg[HEAD_SITES][24];
+    const int tid = threadIdx.x;
+    const int site0 = blockIdx.x * HEAD_SITES;
+    for (int i = tid; i < HEAD_SITES * 128; i += 256) {
+        const int s = site0 + i / 128;
+        s_a4[i / 128][i % 128] = s < n ? a4[(size_t)s * 128 + (i % 128)] : 0.f;
+    }
+    __syncthreads();
+    {
+        float acc[HEAD_SITES];
+#pragma unroll
+        for (int s = 0; s < HEAD_SITES; ++s) acc[s] = b5[tid];
+        for (int k = 0; k < 128; ++k) {
+            const float w = w5[k * 256 + tid];
+#pragma unroll
+            for (int s = 0; s < HEAD_SITES; ++s) acc[s] = fmaf(s_a4[s][k], w, acc[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < HEAD_SITES; ++s) s_a5[s][tid] = selu(acc[s]);
+    }
+    __syncthreads();
+    if (tid < HEAD_SITES * 24) {
+        const int s = tid / 24, o = tid % 24;
+        const int off = o < 21 ? 0 : 128;     // gt21 reads the L5_1 half, genotype the L5_2 half
+        float acc = bo[o];
+        for (int k = 0; k < 128; ++k) acc = fmaf(s_a5[s][off + k], wo[k * 24 + o], acc);
+        s_lg[s][o] = selu(acc);
+    }
+    __syncthreads();
+    if (tid < HEAD_SITES * 2) {
+        const int s = tid >> 1, part = tid & 1;
+        const int o0 = part ? 21 : 0, o1 = part ? 24 : 21;
+        if (site0 + s < n) {
+            float m = -1e30f;
+            for (int o = o0; o < o1; ++o) m = fmaxf(m, s_lg[s][o]);
+            float sum = 0.f;
+            for (int o = o0; o < o1; ++o) sum += __expf(s_lg[s][o] - m);
+            for (int o = o0; o < o1; ++o) probs[(size_t)(site0 + s) * C3R_NPROB + o] = __expf(s_lg[s][o] - m) / sum;
+        }
+    }
+}
+
+// ================================================================================================ host
+struct NetState {
+    bool loaded = false;
+    int channels = 0;
+    int inp1 = 0;                 // padded layer-1 input width
+    float4 *d_w1 = nullptr; float *d_b1 = nullptr;     // packed LSTM1 (both dirs)
+    float4 *d_w2 = nullptr; float *d_b2 = nullptr;     // packed LSTM2
+    float4 *d_w4 = nullptr; float *d_b4 = nullptr;     // packed L4
+    float *d_w5 = nullptr, *d_b5 = nullptr, *d_wo = nullptr, *d_bo = nullptr;
+    float *d_y1 = nullptr, *d_y2 = nullptr, *d_a4 = nullptr, *d_probs = nullptr;
+    int64_t cap_sites = 0;
+};
+
+inline int64_t net_weight_count(int C) {
+    int64_t n = 0;
+    n += 2 * ((int64_t)C * 4 * NET_H1 + (int64_t)NET_H1 * 4 * NET_H1 + 4 * NET_H1);
+    n += 2 * ((int64_t)2 * NET_H1 * 4 * NET_H2 + (int64_t)NET_H2 * 4 * NET_H2 + 4 * NET_H2);
+    n += (int64_t)NET_FLAT * NET_L4 + NET_L4;
+    n += 2 * (128 * 128 + 128);
+    n += 128 * 21 + 21 + 128 * 3 + 3;
+    return n;
+}
+
+inline void net_free(NetState &s) {
+    void *ptrs[] = {s.d_w1, s.d_b1, s.d_w2, s.d_b2, s.d_w4, s.d_b4, s.d_w5, s.d_b5, s.d_wo, s.d_bo, s.d_y1, s.d_y2, s.d_a4, s.d_probs};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    s = NetState();
+}
+
+// Pack one LSTM direction: Wcat = [K_in (padded to INP rows) ; R] of shape [INP+H][4H] (Keras: [in][4H],
+// gate-major columns i|f|c|o) into MFMA fragment order [blk][g][lane][s] and bias into [blk][hh][q][m].
+inline void pack_lstm_dir(const float *Kin, int cin, int inp, const float *R, const float *b, int H,
+                          std::vector<float> &wp, std::vector<float> &bpk) {
+    const int K = inp + H, NG = K / 8, NBLK = 4 * H / 32;
+    wp.assign((size_t)NBLK * NG * 64 * 4, 0.f);
+    bpk.assign((size_t)NBLK * 32, 0.f);
+    auto wcat = [&](int k, int col) -> float {
+        if (k < inp) return k < cin ? Kin[(size_t)k * 4 * H + col] : 0.f;
+        return R[(size_t)(k - inp) * 4 * H + col];
+    };
+    for (int blk = 0; blk < NBLK; ++blk) {
+        for (int r = 0; r < 32; ++r) {
+            const int q = r >> 3, hh = (r >> 2) & 1, m = r & 3;     // r = 8q + 4hh + m
+            const int unit = 8 * blk + 4 * hh + q, col = m * H + unit;
+            bpk[(size_t)(blk * 2 + hh) * 16 + 4 * q + m] = b[col];
+            for (int g = 0; g < NG; ++g)
+                for (int kh = 0; kh < 2; ++kh)
+                    for (int s = 0; s < 4; ++s) {
+                        const int lane = kh * 32 + r;
+                        wp[(((size_t)blk * NG + g) * 64 + lane) * 4 + s] = wcat(8 * g + 4 * kh + s, col);
+                    }
+        }
+    }
+}
+
+#define NET_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return C3R_EHIP; } \
+    } while (0)
+
+template <typename T>
+inline int net_upload(T *&dst, const std::vector<float> &src, hipStream_t st, std::string &err) {
+    if (dst) { (void)hipFree(dst); dst = nullptr; }
+    NET_HIP(hipMalloc((void **)&dst, src.size() * sizeof(float)));
+    NET_HIP(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    NET_HIP(hipStreamSynchronize(st));
+    return C3R_OK;
+}
+
+inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::string &err) {
+    const float *q = blob;
+    const int inp1 = (C + 7) / 8 * 8;
+    std::vector<float> w1, b1, w2, b2, tw, tb;
+    for (int d = 0; d < 2; ++d) {
+        const float *Kin = q; q += (size_t)C * 4 * NET_H1;
+        const float *R = q; q += (size_t)NET_H1 * 4 * NET_H1;
+        const float *b = q; q += 4 * NET_H1;
+        pack_lstm_dir(Kin, C, inp1, R, b, NET_H1, tw, tb);
+        w1.insert(w1.end(), tw.begin(), tw.end()); b1.insert(b1.end(), tb.begin(), tb.end());
+    }
+    for (int d = 0; d < 2; ++d) {
+        const float *Kin = q; q += (size_t)2 * NET_H1 * 4 * NET_H2;
+        const float *R = q; q += (size_t)NET_H2 * 4 * NET_H2;
+        const float *b = q; q += 4 * NET_H2;
+        pack_lstm_dir(Kin, 2 * NET_H1, 2 * NET_H1, R, b, NET_H2, tw, tb);
+        w2.insert(w2.end(), tw.begin(), tw.end()); b2.insert(b2.end(), tb.begin(), tb.end());
+    }
+    const float *W4 = q; q += (size_t)NET_FLAT * NET_L4;
+    const float *b4 = q; q += NET_L4;
+    const float *W51 = q; q += 128 * 128; const float *b51 = q; q += 128;
+    const float *W52 = q; q += 128 * 128; const float *b52 = q; q += 128;
+    const float *Wg = q; q += 128 * 21; const float *bg = q; q += 21;
+    const float *Wz = q; q += 128 * 3; const float *bz = q; q += 3;
+    // L4 packed [blk(4)][g][lane][s]: row r of block blk <-> output unit 32*blk + r
+    const int NG4 = NET_FLAT / 8;
+    std::vector<float> w4((size_t)4 * NG4 * 64 * 4);
+    for (int blk = 0; blk < 4; ++blk)
+        for (int g = 0; g < NG4; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int r = lane & 31, kh = lane >> 5;
+                    w4[(((size_t)blk * NG4 + g) * 64 + lane) * 4 + sidx] = W4[(size_t)(8 * g + 4 * kh + sidx) * NET_L4 + 32 * blk + r];
+                }
+    std::vector<float> vb4(b4, b4 + NET_L4);
+    std::vector<float> w5((size_t)128 * 256), b5(256), wo((size_t)128 * 24), bo(24);
+    for (int k = 0; k < 128; ++k)
+        for (int o = 0; o < 128; ++o) { w5[(size_t)k * 256 + o] = W51[k * 128 + o]; w5[(size_t)k * 256 + 128 + o] = W52[k * 128 + o]; }
+    for (int o = 0; o < 128; ++o) { b5[o] = b51[o]; b5[128 + o] = b52[o]; }
+    for (int k = 0; k < 128; ++k) {
+        for (int o = 0; o < 21; ++o) wo[(size_t)k * 24 + o] = Wg[k * 21 + o];
+        for (int o = 0; o < 3; ++o) wo[(size_t)k * 24 + 21 + o] = Wz[k * 3 + o];
+    }
+    for (int o = 0; o < 21; ++o) bo[o] = bg[o];
+    for (int o = 0; o < 3; ++o) bo[21 + o] = bz[o];
+    int rc;
+    if ((rc = net_upload(s.d_w1, w1, st, err)) || (rc = net_upload(s.d_b1, b1, st, err)) || (rc = net_upload(s.d_w2, w2, st, err)) ||
+        (rc = net_upload(s.d_b2, b2, st, err)) || (rc = net_upload(s.d_w4, w4, st, err)) || (rc = net_upload(s.d_b4, vb4, st, err)) ||
+        (rc = net_upload(s.d_w5, w5, st, err)) || (rc = net_upload(s.d_b5, b5, st, err)) || (rc = net_upload(s.d_wo, wo, st, err)) ||
+        (rc = net_upload(s.d_bo, bo, st, err)))
+        return rc;
+    s.channels = C; s.inp1 = inp1; s.loaded = true;
+    return C3R_OK;
+}
+
+inline int net_reserve(NetState &s, int64_t n, hipStream_t st, std::string &err) {
+    if (n <= s.cap_sites) return C3R_OK;
+    const int64_t cap = n + n / 4 + 64;
+    NET_HIP(hipStreamSynchronize(st));
+    float **bufs[] = {&s.d_y1, &s.d_y2, &s.d_a4, &s.d_probs};
+    const size_t sizes[] = {(size_t)cap * NET_T * 2 * NET_H1, (size_t)cap * NET_T * 2 * NET_H2, (size_t)cap * NET_L4, (size_t)cap * C3R_NPROB};
+    for (int i = 0; i < 4; ++i) {
+        if (*bufs[i]) { (void)hipFree(*bufs[i]); *bufs[i] = nullptr; }
+        NET_HIP(hipMalloc((void **)bufs[i], sizes[i] * sizeof(float)));
+    }
+    s.cap_sites = cap;
+    return C3R_OK;
+}
+
+// d_x: device int32 [n][33][C].  prof(name, 0|1) brackets each kernel for optional event timing.
+inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t st,
+                       const std::function<void(const char *, int)> &prof, std::string &err) {
+    int rc = net_reserve(s, n, st, err);
+    if (rc) return rc;
+    const int nb = (int)((n + NET_SITES - 1) / NET_SITES);
+    const dim3 grid(nb, 2), block(256);
+    prof("k_lstm1", 0);
+    if (s.channels == C3R_CH) {
+        constexpr int INP = 24;
+        hipLaunchKernelGGL((k_lstm<INP, C3R_CH, NET_H1, true>), grid, block, 0, st, (const void *)d_x,
+                           (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n);
+    } else {
+        constexpr int INP = 32;
+        hipLaunchKernelGGL((k_lstm<INP, C3R_CH_PHASED, NET_H1, true>), grid, block, 0, st, (const void *)d_x,
+                           (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n);
+    }
+    prof("k_lstm1", 1);
+    prof("k_lstm2", 0);
+    {
+        constexpr int INP = 2 * NET_H1;
+        hipLaunchKernelGGL((k_lstm<INP, INP, NET_H2, false>), grid, block, 0, st, (const void *)s.d_y1,
+                           (const float4 *)s.d_w2, (const float *)s.d_b2, s.d_y2, (int)n);
+    }
+    prof("k_lstm2", 1);
+    prof("k_fc4", 0);
+    hipLaunchKernelGGL(k_fc4, dim3(nb), block, 0, st, (const float *)s.d_y2, (const float4 *)s.d_w4, (const float *)s.d_b4, s.d_a4, (int)n);
+    prof("k_fc4", 1);
+    prof("k_heads", 0);
+    hipLaunchKernelGGL(k_heads, dim3((unsigned)((n + HEAD_SITES - 1) / HEAD_SITES)), block, 0, st, (const float *)s.d_a4, (const float *)s.d_w5,
+                       (const float *)s.d_b5, (const float *)s.d_wo, (const float *)s.d_bo, s.d_probs, (int)n);
+    prof("k_heads", 1);
+    NET_HIP(hipGetLastError());
+    return C3R_OK;
+}
+
+}  // namespace c3r

@@ -1,0 +1,620 @@
+// pileup_kernels.hpp — gfx950 tensor-build kernels (K1): CIGAR walk -> per-position channel counts
+// in LDS -> candidate gates -> window gather.  Included by c3r_lib.hip only.
+//
+// What it replaces (reference, /root/reference):
+//   samtools mpileup column semantics ........ src/create_tensor_pileup.py:436-451 (third-party htslib)
+//   generate_tensor ........................... src/create_tensor_pileup.py:85-302
+//   sliding-window / candidate driver ......... src/create_tensor_pileup.py:463-637
+//   depth>216 rescale ......................... clair3_rna/utils.py:88-92,120
+//
+// Design: the region is cut into tiles of TILE reference positions.  One
+// 256-thread workgroup owns one tile: its per-position accumulators [TILE][C] int32 live in LDS, every
+// read overlapping the tile is walked by one 64-lane wavefront (lane = CIGAR op, prefix sums by DPP
+// shuffles, read records and CIGARs loaded coalesced), base/deletion/indel events are LDS atomics, and
+// the finished tile is written to HBM once, coalesced.  Windows are then a pure gather of 33
+// consecutive columns (one wavefront per candidate).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/c3r_types.h"
+
+namespace c3r {
+
+constexpr int TILE = 256;      // reference positions per workgroup
+constexpr int SCAN_THREADS = 256;
+constexpr int WAVES = SCAN_THREADS / 64;
+
+// Host-prepared read header (normalised CIGAR: no P/H/zero-length ops, =/X folded into M, adjacent
+// equal ops merged; `end` = pos + reference length).
+struct DevRead {
+    int32_t pos;       // 0-based
+    int32_t end;       // 0-based, exclusive
+    uint32_t cig_off;
+    uint32_t n_cig;
+    uint64_t seq_off;  // byte offset into the 4-bit packed bases
+    uint16_t flag;
+    uint8_t mapq;
+    uint8_t hp;
+    uint32_t l_seq;
+};
+static_assert(sizeof(DevRead) == 32, "DevRead must be 32 bytes");
+
+struct EvRec {          // one indel event, bucketed by position inside a tile
+    uint64_t key;       // insertion: first <=16 base codes, 4 bits each; deletion: 0
+    uint32_t len;
+    uint32_t read_idx;
+    uint32_t qpos;      // query offset of the first inserted base
+    uint16_t pl;        // position inside the tile
+    uint8_t kind;       // bit0 = reverse strand, bit1 = insertion
+    uint8_t ch;         // channel receiving the max-multiplicity (I1 / i1 / D1 / d1)
+};
+static_assert(sizeof(EvRec) == 24, "EvRec must be 24 bytes");
+
+struct ScanArgs {
+    const DevRead *reads;
+    const uint32_t *cigar;
+    const uint8_t *seq;
+    const int32_t *prefmax_end;   // inclusive prefix max of `end` over passing reads
+    int32_t n_reads;
+    const uint8_t *ref;           // upper-cased reference slice
+    int32_t ref_beg0;             // 0-based position of ref[0]
+    int32_t ref_len;
+    int32_t reg_beg0, reg_end0;   // rows exist only for positions in [reg_beg0, reg_end0)
+    int32_t *cols;                // [n_pos][C]
+    int32_t *depth;               // [n_pos]
+    int32_t *ncov;                // [n_pos] number of reads covering (incl. ref-skips)
+    uint8_t *flags;               // [n_pos] bit0 row, bit1 candidate gate, bit2 emitted
+    const int32_t *lbed; int32_t n_lbed;   // -l column filter (merged, sorted, half-open 0-based)
+    const int32_t *cbed; int32_t n_cbed;   // confident bed
+    const int32_t *sites; int32_t n_sites; // genotyping mode (sorted, 1-based)
+    int32_t has_lbed, has_cbed, genotyping;
+    int32_t min_mq, excl_flags, min_cov;
+    double snp_af, indel_af;
+    EvRec *ev;                    // scratch, one slot per I/D op in the loaded reads (+ padding)
+    unsigned long long *ev_cursor;
+    int32_t *last_row;            // atomicMax of the last position with a row
+};
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ bool read_passes(const DevRead &r, int min_mq, int excl) {
+    return !(r.flag & excl) && !(r.flag & 4) && r.mapq >= min_mq && r.end > r.pos;
+}
+
+__device__ __forceinline__ int base_code(const uint8_t *seq, uint64_t off, uint32_t q, uint32_t l_seq) {
+    if (q >= l_seq) return 15;
+    uint8_t b = seq[off + (q >> 1)];
+    return (q & 1) ? (b & 0xf) : (b >> 4);
+}
+// BAM code -> 0..3 for A,C,G,T; -1 otherwise ('=', N and IUPAC codes contribute nothing,
+// src/create_tensor_pileup.py:149,247-258)
+__device__ __forceinline__ int acgt_index(int code) {
+    return code == 1 ? 0 : code == 2 ? 1 : code == 4 ? 2 : code == 8 ? 3 : -1;
+}
+__device__ __forceinline__ int ref_index(uint8_t c) {   // evc_base_from: anything not ACGT counts as 'A'
+    return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0;
+}
+
+// first index i in [0,n) with a[i] > v  (a non-decreasing)
+__device__ __forceinline__ int upper_bound_gt(const int32_t *a, int n, int v) {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] > v) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+__device__ __forceinline__ int lower_bound_pos(const DevRead *r, int n, int v) {  // first i with r[i].pos >= v
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (r[mid].pos >= v) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+// merged, sorted, disjoint half-open intervals: does [b,e) overlap any?
+__device__ __forceinline__ bool intervals_overlap(const int32_t *iv, int n, int b, int e) {
+    int lo = 0, hi = n;   // first interval with end > b
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (iv[2 * mid + 1] > b) hi = mid; else lo = mid + 1; }
+    return lo < n && iv[2 * lo] < e;
+}
+__device__ __forceinline__ bool sorted_contains(const int32_t *a, int n, int v) {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] >= v) hi = mid; else lo = mid + 1; }
+    return lo < n && a[lo] == v;
+}
+
+enum WalkMode { ACCUM = 0, SCATTER = 1, FIRSTSEEN = 2 };
+
+struct TileLds {
+    int32_t *cnt;      // [TILE][C]
+    int32_t *cov;      // [TILE+1] coverage difference array, then inclusive-scanned in place
+    int32_t *evoff;    // [TILE]
+    int32_t *evfill;   // [TILE]
+    int32_t *maxdel;   // [TILE]
+    uint32_t *first;   // [TILE][6] first-seen token index per class A,C,G,T,I,D
+    uint8_t *amb;      // [TILE]
+};
+
+// Walk every read overlapping the tile.  One wavefront per read, one lane per CIGAR op.
+template <int C, int MODE>
+__device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, unsigned long long ev_base) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int r = lo + wave; r < hi; r += WAVES) {
+        const DevRead rd = a.reads[r];
+        if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.pos >= t1) continue;
+        const bool rev = (rd.flag & 16) != 0;
+        if (MODE == ACCUM && lane == 0) {
+            atomicAdd(&s.cov[max(rd.pos, t0) - t0], 1);
+            if (rd.end < t1) atomicAdd(&s.cov[rd.end - t0], -1);
+        }
+        int ref_carry = 0, q_carry = 0, prev_carry = 15;
+        for (uint32_t kb = 0; kb < rd.n_cig; kb += 64) {
+            const uint32_t k = kb + lane;
+            const bool valid = k < rd.n_cig;
+            const uint32_t c = valid ? a.cigar[rd.cig_off + k] : 15u;
+            const int op = (int)(c & 15u);
+            const int len = valid ? (int)(c >> 4) : 0;
+            const int rl = (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) ? len : 0;
+            const int ql = (op == C3R_CIG_M || op == C3R_CIG_I || op == C3R_CIG_S) ? len : 0;
+            const int rincl = wave_incl_scan(rl);
+            const int qincl = wave_incl_scan(ql);
+            const int rstart = rd.pos + ref_carry + rincl - rl;
+            const int qstart = q_carry + qincl - ql;
+            int prev = __shfl_up(op, 1, 64);
+            if (lane == 0) prev = prev_carry;
+
+            if (op == C3R_CIG_M) {
+                const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
+                for (int p = b0; p < b1; ++p) {
+                    const int code = base_code(a.seq, rd.seq_off, (uint32_t)(qstart + (p - rstart)), rd.l_seq);
+                    const int bi = acgt_index(code);
+                    if (bi >= 0) {
+                        const int pl = p - t0;
+                        if (MODE == ACCUM) {
+                            atomicAdd(&s.cnt[pl * C + (rev ? 9 + bi : bi)], 1);
+                            if (C == C3R_CH_PHASED) {
+                                if (rd.hp == 1) atomicAdd(&s.cnt[pl * C + C3R_AP + bi], 1);
+                                else if (rd.hp == 2) atomicAdd(&s.cnt[pl * C + C3R_AM + bi], 1);
+                            }
+                        } else if (MODE == FIRSTSEEN) {
+                            if (s.amb[pl]) atomicMin(&s.first[pl * 6 + bi], 2u * (uint32_t)r);
+                        }
+                    }
+                }
+            } else if (op == C3R_CIG_D && MODE == ACCUM) {
+                const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
+                for (int p = b0; p < b1; ++p) atomicAdd(&s.cnt[(p - t0) * C + (rev ? C3R_HASH : C3R_STAR)], 1);
+            }
+            // indel attached to the column BEFORE the op (htslib: peek the next op at the last
+            // position of the current one).  After normalisation: I needs a ref-consuming predecessor,
+            // D needs an M or N predecessor.
+            const bool prev_ref = (prev == C3R_CIG_M || prev == C3R_CIG_D || prev == C3R_CIG_N);
+            const bool is_ins = (op == C3R_CIG_I) && prev_ref;
+            const bool is_del = (op == C3R_CIG_D) && (prev == C3R_CIG_M || prev == C3R_CIG_N);
+            if (is_ins || is_del) {
+                const int anchor = rstart - 1;
+                if (anchor >= t0 && anchor < t1) {
+                    const int pl = anchor - t0;
+                    if (MODE == ACCUM) {
+                        int ch;
+                        if (is_ins) {
+                            const int fc = base_code(a.seq, rd.seq_off, (uint32_t)qstart, rd.l_seq);
+                            // 'I' iff the first inserted char is one of "ACGTN*" (upper case => forward strand),
+                            // src/create_tensor_pileup.py:227-232
+                            ch = (!rev && (acgt_index(fc) >= 0 || fc == 15)) ? C3R_I : C3R_i;
+                        } else {
+                            ch = rev ? C3R_d : C3R_D;
+                            atomicMax(&s.maxdel[pl], len);
+                        }
+                        atomicAdd(&s.cnt[pl * C + ch], 1);
+                        if (C == C3R_CH_PHASED) {
+                            if (rd.hp == 1) atomicAdd(&s.cnt[pl * C + (is_ins ? C3R_IP : C3R_DP)], 1);
+                            else if (rd.hp == 2) atomicAdd(&s.cnt[pl * C + (is_ins ? C3R_IM : C3R_DM)], 1);
+                        }
+                    } else if (MODE == SCATTER) {
+                        EvRec e;
+                        e.key = 0;
+                        int ch;
+                        if (is_ins) {
+                            const int nk = len < 16 ? len : 16;
+                            for (int j = 0; j < nk; ++j)
+                                e.key |= (uint64_t)base_code(a.seq, rd.seq_off, (uint32_t)(qstart + j), rd.l_seq) << (4 * j);
+                            const int fc = (int)(e.key & 15u);
+                            ch = (!rev && (acgt_index(fc) >= 0 || fc == 15)) ? C3R_I1 : C3R_i1;
+                        } else {
+                            ch = rev ? C3R_d1 : C3R_D1;
+                        }
+                        e.len = (uint32_t)len; e.read_idx = (uint32_t)r; e.qpos = (uint32_t)qstart;
+                        e.pl = (uint16_t)pl; e.kind = (uint8_t)((rev ? 1 : 0) | (is_ins ? 2 : 0)); e.ch = (uint8_t)ch;
+                        const int slot = s.evoff[pl] + atomicAdd(&s.evfill[pl], 1);
+                        a.ev[ev_base + (unsigned)slot] = e;
+                    } else {  // FIRSTSEEN
+                        if (s.amb[pl]) atomicMin(&s.first[pl * 6 + (is_ins ? 4 : 5)], 2u * (uint32_t)r + 1u);
+                    }
+                }
+            }
+            ref_carry += __shfl(rincl, 63, 64);
+            q_carry += __shfl(qincl, 63, 64);
+            prev_carry = __shfl(op, 63, 64);
+            if (rd.pos + ref_carry >= t1) break;
+        }
+    }
+}
+
+__device__ __forceinline__ bool ev_equal(const ScanArgs &a, const EvRec &x, const EvRec &y) {
+    if (x.kind != y.kind || x.len != y.len || x.key != y.key) return false;
+    if ((x.kind & 2) && x.len > 16) {
+        const DevRead rx = a.reads[x.read_idx], ry = a.reads[y.read_idx];
+        for (uint32_t j = 16; j < x.len; ++j)
+            if (base_code(a.seq, rx.seq_off, x.qpos + j, rx.l_seq) != base_code(a.seq, ry.seq_off, y.qpos + j, ry.l_seq)) return false;
+    }
+    return true;
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, *total = sum
+__device__ __forceinline__ int block_excl_scan(int v, int *wave_tot /* LDS [WAVES] */, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(v);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { const int t = wave_tot[w]; if (w < wave) base += t; tot += t; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+template <int C>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
+    __shared__ int32_t s_cnt[TILE * C];
+    __shared__ int32_t s_cov[TILE + 1];
+    __shared__ int32_t s_evoff[TILE];
+    __shared__ int32_t s_evfill[TILE];
+    __shared__ int32_t s_maxdel[TILE];
+    __shared__ uint32_t s_first[TILE * 6];
+    __shared__ uint8_t s_amb[TILE];
+    __shared__ int s_misc[8];
+    __shared__ unsigned long long s_evbase;
+
+    const int tid = threadIdx.x;
+    const int t0 = a.reg_beg0 + (int)blockIdx.x * TILE;
+    const int t1 = min(t0 + TILE, a.reg_end0);
+    if (tid == 0) {
+        // reads that can overlap [t0,t1): index range [lo,hi)
+        s_misc[0] = upper_bound_gt(a.prefmax_end, a.n_reads, t0);
+        s_misc[1] = lower_bound_pos(a.reads, a.n_reads, t1);
+    }
+    __syncthreads();
+    const int lo = s_misc[0], hi = s_misc[1];
+    if (lo >= hi) return;   // nothing covers this tile: flags stay 0 (pre-cleared)
+
+    TileLds s{s_cnt, s_cov, s_evoff, s_evfill, s_maxdel, s_first, s_amb};
+    for (int i = tid; i < TILE * C; i += SCAN_THREADS) s_cnt[i] = 0;
+    for (int i = tid; i < TILE * 6; i += SCAN_THREADS) s_first[i] = 0xffffffffu;
+    s_cov[tid] = 0; if (tid == 0) s_cov[TILE] = 0;
+    s_evfill[tid] = 0; s_maxdel[tid] = 0; s_amb[tid] = 0;
+    __syncthreads();
+
+    walk_reads<C, ACCUM>(a, s, lo, hi, t0, t1, 0ull);
+    __syncthreads();
+
+    // coverage: inclusive scan of the difference array; indel events: exclusive scan of per-position counts
+    int *wave_tot = &s_misc[2];
+    int tot;
+    const int my_cov_d = s_cov[tid];
+    const int cov_ex = block_excl_scan(my_cov_d, wave_tot, &tot);
+    const int my_cov = cov_ex + my_cov_d;
+    const int32_t *row = &s_cnt[tid * C];
+    const int nev = row[C3R_I] + row[C3R_i] + row[C3R_D] + row[C3R_d];
+    int ev_total;
+    const int ev_ex = block_excl_scan(nev, wave_tot, &ev_total);
+    s_evoff[tid] = ev_ex;
+    if (ev_total > 0) {
+        if (tid == 0) s_evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
+        __syncthreads();
+        const unsigned long long evb = s_evbase;
+        walk_reads<C, SCATTER>(a, s, lo, hi, t0, t1, evb);
+        __threadfence_block();
+        __syncthreads();
+        // max multiplicity of one allele per (position, channel): I1 / i1 / D1 / d1
+        for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+            const EvRec me = a.ev[evb + (unsigned)e];
+            const int pl = me.pl;
+            const int b = s_evoff[pl];
+            const int32_t *rw = &s_cnt[pl * C];
+            const int n = rw[C3R_I] + rw[C3R_i] + rw[C3R_D] + rw[C3R_d];
+            int eq = 0;
+            for (int j = 0; j < n; ++j) {
+                const EvRec o = a.ev[evb + (unsigned)(b + j)];
+                eq += ev_equal(a, me, o) ? 1 : 0;
+            }
+            atomicMax(&s_cnt[pl * C + me.ch], eq);
+        }
+        __syncthreads();
+    }
+
+    // ---- per-position gates (src/create_tensor_pileup.py:259-299, :536-556)
+    const int p = t0 + tid;
+    bool is_row = false, cand = false, ambiguous = false;
+    int depth = 0, refi = 0;
+    int cls[6] = {0, 0, 0, 0, 0, 0};
+    bool gates_ok = false;
+    if (p < t1 && my_cov > 0) {
+        is_row = !a.has_lbed || intervals_overlap(a.lbed, a.n_lbed, p, p + 1);
+    }
+    if (is_row) {
+        int32_t *c = &s_cnt[tid * C];
+        const int up = c[C3R_A] + c[C3R_C] + c[C3R_G] + c[C3R_T];
+        const int lw = c[C3R_a] + c[C3R_c] + c[C3R_g] + c[C3R_t];
+        depth = up + lw + c[C3R_STAR] + c[C3R_HASH];
+        const int rp = p - a.ref_beg0;
+        const uint8_t rb = (rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
+        const bool ref_acgt = (rb == 'A' || rb == 'C' || rb == 'G' || rb == 'T');
+        refi = ref_index(rb);
+        cls[0] = c[C3R_A] + c[C3R_a]; cls[1] = c[C3R_C] + c[C3R_c]; cls[2] = c[C3R_G] + c[C3R_g]; cls[3] = c[C3R_T] + c[C3R_t];
+        cls[4] = c[C3R_I] + c[C3R_i]; cls[5] = c[C3R_D] + c[C3R_d];
+        const double denom = depth > 0 ? (double)depth : 1.0;
+        bool pass = false;
+        for (int x = 0; x < 4; ++x)
+            if (x != refi && cls[x] > 0 && (double)cls[x] / denom >= a.snp_af) pass = true;
+        if (cls[4] > 0 && (double)cls[4] / denom >= a.indel_af) pass = true;
+        if (cls[5] > 0 && (double)cls[5] / denom >= a.indel_af) pass = true;
+        if (depth > 0 && (a.snp_af == 0.0 || a.indel_af == 0.0)) pass = true;
+        if (!pass) {
+            // pileup_list[0][0] != reference_base: top class by count, ties broken by first occurrence
+            int m = 0;
+            for (int x = 0; x < 6; ++x) m = max(m, cls[x]);
+            if (m > 0) {
+                if (cls[refi] < m) pass = true;
+                else {
+                    for (int x = 0; x < 6; ++x) if (x != refi && cls[x] == m) ambiguous = true;
+                }
+            }
+        }
+        bool site_ok;
+        if (a.genotyping) site_ok = sorted_contains(a.sites, a.n_sites, p + 1);
+        else {
+            gates_ok = ref_acgt && depth >= a.min_cov &&
+                       (!a.has_cbed || intervals_overlap(a.cbed, a.n_cbed, p, p + s_maxdel[tid] + 2));
+            site_ok = gates_ok && pass;
+            if (!gates_ok) ambiguous = false;
+        }
+        if (a.genotyping) ambiguous = false;
+        cand = site_ok;
+        // reference-base channels are overwritten with minus the strand totals (:296-297)
+        c[refi] = -up;
+        c[9 + refi] = -lw;
+    }
+    s_amb[tid] = ambiguous ? 1 : 0;
+    if (__syncthreads_or(ambiguous ? 1 : 0)) {
+        walk_reads<C, FIRSTSEEN>(a, s, lo, hi, t0, t1, 0ull);
+        __syncthreads();
+        if (ambiguous) {
+            int m = 0;
+            for (int x = 0; x < 6; ++x) m = max(m, cls[x]);
+            const uint32_t fr = s_first[tid * 6 + refi];
+            bool top_ne_ref = false;
+            for (int x = 0; x < 6; ++x)
+                if (x != refi && cls[x] == m && s_first[tid * 6 + x] < fr) top_ne_ref = true;
+            cand = gates_ok && top_ne_ref;
+        }
+    }
+    __syncthreads();
+
+    // ---- write the tile: columns coalesced, then per-position metadata
+    const int npos = t1 - t0;
+    int32_t *gcol = a.cols + (size_t)(t0 - a.reg_beg0) * C;
+    for (int i = tid; i < npos * C; i += SCAN_THREADS) gcol[i] = s_cnt[i];
+    if (p < t1) {
+        const int gi = p - a.reg_beg0;
+        a.depth[gi] = depth;
+        a.ncov[gi] = is_row ? my_cov : 0;
+        a.flags[gi] = (uint8_t)((is_row ? 1 : 0) | (cand ? 2 : 0));
+    }
+    const int lastp = is_row ? p : -1;
+    int mx = lastp;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+    if ((tid & 63) == 0 && mx >= 0) atomicMax(a.last_row, mx);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Window selection (src/create_tensor_pileup.py:512-516,565-568,613-637): a candidate is emitted iff
+// the 33 positions centre-16..centre+16 are contiguous rows; with head_tail the ring is pre-filled
+// with zero columns after every gap (left side always OK) and the stream end is flushed with 16
+// zero columns (right side OK only when the run reaches the last row of the stream).
+__global__ void k_select(uint8_t *flags, int n_pos, int reg_beg0, int head_tail, const int32_t *last_row) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pos) return;
+    const uint8_t f = flags[i];
+    if (!(f & 2)) return;
+    bool ok = true;
+    if (!head_tail) {
+        if (i - C3R_FLANK < 0 || i + C3R_FLANK >= n_pos) ok = false;
+        else for (int q = i - C3R_FLANK; q <= i + C3R_FLANK; ++q) if (!(flags[q] & 1)) { ok = false; break; }
+    } else {
+        const int last = *last_row - reg_beg0;
+        const int hi = min(i + C3R_FLANK, last);
+        for (int q = i + 1; q <= hi; ++q) if (!(flags[q] & 1)) { ok = false; break; }
+    }
+    if (ok) flags[i] = f | 4;
+}
+
+// ordered stream compaction of emitted positions: count -> scan -> write
+constexpr int CMP_THREADS = 256;
+constexpr int CMP_ITEMS = 4;                      // positions per thread
+constexpr int CMP_BLOCK = CMP_THREADS * CMP_ITEMS;
+
+__global__ __launch_bounds__(CMP_THREADS) void k_compact_count(const uint8_t *flags, int n_pos, int32_t *block_cnt) {
+    const int base = blockIdx.x * CMP_BLOCK + threadIdx.x * CMP_ITEMS;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < CMP_ITEMS; ++j) { const int i = base + j; if (i < n_pos && (flags[i] & 4)) ++c; }
+    __shared__ int wsum[CMP_THREADS / 64];
+    int v = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < CMP_THREADS / 64; ++w) t += wsum[w]; block_cnt[blockIdx.x] = t; }
+}
+
+// single-block exclusive scan of n ints (in place); total written to *total
+__global__ __launch_bounds__(1024) void k_excl_scan(int32_t *data, int n, int32_t *total) {
+    __shared__ int wtot[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? data[i] : 0;
+        const int incl = wave_incl_scan(v);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int wb = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int t = wtot[w]; if (w < wave) wb += t; tot += t; }
+        const int carry = carry_s;
+        if (i < n) data[i] = carry + wb + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(CMP_THREADS) void k_compact_write(const uint8_t *flags, int n_pos, const int32_t *block_off,
+                                                                 int32_t *cand_idx /* region-relative index */) {
+    __shared__ int wsum[CMP_THREADS / 64];
+    const int base = blockIdx.x * CMP_BLOCK + threadIdx.x * CMP_ITEMS;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < CMP_ITEMS; ++j) { const int i = base + j; if (i < n_pos && (flags[i] & 4)) ++c; }
+    const int incl = wave_incl_scan(c);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = block_off[blockIdx.x] + incl - c;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+#pragma unroll
+    for (int j = 0; j < CMP_ITEMS; ++j) { const int i = base + j; if (i < n_pos && (flags[i] & 4)) cand_idx[off++] = i; }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Window gather: one wavefront per candidate.  Copies 33 consecutive columns (zero-filled outside the
+// run when head_tail), applies the A5 rescale (clair3_rna/utils.py:88-92: tensor / (depth/144) in
+// float64, truncated toward zero by the int32 store) and writes the site record.
+struct GatherArgs {
+    const int32_t *cols; const int32_t *depth; const int32_t *ncov; const uint8_t *flags;
+    const int32_t *cand_idx; int32_t n_cand; int32_t n_pos; int32_t reg_beg0;
+    const uint8_t *ref; int32_t ref_beg0; int32_t ref_len;
+    int32_t head_tail; const int32_t *last_row;
+    int32_t rescale; int32_t max_depth;   // 144
+    int32_t *tensors;      // [n][33][C]
+    c3r_site_t *sites;     // [n] (may be null)
+    int32_t *tok_cnt;      // [n] (may be null): number of tokens of the centre column
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void k_gather(const GatherArgs g) {
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= g.n_cand) return;
+    const int ci = g.cand_idx[w];
+    int lo_valid = ci - C3R_FLANK, hi_valid = ci + C3R_FLANK;
+    if (g.head_tail) {
+        int q = ci;
+        while (q - 1 >= 0 && q - 1 >= ci - C3R_FLANK && (g.flags[q - 1] & 1)) --q;
+        lo_valid = q;
+        hi_valid = min(ci + C3R_FLANK, *g.last_row - g.reg_beg0);
+    }
+    const int dep = g.depth[ci];
+    const bool scale = g.rescale && dep > 0 && (double)dep > (double)g.max_depth * 1.5;
+    const double sf = (double)dep / (double)g.max_depth;
+    int32_t *out = g.tensors + (size_t)w * C3R_WINDOW * C;
+    const int first = ci - C3R_FLANK;
+    for (int i = lane; i < C3R_WINDOW * C; i += 64) {
+        const int q = first + i / C;
+        int v = 0;
+        if (q >= lo_valid && q <= hi_valid) v = g.cols[(size_t)q * C + (i % C)];
+        if (scale) v = (int32_t)((double)v / sf);
+        out[i] = v;
+    }
+    if (g.sites) {
+        c3r_site_t *s = &g.sites[w];
+        if (lane < C3R_WINDOW) {
+            const int rp = g.reg_beg0 + first + lane - g.ref_beg0;
+            s->ref33[lane] = (rp >= 0 && rp < g.ref_len) ? (char)g.ref[rp] : 'A';
+        } else if (lane < C3R_WINDOW + 3) {
+            s->ref33[lane] = 0;
+        }
+        if (lane == 0) { s->pos = g.reg_beg0 + ci + 1; s->depth = dep; s->n_tok = g.ncov[ci]; s->tok_off = 0; }
+    }
+    if (g.tok_cnt && lane == 0) g.tok_cnt[w] = g.ncov[ci];
+}
+
+// -------------------------------------------------------------------------------------------------
+// Alt tokens: for every emitted candidate list, in BAM order, what each covering read shows at the
+// centre column.  The host rebuilds the ordered alt_info dictionary from these
+// (src/create_tensor_pileup.py:179,221-261,595-596).
+struct TokArgs {
+    const DevRead *reads; const uint32_t *cigar; const uint8_t *seq; const int32_t *prefmax_end; int32_t n_reads;
+    const int32_t *cand_idx; int32_t n_cand; int32_t reg_beg0;
+    const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
+    int32_t min_mq, excl_flags;
+};
+
+__global__ __launch_bounds__(256) void k_tokens(const TokArgs t) {
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= t.n_cand) return;
+    const int p = t.reg_beg0 + t.cand_idx[w];
+    const int lo = upper_bound_gt(t.prefmax_end, t.n_reads, p);
+    const int hi = lower_bound_pos(t.reads, t.n_reads, p + 1);
+    const int base_off = t.tok_off[w];
+    if (lane == 0) t.sites[w].tok_off = (uint32_t)base_off;
+    int written = 0;
+    for (int rb = lo; rb < hi; rb += 64) {
+        const int r = rb + lane;
+        bool cov = false;
+        DevRead rd;
+        if (r < hi) { rd = t.reads[r]; cov = read_passes(rd, t.min_mq, t.excl_flags) && rd.pos <= p && rd.end > p; }
+        const unsigned long long m = __ballot(cov);
+        if (cov) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            c3r_token_t tk; tk.read_idx = (uint32_t)r; tk.indel = 0; tk.qpos = 0; tk.base = 15; tk.rev = (rd.flag & 16) ? 1 : 0; tk.pad[0] = tk.pad[1] = 0;
+            int x = rd.pos, y = 0;
+            for (uint32_t k = 0; k < rd.n_cig; ++k) {
+                const uint32_t c = t.cigar[rd.cig_off + k];
+                const int op = (int)(c & 15u), len = (int)(c >> 4);
+                if (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) {
+                    if (p < x + len) {
+                        if (op == C3R_CIG_M) tk.base = (uint8_t)base_code(t.seq, rd.seq_off, (uint32_t)(y + (p - x)), rd.l_seq);
+                        else tk.base = (op == C3R_CIG_D) ? 16 : 17;
+                        if (p == x + len - 1 && k + 1 < rd.n_cig) {
+                            const uint32_t c2 = t.cigar[rd.cig_off + k + 1];
+                            const int op2 = (int)(c2 & 15u), len2 = (int)(c2 >> 4);
+                            if (op2 == C3R_CIG_I) { tk.indel = len2; tk.qpos = (uint32_t)(y + (op == C3R_CIG_M ? len : 0)); }
+                            else if (op2 == C3R_CIG_D && op != C3R_CIG_D) tk.indel = -len2;
+                        }
+                        break;
+                    }
+                    x += len;
+                    if (op == C3R_CIG_M) y += len;
+                } else if (op == C3R_CIG_I || op == C3R_CIG_S) {
+                    y += len;
+                }
+            }
+            t.tok[base_off + written + rank] = tk;
+        }
+        written += __popcll(m);
+    }
+}
+
+}  // namespace c3r

@@ -1,0 +1,120 @@
+/* c3r.h — C-ABI of libc3r.so, the MI355X-native pileup variant-calling hot path for Clair3-RNA.
+ *
+ * The reference has NO plugin / FFI seam for this path: the boundary is a pair of sub-processes joined
+ * by a text pipe, launched per (contig, chunk) by clair3_rna/call_var_bam.py:288-295.  This header is
+ * therefore the seam the build defines; each entry point names the reference code it
+ * replaces.  INTEGRATION.md shows the ctypes stub a maintainer adds to call_var_bam.py.
+ *
+ * Conventions: plain C, no exceptions across the boundary.  Every call returns 0 on success or a
+ * negative C3R_E* code; c3r_last_error(ctx) returns a human-readable message.  The caller owns all
+ * host buffers; the library owns all device memory inside the opaque c3r_ctx.  One context = one
+ * GPU = one HIP stream; contexts are independent (one process or thread per GPU, no collectives:
+ * chunks are independent work items, run_clair3_rna:681-706).
+ *
+ * There is NO CPU fallback: every compute entry point fails with C3R_ENODEVICE when no gfx950 device
+ * is usable.
+ */
+#ifndef C3R_H
+#define C3R_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "c3r_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C3R_OK 0
+#define C3R_EINVAL (-1)       /* bad argument / call order */
+#define C3R_ENODEVICE (-2)    /* no usable HIP device */
+#define C3R_EHIP (-3)         /* a HIP runtime call failed */
+#define C3R_ENOMEM (-4)
+#define C3R_EUNSUPPORTED (-5) /* valid in the reference, not implemented on the GPU path yet */
+#define C3R_EOVERFLOW (-6)    /* caller buffer too small */
+
+typedef struct c3r_ctx c3r_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* Library version string, e.g. "c3r 0.1 (gfx950)". */
+const char *c3r_version(void);
+/* Create a context on HIP device `device_id`.  `stream` may be NULL (the library creates its own
+ * non-blocking stream) or an existing hipStream_t the caller wants the work ordered on. */
+int c3r_create(int device_id, void *stream, c3r_ctx **out);
+void c3r_destroy(c3r_ctx *ctx);
+const char *c3r_last_error(const c3r_ctx *ctx);
+/* Block until all work queued on the context's stream is complete. */
+int c3r_synchronize(c3r_ctx *ctx);
+/* The hipStream_t the context launches on (for event timing by the caller). */
+void *c3r_stream(c3r_ctx *ctx);
+
+/* ---- configuration ------------------------------------------------------------------------- */
+/* Fill `p` with the defaults run_clair3_rna forwards to call_var_bam (run_clair3_rna:684-705;
+ * shared/param_p.py:20,41,88-90). */
+void c3r_default_params(c3r_params_t *p);
+/* Replaces the argparse surface of src/create_tensor_pileup.py:660-778 that affects tensors.
+ * Returns C3R_EUNSUPPORTED for splice_padding=1 (see DESIGN.md "Out of scope"). */
+int c3r_set_params(c3r_ctx *ctx, const c3r_params_t *p);
+
+/* ---- inputs -------------------------------------------------------------------------------- */
+/* Upload one contig's aligned reads, sorted by pos (BAM order).  Replaces the BAM side of
+ * `samtools mpileup <bam> -r ...` (src/create_tensor_pileup.py:446-451).  Filtering by
+ * excl_flags / min_mq happens on the device.  cigars: BAM-encoded ops; seq4: 4-bit packed bases. */
+int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads,
+                   const uint32_t *cigars, int64_t n_cigar_ops, const uint8_t *seq4, int64_t n_seq_bytes);
+/* Upload the reference slice covering the region.  ref[0] is 1-based position `ref_start`;
+ * replaces reference_sequence_from / `samtools faidx` (shared/utils.py:168-194,
+ * src/create_tensor_pileup.py:424-428).  Upper-cased on upload like the reference does. */
+int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t len);
+/* Optional interval filters, 0-based half-open, for the current contig.  which=0: `-l` column
+ * filter (mpileup -l extend_bed, src/create_tensor_pileup.py:443); which=1: confident-bed candidate
+ * filter (is_region_in, src/create_tensor_pileup.py:551-554).  n=0 clears. */
+int c3r_set_bed(c3r_ctx *ctx, int which, const int32_t *start_end_pairs, int64_t n);
+/* Genotyping mode site list (--vcf_fn; src/create_tensor_pileup.py:399-407,555-556), 1-based. */
+int c3r_set_sites(c3r_ctx *ctx, const int32_t *sites, int64_t n);
+
+/* ---- tensor build (A1-A5) ------------------------------------------------------------------ */
+/* Phase 1+2: CIGAR walk over the reads overlapping [ctg_start-33, ctg_end+33] (1-based, clamped
+ * at 1; src/create_tensor_pileup.py:411-415), per-position channel counts, candidate gates, window
+ * selection, window gather with the depth>216 rescale (clair3_rna/utils.py:88-92).  Tensors and
+ * site records stay resident on the device.  Returns the number of emitted candidates. */
+int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n_candidates);
+/* Copy out what the last scan produced.  Any pointer may be NULL.  tensors: int32 [n][33][C]
+ * row-major (the 594/990 integers of a create_tensor line, after the A5 rescale when
+ * `rescaled` != 0, raw otherwise); sites: [n]; tokens: [n_tokens] (see c3r_token_count). */
+int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_sites);
+int c3r_get_sites(c3r_ctx *ctx, c3r_site_t *sites, int64_t cap_sites);
+int c3r_token_count(c3r_ctx *ctx, int64_t *n_tokens);
+int c3r_get_tokens(c3r_ctx *ctx, c3r_token_t *tokens, int64_t cap_tokens);
+/* Debug / parity: per-position columns of the last scan.  cols: int32 [n_pos][C]; depth: int32
+ * [n_pos]; flags: uint8 [n_pos] (bit0 = row exists, bit1 = candidate gate passed, bit2 = emitted).
+ * Position i is 1-based ctg position region_start + i where region_start is returned. */
+int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t *cols, int32_t *depth,
+                    uint8_t *flags, int64_t cap_pos);
+
+/* ---- network (A6/A7) ----------------------------------------------------------------------- */
+/* Upload network weights: a flat fp32 blob in Keras layout (documented in DESIGN.md §weights):
+ * per LSTM layer and direction K[in,4H], R[H,4H], b[4H] (gate order i,f,c,o); then L4, L5_1, L5_2,
+ * Y_gt21, Y_genotype (W[in,out], b[out]).  Replaces m.load_weights (clair3_rna/call_variants.py:1472).
+ * `channels` is 18 or 30 and must match c3r_set_params. */
+int c3r_load_weights(c3r_ctx *ctx, const float *blob, int64_t n_floats, int channels);
+int64_t c3r_weight_count(int channels);
+/* Forward pass over tensors.  tensors==NULL: use the device-resident tensors of the last scan.
+ * Otherwise `tensors` is a host int32 [n][33][C] array.  probs (host, [n][24]) may be NULL to keep
+ * the result on the device only.  Replaces m.predict_on_batch (clair3_rna/call_variants.py:1505). */
+int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+/* When enabled, every kernel launch is bracketed by HIP events on the context's stream and the
+ * elapsed times are accumulated per kernel name. */
+int c3r_set_profiling(c3r_ctx *ctx, int enabled);
+int c3r_reset_kernel_stats(c3r_ctx *ctx);
+/* Writes up to cap entries; returns the number of distinct kernels via *n.  names[i] points into
+ * storage owned by the context. */
+int c3r_get_kernel_stats(c3r_ctx *ctx, const char **names, double *total_ms, int64_t *launches, int cap, int *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C3R_H */

@@ -1,0 +1,44 @@
+"""Shared helpers for the parity tests: run the CPU oracle and the HIP engine on the same inputs."""
+import numpy as np
+
+from oracle import oracle as orc
+
+CTG = "chr20"
+
+
+def oracle_chunk(rs, ref, ref_start, ctg_start, ctg_end, channels=18, lbed=None, **pk):
+    """Oracle A1..A5 for one chunk.  Returns dict(rows, lines, X, depth)."""
+    es, ee = max(1, ctg_start - 33), ctg_end + 33
+    rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, CTG, es, ee, min_mq=pk.pop("min_mq", 5), excl_flags=pk.pop("excl_flags", 2316),
+                       bed=lbed, with_hp=(channels == 30))
+    P = orc.make_params(phased=(channels == 30), **pk)
+    lines = orc.create_tensor(rows, CTG, ref, ref_start, P)
+    X, depth = orc.batch_from_lines(lines, channels)
+    return dict(rows=rows, lines=lines, X=X, depth=depth)
+
+
+def engine_chunk(eng, rs, ref, ref_start, ctg_start, ctg_end):
+    """HIP A1..A5 for one chunk through the C-ABI.  Returns dict(lines, X, raw, sites, tokens)."""
+    from clair3_rna_amd import altinfo
+    eng.load_reads(rs)
+    eng.set_reference(ref_start, ref)
+    n = eng.scan(ctg_start, ctg_end)
+    raw = eng.tensors(rescaled=False)
+    X = eng.tensors(rescaled=True)
+    sites, toks = eng.sites(), eng.tokens()
+    lines = altinfo.format_lines(CTG, sites, raw, toks, rs, ref.upper(), ref_start)
+    return dict(n=n, lines=lines, X=X, raw=raw, sites=sites, tokens=toks)
+
+
+def first_diff(a, b):
+    for i, (x, y) in enumerate(zip(a, b)):
+        if x != y:
+            fx, fy = x.split("\t"), y.split("\t")
+            for k in range(min(len(fx), len(fy))):
+                if fx[k] != fy[k]:
+                    if k == 3:
+                        vx, vy = np.array(fx[3].split(), int), np.array(fy[3].split(), int)
+                        d = np.nonzero(vx != vy)[0]
+                        return "line %d pos %s field 3 idx %s got %s exp %s" % (i, fx[1], d[:8], vx[d[:8]], vy[d[:8]])
+                    return "line %d pos %s/%s field %d: %r vs %r" % (i, fx[1], fy[1], k, fx[k][:120], fy[k][:120])
+    return "length %d vs %d" % (len(a), len(b))

@@ -1,0 +1,178 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the
+CPU oracle on the same seeded inputs.  Integer work is bit-exact; probabilities within 1e-4 (fp32).
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from clair3_rna_amd import capi
+    e = capi.Engine(0)
+    yield e
+    e.close()
+
+
+def _reset(eng, **kw):
+    from clair3_rna_amd import capi
+    eng.params = capi.default_params()
+    eng.set_bed(0, None)
+    eng.set_bed(1, None)
+    eng.set_params(**kw)
+
+
+def _check(eng, rs, ref, ctg_start, ctg_end, channels=18, ref_start=1, lbed=None, cbed=None, sites=None, **pk):
+    ekw = dict(channels=channels, min_coverage=pk.get("min_coverage", 4), snp_min_af=pk.get("snp_af", 0.08),
+               indel_min_af=pk.get("indel_af", 0.15), head_tail=int(pk.get("head_tail", False)),
+               genotyping_mode=int(sites is not None), min_mq=pk.get("min_mq", 5))
+    _reset(eng, **ekw)
+    if lbed is not None:
+        eng.set_bed(0, lbed)
+    if cbed is not None:
+        eng.set_bed(1, cbed)
+    if sites is not None:
+        eng.set_sites(sites)
+    refslice = ref[ref_start - 1:]
+    exp = H.oracle_chunk(rs, refslice, ref_start, ctg_start, ctg_end, channels=channels, lbed=lbed, bed=cbed, sites=sites, **pk)
+    got = H.engine_chunk(eng, rs, refslice, ref_start, ctg_start, ctg_end)
+    assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
+    assert np.array_equal(got["X"], exp["X"])
+    return got, exp
+
+
+def test_default_18ch(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=3, ref_len=30000, n_genes=6, depth=20)
+    got, exp = _check(eng, rs, ref, 1, len(ref))
+    assert got["n"] > 100
+
+
+def test_columns_match_oracle(eng):
+    """Every covered position: channel vector, depth and candidate gate against generate_tensor."""
+    from clair3_rna_amd import synth
+    from oracle import oracle as orc
+    ref, rs, _ = synth.small_case(seed=11, ref_len=20000, n_genes=5, depth=25)
+    _reset(eng)
+    eng.load_reads(rs)
+    eng.set_reference(1, ref)
+    eng.scan(1, len(ref))
+    col = eng.columns()
+    rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, H.CTG, 1, len(ref) + 33)
+    assert len(rows) == int((col["flags"] & 1).sum())
+    bad = []
+    for row in rows:
+        f = row.split("\t")
+        pos = int(f[1])
+        o = orc.generate_tensor(f[4], ref[pos - 1], pos, ref, 1)
+        i = pos - col["region_start"]
+        cand = o["pass_af"] and o["depth"] >= 4 and ref[pos - 1] in "ACGT"
+        if col["cols"][i].tolist() != o["tensor"] or col["depth"][i] != o["depth"] or bool(col["flags"][i] & 2) != cand:
+            bad.append((pos, col["cols"][i].tolist(), o["tensor"], int(col["depth"][i]), o["depth"], int(col["flags"][i]), cand))
+    assert not bad, bad[:3]
+
+
+def test_chunked_region_and_ref_offset(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=5, ref_len=40000, n_genes=9, depth=15)
+    _check(eng, rs, ref, 9000, 21000, ref_start=8000)
+
+
+def test_phased_30ch(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=7, ref_len=30000, n_genes=6, depth=18, phased=True)
+    got, exp = _check(eng, rs, ref, 1, len(ref), channels=30)
+    assert got["X"].shape[2] == 30
+
+
+def test_head_tail(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=9, ref_len=30000, n_genes=6, depth=12)
+    got, exp = _check(eng, rs, ref, 1, len(ref), head_tail=True)
+    plain = H.oracle_chunk(rs, ref, 1, 1, len(ref))
+    assert len(exp["lines"]) > len(plain["lines"])
+
+
+def test_high_depth_rescale(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=13, ref_len=8000, n_genes=2, depth=500, mean_len=600)
+    got, exp = _check(eng, rs, ref, 1, len(ref))
+    assert exp["depth"].max() > 216          # the A5 rescale path is exercised
+    assert not np.array_equal(got["raw"], got["X"])
+
+
+def test_hifi_low_error(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=15, ref_len=60000, n_genes=8, depth=30, platform="hifi")
+    _check(eng, rs, ref, 1, len(ref))
+
+
+def test_bed_filters(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=17, ref_len=30000, n_genes=6, depth=20)
+    starts = sorted(set(int(r["pos"]) for r in rs.reads))
+    a = starts[len(starts) // 4]
+    lbed = [(a, a + 900), (a + 1200, a + 1201), (a + 2000, a + 6000)]
+    cbed = [(a + 100, a + 500), (a + 2100, a + 2105), (a + 2500, a + 5000), (a + 2400, a + 2600)]
+    _check(eng, rs, ref, 1, len(ref), lbed=lbed, cbed=cbed)
+
+
+def test_genotyping_sites(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=19, ref_len=30000, n_genes=6, depth=20)
+    pos0 = int(rs.reads["pos"][len(rs) // 2])
+    sites = [pos0 + 40, pos0 + 41, pos0 + 90, pos0 + 300, 5]
+    got, exp = _check(eng, rs, ref, min(sites), max(sites), sites=sites)
+
+
+def test_af_zero_and_mincov(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=21, ref_len=12000, n_genes=3, depth=8)
+    _check(eng, rs, ref, 1, len(ref), snp_af=0.0, min_coverage=2)
+
+
+def test_min_mq_filter(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=23, ref_len=20000, n_genes=4, depth=20)
+    _check(eng, rs, ref, 1, len(ref), min_mq=30)
+
+
+def test_empty_region(eng):
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=3, ref_len=30000, n_genes=2, depth=5)
+    _reset(eng)
+    eng.load_reads(rs)
+    eng.set_reference(1, ref)
+    assert eng.scan(29000, 29900) == 0
+    assert eng.tensors().shape == (0, 33, 18)
+
+
+def test_network_probabilities(eng):
+    from clair3_rna_amd import synth
+    from oracle import oracle as orc
+    ref, rs, _ = synth.small_case(seed=3, ref_len=30000, n_genes=6, depth=20)
+    got, exp = _check(eng, rs, ref, 1, len(ref))
+    w = synth.random_weights(18)
+    eng.load_weights(w, 18)
+    p_resident = eng.infer()                    # tensors resident from the scan
+    p_host = eng.infer(tensors=exp["X"])         # host tensors through the boundary
+    po = orc.forward(w, exp["X"])
+    assert np.abs(p_resident - po).max() < 1e-4   # tolerance stated by north_star: 1e-4 fp32
+    assert np.array_equal(p_resident, p_host)
+    assert np.allclose(p_resident[:, :21].sum(1), 1, atol=1e-5) and np.allclose(p_resident[:, 21:].sum(1), 1, atol=1e-5)
+
+
+def test_network_30ch_and_ragged_batch(eng):
+    from clair3_rna_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.RandomState(5)
+    w = synth.random_weights(30, seed=77)
+    eng.load_weights(w, 30)
+    for n in (1, 31, 33, 70):
+        X = rng.randint(-60, 60, size=(n, 33, 30)).astype(np.int32)
+        p = eng.infer(tensors=X)
+        po = orc.forward(w, X)
+        assert np.abs(p - po).max() < 1e-4, n
