@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — candidate sites/sec (tensor build + inference) on synthetic ONT dRNA004 chr20 ~20x.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one synthetic chr20 (BASELINE.json configs[1]): for each of
+the 13 five-megabase chunks (shared/param_p.py:91) tensor build (CIGAR walk -> counts -> candidates -> window
+gather) + network forward + probabilities back on the host.  Reads, reference and weights are resident in
+HBM before the timed region.  Multi-GPU: every rank owns its own chr20-sized contig (weak scaling, the
+reference shards by contig/chunk with no exchange step: run_clair3_rna:681-706); no data-path collective.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+CHUNK = 5000000            # shared/param_p.py:91 CHUNK_SIZE
+# algorithmic work per emitted candidate
+FLOP_PER_SITE = {"k_lstm1": 2.0 * (18 + 128) * 512 * 33 * 2, "k_lstm2": 2.0 * (256 + 160) * 640 * 33 * 2,
+                 "k_fc4": 2.0 * 10560 * 128, "k_heads": 2.0 * (128 * 256 + 128 * 24)}
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def chunk_list(contig_len, chunk=CHUNK):
+    """(ctg_start, ctg_end) per chunk, the arithmetic of src/create_tensor_pileup.py:380-392."""
+    n = (contig_len + chunk - 1) // chunk
+    size = contig_len // n + 1 if contig_len % n else contig_len // n
+    return [(size * i, size * i + size) for i in range(n)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--depth", type=float, default=20.0)
+    ap.add_argument("--contig_len", type=int, default=0, help="default: chr20 (64,444,167)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X (no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from clair3_rna_amd import capi, synth
+    contig_len = args.contig_len or synth.CHR20_LEN
+    ref, rs, info = synth.generate_contig(contig_len=contig_len, seed=synth.SEED + rank, depth=args.depth)
+    chunks = chunk_list(contig_len)
+    eng = capi.Engine(local_rank)
+    eng.set_params()
+    eng.load_reads(rs)
+    eng.set_reference(1, ref)
+    weights = synth.random_weights(18)
+    eng.load_weights(weights, 18)
+
+    def one_step():
+        total = 0
+        for (a, b) in chunks:
+            n = eng.scan(a, b)
+            if n:
+                eng.infer()            # device-resident tensors -> probabilities on the host
+            total += n
+        return total
+
+    def barrier():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    sites = 0
+    for _ in range(args.steps):
+        sites += one_step()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([sites], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        sites = int(s.item())
+    sites_per_step_rank = sites / max(1, args.steps) / world
+
+    # ---- per-kernel durations, live, with HIP events on the engine's stream (one extra untimed step)
+    roofline, kernels = None, {}
+    if not args.no_profile:
+        eng.set_profiling(True)
+        eng.reset_kernel_stats()
+        n_prof = one_step()
+        eng.set_profiling(False)
+        kernels = eng.kernel_stats()
+        dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+        st = kernels[dom]
+        avg_ms = st["total_ms"] / st["launches"]
+        if dom in FLOP_PER_SITE:
+            flops_per_launch = FLOP_PER_SITE[dom] * n_prof / st["launches"]
+            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
+                            launches=st["launches"])
+        else:
+            roofline = dict(kernel=dom, bound="hbm", achieved=None, peak=PEAK_HBM_GBPS, unit="GB/s", frac=None, traffic=None,
+                            avg_launch_ms=round(avg_ms, 4), launches=st["launches"])
+
+    # ---- CPU baseline: the oracle (a port of the reference pipeline) on a bounded sample, rank 0, N=1 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        # bounded sample: successive 2.5 Mb regions of the same contig until >= 12 s of CPU work (cap 6 regions)
+        t1 = time.perf_counter()
+        n_cpu, beg, regions = 0, 0, 0
+        while regions < 6 and (time.perf_counter() - t1) < 12.0 and beg < contig_len:
+            end = min(beg + 2500000, contig_len)
+            rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, "chr20", max(1, beg - 33), end + 33)
+            rstart = max(1, beg - 1000)
+            refslice = ref[rstart - 1:end + 1000].decode()
+            lines = orc.create_tensor(rows, "chr20", refslice, rstart, orc.make_params())
+            X, _ = orc.batch_from_lines(lines, 18)
+            if len(X):
+                orc.forward(weights, X)
+            n_cpu += len(X)
+            beg = end
+            regions += 1
+        dt = time.perf_counter() - t1
+        cpu = dict(value=round(n_cpu / dt, 1), unit="sites/s", cores=os.cpu_count(), kind="port",
+                   sample="chr20:1-%d of the same synthetic contig (%d candidates, %.1f s): text mpileup + parse + window "
+                          "driver single-threaded like the reference's samtools|pypy pair, fp32 network on all cores (OpenMP)"
+                          % (beg, n_cpu, dt))
+
+    if rank == 0:
+        out = {
+            "metric": "candidate sites/sec (tensor build + inference)",
+            "value": round(sites / elapsed, 1), "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic ONT dRNA004 chr20 ~%dx (BASELINE.json configs[1])" % int(args.depth),
+                       "contig_len": contig_len, "chunks": len(chunks), "channels": 18, "reads_per_rank": info["n_reads"],
+                       "exonic_bp_per_rank": info["n_exonic"], "sites_per_step_per_rank": round(sites_per_step_rank, 1),
+                       "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

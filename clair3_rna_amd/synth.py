@@ -217,3 +217,52 @@ def random_weights(channels, seed=1234):
     parts.append(rng.normal(0, 0.3, size=(128, 3)))
     parts.append(rng.normal(0, 0.1, size=3))
     return np.concatenate([p.reshape(-1) for p in parts]).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- chr20-scale generator (C++)
+import ctypes as _C
+import os as _os
+
+_SYNTH_LIB = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libc3r_synth.so")
+
+
+class _SynthParams(_C.Structure):
+    _fields_ = [("contig_len", _C.c_int64), ("seed", _C.c_uint64), ("depth", _C.c_double), ("expressed_frac", _C.c_double),
+                ("platform", _C.c_int32), ("phased", _C.c_int32), ("intron_lo", _C.c_double), ("intron_hi", _C.c_double),
+                ("region_start", _C.c_int64), ("region_end", _C.c_int64)]
+
+
+class _SynthResult(_C.Structure):
+    _fields_ = [("ref", _C.c_void_p), ("ref_len", _C.c_int64), ("reads", _C.c_void_p), ("n_reads", _C.c_int64),
+                ("cigar", _C.c_void_p), ("n_cigar", _C.c_int64), ("seq", _C.c_void_p), ("n_seq", _C.c_int64),
+                ("n_exonic", _C.c_int64), ("n_genes", _C.c_int64), ("owner", _C.c_void_p)]
+
+
+CHR20_LEN = 64444167          # GRCh38 chr20
+SEED = 20240422
+
+
+def generate_contig(contig_len=CHR20_LEN, seed=SEED, depth=20.0, expressed_frac=0.03, platform="ont", phased=False,
+                    intron_lo=100.0, intron_hi=100000.0, region=None):
+    """Synthetic contig + alignments at BASELINE.json config scale.  Returns (ref_bytes, ReadSet, info)."""
+    from .reads import READ_DTYPE
+    if not _os.path.exists(_SYNTH_LIB):
+        raise ImportError("libc3r_synth.so missing — run __graft_entry__.build()")
+    L = _C.CDLL(_SYNTH_LIB)
+    L.c3r_synth_generate.argtypes = [_C.POINTER(_SynthParams), _C.POINTER(_SynthResult)]
+    L.c3r_synth_free.argtypes = [_C.POINTER(_SynthResult)]
+    p = _SynthParams(contig_len, seed, depth, expressed_frac, 0 if platform == "ont" else 1, int(phased), intron_lo, intron_hi,
+                     region[0] if region else 0, region[1] if region else 0)
+    r = _SynthResult()
+    rc = L.c3r_synth_generate(_C.byref(p), _C.byref(r))
+    if rc != 0:
+        raise RuntimeError("c3r_synth_generate failed: %d" % rc)
+    try:
+        ref = _C.string_at(r.ref, r.ref_len)
+        reads = np.frombuffer(_C.string_at(r.reads, r.n_reads * 32), dtype=READ_DTYPE).copy()
+        cigar = np.frombuffer(_C.string_at(r.cigar, r.n_cigar * 4), dtype=np.uint32).copy()
+        seq = np.frombuffer(_C.string_at(r.seq, r.n_seq), dtype=np.uint8).copy()
+        info = dict(n_reads=int(r.n_reads), n_exonic=int(r.n_exonic), n_genes=int(r.n_genes))
+    finally:
+        L.c3r_synth_free(_C.byref(r))
+    return ref, ReadSet(reads, cigar, seq), info
