@@ -176,3 +176,47 @@ def test_network_30ch_and_ragged_batch(eng):
         p = eng.infer(tensors=X)
         po = orc.forward(w, X)
         assert np.abs(p - po).max() < 1e-4, n
+
+
+def test_golden_e2e_lines_from_reference_driver(eng):
+    """HIP path vs the committed lines the REFERENCE's CreateTensorPileup emitted for the same reads (G2b)."""
+    from tests.test_oracle_golden import load_g2b
+    for c in load_g2b():
+        _reset(eng, channels=30 if c["phased"] else 18,
+               head_tail=int("--enable_variant_calling_at_sequence_head_and_tail" in c["argv"]))
+        got = H.engine_chunk(eng, c["rs"], c["ref"], 1, 1, len(c["ref"]))
+        assert got["lines"] == c["lines"], (c["name"], H.first_diff(got["lines"], c["lines"]))
+
+
+def test_weird_cigars_against_oracle_columns(eng):
+    """P ops, =/X, split D/I runs, I after D/N, leading/trailing I, clips, IUPAC and '=' bases, short queries."""
+    from clair3_rna_amd.reads import ReadSet
+    from oracle import oracle as orc
+    ref = "ACGTTGCAAGCTTAGCCATGCGTACGATTACAGGCTTAACGGATCGATCCGATTAGGCTAACGT" * 4
+    base = [(9, "2M1D2D2M", "ACGT"), (9, "2M1I1P1I2M", "ACTTGA"), (9, "1M1=1X3M", "ACGTGC"), (9, "2M2N1I2M", "ACTGA"),
+            (9, "2M1D2I2M", "ACTTGA"), (9, "2M2I1D2M", "ACTTGA"), (9, "2I3M", "TTACG"), (9, "3M2I4S", "ACGTTCCCC"),
+            (9, "2H2S3M1S", "TTACGT"), (9, "4M", "AC"), (9, "4M", "ANRC"), (9, "3M", "A=C"), (9, "4S", "ACGT"),
+            (9, "3M20N3M1D3M", "ACGTTGCAT"), (9, "2M3D", "AC"), (9, "1D3M", "ACG"), (9, "3M17I3M", "ACG" + "ACGTACGTACGTACGTA" + "TGC"),
+            (9, "3M17I3M", "ACG" + "ACGTACGTACGTACGTC" + "TGC"), (9, "3M17I3M", "ACG" + "ACGTACGTACGTACGTA" + "TGC")]
+    recs = []
+    for rep in range(6):
+        for k, (p, cg, sq) in enumerate(base):
+            recs.append(dict(pos=p + rep % 2, cigar=cg, seq=sq, flag=16 if (k + rep) % 3 == 0 else 0, mapq=60, hp=0))
+    rs = ReadSet.from_records(recs)
+    _reset(eng, min_coverage=2)
+    eng.load_reads(rs)
+    eng.set_reference(1, ref)
+    eng.scan(1, 120)
+    col = eng.columns()
+    rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, H.CTG, 1, 153)
+    assert len(rows) == int((col["flags"] & 1).sum())
+    for row in rows:
+        f = row.split("\t")
+        pos = int(f[1])
+        o = orc.generate_tensor(f[4], ref[pos - 1], pos, ref, 1)
+        i = pos - col["region_start"]
+        assert col["cols"][i].tolist() == o["tensor"], (pos, f[4], col["cols"][i].tolist(), o["tensor"])
+        assert col["depth"][i] == o["depth"]
+    got = H.engine_chunk(eng, rs, ref, 1, 1, 120)
+    exp = H.oracle_chunk(rs, ref, 1, 1, 120, min_coverage=2)
+    assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])

@@ -1,0 +1,151 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/c3r.h declares (no compute
+without a GPU), host-side logic (read packing, alt_info reconstruction, chunk arithmetic) and the
+oracle's network restatement against torch.nn.LSTM (golden G5 role: TensorFlow is absent)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from clair3_rna_amd import capi
+    hdr = open(os.path.join(ROOT, "include", "c3r.h")).read()
+    declared = sorted(set(re.findall(r"\b(c3r_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    lib = capi.load_library()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTS) == declared
+    assert lib.c3r_version().startswith(b"c3r")
+    assert lib.c3r_weight_count(18) == 2072216      # parameter count at C=18
+    p = capi.default_params()
+    assert (p.channels, p.min_mq, p.excl_flags, p.min_coverage, p.max_depth_rescale) == (18, 5, 2316, 4, 144)
+    assert (p.snp_min_af, p.indel_min_af) == (0.08, 0.15)
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from clair3_rna_amd import capi
+    with pytest.raises(capi.C3RError):
+        capi.Engine(0)
+
+
+def test_struct_layouts_match_header():
+    from clair3_rna_amd import capi, reads
+    assert reads.READ_DTYPE.itemsize == 32 and capi.SITE_DTYPE.itemsize == 52 and capi.TOKEN_DTYPE.itemsize == 16
+    assert reads.READ_DTYPE.fields["seq_off"][1] == 16 and reads.READ_DTYPE.fields["flag"][1] == 24
+
+
+def test_read_packing_roundtrip():
+    from clair3_rna_amd.reads import ReadSet, parse_cigar
+    rs = ReadSet.from_records([(5, "2S3M1I2M", "ACGTNACG", 16, 30, 2), (2, "4M", "TTTT", 0, 60, 0)])
+    assert rs.reads["pos"].tolist() == [2, 5]
+    assert rs.read_bases(1, 0, 8) == "ACGTNACG" and rs.read_bases(0, 1, 2) == "TT" and rs.read_bases(1, 7, 3) == "GNN"
+    assert parse_cigar("10M2I5N").tolist() == [(10 << 4) | 0, (2 << 4) | 1, (5 << 4) | 3]
+
+
+def test_alt_info_from_tokens_matches_oracle_columns():
+    """tokens (BAM order) -> ordered alt dict must equal generate_tensor's alt_dict for the same column."""
+    from clair3_rna_amd import altinfo, capi
+    from clair3_rna_amd.reads import ReadSet
+    from oracle import oracle as orc
+    ref = "ACGTACGTACGTACGTACGTACGTACGTAC"
+    recs = [(4, "3M2I3M", "ACGTTGTA", 0, 60, 0), (4, "3M1D4M", "TCGACGT", 16, 60, 0), (5, "2M2I3M", "CGTTGTA", 16, 60, 0),
+            (5, "2M", "CA", 0, 60, 0), (6, "1M2D2M", "GCG", 0, 60, 0), (2, "3M4N3M", "GTAGTA", 0, 60, 0)]
+    rs = ReadSet.from_records(recs)
+    rows = {int(r.split("\t")[1]): r.split("\t")[4] for r in orc.mpileup(rs.reads, rs.cigar, rs.seq, "c", 1, 30)}
+    pos = 7      # 1-based column; reads 0,1,2,3 cover with ins / del tokens
+    # hand-build the tokens the kernel would emit for column 7 (0-based 6), in BAM order
+    toks = np.zeros(6, dtype=capi.TOKEN_DTYPE)
+    order = np.argsort([r[0] for r in recs], kind="stable")
+    k = 0
+    for ridx, oi in enumerate(order):
+        p0, cig, seq, flag = recs[oi][0], recs[oi][1], recs[oi][2], recs[oi][3]
+        import re as _re
+        x, y, tok = p0, 0, None
+        ops = [(int(n), o) for n, o in _re.findall(r"(\d+)([MIDNS])", cig)]
+        for i, (n, o) in enumerate(ops):
+            if o in "MDN":
+                if pos - 1 < x + n and pos - 1 >= x:
+                    base = {"A": 1, "C": 2, "G": 4, "T": 8}[seq[y + pos - 1 - x]] if o == "M" else (16 if o == "D" else 17)
+                    indel, q = 0, 0
+                    if pos - 1 == x + n - 1 and i + 1 < len(ops):
+                        if ops[i + 1][1] == "I":
+                            indel, q = ops[i + 1][0], y + (n if o == "M" else 0)
+                        elif ops[i + 1][1] == "D" and o != "D":
+                            indel = -ops[i + 1][0]
+                    tok = (ridx, indel, q, base, 1 if flag & 16 else 0, (0, 0))
+                    break
+                x += n
+                if o == "M":
+                    y += n
+            else:
+                y += n
+        if tok:
+            toks[k] = tok
+            k += 1
+    alt, depth = altinfo.alt_dict_from_tokens(toks[:k], rs, ref, 1, pos)
+    o = orc.generate_tensor(rows[pos], ref[pos - 1], pos, ref, 1)
+    assert [[a, b] for a, b in alt.items()] == o["alt"] and depth == o["depth"]
+
+
+def test_bench_chunk_list_matches_reference_arithmetic():
+    import bench
+    from oracle import oracle as orc
+    L = 64444167
+    ch = bench.chunk_list(L)
+    assert len(ch) == 13
+    for i, (a, b) in enumerate(ch):
+        r = orc.chunk_region(contig_len=L, chunk_id=i + 1, chunk_num=13)
+        assert (a, b) == (r["ctg_start"], r["ctg_end"])
+    assert ch[-1][1] >= L
+
+
+def test_oracle_network_matches_torch_lstm():
+    """Keras LSTM equations as restated in the oracle == torch.nn.LSTM(bidirectional) with weight_ih=K.T,
+    weight_hh=R.T, bias_ih=b, bias_hh=0, and the dense/selu/softmax heads."""
+    import torch
+    from clair3_rna_amd import synth
+    from oracle import oracle as orc
+    torch.manual_seed(0)
+    for C in (18, 30):
+        w = synth.random_weights(C, seed=99 + C)
+        X = np.random.RandomState(C).randint(-40, 40, size=(5, 33, C)).astype(np.int32)
+        probs, y1, y2 = orc.forward(w, X, return_hidden=True)
+        q = [0]
+
+        def take(*shape):
+            n = int(np.prod(shape))
+            a = torch.from_numpy(w[q[0]:q[0] + n].reshape(shape).copy())
+            q[0] += n
+            return a
+
+        x = torch.from_numpy(X.astype(np.float32))
+        for (cin, H, yref) in ((C, 128, y1), (256, 160, y2)):
+            lstm = torch.nn.LSTM(cin, H, batch_first=True, bidirectional=True)
+            with torch.no_grad():
+                for sfx in ("", "_reverse"):
+                    K, Rm, b = take(cin, 4 * H), take(H, 4 * H), take(4 * H)
+                    getattr(lstm, "weight_ih_l0" + sfx).copy_(K.t())
+                    getattr(lstm, "weight_hh_l0" + sfx).copy_(Rm.t())
+                    getattr(lstm, "bias_ih_l0" + sfx).copy_(b)
+                    getattr(lstm, "bias_hh_l0" + sfx).zero_()
+                x, _ = lstm(x)
+            assert np.abs(x.numpy() - yref).max() < 2e-5
+        selu = torch.nn.functional.selu
+        W4, b4 = take(33 * 320, 128), take(128)
+        a4 = selu(x.reshape(5, -1) @ W4 + b4)
+        W51, b51, W52, b52 = take(128, 128), take(128), take(128, 128), take(128)
+        Wg, bg, Wz, bz = take(128, 21), take(21), take(128, 3), take(3)
+        p21 = torch.softmax(selu(selu(a4 @ W51 + b51) @ Wg + bg), 1)
+        p3 = torch.softmax(selu(selu(a4 @ W52 + b52) @ Wz + bz), 1)
+        ref = torch.cat([p21, p3], 1).numpy()
+        assert q[0] == w.size
+        assert np.abs(ref - probs).max() < 1e-5

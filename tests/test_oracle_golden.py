@@ -104,3 +104,23 @@ def test_g3_batches():
         assert X.shape == exp.shape
         assert np.array_equal(X, exp), case["name"]
         assert all(b["dtype"] == "int32" for b in case["batches"])
+
+
+def load_g2b():
+    from clair3_rna_amd.reads import ReadSet, READ_DTYPE
+    g = json.load(gzip.open(os.path.join(G, "g2b_e2e.json.gz"), "rt"))
+    for c in g["cases"]:
+        reads = np.array([tuple(r) for r in c["reads"]], dtype=READ_DTYPE)
+        c["rs"] = ReadSet(reads, np.asarray(c["cigar"], np.uint32), np.asarray(c["seq"], np.uint8))
+    return g["cases"]
+
+
+def test_g2b_reads_to_lines_through_reference_driver():
+    """reads -> oracle mpileup text -> oracle driver must equal reads -> oracle mpileup text -> REFERENCE driver."""
+    for c in load_g2b():
+        rs, ref = c["rs"], c["ref"]
+        rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, "chr20", 1, len(ref) + 33, with_hp=c["phased"])
+        P = orc.make_params(min_coverage=4, phased=c["phased"],
+                            head_tail="--enable_variant_calling_at_sequence_head_and_tail" in c["argv"])
+        got = orc.create_tensor(rows, "chr20", ref, 1, P)
+        assert got == c["lines"], c["name"]
