@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the
 CPU oracle on the same seeded inputs.  Integer work is bit-exact; probabilities within 1e-4 (fp32).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -220,3 +222,47 @@ def test_weird_cigars_against_oracle_columns(eng):
     got = H.engine_chunk(eng, rs, ref, 1, 1, 120)
     exp = H.oracle_chunk(rs, ref, 1, 1, 120, min_coverage=2)
     assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
+
+
+def test_call_var_bam_driver_end_to_end(eng, tmp_path):
+    """The drop-in CLI: BAM + FASTA + weights -> pileup_{ctg}_{chunk}.vcf, against oracle lines -> oracle network ->
+    decode.  Rows must agree exactly except QUAL/GQ, which may move by 0.01 because the probabilities differ at 1e-6."""
+    from clair3_rna_amd import bam, call_var_bam, decode, io, synth, vcf
+    from oracle import oracle as orc
+    ref, rs, _ = synth.small_case(seed=43, ref_len=30000, n_genes=6, depth=20)
+    fa, bm, wfn = str(tmp_path / "ref.fa"), str(tmp_path / "in.bam"), str(tmp_path / "model")
+    io.write_fasta(fa, [("chr20", ref), ("chrM", "ACGT" * 50)])
+    bam.write_bam(bm, [("chr20", len(ref)), ("chrM", 200)], {"chr20": rs})
+    w = synth.random_weights(18, seed=5)
+    np.save(wfn + ".c3rw.npy", w)
+    open(str(tmp_path / "CMD"), "w").write("run_clair3_rna test\n")
+    total_rows = 0
+    for chunk_id in (1, 2, 3):
+        out = str(tmp_path / ("pileup_chr20_%d.vcf" % chunk_id))
+        argv = ["--chkpnt_fn", wfn, "--bam_fn", bm, "--call_fn", out, "--sampleName", "S1", "--ref_fn", fa,
+                "--extend_bed", str(tmp_path / "split_beds" / "chr20"), "--ctgName", "chr20", "--chunk_id", str(chunk_id),
+                "--chunk_num", "3", "--platform", "ont", "--snp_min_af", "0.08", "--indel_min_af", "0.15", "--minMQ", "5",
+                "--minCoverage", "4", "--samtools", "samtools", "--pileup", "--cmd_fn", str(tmp_path / "CMD")]
+        assert call_var_bam.Run(call_var_bam.build_parser().parse_args(argv), engine=eng) == 0
+        a, b = call_var_bam.chunk_region(len(ref), chunk_id, 3)
+        rstart = max(1, a - 1000)
+        exp = H.oracle_chunk(rs, ref[rstart - 1:b + 1000], rstart, a, b)
+        if not exp["lines"]:
+            assert not os.path.exists(out)
+            continue
+        po = orc.forward(w, exp["X"])
+        f = [l.split("\t") for l in exp["lines"]]
+        exp_rows = decode.vcf_rows("chr20", [int(x[1]) for x in f], [x[2] for x in f], [x[4] for x in f], po)
+        text = open(out).read().rstrip("\n").split("\n")
+        hdr = vcf.header(fa, str(tmp_path / "CMD"), "S1").split("\n")
+        assert text[:len(hdr)] == hdr
+        got_rows = text[len(hdr):]
+        assert len(got_rows) == len(exp_rows) > 0
+        for g, e in zip(got_rows, exp_rows):
+            gf, ef = g.split("\t"), e.split("\t")
+            assert gf[:5] == ef[:5] and gf[6:9] == ef[6:9], (g, e)
+            assert abs(float(gf[5]) - float(ef[5])) <= 0.011
+            gs, es = gf[9].split(":"), ef[9].split(":")
+            assert gs[0] == es[0] and gs[2:] == es[2:] and abs(int(gs[1]) - int(es[1])) <= 1
+        total_rows += len(got_rows)
+    assert total_rows > 100
