@@ -241,7 +241,8 @@ __device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, 
             ref_carry += __shfl(rincl, 63, 64);
             q_carry += __shfl(qincl, 63, 64);
             prev_carry = __shfl(op, 63, 64);
-            if (rd.pos + ref_carry >= t1) break;
+            // '>' not '>=': an I/D op starting exactly at t1 is attached to column t1-1, which is ours
+            if (rd.pos + ref_carry > t1) break;
         }
     }
 }

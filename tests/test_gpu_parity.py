@@ -266,3 +266,56 @@ def test_call_var_bam_driver_end_to_end(eng, tmp_path):
             assert gs[0] == es[0] and gs[2:] == es[2:] and abs(int(gs[1]) - int(es[1])) <= 1
         total_rows += len(got_rows)
     assert total_rows > 100
+
+
+def test_dense_short_ops_cross_tile_and_batch_boundaries(eng):
+    """Adversarial CIGARs: hundreds of 1-3 bp ops per read so that 64-op wave batches, 256-bp tiles and indel
+    anchors line up in every possible way (regression: an insertion anchored on the last column of a tile whose
+    op was the first of the next 64-op batch)."""
+    import random
+    from clair3_rna_amd.reads import ReadSet
+    from oracle import oracle as orc
+    ref = __import__("clair3_rna_amd.synth", fromlist=["x"]).random_reference(4000, 77)
+    for seed in range(4):
+        rng = random.Random(seed)
+        recs = []
+        for _ in range(60):
+            pos = rng.randint(0, 1500)
+            ops, seq, x = [], [], pos
+            n_ops = rng.randint(100, 700)
+            prev = None
+            for k in range(n_ops):
+                choices = [o for o in "MMMIDN" if o != prev and not (prev in ("I", "D", "N", None) and o in "IDN")]
+                op = rng.choice(choices) if k else "M"
+                ln = rng.randint(1, 3) if op != "N" else rng.randint(1, 40)
+                if x + ln >= 3900:
+                    break
+                if op == "M":
+                    seq += [rng.choice("ACGT") if rng.random() < 0.7 else ref[x + j] for j in range(ln)]
+                    x += ln
+                elif op == "I":
+                    seq += [rng.choice("ACGT") for _ in range(ln)]
+                else:
+                    x += ln
+                ops.append("%d%s" % (ln, op))
+                prev = op
+            while ops and ops[-1][-1] != "M":
+                op = ops.pop()
+                if op[-1] == "I":
+                    seq = seq[:len(seq) - int(op[:-1])]
+            if not ops:
+                continue
+            recs.append(dict(pos=pos, cigar="".join(ops), seq="".join(seq), flag=16 if rng.random() < 0.5 else 0, mapq=60, hp=0))
+        rs = ReadSet.from_records(recs)
+        _reset(eng, min_coverage=2)
+        got = H.engine_chunk(eng, rs, ref, 1, 1, 3900)
+        exp = H.oracle_chunk(rs, ref, 1, 1, 3900, min_coverage=2)
+        assert got["lines"] == exp["lines"], (seed, H.first_diff(got["lines"], exp["lines"]))
+        col = eng.columns()
+        rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, H.CTG, 1, 3933)
+        for row in rows:
+            f = row.split("\t")
+            pos = int(f[1])
+            o = orc.generate_tensor(f[4], ref[pos - 1], pos, ref, 1)
+            i = pos - col["region_start"]
+            assert col["cols"][i].tolist() == o["tensor"], (seed, pos)
