@@ -1,0 +1,91 @@
+"""GPU tests at BASELINE.json sizes.  A 3 Mb slice at chr20 read density is compared bit-exactly with the oracle;
+the full synthetic chr20 (configs[1]) is checked through size-independent properties: idempotence, agreement of the
+13 chunked scans with one whole-contig scan (checksum of per-site checksums), agreement of the +-33 bp chunk overlaps,
+probabilities normalised."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from clair3_rna_amd import capi
+    e = capi.Engine(0)
+    yield e
+    e.close()
+
+
+def _site_hash(X):
+    """order-independent-per-site 64-bit checksum of each [33][C] tensor"""
+    w = (np.arange(X.shape[1] * X.shape[2], dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1))
+    return (X.reshape(len(X), -1).astype(np.int64).astype(np.uint64) * w).sum(axis=1, dtype=np.uint64)
+
+
+def test_three_megabase_slice_bit_exact_vs_oracle(eng):
+    from clair3_rna_amd import capi, synth
+    L = 3000000
+    ref, rs, info = synth.generate_contig(contig_len=L, seed=synth.SEED, depth=20.0)
+    ref = ref.decode()
+    eng.params = capi.default_params()
+    eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.set_params()
+    got = H.engine_chunk(eng, rs, ref, 1, 1, L)
+    exp = H.oracle_chunk(rs, ref, 1, 1, L)
+    assert len(exp["lines"]) > 3000
+    assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
+    assert np.array_equal(got["X"], exp["X"])
+
+
+def test_full_chr20_properties(eng):
+    import bench
+    from clair3_rna_amd import capi, synth
+    ref, rs, info = synth.generate_contig()          # chr20, ~20x, seed 20240422: BASELINE.json configs[1]
+    L = len(ref)
+    eng.params = capi.default_params()
+    eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.set_params()
+    eng.load_reads(rs)
+    eng.set_reference(1, ref)
+    w = synth.random_weights(18)
+    eng.load_weights(w, 18)
+    chunks = bench.chunk_list(L)
+    per_chunk, probs_all = [], []
+    for (a, b) in chunks:
+        n = eng.scan(a, b)
+        s = eng.sites()
+        X = eng.tensors()
+        p = eng.infer()
+        per_chunk.append((s["pos"].copy(), _site_hash(X), s["depth"].copy()))
+        probs_all.append(p)
+        assert np.all(np.diff(s["pos"]) > 0)                      # sortedness within a chunk
+    # idempotence: scanning a chunk again gives the same bytes
+    a, b = chunks[3]
+    eng.scan(a, b)
+    again = _site_hash(eng.tensors())
+    assert np.array_equal(again, per_chunk[3][1])
+    # overlaps: sites in the +-33 bp margins are emitted by both neighbours with identical tensors
+    n_overlap = 0
+    for i in range(len(chunks) - 1):
+        p0, h0, _ = per_chunk[i]
+        p1, h1, _ = per_chunk[i + 1]
+        common, i0, i1 = np.intersect1d(p0, p1, return_indices=True)
+        n_overlap += len(common)
+        assert np.array_equal(h0[i0], h1[i1])
+    # chunked == whole-contig scan (checksum of checksums over the de-duplicated site set)
+    n_all = eng.scan(1, L)
+    s_all, h_all = eng.sites(), _site_hash(eng.tensors())
+    pos_cat = np.concatenate([c[0] for c in per_chunk])
+    h_cat = np.concatenate([c[1] for c in per_chunk])
+    upos, first = np.unique(pos_cat, return_index=True)
+    assert len(upos) == n_all and np.array_equal(upos, s_all["pos"])
+    assert np.array_equal(h_cat[first], h_all)
+    assert int(np.bitwise_xor.reduce(h_cat[first])) == int(np.bitwise_xor.reduce(h_all))
+    assert len(pos_cat) - len(upos) == n_overlap
+    # probabilities: two softmaxes per site
+    P = np.concatenate(probs_all)
+    assert len(P) == len(pos_cat) > 150000
+    assert np.allclose(P[:, :21].sum(1), 1, atol=1e-5) and np.allclose(P[:, 21:].sum(1), 1, atol=1e-5)
+    assert np.isfinite(P).all() and P.min() >= 0
