@@ -100,12 +100,9 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        s = torch.tensor([sites], dtype=torch.float64, device="cuda")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        sites = int(s.item())
+        from clair3_rna_amd import shard
+        elapsed = shard.reduce_max(dist, elapsed, device="cuda")     # max over ranks
+        sites = int(shard.reduce_sum(dist, sites, device="cuda"))    # whole-job aggregate
     sites_per_step_rank = sites / max(1, args.steps) / world
 
     # ---- per-kernel durations, live, with HIP events on the engine's stream (one extra untimed step)

@@ -1,0 +1,45 @@
+"""N>1 path on CPU: world_size 2, gloo.  Chunk sharding (LPT), no data-path collective, barrier + max-over-ranks
+timing — the protocol bench.py uses with RCCL on the GPUs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+from clair3_rna_amd import shard, synth
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_lpt_assign_balances_and_covers():
+    costs = [50, 3, 20, 20, 7, 1, 30, 9]
+    for world in (1, 2, 3, 8):
+        plan = shard.lpt_assign(costs, world)
+        assert sorted(i for p in plan for i in p) == list(range(len(costs)))
+        loads = [sum(costs[i] for i in p) for p in plan]
+        assert max(loads) - min(loads) <= max(costs)
+    assert shard.lpt_assign(costs, 2) == shard.lpt_assign(costs, 2)     # deterministic on every rank
+
+
+def test_two_rank_gloo_sharded_run_matches_single_process():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "mp_worker.py")]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.split("\n") if l.startswith("MPRESULT ")][0]
+    r = json.loads(line[len("MPRESULT "):])
+    assert r["world"] == 2 and sorted(i for p in r["plan"] for i in p) == list(range(6))
+    ref, rs, _ = synth.small_case(seed=51, ref_len=36000, n_genes=8, depth=15)
+    total = 0
+    for ci in range(6):
+        exp = [l.split("\t")[1] for l in H.oracle_chunk(rs, ref, 1, 6000 * ci, 6000 * (ci + 1))["lines"]]
+        assert r["per_chunk"][str(ci)] == exp
+        total += len(exp)
+    assert r["total"] == total > 0
+    assert abs(r["tmax"] - max(r["elapsed"])) < 1e-9 and r["tmax"] >= r["elapsed"][0]
