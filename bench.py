@@ -74,12 +74,15 @@ def main():
     eng.load_weights(weights, 18)
 
     def one_step():
+        # tensor build chunk by chunk (the reference's work items); the candidates of all chunks stay resident and
+        # go through the network in ONE launch per layer (batch mode), then the probabilities come back to the host
+        eng.begin_batch()
         total = 0
         for (a, b) in chunks:
-            n = eng.scan(a, b)
-            if n:
-                eng.infer()            # device-resident tensors -> probabilities on the host
-            total += n
+            total += eng.scan(a, b)
+        if total:
+            eng.infer()
+        eng.end_batch()
         return total
 
     def barrier():

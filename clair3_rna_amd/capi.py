@@ -33,7 +33,7 @@ class C3RError(RuntimeError):
 
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
-           "c3r_pileup_scan", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
+           "c3r_pileup_scan", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
            "c3r_weight_count", "c3r_load_weights", "c3r_infer", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
@@ -67,6 +67,9 @@ def load_library():
     L.c3r_set_bed.argtypes = [vp, i32, vp, i64]
     L.c3r_set_sites.argtypes = [vp, vp, i64]
     L.c3r_pileup_scan.argtypes = [vp, i64, i64, C.POINTER(i64)]
+    L.c3r_batch_begin.argtypes = [vp]
+    L.c3r_batch_end.argtypes = [vp]
+    L.c3r_batch_count.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.c3r_get_tensors.argtypes = [vp, i32, vp, i64]
     L.c3r_get_sites.argtypes = [vp, vp, i64]
     L.c3r_token_count.argtypes = [vp, C.POINTER(i64)]
@@ -152,8 +155,18 @@ class Engine(object):
     def scan(self, ctg_start, ctg_end):
         n = C.c_int64(0)
         self._chk(self.L.c3r_pileup_scan(self.h, ctg_start, ctg_end, C.byref(n)))
-        self.n_candidates = n.value
+        tot = C.c_int64(0)
+        self._chk(self.L.c3r_batch_count(self.h, C.byref(tot), None))
+        self.n_candidates = tot.value          # resident candidates (== n outside batch mode)
         return n.value
+
+    def begin_batch(self):
+        """Scans append to the device-resident batch until end_batch(); infer() then covers all of them."""
+        self._chk(self.L.c3r_batch_begin(self.h))
+        self.n_candidates = 0
+
+    def end_batch(self):
+        self._chk(self.L.c3r_batch_end(self.h))
 
     def tensors(self, rescaled=True):
         n, Cc = self.n_candidates, self.params.channels

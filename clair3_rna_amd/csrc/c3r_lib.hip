@@ -57,7 +57,9 @@ struct c3r_ctx {
     int32_t reg_beg0 = 0, reg_end0 = 0;
     int64_t n_pos = 0;
     DevBuf d_cols, d_depth, d_ncov, d_flags, d_ev, d_small /* cursor,last_row,totals */, d_blockcnt;
-    int64_t n_cand = 0, n_tok = 0;
+    int64_t n_cand = 0, n_tok = 0;        // totals resident on the device (all scans of the current batch)
+    int64_t last_cand = 0, last_base = 0; // candidates of the most recent scan and their offset in the batch
+    bool batching = false;
     DevBuf d_cand, d_tensors, d_raw, d_sites_out, d_tokcnt, d_tok;
     bool tokens_ready = false;
 
@@ -90,6 +92,20 @@ int ensure(c3r_ctx *ctx, DevBuf &b, size_t bytes) {
     if (b.p) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     HIPCHK(ctx, hipMalloc(&b.p, want));
     b.cap = want;
+    return C3R_OK;
+}
+
+// grow a buffer but keep its first `used` bytes (batch mode appends scan after scan)
+int ensure_keep(c3r_ctx *ctx, DevBuf &b, size_t bytes, size_t used) {
+    if (bytes <= b.cap && b.p) return C3R_OK;
+    if (!b.p || used == 0) return ensure(ctx, b, bytes);
+    size_t want = bytes + bytes / 2;
+    void *np_ = nullptr;
+    HIPCHK(ctx, hipMalloc(&np_, want));
+    HIPCHK(ctx, hipMemcpyAsync(np_, b.p, used, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(b.p));
+    b.p = np_; b.cap = want;
     return C3R_OK;
 }
 
@@ -323,17 +339,18 @@ int c3r_set_sites(c3r_ctx *ctx, const int32_t *sites, int64_t n) {
 
 // ------------------------------------------------------------------------------------------------
 static int run_gather(c3r_ctx *ctx, int rescale, int32_t *dst, bool with_sites) {
+    // operates on the candidates of the most recent scan; `dst` already points at their slot
     GatherArgs g;
     g.cols = (const int32_t *)ctx->d_cols.p; g.depth = (const int32_t *)ctx->d_depth.p; g.ncov = (const int32_t *)ctx->d_ncov.p;
-    g.flags = (const uint8_t *)ctx->d_flags.p; g.cand_idx = (const int32_t *)ctx->d_cand.p; g.n_cand = (int32_t)ctx->n_cand;
+    g.flags = (const uint8_t *)ctx->d_flags.p; g.cand_idx = (const int32_t *)ctx->d_cand.p; g.n_cand = (int32_t)ctx->last_cand;
     g.n_pos = (int32_t)ctx->n_pos; g.reg_beg0 = ctx->reg_beg0;
     g.ref = (const uint8_t *)ctx->d_ref.p; g.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); g.ref_len = (int32_t)ctx->h_ref.size();
     g.head_tail = ctx->prm.head_tail; g.last_row = (const int32_t *)((char *)ctx->d_small.p + 8);
     g.rescale = rescale; g.max_depth = ctx->prm.max_depth_rescale;
     g.tensors = dst;
-    g.sites = with_sites ? (c3r_site_t *)ctx->d_sites_out.p : nullptr;
+    g.sites = with_sites ? (c3r_site_t *)ctx->d_sites_out.p + ctx->last_base : nullptr;
     g.tok_cnt = with_sites ? (int32_t *)ctx->d_tokcnt.p : nullptr;
-    const int blocks = (int)((ctx->n_cand * 64 + 255) / 256);
+    const int blocks = (int)((ctx->last_cand * 64 + 255) / 256);
     Launch L(ctx, "k_gather");
     if (ctx->prm.channels == C3R_CH) hipLaunchKernelGGL(k_gather<C3R_CH>, dim3(blocks), dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL(k_gather<C3R_CH_PHASED>, dim3(blocks), dim3(256), 0, ctx->stream, g);
@@ -352,7 +369,9 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     ctx->reg_beg0 = (int32_t)(es - 1);
     ctx->reg_end0 = (int32_t)ee;
     ctx->n_pos = ee - es + 1;
-    ctx->n_cand = 0; ctx->n_tok = 0; ctx->tokens_ready = false;
+    if (!ctx->batching) { ctx->n_cand = 0; ctx->n_tok = 0; }
+    ctx->last_cand = 0; ctx->last_base = ctx->n_cand; ctx->tokens_ready = false;
+    const int64_t base_cand = ctx->n_cand, base_tok = ctx->n_tok;
     const int64_t n_pos = ctx->n_pos;
     const int n_tiles = (int)((n_pos + TILE - 1) / TILE);
     const int n_cblocks = (int)((n_pos + CMP_BLOCK - 1) / CMP_BLOCK);
@@ -405,19 +424,20 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     HIPCHK(ctx, hipMemcpyAsync(&n_cand, (char *)ctx->d_small.p + 12, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
-    ctx->n_cand = n_cand;
+    ctx->last_cand = n_cand;
     if (n_candidates) *n_candidates = n_cand;
     if (n_cand == 0) return C3R_OK;
+    const size_t tbytes = (size_t)C3R_WINDOW * C * 4;
     if ((rc = ensure(ctx, ctx->d_cand, (size_t)n_cand * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->d_tensors, (size_t)n_cand * C3R_WINDOW * C * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->d_sites_out, (size_t)n_cand * sizeof(c3r_site_t)))) return rc;
+    if ((rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_cand + n_cand) * tbytes, (size_t)base_cand * tbytes))) return rc;
+    if ((rc = ensure_keep(ctx, ctx->d_sites_out, (size_t)(base_cand + n_cand) * sizeof(c3r_site_t), (size_t)base_cand * sizeof(c3r_site_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_tokcnt, (size_t)(n_cand + 1) * 4))) return rc;
     {
         Launch L(ctx, "k_compact_write");
         hipLaunchKernelGGL(k_compact_write, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
                            (const int32_t *)ctx->d_blockcnt.p, (int32_t *)ctx->d_cand.p);
     }
-    if ((rc = run_gather(ctx, 1, (int32_t *)ctx->d_tensors.p, true))) return rc;
+    if ((rc = run_gather(ctx, 1, (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_cand * tbytes), true))) return rc;
     {
         Launch L(ctx, "k_excl_scan");
         hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)ctx->d_tokcnt.p, (int)n_cand,
@@ -426,19 +446,41 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     int32_t n_tok = 0;
     HIPCHK(ctx, hipMemcpyAsync(&n_tok, (char *)ctx->d_small.p + 16, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->n_tok = n_tok;
-    if ((rc = ensure(ctx, ctx->d_tok, std::max<size_t>((size_t)n_tok * sizeof(c3r_token_t), 16)))) return rc;
+    if ((rc = ensure_keep(ctx, ctx->d_tok, std::max<size_t>((size_t)(base_tok + n_tok) * sizeof(c3r_token_t), 16),
+                          (size_t)base_tok * sizeof(c3r_token_t)))) return rc;
     {
         TokArgs t;
         t.reads = a.reads; t.cigar = a.cigar; t.seq = a.seq; t.prefmax_end = a.prefmax_end; t.n_reads = a.n_reads;
         t.cand_idx = (const int32_t *)ctx->d_cand.p; t.n_cand = n_cand; t.reg_beg0 = ctx->reg_beg0;
-        t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p; t.tok = (c3r_token_t *)ctx->d_tok.p;
+        t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
+        t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;
         t.min_mq = a.min_mq; t.excl_flags = a.excl_flags;
         Launch L(ctx, "k_tokens");
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)(((int64_t)n_cand * 64 + 255) / 256)), dim3(256), 0, ctx->stream, t);
     }
     ctx->tokens_ready = true;
+    ctx->n_cand = base_cand + n_cand;
+    ctx->n_tok = base_tok + n_tok;
     HIPCHK(ctx, hipGetLastError());
+    return C3R_OK;
+}
+
+int c3r_batch_begin(c3r_ctx *ctx) {
+    if (!ctx) return C3R_EINVAL;
+    ctx->batching = true; ctx->n_cand = 0; ctx->n_tok = 0; ctx->last_cand = 0; ctx->last_base = 0;
+    return C3R_OK;
+}
+
+int c3r_batch_end(c3r_ctx *ctx) {
+    if (!ctx) return C3R_EINVAL;
+    ctx->batching = false;
+    return C3R_OK;
+}
+
+int c3r_batch_count(c3r_ctx *ctx, int64_t *n_sites, int64_t *n_tokens) {
+    if (!ctx) return C3R_EINVAL;
+    if (n_sites) *n_sites = ctx->n_cand;
+    if (n_tokens) *n_tokens = ctx->n_tok;
     return C3R_OK;
 }
 
@@ -450,6 +492,9 @@ int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_si
     const size_t bytes = (size_t)ctx->n_cand * C3R_WINDOW * ctx->prm.channels * 4;
     const void *src = ctx->d_tensors.p;
     if (!rescaled) {
+        // raw (un-rescaled) windows are re-gathered from the columns of the most recent scan only
+        if (ctx->last_base != 0 || ctx->last_cand != ctx->n_cand)
+            return fail(ctx, C3R_EINVAL, "raw tensors are only available for a single (non-batched) scan");
         int rc = ensure(ctx, ctx->d_raw, bytes);
         if (rc) return rc;
         if ((rc = run_gather(ctx, 0, (int32_t *)ctx->d_raw.p, false))) return rc;
@@ -524,7 +569,7 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
     const int32_t *d_x = nullptr;
     if (tensors == nullptr) {
         if (C != ctx->prm.channels) return fail(ctx, C3R_EINVAL, "weights are for %d channels, scan produced %d", C, ctx->prm.channels);
-        if (n != ctx->n_cand) return fail(ctx, C3R_EINVAL, "n=%lld but the last scan produced %lld candidates", (long long)n, (long long)ctx->n_cand);
+        if (n != ctx->n_cand) return fail(ctx, C3R_EINVAL, "n=%lld but %lld candidates are resident", (long long)n, (long long)ctx->n_cand);
         d_x = (const int32_t *)ctx->d_tensors.p;
     } else if (n > 0) {
         int rc = ensure(ctx, ctx->d_raw, (size_t)n * C3R_WINDOW * C * 4);

@@ -36,14 +36,19 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int NET_H1 = 128;
 constexpr int NET_H2 = 160;
 constexpr int NET_T = C3R_WINDOW;          // 33 time steps
-constexpr int NET_SITES = 32;              // sites per workgroup (one MFMA column block)
+constexpr int NET_SITES = 32;              // sites per MFMA column block
+constexpr int LSTM_SB = 2;                 // column blocks per wavefront in k_lstm
+constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 constexpr int NET_FLAT = NET_T * 2 * NET_H2;   // 10560
 constexpr int NET_L4 = 128;
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// sigmoid / tanh on the hardware transcendentals: v_exp_f32 + v_rcp_f32 (about 1 ulp each), no IEEE division
+// sequence.  exp2 overflow -> inf -> rcp 0; underflow -> 0 -> rcp(1) = 1, so both saturate correctly.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float fast_tanh(float x) {
-    // tanh(x) = 1 - 2/(exp(2x)+1); exp overflow -> inf -> 1, underflow -> 0 -> -1
-    return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f);
+    return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.0f);
 }
 __device__ __forceinline__ float selu(float x) {
     const float scale = 1.0507009873554805f, alpha = 1.6732632423543772f;
@@ -56,119 +61,162 @@ __device__ __forceinline__ float selu(float x) {
 //   CIN   : real input width in memory
 //   H     : hidden units
 //   INT_IN: input is int32 (the pileup tensor) instead of float
-// Wp: packed weights [dir][blk][g][64 lanes] float4, bp: packed bias [dir][blk][2][16]
-template <int INP, int CIN, int H, bool INT_IN>
-__global__ __launch_bounds__(256, 2) void k_lstm(const void *__restrict__ xin, const float4 *__restrict__ Wp,
-                                                 const float *__restrict__ bp, float *__restrict__ y, int n) {
+// Wp: packed weights [dir][wave][g][tile][64 lanes] float4, bp: packed bias [dir][blk][32 rows]
+// ABL: timing-only ablation bits for tools/lstm_probe.hip (0 in the product): 1 weights from one L1-hot group,
+// 2 no gate math, 4 no y store, 8 no barrier, 16 constant x operand.
+// SB : 32-site blocks per wavefront.  Every weight fragment fetched from L2 feeds SB MFMAs; the probe showed the
+//      L2 weight stream, not the matrix pipe, limits SB = 1 (66 % of peak; 81 % with L1-hot weights).
+template <int INP, int CIN, int H, bool INT_IN, int SB = 2, int ABL = 0>
+__global__ __launch_bounds__(256, (SB == 1 ? 2 : 1)) void k_lstm(const void *__restrict__ xin, const float4 *__restrict__ Wp,
+                                                                  const float *__restrict__ bp, float *__restrict__ y, int n) {
     constexpr int NGX = INP / 8;           // k-groups fed from the layer input (global memory)
     constexpr int NGH = H / 8;             // k-groups fed from h_{t-1} (LDS)
     constexpr int NG = NGX + NGH;
     constexpr int HP = H + 4;              // LDS row stride: conflict-free for ds_read_b128 (H=128: 132, H=160: 164)
     constexpr int NBLK = 4 * H / 32;
     constexpr int NT = NBLK / 4;           // 32-row blocks per wave
-    static_assert(INP % 8 == 0 && H % 32 == 0, "shape");
-    __shared__ __attribute__((aligned(16))) float hbuf[2][NET_SITES][HP];   // h double buffer: one barrier per step
+    constexpr int WG_SITES = 32 * SB;
+    static_assert(INP % 16 == 0 && H % 32 == 0, "shape: even k-group counts for the ping-pong pipeline");
+    __shared__ __attribute__((aligned(16))) float hbuf[2][WG_SITES][HP];   // h double buffer: one barrier per step
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y;
-    const int site0 = blockIdx.x * NET_SITES;
-    int sj = site0 + j; if (sj >= n) sj = n - 1;
+    const int site0 = blockIdx.x * WG_SITES;
 
-    const float4 *wl = Wp + ((size_t)dir * NBLK + wave * NT) * NG * 64 + lane;
-    const float *B = bp + ((size_t)dir * NBLK + wave * NT) * 32 + hh * 16;
+    // weights of this wave: [g][tt][lane] float4, contiguous per k-group -> one base pointer + immediate offsets
+    const float4 *wl = Wp + ((size_t)(dir * 4 + wave) * NG) * NT * 64 + lane;
+    // bias enters through one extra MFMA per tile and step: A = bias column (k=0 half of the wave), B = 1
+    float bias_a[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) bias_a[tt] = hh == 0 ? bp[((size_t)dir * NBLK + wave * NT + tt) * 32 + j] : 0.f;
 
-    float cst[NT][4];
+    float cst[NT][SB][4];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cst[tt][q] = 0.f;
+        for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cst[tt][sb][q] = 0.f;
+
+    for (int i = tid; i < WG_SITES * HP; i += 256) (&hbuf[0][0][0])[i] = 0.f;   // h_{-1} = 0
+    __syncthreads();
+
+    size_t xoff[SB];
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb) {
+        int sj = site0 + 32 * sb + j;
+        if (sj >= n) sj = n - 1;
+        xoff[sb] = (size_t)sj * NET_T * CIN;
+    }
 
     for (int step = 0; step < NET_T; ++step) {
         const int t = dir ? NET_T - 1 - step : step;
         const int cur = step & 1, nxt = cur ^ 1;
 
-        floatx16 acc[NT];
+        // B operand for k-group g of the input part: x_t[site][8g+4hh..+3] straight from global (rows stay in L1/L2
+        // across the K loop); of the recurrent part: h_{t-1} from LDS.  Two separate loaders so every load site has
+        // a static address space (a merged pointer select degrades to flat_load + vmcnt(0)).
+        auto ldx = [&](int g, float4 (&b)[SB]) {
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            const float4 *b4 = (const float4 *)(B + tt * 32);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = b4[q];
-                acc[tt][4 * q + 0] = v.x; acc[tt][4 * q + 1] = v.y; acc[tt][4 * q + 2] = v.z; acc[tt][4 * q + 3] = v.w;
-            }
-        }
-        // ---- input part: B operand = x_t[site j][8g + 4hh .. +3], straight from global (L1/L2 resident rows)
-        auto load_x = [&](int g) -> float4 {
-            if (INT_IN) {
-                const int32_t *xp = (const int32_t *)xin + ((size_t)sj * NET_T + t) * CIN;
-                float4 v;
-                const int k0 = 8 * g + 4 * hh;
-                v.x = (k0 + 0 < CIN) ? (float)xp[k0 + 0] : 0.f;
-                v.y = (k0 + 1 < CIN) ? (float)xp[k0 + 1] : 0.f;
-                v.z = (k0 + 2 < CIN) ? (float)xp[k0 + 2] : 0.f;
-                v.w = (k0 + 3 < CIN) ? (float)xp[k0 + 3] : 0.f;
-                return v;
-            } else {
-                return *(const float4 *)((const float *)xin + ((size_t)sj * NET_T + t) * CIN + 8 * g + 4 * hh);
+            for (int sb = 0; sb < SB; ++sb) {
+                if (ABL & 16) { b[sb] = make_float4(1.f, 0.5f, 0.25f, (float)g); continue; }
+                if (INT_IN) {
+                    const int32_t *xp = (const int32_t *)xin + xoff[sb] + (size_t)t * CIN;
+                    const int k0 = 8 * g + 4 * hh;
+                    b[sb].x = (k0 + 0 < CIN) ? (float)xp[k0 + 0] : 0.f;
+                    b[sb].y = (k0 + 1 < CIN) ? (float)xp[k0 + 1] : 0.f;
+                    b[sb].z = (k0 + 2 < CIN) ? (float)xp[k0 + 2] : 0.f;
+                    b[sb].w = (k0 + 3 < CIN) ? (float)xp[k0 + 3] : 0.f;
+                } else {
+                    b[sb] = *(const float4 *)((const float *)xin + xoff[sb] + (size_t)t * CIN + 8 * g + 4 * hh);
+                }
             }
         };
-        float4 bnext = load_x(0);
-#pragma unroll 1
-        for (int g = 0; g < NGX; ++g) {
-            const float4 b = bnext;
-            if (g + 1 < NGX) bnext = load_x(g + 1);
-            float4 a[NT];
+        auto ldh = [&](int g, float4 (&b)[SB]) {
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) a[tt] = wl[((size_t)tt * NG + g) * 64];
+            for (int sb = 0; sb < SB; ++sb) b[sb] = *(const float4 *)&hbuf[cur][32 * sb + j][8 * g + 4 * hh];
+        };
+        auto ldw = [&](int g, float4 (&a)[NT]) {
+            const float4 *wg = wl + (size_t)((ABL & 1) ? 0 : g) * NT * 64;
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].x, b.x, acc[tt], 0, 0, 0);
+            for (int tt = 0; tt < NT; ++tt) a[tt] = wg[tt * 64];
+        };
+
+        floatx16 acc[NT][SB];
+        {
+            floatx16 z;
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].y, b.y, acc[tt], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].z, b.z, acc[tt], 0, 0, 0);
+            for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].w, b.w, acc[tt], 0, 0, 0);
+                for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[tt], 1.0f, z, 0, 0, 0);
         }
-        // ---- recurrent part: B operand = h_{t-1}[site j][8g + 4hh .. +3] from LDS (zero at step 0: skipped)
-        if (step > 0) {
-            const float *hrow = &hbuf[cur][j][4 * hh];
+#define C3R_MMA_K(comp)                                                                                              \
+    _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) _Pragma("unroll") for (int sb = 0; sb < SB; ++sb)             \
+        acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].comp, b[sb].comp, acc[tt][sb], 0, 0, 0);
+        auto mma = [&](const float4 (&a)[NT], const float4 (&b)[SB]) {
+            C3R_MMA_K(x) C3R_MMA_K(y) C3R_MMA_K(z) C3R_MMA_K(w)
+        };
+#undef C3R_MMA_K
+        // Software-pipelined K loop with ping-pong registers: the operands of group g+1 are in flight while group g is
+        // on the matrix pipe.  (h_{-1} = 0 is a zero-filled LDS buffer: straight-line loops keep hipcc's register
+        // allocation sane; skipping the recurrent part at step 0 would save 1.2 % of the MFMAs.)
+        // sched_barrier(0): hipcc's scheduler otherwise clusters the ping and pong loads at the loop top and the
+        // waitcnt pass then has to drain everything (vmcnt(0)) before the first MFMA of each half.
+        float4 a0[NT], a1[NT], b0[SB], b1[SB];
+#define C3R_FENCE() __builtin_amdgcn_sched_barrier(0)
+        ldw(0, a0);
+        ldx(0, b0);
 #pragma unroll 1
-            for (int g = 0; g < NGH; ++g) {
-                const float4 b = *(const float4 *)(hrow + 8 * g);
-                float4 a[NT];
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) a[tt] = wl[((size_t)tt * NG + NGX + g) * 64];
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].x, b.x, acc[tt], 0, 0, 0);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].y, b.y, acc[tt], 0, 0, 0);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].z, b.z, acc[tt], 0, 0, 0);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt].w, b.w, acc[tt], 0, 0, 0);
-            }
+        for (int g = 0; g + 2 < NGX; g += 2) {
+            C3R_FENCE(); ldw(g + 1, a1); ldx(g + 1, b1); C3R_FENCE();
+            mma(a0, b0);
+            C3R_FENCE(); ldw(g + 2, a0); ldx(g + 2, b0); C3R_FENCE();
+            mma(a1, b1);
         }
+        C3R_FENCE(); ldw(NGX - 1, a1); ldx(NGX - 1, b1); C3R_FENCE();
+        mma(a0, b0);
+        C3R_FENCE(); ldw(NGX, a0); ldh(0, b0); C3R_FENCE();
+        mma(a1, b1);
+#pragma unroll 1
+        for (int g = 0; g + 2 < NGH; g += 2) {
+            C3R_FENCE(); ldw(NGX + g + 1, a1); ldh(g + 1, b1); C3R_FENCE();
+            mma(a0, b0);
+            C3R_FENCE(); ldw(NGX + g + 2, a0); ldh(g + 2, b0); C3R_FENCE();
+            mma(a1, b1);
+        }
+        C3R_FENCE(); ldw(NG - 1, a1); ldh(NGH - 1, b1); C3R_FENCE();
+        mma(a0, b0);
+        mma(a1, b1);
+        C3R_FENCE();
+#undef C3R_FENCE
         // ---- lane-local cell update: acc row 4q+m <-> gate m (i,f,g,o) of unit 8*blk + 4*hh + q
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            float hq[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float ig = fast_sigmoid(acc[tt][4 * q + 0]);
-                const float fg = fast_sigmoid(acc[tt][4 * q + 1]);
-                const float gg = fast_tanh(acc[tt][4 * q + 2]);
-                const float og = fast_sigmoid(acc[tt][4 * q + 3]);
-                const float c = fg * cst[tt][q] + ig * gg;
-                cst[tt][q] = c;
-                hq[q] = og * fast_tanh(c);
+            for (int sb = 0; sb < SB; ++sb) {
+                float hq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (ABL & 2) { hq[q] = acc[tt][sb][4 * q] + acc[tt][sb][4 * q + 1] + acc[tt][sb][4 * q + 2] + acc[tt][sb][4 * q + 3]; continue; }
+                    const float ig = fast_sigmoid(acc[tt][sb][4 * q + 0]);
+                    const float fg = fast_sigmoid(acc[tt][sb][4 * q + 1]);
+                    const float gg = fast_tanh(acc[tt][sb][4 * q + 2]);
+                    const float og = fast_sigmoid(acc[tt][sb][4 * q + 3]);
+                    const float c = fg * cst[tt][sb][q] + ig * gg;
+                    cst[tt][sb][q] = c;
+                    hq[q] = og * fast_tanh(c);
+                }
+                *(float4 *)&hbuf[nxt][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = make_float4(hq[0], hq[1], hq[2], hq[3]);
             }
-            *(float4 *)&hbuf[nxt][j][8 * (wave * NT + tt) + 4 * hh] = make_float4(hq[0], hq[1], hq[2], hq[3]);
         }
-        __syncthreads();   // h_t complete; everyone is done reading h_{t-1}
+        if (!(ABL & 8)) __syncthreads();   // h_t complete; everyone is done reading h_{t-1}
         // ---- layer output y[site][t][dir*H + u]: coalesced 16-byte stores from the LDS copy of h_t
         constexpr int HV = H / 4;
-        for (int f = tid; f < NET_SITES * HV; f += 256) {
+        if (!(ABL & 4))
+        for (int f = tid; f < WG_SITES * HV; f += 256) {
             const int row = f / HV, c4 = f % HV;
             const int s = site0 + row;
             if (s < n) {
@@ -308,7 +356,7 @@ inline void net_free(NetState &s) {
 // gate-major columns i|f|c|o) into MFMA fragment order [blk][g][lane][s] and bias into [blk][hh][q][m].
 inline void pack_lstm_dir(const float *Kin, int cin, int inp, const float *R, const float *b, int H,
                           std::vector<float> &wp, std::vector<float> &bpk) {
-    const int K = inp + H, NG = K / 8, NBLK = 4 * H / 32;
+    const int K = inp + H, NG = K / 8, NBLK = 4 * H / 32, NT = NBLK / 4;
     wp.assign((size_t)NBLK * NG * 64 * 4, 0.f);
     bpk.assign((size_t)NBLK * 32, 0.f);
     auto wcat = [&](int k, int col) -> float {
@@ -319,12 +367,12 @@ inline void pack_lstm_dir(const float *Kin, int cin, int inp, const float *R, co
         for (int r = 0; r < 32; ++r) {
             const int q = r >> 3, hh = (r >> 2) & 1, m = r & 3;     // r = 8q + 4hh + m
             const int unit = 8 * blk + 4 * hh + q, col = m * H + unit;
-            bpk[(size_t)(blk * 2 + hh) * 16 + 4 * q + m] = b[col];
+            bpk[(size_t)blk * 32 + r] = b[col];
             for (int g = 0; g < NG; ++g)
                 for (int kh = 0; kh < 2; ++kh)
                     for (int s = 0; s < 4; ++s) {
                         const int lane = kh * 32 + r;
-                        wp[(((size_t)blk * NG + g) * 64 + lane) * 4 + s] = wcat(8 * g + 4 * kh + s, col);
+                        wp[((((size_t)(blk / NT) * NG + g) * NT + (blk % NT)) * 64 + lane) * 4 + s] = wcat(8 * g + 4 * kh + s, col);
                     }
         }
     }
@@ -347,7 +395,7 @@ inline int net_upload(T *&dst, const std::vector<float> &src, hipStream_t st, st
 
 inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::string &err) {
     const float *q = blob;
-    const int inp1 = (C + 7) / 8 * 8;
+    const int inp1 = 32;   // padded to an even number of 8-wide k-groups
     std::vector<float> w1, b1, w2, b2, tw, tb;
     for (int d = 0; d < 2; ++d) {
         const float *Kin = q; q += (size_t)C * 4 * NET_H1;
@@ -420,22 +468,22 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
     int rc = net_reserve(s, n, st, err);
     if (rc) return rc;
     const int nb = (int)((n + NET_SITES - 1) / NET_SITES);
-    const dim3 grid(nb, 2), block(256);
+    const dim3 grid((unsigned)((n + LSTM_SITES - 1) / LSTM_SITES), 2), block(256);
     prof("k_lstm1", 0);
     if (s.channels == C3R_CH) {
-        constexpr int INP = 24;
-        hipLaunchKernelGGL((k_lstm<INP, C3R_CH, NET_H1, true>), grid, block, 0, st, (const void *)d_x,
+        constexpr int INP = 32;
+        hipLaunchKernelGGL((k_lstm<INP, C3R_CH, NET_H1, true, LSTM_SB>), grid, block, 0, st, (const void *)d_x,
                            (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n);
     } else {
         constexpr int INP = 32;
-        hipLaunchKernelGGL((k_lstm<INP, C3R_CH_PHASED, NET_H1, true>), grid, block, 0, st, (const void *)d_x,
+        hipLaunchKernelGGL((k_lstm<INP, C3R_CH_PHASED, NET_H1, true, LSTM_SB>), grid, block, 0, st, (const void *)d_x,
                            (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n);
     }
     prof("k_lstm1", 1);
     prof("k_lstm2", 0);
     {
         constexpr int INP = 2 * NET_H1;
-        hipLaunchKernelGGL((k_lstm<INP, INP, NET_H2, false>), grid, block, 0, st, (const void *)s.d_y1,
+        hipLaunchKernelGGL((k_lstm<INP, INP, NET_H2, false, LSTM_SB>), grid, block, 0, st, (const void *)s.d_y1,
                            (const float4 *)s.d_w2, (const float *)s.d_b2, s.d_y2, (int)n);
     }
     prof("k_lstm2", 1);

@@ -568,6 +568,7 @@ struct TokArgs {
     const DevRead *reads; const uint32_t *cigar; const uint8_t *seq; const int32_t *prefmax_end; int32_t n_reads;
     const int32_t *cand_idx; int32_t n_cand; int32_t reg_beg0;
     const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
+    int32_t tok_base;              // tokens already resident from earlier scans of the batch
     int32_t min_mq, excl_flags;
 };
 
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void k_tokens(const TokArgs t) {
     const int p = t.reg_beg0 + t.cand_idx[w];
     const int lo = upper_bound_gt(t.prefmax_end, t.n_reads, p);
     const int hi = lower_bound_pos(t.reads, t.n_reads, p + 1);
-    const int base_off = t.tok_off[w];
+    const int base_off = t.tok_base + t.tok_off[w];
     if (lane == 0) t.sites[w].tok_off = (uint32_t)base_off;
     int written = 0;
     for (int rb = lo; rb < hi; rb += 64) {

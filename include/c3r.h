@@ -80,7 +80,15 @@ int c3r_set_sites(c3r_ctx *ctx, const int32_t *sites, int64_t n);
  * selection, window gather with the depth>216 rescale (clair3_rna/utils.py:88-92).  Tensors and
  * site records stay resident on the device.  Returns the number of emitted candidates. */
 int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n_candidates);
-/* Copy out what the last scan produced.  Any pointer may be NULL.  tensors: int32 [n][33][C]
+/* Batch mode: between c3r_batch_begin and c3r_batch_end every scan APPENDS its candidates (tensors, sites,
+ * tokens) to the device-resident batch instead of replacing it, so that the chunks of a whole contig go through
+ * the network in one launch per layer (the reference batches 200 sites, shared/param_p.py:51; 288 GB of HBM let
+ * us batch a whole contig).  c3r_batch_count returns the totals; c3r_infer(NULL, n_total) and the c3r_get_*
+ * calls then cover all accumulated candidates in scan order. */
+int c3r_batch_begin(c3r_ctx *ctx);
+int c3r_batch_end(c3r_ctx *ctx);
+int c3r_batch_count(c3r_ctx *ctx, int64_t *n_sites, int64_t *n_tokens);
+/* Copy out what the last scan (or the current batch) produced.  Any pointer may be NULL.  tensors: int32 [n][33][C]
  * row-major (the 594/990 integers of a create_tensor line, after the A5 rescale when
  * `rescaled` != 0, raw otherwise); sites: [n]; tokens: [n_tokens] (see c3r_token_count). */
 int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_sites);

@@ -84,6 +84,17 @@ def test_full_chr20_properties(eng):
     assert np.array_equal(h_cat[first], h_all)
     assert int(np.bitwise_xor.reduce(h_cat[first])) == int(np.bitwise_xor.reduce(h_all))
     assert len(pos_cat) - len(upos) == n_overlap
+    # batch mode: all chunks appended, one network launch per layer == per-chunk results, bit for bit
+    eng.begin_batch()
+    for (a, b) in chunks:
+        eng.scan(a, b)
+    Pb = eng.infer()
+    sb = eng.sites()
+    eng.end_batch()
+    assert np.array_equal(sb["pos"], pos_cat)
+    assert np.array_equal(Pb, np.concatenate(probs_all))
+    tk = eng.tokens()
+    assert len(tk) == int(sb["n_tok"].sum()) and int(sb["tok_off"][-1]) + int(sb["n_tok"][-1]) == len(tk)
     # probabilities: two softmaxes per site
     P = np.concatenate(probs_all)
     assert len(P) == len(pos_cat) > 150000
