@@ -6,6 +6,7 @@
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -45,6 +46,8 @@ struct c3r_ctx {
     std::vector<uint8_t> h_seq;
     int64_t n_indel_ops = 0;
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
+    std::vector<DevSeg> h_segs;            // aligned segments (CIGAR runs between N ops), sorted by ext_start
+    DevBuf d_segs, d_seg_prefmax, d_tile_cols, d_tile_rng, d_tile_list;
     std::string h_ref; int64_t ref_start1 = 1;
     DevBuf d_ref;
     std::vector<int32_t> h_bed[2];
@@ -153,7 +156,16 @@ int upload_prefmax(c3r_ctx *ctx) {
     recompute_prefmax(ctx, pm);
     int rc = upload(ctx, ctx->d_prefmax, pm.data(), pm.size());
     if (rc) return rc;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // pm is a temporary
+    std::vector<int32_t> sm(ctx->h_segs.size());
+    int32_t m = INT_MIN;
+    for (size_t i = 0; i < ctx->h_segs.size(); ++i) {
+        const DevSeg &g = ctx->h_segs[i];
+        const bool pass = !(g.flag & ctx->prm.excl_flags) && !(g.flag & 4) && g.mapq >= ctx->prm.min_mq;
+        if (pass) m = std::max(m, g.end);
+        sm[i] = m;
+    }
+    if ((rc = upload(ctx, ctx->d_seg_prefmax, sm.data(), sm.size()))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // pm / sm are temporaries
     return C3R_OK;
 }
 
@@ -212,7 +224,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+    DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -250,7 +262,7 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     if (!ctx || n_reads < 0 || (n_reads && (!reads || !cigars || !seq4))) return C3R_EINVAL;
     if (n_reads > INT32_MAX) return fail(ctx, C3R_EINVAL, "too many reads");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    ctx->h_reads.clear(); ctx->h_cigar.clear();
+    ctx->h_reads.clear(); ctx->h_cigar.clear(); ctx->h_segs.clear();
     ctx->h_reads.reserve((size_t)n_reads);
     ctx->h_cigar.reserve((size_t)n_cigar_ops);
     ctx->n_indel_ops = 0;
@@ -290,12 +302,45 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
         if ((int64_t)r.pos + rlen > INT32_MAX) return fail(ctx, C3R_EINVAL, "read %lld ends beyond 2^31", (long long)i);
         d.end = (int32_t)(r.pos + rlen);
         ctx->h_reads.push_back(d);
+        // aligned segments: the runs of ops between N ops
+        {
+            int64_t x = r.pos, y = 0;
+            uint32_t k = 0;
+            bool after_n = false;
+            while (k < d.n_cig) {
+                DevSeg g;
+                memset(&g, 0, sizeof g);
+                g.pos = (int32_t)x; g.cig_off = d.cig_off + k; g.qstart = (uint32_t)y; g.l_seq = d.l_seq; g.seq_off = d.seq_off;
+                g.read_idx = (uint32_t)i; g.flag = d.flag; g.mapq = d.mapq; g.hp = d.hp; g.lead_n = after_n ? 1 : 0;
+                const uint32_t first_op = ctx->h_cigar[d.cig_off + k] & 15u;
+                uint32_t k1 = k;
+                bool useful = false;
+                while (k1 < d.n_cig && (ctx->h_cigar[d.cig_off + k1] & 15u) != C3R_CIG_N) {
+                    const uint32_t c = ctx->h_cigar[d.cig_off + k1], op = c & 15u, len = c >> 4;
+                    if (op == C3R_CIG_M || op == C3R_CIG_D) { x += len; useful = true; }
+                    if (op == C3R_CIG_M || op == C3R_CIG_I || op == C3R_CIG_S) y += len;
+                    ++k1;
+                }
+                const bool lead_indel = after_n && (first_op == C3R_CIG_I || first_op == C3R_CIG_D);
+                if (k1 > k && (useful || lead_indel)) {
+                    if (k1 - k > 0xffff) return fail(ctx, C3R_EINVAL, "read %lld: more than 65535 CIGAR ops between two N ops", (long long)i);
+                    g.n_cig = (uint16_t)(k1 - k);
+                    g.ext_start = g.pos - (lead_indel ? 1 : 0);
+                    g.end = (int32_t)std::max<int64_t>(x, (int64_t)g.ext_start + 1);
+                    ctx->h_segs.push_back(g);
+                }
+                if (k1 < d.n_cig) { x += ctx->h_cigar[d.cig_off + k1] >> 4; after_n = true; ++k1; }   // the N op itself
+                k = k1;
+            }
+        }
     }
+    std::stable_sort(ctx->h_segs.begin(), ctx->h_segs.end(), [](const DevSeg &a, const DevSeg &b) { return a.ext_start < b.ext_start; });
     ctx->h_seq.assign(seq4, seq4 + n_seq_bytes);
     int rc;
     if ((rc = upload(ctx, ctx->d_reads, ctx->h_reads.data(), ctx->h_reads.size()))) return rc;
     if ((rc = upload(ctx, ctx->d_cigar, ctx->h_cigar.data(), ctx->h_cigar.size()))) return rc;
     if ((rc = upload(ctx, ctx->d_seq, ctx->h_seq.data(), ctx->h_seq.size()))) return rc;
+    if ((rc = upload(ctx, ctx->d_segs, ctx->h_segs.data(), ctx->h_segs.size()))) return rc;
     if ((rc = upload_prefmax(ctx))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return C3R_OK;
@@ -342,7 +387,7 @@ static int run_gather(c3r_ctx *ctx, int rescale, int32_t *dst, bool with_sites) 
     // operates on the candidates of the most recent scan; `dst` already points at their slot
     GatherArgs g;
     g.cols = (const int32_t *)ctx->d_cols.p; g.depth = (const int32_t *)ctx->d_depth.p; g.ncov = (const int32_t *)ctx->d_ncov.p;
-    g.flags = (const uint8_t *)ctx->d_flags.p; g.cand_idx = (const int32_t *)ctx->d_cand.p; g.n_cand = (int32_t)ctx->last_cand;
+    g.flags = (const uint8_t *)ctx->d_flags.p; g.tile_cols = (const uint8_t *)ctx->d_tile_cols.p; g.cand_idx = (const int32_t *)ctx->d_cand.p; g.n_cand = (int32_t)ctx->last_cand;
     g.n_pos = (int32_t)ctx->n_pos; g.reg_beg0 = ctx->reg_beg0;
     g.ref = (const uint8_t *)ctx->d_ref.p; g.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); g.ref_len = (int32_t)ctx->h_ref.size();
     g.head_tail = ctx->prm.head_tail; g.last_row = (const int32_t *)((char *)ctx->d_small.p + 8);
@@ -382,15 +427,25 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     if ((rc = ensure(ctx, ctx->d_flags, (size_t)n_pos))) return rc;
     if ((rc = ensure(ctx, ctx->d_ev, ((size_t)ctx->n_indel_ops + 16 * (size_t)n_tiles + 16) * sizeof(EvRec)))) return rc;
     if ((rc = ensure(ctx, ctx->d_small, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tile_cols, (size_t)n_tiles + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_blockcnt, (size_t)(n_cblocks + 1) * 4))) return rc;
-    // d_small: [0..7] ev_cursor (u64), [8..11] last_row, [12..15] n_cand, [16..19] n_tok
-    int32_t init[5] = {0, 0, -1, 0, 0};
+    // d_small: [0..7] ev_cursor (u64), [8..11] last_row, [12..15] n_cand, [16..19] n_tok, [20..23] n_tile_list
+    int32_t init[6] = {0, 0, -1, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_small.p, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_flags.p, 0, (size_t)n_pos, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cols.p, 0, (size_t)n_tiles, ctx->stream));
 
     ScanArgs a;
     a.reads = (const DevRead *)ctx->d_reads.p; a.cigar = (const uint32_t *)ctx->d_cigar.p; a.seq = (const uint8_t *)ctx->d_seq.p;
     a.prefmax_end = (const int32_t *)ctx->d_prefmax.p; a.n_reads = (int32_t)ctx->h_reads.size();
+    a.segs = (const DevSeg *)ctx->d_segs.p; a.seg_prefmax = (const int32_t *)ctx->d_seg_prefmax.p; a.n_segs = (int32_t)ctx->h_segs.size();
+    a.tile_cols = (uint8_t *)ctx->d_tile_cols.p;
+    a.tile_rng = (int4 *)ctx->d_tile_rng.p; a.tile_list = (int32_t *)ctx->d_tile_list.p;
+    a.n_tile_list = (int32_t *)((char *)ctx->d_small.p + 20); a.n_tiles = n_tiles;
+    a.head_tail = ctx->prm.head_tail;
+    { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
     a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->h_ref.size();
     a.reg_beg0 = ctx->reg_beg0; a.reg_end0 = ctx->reg_end0;
     a.cols = (int32_t *)ctx->d_cols.p; a.depth = (int32_t *)ctx->d_depth.p; a.ncov = (int32_t *)ctx->d_ncov.p; a.flags = (uint8_t *)ctx->d_flags.p;
@@ -400,6 +455,10 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.min_cov = ctx->prm.min_coverage;
     a.snp_af = ctx->prm.snp_min_af; a.indel_af = ctx->prm.indel_min_af;
     a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)ctx->d_small.p; a.last_row = (int32_t *)((char *)ctx->d_small.p + 8);
+    if (a.n_reads > 0) {
+        Launch L(ctx, "k_tile_ranges");
+        hipLaunchKernelGGL(k_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
+    }
     if (a.n_reads > 0) {
         Launch L(ctx, "k_scan_tiles");
         if (C == C3R_CH) hipLaunchKernelGGL(k_scan_tiles<C3R_CH>, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
@@ -542,7 +601,17 @@ int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t
     if (cols) HIPCHK(ctx, hipMemcpyAsync(cols, ctx->d_cols.p, n * ctx->prm.channels * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (depth) HIPCHK(ctx, hipMemcpyAsync(depth, ctx->d_depth.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (flags) HIPCHK(ctx, hipMemcpyAsync(flags, ctx->d_flags.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t n_tiles = (n + TILE - 1) / TILE;
+    std::vector<uint8_t> tc(n_tiles);
+    HIPCHK(ctx, hipMemcpyAsync(tc.data(), ctx->d_tile_cols.p, n_tiles, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // tiles that hold no aligned base are not materialised on the device: their columns are all-zero by definition
+    for (size_t t = 0; t < n_tiles; ++t) {
+        if (tc[t]) continue;
+        const size_t p0 = t * TILE, p1 = std::min(n, p0 + TILE);
+        if (cols) memset(cols + p0 * ctx->prm.channels, 0, (p1 - p0) * ctx->prm.channels * 4);
+        if (depth) for (size_t q = p0; q < p1; ++q) if (!flags || !(flags[q] & 1)) depth[q] = 0;
+    }
     return C3R_OK;
 }
 

@@ -40,6 +40,28 @@ struct DevRead {
 };
 static_assert(sizeof(DevRead) == 32, "DevRead must be 32 bytes");
 
+// One aligned segment of a read = the CIGAR ops between two N (ref-skip) ops, prepared on the host at load time and
+// sorted by ext_start.  Tiles walk SEGMENTS, so a read spanning a 100-kb intron costs nothing in the intron's tiles;
+// only coverage (which positions have a pileup row) still comes from the whole-read spans, header-only.
+struct DevSeg {
+    int32_t ext_start;  // pos, or pos-1 when the segment starts with an I/D right after an N (indel attached to the
+                        // last intron column)
+    int32_t end;        // 0-based exclusive reference end of the segment's ops (>= ext_start + 1)
+    int32_t pos;        // reference position of the first op
+    uint32_t cig_off;   // absolute index of the first op in the normalised CIGAR array
+    uint32_t qstart;    // query offset at the first op
+    uint32_t l_seq;
+    uint64_t seq_off;
+    uint32_t read_idx;  // BAM-order ordinal (first-seen order, token order)
+    uint16_t n_cig;
+    uint16_t flag;
+    uint8_t mapq;
+    uint8_t hp;
+    uint8_t lead_n;     // the op before the segment is an N
+    uint8_t pad;
+};
+static_assert(sizeof(DevSeg) == 48, "DevSeg must be 48 bytes");
+
 struct EvRec {          // one indel event, bucketed by position inside a tile
     uint64_t key;       // insertion: first <=16 base codes, 4 bits each; deletion: 0
     uint32_t len;
@@ -57,6 +79,16 @@ struct ScanArgs {
     const uint8_t *seq;
     const int32_t *prefmax_end;   // inclusive prefix max of `end` over passing reads
     int32_t n_reads;
+    const DevSeg *segs;           // aligned segments sorted by ext_start
+    const int32_t *seg_prefmax;   // inclusive prefix max of segment `end` over passing segments
+    int32_t n_segs;
+    uint8_t *tile_cols;           // [n_tiles] 1 = this tile's columns were written (0: implicitly all-zero)
+    int4 *tile_rng;               // [n_tiles] {lo, hi, slo, shi} from k_tile_ranges
+    int32_t *tile_list;           // compact list of tiles covered by at least one read span
+    int32_t *n_tile_list;
+    int32_t n_tiles;
+    int32_t head_tail;            // last_row (end of the row stream) is only needed for the head/tail flush rule
+    int32_t abl;                  // timing-only ablation bits (env C3R_SCAN_ABL, 0 in production)
     const uint8_t *ref;           // upper-cased reference slice
     int32_t ref_beg0;             // 0-based position of ref[0]
     int32_t ref_len;
@@ -88,6 +120,14 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 
 __device__ __forceinline__ bool read_passes(const DevRead &r, int min_mq, int excl) {
     return !(r.flag & excl) && !(r.flag & 4) && r.mapq >= min_mq && r.end > r.pos;
+}
+__device__ __forceinline__ bool seg_passes(const DevSeg &g, int min_mq, int excl) {
+    return !(g.flag & excl) && !(g.flag & 4) && g.mapq >= min_mq;
+}
+__device__ __forceinline__ int lower_bound_seg(const DevSeg *g, int n, int v) {  // first i with g[i].ext_start >= v
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (g[mid].ext_start >= v) hi = mid; else lo = mid + 1; }
+    return lo;
 }
 
 __device__ __forceinline__ int base_code(const uint8_t *seq, uint64_t off, uint32_t q, uint32_t l_seq) {
@@ -139,42 +179,71 @@ struct TileLds {
     uint8_t *amb;      // [TILE]
 };
 
-// Walk every read overlapping the tile.  One wavefront per read, one lane per CIGAR op.
-template <int C, int MODE>
-__device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, unsigned long long ev_base) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    for (int r = lo + wave; r < hi; r += WAVES) {
+// Coverage of the tile from whole-read spans (incl. introns): header-only, one lane per read.
+__device__ void cover_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1) {
+    for (int r = lo + (int)threadIdx.x; r < hi; r += SCAN_THREADS) {
         const DevRead rd = a.reads[r];
         if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.pos >= t1) continue;
+        atomicAdd(&s.cov[max(rd.pos, t0) - t0], 1);
+        if (rd.end < t1) atomicAdd(&s.cov[rd.end - t0], -1);
+    }
+}
+
+// Walk every aligned segment overlapping the tile.  One 16-lane group per segment (segments are exon-sized: a dozen
+// CIGAR ops), one lane per CIGAR op: 16 segments in flight per workgroup hide the header -> CIGAR -> bases latency
+// chain four times better than one segment per wavefront.
+constexpr int GRP = 16;                       // lanes per segment
+constexpr int NGRP = SCAN_THREADS / GRP;      // segments in flight per workgroup
+
+__device__ __forceinline__ int grp_incl_scan(int v) {
+    const int gl = threadIdx.x & (GRP - 1);
+#pragma unroll
+    for (int off = 1; off < GRP; off <<= 1) {
+        int t = __shfl_up(v, off, GRP);
+        if (gl >= off) v += t;
+    }
+    return v;
+}
+
+template <int C, int MODE>
+__device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, unsigned long long ev_base) {
+    const int lane = threadIdx.x & (GRP - 1);
+    const int grp = threadIdx.x / GRP;
+    for (int si = lo + grp; si < hi; si += NGRP) {
+        const DevSeg rd = a.segs[si];
+        if (!seg_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.ext_start >= t1) continue;
         const bool rev = (rd.flag & 16) != 0;
-        if (MODE == ACCUM && lane == 0) {
-            atomicAdd(&s.cov[max(rd.pos, t0) - t0], 1);
-            if (rd.end < t1) atomicAdd(&s.cov[rd.end - t0], -1);
-        }
-        int ref_carry = 0, q_carry = 0, prev_carry = 15;
-        for (uint32_t kb = 0; kb < rd.n_cig; kb += 64) {
+        const int r = (int)rd.read_idx;
+        int ref_carry = 0, q_carry = (int)rd.qstart, prev_carry = rd.lead_n ? (int)C3R_CIG_N : 15;
+        for (uint32_t kb = 0; kb < rd.n_cig; kb += GRP) {
             const uint32_t k = kb + lane;
             const bool valid = k < rd.n_cig;
             const uint32_t c = valid ? a.cigar[rd.cig_off + k] : 15u;
             const int op = (int)(c & 15u);
             const int len = valid ? (int)(c >> 4) : 0;
             const int rl = (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) ? len : 0;
-            const int ql = (op == C3R_CIG_M || op == C3R_CIG_I || op == C3R_CIG_S) ? len : 0;
-            const int rincl = wave_incl_scan(rl);
-            const int qincl = wave_incl_scan(ql);
+            const int ql = (op == C3R_CIG_M || op == C3R_CIG_I || op == C3R_CIG_S) ? len : 0;   // (segments hold no N ops)
+            const int rincl = grp_incl_scan(rl);
+            const int qincl = grp_incl_scan(ql);
             const int rstart = rd.pos + ref_carry + rincl - rl;
             const int qstart = q_carry + qincl - ql;
-            int prev = __shfl_up(op, 1, 64);
+            int prev = __shfl_up(op, 1, GRP);
             if (lane == 0) prev = prev_carry;
 
-            if (op == C3R_CIG_M) {
+            if (op == C3R_CIG_M && MODE != SCATTER) {
                 const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
-                for (int p = b0; p < b1; ++p) {
-                    const int code = base_code(a.seq, rd.seq_off, (uint32_t)(qstart + (p - rstart)), rd.l_seq);
-                    const int bi = acgt_index(code);
-                    if (bi >= 0) {
-                        const int pl = p - t0;
+                // 8 bases per round: the 8 byte loads are independent, so they are all in flight before the first
+                // LDS atomic (one latency per 8 bases instead of one per base)
+                for (int pb = b0; pb < b1; pb += 8) {
+                    int code[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        code[u] = (pb + u < b1) ? base_code(a.seq, rd.seq_off, (uint32_t)(qstart + (pb + u - rstart)), rd.l_seq) : 0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int bi = acgt_index(code[u]);
+                        if (bi < 0) continue;
+                        const int pl = pb + u - t0;
                         if (MODE == ACCUM) {
                             atomicAdd(&s.cnt[pl * C + (rev ? 9 + bi : bi)], 1);
                             if (C == C3R_CH_PHASED) {
@@ -238,9 +307,9 @@ __device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, 
                     }
                 }
             }
-            ref_carry += __shfl(rincl, 63, 64);
-            q_carry += __shfl(qincl, 63, 64);
-            prev_carry = __shfl(op, 63, 64);
+            ref_carry += __shfl(rincl, GRP - 1, GRP);
+            q_carry += __shfl(qincl, GRP - 1, GRP);
+            prev_carry = __shfl(op, GRP - 1, GRP);
             // '>' not '>=': an I/D op starting exactly at t1 is attached to column t1-1, which is ours
             if (rd.pos + ref_carry > t1) break;
         }
@@ -271,6 +340,24 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wave_tot /* LDS [WAVE
     return base + incl - v;
 }
 
+// One thread per tile: the four binary searches that bound the tile's reads and segments.  Done here, thousands at a
+// time, instead of by one lane at the head of every tile workgroup (64 dependent global loads = tens of microseconds
+// of pure latency per tile).  Tiles that no read span covers are dropped from the work list.
+__global__ void k_tile_ranges(const ScanArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_tiles) return;
+    const int t0 = a.reg_beg0 + t * TILE;
+    const int t1 = min(t0 + TILE, a.reg_end0);
+    int4 r;
+    r.x = upper_bound_gt(a.prefmax_end, a.n_reads, t0);
+    r.y = lower_bound_pos(a.reads, a.n_reads, t1);
+    if (r.x >= r.y) return;
+    r.z = upper_bound_gt(a.seg_prefmax, a.n_segs, t0);
+    r.w = lower_bound_seg(a.segs, a.n_segs, t1);
+    a.tile_rng[t] = r;
+    a.tile_list[atomicAdd(a.n_tile_list, 1)] = t;
+}
+
 template <int C>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     __shared__ int32_t s_cnt[TILE * C];
@@ -284,25 +371,53 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     __shared__ unsigned long long s_evbase;
 
     const int tid = threadIdx.x;
-    const int t0 = a.reg_beg0 + (int)blockIdx.x * TILE;
+    if ((int)blockIdx.x >= *a.n_tile_list) return;          // the grid is sized for the worst case
+    const int tile = a.tile_list[blockIdx.x];
+    const int t0 = a.reg_beg0 + tile * TILE;
     const int t1 = min(t0 + TILE, a.reg_end0);
-    if (tid == 0) {
-        // reads that can overlap [t0,t1): index range [lo,hi)
-        s_misc[0] = upper_bound_gt(a.prefmax_end, a.n_reads, t0);
-        s_misc[1] = lower_bound_pos(a.reads, a.n_reads, t1);
-    }
-    __syncthreads();
-    const int lo = s_misc[0], hi = s_misc[1];
-    if (lo >= hi) return;   // nothing covers this tile: flags stay 0 (pre-cleared)
+    const int4 rng = a.tile_rng[tile];
+    if ((a.abl & 16) && rng.z >= rng.w) return;   // ablation: skip intron-only tiles
+    if ((a.abl & 32) && rng.z < rng.w) return;    // ablation: skip tiles with aligned bases
+    const int lo = rng.x, hi = rng.y;       // reads whose span can overlap [t0,t1)
+    const int slo = rng.z, shi = rng.w;     // aligned segments that can touch it
 
     TileLds s{s_cnt, s_cov, s_evoff, s_evfill, s_maxdel, s_first, s_amb};
+    s_cov[tid] = 0; if (tid == 0) s_cov[TILE] = 0;
+    if (slo >= shi) {
+        // intron-only tile: rows exist (ref-skip columns) but every count is zero.  Only the flags are written; the
+        // gather treats the columns of such a tile as zeros (tile_cols stays 0).
+        __syncthreads();
+        cover_reads(a, s, lo, hi, t0, t1);
+        __syncthreads();
+        int tot;
+        const int d = s_cov[tid];
+        const int cov = block_excl_scan(d, &s_misc[2], &tot) + d;
+        const int p = t0 + tid;
+        bool is_row = false;
+        if (p < t1 && cov > 0) is_row = !a.has_lbed || intervals_overlap(a.lbed, a.n_lbed, p, p + 1);
+        if (p < t1) {
+            const int gi = p - a.reg_beg0;
+            a.depth[gi] = 0; a.ncov[gi] = is_row ? cov : 0;
+            bool cand = false;
+            if (is_row && a.genotyping) cand = sorted_contains(a.sites, a.n_sites, p + 1);
+            a.flags[gi] = (uint8_t)((is_row ? 1 : 0) | (cand ? 2 : 0));
+        }
+        if (a.head_tail) {
+            int mx = is_row ? p : -1;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+            // racy pre-check is safe (the value only grows) and keeps ~10^5 tiles from serialising on one L2 atomic
+            if ((tid & 63) == 0 && mx > *(volatile int32_t *)a.last_row) atomicMax(a.last_row, mx);
+        }
+        return;
+    }
     for (int i = tid; i < TILE * C; i += SCAN_THREADS) s_cnt[i] = 0;
     for (int i = tid; i < TILE * 6; i += SCAN_THREADS) s_first[i] = 0xffffffffu;
-    s_cov[tid] = 0; if (tid == 0) s_cov[TILE] = 0;
     s_evfill[tid] = 0; s_maxdel[tid] = 0; s_amb[tid] = 0;
     __syncthreads();
 
-    walk_reads<C, ACCUM>(a, s, lo, hi, t0, t1, 0ull);
+    if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1);
+    if (!(a.abl & 1)) walk_reads<C, ACCUM>(a, s, slo, shi, t0, t1, 0ull);
     __syncthreads();
 
     // coverage: inclusive scan of the difference array; indel events: exclusive scan of per-position counts
@@ -316,11 +431,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     int ev_total;
     const int ev_ex = block_excl_scan(nev, wave_tot, &ev_total);
     s_evoff[tid] = ev_ex;
-    if (ev_total > 0) {
+    if (ev_total > 0 && !(a.abl & 2)) {
         if (tid == 0) s_evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
         __syncthreads();
         const unsigned long long evb = s_evbase;
-        walk_reads<C, SCATTER>(a, s, lo, hi, t0, t1, evb);
+        walk_reads<C, SCATTER>(a, s, slo, shi, t0, t1, evb);
         __threadfence_block();
         __syncthreads();
         // max multiplicity of one allele per (position, channel): I1 / i1 / D1 / d1
@@ -394,7 +509,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     }
     s_amb[tid] = ambiguous ? 1 : 0;
     if (__syncthreads_or(ambiguous ? 1 : 0)) {
-        walk_reads<C, FIRSTSEEN>(a, s, lo, hi, t0, t1, 0ull);
+        walk_reads<C, FIRSTSEEN>(a, s, slo, shi, t0, t1, 0ull);
         __syncthreads();
         if (ambiguous) {
             int m = 0;
@@ -411,18 +526,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     // ---- write the tile: columns coalesced, then per-position metadata
     const int npos = t1 - t0;
     int32_t *gcol = a.cols + (size_t)(t0 - a.reg_beg0) * C;
+    if (!(a.abl & 8))
     for (int i = tid; i < npos * C; i += SCAN_THREADS) gcol[i] = s_cnt[i];
+    if (tid == 0) a.tile_cols[tile] = 1;
     if (p < t1) {
         const int gi = p - a.reg_beg0;
         a.depth[gi] = depth;
         a.ncov[gi] = is_row ? my_cov : 0;
         a.flags[gi] = (uint8_t)((is_row ? 1 : 0) | (cand ? 2 : 0));
     }
-    const int lastp = is_row ? p : -1;
-    int mx = lastp;
+    if (a.head_tail) {
+        int mx = is_row ? p : -1;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
-    if ((tid & 63) == 0 && mx >= 0) atomicMax(a.last_row, mx);
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+        if ((tid & 63) == 0 && mx > *(volatile int32_t *)a.last_row) atomicMax(a.last_row, mx);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -512,7 +630,7 @@ __global__ __launch_bounds__(CMP_THREADS) void k_compact_write(const uint8_t *fl
 // run when head_tail), applies the A5 rescale (clair3_rna/utils.py:88-92: tensor / (depth/144) in
 // float64, truncated toward zero by the int32 store) and writes the site record.
 struct GatherArgs {
-    const int32_t *cols; const int32_t *depth; const int32_t *ncov; const uint8_t *flags;
+    const int32_t *cols; const int32_t *depth; const int32_t *ncov; const uint8_t *flags; const uint8_t *tile_cols;
     const int32_t *cand_idx; int32_t n_cand; int32_t n_pos; int32_t reg_beg0;
     const uint8_t *ref; int32_t ref_beg0; int32_t ref_len;
     int32_t head_tail; const int32_t *last_row;
@@ -543,7 +661,7 @@ __global__ __launch_bounds__(256) void k_gather(const GatherArgs g) {
     for (int i = lane; i < C3R_WINDOW * C; i += 64) {
         const int q = first + i / C;
         int v = 0;
-        if (q >= lo_valid && q <= hi_valid) v = g.cols[(size_t)q * C + (i % C)];
+        if (q >= lo_valid && q <= hi_valid && g.tile_cols[q / TILE]) v = g.cols[(size_t)q * C + (i % C)];
         if (scale) v = (int32_t)((double)v / sf);
         out[i] = v;
     }
