@@ -34,7 +34,7 @@ class C3RError(RuntimeError):
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
            "c3r_pileup_scan", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
-           "c3r_weight_count", "c3r_load_weights", "c3r_infer", "c3r_set_profiling", "c3r_reset_kernel_stats",
+           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_infer", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
 _lib = None
@@ -78,6 +78,7 @@ def load_library():
     L.c3r_weight_count.argtypes = [i32]
     L.c3r_weight_count.restype = i64
     L.c3r_load_weights.argtypes = [vp, vp, i64, i32]
+    L.c3r_set_precision.argtypes = [vp, i32]
     L.c3r_infer.argtypes = [vp, vp, i64, vp]
     L.c3r_set_profiling.argtypes = [vp, i32]
     L.c3r_reset_kernel_stats.argtypes = [vp]
@@ -204,6 +205,10 @@ class Engine(object):
         channels = channels or self.params.channels
         w = np.ascontiguousarray(blob, dtype=np.float32)
         self._chk(self.L.c3r_load_weights(self.h, _ptr(w), w.size, channels))
+
+    def set_precision(self, mode):
+        """'f32' (fp32 MFMA) or 'f16x3' (split-f16, fp32-equivalent; default)."""
+        self._chk(self.L.c3r_set_precision(self.h, {"f32": 0, "f16x3": 1}[mode]))
 
     def infer(self, tensors=None, n=None, fetch=True):
         if tensors is None:

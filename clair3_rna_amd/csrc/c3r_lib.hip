@@ -630,6 +630,12 @@ int c3r_load_weights(c3r_ctx *ctx, const float *blob, int64_t n_floats, int chan
     return C3R_OK;
 }
 
+int c3r_set_precision(c3r_ctx *ctx, int mode) {
+    if (!ctx || (mode != 0 && mode != 1)) return C3R_EINVAL;
+    ctx->net.precision = mode;
+    return C3R_OK;
+}
+
 int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
     if (!ctx || n < 0) return C3R_EINVAL;
     if (!ctx->net.loaded) return fail(ctx, C3R_EINVAL, "c3r_load_weights must be called before c3r_infer");

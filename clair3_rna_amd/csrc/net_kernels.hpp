@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <cstring>
 #include <functional>
 #include <string>
 #include <vector>
@@ -227,6 +228,264 @@ __global__ __launch_bounds__(256, (SB == 1 ? 2 : 1)) void k_lstm(const void *__r
     }
 }
 
+// ================================================================================================
+// Split-f16 path ("f16x3"): fp32-equivalent GEMMs on the f16 matrix pipe (16x the f32 MFMA rate).
+// Every fp32 operand v is carried as two halves v = hi + lo (hi = f16(v), lo = f16(v - hi): 22 significand bits)
+// and every product is evaluated as  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi  with fp32 accumulation inside
+// v_mfma_f32_32x32x16_f16; the dropped lo*lo term is 2^-22 relative.  Weights are pre-scaled by 2^12 at pack time so
+// that their lo halves stay normal f16 numbers; the scale is undone for free inside the gate math.  3 MFMAs of 32
+// cycles replace 8 MFMAs of 64 cycles per 16 k's: 5.3x less matrix-pipe time at the same 1e-4 probability bar
+// (tests/test_gpu_parity.py compares both paths with the fp32 oracle).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr float WSCALE_LOG2 = 12.0f;
+constexpr float WSCALE = 4096.0f;
+constexpr float WUNSCALE = 1.0f / 4096.0f;
+
+__device__ __forceinline__ float sigmoid_scaled(float acc) {   // sigmoid(acc * 2^-12)
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((-1.4426950408889634f * WUNSCALE) * acc));
+}
+__device__ __forceinline__ float tanh_scaled(float acc) {      // tanh(acc * 2^-12)
+    return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((-2.8853900817779268f * WUNSCALE) * acc)), -1.0f);
+}
+
+// Fused bidirectional LSTM layer on split-f16 operands.  Same decomposition as k_lstm (32-row gate blocks permuted for
+// a lane-local cell update, SB 32-site blocks per wavefront, h double-buffered in LDS, one barrier per step), with
+//   Wp : [dir][wave][g][tile][hi|lo][64 lanes] half8  (k-groups of 16; lane half hh owns k = 16g + 8hh + 0..7)
+//   xin: INT_IN ? int32 [n][33][CIN] (exact in f16, lo = 0)  :  hi plane then lo plane, each f16 [n][33][CIN]
+//   y  : hi plane then lo plane, each f16 [n][33][2H]
+template <int INP, int CIN, int H, bool INT_IN, int SB = 2, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin, const half8 *__restrict__ Wp,
+                                                    const float *__restrict__ bp, _Float16 *__restrict__ y, int n) {
+    constexpr int NGX = INP / 16;
+    constexpr int NGH = H / 16;
+    constexpr int NG = NGX + NGH;
+    constexpr int HP = H + 8;              // LDS row stride in halves: (H+8)*2 B keeps ds_read_b128 conflict-free
+    constexpr int NBLK = 4 * H / 32;
+    constexpr int NT = NBLK / 4;
+    constexpr int WG_SITES = 32 * SB;
+    static_assert(INP % 32 == 0 && H % 32 == 0, "shape: even 16-wide k-group counts for the ping-pong pipeline");
+    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][WG_SITES][HP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y;
+    const int site0 = blockIdx.x * WG_SITES;
+    const size_t plane_in = (size_t)n * NET_T * CIN;        // halves per input plane
+    const size_t plane_out = (size_t)n * NET_T * 2 * H;
+
+    const half8 *wl = Wp + ((size_t)(dir * 4 + wave) * NG) * NT * 2 * 64 + lane;
+    float bias_a[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) bias_a[tt] = hh == 0 ? WSCALE * bp[((size_t)dir * NBLK + wave * NT + tt) * 32 + j] : 0.f;
+
+    float cst[NT][SB][4];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cst[tt][sb][q] = 0.f;
+
+    for (int i = tid; i < WG_SITES * HP; i += 256) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
+    __syncthreads();
+
+    size_t xoff[SB];
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb) {
+        int sj = site0 + 32 * sb + j;
+        if (sj >= n) sj = n - 1;
+        xoff[sb] = (size_t)sj * NET_T * CIN;
+    }
+
+    for (int step = 0; step < NET_T; ++step) {
+        const int t = dir ? NET_T - 1 - step : step;
+        const int cur = step & 1, nxt = cur ^ 1;
+
+        auto ldx = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                if (INT_IN) {
+                    const int32_t *xp = (const int32_t *)xin + xoff[sb] + (size_t)t * CIN;
+                    const int k0 = 16 * g + 8 * hh;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bh[sb][e] = (k0 + e < CIN) ? (_Float16)(float)xp[k0 + e] : (_Float16)0.f;
+                } else {
+                    const _Float16 *xp = (const _Float16 *)xin + xoff[sb] + (size_t)t * CIN + 16 * g + 8 * hh;
+                    bh[sb] = *(const half8 *)xp;
+                    bl[sb] = *(const half8 *)(xp + plane_in);
+                }
+            }
+        };
+        auto ldh = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                bh[sb] = *(const half8 *)&hb_hi[cur][32 * sb + j][16 * g + 8 * hh];
+                bl[sb] = *(const half8 *)&hb_lo[cur][32 * sb + j][16 * g + 8 * hh];
+            }
+        };
+        auto ldw = [&](int g, half8 (&ah)[NT], half8 (&al)[NT]) {
+            const half8 *wg = wl + (size_t)((ABL & 1) ? 0 : g) * NT * 2 * 64;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) { ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64]; }
+        };
+
+        floatx16 acc[NT][SB];
+        {
+            floatx16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[tt], 1.0f, z, 0, 0, 0);
+        }
+        // three f16 MFMAs per (tile, site block, k-group): hi*hi, hi*lo, lo*hi  (lo of the int32 pileup input is 0)
+        auto mma = [&](const half8 (&ah)[NT], const half8 (&al)[NT], const half8 (&bh)[SB], const half8 (&bl)[SB], bool xlo) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bh[sb], acc[tt][sb], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tt], bh[sb], acc[tt][sb], 0, 0, 0);
+            if (xlo) {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bl[sb], acc[tt][sb], 0, 0, 0);
+            }
+        };
+        half8 a0h[NT], a0l[NT], a1h[NT], a1l[NT], b0h[SB], b0l[SB], b1h[SB], b1l[SB];
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb) { b0l[sb] = (half8)(_Float16)0.f; b1l[sb] = (half8)(_Float16)0.f; }
+        constexpr bool XLO = !INT_IN;
+#define C3R_FENCE() __builtin_amdgcn_sched_barrier(0)
+        ldw(0, a0h, a0l);
+        ldx(0, b0h, b0l);
+#pragma unroll 1
+        for (int g = 0; g + 2 < NGX; g += 2) {
+            C3R_FENCE(); ldw(g + 1, a1h, a1l); ldx(g + 1, b1h, b1l); C3R_FENCE();
+            mma(a0h, a0l, b0h, b0l, XLO);
+            C3R_FENCE(); ldw(g + 2, a0h, a0l); ldx(g + 2, b0h, b0l); C3R_FENCE();
+            mma(a1h, a1l, b1h, b1l, XLO);
+        }
+        C3R_FENCE(); ldw(NGX - 1, a1h, a1l); ldx(NGX - 1, b1h, b1l); C3R_FENCE();
+        mma(a0h, a0l, b0h, b0l, XLO);
+        C3R_FENCE(); ldw(NGX, a0h, a0l); ldh(0, b0h, b0l); C3R_FENCE();
+        mma(a1h, a1l, b1h, b1l, XLO);
+#pragma unroll 1
+        for (int g = 0; g + 2 < NGH; g += 2) {
+            C3R_FENCE(); ldw(NGX + g + 1, a1h, a1l); ldh(g + 1, b1h, b1l); C3R_FENCE();
+            mma(a0h, a0l, b0h, b0l, true);
+            C3R_FENCE(); ldw(NGX + g + 2, a0h, a0l); ldh(g + 2, b0h, b0l); C3R_FENCE();
+            mma(a1h, a1l, b1h, b1l, true);
+        }
+        C3R_FENCE(); ldw(NG - 1, a1h, a1l); ldh(NGH - 1, b1h, b1l); C3R_FENCE();
+        mma(a0h, a0l, b0h, b0l, true);
+        mma(a1h, a1l, b1h, b1l, true);
+        C3R_FENCE();
+#undef C3R_FENCE
+        // ---- lane-local cell update (acc holds 2^12 * z)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                _Float16 hhi[4], hlo[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float hval;
+                    if (ABL & 2) hval = acc[tt][sb][4 * q] + acc[tt][sb][4 * q + 1] + acc[tt][sb][4 * q + 2] + acc[tt][sb][4 * q + 3];
+                    else {
+                        const float ig = sigmoid_scaled(acc[tt][sb][4 * q + 0]);
+                        const float fg = sigmoid_scaled(acc[tt][sb][4 * q + 1]);
+                        const float gg = tanh_scaled(acc[tt][sb][4 * q + 2]);
+                        const float og = sigmoid_scaled(acc[tt][sb][4 * q + 3]);
+                        const float c = fg * cst[tt][sb][q] + ig * gg;
+                        cst[tt][sb][q] = c;
+                        hval = og * fast_tanh(c);
+                    }
+                    hhi[q] = (_Float16)hval;
+                    hlo[q] = (_Float16)(hval - (float)hhi[q]);
+                }
+                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                half4 vh, vl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { vh[q] = hhi[q]; vl[q] = hlo[q]; }
+                *(half4 *)&hb_hi[nxt][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vh;
+                *(half4 *)&hb_lo[nxt][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vl;
+            }
+        }
+        if (!(ABL & 8)) __syncthreads();
+        // ---- layer output planes y_hi / y_lo [site][t][dir*H + u]: coalesced 16-byte stores (8 halves)
+        constexpr int HV = H / 8;
+        if (!(ABL & 4))
+        for (int f = tid; f < WG_SITES * HV * 2; f += 256) {
+            const int pl = f / (WG_SITES * HV), rem = f % (WG_SITES * HV);
+            const int row = rem / HV, c8 = rem % HV;
+            const int s = site0 + row;
+            if (s < n) {
+                const half8 v = pl ? *(const half8 *)&hb_lo[nxt][row][8 * c8] : *(const half8 *)&hb_hi[nxt][row][8 * c8];
+                *(half8 *)(y + (size_t)pl * plane_out + ((size_t)s * NET_T + t) * (2 * H) + dir * H + 8 * c8) = v;
+            }
+        }
+    }
+}
+
+// L4 on split-f16 operands: a4[n][128] = selu(y2 * W4 + b4), y2 given as hi/lo f16 planes [n][10560].
+// grid = ceil(n / (32*SB4)), block = 256 (wave = 32-row block of output units); B straight from global.
+constexpr int FC4_SB = 4;
+__global__ __launch_bounds__(256) void k_fc4_h(const _Float16 *__restrict__ y2, const half8 *__restrict__ Wp,
+                                               const float *__restrict__ bias, float *__restrict__ a4, int n) {
+    constexpr int NG = NET_FLAT / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int site0 = blockIdx.x * 32 * FC4_SB;
+    const size_t plane = (size_t)n * NET_FLAT;
+    const _Float16 *xr[FC4_SB];
+#pragma unroll
+    for (int sb = 0; sb < FC4_SB; ++sb) {
+        int s = site0 + 32 * sb + j; if (s >= n) s = n - 1;
+        xr[sb] = y2 + (size_t)s * NET_FLAT + 8 * hh;
+    }
+    const half8 *wl = Wp + (size_t)wave * NG * 2 * 64 + lane;
+    floatx16 acc[FC4_SB];
+#pragma unroll
+    for (int sb = 0; sb < FC4_SB; ++sb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
+#pragma unroll 2
+    for (int g = 0; g < NG; ++g) {
+        const half8 ah = wl[(size_t)(g * 2 + 0) * 64], al = wl[(size_t)(g * 2 + 1) * 64];
+        half8 bh[FC4_SB], bl[FC4_SB];
+#pragma unroll
+        for (int sb = 0; sb < FC4_SB; ++sb) { bh[sb] = *(const half8 *)(xr[sb] + 16 * g); bl[sb] = *(const half8 *)(xr[sb] + plane + 16 * g); }
+#pragma unroll
+        for (int sb = 0; sb < FC4_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[sb], acc[sb], 0, 0, 0);
+#pragma unroll
+        for (int sb = 0; sb < FC4_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[sb], acc[sb], 0, 0, 0);
+#pragma unroll
+        for (int sb = 0; sb < FC4_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[sb], acc[sb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int sb = 0; sb < FC4_SB; ++sb) {
+        const int s = site0 + 32 * sb + j;
+        if (s < n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u = 32 * wave + 8 * q + 4 * hh;
+                float4 v;
+                v.x = selu(fmaf(acc[sb][4 * q + 0], WUNSCALE, bias[u + 0]));
+                v.y = selu(fmaf(acc[sb][4 * q + 1], WUNSCALE, bias[u + 1]));
+                v.z = selu(fmaf(acc[sb][4 * q + 2], WUNSCALE, bias[u + 2]));
+                v.w = selu(fmaf(acc[sb][4 * q + 3], WUNSCALE, bias[u + 3]));
+                *(float4 *)(a4 + (size_t)s * NET_L4 + u) = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // L4: a4[n][128] = selu(y2[n][10560] * W4 + b4).  grid = ceil(n/32), block = 256 (wave = 32-row block
 // of output units).  Same transposed MFMA scheme; B operand straight from global (each site row is
@@ -332,6 +591,8 @@ struct NetState {
     float4 *d_w2 = nullptr; float *d_b2 = nullptr;     // packed LSTM2
     float4 *d_w4 = nullptr; float *d_b4 = nullptr;     // packed L4
     float *d_w5 = nullptr, *d_b5 = nullptr, *d_wo = nullptr, *d_bo = nullptr;
+    half8 *d_w1h = nullptr, *d_w2h = nullptr, *d_w4h = nullptr;   // split-f16 packed weights (hi/lo, x 2^12)
+    int precision = 1;            // 0 = fp32 MFMA, 1 = split-f16 (f16x3, fp32-equivalent)
     float *d_y1 = nullptr, *d_y2 = nullptr, *d_a4 = nullptr, *d_probs = nullptr;
     int64_t cap_sites = 0;
 };
@@ -347,9 +608,69 @@ inline int64_t net_weight_count(int C) {
 }
 
 inline void net_free(NetState &s) {
-    void *ptrs[] = {s.d_w1, s.d_b1, s.d_w2, s.d_b2, s.d_w4, s.d_b4, s.d_w5, s.d_b5, s.d_wo, s.d_bo, s.d_y1, s.d_y2, s.d_a4, s.d_probs};
+    void *ptrs[] = {s.d_w1, s.d_b1, s.d_w2, s.d_b2, s.d_w4, s.d_b4, s.d_w5, s.d_b5, s.d_wo, s.d_bo, s.d_y1, s.d_y2, s.d_a4, s.d_probs,
+                    s.d_w1h, s.d_w2h, s.d_w4h};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     s = NetState();
+}
+
+// float -> IEEE binary16 (round to nearest even) and back, host side
+inline uint16_t f2h(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t m = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0));
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t hm = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1u))) ++hm;
+        return (uint16_t)(sign | hm);
+    }
+    uint32_t h = (uint32_t)(e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (uint16_t)(sign | h);
+}
+inline float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int sh = 0; while (!(m & 0x400u)) { m <<= 1; ++sh; } m &= 0x3ffu; x = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | (m << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e - 15 + 127) << 23) | (m << 13);
+    float f; memcpy(&f, &x, 4); return f;
+}
+inline void split_h(float v, uint16_t &hi, uint16_t &lo) { hi = f2h(v); lo = f2h(v - h2f(hi)); }
+
+// Split-f16 packing of one LSTM direction: [wave][g16][tile][hi|lo][lane][8 halves], weights x 2^12.
+inline void pack_lstm_dir_h(const float *Kin, int cin, int inp, const float *R, int H, std::vector<uint16_t> &wp) {
+    const int K = inp + H, NG = K / 16, NBLK = 4 * H / 32, NT = NBLK / 4;
+    wp.assign((size_t)NBLK * NG * 2 * 64 * 8, 0);
+    auto wcat = [&](int k, int col) -> float {
+        if (k < inp) return k < cin ? Kin[(size_t)k * 4 * H + col] : 0.f;
+        return R[(size_t)(k - inp) * 4 * H + col];
+    };
+    for (int blk = 0; blk < NBLK; ++blk)
+        for (int r = 0; r < 32; ++r) {
+            const int q = r >> 3, hh = (r >> 2) & 1, m = r & 3;
+            const int unit = 8 * blk + 4 * hh + q, col = m * H + unit;
+            for (int g = 0; g < NG; ++g)
+                for (int kh = 0; kh < 2; ++kh)
+                    for (int e = 0; e < 8; ++e) {
+                        uint16_t hi, lo;
+                        split_h(WSCALE * wcat(16 * g + 8 * kh + e, col), hi, lo);
+                        const int lane = kh * 32 + r;
+                        const size_t base = ((((size_t)(blk / NT) * NG + g) * NT + (blk % NT)) * 2) * 64;
+                        wp[((base + 0 * 64 + lane) * 8) + e] = hi;
+                        wp[((base + 1 * 64 + lane) * 8) + e] = lo;
+                    }
+        }
 }
 
 // Pack one LSTM direction: Wcat = [K_in (padded to INP rows) ; R] of shape [INP+H][4H] (Keras: [in][4H],
@@ -393,16 +714,27 @@ inline int net_upload(T *&dst, const std::vector<float> &src, hipStream_t st, st
     return C3R_OK;
 }
 
+inline int net_upload_h(half8 *&dst, const std::vector<uint16_t> &src, hipStream_t st, std::string &err) {
+    if (dst) { (void)hipFree(dst); dst = nullptr; }
+    NET_HIP(hipMalloc((void **)&dst, src.size() * 2));
+    NET_HIP(hipMemcpyAsync(dst, src.data(), src.size() * 2, hipMemcpyHostToDevice, st));
+    NET_HIP(hipStreamSynchronize(st));
+    return C3R_OK;
+}
+
 inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::string &err) {
     const float *q = blob;
     const int inp1 = 32;   // padded to an even number of 8-wide k-groups
     std::vector<float> w1, b1, w2, b2, tw, tb;
+    std::vector<uint16_t> w1h, w2h, th;
     for (int d = 0; d < 2; ++d) {
         const float *Kin = q; q += (size_t)C * 4 * NET_H1;
         const float *R = q; q += (size_t)NET_H1 * 4 * NET_H1;
         const float *b = q; q += 4 * NET_H1;
         pack_lstm_dir(Kin, C, inp1, R, b, NET_H1, tw, tb);
         w1.insert(w1.end(), tw.begin(), tw.end()); b1.insert(b1.end(), tb.begin(), tb.end());
+        pack_lstm_dir_h(Kin, C, inp1, R, NET_H1, th);
+        w1h.insert(w1h.end(), th.begin(), th.end());
     }
     for (int d = 0; d < 2; ++d) {
         const float *Kin = q; q += (size_t)2 * NET_H1 * 4 * NET_H2;
@@ -410,6 +742,8 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
         const float *b = q; q += 4 * NET_H2;
         pack_lstm_dir(Kin, 2 * NET_H1, 2 * NET_H1, R, b, NET_H2, tw, tb);
         w2.insert(w2.end(), tw.begin(), tw.end()); b2.insert(b2.end(), tb.begin(), tb.end());
+        pack_lstm_dir_h(Kin, 2 * NET_H1, 2 * NET_H1, R, NET_H2, th);
+        w2h.insert(w2h.end(), th.begin(), th.end());
     }
     const float *W4 = q; q += (size_t)NET_FLAT * NET_L4;
     const float *b4 = q; q += NET_L4;
@@ -427,6 +761,20 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
                     const int r = lane & 31, kh = lane >> 5;
                     w4[(((size_t)blk * NG4 + g) * 64 + lane) * 4 + sidx] = W4[(size_t)(8 * g + 4 * kh + sidx) * NET_L4 + 32 * blk + r];
                 }
+    // L4 split-f16: [blk(4)][g16][hi|lo][lane][8]
+    const int NG4h = NET_FLAT / 16;
+    std::vector<uint16_t> w4h((size_t)4 * NG4h * 2 * 64 * 8);
+    for (int blk = 0; blk < 4; ++blk)
+        for (int g = 0; g < NG4h; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int r = lane & 31, kh = lane >> 5;
+                    uint16_t hi, lo;
+                    split_h(WSCALE * W4[(size_t)(16 * g + 8 * kh + e) * NET_L4 + 32 * blk + r], hi, lo);
+                    const size_t base = (((size_t)blk * NG4h + g) * 2) * 64;
+                    w4h[(base + lane) * 8 + e] = hi;
+                    w4h[(base + 64 + lane) * 8 + e] = lo;
+                }
     std::vector<float> vb4(b4, b4 + NET_L4);
     std::vector<float> w5((size_t)128 * 256), b5(256), wo((size_t)128 * 24), bo(24);
     for (int k = 0; k < 128; ++k)
@@ -442,7 +790,8 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
     if ((rc = net_upload(s.d_w1, w1, st, err)) || (rc = net_upload(s.d_b1, b1, st, err)) || (rc = net_upload(s.d_w2, w2, st, err)) ||
         (rc = net_upload(s.d_b2, b2, st, err)) || (rc = net_upload(s.d_w4, w4, st, err)) || (rc = net_upload(s.d_b4, vb4, st, err)) ||
         (rc = net_upload(s.d_w5, w5, st, err)) || (rc = net_upload(s.d_b5, b5, st, err)) || (rc = net_upload(s.d_wo, wo, st, err)) ||
-        (rc = net_upload(s.d_bo, bo, st, err)))
+        (rc = net_upload(s.d_bo, bo, st, err)) || (rc = net_upload_h(s.d_w1h, w1h, st, err)) || (rc = net_upload_h(s.d_w2h, w2h, st, err)) ||
+        (rc = net_upload_h(s.d_w4h, w4h, st, err)))
         return rc;
     s.channels = C; s.inp1 = inp1; s.loaded = true;
     return C3R_OK;
@@ -469,6 +818,26 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
     if (rc) return rc;
     const int nb = (int)((n + NET_SITES - 1) / NET_SITES);
     const dim3 grid((unsigned)((n + LSTM_SITES - 1) / LSTM_SITES), 2), block(256);
+    if (s.precision == 1) {
+        // split-f16 path: y1 / y2 hold hi and lo f16 planes (same bytes as one fp32 plane)
+        _Float16 *y1h = (_Float16 *)s.d_y1, *y2h = (_Float16 *)s.d_y2;
+        prof("k_lstm1", 0);
+        if (s.channels == C3R_CH)
+            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH, NET_H1, true, LSTM_SB>), grid, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
+                               (const float *)s.d_b1, y1h, (int)n);
+        else
+            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH_PHASED, NET_H1, true, LSTM_SB>), grid, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
+                               (const float *)s.d_b1, y1h, (int)n);
+        prof("k_lstm1", 1);
+        prof("k_lstm2", 0);
+        hipLaunchKernelGGL((k_lstm_h<2 * NET_H1, 2 * NET_H1, NET_H2, false, LSTM_SB>), grid, block, 0, st, (const void *)y1h,
+                           (const half8 *)s.d_w2h, (const float *)s.d_b2, y2h, (int)n);
+        prof("k_lstm2", 1);
+        prof("k_fc4", 0);
+        hipLaunchKernelGGL(k_fc4_h, dim3((unsigned)((n + 32 * FC4_SB - 1) / (32 * FC4_SB))), block, 0, st, (const _Float16 *)y2h,
+                           (const half8 *)s.d_w4h, (const float *)s.d_b4, s.d_a4, (int)n);
+        prof("k_fc4", 1);
+    } else {
     prof("k_lstm1", 0);
     if (s.channels == C3R_CH) {
         constexpr int INP = 32;
@@ -490,6 +859,7 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
     prof("k_fc4", 0);
     hipLaunchKernelGGL(k_fc4, dim3(nb), block, 0, st, (const float *)s.d_y2, (const float4 *)s.d_w4, (const float *)s.d_b4, s.d_a4, (int)n);
     prof("k_fc4", 1);
+    }
     prof("k_heads", 0);
     hipLaunchKernelGGL(k_heads, dim3((unsigned)((n + HEAD_SITES - 1) / HEAD_SITES)), block, 0, st, (const float *)s.d_a4, (const float *)s.d_w5,
                        (const float *)s.d_b5, (const float *)s.d_wo, (const float *)s.d_bo, s.d_probs, (int)n);

@@ -108,6 +108,10 @@ int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t
  * `channels` is 18 or 30 and must match c3r_set_params. */
 int c3r_load_weights(c3r_ctx *ctx, const float *blob, int64_t n_floats, int channels);
 int64_t c3r_weight_count(int channels);
+/* Arithmetic of the network GEMMs: 0 = fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32); 1 (default) = split-f16:
+ * every fp32 operand carried as hi + lo halves, products hi*hi + hi*lo + lo*hi accumulated in fp32 on the f16 matrix
+ * pipe (fp32-equivalent: both modes meet the 1e-4 probability tolerance against the fp32 oracle). */
+int c3r_set_precision(c3r_ctx *ctx, int mode);
 /* Forward pass over tensors.  tensors==NULL: use the device-resident tensors of the last scan.
  * Otherwise `tensors` is a host int32 [n][33][C] array.  probs (host, [n][24]) may be NULL to keep
  * the result on the device only.  Replaces m.predict_on_batch (clair3_rna/call_variants.py:1505). */

@@ -167,6 +167,28 @@ def test_network_probabilities(eng):
     assert np.allclose(p_resident[:, :21].sum(1), 1, atol=1e-5) and np.allclose(p_resident[:, 21:].sum(1), 1, atol=1e-5)
 
 
+def test_network_both_precisions_meet_tolerance(eng):
+    """fp32 MFMA and split-f16 (f16x3) GEMMs against the fp32 oracle: both within the 1e-4 bar, on pileup tensors and on
+    large-magnitude random inputs (|x| up to 216 is the post-rescale bound of clair3_rna/utils.py:88-92)."""
+    from clair3_rna_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.RandomState(11)
+    worst = {}
+    for C, wseed in ((18, 1234), (30, 99)):
+        w = synth.random_weights(C, seed=wseed)
+        X = np.concatenate([rng.randint(-216, 217, size=(40, 33, C)), rng.randint(-20, 21, size=(60, 33, C)),
+                            np.zeros((3, 33, C), int)]).astype(np.int32)
+        po = orc.forward(w, X)
+        eng.load_weights(w, C)
+        for mode in ("f32", "f16x3"):
+            eng.set_precision(mode)
+            p = eng.infer(tensors=X)
+            worst[(C, mode)] = float(np.abs(p - po).max())
+            assert worst[(C, mode)] < 1e-4, worst
+    eng.set_precision("f16x3")
+    print("max |dP| per (channels, precision):", worst)
+
+
 def test_network_30ch_and_ragged_batch(eng):
     from clair3_rna_amd import synth
     from oracle import oracle as orc
