@@ -253,9 +253,15 @@ __device__ __forceinline__ float tanh_scaled(float acc) {      // tanh(acc * 2^-
 //   Wp : [dir][wave][g][tile][hi|lo][64 lanes] half8  (k-groups of 16; lane half hh owns k = 16g + 8hh + 0..7)
 //   xin: INT_IN ? int32 [n][33][CIN] (exact in f16, lo = 0)  :  hi plane then lo plane, each f16 [n][33][CIN]
 //   y  : hi plane then lo plane, each f16 [n][33][2H]
-template <int INP, int CIN, int H, bool INT_IN, int SB = 2, int ABL = 0>
+// FC4 (layer 2 only): the flatten + Dense(128) layer L4 is fused in.  After every step the fresh h_t (already in LDS as
+// hi/lo halves) is multiplied by the [160 x 128] slice of W4 that belongs to (t, direction) and accumulated in
+// persistent registers; y2 is never written.  Each workgroup ends by storing its [sites][128] partial pre-activation
+// for its direction; k_heads adds the two directions and the bias and applies selu.
+//   W4p: [dir][t][blk(4)][g(H/16)][hi|lo][64 lanes] half8, x 2^12;   a4part: fp32 [n][2][128]
+template <int INP, int CIN, int H, bool INT_IN, int SB = 2, int ABL = 0, bool FC4 = false>
 __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin, const half8 *__restrict__ Wp,
-                                                    const float *__restrict__ bp, _Float16 *__restrict__ y, int n) {
+                                                    const float *__restrict__ bp, _Float16 *__restrict__ y, int n,
+                                                    const half8 *__restrict__ W4p = nullptr, float *__restrict__ a4part = nullptr) {
     constexpr int NGX = INP / 16;
     constexpr int NGH = H / 16;
     constexpr int NG = NGX + NGH;
@@ -266,6 +272,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
     static_assert(INP % 32 == 0 && H % 32 == 0, "shape: even 16-wide k-group counts for the ping-pong pipeline");
     __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
     __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][WG_SITES][HP];
+    // cell state: registers, or LDS in the FC4 variant (its persistent L4 accumulators need the registers)
+    constexpr int CP = H + 4;
+    __shared__ __attribute__((aligned(16))) float cbuf[FC4 ? WG_SITES : 1][FC4 ? CP : 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
@@ -279,13 +288,22 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) bias_a[tt] = hh == 0 ? WSCALE * bp[((size_t)dir * NBLK + wave * NT + tt) * 32 + j] : 0.f;
 
-    float cst[NT][SB][4];
+    float cst[FC4 ? 1 : NT][SB][4];
+    if (!FC4) {
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
+        for (int tt = 0; tt < (FC4 ? 1 : NT); ++tt)
 #pragma unroll
-        for (int sb = 0; sb < SB; ++sb)
+            for (int sb = 0; sb < SB; ++sb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cst[tt][sb][q] = 0.f;
+                for (int q = 0; q < 4; ++q) cst[tt][sb][q] = 0.f;
+    } else {
+        for (int i = tid; i < WG_SITES * CP; i += 256) (&cbuf[0][0])[i] = 0.f;
+    }
+    floatx16 facc[FC4 ? SB : 1];
+#pragma unroll
+    for (int sb = 0; sb < (FC4 ? SB : 1); ++sb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) facc[sb][r] = 0.f;
 
     for (int i = tid; i < WG_SITES * HP; i += 256) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
     __syncthreads();
@@ -393,21 +411,43 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
 #pragma unroll
             for (int sb = 0; sb < SB; ++sb) {
                 _Float16 hhi[4], hlo[4];
+                float cq[4];
+                float *crow = &cbuf[FC4 ? 32 * sb + j : 0][FC4 ? 8 * (wave * NT + tt) + 4 * hh : 0];
+                if (FC4) { const float4 cv = *(const float4 *)crow; cq[0] = cv.x; cq[1] = cv.y; cq[2] = cv.z; cq[3] = cv.w; }
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cq[q] = cst[FC4 ? 0 : tt][sb][q];
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float hval;
                     if (ABL & 2) hval = acc[tt][sb][4 * q] + acc[tt][sb][4 * q + 1] + acc[tt][sb][4 * q + 2] + acc[tt][sb][4 * q + 3];
                     else {
-                        const float ig = sigmoid_scaled(acc[tt][sb][4 * q + 0]);
-                        const float fg = sigmoid_scaled(acc[tt][sb][4 * q + 1]);
-                        const float gg = tanh_scaled(acc[tt][sb][4 * q + 2]);
-                        const float og = sigmoid_scaled(acc[tt][sb][4 * q + 3]);
-                        const float c = fg * cst[tt][sb][q] + ig * gg;
-                        cst[tt][sb][q] = c;
-                        hval = og * fast_tanh(c);
+                        // i,f,g,o from acc = 2^12 z.  With e_x = exp(-z_x) (e_g = exp(-2 z_g)):
+                        //   sigmoid(i) * tanh(g) = (1 - e_g) / ((1 + e_i)(1 + e_g))      -> one reciprocal for the pair
+                        //   o * tanh(c)          = (1 - e_c) / ((1 + e_o)(1 + e_c))      -> one reciprocal for the pair
+                        // 5 exp2 + 3 rcp per unit instead of 5 + 5 (quarter-rate ops dominate the cell update).
+                        constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
+                        const float ei = __builtin_amdgcn_exp2f(K1 * acc[tt][sb][4 * q + 0]);
+                        const float ef = __builtin_amdgcn_exp2f(K1 * acc[tt][sb][4 * q + 1]);
+                        const float eg = __builtin_amdgcn_exp2f(K2 * acc[tt][sb][4 * q + 2]);
+                        const float eo = __builtin_amdgcn_exp2f(K1 * acc[tt][sb][4 * q + 3]);
+                        // clamp keeps (1+e)(1+e) finite when a gate saturates (e -> inf): the quotient limit is still exact
+                        const float eic = fminf(ei, 1e18f), egc = fminf(eg, 1e18f), eoc = fminf(eo, 1e18f);
+                        const float ig_gg = (1.0f - egc) * __builtin_amdgcn_rcpf((1.0f + eic) * (1.0f + egc));
+                        const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
+                        const float c = fmaf(fg, cq[q], ig_gg);
+                        cq[q] = c;
+                        const float ec = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * c), 1e18f);
+                        hval = (1.0f - ec) * __builtin_amdgcn_rcpf((1.0f + eoc) * (1.0f + ec));
                     }
                     hhi[q] = (_Float16)hval;
                     hlo[q] = (_Float16)(hval - (float)hhi[q]);
+                }
+                if (FC4) *(float4 *)crow = make_float4(cq[0], cq[1], cq[2], cq[3]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cst[FC4 ? 0 : tt][sb][q] = cq[q];
                 }
                 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
                 half4 vh, vl;
@@ -418,9 +458,25 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
             }
         }
         if (!(ABL & 8)) __syncthreads();
+        if (FC4) {
+            // ---- fused L4: facc[sb] += W4[t, dir][32 rows of this wave] x h_t^T   (K = H, B operand = h_t in LDS)
+            const half8 *w4 = W4p + (((size_t)(dir * NET_T + t) * 4 + wave) * NGH) * 2 * 64 + lane;
+#pragma unroll 2
+            for (int g = 0; g < NGH; ++g) {
+                const half8 ah = w4[(size_t)(g * 2 + 0) * 64], al = w4[(size_t)(g * 2 + 1) * 64];
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+                    const half8 bh = *(const half8 *)&hb_hi[nxt][32 * sb + j][16 * g + 8 * hh];
+                    const half8 bl = *(const half8 *)&hb_lo[nxt][32 * sb + j][16 * g + 8 * hh];
+                    facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, facc[sb], 0, 0, 0);
+                    facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, facc[sb], 0, 0, 0);
+                    facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, facc[sb], 0, 0, 0);
+                }
+            }
+        }
         // ---- layer output planes y_hi / y_lo [site][t][dir*H + u]: coalesced 16-byte stores (8 halves)
         constexpr int HV = H / 8;
-        if (!(ABL & 4))
+        if (!(ABL & 4) && !FC4)
         for (int f = tid; f < WG_SITES * HV * 2; f += 256) {
             const int pl = f / (WG_SITES * HV), rem = f % (WG_SITES * HV);
             const int row = rem / HV, c8 = rem % HV;
@@ -428,6 +484,20 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
             if (s < n) {
                 const half8 v = pl ? *(const half8 *)&hb_lo[nxt][row][8 * c8] : *(const half8 *)&hb_hi[nxt][row][8 * c8];
                 *(half8 *)(y + (size_t)pl * plane_out + ((size_t)s * NET_T + t) * (2 * H) + dir * H + 8 * c8) = v;
+            }
+        }
+    }
+    if (FC4) {
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb) {
+            const int sidx = site0 + 32 * sb + j;
+            if (sidx < n) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = make_float4(facc[sb][4 * q] * WUNSCALE, facc[sb][4 * q + 1] * WUNSCALE, facc[sb][4 * q + 2] * WUNSCALE,
+                                           facc[sb][4 * q + 3] * WUNSCALE);
+                    *(float4 *)(a4part + ((size_t)sidx * 2 + dir) * NET_L4 + 32 * wave + 8 * q + 4 * hh) = v;
+                }
             }
         }
     }
@@ -535,7 +605,9 @@ __global__ __launch_bounds__(256) void k_fc4(const float *__restrict__ y2, const
 // Heads: L5_1 / L5_2 (128->128 selu each), Y_gt21 (128->21) / Y_genotype (128->3) with selu THEN
 // softmax (clair3_rna/model.py:150-152,196-198).  0.15 % of the flops: plain VALU, 8 sites per block.
 constexpr int HEAD_SITES = 8;
-__global__ __launch_bounds__(256) void k_heads(const float *__restrict__ a4, const float *__restrict__ w5 /* [128][256] */,
+// parts == 2: a4 is [n][2][128] partial pre-activations of L4 (one per LSTM direction): a4 = selu(p0 + p1 + b4).
+__global__ __launch_bounds__(256) void k_heads(const float *__restrict__ a4, int parts, const float *__restrict__ b4,
+                                               const float *__restrict__ w5 /* [128][256] */,
                                                const float *__restrict__ b5 /* [256] */, const float *__restrict__ wo /* [128][24] */,
                                                const float *__restrict__ bo /* [24] */, float *__restrict__ probs, int n) {
     __shared__ float s_a4[HEAD_SITES][128];
@@ -544,8 +616,10 @@ __global__ __launch_bounds__(256) void k_heads(const float *__restrict__ a4, con
     const int tid = threadIdx.x;
     const int site0 = blockIdx.x * HEAD_SITES;
     for (int i = tid; i < HEAD_SITES * 128; i += 256) {
-        const int s = site0 + i / 128;
-        s_a4[i / 128][i % 128] = s < n ? a4[(size_t)s * 128 + (i % 128)] : 0.f;
+        const int s = site0 + i / 128, u = i % 128;
+        float v = 0.f;
+        if (s < n) v = parts == 2 ? selu(a4[((size_t)s * 2) * 128 + u] + a4[((size_t)s * 2 + 1) * 128 + u] + b4[u]) : a4[(size_t)s * 128 + u];
+        s_a4[i / 128][u] = v;
     }
     __syncthreads();
     {
@@ -591,7 +665,7 @@ struct NetState {
     float4 *d_w2 = nullptr; float *d_b2 = nullptr;     // packed LSTM2
     float4 *d_w4 = nullptr; float *d_b4 = nullptr;     // packed L4
     float *d_w5 = nullptr, *d_b5 = nullptr, *d_wo = nullptr, *d_bo = nullptr;
-    half8 *d_w1h = nullptr, *d_w2h = nullptr, *d_w4h = nullptr;   // split-f16 packed weights (hi/lo, x 2^12)
+    half8 *d_w1h = nullptr, *d_w2h = nullptr, *d_w4h = nullptr, *d_w4f = nullptr;   // d_w4f: L4 packed per (dir, t) for the fused path   // split-f16 packed weights (hi/lo, x 2^12)
     int precision = 1;            // 0 = fp32 MFMA, 1 = split-f16 (f16x3, fp32-equivalent)
     float *d_y1 = nullptr, *d_y2 = nullptr, *d_a4 = nullptr, *d_probs = nullptr;
     int64_t cap_sites = 0;
@@ -609,7 +683,7 @@ inline int64_t net_weight_count(int C) {
 
 inline void net_free(NetState &s) {
     void *ptrs[] = {s.d_w1, s.d_b1, s.d_w2, s.d_b2, s.d_w4, s.d_b4, s.d_w5, s.d_b5, s.d_wo, s.d_bo, s.d_y1, s.d_y2, s.d_a4, s.d_probs,
-                    s.d_w1h, s.d_w2h, s.d_w4h};
+                    s.d_w1h, s.d_w2h, s.d_w4h, s.d_w4f};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     s = NetState();
 }
@@ -775,6 +849,23 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
                     w4h[(base + lane) * 8 + e] = hi;
                     w4h[(base + 64 + lane) * 8 + e] = lo;
                 }
+    // L4 for the fused LSTM2 epilogue: [dir][t][blk(4)][g(10)][hi|lo][lane][8]; flatten order is [t][fwd 160 | bwd 160]
+    const int NGF = NET_H2 / 16;
+    std::vector<uint16_t> w4f((size_t)2 * NET_T * 4 * NGF * 2 * 64 * 8);
+    for (int d = 0; d < 2; ++d)
+        for (int t = 0; t < NET_T; ++t)
+            for (int blk = 0; blk < 4; ++blk)
+                for (int g = 0; g < NGF; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int r = lane & 31, kh = lane >> 5;
+                            const size_t row = (size_t)t * 2 * NET_H2 + (size_t)d * NET_H2 + 16 * g + 8 * kh + e;
+                            uint16_t hi, lo;
+                            split_h(WSCALE * W4[row * NET_L4 + 32 * blk + r], hi, lo);
+                            const size_t base = ((((size_t)(d * NET_T + t) * 4 + blk) * NGF + g) * 2) * 64;
+                            w4f[(base + lane) * 8 + e] = hi;
+                            w4f[(base + 64 + lane) * 8 + e] = lo;
+                        }
     std::vector<float> vb4(b4, b4 + NET_L4);
     std::vector<float> w5((size_t)128 * 256), b5(256), wo((size_t)128 * 24), bo(24);
     for (int k = 0; k < 128; ++k)
@@ -791,7 +882,7 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
         (rc = net_upload(s.d_b2, b2, st, err)) || (rc = net_upload(s.d_w4, w4, st, err)) || (rc = net_upload(s.d_b4, vb4, st, err)) ||
         (rc = net_upload(s.d_w5, w5, st, err)) || (rc = net_upload(s.d_b5, b5, st, err)) || (rc = net_upload(s.d_wo, wo, st, err)) ||
         (rc = net_upload(s.d_bo, bo, st, err)) || (rc = net_upload_h(s.d_w1h, w1h, st, err)) || (rc = net_upload_h(s.d_w2h, w2h, st, err)) ||
-        (rc = net_upload_h(s.d_w4h, w4h, st, err)))
+        (rc = net_upload_h(s.d_w4h, w4h, st, err)) || (rc = net_upload_h(s.d_w4f, w4f, st, err)))
         return rc;
     s.channels = C; s.inp1 = inp1; s.loaded = true;
     return C3R_OK;
@@ -802,7 +893,7 @@ inline int net_reserve(NetState &s, int64_t n, hipStream_t st, std::string &err)
     const int64_t cap = n + n / 4 + 64;
     NET_HIP(hipStreamSynchronize(st));
     float **bufs[] = {&s.d_y1, &s.d_y2, &s.d_a4, &s.d_probs};
-    const size_t sizes[] = {(size_t)cap * NET_T * 2 * NET_H1, (size_t)cap * NET_T * 2 * NET_H2, (size_t)cap * NET_L4, (size_t)cap * C3R_NPROB};
+    const size_t sizes[] = {(size_t)cap * NET_T * 2 * NET_H1, (size_t)cap * NET_T * 2 * NET_H2, (size_t)cap * NET_L4 * 2, (size_t)cap * C3R_NPROB};
     for (int i = 0; i < 4; ++i) {
         if (*bufs[i]) { (void)hipFree(*bufs[i]); *bufs[i] = nullptr; }
         NET_HIP(hipMalloc((void **)bufs[i], sizes[i] * sizeof(float)));
@@ -818,6 +909,7 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
     if (rc) return rc;
     const int nb = (int)((n + NET_SITES - 1) / NET_SITES);
     const dim3 grid((unsigned)((n + LSTM_SITES - 1) / LSTM_SITES), 2), block(256);
+    int heads_parts = 1;
     if (s.precision == 1) {
         // split-f16 path: y1 / y2 hold hi and lo f16 planes (same bytes as one fp32 plane)
         _Float16 *y1h = (_Float16 *)s.d_y1, *y2h = (_Float16 *)s.d_y2;
@@ -830,13 +922,11 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
                                (const float *)s.d_b1, y1h, (int)n);
         prof("k_lstm1", 1);
         prof("k_lstm2", 0);
-        hipLaunchKernelGGL((k_lstm_h<2 * NET_H1, 2 * NET_H1, NET_H2, false, LSTM_SB>), grid, block, 0, st, (const void *)y1h,
-                           (const half8 *)s.d_w2h, (const float *)s.d_b2, y2h, (int)n);
+        // layer 2 with the L4 dense layer fused in: y2 is never materialised
+        hipLaunchKernelGGL((k_lstm_h<2 * NET_H1, 2 * NET_H1, NET_H2, false, LSTM_SB, 0, true>), grid, block, 0, st, (const void *)y1h,
+                           (const half8 *)s.d_w2h, (const float *)s.d_b2, y2h, (int)n, (const half8 *)s.d_w4f, s.d_a4);
         prof("k_lstm2", 1);
-        prof("k_fc4", 0);
-        hipLaunchKernelGGL(k_fc4_h, dim3((unsigned)((n + 32 * FC4_SB - 1) / (32 * FC4_SB))), block, 0, st, (const _Float16 *)y2h,
-                           (const half8 *)s.d_w4h, (const float *)s.d_b4, s.d_a4, (int)n);
-        prof("k_fc4", 1);
+        heads_parts = 2;
     } else {
     prof("k_lstm1", 0);
     if (s.channels == C3R_CH) {
@@ -861,7 +951,7 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
     prof("k_fc4", 1);
     }
     prof("k_heads", 0);
-    hipLaunchKernelGGL(k_heads, dim3((unsigned)((n + HEAD_SITES - 1) / HEAD_SITES)), block, 0, st, (const float *)s.d_a4, (const float *)s.d_w5,
+    hipLaunchKernelGGL(k_heads, dim3((unsigned)((n + HEAD_SITES - 1) / HEAD_SITES)), block, 0, st, (const float *)s.d_a4, heads_parts, (const float *)s.d_b4, (const float *)s.d_w5,
                        (const float *)s.d_b5, (const float *)s.d_wo, (const float *)s.d_bo, s.d_probs, (int)n);
     prof("k_heads", 1);
     NET_HIP(hipGetLastError());
