@@ -28,7 +28,10 @@ CHUNK = 5000000            # shared/param_p.py:91 CHUNK_SIZE
 FLOP_PER_SITE = {"k_lstm1": 2.0 * (18 + 128) * 512 * 33 * 2, "k_lstm2": 2.0 * (256 + 160) * 640 * 33 * 2,
                  "k_fc4": 2.0 * 10560 * 128, "k_heads": 2.0 * (128 * 256 + 128 * 24)}
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (never the 2:1-sparse figure)
 PEAK_HBM_GBPS = 8000.0
+# algorithmic bytes per emitted candidate for the tensor-build kernels (SURVEY.md §8d worked example, D = 20)
+K1_BYTES_PER_SITE = 773 + 2424
 
 
 def chunk_list(contig_len, chunk=CHUNK):
@@ -47,6 +50,8 @@ def main():
     ap.add_argument("--contig_len", type=int, default=0, help="default: chr20 (64,444,167)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
+                    help="network GEMM arithmetic: split-f16 (fp32-equivalent, default) or fp32 MFMA")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,6 +77,7 @@ def main():
     eng.set_reference(1, ref)
     weights = synth.random_weights(18)
     eng.load_weights(weights, 18)
+    eng.set_precision(args.precision)
 
     def one_step():
         # tensor build chunk by chunk (the reference's work items); the candidates of all chunks stay resident and
@@ -120,14 +126,34 @@ def main():
         st = kernels[dom]
         avg_ms = st["total_ms"] / st["launches"]
         if dom in FLOP_PER_SITE:
-            flops_per_launch = FLOP_PER_SITE[dom] * n_prof / st["launches"]
+            per_site = FLOP_PER_SITE[dom]
+            if dom == "k_lstm2" and args.precision == "f16x3":
+                per_site += FLOP_PER_SITE["k_fc4"]          # the L4 dense layer is fused into the layer-2 kernel
+            flops_per_launch = per_site * n_prof / st["launches"]
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
-                            launches=st["launches"])
+            if args.precision == "f16x3":
+                # ALGORITHMIC flops against the dense f16 MFMA peak.  The kernel executes 3 f16 products per algorithmic
+                # product (hi*hi + hi*lo + lo*hi), so matrix-pipe utilisation is 3x `frac`.
+                roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s",
+                                frac=round(ach / PEAK_F16_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
+                                launches=st["launches"], executed_tflops=round(3 * ach, 1),
+                                executed_frac=round(3 * ach / PEAK_F16_MFMA_TFLOPS, 4),
+                                vs_f32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 3),
+                                note="split-f16: fp32-equivalent GEMM as 3 f16 MFMAs with fp32 accumulation")
+            else:
+                roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                                frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
+                                launches=st["launches"])
         else:
-            roofline = dict(kernel=dom, bound="hbm", achieved=None, peak=PEAK_HBM_GBPS, unit="GB/s", frac=None, traffic=None,
-                            avg_launch_ms=round(avg_ms, 4), launches=st["launches"])
+            gbps = K1_BYTES_PER_SITE * n_prof / st["launches"] / (avg_ms * 1e-3) / 1e9
+            roofline = dict(kernel=dom, bound="hbm", achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                            frac=round(gbps / PEAK_HBM_GBPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4), launches=st["launches"])
+        traffic_fn = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
+        if roofline and os.path.exists(traffic_fn):
+            try:
+                roofline["traffic"] = json.load(open(traffic_fn)).get(args.precision, {}).get(dom)
+            except Exception:
+                pass
 
     # ---- CPU baseline: the oracle (a port of the reference pipeline) on a bounded sample, rank 0, N=1 only
     cpu = None
@@ -159,9 +185,10 @@ def main():
             "metric": "candidate sites/sec (tensor build + inference)",
             "value": round(sites / elapsed, 1), "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": ("f16 hi/lo split x3, f32 accumulate (fp32-equivalent)" if args.precision == "f16x3" else "f32"),
+            "data": "synthetic",
             "config": {"workload": "synthetic ONT dRNA004 chr20 ~%dx (BASELINE.json configs[1])" % int(args.depth),
-                       "contig_len": contig_len, "chunks": len(chunks), "channels": 18, "reads_per_rank": info["n_reads"],
+                       "contig_len": contig_len, "chunks": len(chunks), "channels": 18, "precision": args.precision, "reads_per_rank": info["n_reads"],
                        "exonic_bp_per_rank": info["n_exonic"], "sites_per_step_per_rank": round(sites_per_step_rank, 1),
                        "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world},
             "roofline": roofline, "cpu_baseline": cpu,

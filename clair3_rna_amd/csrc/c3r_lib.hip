@@ -47,7 +47,7 @@ struct c3r_ctx {
     int64_t n_indel_ops = 0;
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
     std::vector<DevSeg> h_segs;            // aligned segments (CIGAR runs between N ops), sorted by ext_start
-    DevBuf d_segs, d_seg_prefmax, d_tile_cols, d_tile_rng, d_tile_list;
+    DevBuf d_segs, d_seg_prefmax, d_tile_cols, d_tile_rng, d_tile_list, d_rsegs, d_rseg_first;
     std::string h_ref; int64_t ref_start1 = 1;
     DevBuf d_ref;
     std::vector<int32_t> h_bed[2];
@@ -224,7 +224,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+    DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -333,6 +333,15 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
                 k = k1;
             }
         }
+    }
+    {   // read-order copy of the segments (for the per-candidate token kernel) before the global sort
+        std::vector<uint32_t> first((size_t)n_reads + 1, 0);
+        for (const DevSeg &g : ctx->h_segs) first[g.read_idx + 1]++;
+        for (int64_t i = 0; i < n_reads; ++i) first[i + 1] += first[i];
+        int rc2;
+        if ((rc2 = upload(ctx, ctx->d_rsegs, ctx->h_segs.data(), ctx->h_segs.size()))) return rc2;
+        if ((rc2 = upload(ctx, ctx->d_rseg_first, first.data(), first.size()))) return rc2;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     std::stable_sort(ctx->h_segs.begin(), ctx->h_segs.end(), [](const DevSeg &a, const DevSeg &b) { return a.ext_start < b.ext_start; });
     ctx->h_seq.assign(seq4, seq4 + n_seq_bytes);
@@ -510,6 +519,7 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     {
         TokArgs t;
         t.reads = a.reads; t.cigar = a.cigar; t.seq = a.seq; t.prefmax_end = a.prefmax_end; t.n_reads = a.n_reads;
+        t.rsegs = (const DevSeg *)ctx->d_rsegs.p; t.rseg_first = (const uint32_t *)ctx->d_rseg_first.p;
         t.cand_idx = (const int32_t *)ctx->d_cand.p; t.n_cand = n_cand; t.reg_beg0 = ctx->reg_beg0;
         t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
         t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;

@@ -684,6 +684,8 @@ __global__ __launch_bounds__(256) void k_gather(const GatherArgs g) {
 // (src/create_tensor_pileup.py:179,221-261,595-596).
 struct TokArgs {
     const DevRead *reads; const uint32_t *cigar; const uint8_t *seq; const int32_t *prefmax_end; int32_t n_reads;
+    const DevSeg *rsegs;           // aligned segments in READ order
+    const uint32_t *rseg_first;    // [n_reads+1] first segment of each read in rsegs
     const int32_t *cand_idx; int32_t n_cand; int32_t reg_beg0;
     const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
     int32_t tok_base;              // tokens already resident from earlier scans of the batch
@@ -709,27 +711,44 @@ __global__ __launch_bounds__(256) void k_tokens(const TokArgs t) {
         if (cov) {
             const int rank = __popcll(m & ((1ull << lane) - 1ull));
             c3r_token_t tk; tk.read_idx = (uint32_t)r; tk.indel = 0; tk.qpos = 0; tk.base = 15; tk.rev = (rd.flag & 16) ? 1 : 0; tk.pad[0] = tk.pad[1] = 0;
-            int x = rd.pos, y = 0;
-            for (uint32_t k = 0; k < rd.n_cig; ++k) {
-                const uint32_t c = t.cigar[rd.cig_off + k];
-                const int op = (int)(c & 15u), len = (int)(c >> 4);
-                if (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) {
-                    if (p < x + len) {
-                        if (op == C3R_CIG_M) tk.base = (uint8_t)base_code(t.seq, rd.seq_off, (uint32_t)(y + (p - x)), rd.l_seq);
-                        else tk.base = (op == C3R_CIG_D) ? 16 : 17;
-                        if (p == x + len - 1 && k + 1 < rd.n_cig) {
-                            const uint32_t c2 = t.cigar[rd.cig_off + k + 1];
-                            const int op2 = (int)(c2 & 15u), len2 = (int)(c2 >> 4);
-                            if (op2 == C3R_CIG_I) { tk.indel = len2; tk.qpos = (uint32_t)(y + (op == C3R_CIG_M ? len : 0)); }
-                            else if (op2 == C3R_CIG_D && op != C3R_CIG_D) tk.indel = -len2;
-                        }
-                        break;
-                    }
-                    x += len;
-                    if (op == C3R_CIG_M) y += len;
-                } else if (op == C3R_CIG_I || op == C3R_CIG_S) {
-                    y += len;
+            // locate the aligned segment of this read that holds p (a handful per read), then walk only its ops;
+            // p inside an N op -> ref-skip token, possibly with the indel a following segment attaches to it
+            tk.base = 17;
+            const uint32_t s0 = t.rseg_first[r], s1 = t.rseg_first[r + 1];
+            for (uint32_t si = s0; si < s1; ++si) {
+                const DevSeg sg = t.rsegs[si];
+                if (sg.ext_start > p) break;
+                if (p >= sg.end) continue;
+                int x = sg.pos, y = (int)sg.qstart;
+                if (p < sg.pos) {          // p == pos-1: I/D right after an N, attached to the last intron column
+                    const uint32_t c0 = t.cigar[sg.cig_off];
+                    const int op0 = (int)(c0 & 15u), len0 = (int)(c0 >> 4);
+                    if (op0 == C3R_CIG_I) { tk.indel = len0; tk.qpos = (uint32_t)y; }
+                    else if (op0 == C3R_CIG_D) tk.indel = -len0;
+                    break;
                 }
+                for (uint32_t k = 0; k < sg.n_cig; ++k) {
+                    const uint32_t c = t.cigar[sg.cig_off + k];
+                    const int op = (int)(c & 15u), len = (int)(c >> 4);
+                    if (op == C3R_CIG_M || op == C3R_CIG_D) {
+                        if (p < x + len) {
+                            if (op == C3R_CIG_M) tk.base = (uint8_t)base_code(t.seq, rd.seq_off, (uint32_t)(y + (p - x)), rd.l_seq);
+                            else tk.base = 16;
+                            if (p == x + len - 1 && k + 1 < sg.n_cig) {
+                                const uint32_t c2 = t.cigar[sg.cig_off + k + 1];
+                                const int op2 = (int)(c2 & 15u), len2 = (int)(c2 >> 4);
+                                if (op2 == C3R_CIG_I) { tk.indel = len2; tk.qpos = (uint32_t)(y + (op == C3R_CIG_M ? len : 0)); }
+                                else if (op2 == C3R_CIG_D && op != C3R_CIG_D) tk.indel = -len2;
+                            }
+                            break;
+                        }
+                        x += len;
+                        if (op == C3R_CIG_M) y += len;
+                    } else if (op == C3R_CIG_I || op == C3R_CIG_S) {
+                        y += len;
+                    }
+                }
+                break;
             }
             t.tok[base_off + written + rank] = tk;
         }
