@@ -39,6 +39,7 @@ constexpr int NET_H2 = 160;
 constexpr int NET_T = C3R_WINDOW;          // 33 time steps
 constexpr int NET_SITES = 32;              // sites per MFMA column block
 constexpr int LSTM_SB = 2;                 // column blocks per wavefront in k_lstm
+constexpr int LSTM1H_SB = 2;               // layer 1 of the split-f16 path (3 spills registers and is slower: measured)
 constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 constexpr int NET_FLAT = NET_T * 2 * NET_H2;   // 10560
 constexpr int NET_L4 = 128;
@@ -405,54 +406,64 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
         mma(a1h, a1l, b1h, b1l, true);
         C3R_FENCE();
 #undef C3R_FENCE
-        // ---- lane-local cell update (acc holds 2^12 * z)
+        // ---- lane-local cell update (acc holds 2^12 * z).  Written stage by stage over the NU = 4*SB independent
+        // (unit, site) values of a tile so that the dependent exp2 -> rcp -> fma chains of different units overlap
+        // (one wavefront per SIMD: there is no other wave to hide VALU / transcendental latency behind).
+        //   sigmoid(i) * tanh(g) = (1 - e_g) / ((1 + e_i)(1 + e_g)),  o * tanh(c) = (1 - e_c) / ((1 + e_o)(1 + e_c)):
+        //   5 exp2 + 3 rcp per unit instead of 5 + 5.  The clamp keeps the denominators finite when a gate saturates.
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
+            constexpr int NU = 4 * SB;
+            constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
+            float cq[NU], ei[NU], ef[NU], eg[NU], eo[NU], hval[NU];
 #pragma unroll
             for (int sb = 0; sb < SB; ++sb) {
-                _Float16 hhi[4], hlo[4];
-                float cq[4];
-                float *crow = &cbuf[FC4 ? 32 * sb + j : 0][FC4 ? 8 * (wave * NT + tt) + 4 * hh : 0];
-                if (FC4) { const float4 cv = *(const float4 *)crow; cq[0] = cv.x; cq[1] = cv.y; cq[2] = cv.z; cq[3] = cv.w; }
+                if (FC4) {
+                    const float4 cv = *(const float4 *)&cbuf[FC4 ? 32 * sb + j : 0][FC4 ? 8 * (wave * NT + tt) + 4 * hh : 0];
+                    cq[4 * sb] = cv.x; cq[4 * sb + 1] = cv.y; cq[4 * sb + 2] = cv.z; cq[4 * sb + 3] = cv.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cq[4 * sb + q] = cst[FC4 ? 0 : tt][sb][q];
+                }
+            }
+            if (ABL & 2) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) hval[u] = acc[tt][u >> 2][4 * (u & 3)] + acc[tt][u >> 2][4 * (u & 3) + 1] + acc[tt][u >> 2][4 * (u & 3) + 2] + acc[tt][u >> 2][4 * (u & 3) + 3];
+            } else {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ei[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 0]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 1]);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(K2 * acc[tt][u >> 2][4 * (u & 3) + 2]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) eo[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 3]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ei[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + ei[u]) * (1.0f + eg[u]));   // sig(i)*tanh(g)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_rcpf(1.0f + ef[u]);                                          // sig(f)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) cq[u] = fmaf(ef[u], cq[u], ei[u]);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[u]), 1e18f);            // e_c
+#pragma unroll
+                for (int u = 0; u < NU; ++u) hval[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + eo[u]) * (1.0f + eg[u]));
+            }
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                if (FC4) *(float4 *)&cbuf[FC4 ? 32 * sb + j : 0][FC4 ? 8 * (wave * NT + tt) + 4 * hh : 0] =
+                             make_float4(cq[4 * sb], cq[4 * sb + 1], cq[4 * sb + 2], cq[4 * sb + 3]);
                 else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) cq[q] = cst[FC4 ? 0 : tt][sb][q];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float hval;
-                    if (ABL & 2) hval = acc[tt][sb][4 * q] + acc[tt][sb][4 * q + 1] + acc[tt][sb][4 * q + 2] + acc[tt][sb][4 * q + 3];
-                    else {
-                        // i,f,g,o from acc = 2^12 z.  With e_x = exp(-z_x) (e_g = exp(-2 z_g)):
-                        //   sigmoid(i) * tanh(g) = (1 - e_g) / ((1 + e_i)(1 + e_g))      -> one reciprocal for the pair
-                        //   o * tanh(c)          = (1 - e_c) / ((1 + e_o)(1 + e_c))      -> one reciprocal for the pair
-                        // 5 exp2 + 3 rcp per unit instead of 5 + 5 (quarter-rate ops dominate the cell update).
-                        constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
-                        const float ei = __builtin_amdgcn_exp2f(K1 * acc[tt][sb][4 * q + 0]);
-                        const float ef = __builtin_amdgcn_exp2f(K1 * acc[tt][sb][4 * q + 1]);
-                        const float eg = __builtin_amdgcn_exp2f(K2 * acc[tt][sb][4 * q + 2]);
-                        const float eo = __builtin_amdgcn_exp2f(K1 * acc[tt][sb][4 * q + 3]);
-                        // clamp keeps (1+e)(1+e) finite when a gate saturates (e -> inf): the quotient limit is still exact
-                        const float eic = fminf(ei, 1e18f), egc = fminf(eg, 1e18f), eoc = fminf(eo, 1e18f);
-                        const float ig_gg = (1.0f - egc) * __builtin_amdgcn_rcpf((1.0f + eic) * (1.0f + egc));
-                        const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
-                        const float c = fmaf(fg, cq[q], ig_gg);
-                        cq[q] = c;
-                        const float ec = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * c), 1e18f);
-                        hval = (1.0f - ec) * __builtin_amdgcn_rcpf((1.0f + eoc) * (1.0f + ec));
-                    }
-                    hhi[q] = (_Float16)hval;
-                    hlo[q] = (_Float16)(hval - (float)hhi[q]);
-                }
-                if (FC4) *(float4 *)crow = make_float4(cq[0], cq[1], cq[2], cq[3]);
-                else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cst[FC4 ? 0 : tt][sb][q] = cq[q];
+                    for (int q = 0; q < 4; ++q) cst[FC4 ? 0 : tt][sb][q] = cq[4 * sb + q];
                 }
                 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
                 half4 vh, vl;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { vh[q] = hhi[q]; vl[q] = hlo[q]; }
+                for (int q = 0; q < 4; ++q) {
+                    vh[q] = (_Float16)hval[4 * sb + q];
+                    vl[q] = (_Float16)(hval[4 * sb + q] - (float)vh[q]);
+                }
                 *(half4 *)&hb_hi[nxt][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vh;
                 *(half4 *)&hb_lo[nxt][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vl;
             }
@@ -913,12 +924,13 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
     if (s.precision == 1) {
         // split-f16 path: y1 / y2 hold hi and lo f16 planes (same bytes as one fp32 plane)
         _Float16 *y1h = (_Float16 *)s.d_y1, *y2h = (_Float16 *)s.d_y2;
+        const dim3 grid1((unsigned)((n + 32 * LSTM1H_SB - 1) / (32 * LSTM1H_SB)), 2);
         prof("k_lstm1", 0);
         if (s.channels == C3R_CH)
-            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH, NET_H1, true, LSTM_SB>), grid, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
+            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH, NET_H1, true, LSTM1H_SB>), grid1, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
                                (const float *)s.d_b1, y1h, (int)n);
         else
-            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH_PHASED, NET_H1, true, LSTM_SB>), grid, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
+            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH_PHASED, NET_H1, true, LSTM1H_SB>), grid1, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
                                (const float *)s.d_b1, y1h, (int)n);
         prof("k_lstm1", 1);
         prof("k_lstm2", 0);
