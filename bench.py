@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--contig_len", type=int, default=0, help="default: chr20 (64,444,167)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--no_overlap", action="store_true",
+                    help="one context / one stream: tensor build and network strictly back to back")
     ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
                     help="network GEMM arithmetic: split-f16 (fp32-equivalent, default) or fp32 MFMA")
     args = ap.parse_args()
@@ -79,32 +81,62 @@ def main():
     eng.load_weights(weights, 18)
     eng.set_precision(args.precision)
 
-    def one_step():
-        # tensor build chunk by chunk (the reference's work items); the candidates of all chunks stay resident and
-        # go through the network in ONE launch per layer (batch mode), then the probabilities come back to the host
-        eng.begin_batch()
+    def tensor_build(e):
+        # tensor build chunk by chunk (the reference's work items); the candidates of all chunks stay resident
+        e.begin_batch()
         total = 0
         for (a, b) in chunks:
-            total += eng.scan(a, b)
+            total += e.scan(a, b)
+        e.end_batch()
+        return total
+
+    def one_step():
+        # ... and go through the network in ONE launch per layer (batch mode); probabilities come back to the host
+        total = tensor_build(eng)
         if total:
             eng.infer()
-        eng.end_batch()
+        return total
+
+    # Two contexts = two HIP streams on the same GPU: while context A runs the network of pass i, context B builds the
+    # tensors of pass i+1 (the scan workgroups fit beside the persistent LSTM workgroups: 29 KB vs 128 KB of LDS).
+    # Every pass still does all of its work; only the order of independent passes is pipelined.
+    engs = [eng]
+    if not args.no_overlap:
+        e2 = capi.Engine(local_rank)
+        e2.set_params(); e2.load_reads(rs); e2.set_reference(1, ref); e2.load_weights(weights, 18); e2.set_precision(args.precision)
+        engs.append(e2)
+
+    def run_steps(k):
+        if len(engs) == 1:
+            return sum(one_step() for _ in range(k))
+        total, pending = 0, [None, None]
+        for i in range(k):
+            e = engs[i & 1]
+            if pending[i & 1] is not None:                       # results of pass i-2 (already long finished)
+                e.fetch_probs(pending[i & 1])
+            n = tensor_build(e)                                   # overlaps with the other context's network launch
+            if n:
+                e.infer(fetch=False)
+            pending[i & 1] = n
+            total += n
+        for j in (0, 1):
+            if pending[j]:
+                engs[j].fetch_probs(pending[j])
         return total
 
     def barrier():
-        eng.synchronize()
+        for e in engs:
+            e.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        one_step()
+    run_steps(max(args.warmup, 0))
     barrier()
     t0 = time.perf_counter()
-    sites = 0
-    for _ in range(args.steps):
-        sites += one_step()
-    eng.synchronize()
+    sites = run_steps(args.steps)
+    for e in engs:
+        e.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -190,7 +222,8 @@ def main():
             "config": {"workload": "synthetic ONT dRNA004 chr20 ~%dx (BASELINE.json configs[1])" % int(args.depth),
                        "contig_len": contig_len, "chunks": len(chunks), "channels": 18, "precision": args.precision, "reads_per_rank": info["n_reads"],
                        "exonic_bp_per_rank": info["n_exonic"], "sites_per_step_per_rank": round(sites_per_step_rank, 1),
-                       "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world},
+                       "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world,
+                       "streams": len(engs)},
             "roofline": roofline, "cpu_baseline": cpu,
             "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
         }

@@ -34,7 +34,7 @@ class C3RError(RuntimeError):
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
            "c3r_pileup_scan", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
-           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_infer", "c3r_set_profiling", "c3r_reset_kernel_stats",
+           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_infer", "c3r_get_probs", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
 _lib = None
@@ -80,6 +80,7 @@ def load_library():
     L.c3r_load_weights.argtypes = [vp, vp, i64, i32]
     L.c3r_set_precision.argtypes = [vp, i32]
     L.c3r_infer.argtypes = [vp, vp, i64, vp]
+    L.c3r_get_probs.argtypes = [vp, vp, i64]
     L.c3r_set_profiling.argtypes = [vp, i32]
     L.c3r_reset_kernel_stats.argtypes = [vp]
     L.c3r_get_kernel_stats.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i64), i32, C.POINTER(i32)]
@@ -219,6 +220,12 @@ class Engine(object):
             n = x.shape[0]
         probs = np.zeros((n, 24), dtype=np.float32) if fetch else None
         self._chk(self.L.c3r_infer(self.h, _ptr(x), n, _ptr(probs)))
+        return probs
+
+    def fetch_probs(self, n):
+        """Probabilities of the last infer(fetch=False): waits for the context's stream, then copies [n][24]."""
+        probs = np.zeros((n, 24), dtype=np.float32)
+        self._chk(self.L.c3r_get_probs(self.h, _ptr(probs), n))
         return probs
 
     # ---- measurement

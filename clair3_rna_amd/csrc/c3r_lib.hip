@@ -683,6 +683,16 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
     return C3R_OK;
 }
 
+int c3r_get_probs(c3r_ctx *ctx, float *probs, int64_t n) {
+    if (!ctx || !probs || n < 0) return C3R_EINVAL;
+    if (n == 0) return C3R_OK;
+    if (!ctx->net.d_probs || n > ctx->net.cap_sites) return fail(ctx, C3R_EINVAL, "no probabilities resident for %lld sites", (long long)n);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, (size_t)n * C3R_NPROB * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 int c3r_set_profiling(c3r_ctx *ctx, int enabled) {
     if (!ctx) return C3R_EINVAL;

@@ -116,6 +116,9 @@ int c3r_set_precision(c3r_ctx *ctx, int mode);
  * Otherwise `tensors` is a host int32 [n][33][C] array.  probs (host, [n][24]) may be NULL to keep
  * the result on the device only.  Replaces m.predict_on_batch (clair3_rna/call_variants.py:1505). */
 int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs);
+/* Fetch the [n][24] probabilities of the last c3r_infer(…, probs = NULL) — lets the caller queue the network on this
+ * context's stream, do other work (e.g. the tensor build of the next contig on a second context), and collect later. */
+int c3r_get_probs(c3r_ctx *ctx, float *probs, int64_t n);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream and the
