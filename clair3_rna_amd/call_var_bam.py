@@ -167,17 +167,12 @@ def Run(args, engine=None):
     n = eng.scan(ctg_start, ctg_end)
     rows = []
     if n:
-        probs = eng.infer()
-        sites_out, toks = eng.sites(), eng.tokens()
-        alt_infos = []
-        for s in sites_out:
-            tk = toks[int(s["tok_off"]):int(s["tok_off"]) + int(s["n_tok"])]
-            alt, _ = altinfo.alt_dict_from_tokens(tk, rs, ref_seq, ref_start, int(s["pos"]))
-            alt_infos.append(altinfo.alt_info_string(int(s["depth"]), alt))
-        ref33 = [s["ref33"].decode() for s in sites_out]
+        eng.infer(fetch=False)
         qual = args.qual if args.qual is not None else 2            # call_variants.py:1827 default
-        rows = decode.vcf_rows(ctg, sites_out["pos"], ref33, alt_infos, probs, qual_for_pass=qual, show_ref=args.show_ref)
+        # A8 on host threads inside libc3r: ordered alt_info from the per-read tokens, decode, row text
+        rows = eng.call_rows(ctg, qual=qual, show_ref=args.show_ref)
         if args.tensor_dump_fn:
+            sites_out, toks = eng.sites(), eng.tokens()
             raw = eng.tensors(rescaled=False)
             with open(args.tensor_dump_fn, "w") as f:
                 for line in altinfo.format_lines(ctg, sites_out, raw, toks, rs, ref_seq, ref_start):

@@ -34,7 +34,7 @@ class C3RError(RuntimeError):
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
            "c3r_pileup_scan", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
-           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_infer", "c3r_get_probs", "c3r_set_profiling", "c3r_reset_kernel_stats",
+           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
 _lib = None
@@ -81,6 +81,9 @@ def load_library():
     L.c3r_set_precision.argtypes = [vp, i32]
     L.c3r_infer.argtypes = [vp, vp, i64, vp]
     L.c3r_get_probs.argtypes = [vp, vp, i64]
+    L.c3r_call_rows.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.c3r_get_rows.argtypes = [vp, vp, i64]
+    L.c3r_decode_text.argtypes = [C.c_char_p, i64, vp, vp, i32, C.POINTER(C.c_char_p), vp, i32, i32, vp, i64, C.POINTER(i64)]
     L.c3r_set_profiling.argtypes = [vp, i32]
     L.c3r_reset_kernel_stats.argtypes = [vp]
     L.c3r_get_kernel_stats.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i64), i32, C.POINTER(i32)]
@@ -228,6 +231,15 @@ class Engine(object):
         self._chk(self.L.c3r_get_probs(self.h, _ptr(probs), n))
         return probs
 
+    def call_rows(self, ctg, qual=2, show_ref=True):
+        """A8 on host threads (C++): VCF rows for the resident candidates, after infer()."""
+        n, nr = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.c3r_call_rows(self.h, ctg.encode(), -1 if qual is None else int(qual), int(show_ref), C.byref(n), C.byref(nr)))
+        buf = C.create_string_buffer(n.value + 1)
+        self._chk(self.L.c3r_get_rows(self.h, buf, n.value + 1))
+        text = buf.value.decode()
+        return text.split("\n")[:-1] if text else []
+
     # ---- measurement
     def synchronize(self):
         self._chk(self.L.c3r_synchronize(self.h))
@@ -249,3 +261,24 @@ class Engine(object):
         n = C.c_int(0)
         self._chk(self.L.c3r_get_kernel_stats(self.h, names, ms, cnt, cap, C.byref(n)))
         return {names[i].decode(): dict(total_ms=ms[i], launches=cnt[i]) for i in range(min(n.value, cap))}
+
+
+def decode_text(ctg, positions, ref33_list, alt_info_list, probs, qual=2, show_ref=True):
+    """The C++ decoder on caller-supplied text (no GPU needed): list of VCF rows."""
+    L = load_library()
+    n = len(positions)
+    pos = np.ascontiguousarray(positions, dtype=np.int32)
+    r33 = np.zeros((n, 36), dtype="S1")
+    refs = np.frombuffer(b"".join(r.encode().ljust(36, b"\0") for r in ref33_list), dtype=np.uint8).copy() if n else np.zeros(0, np.uint8)
+    alts = (C.c_char_p * max(n, 1))(*[a.encode() for a in alt_info_list])
+    pr = np.ascontiguousarray(probs, dtype=np.float32)
+    need = C.c_int64(0)
+    rc = L.c3r_decode_text(ctg.encode(), n, _ptr(pos), _ptr(refs), 36, alts, _ptr(pr), -1 if qual is None else int(qual), int(show_ref), None, 0,
+                           C.byref(need))
+    buf = C.create_string_buffer(need.value + 1)
+    rc = L.c3r_decode_text(ctg.encode(), n, _ptr(pos), _ptr(refs), 36, alts, _ptr(pr), -1 if qual is None else int(qual), int(show_ref), buf,
+                           need.value + 1, C.byref(need))
+    if rc != 0:
+        raise C3RError(rc, "c3r_decode_text failed")
+    text = buf.value.decode()
+    return text.split("\n")[:-1] if text else []

@@ -10,9 +10,11 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/c3r.h"
+#include "decode.hpp"
 #include "net_kernels.hpp"
 #include "pileup_kernels.hpp"
 
@@ -68,6 +70,10 @@ struct c3r_ctx {
 
     // ---- network
     NetState net;
+
+    // ---- host decode (A8)
+    std::string rows_cache;
+    int64_t rows_count = 0;
 };
 
 namespace {
@@ -690,6 +696,73 @@ int c3r_get_probs(c3r_ctx *ctx, float *probs, int64_t n) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, (size_t)n * C3R_NPROB * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ A8 on the host
+int c3r_decode_text(const char *ctg, int64_t n, const int32_t *pos, const char *ref33s, int ref33_stride, const char *const *alt_infos,
+                    const float *probs, int qual, int show_ref, char *out, int64_t cap, int64_t *out_len) {
+    if (!ctg || n < 0 || (n && (!pos || !ref33s || !alt_infos || !probs)) || !out_len) return C3R_EINVAL;
+    std::string rows;
+    for (int64_t i = 0; i < n; ++i) {
+        int depth; AltDict alt;
+        parse_alt_info(alt_infos[i], depth, alt);
+        vcf_row(ctg, pos[i], ref33s + (size_t)i * ref33_stride, depth, alt, probs + (size_t)i * C3R_NPROB, qual, show_ref != 0, rows);
+    }
+    *out_len = (int64_t)rows.size();
+    if (!out || cap < (int64_t)rows.size() + 1) return C3R_EOVERFLOW;
+    memcpy(out, rows.c_str(), rows.size() + 1);
+    return C3R_OK;
+}
+
+int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t *out_len, int64_t *n_rows) {
+    if (!ctx || !ctg || !out_len) return C3R_EINVAL;
+    ctx->rows_cache.clear(); ctx->rows_count = 0;
+    const int64_t n = ctx->n_cand;
+    *out_len = 0; if (n_rows) *n_rows = 0;
+    if (n == 0) return C3R_OK;
+    if (!ctx->net.d_probs || n > ctx->net.cap_sites) return fail(ctx, C3R_EINVAL, "c3r_infer must run before c3r_call_rows");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<c3r_site_t> sites((size_t)n);
+    std::vector<c3r_token_t> toks((size_t)std::max<int64_t>(ctx->n_tok, 1));
+    std::vector<float> probs((size_t)n * C3R_NPROB);
+    HIPCHK(ctx, hipMemcpyAsync(sites.data(), ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->n_tok) HIPCHK(ctx, hipMemcpyAsync(toks.data(), ctx->d_tok.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(probs.data(), ctx->net.d_probs, probs.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint8_t *seq = ctx->h_seq.data();
+    const std::vector<DevRead> &reads = ctx->h_reads;
+    auto get_read = [&](uint32_t r) { return ReadView{seq, reads[r].seq_off, reads[r].l_seq}; };
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if ((int64_t)nt > n) nt = 1;
+    std::vector<std::string> part(nt);
+    std::vector<int64_t> cnt(nt, 0);
+    auto work = [&](unsigned t) {
+        const int64_t a = n * t / nt, b = n * (t + 1) / nt;
+        AltDict alt;
+        for (int64_t i = a; i < b; ++i) {
+            int depth_tok;
+            alt_from_tokens(toks.data() + sites[(size_t)i].tok_off, sites[(size_t)i].n_tok, get_read, ctx->h_ref, ctx->ref_start1, sites[(size_t)i].pos,
+                            alt, depth_tok);
+            if (vcf_row(ctg, sites[(size_t)i].pos, sites[(size_t)i].ref33, sites[(size_t)i].depth, alt, probs.data() + (size_t)i * C3R_NPROB, qual,
+                        show_ref != 0, part[t]))
+                cnt[t]++;
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (unsigned t = 0; t < nt; ++t) { ctx->rows_cache += part[t]; ctx->rows_count += cnt[t]; }
+    *out_len = (int64_t)ctx->rows_cache.size();
+    if (n_rows) *n_rows = ctx->rows_count;
+    return C3R_OK;
+}
+
+int c3r_get_rows(c3r_ctx *ctx, char *out, int64_t cap) {
+    if (!ctx || !out) return C3R_EINVAL;
+    if (cap < (int64_t)ctx->rows_cache.size() + 1) return fail(ctx, C3R_EOVERFLOW, "need %lld bytes", (long long)ctx->rows_cache.size() + 1);
+    memcpy(out, ctx->rows_cache.c_str(), ctx->rows_cache.size() + 1);
     return C3R_OK;
 }
 

@@ -120,6 +120,19 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs);
  * context's stream, do other work (e.g. the tensor build of the next contig on a second context), and collect later. */
 int c3r_get_probs(c3r_ctx *ctx, float *probs, int64_t n);
 
+/* ---- decode on the host (A8) --------------------------------------------------------------- */
+/* Probabilities -> genotype / ALT / QUAL -> VCF text rows, replacing batch_output / output_with / output_from
+ * (clair3_rna/call_variants.py:1077-1392, :684-1020).  c3r_call_rows works on the resident candidates after
+ * c3r_infer: it rebuilds each site's ordered alt_info from the per-read tokens (src/create_tensor_pileup.py:221-261,
+ * 595-596), decodes on host threads and caches the '\n'-terminated rows; c3r_get_rows copies them out.
+ * qual < 0 means "no quality cut-off" (--qual None); show_ref != 0 keeps RefCall rows (--showRef). */
+int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t *out_len, int64_t *n_rows);
+int c3r_get_rows(c3r_ctx *ctx, char *out, int64_t cap);
+/* The same decoder on caller-supplied text (no GPU, no context): n sites, alt_info strings "<depth>-<k v ...>".
+ * Returns C3R_EOVERFLOW (with *out_len = bytes needed, excluding the NUL) when `out` is too small. */
+int c3r_decode_text(const char *ctg, int64_t n, const int32_t *pos, const char *ref33s, int ref33_stride, const char *const *alt_infos,
+                    const float *probs, int qual, int show_ref, char *out, int64_t cap, int64_t *out_len);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream and the
  * elapsed times are accumulated per kernel name. */

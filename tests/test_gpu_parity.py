@@ -341,3 +341,25 @@ def test_dense_short_ops_cross_tile_and_batch_boundaries(eng):
             o = orc.generate_tensor(f[4], ref[pos - 1], pos, ref, 1)
             i = pos - col["region_start"]
             assert col["cols"][i].tolist() == o["tensor"], (seed, pos)
+
+
+def test_cpp_call_rows_equals_python_decode(eng):
+    """c3r_call_rows (C++: tokens -> ordered alt_info -> decode -> row text, on host threads) == altinfo.py + decode.py."""
+    from clair3_rna_amd import altinfo, decode, synth
+    ref, rs, _ = synth.small_case(seed=61, ref_len=40000, n_genes=8, depth=25)
+    _reset(eng)
+    eng.load_reads(rs)
+    eng.set_reference(1, ref)
+    n = eng.scan(1, len(ref))
+    assert n > 100
+    eng.load_weights(synth.random_weights(18, seed=9), 18)
+    probs = eng.infer()
+    sites, toks = eng.sites(), eng.tokens()
+    infos = []
+    for s in sites:
+        alt, _ = altinfo.alt_dict_from_tokens(toks[int(s["tok_off"]):int(s["tok_off"]) + int(s["n_tok"])], rs, ref, 1, int(s["pos"]))
+        infos.append(altinfo.alt_info_string(int(s["depth"]), alt))
+    py = decode.vcf_rows("chr20", sites["pos"], [s["ref33"].decode() for s in sites], infos, probs)
+    assert eng.call_rows("chr20") == py
+    assert eng.call_rows("chr20", qual=None, show_ref=False) == decode.vcf_rows(
+        "chr20", sites["pos"], [s["ref33"].decode() for s in sites], infos, probs, qual_for_pass=None, show_ref=False)
