@@ -39,8 +39,22 @@ constexpr int NET_H2 = 160;
 constexpr int NET_T = C3R_WINDOW;          // 33 time steps
 constexpr int NET_SITES = 32;              // sites per MFMA column block
 constexpr int LSTM_SB = 2;                 // column blocks per wavefront in k_lstm
-constexpr int LSTM1H_SB = 2;               // layer 1 of the split-f16 path (3 spills registers and is slower: measured)
+constexpr int LSTM1H_SB = 2;               // layer 1 of the split-f16 path (3 measured slower: 9.9 vs 8.3 ms)
 constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
+// split-f16 K-loop schedule per layer: prefetch distance in k-groups, and whether the prefetch loads are interleaved
+// with the MFMAs (sched_group_barrier) or issued as one burst ahead of them.  Chosen by A/B runs of bench.py on one box.
+#ifndef C3R_L1_PD
+#define C3R_L1_PD 2
+#endif
+#ifndef C3R_L1_ILV
+#define C3R_L1_ILV false
+#endif
+#ifndef C3R_L2_PD
+#define C3R_L2_PD 2
+#endif
+#ifndef C3R_L2_ILV
+#define C3R_L2_ILV true
+#endif
 constexpr int NET_FLAT = NET_T * 2 * NET_H2;   // 10560
 constexpr int NET_L4 = 128;
 
@@ -249,17 +263,37 @@ __device__ __forceinline__ float tanh_scaled(float acc) {      // tanh(acc * 2^-
     return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((-2.8853900817779268f * WUNSCALE) * acc)), -1.0f);
 }
 
+// Interleave plan for one scheduling region: NM MFMAs with NV global loads and ND LDS reads spread evenly between them
+// (sched_group_barrier masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read).  One wavefront per SIMD issues everything:
+// a burst of 14 wave-wide 16-byte loads holds the issue port for a few hundred cycles and drains the matrix pipe's
+// short queue, whereas one load every second MFMA hides completely (<= 5 fillers fit into a 32-cycle MFMA).
+template <int NM, int NV, int ND>
+__device__ __forceinline__ void sched_interleave() {
+    constexpr int K = (NM / (NV + ND + 1)) > 0 ? (NM / (NV + ND + 1)) : 1;
+    if constexpr (NV > 0 && NM >= K) {
+        __builtin_amdgcn_sched_group_barrier(0x008, K, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        sched_interleave<NM - K, NV - 1, ND>();
+    } else if constexpr (ND > 0 && NM >= K) {
+        __builtin_amdgcn_sched_group_barrier(0x008, K, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        sched_interleave<NM - K, NV, ND - 1>();
+    } else if constexpr (NM > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    }
+}
+
 // Fused bidirectional LSTM layer on split-f16 operands.  Same decomposition as k_lstm (32-row gate blocks permuted for
 // a lane-local cell update, SB 32-site blocks per wavefront, h double-buffered in LDS, one barrier per step), with
 //   Wp : [dir][wave][g][tile][hi|lo][64 lanes] half8  (k-groups of 16; lane half hh owns k = 16g + 8hh + 0..7)
-//   xin: INT_IN ? int32 [n][33][CIN] (exact in f16, lo = 0)  :  hi plane then lo plane, each f16 [n][33][CIN]
-//   y  : hi plane then lo plane, each f16 [n][33][2H]
+//   xin: INT_IN ? int32 [n][33][CIN] (exact in f16, lo = 0)  :  hi plane then lo plane, each f16 [33][CIN/8][n][8]
+//   y  : hi plane then lo plane, each f16 [33][2H/8][n][8]
 // FC4 (layer 2 only): the flatten + Dense(128) layer L4 is fused in.  After every step the fresh h_t (already in LDS as
 // hi/lo halves) is multiplied by the [160 x 128] slice of W4 that belongs to (t, direction) and accumulated in
 // persistent registers; y2 is never written.  Each workgroup ends by storing its [sites][128] partial pre-activation
 // for its direction; k_heads adds the two directions and the bias and applies selu.
 //   W4p: [dir][t][blk(4)][g(H/16)][hi|lo][64 lanes] half8, x 2^12;   a4part: fp32 [n][2][128]
-template <int INP, int CIN, int H, bool INT_IN, int SB = 2, int ABL = 0, bool FC4 = false>
+template <int INP, int CIN, int H, bool INT_IN, int SB = 2, int ABL = 0, bool FC4 = false, int PD = 1, bool ILV = false>
 __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin, const half8 *__restrict__ Wp,
                                                     const float *__restrict__ bp, _Float16 *__restrict__ y, int n,
                                                     const half8 *__restrict__ W4p = nullptr, float *__restrict__ a4part = nullptr) {
@@ -309,12 +343,12 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
     for (int i = tid; i < WG_SITES * HP; i += 256) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
     __syncthreads();
 
-    size_t xoff[SB];
+    size_t xoff[SB];     // per-lane part of the x address (elements)
 #pragma unroll
     for (int sb = 0; sb < SB; ++sb) {
         int sj = site0 + 32 * sb + j;
         if (sj >= n) sj = n - 1;
-        xoff[sb] = (size_t)sj * NET_T * CIN;
+        xoff[sb] = INT_IN ? (size_t)sj * NET_T * CIN : ((size_t)hh * n + sj) * 8;
     }
 
     for (int step = 0; step < NET_T; ++step) {
@@ -324,13 +358,16 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
         auto ldx = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
 #pragma unroll
             for (int sb = 0; sb < SB; ++sb) {
+                if ((ABL & 32) && g > 0) continue;      // probe: no x operand traffic
                 if (INT_IN) {
                     const int32_t *xp = (const int32_t *)xin + xoff[sb] + (size_t)t * CIN;
                     const int k0 = 16 * g + 8 * hh;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bh[sb][e] = (k0 + e < CIN) ? (_Float16)(float)xp[k0 + e] : (_Float16)0.f;
                 } else {
-                    const _Float16 *xp = (const _Float16 *)xin + xoff[sb] + (size_t)t * CIN + 16 * g + 8 * hh;
+                    // [t][k/8][site][8]: the 32 lanes of a half-wave read 32 consecutive 16-byte pieces (512 B), so a
+                    // wave load costs the L1 what a weight load costs (the [site][t][k] layout touched 32 cache lines)
+                    const _Float16 *xp = (const _Float16 *)xin + ((size_t)(t * (CIN / 8) + 2 * g) * n) * 8 + xoff[sb];
                     bh[sb] = *(const half8 *)xp;
                     bl[sb] = *(const half8 *)(xp + plane_in);
                 }
@@ -344,9 +381,19 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
             }
         };
         auto ldw = [&](int g, half8 (&ah)[NT], half8 (&al)[NT]) {
-            const half8 *wg = wl + (size_t)((ABL & 1) ? 0 : g) * NT * 2 * 64;
+            // the empty asm hides the pointer's provenance: with literal group numbers hipcc would otherwise precompute
+            // all NG*NT*2 load addresses outside the step loop (520 registers) and spill them
+            // (as an integer, re-typed as an address_space(1) pointer: an opaque generic pointer would become flat_load,
+            // which returns out of order and forces vmcnt(0) lgkmcnt(0) drains)
+            typedef const half8 __attribute__((address_space(1))) *gptr_t;
+            uintptr_t wbase = (uintptr_t)wl;
+            asm volatile("" : "+v"(wbase));
+            const gptr_t wg = (gptr_t)wbase + (size_t)((ABL & 1) ? 0 : g) * NT * 2 * 64;
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) { ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64]; }
+            for (int tt = 0; tt < NT; ++tt) {
+                if ((ABL & 16) && g > 0) continue;      // probe: weights register-stationary (no L1 traffic)
+                ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64];
+            }
         };
 
         floatx16 acc[NT][SB];
@@ -376,35 +423,46 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
                     for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bl[sb], acc[tt][sb], 0, 0, 0);
             }
         };
-        half8 a0h[NT], a0l[NT], a1h[NT], a1l[NT], b0h[SB], b0l[SB], b1h[SB], b1l[SB];
-#pragma unroll
-        for (int sb = 0; sb < SB; ++sb) { b0l[sb] = (half8)(_Float16)0.f; b1l[sb] = (half8)(_Float16)0.f; }
+        // Fully unrolled, software-pipelined K loop with prefetch distance PD k-groups and a ring of PD+1 register
+        // buffers.  With ONE wavefront per SIMD nothing else hides the L2 latency of the weight stream: the probe showed
+        // the kernel latency x concurrency bound (more reuse per fetch did not help, L1-hot weights did), so the fix is
+        // more bytes in flight, not fewer bytes.  sched_barrier(0) pins the load/MFMA order (hipcc otherwise clusters the
+        // loads and drains them with vmcnt(0)); full unrolling makes the ring slots and the x/h operand source
+        // compile-time constants (no flat loads).
         constexpr bool XLO = !INT_IN;
+        half8 ah[PD + 1][NT], al[PD + 1][NT], bh[PD + 1][SB], bl[PD + 1][SB];
+#pragma unroll
+        for (int d = 0; d <= PD; ++d)
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) bl[d][sb] = (half8)(_Float16)0.f;
 #define C3R_FENCE() __builtin_amdgcn_sched_barrier(0)
-        ldw(0, a0h, a0l);
-        ldx(0, b0h, b0l);
-#pragma unroll 1
-        for (int g = 0; g + 2 < NGX; g += 2) {
-            C3R_FENCE(); ldw(g + 1, a1h, a1l); ldx(g + 1, b1h, b1l); C3R_FENCE();
-            mma(a0h, a0l, b0h, b0l, XLO);
-            C3R_FENCE(); ldw(g + 2, a0h, a0l); ldx(g + 2, b0h, b0l); C3R_FENCE();
-            mma(a1h, a1l, b1h, b1l, XLO);
-        }
-        C3R_FENCE(); ldw(NGX - 1, a1h, a1l); ldx(NGX - 1, b1h, b1l); C3R_FENCE();
-        mma(a0h, a0l, b0h, b0l, XLO);
-        C3R_FENCE(); ldw(NGX, a0h, a0l); ldh(0, b0h, b0l); C3R_FENCE();
-        mma(a1h, a1l, b1h, b1l, XLO);
-#pragma unroll 1
-        for (int g = 0; g + 2 < NGH; g += 2) {
-            C3R_FENCE(); ldw(NGX + g + 1, a1h, a1l); ldh(g + 1, b1h, b1l); C3R_FENCE();
-            mma(a0h, a0l, b0h, b0l, true);
-            C3R_FENCE(); ldw(NGX + g + 2, a0h, a0l); ldh(g + 2, b0h, b0l); C3R_FENCE();
-            mma(a1h, a1l, b1h, b1l, true);
-        }
-        C3R_FENCE(); ldw(NG - 1, a1h, a1l); ldh(NGH - 1, b1h, b1l); C3R_FENCE();
-        mma(a0h, a0l, b0h, b0l, true);
-        mma(a1h, a1l, b1h, b1l, true);
+#define C3R_LOAD(G) do { ldw((G), ah[(G) % (PD + 1)], al[(G) % (PD + 1)]); \
+                         if ((G) < NGX) ldx((G), bh[(G) % (PD + 1)], bl[(G) % (PD + 1)]); \
+                         else ldh((G) - NGX, bh[(G) % (PD + 1)], bl[(G) % (PD + 1)]); } while (0)
+        // literal group numbers (macro expansion) guarantee compile-time ring slots: a `#pragma unroll` that the
+        // optimiser declines turns the ring into a scratch-memory array
+#define C3R_PRE(D) if constexpr ((D) < PD && (D) < NG) { C3R_LOAD(D); }
+#define C3R_STEP(G)                                                                                              \
+    if constexpr ((G) < NG) {                                                                                     \
+        C3R_FENCE();                                                                                              \
+        if constexpr ((G) + PD < NG) { C3R_LOAD((G) + PD); }                                                      \
+        if constexpr (!ILV) C3R_FENCE();                                                                          \
+        mma(ah[(G) % (PD + 1)], al[(G) % (PD + 1)], bh[(G) % (PD + 1)], bl[(G) % (PD + 1)], (G) < NGX ? XLO : true); \
+        if constexpr (ILV && (G) + PD < NG) {                                                                     \
+            constexpr bool LX = (G) + PD < NGX;        /* the prefetched group is an x group */                   \
+            constexpr int NMM = NT * SB * (((G) < NGX && !XLO) ? 2 : 3);                                          \
+            sched_interleave<NMM, NT * 2 + (LX ? (INT_IN ? 0 : SB * 2) : 0), LX ? 0 : SB * 2>();                  \
+        }                                                                                                         \
+    }
+        C3R_PRE(0) C3R_PRE(1) C3R_PRE(2) C3R_PRE(3) C3R_PRE(4) C3R_PRE(5)
+        C3R_STEP(0) C3R_STEP(1) C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
+        C3R_STEP(10) C3R_STEP(11) C3R_STEP(12) C3R_STEP(13) C3R_STEP(14) C3R_STEP(15) C3R_STEP(16) C3R_STEP(17) C3R_STEP(18)
+        C3R_STEP(19) C3R_STEP(20) C3R_STEP(21) C3R_STEP(22) C3R_STEP(23) C3R_STEP(24) C3R_STEP(25) C3R_STEP(26) C3R_STEP(27)
+        static_assert(NG <= 28 && PD <= 6, "extend the C3R_STEP / C3R_PRE lists");
         C3R_FENCE();
+#undef C3R_PRE
+#undef C3R_STEP
+#undef C3R_LOAD
 #undef C3R_FENCE
         // ---- lane-local cell update (acc holds 2^12 * z).  Written stage by stage over the NU = 4*SB independent
         // (unit, site) values of a tile so that the dependent exp2 -> rcp -> fma chains of different units overlap
@@ -413,6 +471,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
         //   5 exp2 + 3 rcp per unit instead of 5 + 5.  The clamp keeps the denominators finite when a gate saturates.
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
+            __builtin_amdgcn_sched_barrier(0);   // one tile at a time: bounds the accumulator values live in VGPRs
             constexpr int NU = 4 * SB;
             constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
             float cq[NU], ei[NU], ef[NU], eg[NU], eo[NU], hval[NU];
@@ -485,16 +544,17 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
                 }
             }
         }
-        // ---- layer output planes y_hi / y_lo [site][t][dir*H + u]: coalesced 16-byte stores (8 halves)
+        // ---- layer output planes y_hi / y_lo [t][(dir*H + u)/8][site][8 halves]: the layout the next layer's B-operand
+        // loads want (see ldx); consecutive threads store consecutive sites, 16 bytes each
         constexpr int HV = H / 8;
         if (!(ABL & 4) && !FC4)
         for (int f = tid; f < WG_SITES * HV * 2; f += 256) {
             const int pl = f / (WG_SITES * HV), rem = f % (WG_SITES * HV);
-            const int row = rem / HV, c8 = rem % HV;
+            const int c8 = rem / WG_SITES, row = rem % WG_SITES;
             const int s = site0 + row;
             if (s < n) {
                 const half8 v = pl ? *(const half8 *)&hb_lo[nxt][row][8 * c8] : *(const half8 *)&hb_hi[nxt][row][8 * c8];
-                *(half8 *)(y + (size_t)pl * plane_out + ((size_t)s * NET_T + t) * (2 * H) + dir * H + 8 * c8) = v;
+                *(half8 *)(y + (size_t)pl * plane_out + (((size_t)t * (2 * HV) + dir * HV + c8) * n + s) * 8) = v;
             }
         }
     }
@@ -509,59 +569,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
                                            facc[sb][4 * q + 3] * WUNSCALE);
                     *(float4 *)(a4part + ((size_t)sidx * 2 + dir) * NET_L4 + 32 * wave + 8 * q + 4 * hh) = v;
                 }
-            }
-        }
-    }
-}
-
-// L4 on split-f16 operands: a4[n][128] = selu(y2 * W4 + b4), y2 given as hi/lo f16 planes [n][10560].
-// grid = ceil(n / (32*SB4)), block = 256 (wave = 32-row block of output units); B straight from global.
-constexpr int FC4_SB = 4;
-__global__ __launch_bounds__(256) void k_fc4_h(const _Float16 *__restrict__ y2, const half8 *__restrict__ Wp,
-                                               const float *__restrict__ bias, float *__restrict__ a4, int n) {
-    constexpr int NG = NET_FLAT / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hh = lane >> 5;
-    const int site0 = blockIdx.x * 32 * FC4_SB;
-    const size_t plane = (size_t)n * NET_FLAT;
-    const _Float16 *xr[FC4_SB];
-#pragma unroll
-    for (int sb = 0; sb < FC4_SB; ++sb) {
-        int s = site0 + 32 * sb + j; if (s >= n) s = n - 1;
-        xr[sb] = y2 + (size_t)s * NET_FLAT + 8 * hh;
-    }
-    const half8 *wl = Wp + (size_t)wave * NG * 2 * 64 + lane;
-    floatx16 acc[FC4_SB];
-#pragma unroll
-    for (int sb = 0; sb < FC4_SB; ++sb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
-#pragma unroll 2
-    for (int g = 0; g < NG; ++g) {
-        const half8 ah = wl[(size_t)(g * 2 + 0) * 64], al = wl[(size_t)(g * 2 + 1) * 64];
-        half8 bh[FC4_SB], bl[FC4_SB];
-#pragma unroll
-        for (int sb = 0; sb < FC4_SB; ++sb) { bh[sb] = *(const half8 *)(xr[sb] + 16 * g); bl[sb] = *(const half8 *)(xr[sb] + plane + 16 * g); }
-#pragma unroll
-        for (int sb = 0; sb < FC4_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[sb], acc[sb], 0, 0, 0);
-#pragma unroll
-        for (int sb = 0; sb < FC4_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[sb], acc[sb], 0, 0, 0);
-#pragma unroll
-        for (int sb = 0; sb < FC4_SB; ++sb) acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[sb], acc[sb], 0, 0, 0);
-    }
-#pragma unroll
-    for (int sb = 0; sb < FC4_SB; ++sb) {
-        const int s = site0 + 32 * sb + j;
-        if (s < n) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int u = 32 * wave + 8 * q + 4 * hh;
-                float4 v;
-                v.x = selu(fmaf(acc[sb][4 * q + 0], WUNSCALE, bias[u + 0]));
-                v.y = selu(fmaf(acc[sb][4 * q + 1], WUNSCALE, bias[u + 1]));
-                v.z = selu(fmaf(acc[sb][4 * q + 2], WUNSCALE, bias[u + 2]));
-                v.w = selu(fmaf(acc[sb][4 * q + 3], WUNSCALE, bias[u + 3]));
-                *(float4 *)(a4 + (size_t)s * NET_L4 + u) = v;
             }
         }
     }
@@ -927,15 +934,15 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
         const dim3 grid1((unsigned)((n + 32 * LSTM1H_SB - 1) / (32 * LSTM1H_SB)), 2);
         prof("k_lstm1", 0);
         if (s.channels == C3R_CH)
-            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH, NET_H1, true, LSTM1H_SB>), grid1, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
+            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH, NET_H1, true, LSTM1H_SB, 0, false, C3R_L1_PD, C3R_L1_ILV>), grid1, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
                                (const float *)s.d_b1, y1h, (int)n);
         else
-            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH_PHASED, NET_H1, true, LSTM1H_SB>), grid1, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
+            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH_PHASED, NET_H1, true, LSTM1H_SB, 0, false, C3R_L1_PD, C3R_L1_ILV>), grid1, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
                                (const float *)s.d_b1, y1h, (int)n);
         prof("k_lstm1", 1);
         prof("k_lstm2", 0);
         // layer 2 with the L4 dense layer fused in: y2 is never materialised
-        hipLaunchKernelGGL((k_lstm_h<2 * NET_H1, 2 * NET_H1, NET_H2, false, LSTM_SB, 0, true>), grid, block, 0, st, (const void *)y1h,
+        hipLaunchKernelGGL((k_lstm_h<2 * NET_H1, 2 * NET_H1, NET_H2, false, LSTM_SB, 0, true, C3R_L2_PD, C3R_L2_ILV>), grid, block, 0, st, (const void *)y1h,
                            (const half8 *)s.d_w2h, (const float *)s.d_b2, y2h, (int)n, (const half8 *)s.d_w4f, s.d_a4);
         prof("k_lstm2", 1);
         heads_parts = 2;
