@@ -61,7 +61,7 @@ struct c3r_ctx {
     // ---- scan state
     int32_t reg_beg0 = 0, reg_end0 = 0;
     int64_t n_pos = 0;
-    DevBuf d_cols, d_depth, d_ncov, d_flags, d_ev, d_small /* cursor,last_row,totals */, d_blockcnt;
+    DevBuf d_cols, d_depth, d_ncov, d_flags, d_skipmax, d_ev, d_small /* cursor,last_row,totals */, d_blockcnt;
     int64_t n_cand = 0, n_tok = 0;        // totals resident on the device (all scans of the current batch)
     int64_t last_cand = 0, last_base = 0; // candidates of the most recent scan and their offset in the batch
     bool batching = false;
@@ -231,7 +231,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
-                      &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_ev, &ctx->d_small,
+                      &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     net_free(ctx->net);
@@ -254,8 +254,6 @@ void *c3r_stream(c3r_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int c3r_set_params(c3r_ctx *ctx, const c3r_params_t *p) {
     if (!ctx || !p) return C3R_EINVAL;
     if (p->channels != C3R_CH && p->channels != C3R_CH_PHASED) return fail(ctx, C3R_EINVAL, "channels must be 18 or 30");
-    if (p->splice_padding)
-        return fail(ctx, C3R_EUNSUPPORTED, "enable_padding_in_splice_junction_regions is not implemented on the GPU path");
     const bool refilter = p->min_mq != ctx->prm.min_mq || p->excl_flags != ctx->prm.excl_flags;
     ctx->prm = *p;
     if (ctx->prm.max_depth_rescale <= 0) ctx->prm.max_depth_rescale = 144;
@@ -408,9 +406,18 @@ static int run_gather(c3r_ctx *ctx, int rescale, int32_t *dst, bool with_sites) 
     g.head_tail = ctx->prm.head_tail; g.last_row = (const int32_t *)((char *)ctx->d_small.p + 8);
     g.rescale = rescale; g.max_depth = ctx->prm.max_depth_rescale;
     g.tensors = dst;
+    g.raw = nullptr; g.skipmax = nullptr;
     g.sites = with_sites ? (c3r_site_t *)ctx->d_sites_out.p + ctx->last_base : nullptr;
     g.tok_cnt = with_sites ? (int32_t *)ctx->d_tokcnt.p : nullptr;
     const int blocks = (int)((ctx->last_cand * 64 + 255) / 256);
+    if (ctx->prm.splice_padding) {
+        // in-place column edits, candidate after candidate: runs once per scan and also keeps the raw windows
+        g.raw = (int32_t *)ctx->d_raw.p; g.skipmax = (const int32_t *)ctx->d_skipmax.p;
+        Launch L(ctx, "k_splice_gather");
+        if (ctx->prm.channels == C3R_CH) hipLaunchKernelGGL(k_splice_gather<C3R_CH>, dim3(blocks), dim3(256), 0, ctx->stream, g);
+        else hipLaunchKernelGGL(k_splice_gather<C3R_CH_PHASED>, dim3(blocks), dim3(256), 0, ctx->stream, g);
+        return C3R_OK;
+    }
     Launch L(ctx, "k_gather");
     if (ctx->prm.channels == C3R_CH) hipLaunchKernelGGL(k_gather<C3R_CH>, dim3(blocks), dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL(k_gather<C3R_CH_PHASED>, dim3(blocks), dim3(256), 0, ctx->stream, g);
@@ -446,6 +453,7 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     if ((rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_blockcnt, (size_t)(n_cblocks + 1) * 4))) return rc;
+    if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_skipmax, (size_t)n_pos * 4))) return rc;
     // d_small: [0..7] ev_cursor (u64), [8..11] last_row, [12..15] n_cand, [16..19] n_tok, [20..23] n_tile_list
     int32_t init[6] = {0, 0, -1, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_small.p, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
@@ -470,6 +478,7 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.min_cov = ctx->prm.min_coverage;
     a.snp_af = ctx->prm.snp_min_af; a.indel_af = ctx->prm.indel_min_af;
     a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)ctx->d_small.p; a.last_row = (int32_t *)((char *)ctx->d_small.p + 8);
+    a.splice = ctx->prm.splice_padding; a.skipmax = (int32_t *)ctx->d_skipmax.p;
     if (a.n_reads > 0) {
         Launch L(ctx, "k_tile_ranges");
         hipLaunchKernelGGL(k_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
@@ -478,6 +487,11 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
         Launch L(ctx, "k_scan_tiles");
         if (C == C3R_CH) hipLaunchKernelGGL(k_scan_tiles<C3R_CH>, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
         else hipLaunchKernelGGL(k_scan_tiles<C3R_CH_PHASED>, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
+    }
+    if (a.n_reads > 0 && a.splice) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_skipmax.p, 0, (size_t)n_pos * 4, ctx->stream));
+        Launch L(ctx, "k_skip_counts");
+        hipLaunchKernelGGL(k_skip_counts, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
     }
     {
         Launch L(ctx, "k_select");
@@ -506,6 +520,7 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     if ((rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_cand + n_cand) * tbytes, (size_t)base_cand * tbytes))) return rc;
     if ((rc = ensure_keep(ctx, ctx->d_sites_out, (size_t)(base_cand + n_cand) * sizeof(c3r_site_t), (size_t)base_cand * sizeof(c3r_site_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_tokcnt, (size_t)(n_cand + 1) * 4))) return rc;
+    if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_raw, (size_t)n_cand * tbytes))) return rc;
     {
         Launch L(ctx, "k_compact_write");
         hipLaunchKernelGGL(k_compact_write, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
@@ -570,9 +585,11 @@ int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_si
         // raw (un-rescaled) windows are re-gathered from the columns of the most recent scan only
         if (ctx->last_base != 0 || ctx->last_cand != ctx->n_cand)
             return fail(ctx, C3R_EINVAL, "raw tensors are only available for a single (non-batched) scan");
-        int rc = ensure(ctx, ctx->d_raw, bytes);
-        if (rc) return rc;
-        if ((rc = run_gather(ctx, 0, (int32_t *)ctx->d_raw.p, false))) return rc;
+        if (!ctx->prm.splice_padding) {     // (splice padding: the scan already kept the raw windows, the columns have moved on)
+            int rc = ensure(ctx, ctx->d_raw, bytes);
+            if (rc) return rc;
+            if ((rc = run_gather(ctx, 0, (int32_t *)ctx->d_raw.p, false))) return rc;
+        }
         src = ctx->d_raw.p;
     }
     HIPCHK(ctx, hipMemcpyAsync(tensors, src, bytes, hipMemcpyDeviceToHost, ctx->stream));

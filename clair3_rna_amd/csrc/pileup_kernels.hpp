@@ -106,6 +106,8 @@ struct ScanArgs {
     EvRec *ev;                    // scratch, one slot per I/D op in the loaded reads (+ padding)
     unsigned long long *ev_cursor;
     int32_t *last_row;            // atomicMax of the last position with a row
+    int32_t splice;               // --enable_padding_in_splice_junction_regions: also produce skipmax[], materialise every tile
+    int32_t *skipmax;             // [n_pos] max(#read starts, #read ends, #fwd ref-skips, #rev ref-skips) of the row
 };
 
 __device__ __forceinline__ int wave_incl_scan(int v) {
@@ -409,6 +411,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
             // racy pre-check is safe (the value only grows) and keeps ~10^5 tiles from serialising on one L2 atomic
             if ((tid & 63) == 0 && mx > *(volatile int32_t *)a.last_row) atomicMax(a.last_row, mx);
         }
+        if (a.splice) {
+            // splice padding writes into low-depth columns in place: they must exist
+            int32_t *gcol = a.cols + (size_t)(t0 - a.reg_beg0) * C;
+            for (int i = tid; i < (t1 - t0) * C; i += SCAN_THREADS) gcol[i] = 0;
+            if (tid == 0) a.tile_cols[tile] = 1;
+        }
         return;
     }
     for (int i = tid; i < TILE * C; i += SCAN_THREADS) s_cnt[i] = 0;
@@ -544,6 +552,58 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Splice-junction padding, part 1 (src/create_tensor_pileup.py:151-178, :532-534): per row
+//   max_skip_count = max(#'$', #'^', #'<', #'>')
+// i.e. reads ending here, reads starting here, reverse / forward reads showing a ref-skip here.  Header-only: starts,
+// ends and per-strand read coverage come from the read spans, per-strand ALIGNED coverage from the segment spans, and
+// ref-skips = covering - aligned.  Same tile list as k_scan_tiles; only launched in splice-padding mode.
+__global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) {
+    __shared__ int32_t s_cov[2][TILE + 1];     // reads covering, by strand (difference arrays)
+    __shared__ int32_t s_seg[2][TILE + 1];     // aligned segments covering, by strand
+    __shared__ int32_t s_start[TILE], s_end[TILE];
+    __shared__ int s_w[WAVES];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= *a.n_tile_list) return;
+    const int tile = a.tile_list[blockIdx.x];
+    const int t0 = a.reg_beg0 + tile * TILE;
+    const int t1 = min(t0 + TILE, a.reg_end0);
+    const int4 rng = a.tile_rng[tile];
+    for (int i = tid; i < 2 * (TILE + 1); i += SCAN_THREADS) { (&s_cov[0][0])[i] = 0; (&s_seg[0][0])[i] = 0; }
+    s_start[tid] = 0; s_end[tid] = 0;
+    __syncthreads();
+    for (int r = rng.x + tid; r < rng.y; r += SCAN_THREADS) {
+        const DevRead rd = a.reads[r];
+        if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.pos >= t1) continue;
+        const int st = (rd.flag & 16) ? 1 : 0;
+        atomicAdd(&s_cov[st][max(rd.pos, t0) - t0], 1);
+        if (rd.end < t1) atomicAdd(&s_cov[st][rd.end - t0], -1);
+        if (rd.pos >= t0) atomicAdd(&s_start[rd.pos - t0], 1);
+        if (rd.end - 1 < t1) atomicAdd(&s_end[rd.end - 1 - t0], 1);
+    }
+    for (int g = rng.z + tid; g < rng.w; g += SCAN_THREADS) {
+        const DevSeg sg = a.segs[g];
+        if (!seg_passes(sg, a.min_mq, a.excl_flags) || sg.end <= t0 || sg.pos >= t1 || sg.end <= sg.pos) continue;
+        const int st = (sg.flag & 16) ? 1 : 0;
+        atomicAdd(&s_seg[st][max(sg.pos, t0) - t0], 1);
+        if (sg.end < t1) atomicAdd(&s_seg[st][sg.end - t0], -1);
+    }
+    __syncthreads();
+    int tot, v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = (k < 2) ? s_cov[k][tid] : s_seg[k - 2][tid];
+        v[k] = block_excl_scan(d, s_w, &tot) + d;
+    }
+    const int p = t0 + tid;
+    if (p < t1) {
+        const int gi = p - a.reg_beg0;
+        int m = max(s_start[tid], s_end[tid]);
+        m = max(m, max(v[0] - v[2], v[1] - v[3]));
+        a.skipmax[gi] = (a.flags[gi] & 1) ? m : 0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Window selection (src/create_tensor_pileup.py:512-516,565-568,613-637): a candidate is emitted iff
 // the 33 positions centre-16..centre+16 are contiguous rows; with head_tail the ring is pre-filled
 // with zero columns after every gap (left side always OK) and the stream end is flushed with 16
@@ -636,16 +696,14 @@ struct GatherArgs {
     int32_t head_tail; const int32_t *last_row;
     int32_t rescale; int32_t max_depth;   // 144
     int32_t *tensors;      // [n][33][C]
+    int32_t *raw;          // [n][33][C] un-rescaled copy (may be null)
+    const int32_t *skipmax; // splice-padding mode only
     c3r_site_t *sites;     // [n] (may be null)
     int32_t *tok_cnt;      // [n] (may be null): number of tokens of the centre column
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void k_gather(const GatherArgs g) {
-    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (w >= g.n_cand) return;
-    const int ci = g.cand_idx[w];
+__device__ __forceinline__ void gather_window(const GatherArgs &g, int w, int ci, int lane, const int32_t *zcol = nullptr) {
     int lo_valid = ci - C3R_FLANK, hi_valid = ci + C3R_FLANK;
     if (g.head_tail) {
         int q = ci;
@@ -657,11 +715,14 @@ __global__ __launch_bounds__(256) void k_gather(const GatherArgs g) {
     const bool scale = g.rescale && dep > 0 && (double)dep > (double)g.max_depth * 1.5;
     const double sf = (double)dep / (double)g.max_depth;
     int32_t *out = g.tensors + (size_t)w * C3R_WINDOW * C;
+    int32_t *raw = g.raw ? g.raw + (size_t)w * C3R_WINDOW * C : nullptr;
     const int first = ci - C3R_FLANK;
     for (int i = lane; i < C3R_WINDOW * C; i += 64) {
         const int q = first + i / C;
         int v = 0;
         if (q >= lo_valid && q <= hi_valid && g.tile_cols[q / TILE]) v = g.cols[(size_t)q * C + (i % C)];
+        else if (zcol && q < lo_valid) v = zcol[i % C];      // the run's shared pre-fill column (splice padding edits it)
+        if (raw) raw[i] = v;
         if (scale) v = (int32_t)((double)v / sf);
         out[i] = v;
     }
@@ -676,6 +737,100 @@ __global__ __launch_bounds__(256) void k_gather(const GatherArgs g) {
         if (lane == 0) { s->pos = g.reg_beg0 + ci + 1; s->depth = dep; s->n_tok = g.ncov[ci]; s->tok_off = 0; }
     }
     if (g.tok_cnt && lane == 0) g.tok_cnt[w] = g.ncov[ci];
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_gather(const GatherArgs g) {
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= g.n_cand) return;
+    gather_window<C>(g, w, g.cand_idx[w], lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Splice-junction padding, part 2 (src/create_tensor_pileup.py:573-593, :611).  The reference edits the ring's column
+// lists IN PLACE while it emits candidates in position order, so a window sees the edits made for every earlier
+// candidate within 32 bp, and `del depth_dict[center]` makes an emitted centre count as depth 0 for later windows.
+// Emitted candidates less than 33 bp apart therefore form a chain that has to be processed in order; chains are
+// independent.  One wavefront per chain (the wavefront of the chain's first candidate; the others exit), lane = window
+// slot: decide, edit the columns in HBM, then gather that candidate's window before moving on.
+__device__ __forceinline__ int pad_channel(uint8_t up, bool lower) {   // BASE2INDEX of a reference letter
+    switch (up) {
+        case 'A': return lower ? C3R_a : C3R_A;  case 'C': return lower ? C3R_c : C3R_C;
+        case 'G': return lower ? C3R_g : C3R_G;  case 'T': return lower ? C3R_t : C3R_T;
+        case 'I': return lower ? C3R_i : C3R_I;  case 'D': return lower ? C3R_d : C3R_D;   // IUPAC letters that are keys too
+        default: return -1;                                                                // (the reference raises KeyError)
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_splice_gather(const GatherArgs g) {
+    // with head/tail calling the ring is pre-filled after every gap with 33 references to ONE zero list
+    // ([[0]*C]*33, :467,:514): padding a slot left of the run start edits that shared list, and every such slot of
+    // this and later windows of the run shows it.  One copy per wavefront, keyed by the run start.
+    __shared__ int32_t s_z[4][C];
+    const int w0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    int32_t *zc = s_z[threadIdx.x >> 6];
+    if (w0 >= g.n_cand) return;
+    if (w0 > 0 && g.cand_idx[w0] - g.cand_idx[w0 - 1] <= 2 * C3R_FLANK) return;     // not the head of a chain
+    int32_t *cols = const_cast<int32_t *>(g.cols);
+    int z_run = INT32_MIN;
+    for (int w = w0; w < g.n_cand; ++w) {
+        const int ci = g.cand_idx[w];
+        if (w > w0 && ci - g.cand_idx[w - 1] > 2 * C3R_FLANK) break;
+        int lo_valid = ci - C3R_FLANK, hi_valid = ci + C3R_FLANK;
+        if (g.head_tail) {
+            int qq = ci;
+            while (qq - 1 >= 0 && qq - 1 >= ci - C3R_FLANK && (g.flags[qq - 1] & 1)) --qq;
+            lo_valid = qq;
+            hi_valid = min(ci + C3R_FLANK, *g.last_row - g.reg_beg0);
+            if (lo_valid > ci - C3R_FLANK && lo_valid != z_run) {       // first window of a new run: fresh zero list
+                for (int i = lane; i < C; i += 64) zc[i] = 0;
+                z_run = lo_valid;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        const int q = ci - C3R_FLANK + lane;                   // lane < 33: window slot
+        const bool in_win = lane < C3R_WINDOW;
+        const bool real = in_win && q >= lo_valid && q <= hi_valid;      // has a pileup row (is in depth_dict)
+        // depth_dict lookup: entries of already-emitted centres (all of them left of ci) have been deleted
+        const bool deleted = real && q < ci && (g.flags[q] & 4);
+        const int cur = (real && !deleted) ? g.depth[q] : 0;
+        int md = (real && !deleted) ? cur : INT32_MIN;
+        int ms = real ? g.skipmax[q] : INT32_MIN;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { md = max(md, __shfl_xor(md, off, 64)); ms = max(ms, __shfl_xor(ms, off, 64)); }
+        const int cdepth = g.depth[ci];
+        // candidates closer than 16 rows to the end of the stream leave through the tail flush, which does not pad (:613-637)
+        const bool pads = hi_valid == ci + C3R_FLANK;
+        if (pads && (double)ms / (double)md > 0.2) {
+            const int rp = g.reg_beg0 + ci - g.ref_beg0;
+            const uint8_t rc = (rp >= 0 && rp < g.ref_len) ? g.ref[rp] : (uint8_t)'N';
+            const int cu = pad_channel(rc, false), cl = pad_channel(rc, true);
+            int sf = cu >= 0 ? cols[(size_t)ci * C + cu] : 0, sr = cl >= 0 ? cols[(size_t)ci * C + cl] : 0;
+            sf = sf < 0 ? -sf : sf; sr = sr < 0 ? -sr : sr;
+            const double fpct = (sf + sr > 0) ? (double)sf / (double)(sf + sr) : 0.0;
+            const double rpct = 1 - fpct;
+            if (in_win && lane != C3R_FLANK && (double)cur < (double)cdepth * 0.2) {
+                int rq = g.reg_beg0 + q - g.ref_beg0;
+                if (rq < 0) rq += g.ref_len;                  // Python negative index (slots left of the contig start)
+                const uint8_t rb = (rq >= 0 && rq < g.ref_len) ? g.ref[rq] : (uint8_t)'N';
+                const int u = pad_channel(rb, false), l = pad_channel(rb, true);
+                if (u >= 0) {
+                    const int vf = -1 * (int)((double)cdepth * fpct), vr = -1 * (int)((double)cdepth * rpct);
+                    if (real) { cols[(size_t)q * C + u] = vf; cols[(size_t)q * C + l] = vr; }
+                    else if (q < lo_valid) { zc[u] = vf; zc[l] = vr; }     // (every such lane writes the same two values)
+                }
+            }
+            __threadfence();
+            __builtin_amdgcn_wave_barrier();
+        }
+        gather_window<C>(g, w, ci, lane, g.head_tail ? zc : nullptr);
+        __threadfence();
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // -------------------------------------------------------------------------------------------------

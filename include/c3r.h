@@ -54,7 +54,8 @@ void *c3r_stream(c3r_ctx *ctx);
  * shared/param_p.py:20,41,88-90). */
 void c3r_default_params(c3r_params_t *p);
 /* Replaces the argparse surface of src/create_tensor_pileup.py:660-778 that affects tensors.
- * Returns C3R_EUNSUPPORTED for splice_padding=1 (see DESIGN.md "Out of scope"). */
+ * splice_padding=1 (src/create_tensor_pileup.py:573-593) is supported, also together with head_tail=1
+ * (including the reference's shared pre-fill column, [[0]*C]*33, that padding edits in place). */
 int c3r_set_params(c3r_ctx *ctx, const c3r_params_t *p);
 
 /* ---- inputs -------------------------------------------------------------------------------- */

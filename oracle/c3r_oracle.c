@@ -660,7 +660,9 @@ char *orc_create_tensor(const char *rows_text, const char *ctg, const char *ref_
                                 if (pinfo[k].pos == pp) { cur = pinfo[k].has_depth ? pinfo[k].depth : 0; break; }
                             }
                             if (cur < cdepth * 0.2 && idx != C3R_FLANK) {
-                                char rb = (char)toupper((unsigned char)ref_seq[pp - reference_start]);
+                                int64_t ri = pp - reference_start;
+                                if (ri < 0) ri += ref_len;   /* Python negative index: head slots left of the reference slice */
+                                char rb = (char)toupper((unsigned char)ref_seq[ri]);
                                 win[idx][chan_of_char(rb)] = -1 * (int)(cdepth * fpct);
                                 win[idx][chan_of_char((char)tolower((unsigned char)rb))] = -1 * (int)(cdepth * rpct);
                             }

@@ -94,3 +94,26 @@ def test_config2_many_contigs_lpt_order(eng):
             assert got["lines"] == exp["lines"], (ci, H.first_diff(got["lines"], exp["lines"]))
             if len(exp["X"]):
                 assert np.abs(eng.infer() - orc.forward(w, exp["X"])).max() < 1e-4
+
+
+@pytest.mark.parametrize("channels,seed,head_tail", [(18, 41, 0), (30, 42, 0), (18, 43, 0), (18, 44, 1), (30, 45, 1)])
+def test_splice_junction_padding_matches_reference_order_semantics(eng, channels, seed, head_tail):
+    """--enable_padding_in_splice_junction_regions (src/create_tensor_pileup.py:573-593): in-place column edits that
+    persist into later windows, `del depth_dict[center]`, max_skip_count from read starts/ends/ref-skips; with
+    head/tail calling also the shared pre-fill column ([[0]*C]*33) that padding edits."""
+    from clair3_rna_amd import synth
+    L = 400000
+    # short exons, many reads ending inside exons and low-depth exon edges: padding triggers often
+    ref, rs, info = synth.generate_contig(contig_len=L, seed=seed, depth=25.0, expressed_frac=0.06, intron_lo=100.0, intron_hi=3000.0,
+                                          phased=(channels == 30))
+    ref = ref.decode()
+    _fresh(eng, channels=channels, splice_padding=1, head_tail=head_tail)
+    got = H.engine_chunk(eng, rs, ref, 1, 1, L)
+    exp = H.oracle_chunk(rs, ref, 1, 1, L, channels=channels, splice_padding=True, head_tail=bool(head_tail))
+    plain = H.oracle_chunk(rs, ref, 1, 1, L, channels=channels, head_tail=bool(head_tail))
+    assert len(exp["lines"]) > 100 and len(exp["lines"]) == len(plain["lines"])
+    n_changed = sum(a != b for a, b in zip(exp["lines"], plain["lines"]))
+    assert n_changed > 20, n_changed                     # the option actually changes windows on this input
+    assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
+    assert np.array_equal(got["X"], exp["X"])
+    _fresh(eng)
