@@ -160,7 +160,7 @@ def Run(args, engine=None):
     eng.set_params(channels=channels, min_mq=args.minMQ, min_coverage=args.minCoverage, snp_min_af=args.snp_min_af,
                    indel_min_af=args.indel_min_af, head_tail=int(args.enable_variant_calling_at_sequence_head_and_tail),
                    splice_padding=int(args.enable_padding_in_splice_junction_regions), genotyping_mode=int(sites is not None))
-    rs = io.load_reads(args.bam_fn, ctg)
+    rs = io.load_reads(args.bam_fn, ctg, extend_start - 1, extend_end)      # mpileup -r ctg:extend_start-extend_end
     eng.load_reads(rs)
     eng.set_reference(ref_start, ref_seq)
     eng.load_weights(io.load_weights(args.chkpnt_fn, channels), channels)

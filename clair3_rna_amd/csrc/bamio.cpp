@@ -1,0 +1,562 @@
+// bamio.cpp — libc3r_io.so: BAM / BGZF / BAI reader producing the flat read records of c3r_load_reads.
+// C ABI in include/c3r_io.h.  Host-only (g++ -O2 -pthread -lz).
+//
+// What it replaces: the input side of `samtools mpileup <bam> -r ctg:beg-end --output-extra HP`
+// (reference src/create_tensor_pileup.py:436-451).  Formats follow the SAM/BAM specification v1 (§4 BAM, §4.1 BGZF,
+// §5.2 BAI: UCSC binning with 16 kb linear index); nothing here is derived from htslib sources.
+//
+//   indexed fetch ..... reg2bins -> chunk list (clipped by the linear index) -> inflate only those BGZF blocks
+//   full load ......... block table from the BGZF headers, blocks inflated by a thread pool in batches, records parsed
+//                       in file order with early exit once the contig is passed
+//   index build ....... one pass over the records with their virtual offsets (`samtools index` equivalent)
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/c3r.h"
+#include "../../include/c3r_io.h"
+
+namespace {
+
+struct Mapped {
+    const uint8_t *p = nullptr; size_t n = 0; int fd = -1;
+    bool open(const char *path) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        n = (size_t)st.st_size;
+        if (n == 0) { p = nullptr; return true; }
+        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return false;
+        p = (const uint8_t *)m;
+        return true;
+    }
+    void close() {
+        if (p) munmap((void *)p, n);
+        if (fd >= 0) ::close(fd);
+        p = nullptr; fd = -1; n = 0;
+    }
+};
+
+inline uint16_t le16(const uint8_t *q) { return (uint16_t)(q[0] | (q[1] << 8)); }
+inline uint32_t le32(const uint8_t *q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); }
+inline int32_t le32s(const uint8_t *q) { return (int32_t)le32(q); }
+inline uint64_t le64(const uint8_t *q) { return (uint64_t)le32(q) | ((uint64_t)le32(q + 4) << 32); }
+
+// BGZF block at file offset `off`: total size and the position of the deflate payload.  0 on malformed input.
+size_t bgzf_block_size(const uint8_t *f, size_t n, size_t off, size_t *payload_off) {
+    if (off + 18 > n) return 0;
+    const uint8_t *h = f + off;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return 0;
+    const size_t xlen = le16(h + 10);
+    if (off + 12 + xlen > n) return 0;
+    size_t p = 12, bsize = 0;
+    while (p + 4 <= 12 + xlen) {
+        const uint8_t si1 = h[p], si2 = h[p + 1];
+        const size_t slen = le16(h + p + 2);
+        if (si1 == 66 && si2 == 67 && slen == 2) bsize = (size_t)le16(h + p + 4) + 1;
+        p += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8 || off + bsize > n) return 0;
+    *payload_off = 12 + xlen;
+    return bsize;
+}
+
+struct Inflater {
+    z_stream zs; bool ok;
+    Inflater() { memset(&zs, 0, sizeof zs); ok = inflateInit2(&zs, -15) == Z_OK; }
+    ~Inflater() { if (ok) inflateEnd(&zs); }
+    // raw-deflate payload -> dst (isize bytes expected)
+    bool run(const uint8_t *src, size_t n_src, uint8_t *dst, size_t isize) {
+        if (!ok) return false;
+        if (isize == 0) return true;
+        inflateReset(&zs);
+        zs.next_in = const_cast<Bytef *>(src); zs.avail_in = (uInt)n_src;
+        zs.next_out = dst; zs.avail_out = (uInt)isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        return rc == Z_STREAM_END && zs.avail_out == 0;
+    }
+};
+
+// ---- sequential reader over virtual offsets (coffset << 16 | uoffset), used by the indexed fetch
+struct BgzfCursor {
+    const uint8_t *f; size_t n;
+    Inflater inf;
+    std::vector<uint8_t> buf;   // current block, inflated
+    size_t coff = 0, bsize = 0, upos = 0;
+    bool load(size_t off) {
+        size_t pl;
+        const size_t bs = bgzf_block_size(f, n, off, &pl);
+        if (!bs) return false;
+        const size_t isize = le32(f + off + bs - 4);
+        buf.resize(isize);
+        if (!inf.run(f + off + pl, bs - pl - 8, buf.data(), isize)) return false;
+        coff = off; bsize = bs; upos = 0;
+        return true;
+    }
+    bool seek(uint64_t voff) {
+        if (!load((size_t)(voff >> 16))) return false;
+        upos = (size_t)(voff & 0xffff);
+        return upos <= buf.size();
+    }
+    uint64_t tell() const { return ((uint64_t)coff << 16) | (uint64_t)upos; }
+    // 1 ok, 0 clean EOF before the first byte, -1 error / truncated
+    int read(uint8_t *dst, size_t len) {
+        size_t got = 0;
+        while (got < len) {
+            if (upos == buf.size()) {
+                const size_t next = coff + bsize;
+                if (next >= n) return got == 0 ? 0 : -1;
+                if (!load(next)) return -1;
+                continue;                      // (an empty block, e.g. the EOF marker, just moves on)
+            }
+            const size_t k = std::min(len - got, buf.size() - upos);
+            memcpy(dst + got, buf.data() + upos, k);
+            got += k; upos += k;
+        }
+        return 1;
+    }
+};
+
+// ---- UCSC binning (SAM spec §5.3)
+inline int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+inline void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t> &out) {
+    --end;
+    out.push_back(0);
+    for (int64_t k = 1 + (beg >> 26); k <= 1 + (end >> 26); ++k) out.push_back((uint32_t)k);
+    for (int64_t k = 9 + (beg >> 23); k <= 9 + (end >> 23); ++k) out.push_back((uint32_t)k);
+    for (int64_t k = 73 + (beg >> 20); k <= 73 + (end >> 20); ++k) out.push_back((uint32_t)k);
+    for (int64_t k = 585 + (beg >> 17); k <= 585 + (end >> 17); ++k) out.push_back((uint32_t)k);
+    for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (end >> 14); ++k) out.push_back((uint32_t)k);
+}
+
+struct RefIndex {
+    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+    std::vector<uint64_t> linear;
+};
+
+}  // namespace
+
+struct c3r_bam {
+    Mapped file;
+    std::string path, err;
+    std::vector<std::string> names;
+    std::vector<int64_t> lens;
+    uint64_t first_record_voff = 0;     // virtual offset of the first alignment
+    size_t header_bytes = 0;            // uncompressed size of header + reference list
+    bool has_bai = false;
+    std::vector<RefIndex> bai;
+    int n_threads = 1;
+    // result of the last fetch
+    std::vector<c3r_read_t> reads;
+    std::vector<uint32_t> cigar;
+    std::vector<uint8_t> seq;
+};
+
+namespace {
+
+int failb(c3r_bam *b, int code, const char *fmt, ...) {
+    char tmp[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(tmp, sizeof tmp, fmt, ap); va_end(ap);
+    if (b) b->err = tmp;
+    return code;
+}
+
+// Append one alignment (pointer to the 32 fixed bytes after block_size) if it belongs to (tid, [beg,end)).
+// Returns 1 appended, 0 skipped, 2 = past the region (sorted input: the caller may stop).
+int take_record(c3r_bam *b, const uint8_t *r, size_t block_size, int tid, int64_t beg, int64_t end) {
+    if (block_size < 32) return 0;
+    const int32_t ref_id = le32s(r), pos = le32s(r + 4);
+    const uint32_t l_read_name = r[8], mapq = r[9];
+    uint32_t n_cig = le16(r + 12);
+    const uint32_t flag = le16(r + 14);
+    const uint32_t l_seq = le32(r + 16);
+    if (ref_id != tid) return (ref_id > tid || ref_id < 0) ? 2 : 0;
+    if (pos < 0) return 0;
+    if (end > 0 && pos >= end) return 2;
+    const size_t c0 = 32 + l_read_name, s0 = c0 + 4 * (size_t)n_cig, nb = ((size_t)l_seq + 1) / 2, a0 = s0 + nb + l_seq;
+    if (a0 > block_size) return 0;
+    const uint8_t *cig = r + c0;
+    // aux: HP (any integer type) and CG:B,I (real CIGAR of reads with > 65535 ops, SAM spec §4.2.2)
+    uint32_t hp = 0; const uint8_t *cg = nullptr; uint32_t cg_n = 0;
+    size_t p = a0;
+    while (p + 3 <= block_size) {
+        const uint8_t t0 = r[p], t1 = r[p + 1], ty = r[p + 2];
+        p += 3;
+        size_t sz = 0;
+        switch (ty) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': { while (p < block_size && r[p]) ++p; ++p; continue; }
+            case 'B': {
+                if (p + 5 > block_size) { p = block_size; continue; }
+                const uint8_t sub = r[p]; const uint32_t cnt = le32(r + p + 1);
+                const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg = r + p + 5; cg_n = cnt; }
+                p += 5 + (size_t)cnt * es;
+                continue;
+            }
+            default: p = block_size; continue;   // unknown type: stop scanning
+        }
+        if (p + sz > block_size) break;
+        if (t0 == 'H' && t1 == 'P' && ty != 'A' && ty != 'f') {
+            int64_t v = 0;
+            switch (ty) {
+                case 'c': v = (int8_t)r[p]; break;  case 'C': v = r[p]; break;
+                case 's': v = (int16_t)le16(r + p); break;  case 'S': v = le16(r + p); break;
+                case 'i': v = le32s(r + p); break;  case 'I': v = le32(r + p); break;
+            }
+            hp = (v > 0 && v < 256) ? (uint32_t)v : 0;
+        }
+        p += sz;
+    }
+    if (cg && n_cig == 2 && (le32(cig) & 15) == 4 && (le32(cig) >> 4) == l_seq && (le32(cig + 4) & 15) == 3) { cig = cg; n_cig = cg_n; }
+    if (n_cig == 0) return 0;
+    int64_t rlen = 0;
+    for (uint32_t k = 0; k < n_cig; ++k) {
+        const uint32_t c = le32(cig + 4 * k), op = c & 15;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += c >> 4;
+    }
+    if ((int64_t)pos + std::max<int64_t>(rlen, 1) <= beg) return 0;
+    c3r_read_t o;
+    memset(&o, 0, sizeof o);
+    o.pos = pos; o.cigar_off = (uint32_t)b->cigar.size(); o.n_cigar = n_cig; o.l_seq = l_seq; o.seq_off = (uint64_t)b->seq.size();
+    o.flag = (uint16_t)flag; o.mapq = (uint8_t)mapq; o.hp = (uint8_t)hp;
+    b->reads.push_back(o);
+    const size_t cb = b->cigar.size();
+    b->cigar.resize(cb + n_cig);
+    for (uint32_t k = 0; k < n_cig; ++k) b->cigar[cb + k] = le32(cig + 4 * k);
+    b->seq.insert(b->seq.end(), r + s0, r + s0 + nb);
+    return 1;
+}
+
+// ---- header (through a cursor: it may span BGZF blocks)
+int parse_header(c3r_bam *b) {
+    BgzfCursor cur; cur.f = b->file.p; cur.n = b->file.n;
+    if (!cur.load(0)) return failb(b, C3R_EINVAL, "%s: not a BGZF file", b->path.c_str());
+    uint8_t h[12];
+    if (cur.read(h, 8) != 1 || memcmp(h, "BAM\1", 4) != 0) return failb(b, C3R_EINVAL, "%s: bad BAM magic", b->path.c_str());
+    const int32_t l_text = le32s(h + 4);
+    std::vector<uint8_t> tmp((size_t)std::max(l_text, 0));
+    if (l_text > 0 && cur.read(tmp.data(), (size_t)l_text) != 1) return failb(b, C3R_EINVAL, "%s: truncated header", b->path.c_str());
+    if (cur.read(h, 4) != 1) return failb(b, C3R_EINVAL, "%s: truncated header", b->path.c_str());
+    const int32_t n_ref = le32s(h);
+    size_t total = 12 + (size_t)std::max(l_text, 0);
+    for (int i = 0; i < n_ref; ++i) {
+        if (cur.read(h, 4) != 1) return failb(b, C3R_EINVAL, "%s: truncated reference list", b->path.c_str());
+        const int32_t l_name = le32s(h);
+        std::vector<uint8_t> nm((size_t)l_name + 4);
+        if (cur.read(nm.data(), (size_t)l_name + 4) != 1) return failb(b, C3R_EINVAL, "%s: truncated reference list", b->path.c_str());
+        b->names.emplace_back((const char *)nm.data(), (size_t)std::max(l_name - 1, 0));
+        b->lens.push_back(le32s(nm.data() + l_name));
+        total += 8 + (size_t)l_name;
+    }
+    b->header_bytes = total;
+    if (cur.upos == cur.buf.size() && cur.coff + cur.bsize < cur.n) cur.load(cur.coff + cur.bsize);   // normalise like tell() after a read
+    b->first_record_voff = cur.tell();
+    return C3R_OK;
+}
+
+int load_bai(c3r_bam *b, const std::string &p) {
+    Mapped m;
+    if (!m.open(p.c_str())) return 1;
+    int rc = 1;
+    do {
+        if (m.n < 8 || memcmp(m.p, "BAI\1", 4) != 0) break;
+        size_t o = 4;
+        const int32_t n_ref = le32s(m.p + o); o += 4;
+        std::vector<RefIndex> idx((size_t)std::max(n_ref, 0));
+        bool bad = false;
+        for (int r = 0; r < n_ref && !bad; ++r) {
+            if (o + 4 > m.n) { bad = true; break; }
+            const int32_t n_bin = le32s(m.p + o); o += 4;
+            for (int k = 0; k < n_bin; ++k) {
+                if (o + 8 > m.n) { bad = true; break; }
+                const uint32_t bin = le32(m.p + o); const int32_t n_chunk = le32s(m.p + o + 4); o += 8;
+                if (o + 16 * (size_t)n_chunk > m.n) { bad = true; break; }
+                if (bin != 37450) {   // (37450 = metadata pseudo-bin)
+                    auto &v = idx[r].bins[bin];
+                    for (int c = 0; c < n_chunk; ++c) v.emplace_back(le64(m.p + o + 16 * c), le64(m.p + o + 16 * c + 8));
+                }
+                o += 16 * (size_t)n_chunk;
+            }
+            if (bad || o + 4 > m.n) { bad = true; break; }
+            const int32_t n_intv = le32s(m.p + o); o += 4;
+            if (o + 8 * (size_t)n_intv > m.n) { bad = true; break; }
+            idx[r].linear.resize((size_t)n_intv);
+            for (int i = 0; i < n_intv; ++i) idx[r].linear[i] = le64(m.p + o + 8 * i);
+            o += 8 * (size_t)n_intv;
+        }
+        if (bad || (size_t)n_ref != b->names.size()) break;
+        b->bai.swap(idx); b->has_bai = true; rc = 0;
+    } while (0);
+    m.close();
+    return rc;
+}
+
+int fetch_indexed(c3r_bam *b, int tid, int64_t beg, int64_t end) {
+    const RefIndex &ri = b->bai[tid];
+    std::vector<uint32_t> bins;
+    reg2bins(beg, end, bins);
+    uint64_t min_off = 0;
+    const size_t w = (size_t)(beg >> 14);
+    if (!ri.linear.empty()) min_off = ri.linear[std::min(w, ri.linear.size() - 1)];
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    for (uint32_t bin : bins) {
+        auto it = ri.bins.find(bin);
+        if (it == ri.bins.end()) continue;
+        for (auto &c : it->second) if (c.second > min_off) chunks.emplace_back(std::max(c.first, min_off), c.second);
+    }
+    std::sort(chunks.begin(), chunks.end());
+    // merge overlapping / adjacent chunks so that no record is read twice
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    for (auto &c : chunks) {
+        if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second);
+        else merged.push_back(c);
+    }
+    BgzfCursor cur; cur.f = b->file.p; cur.n = b->file.n;
+    std::vector<uint8_t> rec;
+    for (auto &c : merged) {
+        if (!cur.seek(c.first)) return failb(b, C3R_EINVAL, "%s: index points outside the file", b->path.c_str());
+        for (;;) {
+            if (cur.upos == cur.buf.size() && cur.coff + cur.bsize < cur.n && !cur.load(cur.coff + cur.bsize))
+                return failb(b, C3R_EINVAL, "%s: corrupt BGZF block", b->path.c_str());
+            if (cur.tell() >= c.second) break;
+            uint8_t h[4];
+            const int g = cur.read(h, 4);
+            if (g == 0) break;
+            if (g < 0) return failb(b, C3R_EINVAL, "%s: truncated record", b->path.c_str());
+            const size_t bs = le32(h);
+            rec.resize(bs);
+            if (cur.read(rec.data(), bs) != 1) return failb(b, C3R_EINVAL, "%s: truncated record", b->path.c_str());
+            if (take_record(b, rec.data(), bs, tid, beg, end) == 2) return C3R_OK;   // sorted: nothing further can overlap
+        }
+    }
+    return C3R_OK;
+}
+
+struct BlockRef { size_t off, payload, bsize, isize; };
+
+// Whole-file pass: batches of blocks inflated in parallel, records handed to `visit(rec, block_size, voff_begin, voff_end)`
+// in file order; visit returns false to stop.
+template <class F>
+int scan_all(c3r_bam *b, F visit) {
+    const uint8_t *f = b->file.p; const size_t n = b->file.n;
+    std::vector<BlockRef> blocks;
+    for (size_t off = 0; off < n;) {
+        size_t pl;
+        const size_t bs = bgzf_block_size(f, n, off, &pl);
+        if (!bs) return failb(b, C3R_EINVAL, "%s: corrupt BGZF block at %zu", b->path.c_str(), off);
+        blocks.push_back({off, pl, bs, le32(f + off + bs - 4)});
+        off += bs;
+    }
+    size_t BATCH = 512;                   // blocks inflated per round (<= 32 MB of records in memory)
+    if (const char *e = getenv("C3R_IO_BATCH")) BATCH = (size_t)std::max(1, atoi(e));   // tests: force records across rounds
+    const int nt = std::max(1, b->n_threads);
+    std::vector<uint8_t> carry;           // partial record bytes from the previous batch
+    uint64_t carry_first_voff = 0;
+    std::vector<uint8_t> buf;
+    std::vector<size_t> uoff;
+    size_t skip = b->header_bytes;        // uncompressed bytes of header still to skip
+    bool stop = false;
+    for (size_t b0 = 0; b0 < blocks.size() && !stop; b0 += BATCH) {
+        const size_t b1 = std::min(blocks.size(), b0 + BATCH);
+        uoff.assign(b1 - b0 + 1, 0);
+        for (size_t i = b0; i < b1; ++i) uoff[i - b0 + 1] = uoff[i - b0] + blocks[i].isize;
+        buf.resize(uoff.back());
+        std::atomic<size_t> next(b0);
+        std::atomic<bool> bad(false);
+        auto work = [&]() {
+            Inflater inf;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= b1) break;
+                const BlockRef &k = blocks[i];
+                if (!inf.run(f + k.off + k.payload, k.bsize - k.payload - 8, buf.data() + uoff[i - b0], k.isize)) bad = true;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        if (bad) return failb(b, C3R_EINVAL, "%s: inflate failed", b->path.c_str());
+        // virtual offset of byte u of this batch, in the canonical form a reader's tell() has after consuming byte u-1:
+        // inside a block (coffset, u - block start); exactly at a block's end the address of the block that follows
+        // (empty blocks hold no byte and are never chosen, so the value does not depend on how blocks are batched)
+        auto voff_of = [&](size_t u) -> uint64_t {
+            if (u == 0) return (uint64_t)blocks[b0].off << 16;
+            const size_t j = (size_t)(std::upper_bound(uoff.begin(), uoff.end(), u - 1) - uoff.begin()) - 1;
+            const BlockRef &k = blocks[b0 + j];
+            if (u == uoff[j + 1]) return (uint64_t)(k.off + k.bsize) << 16;
+            return ((uint64_t)k.off << 16) | (uint64_t)(u - uoff[j]);
+        };
+        size_t u = 0;
+        if (skip) { const size_t k = std::min(skip, buf.size()); u = k; skip -= k; if (skip) continue; }
+        // finish a carried record first
+        if (!carry.empty()) {
+            while (carry.size() < 4 && u < buf.size()) carry.push_back(buf[u++]);
+            if (carry.size() < 4) continue;
+            const size_t bs = le32(carry.data());
+            while (carry.size() < 4 + bs && u < buf.size()) carry.push_back(buf[u++]);
+            if (carry.size() < 4 + bs) continue;
+            if (!visit(carry.data() + 4, bs, carry_first_voff, voff_of(u))) { stop = true; break; }
+            carry.clear();
+        }
+        while (u < buf.size()) {
+            if (u + 4 > buf.size() || u + 4 + le32(buf.data() + u) > buf.size()) {
+                carry.assign(buf.begin() + (long)u, buf.end());
+                carry_first_voff = voff_of(u);
+                break;
+            }
+            const size_t bs = le32(buf.data() + u);
+            if (!visit(buf.data() + u + 4, bs, voff_of(u), voff_of(u + 4 + bs))) { stop = true; break; }
+            u += 4 + bs;
+        }
+    }
+    return C3R_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int c3r_bam_open(const char *path, int n_threads, c3r_bam **out) {
+    if (!path || !out) return C3R_EINVAL;
+    c3r_bam *b = new c3r_bam();
+    b->path = path;
+    b->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    *out = b;                      // handed back even on failure so that the caller can read the message
+    if (!b->file.open(path)) return failb(b, C3R_EINVAL, "%s: cannot open", path);
+    int rc = parse_header(b);
+    if (rc) return rc;
+    std::string p1 = b->path + ".bai", p2;
+    if (b->path.size() > 4 && b->path.compare(b->path.size() - 4, 4, ".bam") == 0) p2 = b->path.substr(0, b->path.size() - 4) + ".bai";
+    if (load_bai(b, p1) != 0 && !p2.empty()) load_bai(b, p2);
+    return C3R_OK;
+}
+
+void c3r_bam_close(c3r_bam *b) {
+    if (!b) return;
+    b->file.close();
+    delete b;
+}
+
+const char *c3r_bam_last_error(c3r_bam *b) { return b ? b->err.c_str() : "null handle"; }
+int c3r_bam_n_contigs(c3r_bam *b) { return b ? (int)b->names.size() : C3R_EINVAL; }
+int c3r_bam_has_index(c3r_bam *b) { return b && b->has_bai ? 1 : 0; }
+
+int c3r_bam_contig(c3r_bam *b, int i, const char **name, int64_t *length) {
+    if (!b || i < 0 || i >= (int)b->names.size()) return C3R_EINVAL;
+    if (name) *name = b->names[(size_t)i].c_str();
+    if (length) *length = b->lens[(size_t)i];
+    return C3R_OK;
+}
+
+int c3r_bam_fetch(c3r_bam *b, const char *contig, int64_t beg0, int64_t end0, int64_t *n_reads, int64_t *n_cigar, int64_t *n_seq_bytes) {
+    if (!b || !contig) return C3R_EINVAL;
+    b->reads.clear(); b->cigar.clear(); b->seq.clear();
+    int tid = -1;
+    for (size_t i = 0; i < b->names.size(); ++i) if (b->names[i] == contig) { tid = (int)i; break; }
+    int rc = C3R_OK;
+    if (tid >= 0) {
+        if (beg0 < 0) beg0 = 0;
+        if (end0 <= 0) end0 = std::max<int64_t>(b->lens[(size_t)tid], (int64_t)1 << 29);
+        if (b->has_bai) {
+            rc = fetch_indexed(b, tid, beg0, end0);
+        } else {
+            rc = scan_all(b, [&](const uint8_t *r, size_t bs, uint64_t, uint64_t) { return take_record(b, r, bs, tid, beg0, end0) != 2; });
+        }
+    }
+    if (n_reads) *n_reads = (int64_t)b->reads.size();
+    if (n_cigar) *n_cigar = (int64_t)b->cigar.size();
+    if (n_seq_bytes) *n_seq_bytes = (int64_t)b->seq.size();
+    return rc;
+}
+
+int c3r_bam_copy(c3r_bam *b, c3r_read_t *reads, uint32_t *cigar, uint8_t *seq) {
+    if (!b) return C3R_EINVAL;
+    if (reads && !b->reads.empty()) memcpy(reads, b->reads.data(), b->reads.size() * sizeof(c3r_read_t));
+    if (cigar && !b->cigar.empty()) memcpy(cigar, b->cigar.data(), b->cigar.size() * 4);
+    if (seq && !b->seq.empty()) memcpy(seq, b->seq.data(), b->seq.size());
+    return C3R_OK;
+}
+
+int c3r_bam_index_build(const char *bam_path, const char *bai_path) {
+    if (!bam_path || !bai_path) return C3R_EINVAL;
+    c3r_bam *b = nullptr;
+    int rc = c3r_bam_open(bam_path, 0, &b);
+    if (rc) { c3r_bam_close(b); return rc; }
+    const size_t n_ref = b->names.size();
+    std::vector<RefIndex> idx(n_ref);
+    int32_t last_tid = -1, last_pos = -1;
+    bool unsorted = false;
+    rc = scan_all(b, [&](const uint8_t *r, size_t bs, uint64_t v0, uint64_t v1) {
+        if (bs < 32) return true;
+        const int32_t tid = le32s(r), pos = le32s(r + 4);
+        if (tid < 0 || (size_t)tid >= n_ref || pos < 0) return true;        // unplaced reads are not indexed
+        if (tid < last_tid || (tid == last_tid && pos < last_pos)) { unsorted = true; return false; }
+        last_tid = tid; last_pos = pos;
+        const uint32_t l_read_name = r[8], n_cig = le16(r + 12);
+        int64_t rlen = 0;
+        const uint8_t *cig = r + 32 + l_read_name;
+        if (32 + l_read_name + 4 * (size_t)n_cig <= bs)
+            for (uint32_t k = 0; k < n_cig; ++k) { const uint32_t c = le32(cig + 4 * k), op = c & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += c >> 4; }
+        const int64_t beg = pos, end = pos + std::max<int64_t>(rlen, 1);
+        RefIndex &ri = idx[(size_t)tid];
+        auto &ch = ri.bins[(uint32_t)reg2bin(beg, end)];
+        if (!ch.empty() && ch.back().second == v0) ch.back().second = v1; else ch.emplace_back(v0, v1);
+        const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+        if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, 0);
+        for (size_t w = w0; w <= w1; ++w) if (ri.linear[w] == 0) ri.linear[w] = v0;
+        return true;
+    });
+    if (rc == C3R_OK && unsorted) rc = failb(b, C3R_EINVAL, "%s: not coordinate-sorted", bam_path);
+    if (rc == C3R_OK) {
+        // windows no read starts in inherit the offset of the next populated window's predecessor (spec: fill from the left)
+        for (auto &ri : idx) for (size_t w = 1; w < ri.linear.size(); ++w) if (ri.linear[w] == 0) ri.linear[w] = ri.linear[w - 1];
+        FILE *fo = fopen(bai_path, "wb");
+        if (!fo) rc = failb(b, C3R_EINVAL, "%s: cannot write", bai_path);
+        else {
+            auto w32 = [&](uint32_t v) { fwrite(&v, 4, 1, fo); };
+            auto w64 = [&](uint64_t v) { fwrite(&v, 8, 1, fo); };
+            fwrite("BAI\1", 1, 4, fo); w32((uint32_t)n_ref);
+            for (auto &ri : idx) {
+                w32((uint32_t)ri.bins.size());
+                for (auto &kv : ri.bins) {
+                    w32(kv.first); w32((uint32_t)kv.second.size());
+                    for (auto &c : kv.second) { w64(c.first); w64(c.second); }
+                }
+                w32((uint32_t)ri.linear.size());
+                for (uint64_t v : ri.linear) w64(v);
+            }
+            fclose(fo);
+        }
+    }
+    c3r_bam_close(b);
+    return rc;
+}
+
+}  // extern "C"

@@ -119,16 +119,19 @@ def save_reads(path, contig_reads):
     np.savez(path, **arrs)
 
 
-def load_reads(path, contig):
-    """Read source of the per-chunk driver.  *.npz = flat read archive; *.bam = BGZF/BAM (bam.py)."""
+def load_reads(path, contig, beg0=None, end0=None):
+    """Read source of the per-chunk driver.  *.npz = flat read archive; *.bam = BGZF/BAM through libc3r_io.so
+    (csrc/bamio.cpp): with a .bai only the BGZF blocks holding alignments that overlap the 0-based half-open region
+    [beg0, end0) are inflated — the `-r ctg:beg-end` of the reference's mpileup call (create_tensor_pileup.py:446-451)."""
     if path.endswith(".npz"):
         z = np.load(path)
         key = "reads__" + contig
         if key not in z.files:
             return ReadSet(np.zeros(0, READ_DTYPE), np.zeros(0, np.uint32), np.zeros(0, np.uint8))
         return ReadSet(z[key], z["cigar__" + contig], z["seq__" + contig])
-    from . import bam
-    return bam.read_contig(path, contig)
+    from . import bamio
+    with bamio.BamFile(path) as bf:
+        return bf.fetch(contig, beg0 or 0, end0)
 
 
 # ----------------------------------------------------------------------------- weights

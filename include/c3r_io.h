@@ -1,0 +1,54 @@
+/* c3r_io.h — C ABI of libc3r_io.so: BAM/BGZF/BAI -> the flat read records c3r_load_reads takes.
+ *
+ * Replaces the input side of the reference's `samtools mpileup <bam> -r ctg:beg-end` subprocess
+ * (src/create_tensor_pileup.py:436-451; region set-up :409-428): open the BAM, use its .bai to find the
+ * alignments overlapping the region, and hand back exactly the fields the tensor builder reads — core.pos,
+ * flag, MAPQ, CIGAR (incl. the CG:B,I long-CIGAR convention), 4-bit SEQ and the HP aux tag
+ * (--output-extra HP, create_tensor_pileup.py:440).  Flag / MAPQ filtering is NOT done here: it belongs to
+ * the scan (c3r_params_t.excl_flags / min_mq), as it belongs to mpileup in the reference.
+ *
+ * Host-only C++ (zlib), no GPU, no torch types.  Every call returns 0 or a negative C3R_E* code
+ * (include/c3r.h); c3r_bam_last_error gives the message.
+ */
+#ifndef C3R_IO_H
+#define C3R_IO_H
+
+#include <stdint.h>
+
+#include "c3r_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct c3r_bam c3r_bam;
+
+/* Open `path`, parse the header; loads `<path>.bai` or `<path without .bam>.bai` when present.
+ * n_threads: BGZF inflate threads for whole-file loads (<=0: hardware concurrency). */
+int c3r_bam_open(const char *path, int n_threads, c3r_bam **out);
+void c3r_bam_close(c3r_bam *b);
+const char *c3r_bam_last_error(c3r_bam *b);
+
+int c3r_bam_n_contigs(c3r_bam *b);
+/* name points into the handle (valid until close) */
+int c3r_bam_contig(c3r_bam *b, int i, const char **name, int64_t *length);
+int c3r_bam_has_index(c3r_bam *b);
+
+/* Collect the alignments of `contig` overlapping the 0-based half-open region [beg0, end0) in file
+ * (coordinate) order; end0 <= 0 means the whole contig.  Uses the .bai when loaded, else inflates the
+ * whole file (in parallel) and filters.  Unmapped-position records (pos < 0) and records without CIGAR are
+ * skipped, as mpileup never sees them.  Sizes of the three flat arrays are returned. */
+int c3r_bam_fetch(c3r_bam *b, const char *contig, int64_t beg0, int64_t end0, int64_t *n_reads, int64_t *n_cigar,
+                  int64_t *n_seq_bytes);
+/* Copy the result of the last fetch: reads[n_reads] (cigar_off / seq_off index the other two arrays),
+ * cigar[n_cigar] BAM-encoded (len<<4|op), seq[n_seq_bytes] 4-bit packed, (l_seq+1)/2 bytes per read. */
+int c3r_bam_copy(c3r_bam *b, c3r_read_t *reads, uint32_t *cigar, uint8_t *seq);
+
+/* `samtools index` equivalent (samtools is not a dependency of this path): write a .bai for a
+ * coordinate-sorted BAM. */
+int c3r_bam_index_build(const char *bam_path, const char *bai_path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

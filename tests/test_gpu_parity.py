@@ -255,6 +255,8 @@ def test_call_var_bam_driver_end_to_end(eng, tmp_path):
     fa, bm, wfn = str(tmp_path / "ref.fa"), str(tmp_path / "in.bam"), str(tmp_path / "model")
     io.write_fasta(fa, [("chr20", ref), ("chrM", "ACGT" * 50)])
     bam.write_bam(bm, [("chr20", len(ref)), ("chrM", 200)], {"chr20": rs})
+    from clair3_rna_amd import bamio
+    bamio.index_build(bm)          # the driver fetches ctg:start-end through the .bai, like `samtools mpileup -r`
     w = synth.random_weights(18, seed=5)
     np.save(wfn + ".c3rw.npy", w)
     open(str(tmp_path / "CMD"), "w").write("run_clair3_rna test\n")
