@@ -1,0 +1,213 @@
+"""Merge the per-chunk VCFs into the final call set: SURVEY §8(f) row F4, the `sort_vcf` step of the reference
+(src/sort_vcf.py:85-292; invoked by run_clair3_rna:711-726 and :838-853 with the flag set accepted below).
+
+Behaviour kept, including the parts that are accidents of the reference's implementation, because downstream files
+must be identical (fixture tests/golden/g6_sortvcf.json.gz was produced by the reference's own function):
+  * chunk files are chosen by name: prefix, suffix, and the contig name being a SUBSTRING of the file name; a file is
+    read until its first record of another contig (that is how `chr1` skips the `chr11` files);
+  * duplicate positions (adjacent chunks overlap by 33 bp) are resolved last-file-wins in directory-listing order;
+  * header lines are collected as a set-in-order from the files read so far and written once, at the end of the first
+    contig for which any exist;
+  * RefCall rows are dropped unless --show_ref; a variant row is re-labelled LowQual when QUAL <= --qual;
+  * REDIportal tagging sets FILTER=RNAEditing when (contig, pos, ref, alt) is in the table and the row mentions neither
+    "Germline" nor "RefCall"; the untagged copy is the same text with RNAEditing -> PASS;
+  * no input rows at all, or no row kept: the output file is left EMPTY (not even a header).
+--compress_vcf writes <out>.gz as BGZF with this package's own writer (bgzip is not a dependency); a tabix index is
+not produced.
+"""
+import gzip
+import os
+import sys
+from argparse import ArgumentParser
+
+MAJOR_CONTIGS = ["chr%s" % c for c in list(range(1, 23)) + ["X", "Y"]] + [str(c) for c in list(range(1, 23)) + ["X", "Y"]]
+
+
+def _str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("yes", "ture", "true", "t", "y", "1"):
+        return True
+    if v.lower() in ("no", "flase", "false", "f", "n", "0"):
+        return False
+    raise ValueError("Boolean value expected.")
+
+
+def _contig_order(names, extra):
+    order = MAJOR_CONTIGS + list(extra)
+    return sorted(names, key=order.index)
+
+
+def load_rediportal(path, contigs, filter_tags=None):
+    """REDIportal table (gzip or plain TSV: contig, pos, ref, edited base, strand, db, ...) -> {(contig, pos): (ref, alt, db)}."""
+    table = {}
+    opener = gzip.open if open(path, "rb").read(2) == b"\x1f\x8b" else open
+    with opener(path, "rt") as f:
+        for i, line in enumerate(f):
+            if i == 0:
+                continue
+            c = line.rstrip().split("\t", 6)
+            if len(c) < 6 or (contigs and c[0] not in contigs):
+                continue
+            try:
+                key = (c[0], int(c[1]))
+            except ValueError:
+                continue
+            if filter_tags is not None and c[5] not in filter_tags:
+                continue
+            table[key] = (c[2], c[3], c[5])
+    return table
+
+
+def _relabel(row, label):
+    f = row.split("\t")
+    f[6] = label
+    return "\t".join(f)
+
+
+def merge_chunk_vcfs(input_dir, output_fn, contigs, prefix="pileup", suffix=".vcf", qual=2, show_ref=False,
+                     rediportal=None, output_no_tagging_fn=None, listing=None, log=print):
+    """Returns (rows_read, rows_written, rows_tagged).  `listing` pins the directory order (tests); default os.listdir."""
+    names = list(listing) if listing is not None else os.listdir(input_dir)
+    if prefix is not None:
+        names = [n for n in names if n.startswith(prefix)]
+    if suffix is not None:
+        names = [n for n in names if n.endswith(suffix)]
+    if not names:
+        open(output_fn, "w").close()
+        log("[WARNING] No vcf file found with prefix/suffix %s/%s*%s, output empty vcf file" % (input_dir, prefix, suffix))
+        return 0, 0, 0
+    tagging = rediportal is not None
+    out = open(output_fn, "w")
+    out_nt = open(output_no_tagging_fn, "w") if tagging and output_no_tagging_fn else None
+    header, header_done = [], False
+    n_read = n_kept = n_tagged = 0
+    for contig in _contig_order(contigs, contigs):
+        by_pos = {}
+        for name in (n for n in names if contig in n):
+            with open(os.path.join(input_dir, name)) as f:
+                for row in f:
+                    n_read += 1
+                    if row[0] == "#":
+                        if row not in header:
+                            header.append(row)
+                        continue
+                    c = row.strip().split(None, 6)
+                    if c[0] != contig:
+                        break                      # a file of another contig whose name merely contains this one
+                    pos, q, ref, alt = int(c[1]), float(c[5]), c[3], c[4]
+                    is_ref = alt == "." or ref == alt
+                    if is_ref and not show_ref:
+                        continue
+                    if not is_ref and qual and q <= qual:
+                        row = _relabel(row, "LowQual")
+                    hit = rediportal.get((contig, pos)) if tagging else None
+                    if hit is not None and "Germline" not in row and "RefCall" not in row:
+                        f9 = row.split("\t", 8)
+                        if f9[3] == hit[0] and f9[4] == hit[1]:
+                            f9[6] = "RNAEditing"
+                            row = "\t".join(f9)
+                            n_tagged += 1
+                    by_pos[pos] = row
+                    n_kept += 1
+        if not header_done and header:
+            out.write("".join(header))
+            if out_nt:
+                out_nt.write("".join(header))
+            header_done = True
+        for pos in sorted(by_pos):
+            out.write(by_pos[pos])
+            if out_nt:
+                out_nt.write(by_pos[pos].replace("RNAEditing", "PASS"))
+    out.close()
+    if out_nt:
+        out_nt.close()
+    if n_read == 0 or n_kept == 0:
+        open(output_fn, "w").close()
+        log("[WARNING] No %s found, output empty vcf file" % ("vcf file" if n_read == 0 else "variant"))
+    return n_read, n_kept, n_tagged
+
+
+def merge_stream(lines, output_fn):
+    """stdin mode (src/sort_vcf.py:85-121): concatenated VCF text -> sorted VCF."""
+    header, per = [], {}
+    for row in lines:
+        if row[0] == "#":
+            if row not in header:
+                header.append(row)
+            continue
+        c = row.strip().split(None, 3)
+        per.setdefault(c[0], {})[int(c[1])] = row
+    with open(output_fn, "w") as out:
+        out.write("".join(header))
+        for contig in _contig_order(list(per), list(per)):
+            for pos in sorted(per[contig]):
+                out.write(per[contig][pos])
+
+
+def compress_vcf(path):
+    """`bgzip -f` equivalent: <path> -> <path>.gz (BGZF), original removed."""
+    from .bam import _BGZF_EOF, _bgzf_write
+    data = open(path, "rb").read()
+    with open(path + ".gz", "wb") as f:
+        _bgzf_write(f, data)
+        f.write(_BGZF_EOF)
+    os.remove(path)
+    return path + ".gz"
+
+
+def build_parser():
+    p = ArgumentParser(description="Sort and merge per-chunk VCF files by contig and position (drop-in for `sort_vcf`)")
+    a = p.add_argument
+    a("--output_fn", type=str, required=True)
+    a("--input_dir", type=str, default=None)
+    a("--vcf_fn_prefix", type=str, default=None)
+    a("--vcf_fn_suffix", type=str, default=".vcf")
+    a("--ref_fn", type=str, default=None)
+    a("--sample_name", type=str, default="SAMPLE")
+    a("--contigs_fn", type=str, default=None)
+    a("--compress_vcf", type=_str2bool, default=False)
+    a("--show_ref", type=_str2bool, default=False)
+    a("--cmd_fn", type=str, default=None)
+    a("--qual", type=int, default=2)
+    a("--output_no_tagging_fn", type=str, default=None)
+    a("--tag_variant_using_readiportal", type=_str2bool, default=None)
+    a("--readiportal_source_fn", type=str, default=None)
+    a("--readiportal_database_filter_tag", type=str, default=None)
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.input_dir is None:
+        merge_stream(sys.stdin, args.output_fn)
+        return 0
+    print("[INFO] Sorting VCFs...")
+    if not os.path.exists(args.input_dir):
+        sys.exit("[ERROR] Input directory: %s not exists!" % args.input_dir)
+    if not (args.contigs_fn and os.path.exists(args.contigs_fn)):
+        sys.exit("[ERROR] Cannot find contig file %s. Exit!" % args.contigs_fn)
+    contigs = [l.rstrip() for l in open(args.contigs_fn)]
+    table = None
+    if args.tag_variant_using_readiportal:
+        src = args.readiportal_source_fn
+        if src is None or src.upper() == "NONE" or not os.path.exists(src):
+            print("[WARNING] Enabled tagging variant using readiportal, but --readiportal_source_fn %s file not found, skip tagging!" % src)
+            table = {}
+        else:
+            tags = set(args.readiportal_database_filter_tag.split(":")) if args.readiportal_database_filter_tag is not None else None
+            table = load_rediportal(src, contigs, tags)
+    n_read, n_kept, n_tag = merge_chunk_vcfs(args.input_dir, args.output_fn, contigs, args.vcf_fn_prefix, args.vcf_fn_suffix, args.qual,
+                                             args.show_ref, table, args.output_no_tagging_fn)
+    if args.compress_vcf:
+        compress_vcf(args.output_fn)
+        if table is not None and args.output_no_tagging_fn and n_kept:
+            compress_vcf(args.output_no_tagging_fn)
+    if table is not None:
+        print("[INFO] Dataset size:%d, total variants tagged by REDIportal dataset: %d" % (len(table), n_tag))
+    print("[INFO] Finished VCF sorting!")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
