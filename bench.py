@@ -153,7 +153,7 @@ def main():
     sites_per_step_rank = sites / max(1, args.steps) / world
 
     # ---- per-kernel durations, live, with HIP events on the engine's stream (one extra untimed step)
-    roofline, kernels = None, {}
+    roofline, kernels, stage_rates = None, {}, None
     if not args.no_profile:
         eng.set_profiling(True)
         eng.reset_kernel_stats()
@@ -186,6 +186,13 @@ def main():
             gbps = K1_BYTES_PER_SITE * n_prof / st["launches"] / (avg_ms * 1e-3) / 1e9
             roofline = dict(kernel=dom, bound="hbm", achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
                             frac=round(gbps / PEAK_HBM_GBPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4), launches=st["launches"])
+        # the two halves on their own (device time of each half's kernels in the profiled pass)
+        net_ms = sum(v["total_ms"] for k, v in kernels.items() if k in ("k_lstm1", "k_lstm2", "k_fc4", "k_heads"))
+        k1_ms = sum(v["total_ms"] for k, v in kernels.items()) - net_ms
+        stage_rates = dict(tensor_build_sites_per_s=round(n_prof / (k1_ms * 1e-3), 1) if k1_ms else None,
+                           inference_sites_per_s=round(n_prof / (net_ms * 1e-3), 1) if net_ms else None,
+                           tensor_build_algorithmic_GBps=round(K1_BYTES_PER_SITE * n_prof / (k1_ms * 1e-3) / 1e9, 1) if k1_ms else None,
+                           tensor_build_ms=round(k1_ms, 3), inference_ms=round(net_ms, 3))
         traffic_fn = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
         if roofline and os.path.exists(traffic_fn):
             try:
@@ -230,7 +237,7 @@ def main():
                        "exonic_bp_per_rank": info["n_exonic"], "sites_per_step_per_rank": round(sites_per_step_rank, 1),
                        "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world,
                        "streams": len(engs)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "stage_rates": stage_rates,
             "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
         }
         print(json.dumps(out), flush=True)

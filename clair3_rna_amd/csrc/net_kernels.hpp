@@ -20,6 +20,7 @@
 //   * 4 wavefronts split the 4H/32 row blocks evenly (H=128: 4 each, H=160: 5 each).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include <cmath>
@@ -296,7 +297,8 @@ __device__ __forceinline__ void sched_interleave() {
 template <int INP, int CIN, int H, bool INT_IN, int SB = 2, int ABL = 0, bool FC4 = false, int PD = 1, bool ILV = false>
 __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin, const half8 *__restrict__ Wp,
                                                     const float *__restrict__ bp, _Float16 *__restrict__ y, int n,
-                                                    const half8 *__restrict__ W4p = nullptr, float *__restrict__ a4part = nullptr) {
+                                                    const half8 *__restrict__ W4p = nullptr, float *__restrict__ a4part = nullptr,
+                                                    int nstride = 0 /* site stride of the [t][k/8][site][8] planes; 0 = n */) {
     constexpr int NGX = INP / 16;
     constexpr int NGH = H / 16;
     constexpr int NG = NGX + NGH;
@@ -315,8 +317,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
     const int j = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y;
     const int site0 = blockIdx.x * WG_SITES;
-    const size_t plane_in = (size_t)n * NET_T * CIN;        // halves per input plane
-    const size_t plane_out = (size_t)n * NET_T * 2 * H;
+    const int ns = nstride ? nstride : n;
+    const size_t plane_in = (size_t)ns * NET_T * CIN;        // halves per input plane
+    const size_t plane_out = (size_t)ns * NET_T * 2 * H;
 
     const half8 *wl = Wp + ((size_t)(dir * 4 + wave) * NG) * NT * 2 * 64 + lane;
     float bias_a[NT];
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
     for (int sb = 0; sb < SB; ++sb) {
         int sj = site0 + 32 * sb + j;
         if (sj >= n) sj = n - 1;
-        xoff[sb] = INT_IN ? (size_t)sj * NET_T * CIN : ((size_t)hh * n + sj) * 8;
+        xoff[sb] = INT_IN ? (size_t)sj * NET_T * CIN : ((size_t)hh * ns + sj) * 8;
     }
 
     for (int step = 0; step < NET_T; ++step) {
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
                 } else {
                     // [t][k/8][site][8]: the 32 lanes of a half-wave read 32 consecutive 16-byte pieces (512 B), so a
                     // wave load costs the L1 what a weight load costs (the [site][t][k] layout touched 32 cache lines)
-                    const _Float16 *xp = (const _Float16 *)xin + ((size_t)(t * (CIN / 8) + 2 * g) * n) * 8 + xoff[sb];
+                    const _Float16 *xp = (const _Float16 *)xin + ((size_t)(t * (CIN / 8) + 2 * g) * ns) * 8 + xoff[sb];
                     bh[sb] = *(const half8 *)xp;
                     bl[sb] = *(const half8 *)(xp + plane_in);
                 }
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
             const int s = site0 + row;
             if (s < n) {
                 const half8 v = pl ? *(const half8 *)&hb_lo[nxt][row][8 * c8] : *(const half8 *)&hb_hi[nxt][row][8 * c8];
-                *(half8 *)(y + (size_t)pl * plane_out + (((size_t)t * (2 * HV) + dir * HV + c8) * n + s) * 8) = v;
+                *(half8 *)(y + (size_t)pl * plane_out + (((size_t)t * (2 * HV) + dir * HV + c8) * ns + s) * 8) = v;
             }
         }
     }
@@ -572,6 +575,196 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layer 1 of the split-f16 path with the cell update hidden behind the matrix pipe.
+//
+// k_lstm_h spends 28 % of layer 1 in the lane-local cell update (5 exp2 + 3 rcp per unit: ~1000 VALU / transcendental
+// instructions per step) and 20 % storing y1, with the matrix pipe idle meanwhile: ONE wavefront per SIMD means nothing
+// else can issue.  Here a workgroup owns TWO groups of 64 sites, A and B, one step apart in phase:
+//      phase 2 of step s   : MFMAs of (B, s)   with the cell update + stores of (A, s)   interleaved between them
+//      phase 1 of step s+1 : MFMAs of (A, s+1) with the cell update + stores of (B, s)   interleaved
+// so the VALU work of one group always runs in the shadow of the other group's MFMAs (<= 5 single-issue instructions
+// hide behind a 32-cycle MFMA).  Weight traffic per site is unchanged (every phase still feeds 64 sites from one pass
+// over the weights).  A group's h is read (its MFMA phase) and rewritten (its update phase) in different phases with
+// a barrier between, so ONE LDS buffer per group is enough.  Accumulators: 2 x 128 registers.  y1 is stored straight
+// from registers (8 bytes per lane, 512 contiguous bytes per wave-store) in the [t][k/8][site][8] plane layout.
+template <int CIN, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp,
+                                                        const float *__restrict__ bp, _Float16 *__restrict__ y, int n, int nstride) {
+    constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NT = 4, SB = 2, GS = 32 * SB, HV = H / 8;
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][GS][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][GS][HP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y;
+    const int site0 = blockIdx.x * 2 * GS;
+    const size_t plane_out = (size_t)nstride * NET_T * 2 * H;     // nstride = n rounded up to the workgroup's 128 sites:
+                                                                  // sites past n own (unused) slots, so stores need no guard
+
+    const half8 *wl = Wp + ((size_t)(dir * 4 + wave) * NG) * NT * 2 * 64 + lane;
+    float bias_a[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) bias_a[tt] = hh == 0 ? WSCALE * bp[((size_t)dir * 16 + wave * NT + tt) * 32 + j] : 0.f;
+
+    // cell state in LDS ([group][site][unit], fp32): the two accumulator sets leave no registers for it
+    constexpr int CP = H + 4;
+    __shared__ __attribute__((aligned(16))) float cbuf[2][GS][CP];
+    for (int i = tid; i < 2 * GS * CP; i += 256) (&cbuf[0][0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * GS * HP; i += 256) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
+    __syncthreads();
+
+    size_t xoff[2][SB];
+    uint32_t yoff[2][SB];       // per-lane element offset inside a [site][8] row block of the y planes
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb) {
+            const int sj = site0 + GS * g + 32 * sb + j;
+            yoff[g][sb] = (uint32_t)sj * 8 + 4 * hh;
+            xoff[g][sb] = (size_t)(sj < n ? sj : n - 1) * NET_T * CIN;
+        }
+
+    floatx16 accA[NT][SB], accB[NT][SB];
+
+    // One phase.  MMA: accumulate group gm's pre-activations of time index tm into accM.  GATE: cell update of group gg
+    // from accG (finished in the previous phase), writing h (LDS) and y1 (HBM) of time index tg.
+    auto phase = [&](auto mma_c, auto gate_c, floatx16 (&accM)[NT][SB], const int gm, const int tm,
+                     floatx16 (&accG)[NT][SB], const int gg, const int tg) {
+        constexpr bool MMA = decltype(mma_c)::value, GATE = decltype(gate_c)::value;
+        auto ldx = [&](int g, half8 (&bh)[SB]) {
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                // branch-free (a divergent guard would split the scheduling region the interleave lives in): always
+                // load from a clamped index, then select
+                const int32_t *xp = xin + xoff[gm][sb] + (size_t)tm * CIN;
+                const int k0 = 16 * g + 8 * hh;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + e;
+                    const int32_t v = xp[k < CIN ? k : CIN - 1];
+                    bh[sb][e] = (k < CIN) ? (_Float16)(float)v : (_Float16)0.f;
+                }
+            }
+        };
+        auto ldh = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                bh[sb] = *(const half8 *)&hb_hi[gm][32 * sb + j][16 * g + 8 * hh];
+                bl[sb] = *(const half8 *)&hb_lo[gm][32 * sb + j][16 * g + 8 * hh];
+            }
+        };
+        auto ldw = [&](int g, half8 (&ah)[NT], half8 (&al)[NT]) {
+            typedef const half8 __attribute__((address_space(1))) *gptr_t;     // see k_lstm_h::ldw
+            uintptr_t wbase = (uintptr_t)wl;
+            asm volatile("" : "+v"(wbase));
+            const gptr_t wg = (gptr_t)wbase + (size_t)g * NT * 2 * 64;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) { ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64]; }
+        };
+        // cell update of one (tile, site block): 4 units per lane
+        auto gate = [&](const int tt, const int sb) {
+            constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
+            float ei[4], ef[4], eg[4], eo[4], hv[4], cq[4];
+            float4 *cp = (float4 *)&cbuf[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh];
+            { const float4 cv = *cp; cq[0] = cv.x; cq[1] = cv.y; cq[2] = cv.z; cq[3] = cv.w; }
+            if (ABL & 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[q] = accG[tt][sb][4 * q] + accG[tt][sb][4 * q + 1] + accG[tt][sb][4 * q + 2] + accG[tt][sb][4 * q + 3] + cq[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ei[q] = fminf(__builtin_amdgcn_exp2f(K1 * accG[tt][sb][4 * q + 0]), 1e18f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ef[q] = __builtin_amdgcn_exp2f(K1 * accG[tt][sb][4 * q + 1]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) eg[q] = fminf(__builtin_amdgcn_exp2f(K2 * accG[tt][sb][4 * q + 2]), 1e18f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) eo[q] = fminf(__builtin_amdgcn_exp2f(K1 * accG[tt][sb][4 * q + 3]), 1e18f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ei[q] = (1.0f - eg[q]) * __builtin_amdgcn_rcpf((1.0f + ei[q]) * (1.0f + eg[q]));   // sig(i)*tanh(g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ef[q] = __builtin_amdgcn_rcpf(1.0f + ef[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cq[q] = fmaf(ef[q], cq[q], ei[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) eg[q] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[q]), 1e18f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[q] = (1.0f - eg[q]) * __builtin_amdgcn_rcpf((1.0f + eo[q]) * (1.0f + eg[q]));
+                *cp = make_float4(cq[0], cq[1], cq[2], cq[3]);
+            }
+            half4 vh, vl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { vh[q] = (_Float16)hv[q]; vl[q] = (_Float16)(hv[q] - (float)vh[q]); }
+            *(half4 *)&hb_hi[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vh;
+            *(half4 *)&hb_lo[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vl;
+            if (!(ABL & 4)) {
+                _Float16 *yp = y + ((size_t)tg * (2 * HV) + dir * HV + wave * NT + tt) * nstride * 8 + yoff[gg][sb];
+                *(half4 *)yp = vh;
+                *(half4 *)(yp + plane_out) = vl;
+            }
+        };
+        if (MMA) {
+            floatx16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[tt], 1.0f, z, 0, 0, 0);
+        }
+        half8 ah[2][NT], al[2][NT], bh[2][SB], bl[2][SB];
+#define C3R_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define C3R_LOAD(G) do { ldw((G), ah[(G) & 1], al[(G) & 1]); \
+                         if ((G) < NGX) ldx((G), bh[(G) & 1]); else ldh((G) - NGX, bh[(G) & 1], bl[(G) & 1]); } while (0)
+#define C3R_MMA(G) do {                                                                                                      \
+        _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) _Pragma("unroll") for (int sb = 0; sb < SB; ++sb)                    \
+            accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(G) & 1][tt], bh[(G) & 1][sb], accM[tt][sb], 0, 0, 0);    \
+        _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) _Pragma("unroll") for (int sb = 0; sb < SB; ++sb)                    \
+            accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[(G) & 1][tt], bh[(G) & 1][sb], accM[tt][sb], 0, 0, 0);    \
+        if ((G) >= NGX) {                                                                                                      \
+            _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) _Pragma("unroll") for (int sb = 0; sb < SB; ++sb)                \
+                accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(G) & 1][tt], bl[(G) & 1][sb], accM[tt][sb], 0, 0, 0); \
+        } } while (0)
+        // one region per k-group: prefetch of the next group, this group's MFMAs, and one eighth of the other group's
+        // cell update; the sched_group_barrier sequence asks for  MFMA, 5 VALU, MFMA, 5 VALU, ...  with the loads spread
+#define C3R_MIX(NMF) do { _Pragma("unroll") for (int m_ = 0; m_ < (NMF); ++m_) {                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                 \
+            if constexpr (GATE) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                            \
+            if (m_ < 12) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                    \
+            else if (m_ < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } } while (0)
+#define C3R_STEP(G)                                                                                                          \
+        C3R_FENCE();                                                                                                           \
+        if (MMA) { if ((G) + 1 < NG) C3R_LOAD((G) + 1); C3R_MMA(G); }                                                          \
+        if (GATE && (G) < NT * SB) gate((G) >> 1, (G) & 1);                                                                    \
+        if (MMA) C3R_MIX(((G) < NGX) ? NT * SB * 2 : NT * SB * 3);
+        if (MMA) C3R_LOAD(0);
+        C3R_STEP(0) C3R_STEP(1) C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
+        static_assert(NG == 10, "C3R_STEP list");
+        C3R_FENCE();
+#undef C3R_STEP
+#undef C3R_MIX
+#undef C3R_MMA
+#undef C3R_LOAD
+#undef C3R_FENCE
+    };
+    const std::true_type yes{}; const std::false_type no{};
+    auto tix = [&](int step) { return dir ? NET_T - 1 - step : step; };
+
+    phase(yes, no, accA, 0, tix(0), accB, 1, 0);                       // (A, 0)
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s + 1 < NET_T; ++s) {
+        phase(yes, yes, accB, 1, tix(s), accA, 0, tix(s));             // MFMA (B, s)   | update (A, s)
+        __syncthreads();
+        phase(yes, yes, accA, 0, tix(s + 1), accB, 1, tix(s));         // MFMA (A, s+1) | update (B, s)
+        __syncthreads();
+    }
+    phase(yes, yes, accB, 1, tix(NET_T - 1), accA, 0, tix(NET_T - 1));
+    __syncthreads();
+    phase(no, yes, accA, 0, 0, accB, 1, tix(NET_T - 1));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -907,8 +1100,9 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
 }
 
 inline int net_reserve(NetState &s, int64_t n, hipStream_t st, std::string &err) {
-    if (n <= s.cap_sites) return C3R_OK;
-    const int64_t cap = n + n / 4 + 64;
+    const int64_t need = (n + 127) / 128 * 128;    // the y1 planes are stored with the site stride rounded up to 128
+    if (need <= s.cap_sites) return C3R_OK;
+    const int64_t cap = need + need / 4 + 256;
     NET_HIP(hipStreamSynchronize(st));
     float **bufs[] = {&s.d_y1, &s.d_y2, &s.d_a4, &s.d_probs};
     const size_t sizes[] = {(size_t)cap * NET_T * 2 * NET_H1, (size_t)cap * NET_T * 2 * NET_H2, (size_t)cap * NET_L4 * 2, (size_t)cap * C3R_NPROB};
@@ -931,19 +1125,20 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
     if (s.precision == 1) {
         // split-f16 path: y1 / y2 hold hi and lo f16 planes (same bytes as one fp32 plane)
         _Float16 *y1h = (_Float16 *)s.d_y1, *y2h = (_Float16 *)s.d_y2;
-        const dim3 grid1((unsigned)((n + 32 * LSTM1H_SB - 1) / (32 * LSTM1H_SB)), 2);
+        // layer 1: two 64-site groups per workgroup, phases skewed (k_lstm1_skew); the y1 planes use a site stride padded
+        // to the workgroup's 128 sites so that its stores need no bounds guard
+        const int ns = (int)((n + 127) / 128 * 128);
+        const dim3 grid1((unsigned)(ns / 128), 2);
         prof("k_lstm1", 0);
         if (s.channels == C3R_CH)
-            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH, NET_H1, true, LSTM1H_SB, 0, false, C3R_L1_PD, C3R_L1_ILV>), grid1, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
-                               (const float *)s.d_b1, y1h, (int)n);
+            hipLaunchKernelGGL((k_lstm1_skew<C3R_CH>), grid1, block, 0, st, d_x, (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, ns);
         else
-            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH_PHASED, NET_H1, true, LSTM1H_SB, 0, false, C3R_L1_PD, C3R_L1_ILV>), grid1, block, 0, st, (const void *)d_x, (const half8 *)s.d_w1h,
-                               (const float *)s.d_b1, y1h, (int)n);
+            hipLaunchKernelGGL((k_lstm1_skew<C3R_CH_PHASED>), grid1, block, 0, st, d_x, (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, ns);
         prof("k_lstm1", 1);
         prof("k_lstm2", 0);
         // layer 2 with the L4 dense layer fused in: y2 is never materialised
         hipLaunchKernelGGL((k_lstm_h<2 * NET_H1, 2 * NET_H1, NET_H2, false, LSTM_SB, 0, true, C3R_L2_PD, C3R_L2_ILV>), grid, block, 0, st, (const void *)y1h,
-                           (const half8 *)s.d_w2h, (const float *)s.d_b2, y2h, (int)n, (const half8 *)s.d_w4f, s.d_a4);
+                           (const half8 *)s.d_w2h, (const float *)s.d_b2, y2h, (int)n, (const half8 *)s.d_w4f, s.d_a4, ns);
         prof("k_lstm2", 1);
         heads_parts = 2;
     } else {

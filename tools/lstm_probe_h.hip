@@ -24,6 +24,38 @@ static float run(const _Float16 *x, const half8 *w, const float *b, _Float16 *y,
     return ms / reps;
 }
 
+// layer-1 shape: int32 pileup input [n][33][18], H = 128, y1 planes out
+template <int SB, int ABL, int PD = 2, bool ILV = false>
+static float run1(const int32_t *x, const half8 *w, const float *b, _Float16 *y, int n, int reps) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    dim3 grid((n + 32 * SB - 1) / (32 * SB), 2);
+    hipLaunchKernelGGL((k_lstm_h<32, 18, 128, true, SB, ABL, false, PD, ILV>), grid, dim3(256), 0, 0, (const void *)x, w, b, y, n, nullptr, nullptr);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL((k_lstm_h<32, 18, 128, true, SB, ABL, false, PD, ILV>), grid, dim3(256), 0, 0, (const void *)x, w, b, y, n, nullptr, nullptr);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
+template <int ABL>
+static float run1s(const int32_t *x, const half8 *w, const float *b, _Float16 *y, int n, int reps) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    dim3 grid((n + 127) / 128, 2);
+    hipLaunchKernelGGL((k_lstm1_skew<18, ABL>), grid, dim3(256), 0, 0, x, w, b, y, n, (n + 127) / 128 * 128);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_lstm1_skew<18, ABL>), grid, dim3(256), 0, 0, x, w, b, y, n, (n + 127) / 128 * 128);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 200000;
     const size_t nx = (size_t)n * 33 * 256 * 2, ny = (size_t)n * 33 * 320 * 2, nw = (size_t)2 * 20 * 26 * 2 * 64, nb = 2 * 20 * 32;
@@ -71,6 +103,36 @@ int main(int argc, char **argv) {
         {"SB2 PD3 full", run<2, 0, 3>(x, w, b, y, n, 3)},
         {"SB3 PD2 full", run<3, 0, 2>(x, w, b, y, n, 3)},
     };
+    if (argc > 2) {
+        // layer 1
+        int32_t *xi; hipMalloc(&xi, (size_t)n * 33 * 18 * 4);
+        {
+            std::vector<int32_t> h((size_t)n * 33 * 18);
+            unsigned long long s = 12345;
+            for (auto &v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (int)(s % 41) - 20; }
+            hipMemcpy(xi, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        }
+        const double flop1 = 2.0 * (32 + 128) * 512 * 33 * 2 * n;
+        struct { const char *name; float ms; } r1[] = {
+            {"L1 SB2 PD2 full", run1<2, 0>(xi, w, b, y, n, 3)},
+            {"L1 SB2 PD1 full", run1<2, 0, 1>(xi, w, b, y, n, 3)},
+            {"L1 SB2 PD2 ILV", run1<2, 0, 2, true>(xi, w, b, y, n, 3)},
+            {"L1 no gate math", run1<2, 2>(xi, w, b, y, n, 3)},
+            {"L1 no y store", run1<2, 4>(xi, w, b, y, n, 3)},
+            {"L1 no barrier", run1<2, 8>(xi, w, b, y, n, 3)},
+            {"L1 no weight loads", run1<2, 16>(xi, w, b, y, n, 3)},
+            {"L1 no x loads", run1<2, 32>(xi, w, b, y, n, 3)},
+            {"L1 no gate,y", run1<2, 6>(xi, w, b, y, n, 3)},
+            {"L1 all ablated", run1<2, 63>(xi, w, b, y, n, 3)},
+            {"L1 skew full", run1s<0>(xi, w, b, y, n, 3)},
+            {"L1 skew no gate", run1s<2>(xi, w, b, y, n, 3)},
+            {"L1 skew no y store", run1s<4>(xi, w, b, y, n, 3)},
+            {"L1 SB3 PD2 full", run1<3, 0>(xi, w, b, y, n, 3)},
+            {"L1 SB4 PD1 full", run1<4, 0, 1>(xi, w, b, y, n, 3)},
+        };
+        for (auto &e : r1) printf("%-22s %8.3f ms  %7.1f padded-K algorithmic TFLOP/s\n", e.name, e.ms, flop1 / e.ms / 1e9);
+        return 0;
+    }
     for (auto &e : r) printf("%-22s %8.3f ms  %7.1f algorithmic TFLOP/s (x3 executed = %6.1f = %4.1f %% of 2500)\n", e.name, e.ms, flop / e.ms / 1e9,
                              3 * flop / e.ms / 1e9, 3 * flop / e.ms / 1e9 / 2500 * 100);
     return 0;
