@@ -50,6 +50,9 @@ constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 #ifndef C3R_L1_ILV
 #define C3R_L1_ILV false
 #endif
+#ifndef C3R_L1_SKEW
+#define C3R_L1_SKEW 1        // layer 1 through k_lstm1_skew (two site groups, skewed phases) instead of k_lstm_h
+#endif
 #ifndef C3R_L2_PD
 #define C3R_L2_PD 2
 #endif
@@ -307,8 +310,16 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
     constexpr int NT = NBLK / 4;
     constexpr int WG_SITES = 32 * SB;
     static_assert(INP % 32 == 0 && H % 32 == 0, "shape: even 16-wide k-group counts for the ping-pong pipeline");
-    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
-    __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][WG_SITES][HP];
+    // XLDS (layer 2): x_t is staged in LDS one step ahead by LDS-DMA (global_load_lds), shared by the four wavefronts.
+    // The y1 planes stream from HBM (15 GB per pass): fetched straight into registers two k-groups ahead their ~2 us
+    // loaded latency was exposed in every step, and every wavefront fetched the same 64 KB.  The LDS budget for the
+    // 64 KB tile comes from single-buffering h (a second barrier per step separates its readers from its writers).
+    constexpr bool XLDS = FC4 && !INT_IN && !(ABL & 64);
+    constexpr int NHB = XLDS ? 1 : 2;
+    constexpr int KC = CIN / 8;
+    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[NHB][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 hb_lo[NHB][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 xs[XLDS ? 2 : 1][XLDS ? KC : 1][XLDS ? WG_SITES : 1][8];   // [plane][k/8][site][8]
     // cell state: registers, or LDS in the FC4 variant (its persistent L4 accumulators need the registers)
     constexpr int CP = H + 4;
     __shared__ __attribute__((aligned(16))) float cbuf[FC4 ? WG_SITES : 1][FC4 ? CP : 4];
@@ -354,9 +365,31 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
         xoff[sb] = INT_IN ? (size_t)sj * NET_T * CIN : ((size_t)hh * ns + sj) * 8;
     }
 
+    // LDS-DMA of x_t: one wave-instruction moves the 64 sites' 16-byte pieces of one (plane, k/8) row = 1 KiB, contiguous in
+    // the [t][k/8][site][8] planes and in xs; 2*KC rows per step, a quarter per wavefront
+    int xsite = site0 + lane;
+    if (xsite >= n) xsite = n - 1;
+    auto dma_x = [&](int tt_) {
+        if (XLDS) {
+            typedef const _Float16 __attribute__((address_space(1))) *gp_t;
+            typedef _Float16 __attribute__((address_space(3))) *lp_t;
+#pragma unroll
+            for (int r = 0; r < (XLDS ? 2 * KC / 4 : 0); ++r) {
+                const int row = wave * (2 * KC / 4) + r, pl = row / KC, kc = row % KC;
+                const _Float16 *src = (const _Float16 *)xin + (size_t)pl * plane_in + (((size_t)tt_ * KC + kc) * ns + xsite) * 8;
+                __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)&xs[XLDS ? pl : 0][XLDS ? kc : 0][0][0], 16, 0, 0);
+            }
+        }
+    };
+    if (XLDS) {
+        dma_x(dir ? NET_T - 1 : 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
     for (int step = 0; step < NET_T; ++step) {
         const int t = dir ? NET_T - 1 - step : step;
-        const int cur = step & 1, nxt = cur ^ 1;
+        const int cur = XLDS ? 0 : (step & 1), nxt = XLDS ? 0 : (cur ^ 1);
 
         auto ldx = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
 #pragma unroll
@@ -367,6 +400,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
                     const int k0 = 16 * g + 8 * hh;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bh[sb][e] = (k0 + e < CIN) ? (_Float16)(float)xp[k0 + e] : (_Float16)0.f;
+                } else if (XLDS) {
+                    bh[sb] = *(const half8 *)&xs[0][XLDS ? 2 * g + hh : 0][XLDS ? 32 * sb + j : 0][0];
+                    bl[sb] = *(const half8 *)&xs[XLDS ? 1 : 0][XLDS ? 2 * g + hh : 0][XLDS ? 32 * sb + j : 0][0];
                 } else {
                     // [t][k/8][site][8]: the 32 lanes of a half-wave read 32 consecutive 16-byte pieces (512 B), so a
                     // wave load costs the L1 what a weight load costs (the [site][t][k] layout touched 32 cache lines)
@@ -454,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
         if constexpr (ILV && (G) + PD < NG) {                                                                     \
             constexpr bool LX = (G) + PD < NGX;        /* the prefetched group is an x group */                   \
             constexpr int NMM = NT * SB * (((G) < NGX && !XLO) ? 2 : 3);                                          \
-            sched_interleave<NMM, NT * 2 + (LX ? (INT_IN ? 0 : SB * 2) : 0), LX ? 0 : SB * 2>();                  \
+            sched_interleave<NMM, NT * 2 + ((LX && !XLDS) ? (INT_IN ? 0 : SB * 2) : 0), (LX && !XLDS) ? 0 : SB * 2>(); \
         }                                                                                                         \
     }
         C3R_PRE(0) C3R_PRE(1) C3R_PRE(2) C3R_PRE(3) C3R_PRE(4) C3R_PRE(5)
@@ -467,6 +503,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
 #undef C3R_STEP
 #undef C3R_LOAD
 #undef C3R_FENCE
+        if (XLDS) {
+            __syncthreads();                                   // every wavefront is done reading x_t and h_{t-1}
+            if (step + 1 < NET_T) dma_x(dir ? NET_T - 2 - step : step + 1);      // lands during the cell update
+        }
         // ---- lane-local cell update (acc holds 2^12 * z).  Written stage by stage over the NU = 4*SB independent
         // (unit, site) values of a tile so that the dependent exp2 -> rcp -> fma chains of different units overlap
         // (one wavefront per SIMD: there is no other wave to hide VALU / transcendental latency behind).
@@ -530,6 +570,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
                 *(half4 *)&hb_lo[nxt][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vl;
             }
         }
+        if (XLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // x_{t+1} has landed (LDS-DMA is tracked by vmcnt)
         if (!(ABL & 8)) __syncthreads();
         if (FC4) {
             // ---- fused L4: facc[sb] += W4[t, dir][32 rows of this wave] x h_t^T   (K = H, B operand = h_t in LDS)
@@ -1130,10 +1171,19 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
         const int ns = (int)((n + 127) / 128 * 128);
         const dim3 grid1((unsigned)(ns / 128), 2);
         prof("k_lstm1", 0);
+#if C3R_L1_SKEW
         if (s.channels == C3R_CH)
             hipLaunchKernelGGL((k_lstm1_skew<C3R_CH>), grid1, block, 0, st, d_x, (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, ns);
         else
             hipLaunchKernelGGL((k_lstm1_skew<C3R_CH_PHASED>), grid1, block, 0, st, d_x, (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, ns);
+#else
+        if (s.channels == C3R_CH)
+            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH, NET_H1, true, LSTM1H_SB, 0, false, C3R_L1_PD, C3R_L1_ILV>), grid, block, 0, st, (const void *)d_x,
+                               (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, nullptr, nullptr, ns);
+        else
+            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH_PHASED, NET_H1, true, LSTM1H_SB, 0, false, C3R_L1_PD, C3R_L1_ILV>), grid, block, 0, st, (const void *)d_x,
+                               (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, nullptr, nullptr, ns);
+#endif
         prof("k_lstm1", 1);
         prof("k_lstm2", 0);
         // layer 2 with the L4 dense layer fused in: y2 is never materialised

@@ -79,6 +79,10 @@ int main(int argc, char **argv) {
         hipMalloc(&g_a4, (size_t)n * 2 * 128 * 4);
     }
     const double flop = 2.0 * 416 * 640 * 33 * 2 * n;
+    if (argc > 2 && argv[2][0] == 'p') {       // counters: only the production layer-2 kernel
+        printf("prod %.3f ms\n", run<2, 0, C3R_L2_PD, true, C3R_L2_ILV>(x, w, b, y, n, 2));
+        return 0;
+    }
     struct { const char *name; float ms; } r[] = {
         {"SB2 full", run<2, 0>(x, w, b, y, n, 3)},
         {"SB2 weights L1-hot", run<2, 1>(x, w, b, y, n, 3)},
@@ -93,6 +97,12 @@ int main(int argc, char **argv) {
         {"SB2 PD1 full", run<2, 0, 1>(x, w, b, y, n, 3)},
         {"SB2 PD1 full noILV", run<2, 0, 1, false, false>(x, w, b, y, n, 3)},
         {"SB2 PD2 full noILV", run<2, 0, 2, false, false>(x, w, b, y, n, 3)},
+        {"FC4 PD2 ILV xLDS (prod)", run<2, 0, 2, true, true>(x, w, b, y, n, 3)},
+        {"FC4 PD2 ILV x global", run<2, 64, 2, true, true>(x, w, b, y, n, 3)},
+        {"FC4 PD1 xLDS", run<2, 0, 1, true, false>(x, w, b, y, n, 3)},
+        {"FC4 PD2 noILV xLDS", run<2, 0, 2, true, false>(x, w, b, y, n, 3)},
+        {"FC4 xLDS nogate", run<2, 2, 2, true, true>(x, w, b, y, n, 3)},
+        {"FC4 xLDS no w loads", run<2, 16, 2, true, true>(x, w, b, y, n, 3)},
         {"SB2 PD1 FC4 (prod)", run<2, 0, 1, true>(x, w, b, y, n, 3)},
         {"SB2 PD1 FC4 noILV", run<2, 0, 1, true, false>(x, w, b, y, n, 3)},
         {"SB2 PD2 FC4", run<2, 0, 2, true>(x, w, b, y, n, 3)},
