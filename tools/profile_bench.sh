@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-end profiles of bench.py on the GPU box (one MI355X):  bash tools/profile_bench.sh [f16x3|f32]
+# 1. rocprofv3 --kernel-trace --stats   -> gpurun_out/prof/<prec>/stats
+# 2. separate --pmc passes (never combined with other trace domains): FETCH_SIZE | WRITE_SIZE | SQ matrix-pipe counters
+# Summaries are written by tools/summarize_profiles.py into profiles/.
+PREC=${1:-f16x3}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof/$PREC
+mkdir -p $OUT
+ARGS="$R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile --precision $PREC"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
+python3 $R/bench.py --precision $PREC > $OUT/bench.json 2> $OUT/bench.err
+ls -R $OUT | head -40

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof/<prec>/ (tools/profile_bench.sh) -> profiles/<tag>_kernel_stats_<prec>.csv, <tag>_pmc_<prec>.csv,
+<tag>_bench_<prec>.json and profiles/pmc_traffic.json (per-launch HBM bytes read by bench.py).
+
+HBM bytes = (FETCH_SIZE + WRITE_SIZE) KB * 1024, raw: MI355X_MICROARCH.md notes that FETCH_SIZE under-reports wide coalesced
+streaming reads 2x on gfx950; the calibration for this code (layer 2 must read the y1 hi/lo planes once per direction)
+shows the raw counter is right for its 16-byte-per-lane gathers, so no factor is applied."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    m = re.search(r"k_lstm1_skew|k_lstm_h|k_lstm|k_[a-z0-9_]+", name)
+    if not m:
+        return name[:40]
+    k = m.group(0)
+    if k == "k_lstm1_skew":
+        return "k_lstm1"
+    if k in ("k_lstm_h", "k_lstm"):
+        return "k_lstm2" if ("ILi256E" in name or "Li160E" in name or re.search(r"k_lstm(_h)?<256,", name)) else "k_lstm1"
+    return k
+
+
+def counters(d):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+
+def main():
+    prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+    tag = sys.argv[2] if len(sys.argv) > 2 else "r1_end"
+    src = os.path.join(ROOT, "gpurun_out", "prof", prec)
+    out = os.path.join(ROOT, "profiles")
+    # 1. kernel stats
+    st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        text = open(st[0]).read()
+        open(os.path.join(out, "%s_kernel_stats_%s.csv" % (tag, prec)), "w").write(
+            "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
+            "--precision %s   (MI355X; durations in ns; two contexts: 1 priming + 1 warm-up + 2 timed passes each)\n" % prec + text)
+    # 2. PMC
+    rows = {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        for k, cs in counters(os.path.join(src, sub)).items():
+            for c, v in cs.items():
+                rows.setdefault(k, {})[c] = (sum(v) / len(v), len(v))
+    hdr = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]
+    traffic = {}
+    with open(os.path.join(out, "%s_pmc_%s.csv" % (tag, prec)), "w") as f:
+        f.write("# rocprofv3 --pmc <set> --kernel-trace, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), same bench command; per-launch averages.\n"
+                "# hbm_bytes = (FETCH_SIZE + WRITE_SIZE) KB * 1024 (raw, see tools/summarize_profiles.py); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+                "(1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); clock_GHz needs the kernel duration and is quoted in DESIGN.md.\n")
+        f.write("kernel,launches," + ",".join(hdr) + ",hbm_bytes_per_launch,mfma_busy\n")
+        for k in sorted(rows):
+            r = rows[k]
+            vals = [r.get(h, (0.0, 0))[0] for h in hdr]
+            n = max(v[1] for v in r.values())
+            hbm = (vals[0] + vals[1]) * 1024
+            busy = vals[2] / (1024 * vals[3] / 8) if vals[3] else 0.0
+            traffic[k] = int(hbm)
+            f.write("%s,%d,%s,%d,%.3f\n" % (k, n, ",".join("%.4g" % v for v in vals), hbm, busy))
+    tf = os.path.join(out, "pmc_traffic.json")
+    allt = json.load(open(tf)) if os.path.exists(tf) else {}
+    allt[prec] = traffic
+    json.dump(allt, open(tf, "w"), indent=1, sort_keys=True)
+    b = os.path.join(src, "bench.json")
+    if os.path.exists(b) and os.path.getsize(b):
+        open(os.path.join(out, "%s_bench_%s.json" % (tag, prec)), "w").write(open(b).read())
+    print("wrote", tag, prec, sorted(rows))
+
+
+if __name__ == "__main__":
+    main()
