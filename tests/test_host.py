@@ -149,3 +149,16 @@ def test_oracle_network_matches_torch_lstm():
         ref = torch.cat([p21, p3], 1).numpy()
         assert q[0] == w.size
         assert np.abs(ref - probs).max() < 1e-5
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """include/c3r.h and include/c3r_io.h are C (not C++) headers; a C99 program resolves the entry points and runs the
+    calls that need no GPU (defaults, weight count, struct sizes, a failing open with its message)."""
+    import subprocess
+    exe = str(tmp_path / "abi_check")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_check.c"), "-o", exe, "-ldl"])
+    out = subprocess.run([exe, os.path.join(ROOT, "clair3_rna_amd", "libc3r.so"), os.path.join(ROOT, "clair3_rna_amd", "libc3r_io.so")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.startswith("ok c3r")
