@@ -83,10 +83,10 @@ def main():
 
     def tensor_build(e):
         # tensor build chunk by chunk (the reference's work items); the candidates of all chunks stay resident
+        # the reference's work items are the 13 chunks (each with its own +-33 bp halo); they go through ONE set of kernel
+        # launches (c3r_pileup_scan_regions) and their candidates stay resident for the network
         e.begin_batch()
-        total = 0
-        for (a, b) in chunks:
-            total += e.scan(a, b)
+        total = e.scan_regions(chunks)
         e.end_batch()
         return total
 

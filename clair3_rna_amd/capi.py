@@ -33,7 +33,7 @@ class C3RError(RuntimeError):
 
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
-           "c3r_pileup_scan", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
+           "c3r_pileup_scan", "c3r_pileup_scan_regions", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
            "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
@@ -67,6 +67,7 @@ def load_library():
     L.c3r_set_bed.argtypes = [vp, i32, vp, i64]
     L.c3r_set_sites.argtypes = [vp, vp, i64]
     L.c3r_pileup_scan.argtypes = [vp, i64, i64, C.POINTER(i64)]
+    L.c3r_pileup_scan_regions.argtypes = [vp, C.c_int32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.c3r_batch_begin.argtypes = [vp]
     L.c3r_batch_end.argtypes = [vp]
     L.c3r_batch_count.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
@@ -163,6 +164,19 @@ class Engine(object):
         tot = C.c_int64(0)
         self._chk(self.L.c3r_batch_count(self.h, C.byref(tot), None))
         self.n_candidates = tot.value          # resident candidates (== n outside batch mode)
+        return n.value
+
+    def scan_regions(self, regions):
+        """All (ctg_start, ctg_end) regions — e.g. the chunks of a contig — in one set of launches; same candidates, in
+        the same order, as successive scan() calls in batch mode."""
+        starts = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+        ends = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+        n = C.c_int64(0)
+        self._chk(self.L.c3r_pileup_scan_regions(self.h, len(starts), starts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                 ends.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(n)))
+        tot = C.c_int64(0)
+        self._chk(self.L.c3r_batch_count(self.h, C.byref(tot), None))
+        self.n_candidates = tot.value
         return n.value
 
     def begin_batch(self):

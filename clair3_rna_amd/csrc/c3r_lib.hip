@@ -59,8 +59,12 @@ struct c3r_ctx {
     DevBuf d_sites;
 
     // ---- scan state
-    int32_t reg_beg0 = 0, reg_end0 = 0;
-    int64_t n_pos = 0;
+    int32_t reg_beg0 = 0, reg_end0 = 0;   // first region of the most recent scan (c3r_get_columns)
+    int64_t n_pos = 0;                    // position slots of the most recent scan (all regions, tile-padded)
+    std::vector<TileGeo> h_geo;           // tile geometry of the most recent scan; re-uploaded only when it changes
+    std::vector<int64_t> geo_key;         // the (start, end) list h_geo was built for
+    DevBuf d_geo, d_lastrow;
+    int32_t n_regions = 0;
     DevBuf d_cols, d_depth, d_ncov, d_flags, d_skipmax, d_ev, d_small /* cursor,last_row,totals */, d_blockcnt;
     int64_t n_cand = 0, n_tok = 0;        // totals resident on the device (all scans of the current batch)
     int64_t last_cand = 0, last_base = 0; // candidates of the most recent scan and their offset in the batch
@@ -231,7 +235,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
-                      &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_ev, &ctx->d_small,
+                      &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     net_free(ctx->net);
@@ -401,9 +405,9 @@ static int run_gather(c3r_ctx *ctx, int rescale, int32_t *dst, bool with_sites) 
     GatherArgs g;
     g.cols = (const int32_t *)ctx->d_cols.p; g.depth = (const int32_t *)ctx->d_depth.p; g.ncov = (const int32_t *)ctx->d_ncov.p;
     g.flags = (const uint8_t *)ctx->d_flags.p; g.tile_cols = (const uint8_t *)ctx->d_tile_cols.p; g.cand_idx = (const int32_t *)ctx->d_cand.p; g.n_cand = (int32_t)ctx->last_cand;
-    g.n_pos = (int32_t)ctx->n_pos; g.reg_beg0 = ctx->reg_beg0;
+    g.n_pos = (int32_t)ctx->n_pos; g.geo = (const TileGeo *)ctx->d_geo.p;
     g.ref = (const uint8_t *)ctx->d_ref.p; g.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); g.ref_len = (int32_t)ctx->h_ref.size();
-    g.head_tail = ctx->prm.head_tail; g.last_row = (const int32_t *)((char *)ctx->d_small.p + 8);
+    g.head_tail = ctx->prm.head_tail; g.last_row = (const int32_t *)ctx->d_lastrow.p;
     g.rescale = rescale; g.max_depth = ctx->prm.max_depth_rescale;
     g.tensors = dst;
     g.raw = nullptr; g.skipmax = nullptr;
@@ -425,38 +429,62 @@ static int run_gather(c3r_ctx *ctx, int rescale, int32_t *dst, bool with_sites) 
 }
 
 int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n_candidates) {
-    if (!ctx || ctg_end < ctg_start) return C3R_EINVAL;
+    return c3r_pileup_scan_regions(ctx, 1, &ctg_start, &ctg_end, n_candidates);
+}
+
+int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int64_t *n_candidates) {
+    if (!ctx || n_regions < 1 || !ctg_starts || !ctg_ends) return C3R_EINVAL;
     if (ctx->h_ref.empty()) return fail(ctx, C3R_EINVAL, "c3r_set_reference must be called before c3r_pileup_scan");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int C = ctx->prm.channels;
-    // rows: 1-based [max(1, ctg_start-33), ctg_end+33]  (src/create_tensor_pileup.py:411-415)
-    int64_t es = ctg_start - C3R_WINDOW, ee = ctg_end + C3R_WINDOW;
-    if (es < 1) es = 1;
-    if (ee > INT32_MAX - 1) return fail(ctx, C3R_EINVAL, "region beyond 2^31");
-    ctx->reg_beg0 = (int32_t)(es - 1);
-    ctx->reg_end0 = (int32_t)ee;
-    ctx->n_pos = ee - es + 1;
+    // per region, rows: 1-based [max(1, ctg_start-33), ctg_end+33]  (src/create_tensor_pileup.py:411-415); slots: the regions
+    // back to back, each padded to whole tiles plus one guard tile (pileup_kernels.hpp, TileGeo)
+    std::vector<int64_t> key;
+    for (int r = 0; r < n_regions; ++r) {
+        if (ctg_ends[r] < ctg_starts[r]) return C3R_EINVAL;
+        if (ctg_ends[r] + C3R_WINDOW > INT32_MAX - 1) return fail(ctx, C3R_EINVAL, "region beyond 2^31");
+        key.push_back(ctg_starts[r]); key.push_back(ctg_ends[r]);
+    }
+    bool geo_changed = key != ctx->geo_key;
+    if (geo_changed) {
+        ctx->h_geo.clear();
+        for (int r = 0; r < n_regions; ++r) {
+            int64_t es = ctg_starts[r] - C3R_WINDOW, ee = ctg_ends[r] + C3R_WINDOW;
+            if (es < 1) es = 1;
+            const int32_t beg0 = (int32_t)(es - 1), end0 = (int32_t)ee;
+            for (int32_t p0 = beg0; p0 < end0; p0 += TILE) ctx->h_geo.push_back(TileGeo{p0, std::min(p0 + TILE, end0), r, 0});
+            ctx->h_geo.push_back(TileGeo{end0, end0, r, 0});          // guard tile
+            if (r == 0) { ctx->reg_beg0 = beg0; ctx->reg_end0 = end0; }
+        }
+        if ((int64_t)ctx->h_geo.size() * TILE > INT32_MAX - TILE) return fail(ctx, C3R_EINVAL, "regions too large for one scan (2^31 slots)");
+        ctx->geo_key = key;
+    }
+    ctx->n_regions = n_regions;
+    const int n_tiles = (int)ctx->h_geo.size();
+    ctx->n_pos = (int64_t)n_tiles * TILE;
     if (!ctx->batching) { ctx->n_cand = 0; ctx->n_tok = 0; }
     ctx->last_cand = 0; ctx->last_base = ctx->n_cand; ctx->tokens_ready = false;
     const int64_t base_cand = ctx->n_cand, base_tok = ctx->n_tok;
     const int64_t n_pos = ctx->n_pos;
-    const int n_tiles = (int)((n_pos + TILE - 1) / TILE);
     const int n_cblocks = (int)((n_pos + CMP_BLOCK - 1) / CMP_BLOCK);
     int rc;
+    if (geo_changed && (rc = upload(ctx, ctx->d_geo, ctx->h_geo.data(), ctx->h_geo.size()))) return rc;
+    if ((rc = ensure(ctx, ctx->d_lastrow, (size_t)n_regions * 4 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_cols, (size_t)n_pos * C * 4))) return rc;
     if ((rc = ensure(ctx, ctx->d_depth, (size_t)n_pos * 4))) return rc;
     if ((rc = ensure(ctx, ctx->d_ncov, (size_t)n_pos * 4))) return rc;
     if ((rc = ensure(ctx, ctx->d_flags, (size_t)n_pos))) return rc;
-    if ((rc = ensure(ctx, ctx->d_ev, ((size_t)ctx->n_indel_ops + 16 * (size_t)n_tiles + 16) * sizeof(EvRec)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ev, ((size_t)ctx->n_indel_ops * (size_t)std::min(n_regions, 2) + 16 * (size_t)n_tiles + 16) * sizeof(EvRec)))) return rc;
     if ((rc = ensure(ctx, ctx->d_small, 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_cols, (size_t)n_tiles + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_blockcnt, (size_t)(n_cblocks + 1) * 4))) return rc;
     if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_skipmax, (size_t)n_pos * 4))) return rc;
-    // d_small: [0..7] ev_cursor (u64), [8..11] last_row, [12..15] n_cand, [16..19] n_tok, [20..23] n_tile_list
-    int32_t init[6] = {0, 0, -1, 0, 0, 0};
+    // d_small: [0..7] ev_cursor (u64), [8..11] unused, [12..15] n_cand, [16..19] n_tok, [20..23] n_tile_list
+    int32_t init[6] = {0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_small.p, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_lastrow.p, 0xff, (size_t)n_regions * 4, ctx->stream));      // -1
     HIPCHK(ctx, hipMemsetAsync(ctx->d_flags.p, 0, (size_t)n_pos, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cols.p, 0, (size_t)n_tiles, ctx->stream));
 
@@ -470,14 +498,14 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     a.head_tail = ctx->prm.head_tail;
     { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
     a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->h_ref.size();
-    a.reg_beg0 = ctx->reg_beg0; a.reg_end0 = ctx->reg_end0;
+    a.geo = (const TileGeo *)ctx->d_geo.p;
     a.cols = (int32_t *)ctx->d_cols.p; a.depth = (int32_t *)ctx->d_depth.p; a.ncov = (int32_t *)ctx->d_ncov.p; a.flags = (uint8_t *)ctx->d_flags.p;
     a.lbed = (const int32_t *)ctx->d_bed[0].p; a.n_lbed = (int32_t)(ctx->h_bed[0].size() / 2); a.has_lbed = ctx->has_bed[0];
     a.cbed = (const int32_t *)ctx->d_bed[1].p; a.n_cbed = (int32_t)(ctx->h_bed[1].size() / 2); a.has_cbed = ctx->has_bed[1];
     a.sites = (const int32_t *)ctx->d_sites.p; a.n_sites = (int32_t)ctx->h_sites.size(); a.genotyping = ctx->prm.genotyping_mode;
     a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.min_cov = ctx->prm.min_coverage;
     a.snp_af = ctx->prm.snp_min_af; a.indel_af = ctx->prm.indel_min_af;
-    a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)ctx->d_small.p; a.last_row = (int32_t *)((char *)ctx->d_small.p + 8);
+    a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)ctx->d_small.p; a.last_row = (int32_t *)ctx->d_lastrow.p;
     a.splice = ctx->prm.splice_padding; a.skipmax = (int32_t *)ctx->d_skipmax.p;
     if (a.n_reads > 0) {
         Launch L(ctx, "k_tile_ranges");
@@ -496,7 +524,7 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
     {
         Launch L(ctx, "k_select");
         hipLaunchKernelGGL(k_select, dim3((unsigned)((n_pos + 255) / 256)), dim3(256), 0, ctx->stream, (uint8_t *)ctx->d_flags.p,
-                           (int)n_pos, ctx->reg_beg0, ctx->prm.head_tail, (const int32_t *)((char *)ctx->d_small.p + 8));
+                           (int)n_pos, (const TileGeo *)ctx->d_geo.p, ctx->prm.head_tail, (const int32_t *)ctx->d_lastrow.p);
     }
     {
         Launch L(ctx, "k_compact_count");
@@ -541,7 +569,8 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
         TokArgs t;
         t.reads = a.reads; t.cigar = a.cigar; t.seq = a.seq; t.prefmax_end = a.prefmax_end; t.n_reads = a.n_reads;
         t.rsegs = (const DevSeg *)ctx->d_rsegs.p; t.rseg_first = (const uint32_t *)ctx->d_rseg_first.p;
-        t.cand_idx = (const int32_t *)ctx->d_cand.p; t.n_cand = n_cand; t.reg_beg0 = ctx->reg_beg0;
+        t.cand_idx = (const int32_t *)ctx->d_cand.p; t.n_cand = n_cand; t.geo = (const TileGeo *)ctx->d_geo.p;
+        t.tile_rng = (const int4 *)ctx->d_tile_rng.p;
         t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
         t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;
         t.min_mq = a.min_mq; t.excl_flags = a.excl_flags;
@@ -626,11 +655,13 @@ int c3r_get_tokens(c3r_ctx *ctx, c3r_token_t *tokens, int64_t cap_tokens) {
 int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t *cols, int32_t *depth, uint8_t *flags, int64_t cap_pos) {
     if (!ctx) return C3R_EINVAL;
     if (region_start) *region_start = (int64_t)ctx->reg_beg0 + 1;
-    if (n_pos) *n_pos = ctx->n_pos;
+    // the first region of the most recent scan (its slots start at 0 and are contiguous)
+    const int64_t npos0 = (int64_t)ctx->reg_end0 - ctx->reg_beg0;
+    if (n_pos) *n_pos = npos0;
     if (!cols && !depth && !flags) return C3R_OK;
-    if (cap_pos < ctx->n_pos) return fail(ctx, C3R_EOVERFLOW, "need room for %lld positions", (long long)ctx->n_pos);
+    if (cap_pos < npos0) return fail(ctx, C3R_EOVERFLOW, "need room for %lld positions", (long long)npos0);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const size_t n = (size_t)ctx->n_pos;
+    const size_t n = (size_t)npos0;
     if (cols) HIPCHK(ctx, hipMemcpyAsync(cols, ctx->d_cols.p, n * ctx->prm.channels * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (depth) HIPCHK(ctx, hipMemcpyAsync(depth, ctx->d_depth.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (flags) HIPCHK(ctx, hipMemcpyAsync(flags, ctx->d_flags.p, n, hipMemcpyDeviceToHost, ctx->stream));

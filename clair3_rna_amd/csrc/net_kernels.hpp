@@ -575,17 +575,22 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
         if (FC4) {
             // ---- fused L4: facc[sb] += W4[t, dir][32 rows of this wave] x h_t^T   (K = H, B operand = h_t in LDS)
             const half8 *w4 = W4p + (((size_t)(dir * NET_T + t) * 4 + wave) * NGH) * 2 * 64 + lane;
+            // products ordered so that consecutive MFMAs never share an accumulator (only SB chains exist here)
 #pragma unroll 2
             for (int g = 0; g < NGH; ++g) {
                 const half8 ah = w4[(size_t)(g * 2 + 0) * 64], al = w4[(size_t)(g * 2 + 1) * 64];
+                half8 bh[SB], bl[SB];
 #pragma unroll
                 for (int sb = 0; sb < SB; ++sb) {
-                    const half8 bh = *(const half8 *)&hb_hi[nxt][32 * sb + j][16 * g + 8 * hh];
-                    const half8 bl = *(const half8 *)&hb_lo[nxt][32 * sb + j][16 * g + 8 * hh];
-                    facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, facc[sb], 0, 0, 0);
-                    facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, facc[sb], 0, 0, 0);
-                    facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, facc[sb], 0, 0, 0);
+                    bh[sb] = *(const half8 *)&hb_hi[nxt][32 * sb + j][16 * g + 8 * hh];
+                    bl[sb] = *(const half8 *)&hb_lo[nxt][32 * sb + j][16 * g + 8 * hh];
                 }
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[sb], facc[sb], 0, 0, 0);
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[sb], facc[sb], 0, 0, 0);
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[sb], facc[sb], 0, 0, 0);
             }
         }
         // ---- layer output planes y_hi / y_lo [t][(dir*H + u)/8][site][8 halves]: the layout the next layer's B-operand

@@ -73,6 +73,19 @@ struct EvRec {          // one indel event, bucketed by position inside a tile
 };
 static_assert(sizeof(EvRec) == 24, "EvRec must be 24 bytes");
 
+// One scan can cover several regions (the reference's chunks, each ctg_start-33 .. ctg_end+33) in ONE set of launches:
+// their position slots are laid out back to back, every region padded to whole tiles plus one empty guard tile, so that
+// slot arithmetic (slot +- 16) never crosses from one region into the next and the 33-contiguous-rows rule sees a gap there.
+// slot = tile * TILE + (p - p0).  Thirteen chunk launches of ~1.5 k tiles each were latency-bound; one launch of ~20 k tiles
+// fills the chip.
+struct TileGeo {
+    int32_t p0;        // 0-based genome position of the tile's first slot
+    int32_t p1;        // end (exclusive) of the positions that belong to the region; p1 == p0 for a guard tile
+    int32_t region;
+    int32_t pad;
+};
+static_assert(sizeof(TileGeo) == 16, "TileGeo must be 16 bytes");
+
 struct ScanArgs {
     const DevRead *reads;
     const uint32_t *cigar;
@@ -92,7 +105,7 @@ struct ScanArgs {
     const uint8_t *ref;           // upper-cased reference slice
     int32_t ref_beg0;             // 0-based position of ref[0]
     int32_t ref_len;
-    int32_t reg_beg0, reg_end0;   // rows exist only for positions in [reg_beg0, reg_end0)
+    const TileGeo *geo;           // [n_tiles] where each tile sits on the genome; several regions (chunks) share one launch
     int32_t *cols;                // [n_pos][C]
     int32_t *depth;               // [n_pos]
     int32_t *ncov;                // [n_pos] number of reads covering (incl. ref-skips)
@@ -105,7 +118,7 @@ struct ScanArgs {
     double snp_af, indel_af;
     EvRec *ev;                    // scratch, one slot per I/D op in the loaded reads (+ padding)
     unsigned long long *ev_cursor;
-    int32_t *last_row;            // atomicMax of the last position with a row
+    int32_t *last_row;            // [n_regions] atomicMax of the last SLOT (index into the position arrays) with a row
     int32_t splice;               // --enable_padding_in_splice_junction_regions: also produce skipmax[], materialise every tile
     int32_t *skipmax;             // [n_pos] max(#read starts, #read ends, #fwd ref-skips, #rev ref-skips) of the row
 };
@@ -348,8 +361,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wave_tot /* LDS [WAVE
 __global__ void k_tile_ranges(const ScanArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n_tiles) return;
-    const int t0 = a.reg_beg0 + t * TILE;
-    const int t1 = min(t0 + TILE, a.reg_end0);
+    const TileGeo tg = a.geo[t];
+    const int t0 = tg.p0, t1 = tg.p1;
+    if (t1 <= t0) return;                 // guard tile
     int4 r;
     r.x = upper_bound_gt(a.prefmax_end, a.n_reads, t0);
     r.y = lower_bound_pos(a.reads, a.n_reads, t1);
@@ -375,8 +389,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= *a.n_tile_list) return;          // the grid is sized for the worst case
     const int tile = a.tile_list[blockIdx.x];
-    const int t0 = a.reg_beg0 + tile * TILE;
-    const int t1 = min(t0 + TILE, a.reg_end0);
+    const TileGeo tg = a.geo[tile];
+    const int t0 = tg.p0, t1 = tg.p1;
+    const int slot0 = tile * TILE;        // index of the tile's first position in cols / depth / ncov / flags
     const int4 rng = a.tile_rng[tile];
     if ((a.abl & 16) && rng.z >= rng.w) return;   // ablation: skip intron-only tiles
     if ((a.abl & 32) && rng.z < rng.w) return;    // ablation: skip tiles with aligned bases
@@ -398,22 +413,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         bool is_row = false;
         if (p < t1 && cov > 0) is_row = !a.has_lbed || intervals_overlap(a.lbed, a.n_lbed, p, p + 1);
         if (p < t1) {
-            const int gi = p - a.reg_beg0;
+            const int gi = slot0 + tid;
             a.depth[gi] = 0; a.ncov[gi] = is_row ? cov : 0;
             bool cand = false;
             if (is_row && a.genotyping) cand = sorted_contains(a.sites, a.n_sites, p + 1);
             a.flags[gi] = (uint8_t)((is_row ? 1 : 0) | (cand ? 2 : 0));
         }
         if (a.head_tail) {
-            int mx = is_row ? p : -1;
+            int mx = is_row ? slot0 + tid : -1;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
             // racy pre-check is safe (the value only grows) and keeps ~10^5 tiles from serialising on one L2 atomic
-            if ((tid & 63) == 0 && mx > *(volatile int32_t *)a.last_row) atomicMax(a.last_row, mx);
+            if ((tid & 63) == 0 && mx > *(volatile int32_t *)&a.last_row[tg.region]) atomicMax(&a.last_row[tg.region], mx);
         }
         if (a.splice) {
             // splice padding writes into low-depth columns in place: they must exist
-            int32_t *gcol = a.cols + (size_t)(t0 - a.reg_beg0) * C;
+            int32_t *gcol = a.cols + (size_t)slot0 * C;
             for (int i = tid; i < (t1 - t0) * C; i += SCAN_THREADS) gcol[i] = 0;
             if (tid == 0) a.tile_cols[tile] = 1;
         }
@@ -533,21 +548,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
 
     // ---- write the tile: columns coalesced, then per-position metadata
     const int npos = t1 - t0;
-    int32_t *gcol = a.cols + (size_t)(t0 - a.reg_beg0) * C;
+    int32_t *gcol = a.cols + (size_t)slot0 * C;
     if (!(a.abl & 8))
     for (int i = tid; i < npos * C; i += SCAN_THREADS) gcol[i] = s_cnt[i];
     if (tid == 0) a.tile_cols[tile] = 1;
     if (p < t1) {
-        const int gi = p - a.reg_beg0;
+        const int gi = slot0 + tid;
         a.depth[gi] = depth;
         a.ncov[gi] = is_row ? my_cov : 0;
         a.flags[gi] = (uint8_t)((is_row ? 1 : 0) | (cand ? 2 : 0));
     }
     if (a.head_tail) {
-        int mx = is_row ? p : -1;
+        int mx = is_row ? slot0 + tid : -1;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
-        if ((tid & 63) == 0 && mx > *(volatile int32_t *)a.last_row) atomicMax(a.last_row, mx);
+        if ((tid & 63) == 0 && mx > *(volatile int32_t *)&a.last_row[tg.region]) atomicMax(&a.last_row[tg.region], mx);
     }
 }
 
@@ -565,8 +580,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) 
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= *a.n_tile_list) return;
     const int tile = a.tile_list[blockIdx.x];
-    const int t0 = a.reg_beg0 + tile * TILE;
-    const int t1 = min(t0 + TILE, a.reg_end0);
+    const TileGeo tg = a.geo[tile];
+    const int t0 = tg.p0, t1 = tg.p1;
+    const int slot0 = tile * TILE;        // index of the tile's first position in cols / depth / ncov / flags
     const int4 rng = a.tile_rng[tile];
     for (int i = tid; i < 2 * (TILE + 1); i += SCAN_THREADS) { (&s_cov[0][0])[i] = 0; (&s_seg[0][0])[i] = 0; }
     s_start[tid] = 0; s_end[tid] = 0;
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) 
     }
     const int p = t0 + tid;
     if (p < t1) {
-        const int gi = p - a.reg_beg0;
+        const int gi = slot0 + tid;
         int m = max(s_start[tid], s_end[tid]);
         m = max(m, max(v[0] - v[2], v[1] - v[3]));
         a.skipmax[gi] = (a.flags[gi] & 1) ? m : 0;
@@ -608,7 +624,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) 
 // the 33 positions centre-16..centre+16 are contiguous rows; with head_tail the ring is pre-filled
 // with zero columns after every gap (left side always OK) and the stream end is flushed with 16
 // zero columns (right side OK only when the run reaches the last row of the stream).
-__global__ void k_select(uint8_t *flags, int n_pos, int reg_beg0, int head_tail, const int32_t *last_row) {
+__global__ void k_select(uint8_t *flags, int n_pos, const TileGeo *geo, int head_tail, const int32_t *last_row) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pos) return;
     const uint8_t f = flags[i];
@@ -618,7 +634,7 @@ __global__ void k_select(uint8_t *flags, int n_pos, int reg_beg0, int head_tail,
         if (i - C3R_FLANK < 0 || i + C3R_FLANK >= n_pos) ok = false;
         else for (int q = i - C3R_FLANK; q <= i + C3R_FLANK; ++q) if (!(flags[q] & 1)) { ok = false; break; }
     } else {
-        const int last = *last_row - reg_beg0;
+        const int last = last_row[geo[i / TILE].region];
         const int hi = min(i + C3R_FLANK, last);
         for (int q = i + 1; q <= hi; ++q) if (!(flags[q] & 1)) { ok = false; break; }
     }
@@ -691,7 +707,7 @@ __global__ __launch_bounds__(CMP_THREADS) void k_compact_write(const uint8_t *fl
 // float64, truncated toward zero by the int32 store) and writes the site record.
 struct GatherArgs {
     const int32_t *cols; const int32_t *depth; const int32_t *ncov; const uint8_t *flags; const uint8_t *tile_cols;
-    const int32_t *cand_idx; int32_t n_cand; int32_t n_pos; int32_t reg_beg0;
+    const int32_t *cand_idx; int32_t n_cand; int32_t n_pos; const TileGeo *geo;
     const uint8_t *ref; int32_t ref_beg0; int32_t ref_len;
     int32_t head_tail; const int32_t *last_row;
     int32_t rescale; int32_t max_depth;   // 144
@@ -709,8 +725,9 @@ __device__ __forceinline__ void gather_window(const GatherArgs &g, int w, int ci
         int q = ci;
         while (q - 1 >= 0 && q - 1 >= ci - C3R_FLANK && (g.flags[q - 1] & 1)) --q;
         lo_valid = q;
-        hi_valid = min(ci + C3R_FLANK, *g.last_row - g.reg_beg0);
+        hi_valid = min(ci + C3R_FLANK, g.last_row[g.geo[ci / TILE].region]);
     }
+    const int pc = g.geo[ci / TILE].p0 + (ci % TILE);      // genome position of the centre; slots +-16 are positions +-16
     const int dep = g.depth[ci];
     const bool scale = g.rescale && dep > 0 && (double)dep > (double)g.max_depth * 1.5;
     const double sf = (double)dep / (double)g.max_depth;
@@ -729,12 +746,12 @@ __device__ __forceinline__ void gather_window(const GatherArgs &g, int w, int ci
     if (g.sites) {
         c3r_site_t *s = &g.sites[w];
         if (lane < C3R_WINDOW) {
-            const int rp = g.reg_beg0 + first + lane - g.ref_beg0;
+            const int rp = pc - C3R_FLANK + lane - g.ref_beg0;
             s->ref33[lane] = (rp >= 0 && rp < g.ref_len) ? (char)g.ref[rp] : 'A';
         } else if (lane < C3R_WINDOW + 3) {
             s->ref33[lane] = 0;
         }
-        if (lane == 0) { s->pos = g.reg_beg0 + ci + 1; s->depth = dep; s->n_tok = g.ncov[ci]; s->tok_off = 0; }
+        if (lane == 0) { s->pos = pc + 1; s->depth = dep; s->n_tok = g.ncov[ci]; s->tok_off = 0; }
     }
     if (g.tok_cnt && lane == 0) g.tok_cnt[w] = g.ncov[ci];
 }
@@ -784,7 +801,7 @@ __global__ __launch_bounds__(256) void k_splice_gather(const GatherArgs g) {
             int qq = ci;
             while (qq - 1 >= 0 && qq - 1 >= ci - C3R_FLANK && (g.flags[qq - 1] & 1)) --qq;
             lo_valid = qq;
-            hi_valid = min(ci + C3R_FLANK, *g.last_row - g.reg_beg0);
+            hi_valid = min(ci + C3R_FLANK, g.last_row[g.geo[ci / TILE].region]);
             if (lo_valid > ci - C3R_FLANK && lo_valid != z_run) {       // first window of a new run: fresh zero list
                 for (int i = lane; i < C; i += 64) zc[i] = 0;
                 z_run = lo_valid;
@@ -806,7 +823,8 @@ __global__ __launch_bounds__(256) void k_splice_gather(const GatherArgs g) {
         // candidates closer than 16 rows to the end of the stream leave through the tail flush, which does not pad (:613-637)
         const bool pads = hi_valid == ci + C3R_FLANK;
         if (pads && (double)ms / (double)md > 0.2) {
-            const int rp = g.reg_beg0 + ci - g.ref_beg0;
+            const int pc = g.geo[ci / TILE].p0 + (ci % TILE);
+            const int rp = pc - g.ref_beg0;
             const uint8_t rc = (rp >= 0 && rp < g.ref_len) ? g.ref[rp] : (uint8_t)'N';
             const int cu = pad_channel(rc, false), cl = pad_channel(rc, true);
             int sf = cu >= 0 ? cols[(size_t)ci * C + cu] : 0, sr = cl >= 0 ? cols[(size_t)ci * C + cl] : 0;
@@ -814,7 +832,7 @@ __global__ __launch_bounds__(256) void k_splice_gather(const GatherArgs g) {
             const double fpct = (sf + sr > 0) ? (double)sf / (double)(sf + sr) : 0.0;
             const double rpct = 1 - fpct;
             if (in_win && lane != C3R_FLANK && (double)cur < (double)cdepth * 0.2) {
-                int rq = g.reg_beg0 + q - g.ref_beg0;
+                int rq = pc + (q - ci) - g.ref_beg0;
                 if (rq < 0) rq += g.ref_len;                  // Python negative index (slots left of the contig start)
                 const uint8_t rb = (rq >= 0 && rq < g.ref_len) ? g.ref[rq] : (uint8_t)'N';
                 const int u = pad_channel(rb, false), l = pad_channel(rb, true);
@@ -841,7 +859,8 @@ struct TokArgs {
     const DevRead *reads; const uint32_t *cigar; const uint8_t *seq; const int32_t *prefmax_end; int32_t n_reads;
     const DevSeg *rsegs;           // aligned segments in READ order
     const uint32_t *rseg_first;    // [n_reads+1] first segment of each read in rsegs
-    const int32_t *cand_idx; int32_t n_cand; int32_t reg_beg0;
+    const int32_t *cand_idx; int32_t n_cand; const TileGeo *geo;
+    const int4 *tile_rng;          // from k_tile_ranges: the reads whose span can overlap the candidate's tile
     const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
     int32_t tok_base;              // tokens already resident from earlier scans of the batch
     int32_t min_mq, excl_flags;
@@ -851,9 +870,11 @@ __global__ __launch_bounds__(256) void k_tokens(const TokArgs t) {
     const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (w >= t.n_cand) return;
-    const int p = t.reg_beg0 + t.cand_idx[w];
-    const int lo = upper_bound_gt(t.prefmax_end, t.n_reads, p);
-    const int hi = lower_bound_pos(t.reads, t.n_reads, p + 1);
+    const int ci = t.cand_idx[w];
+    const int p = t.geo[ci / TILE].p0 + (ci % TILE);
+    // (two 16-step binary searches per candidate were most of this kernel's latency; the tile's range is a superset)
+    const int4 rng = t.tile_rng[ci / TILE];
+    const int lo = rng.x, hi = rng.y;
     const int base_off = t.tok_base + t.tok_off[w];
     if (lane == 0) t.sites[w].tok_off = (uint32_t)base_off;
     int written = 0;

@@ -81,6 +81,11 @@ int c3r_set_sites(c3r_ctx *ctx, const int32_t *sites, int64_t n);
  * selection, window gather with the depth>216 rescale (clair3_rna/utils.py:88-92).  Tensors and
  * site records stay resident on the device.  Returns the number of emitted candidates. */
 int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n_candidates);
+/* The same for several regions (the chunks of one contig) in ONE set of kernel launches: results are exactly those of
+ * n_regions successive c3r_pileup_scan calls in batch mode — candidates of region 0 first, each region with its own
+ * +-33 bp halo, head/tail flush and window rule — but the chip sees ~20 k tiles at once instead of 13 latency-bound
+ * launches of ~1.5 k.  *n_candidates receives the total. */
+int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int64_t *n_candidates);
 /* Batch mode: between c3r_batch_begin and c3r_batch_end every scan APPENDS its candidates (tensors, sites,
  * tokens) to the device-resident batch instead of replacing it, so that the chunks of a whole contig go through
  * the network in one launch per layer (the reference batches 200 sites, shared/param_p.py:51; 288 GB of HBM let

@@ -100,3 +100,39 @@ def test_full_chr20_properties(eng):
     assert len(P) == len(pos_cat) > 150000
     assert np.allclose(P[:, :21].sum(1), 1, atol=1e-5) and np.allclose(P[:, 21:].sum(1), 1, atol=1e-5)
     assert np.isfinite(P).all() and P.min() >= 0
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(head_tail=1), dict(splice_padding=1), dict(channels=30)])
+def test_scan_regions_equals_successive_chunk_scans(eng, kw):
+    """c3r_pileup_scan_regions: all chunks of a contig in one set of launches == the chunk-by-chunk scans in batch mode
+    (same candidates in the same order, same tensors, sites and tokens), including each chunk's own +-33 bp halo,
+    head/tail flush and the in-place splice padding; chunk sizes chosen so that some regions end exactly on a tile edge."""
+    from clair3_rna_amd import capi, synth
+    L = 1536 * 256 + 7            # chunk size 256*k: region lengths hit multiples of the 256-position tile
+    ref, rs, _ = synth.generate_contig(contig_len=L, seed=91, depth=25.0, expressed_frac=0.08, intron_lo=100.0, intron_hi=4000.0,
+                                       phased=(kw.get("channels") == 30))
+    ref = ref.decode()
+    size = 256 * 190 + 33 * 2
+    chunks = [(a, min(a + size, L)) for a in range(1, L, size)]
+    assert len(chunks) >= 8
+    eng.params = capi.default_params()
+    eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.set_params(**kw)
+    eng.load_reads(rs)
+    eng.set_reference(1, ref)
+    eng.begin_batch()
+    n_seq = sum(eng.scan(a, b) for a, b in chunks)
+    eng.end_batch()
+    X1, S1, T1 = eng.tensors(), eng.sites(), eng.tokens()
+    eng.begin_batch()
+    n_one = eng.scan_regions(chunks)
+    eng.end_batch()
+    X2, S2, T2 = eng.tensors(), eng.sites(), eng.tokens()
+    assert n_seq == n_one > 500
+    assert np.array_equal(X1, X2)
+    assert S1.tobytes() == S2.tobytes() and T1.tobytes() == T2.tobytes()
+    # region order, then position order inside a region (the halos overlap, so positions may repeat across regions)
+    pos = S2["pos"].astype(np.int64)
+    assert (np.diff(pos) < 0).sum() <= len(chunks) - 1
+    eng.params = capi.default_params()
+    eng.set_params()
