@@ -136,3 +136,40 @@ def test_scan_regions_equals_successive_chunk_scans(eng, kw):
     assert (np.diff(pos) < 0).sum() <= len(chunks) - 1
     eng.params = capi.default_params()
     eng.set_params()
+
+
+def test_two_contexts_on_two_streams_like_the_bench(eng):
+    """bench.py pipelines passes on two contexts (two HIP streams, one GPU): context B builds tensors while context A's
+    persistent LSTM workgroups run.  Interleaved asynchronous use must give what one context gives synchronously."""
+    from clair3_rna_amd import capi, synth
+    L = 1500000
+    ref, rs, _ = synth.generate_contig(contig_len=L, seed=123, depth=20.0, expressed_frac=0.05)
+    ref = ref.decode()
+    w = synth.random_weights(18, seed=9)
+    chunks = [(a, min(a + 400000, L)) for a in range(1, L, 400000)]
+    eng.params = capi.default_params()
+    eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.set_params()
+    eng.load_reads(rs); eng.set_reference(1, ref); eng.load_weights(w, 18); eng.set_precision("f16x3")
+    eng.begin_batch(); n = eng.scan_regions(chunks); eng.end_batch()
+    want = eng.infer().copy()
+    assert n > 1000
+    e2 = capi.Engine(0)
+    try:
+        e2.set_params(); e2.load_reads(rs); e2.set_reference(1, ref); e2.load_weights(w, 18); e2.set_precision("f16x3")
+        engs, pending, got = [eng, e2], [None, None], []
+        for i in range(6):
+            e = engs[i & 1]
+            if pending[i & 1] is not None:
+                got.append(e.fetch_probs(pending[i & 1]).copy())
+            e.begin_batch(); m = e.scan_regions(chunks); e.end_batch()
+            assert m == n
+            e.infer(fetch=False)
+            pending[i & 1] = m
+        for k in (0, 1):
+            got.append(engs[k].fetch_probs(pending[k]).copy())
+        assert len(got) == 6
+        for g in got:
+            assert np.array_equal(g, want)          # same kernels, same data: bitwise equal
+    finally:
+        e2.close()
