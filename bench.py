@@ -63,11 +63,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    # C3R_BENCH_ONE_GPU=1 (test hook for 1-GPU boxes): all ranks share device 0 and rendezvous over gloo, so that the N > 1
+    # control flow (sharding by rank, barrier, max-over-ranks timing, summed sites) can be exercised; never set by the driver
+    one_gpu = os.environ.get("C3R_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = None
+    dist, red_dev = None, "cuda"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+            red_dev = "cpu"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from clair3_rna_amd import capi, synth
     contig_len = args.contig_len or synth.CHR20_LEN
@@ -148,8 +157,8 @@ def main():
     if dist is not None:
         dist.barrier()
         from clair3_rna_amd import shard
-        elapsed = shard.reduce_max(dist, elapsed, device="cuda")     # max over ranks
-        sites = int(shard.reduce_sum(dist, sites, device="cuda"))    # whole-job aggregate
+        elapsed = shard.reduce_max(dist, elapsed, device=red_dev)    # max over ranks
+        sites = int(shard.reduce_sum(dist, sites, device=red_dev))   # whole-job aggregate
     sites_per_step_rank = sites / max(1, args.steps) / world
 
     # ---- per-kernel durations, live, with HIP events on the engine's stream (one extra untimed step)
