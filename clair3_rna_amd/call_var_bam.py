@@ -165,12 +165,12 @@ def Run(args, engine=None):
     eng.set_reference(ref_start, ref_seq)
     eng.load_weights(io.load_weights(args.chkpnt_fn, channels), channels)
     n = eng.scan(ctg_start, ctg_end)
-    rows = []
+    rows = b""
     if n:
         eng.infer(fetch=False)
         qual = args.qual if args.qual is not None else 2            # call_variants.py:1827 default
         # A8 on host threads inside libc3r: ordered alt_info from the per-read tokens, decode, row text
-        rows = eng.call_rows(ctg, qual=qual, show_ref=args.show_ref)
+        rows, _n_rows = eng.call_rows_text(ctg, qual=qual, show_ref=args.show_ref)
         if args.tensor_dump_fn:
             sites_out, toks = eng.sites(), eng.tokens()
             raw = eng.tensors(rescaled=False)

@@ -145,9 +145,16 @@ class Engine(object):
         self._chk(self.L.c3r_load_reads(self.h, _ptr(rs.reads), len(rs.reads), _ptr(rs.cigar), len(rs.cigar), _ptr(rs.seq), len(rs.seq)))
 
     def set_reference(self, ref_start, seq):
-        b = seq.encode() if isinstance(seq, str) else bytes(seq)
-        self.ref_start, self.ref_seq = ref_start, b.decode().upper()
+        b = seq.encode() if isinstance(seq, str) else (seq if isinstance(seq, bytes) else bytes(seq))
+        self.ref_start, self._ref_bytes, self._ref_upper = ref_start, b, None
         self._chk(self.L.c3r_set_reference(self.h, ref_start, b, len(b)))
+
+    @property
+    def ref_seq(self):
+        """Upper-cased reference slice as str (debug dumps only: 40 ms per 64 MB contig, so built on demand)."""
+        if self._ref_upper is None:
+            self._ref_upper = self._ref_bytes.decode().upper()
+        return self._ref_upper
 
     def set_bed(self, which, intervals):
         a = np.ascontiguousarray(np.asarray(intervals if intervals is not None else [], dtype=np.int32).reshape(-1, 2))
@@ -245,14 +252,19 @@ class Engine(object):
         self._chk(self.L.c3r_get_probs(self.h, _ptr(probs), n))
         return probs
 
-    def call_rows(self, ctg, qual=2, show_ref=True):
-        """A8 on host threads (C++): VCF rows for the resident candidates, after infer()."""
+    def call_rows_text(self, ctg, qual=2, show_ref=True):
+        """A8 on host threads (C++): the VCF rows of the resident candidates as ONE bytes object (newline-terminated rows),
+        ready to be appended to the chunk's VCF; returns (text, n_rows).  After infer()."""
         n, nr = C.c_int64(0), C.c_int64(0)
         self._chk(self.L.c3r_call_rows(self.h, ctg.encode(), -1 if qual is None else int(qual), int(show_ref), C.byref(n), C.byref(nr)))
         buf = C.create_string_buffer(n.value + 1)
         self._chk(self.L.c3r_get_rows(self.h, buf, n.value + 1))
-        text = buf.value.decode()
-        return text.split("\n")[:-1] if text else []
+        return buf.raw[:n.value], nr.value
+
+    def call_rows(self, ctg, qual=2, show_ref=True):
+        """The same as a list of row strings (tests; 200 k Python strings cost more than producing the rows)."""
+        text, _ = self.call_rows_text(ctg, qual, show_ref)
+        return text.decode().split("\n")[:-1] if text else []
 
     # ---- measurement
     def synchronize(self):

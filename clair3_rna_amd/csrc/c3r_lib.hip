@@ -1,6 +1,7 @@
 // c3r_lib.hip — host side of libc3r.so: the C-ABI of include/c3r.h over the gfx950 kernels.
 // No CPU fallback: every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <climits>
@@ -76,6 +77,7 @@ struct c3r_ctx {
     NetState net;
 
     // ---- host decode (A8)
+    void *h_stage = nullptr; size_t h_stage_cap = 0;     // pinned staging buffer for sites + tokens + probabilities
     std::string rows_cache;
     int64_t rows_count = 0;
 };
@@ -239,6 +241,7 @@ void c3r_destroy(c3r_ctx *ctx) {
                       &ctx->d_blockcnt, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     net_free(ctx->net);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -366,8 +369,14 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
 int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t len) {
     if (!ctx || !ref || len < 0 || ref_start < 1) return C3R_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    ctx->h_ref.assign(ref, ref + len);
-    for (auto &ch : ctx->h_ref) if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+    ctx->h_ref.resize((size_t)len);
+    {
+        char *dst = &ctx->h_ref[0];
+        for (int64_t i = 0; i < len; ++i) {          // branch-free, so the loop vectorises (64 MB per contig)
+            const unsigned char c = (unsigned char)ref[i];
+            dst[i] = (char)(c - (((unsigned)(c - 'a') < 26u) << 5));
+        }
+    }
     ctx->ref_start1 = ref_start;
     int rc = upload(ctx, ctx->d_ref, (const uint8_t *)ctx->h_ref.data(), ctx->h_ref.size());
     if (rc) return rc;
@@ -771,18 +780,37 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
     if (n == 0) return C3R_OK;
     if (!ctx->net.d_probs || n > ctx->net.cap_sites) return fail(ctx, C3R_EINVAL, "c3r_infer must run before c3r_call_rows");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    std::vector<c3r_site_t> sites((size_t)n);
-    std::vector<c3r_token_t> toks((size_t)std::max<int64_t>(ctx->n_tok, 1));
-    std::vector<float> probs((size_t)n * C3R_NPROB);
-    HIPCHK(ctx, hipMemcpyAsync(sites.data(), ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->n_tok) HIPCHK(ctx, hipMemcpyAsync(toks.data(), ctx->d_tok.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(probs.data(), ctx->net.d_probs, probs.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    const bool timing = getenv("C3R_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
+    // one pinned staging buffer, grown geometrically and kept: 200 MB of pageable vectors cost 37 ms just to zero-fill
+    const size_t b_sites = ((size_t)n * sizeof(c3r_site_t) + 255) & ~(size_t)255;
+    const size_t b_toks = ((size_t)std::max<int64_t>(ctx->n_tok, 1) * sizeof(c3r_token_t) + 255) & ~(size_t)255;
+    const size_t b_probs = (size_t)n * C3R_NPROB * sizeof(float);
+    if (b_sites + b_toks + b_probs > ctx->h_stage_cap) {
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr; ctx->h_stage_cap = 0;
+        const size_t cap = (b_sites + b_toks + b_probs) * 5 / 4 + 4096;
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
+        ctx->h_stage_cap = cap;
+    }
+    c3r_site_t *sites = (c3r_site_t *)ctx->h_stage;
+    c3r_token_t *toks = (c3r_token_t *)((char *)ctx->h_stage + b_sites);
+    float *probs = (float *)((char *)ctx->h_stage + b_sites + b_toks);
+    const auto t1 = now();
+    HIPCHK(ctx, hipMemcpyAsync(sites, ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->n_tok) HIPCHK(ctx, hipMemcpyAsync(toks, ctx->d_tok.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, b_probs, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t2 = now();
     const uint8_t *seq = ctx->h_seq.data();
     const std::vector<DevRead> &reads = ctx->h_reads;
     auto get_read = [&](uint32_t r) { return ReadView{seq, reads[r].seq_off, reads[r].l_seq}; };
-    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    if ((int64_t)nt > n) nt = 1;
+    // host threads: C3R_THREADS, else up to 32 (one process per GPU shares the node's cores with its peers)
+    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("C3R_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    if ((int64_t)nt * 64 > n) nt = 1;
     std::vector<std::string> part(nt);
     std::vector<int64_t> cnt(nt, 0);
     auto work = [&](unsigned t) {
@@ -790,9 +818,9 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
         AltDict alt;
         for (int64_t i = a; i < b; ++i) {
             int depth_tok;
-            alt_from_tokens(toks.data() + sites[(size_t)i].tok_off, sites[(size_t)i].n_tok, get_read, ctx->h_ref, ctx->ref_start1, sites[(size_t)i].pos,
+            alt_from_tokens(toks + sites[(size_t)i].tok_off, sites[(size_t)i].n_tok, get_read, ctx->h_ref, ctx->ref_start1, sites[(size_t)i].pos,
                             alt, depth_tok);
-            if (vcf_row(ctg, sites[(size_t)i].pos, sites[(size_t)i].ref33, sites[(size_t)i].depth, alt, probs.data() + (size_t)i * C3R_NPROB, qual,
+            if (vcf_row(ctg, sites[(size_t)i].pos, sites[(size_t)i].ref33, sites[(size_t)i].depth, alt, probs + (size_t)i * C3R_NPROB, qual,
                         show_ref != 0, part[t]))
                 cnt[t]++;
         }
@@ -801,7 +829,13 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
     for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
     work(0);
     for (auto &x : th) x.join();
+    const auto t3 = now();
+    size_t total = 0;
+    for (unsigned t = 0; t < nt; ++t) total += part[t].size();
+    ctx->rows_cache.reserve(total + 1);
     for (unsigned t = 0; t < nt; ++t) { ctx->rows_cache += part[t]; ctx->rows_count += cnt[t]; }
+    if (timing) fprintf(stderr, "[c3r_call_rows] alloc %.1f ms, D2H %.1f ms (%.1f MB), decode %.1f ms on %u threads, concat %.1f ms\n", ms(t0, t1), ms(t1, t2),
+                        ((double)n * (sizeof(c3r_site_t) + 4 * C3R_NPROB) + (double)ctx->n_tok * sizeof(c3r_token_t)) / 1e6, ms(t2, t3), nt, ms(t3, now()));
     *out_len = (int64_t)ctx->rows_cache.size();
     if (n_rows) *n_rows = ctx->rows_count;
     return C3R_OK;

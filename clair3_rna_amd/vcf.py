@@ -42,11 +42,17 @@ def header(ref_fn=None, cmd_fn=None, sample_name="SAMPLE"):
 
 
 def write_chunk_vcf(path, header_text, rows):
-    """Header + rows; the file is deleted again when there is no record (call_variants.py:1594-1599)."""
-    with open(path, "w") as f:
-        print(header_text, file=f)
-        for r in rows:
-            print(r, file=f)
+    """Header + rows; the file is deleted again when there is no record (call_variants.py:1594-1599).
+    `rows` is a list of row strings or one bytes blob of newline-terminated rows (Engine.call_rows_text)."""
+    if isinstance(rows, (bytes, bytearray)):
+        with open(path, "wb") as f:
+            f.write(header_text.encode() + b"\n")
+            f.write(rows)
+    else:
+        with open(path, "w") as f:
+            print(header_text, file=f)
+            for r in rows:
+                print(r, file=f)
     if not rows:
         os.remove(path)
         return False
