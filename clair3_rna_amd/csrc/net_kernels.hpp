@@ -267,6 +267,11 @@ __device__ __forceinline__ float tanh_scaled(float acc) {      // tanh(acc * 2^-
     return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((-2.8853900817779268f * WUNSCALE) * acc)), -1.0f);
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 // Interleave plan for one scheduling region: NM MFMAs with NV global loads and ND LDS reads spread evenly between them
 // (sched_group_barrier masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read).  One wavefront per SIMD issues everything:
 // a burst of 14 wave-wide 16-byte loads holds the issue port for a few hundred cycles and drains the matrix pipe's
@@ -564,7 +569,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     vh[q] = (_Float16)hval[4 * sb + q];
-                    vl[q] = (_Float16)(hval[4 * sb + q] - (float)vh[q]);
+                    float d = hval[4 * sb + q] - (float)vh[q];
+                    asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
+                    vl[q] = (_Float16)d;
                 }
                 *(half4 *)&hb_hi[nxt][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vh;
                 *(half4 *)&hb_lo[nxt][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vl;
@@ -681,76 +688,65 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
     auto phase = [&](auto mma_c, auto gate_c, floatx16 (&accM)[NT][SB], const int gm, const int tm,
                      floatx16 (&accG)[NT][SB], const int gg, const int tg) {
         constexpr bool MMA = decltype(mma_c)::value, GATE = decltype(gate_c)::value;
-        auto ldx = [&](int g, half8 (&bh)[SB]) {
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb) {
-                // branch-free (a divergent guard would split the scheduling region the interleave lives in): always
-                // load from a clamped index, then select
-                const int32_t *xp = xin + xoff[gm][sb] + (size_t)tm * CIN;
-                const int k0 = 16 * g + 8 * hh;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = k0 + e;
-                    const int32_t v = xp[k < CIN ? k : CIN - 1];
-                    bh[sb][e] = (k < CIN) ? (_Float16)(float)v : (_Float16)0.f;
+        // ---- the cell update of one (tile, site block) = 4 units per lane, cut into NS short stages of 4 independent
+        // operations each.  A wavefront issues IN ORDER: an MFMA that finds the matrix pipe busy blocks everything behind
+        // it, so VALU work only hides if it sits BETWEEN consecutive MFMAs, a handful of instructions at a time
+        // (<= 5-7 single-issue instructions fit into the 32 cycles of one MFMA).  sched_group_barrier hints did not
+        // get the compiler there (gaps of 0..94 instructions); the regions below are therefore written slot by slot —
+        // one MFMA, one prefetch item, one or two stages, sched_barrier — which pins exactly that order.
+        constexpr int NS = 25;
+        float ei[4], ef[4], eg[4], eo[4], tq[4], cq[4], hv[4];
+        half4 vh, vl;
+        auto stage = [&](auto sc, const int tt, const int sb) {
+            // no implicit mul+add fusion: the phase lambda is instantiated several times (group A / B, with / without MFMAs,
+            // 16 / 24 / 25 slots) and which stages share a slot differs between them; a site's result must not depend on
+            // which copy it ran through (batch composition decides whether it lands in group A or B)
+#pragma clang fp contract(off)
+            constexpr int S = decltype(sc)::value;
+            constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
+            float4 *cp = (float4 *)&cbuf[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh];
+#define C3R_Q _Pragma("unroll") for (int q = 0; q < 4; ++q)
+            if constexpr (S == 0) { C3R_Q ei[q] = K1 * accG[tt][sb][4 * q + 0]; }
+            if constexpr (S == 1) { C3R_Q ei[q] = __builtin_amdgcn_exp2f(ei[q]); }
+            if constexpr (S == 2) { C3R_Q ei[q] = fminf(ei[q], 1e18f); }
+            if constexpr (S == 3) { C3R_Q ef[q] = K1 * accG[tt][sb][4 * q + 1]; }
+            if constexpr (S == 4) { C3R_Q ef[q] = __builtin_amdgcn_exp2f(ef[q]); }
+            if constexpr (S == 5) { C3R_Q eg[q] = K2 * accG[tt][sb][4 * q + 2]; }
+            if constexpr (S == 6) { C3R_Q eg[q] = __builtin_amdgcn_exp2f(eg[q]); }
+            if constexpr (S == 7) { C3R_Q eg[q] = fminf(eg[q], 1e18f); }
+            if constexpr (S == 8) { C3R_Q eo[q] = K1 * accG[tt][sb][4 * q + 3]; }
+            if constexpr (S == 9) { C3R_Q eo[q] = __builtin_amdgcn_exp2f(eo[q]); }
+            if constexpr (S == 10) { C3R_Q eo[q] = fminf(eo[q], 1e18f); }
+            if constexpr (S == 11) { C3R_Q tq[q] = (1.0f + ei[q]) * (1.0f + eg[q]); }
+            if constexpr (S == 12) { C3R_Q tq[q] = __builtin_amdgcn_rcpf(tq[q]); }
+            if constexpr (S == 13) { C3R_Q tq[q] = (1.0f - eg[q]) * tq[q]; }                       // sig(i) * tanh(g)
+            if constexpr (S == 14) { C3R_Q ef[q] = __builtin_amdgcn_rcpf(1.0f + ef[q]);            // sig(f)
+                                     const float4 cv = *cp; cq[0] = cv.x; cq[1] = cv.y; cq[2] = cv.z; cq[3] = cv.w; }
+            if constexpr (S == 15) { C3R_Q cq[q] = fmaf(ef[q], cq[q], tq[q]); *cp = make_float4(cq[0], cq[1], cq[2], cq[3]); }
+            if constexpr (S == 16) { C3R_Q eg[q] = __builtin_amdgcn_exp2f(-2.8853900817779268f * cq[q]); }   // e_c
+            if constexpr (S == 17) { C3R_Q eg[q] = fminf(eg[q], 1e18f); }
+            if constexpr (S == 18) { C3R_Q tq[q] = (1.0f + eo[q]) * (1.0f + eg[q]); }
+            if constexpr (S == 19) { C3R_Q tq[q] = __builtin_amdgcn_rcpf(tq[q]); }
+            if constexpr (S == 20) { C3R_Q hv[q] = (ABL & 2) ? accG[tt][sb][4 * q] + cq[q] : (1.0f - eg[q]) * tq[q]; }     // sig(o) * tanh(c)
+            if constexpr (S == 21) { C3R_Q vh[q] = (_Float16)hv[q]; }
+            if constexpr (S == 22) {
+                // the residual is pinned to "subtract in fp32, then convert": left alone the compiler picks v_fma_mixlo_f16
+                // in some copies of this lambda and v_sub + v_cvt in others, and the two treat f16-subnormal residuals
+                // (|h| < 0.12) differently — results would depend on which copy a site ran through
+                C3R_Q { float d = hv[q] - (float)vh[q]; asm volatile("" : "+v"(d)); vl[q] = (_Float16)d; }
+            }
+            if constexpr (S == 23) {
+                *(half4 *)&hb_hi[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vh;
+                *(half4 *)&hb_lo[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vl;
+            }
+            if constexpr (S == 24) {
+                if (!(ABL & 4)) {
+                    _Float16 *yp = y + ((size_t)tg * (2 * HV) + dir * HV + wave * NT + tt) * nstride * 8 + yoff[gg][sb];
+                    *(half4 *)yp = vh;
+                    *(half4 *)(yp + plane_out) = vl;
                 }
             }
-        };
-        auto ldh = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb) {
-                bh[sb] = *(const half8 *)&hb_hi[gm][32 * sb + j][16 * g + 8 * hh];
-                bl[sb] = *(const half8 *)&hb_lo[gm][32 * sb + j][16 * g + 8 * hh];
-            }
-        };
-        auto ldw = [&](int g, half8 (&ah)[NT], half8 (&al)[NT]) {
-            typedef const half8 __attribute__((address_space(1))) *gptr_t;     // see k_lstm_h::ldw
-            uintptr_t wbase = (uintptr_t)wl;
-            asm volatile("" : "+v"(wbase));
-            const gptr_t wg = (gptr_t)wbase + (size_t)g * NT * 2 * 64;
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) { ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64]; }
-        };
-        // cell update of one (tile, site block): 4 units per lane
-        auto gate = [&](const int tt, const int sb) {
-            constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
-            float ei[4], ef[4], eg[4], eo[4], hv[4], cq[4];
-            float4 *cp = (float4 *)&cbuf[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh];
-            { const float4 cv = *cp; cq[0] = cv.x; cq[1] = cv.y; cq[2] = cv.z; cq[3] = cv.w; }
-            if (ABL & 2) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hv[q] = accG[tt][sb][4 * q] + accG[tt][sb][4 * q + 1] + accG[tt][sb][4 * q + 2] + accG[tt][sb][4 * q + 3] + cq[q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ei[q] = fminf(__builtin_amdgcn_exp2f(K1 * accG[tt][sb][4 * q + 0]), 1e18f);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ef[q] = __builtin_amdgcn_exp2f(K1 * accG[tt][sb][4 * q + 1]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) eg[q] = fminf(__builtin_amdgcn_exp2f(K2 * accG[tt][sb][4 * q + 2]), 1e18f);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) eo[q] = fminf(__builtin_amdgcn_exp2f(K1 * accG[tt][sb][4 * q + 3]), 1e18f);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ei[q] = (1.0f - eg[q]) * __builtin_amdgcn_rcpf((1.0f + ei[q]) * (1.0f + eg[q]));   // sig(i)*tanh(g)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ef[q] = __builtin_amdgcn_rcpf(1.0f + ef[q]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cq[q] = fmaf(ef[q], cq[q], ei[q]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) eg[q] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[q]), 1e18f);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hv[q] = (1.0f - eg[q]) * __builtin_amdgcn_rcpf((1.0f + eo[q]) * (1.0f + eg[q]));
-                *cp = make_float4(cq[0], cq[1], cq[2], cq[3]);
-            }
-            half4 vh, vl;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { vh[q] = (_Float16)hv[q]; vl[q] = (_Float16)(hv[q] - (float)vh[q]); }
-            *(half4 *)&hb_hi[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vh;
-            *(half4 *)&hb_lo[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vl;
-            if (!(ABL & 4)) {
-                _Float16 *yp = y + ((size_t)tg * (2 * HV) + dir * HV + wave * NT + tt) * nstride * 8 + yoff[gg][sb];
-                *(half4 *)yp = vh;
-                *(half4 *)(yp + plane_out) = vl;
-            }
+#undef C3R_Q
         };
         if (MMA) {
             floatx16 z;
@@ -762,39 +758,66 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
                 for (int sb = 0; sb < SB; ++sb) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[tt], 1.0f, z, 0, 0, 0);
         }
         half8 ah[2][NT], al[2][NT], bh[2][SB], bl[2][SB];
-#define C3R_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define C3R_LOAD(G) do { ldw((G), ah[(G) & 1], al[(G) & 1]); \
-                         if ((G) < NGX) ldx((G), bh[(G) & 1]); else ldh((G) - NGX, bh[(G) & 1], bl[(G) & 1]); } while (0)
-#define C3R_MMA(G) do {                                                                                                      \
-        _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) _Pragma("unroll") for (int sb = 0; sb < SB; ++sb)                    \
-            accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(G) & 1][tt], bh[(G) & 1][sb], accM[tt][sb], 0, 0, 0);    \
-        _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) _Pragma("unroll") for (int sb = 0; sb < SB; ++sb)                    \
-            accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[(G) & 1][tt], bh[(G) & 1][sb], accM[tt][sb], 0, 0, 0);    \
-        if ((G) >= NGX) {                                                                                                      \
-            _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) _Pragma("unroll") for (int sb = 0; sb < SB; ++sb)                \
-                accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[(G) & 1][tt], bl[(G) & 1][sb], accM[tt][sb], 0, 0, 0); \
-        } } while (0)
-        // one region per k-group: prefetch of the next group, this group's MFMAs, and one eighth of the other group's
-        // cell update; the sched_group_barrier sequence asks for  MFMA, 5 VALU, MFMA, 5 VALU, ...  with the loads spread
-#define C3R_MIX(NMF) do { _Pragma("unroll") for (int m_ = 0; m_ < (NMF); ++m_) {                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                 \
-            if constexpr (GATE) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                            \
-            if (m_ < 12) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                    \
-            else if (m_ < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } } while (0)
-#define C3R_STEP(G)                                                                                                          \
-        C3R_FENCE();                                                                                                           \
-        if (MMA) { if ((G) + 1 < NG) C3R_LOAD((G) + 1); C3R_MMA(G); }                                                          \
-        if (GATE && (G) < NT * SB) gate((G) >> 1, (G) & 1);                                                                    \
-        if (MMA) C3R_MIX(((G) < NGX) ? NT * SB * 2 : NT * SB * 3);
-        if (MMA) C3R_LOAD(0);
-        C3R_STEP(0) C3R_STEP(1) C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
-        static_assert(NG == 10, "C3R_STEP list");
-        C3R_FENCE();
-#undef C3R_STEP
-#undef C3R_MIX
-#undef C3R_MMA
-#undef C3R_LOAD
-#undef C3R_FENCE
+        typedef const half8 __attribute__((address_space(1))) *gptr_t;     // see k_lstm_h::ldw
+        // prefetch item I of k-group G1: items 0..2NT-1 = the weight fragments, then one B-operand item per site block
+        auto load_item = [&](auto g1c, auto ic, gptr_t wg) {
+            constexpr int G1 = decltype(g1c)::value, I = decltype(ic)::value;
+            if constexpr (I < 2 * NT) {
+                if constexpr (I % 2 == 0) ah[G1 & 1][I / 2] = wg[(I / 2 * 2 + 0) * 64];
+                else al[G1 & 1][I / 2] = wg[(I / 2 * 2 + 1) * 64];
+            } else {
+                constexpr int sb = I - 2 * NT;
+                if constexpr (G1 < NGX) {
+                    // branch-free (a divergent guard would split the region): load from a clamped index, then select
+                    const int32_t *xp = xin + xoff[gm][sb] + (size_t)tm * CIN;
+                    const int k0 = 16 * G1 + 8 * hh;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = k0 + e;
+                        const int32_t v = xp[k < CIN ? k : CIN - 1];
+                        bh[G1 & 1][sb][e] = (k < CIN) ? (_Float16)(float)v : (_Float16)0.f;
+                    }
+                } else {
+                    bh[G1 & 1][sb] = *(const half8 *)&hb_hi[gm][32 * sb + j][16 * (G1 - NGX) + 8 * hh];
+                    bl[G1 & 1][sb] = *(const half8 *)&hb_lo[gm][32 * sb + j][16 * (G1 - NGX) + 8 * hh];
+                }
+            }
+        };
+        auto wptr = [&](int g) -> gptr_t {
+            uintptr_t wbase = (uintptr_t)wl;
+            asm volatile("" : "+v"(wbase));              // keeps hipcc from precomputing every group's addresses (k_lstm_h::ldw)
+            return (gptr_t)wbase + (size_t)g * NT * 2 * 64;
+        };
+        constexpr int NITEM = 2 * NT + SB;
+        // one region = k-group G: its MFMAs, the prefetch of group G+1, and (GATE, G < NT*SB) the cell update of chunk G
+        auto region = [&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            constexpr int NM = MMA ? NT * SB * (G < NGX ? 2 : 3) : NS;     // slots; without MFMAs one stage per slot
+            constexpr bool ST = GATE && G < NT * SB;
+            const gptr_t wg = wptr(G + 1 < NG ? G + 1 : G);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                if constexpr (MMA) {
+                    constexpr int p = m / (NT * SB), tt = (m % (NT * SB)) / SB, sb = m % SB;
+                    if constexpr (p == 0) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[G & 1][tt], bh[G & 1][sb], accM[tt][sb], 0, 0, 0);
+                    if constexpr (p == 1) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[G & 1][tt], bh[G & 1][sb], accM[tt][sb], 0, 0, 0);
+                    if constexpr (p == 2) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[G & 1][tt], bl[G & 1][sb], accM[tt][sb], 0, 0, 0);
+                    if constexpr (G + 1 < NG && m < NITEM) load_item(std::integral_constant<int, (G + 1 < NG ? G + 1 : G)>{}, mc, wg);
+                }
+                if constexpr (ST) {
+                    constexpr int s0 = m * NS / NM, s1 = (m + 1) * NS / NM;
+                    static_for<s0, s1>([&](auto sc) { stage(sc, G >> 1, G & 1); });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        if (MMA) {
+            const gptr_t w0 = wptr(0);
+            static_for<0, NITEM>([&](auto ic) { load_item(std::integral_constant<int, 0>{}, ic, w0); });
+        }
+        static_for<0, NG>(region);
+        static_assert(NG == 10 && NT * SB <= NG, "one cell-update chunk per k-group region");
     };
     const std::true_type yes{}; const std::false_type no{};
     auto tix = [&](int step) { return dir ? NET_T - 1 - step : step; };

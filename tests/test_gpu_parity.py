@@ -365,3 +365,23 @@ def test_cpp_call_rows_equals_python_decode(eng):
     assert eng.call_rows("chr20") == py
     assert eng.call_rows("chr20", qual=None, show_ref=False) == decode.vcf_rows(
         "chr20", sites["pos"], [s["ref33"].decode() for s in sites], infos, probs, qual_for_pass=None, show_ref=False)
+
+
+def test_network_result_does_not_depend_on_batch_position(eng):
+    """A site's probabilities must be bitwise the same wherever it sits in the batch: which 32-site MFMA block, which of
+    the two skewed site groups of layer 1 (they run through different instantiations of the phase code), which
+    workgroup.  Guards against instruction-selection differences between code copies (v_fma_mixlo_f16 vs v_sub+v_cvt
+    treat f16-subnormal residuals differently)."""
+    from clair3_rna_amd import capi, synth
+    rng = np.random.RandomState(17)
+    n = 700
+    X = rng.randint(-40, 60, size=(n, 33, 18)).astype(np.int32)
+    X[::7] //= 8                                   # small activations -> small h -> subnormal lo halves
+    w = synth.random_weights(18, seed=77)
+    eng.load_weights(w, 18)
+    for mode in ("f16x3", "f32"):
+        eng.set_precision(mode)
+        base = eng.infer(tensors=X).copy()
+        for k in (1, 32, 64, 100, 129):
+            assert np.array_equal(eng.infer(tensors=X[k:]), base[k:]), (mode, k)
+    eng.set_precision("f16x3")
