@@ -294,7 +294,17 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
             uint32_t c = cigars[r.cigar_off + k];
             uint32_t op = c & 15u, len = c >> 4;
             if (op == C3R_CIG_EQ || op == C3R_CIG_X) op = C3R_CIG_M;
-            if (len == 0 || op == C3R_CIG_P || op == C3R_CIG_H) continue;
+            if (len == 0 || op == C3R_CIG_H) continue;
+            if (op == C3R_CIG_P) {
+                // htslib marks a deletion only when the D op IMMEDIATELY follows the M/N op that ends on the column (a pad
+                // in between hides it; insertions are found through pads).  So a pad is kept — as a 1-long op that consumes
+                // nothing — exactly when the next real op is a D; every other pad is dropped.
+                uint32_t k2 = k + 1;
+                while (k2 < r.n_cigar && ((cigars[r.cigar_off + k2] >> 4) == 0 || (cigars[r.cigar_off + k2] & 15u) == C3R_CIG_P ||
+                                          (cigars[r.cigar_off + k2] & 15u) == C3R_CIG_H)) ++k2;
+                if (k2 >= r.n_cigar || (cigars[r.cigar_off + k2] & 15u) != C3R_CIG_D) continue;
+                len = 1;
+            }
             if (op > C3R_CIG_X) return fail(ctx, C3R_EINVAL, "bad cigar op in read %lld", (long long)i);
             if (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) rlen += len;
             if (ctx->h_cigar.size() > d.cig_off && (ctx->h_cigar.back() & 15u) == op) {

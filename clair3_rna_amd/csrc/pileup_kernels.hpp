@@ -526,9 +526,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         }
         if (a.genotyping) ambiguous = false;
         cand = site_ok;
-        // reference-base channels are overwritten with minus the strand totals (:296-297)
-        c[refi] = -up;
-        c[9 + refi] = -lw;
+        // reference-base channels are overwritten with minus the strand totals (:296-297).  BASE2INDEX is keyed by channel
+        // NAME, so an IUPAC 'D' (or an 'I') in the reference lands on the D / d (I / i) channels; other letters count as 'A'
+        // (the reference raises KeyError there)
+        const int ch_up = rb == 'D' ? (int)C3R_D : rb == 'I' ? (int)C3R_I : refi;
+        const int ch_lo = rb == 'D' ? (int)C3R_d : rb == 'I' ? (int)C3R_i : 9 + refi;
+        c[ch_up] = -up;
+        c[ch_lo] = -lw;
     }
     s_amb[tid] = ambiguous ? 1 : 0;
     if (__syncthreads_or(ambiguous ? 1 : 0)) {
@@ -811,12 +815,16 @@ __global__ __launch_bounds__(256) void k_splice_gather(const GatherArgs g) {
         }
         const int q = ci - C3R_FLANK + lane;                   // lane < 33: window slot
         const bool in_win = lane < C3R_WINDOW;
-        const bool real = in_win && q >= lo_valid && q <= hi_valid;      // has a pileup row (is in depth_dict)
-        // depth_dict lookup: entries of already-emitted centres (all of them left of ci) have been deleted
-        const bool deleted = real && q < ci && (g.flags[q] & 4);
-        const int cur = (real && !deleted) ? g.depth[q] : 0;
-        int md = (real && !deleted) ? cur : INT32_MIN;
-        int ms = real ? g.skipmax[q] : INT32_MIN;
+        const bool real = in_win && q >= lo_valid && q <= hi_valid;      // the ring slot holds this position's own column
+        // depth_dict / max_skip_count_dict are keyed by POSITION and survive ring resets: a slot left of the run start
+        // (head/tail mode: it shows the shared pre-fill column) still finds the depth of that position if an EARLIER run
+        // had a row there (gap < 16 bp), and counts in the window maxima
+        const bool has_row = in_win && q >= 0 && q <= hi_valid && (real || (g.flags[q] & 1));
+        // entries of already-emitted centres (all of them left of ci) have been deleted from depth_dict
+        const bool deleted = has_row && q < ci && (g.flags[q] & 4);
+        const int cur = (has_row && !deleted) ? g.depth[q] : 0;
+        int md = (has_row && !deleted) ? cur : INT32_MIN;
+        int ms = has_row ? g.skipmax[q] : INT32_MIN;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { md = max(md, __shfl_xor(md, off, 64)); ms = max(ms, __shfl_xor(ms, off, 64)); }
         const int cdepth = g.depth[ci];

@@ -165,9 +165,28 @@ static int bed_contains(const int32_t *bed, int n_bed, int64_t pos0) {
 /* reads must be sorted by pos (BAM order).  beg1/end1: 1-based inclusive region (-r).  bed: the
  * `-l` file's intervals for this contig (NULL = none).  Returns text rows
  * "ctg\tpos\tN\tn\tBASES\tQUALS[\tHP,...]\n". */
-char *orc_mpileup(const c3r_read_t *reads, int64_t n_reads, const uint32_t *cigar, const uint8_t *seq,
+char *orc_mpileup(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *cigar_in, const uint8_t *seq,
                   const char *ctg, int64_t beg1, int64_t end1, int min_mq, int excl_flags,
                   const int32_t *bed, int n_bed, int with_hp, int64_t *out_len) {
+    /* Zero-length CIGAR ops are dropped before the walk (conscious deviation): BAM writers do not emit
+     * them, and what htslib's cursor does with them is an accident of its peek-next-op logic (e.g. `3M0I2D` loses the
+     * deletion marker, `3M0D2I` the insertion).  The product path drops them at load, so the checker does too. */
+    int64_t n_ops_total = 0;
+    for (int64_t i = 0; i < n_reads; ++i) n_ops_total += reads_in[i].n_cigar;
+    c3r_read_t *reads = (c3r_read_t *)malloc(sizeof(c3r_read_t) * (size_t)(n_reads > 0 ? n_reads : 1));
+    uint32_t *cigar = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n_ops_total > 0 ? n_ops_total : 1));
+    {
+        int64_t w = 0;
+        for (int64_t i = 0; i < n_reads; ++i) {
+            reads[i] = reads_in[i];
+            reads[i].cigar_off = (uint32_t)w;
+            for (uint32_t k = 0; k < reads_in[i].n_cigar; ++k) {
+                const uint32_t c = cigar_in[reads_in[i].cigar_off + k];
+                if (cig_len(c) > 0) cigar[w++] = c;
+            }
+            reads[i].n_cigar = (uint32_t)(w - reads[i].cigar_off);
+        }
+    }
     sbuf out = {0}, bases = {0}, hps = {0};
     sb_reserve(&out, 1);
     out.p[0] = 0;
@@ -244,7 +263,7 @@ char *orc_mpileup(const c3r_read_t *reads, int64_t n_reads, const uint32_t *ciga
         }
         ++pos;
     }
-    free(act); free(bases.p); free(hps.p);
+    free(act); free(bases.p); free(hps.p); free(reads); free(cigar);
     if (out_len) *out_len = (int64_t)out.n;
     return out.p;
 }
@@ -452,7 +471,12 @@ static void generate_tensor(const char *s, int n, char **hp, int n_hp, int64_t p
     if (out->plist.n >= 1 && out->plist.v[0].key[0] != reference_base) af = (double)out->plist.v[0].count / denominator;
     out->af = af;
 
+    /* BASE2INDEX[reference_base] (src/create_tensor_pileup.py:296-297): the channel names double as keys, so an IUPAC 'D' in
+     * the reference indexes the D / d channels; any other non-ACGT letter raises KeyError in the reference.  There the
+     * build (oracle and HIP path alike) falls back to evc_base_from's rule: counts as 'A' / 'a'. */
     int up = chan_of_char(reference_base), lo = chan_of_char((char)tolower((unsigned char)reference_base));
+    if (up < 0) up = chan_of_char(evc_base(reference_base));
+    if (lo < 0) lo = chan_of_char(evc_base((char)tolower((unsigned char)reference_base)));
     out->tensor[up] = -(out->tensor[C3R_A] + out->tensor[C3R_C] + out->tensor[C3R_G] + out->tensor[C3R_T]);
     out->tensor[lo] = -(out->tensor[C3R_a] + out->tensor[C3R_c] + out->tensor[C3R_g] + out->tensor[C3R_t]);
 
@@ -646,9 +670,12 @@ char *orc_create_tensor(const char *rows_text, const char *ctg, const char *ref_
                         }
                     }
                     if ((double)max_skip / (double)max_depth > 0.2) {
+                        /* BASE2INDEX[letter]: a reference letter that is no channel name raises KeyError in the reference;
+                         * the build (oracle and HIP path) reads 0 / pads nothing there */
                         char rc = ref_seq[center - reference_start];
-                        int sf = win[C3R_FLANK][chan_of_char((char)toupper((unsigned char)rc))];
-                        int sr = win[C3R_FLANK][chan_of_char((char)tolower((unsigned char)rc))];
+                        int cu = chan_of_char((char)toupper((unsigned char)rc)), cl = chan_of_char((char)tolower((unsigned char)rc));
+                        int sf = cu >= 0 ? win[C3R_FLANK][cu] : 0;
+                        int sr = cl >= 0 ? win[C3R_FLANK][cl] : 0;
                         if (sf < 0) sf = -sf; if (sr < 0) sr = -sr;
                         double fpct = (sf + sr > 0) ? sf / (double)(sf + sr) : 0.0;
                         double rpct = 1 - fpct;
@@ -663,8 +690,11 @@ char *orc_create_tensor(const char *rows_text, const char *ctg, const char *ref_
                                 int64_t ri = pp - reference_start;
                                 if (ri < 0) ri += ref_len;   /* Python negative index: head slots left of the reference slice */
                                 char rb = (char)toupper((unsigned char)ref_seq[ri]);
-                                win[idx][chan_of_char(rb)] = -1 * (int)(cdepth * fpct);
-                                win[idx][chan_of_char((char)tolower((unsigned char)rb))] = -1 * (int)(cdepth * rpct);
+                                int pu = chan_of_char(rb), pl = chan_of_char((char)tolower((unsigned char)rb));
+                                if (pu >= 0 && pl >= 0) {
+                                    win[idx][pu] = -1 * (int)(cdepth * fpct);
+                                    win[idx][pl] = -1 * (int)(cdepth * rpct);
+                                }
                             }
                         }
                     }

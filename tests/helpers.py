@@ -12,7 +12,8 @@ def oracle_chunk(rs, ref, ref_start, ctg_start, ctg_end, channels=18, lbed=None,
     rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, CTG, es, ee, min_mq=pk.pop("min_mq", 5), excl_flags=pk.pop("excl_flags", 2316),
                        bed=lbed, with_hp=(channels == 30))
     P = orc.make_params(phased=(channels == 30), **pk)
-    lines = orc.create_tensor(rows, CTG, ref, ref_start, P)
+    # the reference upper-cases the whole slice when it loads it ("uppercase for masked sequences", shared/utils.py:186-187)
+    lines = orc.create_tensor(rows, CTG, ref.upper(), ref_start, P)
     X, depth = orc.batch_from_lines(lines, channels)
     return dict(rows=rows, lines=lines, X=X, depth=depth)
 
