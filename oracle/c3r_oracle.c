@@ -151,14 +151,9 @@ static void resolve(const c3r_read_t *r, const uint32_t *cg, cursor_t *s, int64_
 }
 
 static int bed_contains(const int32_t *bed, int n_bed, int64_t pos0) {
-    /* sorted, half-open 0-based intervals */
-    int lo = 0, hi = n_bed - 1;
-    while (lo <= hi) {
-        int mid = (lo + hi) / 2;
-        if (pos0 < bed[2 * mid]) hi = mid - 1;
-        else if (pos0 >= bed[2 * mid + 1]) lo = mid + 1;
-        else return 1;
-    }
+    /* half-open 0-based intervals in any order, possibly overlapping (samtools -l takes them as they come) */
+    for (int i = 0; i < n_bed; ++i)
+        if (pos0 >= bed[2 * i] && pos0 < bed[2 * i + 1]) return 1;
     return 0;
 }
 

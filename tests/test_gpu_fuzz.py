@@ -127,3 +127,100 @@ def test_random_cigars_match_the_oracle(eng, kw):
     assert n_cases == 120 and n_lines > 300, n_lines
     eng.params = capi.default_params()
     eng.set_params()
+
+
+@pytest.mark.parametrize("mode", ["lbed", "cbed", "both_beds", "sites", "subregion", "deep"])
+def test_random_cigars_with_filters_and_regions(eng, mode):
+    """The same random read sets through the -l BED, the confident BED, a genotyping site list, a sub-region with a shifted
+    reference slice, and at depths that cross the 216 rescale threshold."""
+    from clair3_rna_amd import capi
+    from clair3_rna_amd.reads import ReadSet
+    n_lines = 0
+    for seed in range(60):
+        rng = random.Random(7000 + seed)
+        ref, recs = _case(50000 + seed, phased=False)
+        if mode == "deep":              # replicate the reads: depth 150-400 with identical alleles (I1/D1 multiplicities, rescale)
+            rep = rng.randint(6, 9)
+            recs = [dict(r) for r in recs for _ in range(rep)]
+            recs.sort(key=lambda r: r["pos"])
+        rs = ReadSet.from_records(recs)
+        L = len(ref)
+
+        def intervals(k):
+            out = []
+            for _ in range(k):
+                a = rng.randint(0, L - 2)
+                out.append((a, min(L, a + rng.choice([1, 2, 5, 17, 33, 60, 150]))))
+            return out
+        lbed = intervals(rng.randint(1, 6)) if mode in ("lbed", "both_beds") else None
+        cbed = intervals(rng.randint(1, 6)) if mode in ("cbed", "both_beds") else None
+        sites = sorted(set(rng.randint(1, L) for _ in range(rng.randint(1, 25)))) if mode == "sites" else None
+        ref_start, a, b = 1, 1, L
+        if mode == "subregion":
+            a = rng.randint(2, L // 2); b = rng.randint(a, L)
+            ref_start = rng.randint(1, max(1, a - 49))   # the slice starts before the region's halo and its windows (the
+                                                         # reference fetches ctg_start - 1000: every row and flank is covered)
+        if mode == "sites":
+            a, b = min(sites), max(sites)
+        eng.params = capi.default_params()
+        eng.set_bed(0, lbed); eng.set_bed(1, cbed)
+        if sites is not None:
+            eng.set_sites(sites)
+        eng.set_params(min_coverage=2, genotyping_mode=int(sites is not None), head_tail=seed % 2)
+        refslice = ref[ref_start - 1:]
+        exp = H.oracle_chunk(rs, refslice, ref_start, a, b, lbed=lbed, bed=cbed, sites=sites, min_coverage=2, head_tail=bool(seed % 2))
+        got = H.engine_chunk(eng, rs, refslice, ref_start, a, b)
+        assert got["lines"] == exp["lines"], (mode, seed, lbed, cbed, sites, (ref_start, a, b), H.first_diff(got["lines"], exp["lines"]))
+        assert np.array_equal(got["X"], exp["X"]), (mode, seed)
+        n_lines += len(exp["lines"])
+    assert n_lines > (20 if mode in ("sites", "lbed", "both_beds") else 200), (mode, n_lines)
+    eng.params = capi.default_params()
+    eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.set_params()
+
+
+def test_random_cigars_decode_rows_cpp_equals_python_and_regions(eng):
+    """On the random read sets: (1) c3r_call_rows (C++: tokens -> ordered alt_info -> decode -> row text) equals the Python
+    path fed with the ORACLE's alt_info strings; (2) a multi-region scan over random chunk boundaries equals successive
+    scans.  Random weights make every genotype class and the decoder's retry loop show up."""
+    from clair3_rna_amd import capi, decode, synth
+    from clair3_rna_amd.reads import ReadSet
+    from oracle import oracle as orc
+    w = synth.random_weights(18, seed=4242)
+    w[-24 * 129:] *= 6.0                       # sharper output layers: not everything decodes to RefCall
+    eng.load_weights(w, 18)
+    eng.set_precision("f16x3")
+    n_rows, kinds = 0, set()
+    for seed in range(60):
+        rng = random.Random(9000 + seed)
+        ref, recs = _case(80000 + seed, phased=False)
+        rs = ReadSet.from_records(recs)
+        L = len(ref)
+        eng.params = capi.default_params()
+        eng.set_bed(0, None); eng.set_bed(1, None)
+        eng.set_params(min_coverage=2)
+        got = H.engine_chunk(eng, rs, ref, 1, 1, L)
+        exp = H.oracle_chunk(rs, ref, 1, 1, L, min_coverage=2)
+        assert got["lines"] == exp["lines"]
+        if exp["lines"]:
+            probs = eng.infer()
+            po = orc.forward(w, exp["X"])
+            assert np.abs(probs - po).max() < 1e-4
+            f = [l.split("\t") for l in exp["lines"]]
+            py = decode.vcf_rows("chr20", [int(x[1]) for x in f], [x[2] for x in f], [x[4] for x in f], probs)
+            cpp = eng.call_rows("chr20")
+            assert cpp == py, (seed, [a for a, b in zip(cpp, py) if a != b][:2], [b for a, b in zip(cpp, py) if a != b][:2])
+            n_rows += len(py)
+            kinds.update(r.split("\t")[9].split(":")[0] for r in py)
+        # random chunking of the same contig
+        cuts = sorted(set([1, L] + [rng.randint(2, L - 1) for _ in range(rng.randint(1, 5))]))
+        chunks = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+        eng.begin_batch()
+        for a, b in chunks:
+            eng.scan(a, b)
+        eng.end_batch()
+        X1, S1, T1 = eng.tensors(), eng.sites(), eng.tokens()
+        eng.begin_batch(); eng.scan_regions(chunks); eng.end_batch()
+        assert np.array_equal(X1, eng.tensors()) and S1.tobytes() == eng.sites().tobytes() and T1.tobytes() == eng.tokens().tobytes(), (seed, chunks)
+    assert n_rows > 1500 and {"0/0", "0/1", "1/1"} <= kinds, (n_rows, kinds)
+    eng.set_params()
