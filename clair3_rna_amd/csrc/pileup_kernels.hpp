@@ -859,6 +859,52 @@ __global__ __launch_bounds__(256) void k_splice_gather(const GatherArgs g) {
     }
 }
 
+// What read r (header rd) shows at reference position p: base code (0..15 BAM nibble, 16 = deleted base, 17 = ref-skip)
+// and the indel attached to the column (+len insertion with its query offset, -len deletion, 0 none).  The read's aligned
+// segment that holds p is found through the read-ordered segment list (a handful per read), then only its ops are walked.
+struct TokenAt { uint8_t base; int32_t indel; uint32_t qpos; };
+__device__ __forceinline__ TokenAt token_at(const DevRead &rd, int r, int p, const DevSeg *rsegs, const uint32_t *rseg_first,
+                                            const uint32_t *cigar, const uint8_t *seq) {
+    TokenAt tk; tk.base = 17; tk.indel = 0; tk.qpos = 0;
+    const uint32_t s0 = rseg_first[r], s1 = rseg_first[r + 1];
+    for (uint32_t si = s0; si < s1; ++si) {
+        const DevSeg sg = rsegs[si];
+        if (sg.ext_start > p) break;
+        if (p >= sg.end) continue;
+        int x = sg.pos, y = (int)sg.qstart;
+        if (p < sg.pos) {          // p == pos-1: I/D right after an N, attached to the last intron column
+            const uint32_t c0 = cigar[sg.cig_off];
+            const int op0 = (int)(c0 & 15u), len0 = (int)(c0 >> 4);
+            if (op0 == C3R_CIG_I) { tk.indel = len0; tk.qpos = (uint32_t)y; }
+            else if (op0 == C3R_CIG_D) tk.indel = -len0;
+            break;
+        }
+        for (uint32_t k = 0; k < sg.n_cig; ++k) {
+            const uint32_t c = cigar[sg.cig_off + k];
+            const int op = (int)(c & 15u), len = (int)(c >> 4);
+            if (op == C3R_CIG_M || op == C3R_CIG_D) {
+                if (p < x + len) {
+                    if (op == C3R_CIG_M) tk.base = (uint8_t)base_code(seq, rd.seq_off, (uint32_t)(y + (p - x)), rd.l_seq);
+                    else tk.base = 16;
+                    if (p == x + len - 1 && k + 1 < sg.n_cig) {
+                        const uint32_t c2 = cigar[sg.cig_off + k + 1];
+                        const int op2 = (int)(c2 & 15u), len2 = (int)(c2 >> 4);
+                        if (op2 == C3R_CIG_I) { tk.indel = len2; tk.qpos = (uint32_t)(y + (op == C3R_CIG_M ? len : 0)); }
+                        else if (op2 == C3R_CIG_D && op != C3R_CIG_D) tk.indel = -len2;
+                    }
+                    break;
+                }
+                x += len;
+                if (op == C3R_CIG_M) y += len;
+            } else if (op == C3R_CIG_I || op == C3R_CIG_S) {
+                y += len;
+            }
+        }
+        break;
+    }
+    return tk;
+}
+
 // -------------------------------------------------------------------------------------------------
 // Alt tokens: for every emitted candidate list, in BAM order, what each covering read shows at the
 // centre column.  The host rebuilds the ordered alt_info dictionary from these
@@ -894,49 +940,58 @@ __global__ __launch_bounds__(256) void k_tokens(const TokArgs t) {
         const unsigned long long m = __ballot(cov);
         if (cov) {
             const int rank = __popcll(m & ((1ull << lane) - 1ull));
-            c3r_token_t tk; tk.read_idx = (uint32_t)r; tk.indel = 0; tk.qpos = 0; tk.base = 15; tk.rev = (rd.flag & 16) ? 1 : 0; tk.pad[0] = tk.pad[1] = 0;
-            // locate the aligned segment of this read that holds p (a handful per read), then walk only its ops;
-            // p inside an N op -> ref-skip token, possibly with the indel a following segment attaches to it
-            tk.base = 17;
-            const uint32_t s0 = t.rseg_first[r], s1 = t.rseg_first[r + 1];
-            for (uint32_t si = s0; si < s1; ++si) {
-                const DevSeg sg = t.rsegs[si];
-                if (sg.ext_start > p) break;
-                if (p >= sg.end) continue;
-                int x = sg.pos, y = (int)sg.qstart;
-                if (p < sg.pos) {          // p == pos-1: I/D right after an N, attached to the last intron column
-                    const uint32_t c0 = t.cigar[sg.cig_off];
-                    const int op0 = (int)(c0 & 15u), len0 = (int)(c0 >> 4);
-                    if (op0 == C3R_CIG_I) { tk.indel = len0; tk.qpos = (uint32_t)y; }
-                    else if (op0 == C3R_CIG_D) tk.indel = -len0;
-                    break;
-                }
-                for (uint32_t k = 0; k < sg.n_cig; ++k) {
-                    const uint32_t c = t.cigar[sg.cig_off + k];
-                    const int op = (int)(c & 15u), len = (int)(c >> 4);
-                    if (op == C3R_CIG_M || op == C3R_CIG_D) {
-                        if (p < x + len) {
-                            if (op == C3R_CIG_M) tk.base = (uint8_t)base_code(t.seq, rd.seq_off, (uint32_t)(y + (p - x)), rd.l_seq);
-                            else tk.base = 16;
-                            if (p == x + len - 1 && k + 1 < sg.n_cig) {
-                                const uint32_t c2 = t.cigar[sg.cig_off + k + 1];
-                                const int op2 = (int)(c2 & 15u), len2 = (int)(c2 >> 4);
-                                if (op2 == C3R_CIG_I) { tk.indel = len2; tk.qpos = (uint32_t)(y + (op == C3R_CIG_M ? len : 0)); }
-                                else if (op2 == C3R_CIG_D && op != C3R_CIG_D) tk.indel = -len2;
-                            }
-                            break;
-                        }
-                        x += len;
-                        if (op == C3R_CIG_M) y += len;
-                    } else if (op == C3R_CIG_I || op == C3R_CIG_S) {
-                        y += len;
-                    }
-                }
-                break;
-            }
+            const TokenAt ta = token_at(rd, r, p, t.rsegs, t.rseg_first, t.cigar, t.seq);
+            c3r_token_t tk; tk.read_idx = (uint32_t)r; tk.indel = ta.indel; tk.qpos = ta.qpos; tk.base = ta.base; tk.rev = (rd.flag & 16) ? 1 : 0; tk.pad[0] = tk.pad[1] = 0;
             t.tok[base_off + written + rank] = tk;
         }
         written += __popcll(m);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Phased channels of an indel that follows a ref-skip directly (N then I / D: the indel sits on the read's last intron
+// column).  The reference gives an indel token the haplotype of phasing[idx-1], the PREVIOUS entry of the column's token
+// list (src/create_tensor_pileup.py:183,189): normally the carrying read's own base, but a ref-skip read has no base
+// entry, so the haplotype comes from whatever the previous read contributed last — its indel token ('0': no count), else
+// its base / deleted-base token (its HP), reads showing a ref-skip or an ignored IUPAC base contributing nothing.
+// k_scan_tiles counted the carrying read's own HP; this pass (30 channels only, one thread per such indel and region)
+// moves the count.  Such alignments are rare, so the backward search over the covering reads is affordable.
+struct LeadIndel { int32_t read_idx; int32_t anchor; int32_t is_ins; int32_t pad; };
+struct PhaseFixArgs {
+    const LeadIndel *items; int32_t n_items;
+    const int32_t *reg_tile0; int32_t n_regions;       // first tile of every region (+ one past the last)
+    const TileGeo *geo;
+    const DevRead *reads; const int32_t *prefmax_end; int32_t n_reads;
+    const DevSeg *rsegs; const uint32_t *rseg_first; const uint32_t *cigar; const uint8_t *seq;
+    const uint8_t *flags; int32_t *cols;
+    int32_t min_mq, excl_flags;
+};
+__global__ void k_phase_fix(const PhaseFixArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_items * a.n_regions) return;
+    const LeadIndel it = a.items[idx / a.n_regions];
+    const int reg = idx % a.n_regions;
+    const int t0 = a.reg_tile0[reg], t1 = a.reg_tile0[reg + 1] - 1;      // last tile of a region is its guard tile
+    const int beg0 = a.geo[t0].p0, end0 = a.geo[t1].p0, p = it.anchor;
+    if (p < beg0 || p >= end0) return;
+    const int slot = t0 * TILE + (p - beg0);
+    if (!(a.flags[slot] & 1)) return;
+    const DevRead me = a.reads[it.read_idx];
+    if (!read_passes(me, a.min_mq, a.excl_flags)) return;
+    int32_t *c = a.cols + (size_t)slot * C3R_CH_PHASED;
+    if (me.hp == 1) atomicAdd(&c[it.is_ins ? C3R_IP : C3R_DP], -1);
+    else if (me.hp == 2) atomicAdd(&c[it.is_ins ? C3R_IM : C3R_DM], -1);
+    const int lo = upper_bound_gt(a.prefmax_end, a.n_reads, p);
+    for (int r = it.read_idx - 1; r >= lo; --r) {
+        const DevRead rd = a.reads[r];
+        if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.pos > p || rd.end <= p) continue;
+        const TokenAt tk = token_at(rd, r, p, a.rsegs, a.rseg_first, a.cigar, a.seq);
+        if (tk.indel != 0) return;                                        // previous entry is an indel token: phasing '0'
+        const bool listed = tk.base == 16 || acgt_index(tk.base) >= 0 || tk.base == 15;   // * / #, A C G T, N
+        if (!listed) continue;                                            // ref-skip or ignored letter: no entry
+        if (rd.hp == 1) atomicAdd(&c[it.is_ins ? C3R_IP : C3R_DP], 1);
+        else if (rd.hp == 2) atomicAdd(&c[it.is_ins ? C3R_IM : C3R_DM], 1);
+        return;
     }
 }
 
