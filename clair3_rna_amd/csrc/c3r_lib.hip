@@ -370,6 +370,7 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     }
     std::stable_sort(ctx->h_segs.begin(), ctx->h_segs.end(), [](const DevSeg &a, const DevSeg &b) { return a.ext_start < b.ext_start; });
     ctx->h_seq.assign(seq4, seq4 + n_seq_bytes);
+    ctx->h_seq.resize((size_t)n_seq_bytes + 16, 0);        // the walk reads the packed bases 8 bytes at a time
     int rc;
     if ((rc = upload(ctx, ctx->d_reads, ctx->h_reads.data(), ctx->h_reads.size()))) return rc;
     if ((rc = upload(ctx, ctx->d_cigar, ctx->h_cigar.data(), ctx->h_cigar.size()))) return rc;

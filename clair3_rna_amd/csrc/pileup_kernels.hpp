@@ -247,16 +247,23 @@ __device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, 
 
             if (op == C3R_CIG_M && MODE != SCATTER) {
                 const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
-                // 8 bases per round: the 8 byte loads are independent, so they are all in flight before the first
-                // LDS atomic (one latency per 8 bases instead of one per base)
-                for (int pb = b0; pb < b1; pb += 8) {
-                    int code[8];
+                // up to 16 bases per round from ONE 8-byte load (the query bases of an M op are consecutive nibbles; the
+                // packed-base buffer is padded so that the load may run past a read's last byte): one load latency per 16
+                // bases instead of eight byte loads per 8
+                int pb = b0;
+                while (pb < b1) {
+                    const uint32_t q0 = (uint32_t)(qstart + (pb - rstart));
+                    const int odd = (int)(q0 & 1u);
+                    const int nb = min(b1 - pb, 16 - odd);
+                    uint64_t w = 0;
+                    if (q0 < rd.l_seq) __builtin_memcpy(&w, a.seq + rd.seq_off + (q0 >> 1), 8);   // (a CIGAR may claim more bases than SEQ holds)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        code[u] = (pb + u < b1) ? base_code(a.seq, rd.seq_off, (uint32_t)(qstart + (pb + u - rstart)), rd.l_seq) : 0;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int bi = acgt_index(code[u]);
+                    for (int u = 0; u < 16; ++u) {
+                        if (u >= nb) break;
+                        const int ni = odd + u;                                  // nibble index inside w (high nibble first)
+                        int code = (int)((w >> (8 * (ni >> 1) + ((ni & 1) ? 0 : 4))) & 15u);
+                        if (q0 + (uint32_t)u >= rd.l_seq) code = 15;
+                        const int bi = acgt_index(code);
                         if (bi < 0) continue;
                         const int pl = pb + u - t0;
                         if (MODE == ACCUM) {
@@ -269,6 +276,7 @@ __device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, 
                             if (s.amb[pl]) atomicMin(&s.first[pl * 6 + bi], 2u * (uint32_t)r);
                         }
                     }
+                    pb += nb;
                 }
             } else if (op == C3R_CIG_D && MODE == ACCUM) {
                 const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
