@@ -674,21 +674,28 @@ __global__ __launch_bounds__(CMP_THREADS) void k_compact_count(const uint8_t *fl
 
 // single-block exclusive scan of n ints (in place); total written to *total
 __global__ __launch_bounds__(1024) void k_excl_scan(int32_t *data, int n, int32_t *total) {
+    // 8 consecutive items per thread and round (8192 per round): the carry chain between rounds is the serial part, so fewer,
+    // fatter rounds (the 202 k token counts of a chr20 pass: 25 rounds instead of 198)
+    constexpr int IT = 8;
     __shared__ int wtot[16];
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? data[i] : 0;
-        const int incl = wave_incl_scan(v);
+    for (int base = 0; base < n; base += 1024 * IT) {
+        const int i0 = base + threadIdx.x * IT;
+        int v[IT], sum = 0;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { v[k] = (i0 + k < n) ? data[i0 + k] : 0; sum += v[k]; }
+        const int incl = wave_incl_scan(sum);
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
         int wb = 0, tot = 0;
         for (int w = 0; w < 16; ++w) { const int t = wtot[w]; if (w < wave) wb += t; tot += t; }
         const int carry = carry_s;
-        if (i < n) data[i] = carry + wb + incl - v;
+        int run = carry + wb + incl - sum;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { if (i0 + k < n) data[i0 + k] = run; run += v[k]; }
         __syncthreads();
         if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
