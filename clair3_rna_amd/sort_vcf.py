@@ -12,8 +12,7 @@ must be identical (fixture tests/golden/g6_sortvcf.json.gz was produced by the r
   * REDIportal tagging sets FILTER=RNAEditing when (contig, pos, ref, alt) is in the table and the row mentions neither
     "Germline" nor "RefCall"; the untagged copy is the same text with RNAEditing -> PASS;
   * no input rows at all, or no row kept: the output file is left EMPTY (not even a header).
---compress_vcf writes <out>.gz as BGZF with this package's own writer (bgzip is not a dependency); a tabix index is
-not produced.
+--compress_vcf writes <out>.gz as BGZF and <out>.gz.tbi with this package's own writers (bgzip / tabix are not dependencies).
 """
 import gzip
 import os
@@ -145,12 +144,86 @@ def merge_stream(lines, output_fn):
                 out.write(per[contig][pos])
 
 
+def _reg2bin(beg, end):
+    """UCSC binning scheme (SAM spec 5.3), 0-based half-open."""
+    end -= 1
+    if beg >> 14 == end >> 14: return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17: return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20: return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23: return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26: return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
 def compress_vcf(path):
-    """`bgzip -f` equivalent: <path> -> <path>.gz (BGZF), original removed."""
-    from .bam import _BGZF_EOF, _bgzf_write
+    """`bgzip -f` + `tabix -f -p vcf` equivalent (src/sort_vcf.py:70-75): <path> -> <path>.gz (BGZF) + <path>.gz.tbi, original
+    removed.  The index follows the tabix format description (TBI v1: VCF preset, UCSC bins, 16 kb linear index); tabix
+    itself is not in the image, so it is checked against the format and by reading records back through it
+    (tests/test_sort_vcf.py), not against tabix' own output."""
+    import struct
+    import zlib
+    from .bam import _BGZF_EOF
     data = open(path, "rb").read()
+    BLK = 0xff00
+    coffs, out = [], bytearray()
+    for i in range(0, len(data), BLK):
+        chunk = data[i:i + BLK]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        cdata = co.compress(chunk) + co.flush()
+        coffs.append(len(out))
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cdata) + 25)
+        out += cdata + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+    end_coff = len(out)
+    out += _BGZF_EOF
     with open(path + ".gz", "wb") as f:
-        _bgzf_write(f, data)
+        f.write(out)
+
+    def voff(u):            # virtual offset of uncompressed byte u (a position at a block's end belongs to the next block)
+        if u >= len(data):
+            return end_coff << 16
+        return (coffs[u // BLK] << 16) | (u % BLK)
+
+    names, idx = [], {}     # contig -> (bins {bin: [[beg, end], ...]}, linear [])
+    u = 0
+    for line in data.split(b"\n"):
+        n = len(line) + 1
+        if line and not line.startswith(b"#"):
+            f = line.split(b"\t", 5)
+            ctg, beg = f[0].decode(), int(f[1]) - 1
+            end = beg + max(1, len(f[3]))
+            if ctg not in idx:
+                names.append(ctg)
+                idx[ctg] = ({}, [])
+            bins, lin = idx[ctg]
+            v0, v1 = voff(u), voff(u + n)
+            ch = bins.setdefault(_reg2bin(beg, end), [])
+            if ch and ch[-1][1] == v0:
+                ch[-1][1] = v1
+            else:
+                ch.append([v0, v1])
+            w1 = (end - 1) >> 14
+            if len(lin) <= w1:
+                lin.extend([0] * (w1 + 1 - len(lin)))
+            for w in range(beg >> 14, w1 + 1):
+                if lin[w] == 0:
+                    lin[w] = v0
+        u += n
+    nm = b"".join(x.encode() + b"\x00" for x in names)
+    tbi = bytearray(b"TBI\x01" + struct.pack("<8i", len(names), 2, 1, 2, 0, ord("#"), 0, len(nm)) + nm)
+    for ctg in names:
+        bins, lin = idx[ctg]
+        for w in range(1, len(lin)):
+            if lin[w] == 0:
+                lin[w] = lin[w - 1]
+        tbi += struct.pack("<i", len(bins))
+        for b_, chunks in sorted(bins.items()):
+            tbi += struct.pack("<Ii", b_, len(chunks))
+            for c0, c1 in chunks:
+                tbi += struct.pack("<QQ", c0, c1)
+        tbi += struct.pack("<i", len(lin)) + b"".join(struct.pack("<Q", v) for v in lin)
+    from .bam import _bgzf_write
+    with open(path + ".gz.tbi", "wb") as f:
+        _bgzf_write(f, bytes(tbi))
         f.write(_BGZF_EOF)
     os.remove(path)
     return path + ".gz"

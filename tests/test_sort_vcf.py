@@ -64,3 +64,81 @@ def test_cli_empty_inputs_and_bgzf_output(tmp_path):
     assert open(out + ".gz", "rb").read()[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
     with pytest.raises(SystemExit):
         sort_vcf.main(["--input_dir", str(tmp_path / "nope"), "--output_fn", out, "--contigs_fn", str(tmp_path / "CONTIGS")])
+
+
+def test_bgzf_and_tabix_index_read_back(tmp_path):
+    """compress_vcf: the .tbi (TBI v1, VCF preset) must lead a reader from a region to exactly the records overlapping it."""
+    import random
+    import struct
+    import zlib
+    rng = random.Random(5)
+    hdr = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"
+    recs = []
+    for ctg, n in (("chr1", 4000), ("chr2", 2500), ("chrM", 3)):
+        pos = sorted(rng.sample(range(1, 3000000), n))
+        for p in pos:
+            ref = "ACGT"[p % 4] + "".join(rng.choice("ACGT") for _ in range(rng.choice([0, 0, 0, 1, 5, 40])))
+            recs.append((ctg, p, ref, "%s\t%d\t.\t%s\tG\t%.2f\tPASS\t.\tGT:GQ\t0/1:%d\n" % (ctg, p, ref, rng.uniform(0, 40), rng.randint(0, 40))))
+    path = str(tmp_path / "m.vcf")
+    open(path, "w").write(hdr + "".join(r[3] for r in recs))
+    gz = sort_vcf.compress_vcf(path)
+    assert not os.path.exists(path) and gzip.open(gz, "rt").read() == hdr + "".join(r[3] for r in recs)
+    raw = open(gz, "rb").read()
+    tbi = gzip.open(gz + ".tbi", "rb").read()
+    assert tbi[:4] == b"TBI\x01"
+    n_ref, fmt, cs, cb, ce, meta, skip, l_nm = struct.unpack_from("<8i", tbi, 4)
+    assert (fmt, cs, cb, ce, meta, skip) == (2, 1, 2, 0, ord("#"), 0)
+    names = tbi[36:36 + l_nm].split(b"\x00")[:-1]
+    assert [n.decode() for n in names] == ["chr1", "chr2", "chrM"]
+    o = 36 + l_nm
+    index = {}
+    for nm in names:
+        n_bin = struct.unpack_from("<i", tbi, o)[0]; o += 4
+        bins = {}
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", tbi, o); o += 8
+            bins[b] = [struct.unpack_from("<QQ", tbi, o + 16 * k) for k in range(n_chunk)]; o += 16 * n_chunk
+        n_intv = struct.unpack_from("<i", tbi, o)[0]; o += 4
+        lin = list(struct.unpack_from("<%dQ" % n_intv, tbi, o)); o += 8 * n_intv
+        index[nm.decode()] = (bins, lin)
+    assert o == len(tbi)
+
+    def block(coff):
+        bs = struct.unpack_from("<H", raw, coff + 16)[0] + 1
+        return zlib.decompress(raw[coff + 18:coff + bs - 8], -15), coff + bs
+
+    def read_from(v0, v1):
+        coff, u = v0 >> 16, v0 & 0xffff
+        out = b""
+        while (coff << 16 | u) < v1:
+            data, nxt = block(coff)
+            stop = (v1 & 0xffff) if (v1 >> 16) == coff else len(data)
+            out += data[u:stop]
+            coff, u = nxt, 0
+        return out
+
+    def bins_of(beg, end):
+        end -= 1
+        out = [0]
+        for sh, off in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+            out += list(range(off + (beg >> sh), off + (end >> sh) + 1))
+        return out
+
+    for _ in range(40):
+        ctg = rng.choice(["chr1", "chr2", "chrM"])
+        beg = rng.randint(0, 3000000); end = beg + rng.choice([1, 100, 20000, 700000])
+        bins, lin = index[ctg]
+        lo = lin[min(beg >> 14, len(lin) - 1)] if lin else 0
+        got = set()
+        for b in bins_of(beg, end):
+            for c0, c1 in bins.get(b, []):
+                if c1 <= lo:
+                    continue
+                for line in read_from(max(c0, lo), c1).decode().split("\n"):
+                    if line:
+                        f = line.split("\t")
+                        p0 = int(f[1]) - 1
+                        if f[0] == ctg and p0 < end and p0 + len(f[3]) > beg:
+                            got.add(line + "\n")
+        want = set(r[3] for r in recs if r[0] == ctg and r[1] - 1 < end and r[1] - 1 + len(r[2]) > beg)
+        assert got == want, (ctg, beg, end, len(got), len(want))
