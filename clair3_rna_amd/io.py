@@ -136,12 +136,16 @@ def load_reads(path, contig, beg0=None, end0=None):
 
 # ----------------------------------------------------------------------------- weights
 def load_weights(chkpnt_fn, channels):
-    """Flat fp32 blob in the layout of include/c3r.h (`<prefix>.c3rw.npy`, produced by tools/convert_tf_checkpoint.py
-    wherever TensorFlow exists).  The TF checkpoint bundle itself cannot be verified here (no TensorFlow, no
-    checkpoint in the image) — see DESIGN.md §7 F5."""
+    """Flat fp32 blob in the layout of include/c3r.h.  Looked for in this order: `<prefix>.c3rw.npy` (converted once where
+    TensorFlow exists, INTEGRATION.md section 3 — the verified route); `<prefix>.index` + `.data-*`, the TensorFlow checkpoint
+    bundle itself, through the TF-free reader tfckpt.py (written from the format descriptions; no TF-written file was available
+    to verify it against — DESIGN.md section 7, F5)."""
     for cand in (chkpnt_fn, chkpnt_fn + ".c3rw.npy", chkpnt_fn + ".npy"):
         if os.path.isfile(cand) and cand.endswith(".npy"):
             w = np.load(cand).astype(np.float32).reshape(-1)
             return w
-    raise FileNotFoundError("no converted weights found for --chkpnt_fn %s (expected %s.c3rw.npy; run "
-                            "tools/convert_tf_checkpoint.py where TensorFlow is installed)" % (chkpnt_fn, chkpnt_fn))
+    if os.path.isfile(chkpnt_fn + ".index"):
+        from . import tfckpt
+        return tfckpt.weights_from_bundle(chkpnt_fn, channels)
+    raise FileNotFoundError("no weights found for --chkpnt_fn %s (expected %s.c3rw.npy or the checkpoint bundle %s.index)"
+                            % (chkpnt_fn, chkpnt_fn, chkpnt_fn))
