@@ -1,0 +1,37 @@
+# One-off evidence run on the GPU box: the WHOLE synthetic chr20 (BASELINE.json configs[1]) through the HIP path and through
+# the oracle, chunk by chunk — every line (position, ref33, 594 ints, ordered alt_info) and every rescaled tensor identical,
+# probabilities within 1e-4.  ~3 min of host time (the oracle's text stages are single-threaded).  python tools/full_contig_check.py
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+import bench
+from clair3_rna_amd import capi, synth, altinfo
+from oracle import oracle as orc
+ref, rs, info = synth.generate_contig()
+L = len(ref)
+refs = ref.decode()
+chunks = bench.chunk_list(L)
+eng = capi.Engine(0); eng.set_params(); eng.load_reads(rs); eng.set_reference(1, ref)
+w = synth.random_weights(18); eng.load_weights(w, 18)
+t0 = time.time()
+n_tot, worst = 0, 0.0
+for ci, (a, b) in enumerate(chunks):
+    n = eng.scan(a, b)
+    raw, X = eng.tensors(rescaled=False), eng.tensors(rescaled=True)
+    sites, toks = eng.sites(), eng.tokens()
+    rstart = max(1, a - 1000)
+    refslice = refs[rstart - 1:b + 1000]
+    lines = altinfo.format_lines("chr20", sites, raw, toks, rs, refslice.upper(), rstart) if n else []
+    es, ee = max(1, a - 33), b + 33
+    rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, "chr20", es, ee)
+    exp = orc.create_tensor(rows, "chr20", refslice.upper(), rstart, orc.make_params())
+    assert lines == exp, (ci, len(lines), len(exp))
+    Xo, _ = orc.batch_from_lines(exp, 18)
+    assert np.array_equal(X, Xo)
+    if n:
+        p = eng.infer(); po = orc.forward(w, Xo)
+        worst = max(worst, float(np.abs(p - po).max()))
+    n_tot += n
+    print("chunk %2d/%d: %6d sites identical, max |dP| so far %.2e  (%.0f s)" % (ci + 1, len(chunks), n, worst, time.time() - t0), flush=True)
+assert worst < 1e-4
+print("FULL CONTIG OK: %d sites, %d reads, all lines and tensors identical, max |dP| = %.2e" % (n_tot, len(rs), worst))
