@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--depth", type=float, default=20.0)
     ap.add_argument("--contig_len", type=int, default=0, help="default: chr20 (64,444,167)")
+    ap.add_argument("--contexts", type=int, default=2, help="engine contexts (HIP streams) whose passes are pipelined on the GPU")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
     ap.add_argument("--no_overlap", action="store_true",
@@ -110,7 +111,7 @@ def main():
     # tensors of pass i+1 (the scan workgroups fit beside the persistent LSTM workgroups: 29 KB vs 128 KB of LDS).
     # Every pass still does all of its work; only the order of independent passes is pipelined.
     engs = [eng]
-    if not args.no_overlap:
+    for _ in range(0 if args.no_overlap else max(1, args.contexts) - 1):
         e2 = capi.Engine(local_rank)
         e2.set_params(); e2.load_reads(rs); e2.set_reference(1, ref); e2.load_weights(weights, 18); e2.set_precision(args.precision)
         engs.append(e2)
@@ -118,17 +119,19 @@ def main():
     def run_steps(k):
         if len(engs) == 1:
             return sum(one_step() for _ in range(k))
-        total, pending = 0, [None, None]
+        ne = len(engs)
+        total, pending = 0, [None] * ne
         for i in range(k):
-            e = engs[i & 1]
-            if pending[i & 1] is not None:                       # results of pass i-2 (already long finished)
-                e.fetch_probs(pending[i & 1])
-            n = tensor_build(e)                                   # overlaps with the other context's network launch
+            j = i % ne
+            e = engs[j]
+            if pending[j] is not None:                            # results of pass i-ne (already long finished)
+                e.fetch_probs(pending[j])
+            n = tensor_build(e)                                   # overlaps with the other contexts' network launches
             if n:
                 e.infer(fetch=False)
-            pending[i & 1] = n
+            pending[j] = n
             total += n
-        for j in (0, 1):
+        for j in range(ne):
             if pending[j]:
                 engs[j].fetch_probs(pending[j])
         return total
