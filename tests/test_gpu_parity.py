@@ -385,3 +385,83 @@ def test_network_result_does_not_depend_on_batch_position(eng):
         for k in (1, 32, 64, 100, 129):
             assert np.array_equal(eng.infer(tensors=X[k:]), base[k:]), (mode, k)
     eng.set_precision("f16x3")
+
+
+def test_error_codes_and_messages(eng):
+    """Every misuse returns a negative C3R_E* code with a message (C3RError), never a crash or a silent fallback."""
+    from clair3_rna_amd import capi, synth
+    from clair3_rna_amd.reads import ReadSet
+    ref, rs, _ = synth.small_case(seed=71, ref_len=8000, n_genes=2, depth=10)
+    e = capi.Engine(0)
+    try:
+        e.set_params()
+        with pytest.raises(capi.C3RError, match="set_reference"):
+            e.load_reads(rs); e.scan(1, 1000)
+        e.set_reference(1, ref)
+        with pytest.raises(capi.C3RError):
+            e.scan(500, 100)                                    # end before start
+        with pytest.raises(capi.C3RError, match="load_weights"):
+            e.scan(1, len(ref)); e.infer()
+        with pytest.raises(capi.C3RError):
+            e.load_weights(np.zeros(1000, np.float32), 18)      # wrong blob size
+        with pytest.raises(capi.C3RError):
+            e.load_weights(synth.random_weights(18), 24)        # channels must be 18 or 30
+        with pytest.raises(capi.C3RError):
+            e.set_params(channels=24)
+        # reads not sorted by position
+        recs = [dict(pos=500, cigar="50M", seq="A" * 50), dict(pos=100, cigar="50M", seq="C" * 50)]
+        bad = ReadSet.from_records(recs)
+        bad.reads[["pos"]] = bad.reads[["pos"]][::-1]
+        with pytest.raises(capi.C3RError, match="sorted"):
+            e.load_reads(bad)
+        # CIGAR range out of bounds
+        bad2 = ReadSet.from_records(recs)
+        bad2.reads["n_cigar"][1] = 99
+        with pytest.raises(capi.C3RError, match="out of bounds"):
+            e.load_reads(bad2)
+        # weights for 30 channels, scan for 18
+        e.load_reads(rs)
+        e.load_weights(synth.random_weights(30), 30)
+        e.scan(1, len(ref))
+        with pytest.raises(capi.C3RError, match="channels"):
+            e.infer()
+        # and the context still works afterwards
+        e.load_weights(synth.random_weights(18), 18)
+        p = e.infer()
+        assert p.shape == (e.n_candidates, 24) and np.isfinite(p).all()
+    finally:
+        e.close()
+
+
+def test_two_engines_driven_from_two_threads(eng):
+    """One context per host thread (how a multi-GPU or multi-stream host would drive the library): no shared mutable state."""
+    import threading
+    from clair3_rna_amd import capi, synth
+    cases = [synth.small_case(seed=81 + k, ref_len=40000, n_genes=8, depth=20) for k in range(2)]
+    w = synth.random_weights(18, seed=3)
+    want = []
+    for ref, rs, _ in cases:
+        _reset(eng)
+        eng.load_reads(rs); eng.set_reference(1, ref); eng.load_weights(w, 18)
+        eng.scan(1, len(ref))
+        want.append((eng.tensors().copy(), eng.infer().copy()))
+    got, errs = [None, None], []
+
+    def work(k):
+        try:
+            e = capi.Engine(0)
+            ref, rs, _ = cases[k]
+            e.set_params(); e.load_weights(w, 18)
+            for _ in range(5):
+                e.load_reads(rs); e.set_reference(1, ref)
+                e.scan(1, len(ref))
+                got[k] = (e.tensors().copy(), e.infer().copy())
+            e.close()
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for k in range(2):
+        assert np.array_equal(got[k][0], want[k][0]) and np.array_equal(got[k][1], want[k][1])
