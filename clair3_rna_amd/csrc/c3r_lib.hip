@@ -62,9 +62,6 @@ struct c3r_ctx {
     // ---- scan state
     int32_t reg_beg0 = 0, reg_end0 = 0;   // first region of the most recent scan (c3r_get_columns)
     int64_t n_pos = 0;                    // position slots of the most recent scan (all regions, tile-padded)
-    std::vector<LeadIndel> h_lead;        // indels that directly follow a ref-skip (phased channels need a second look)
-    std::vector<int32_t> h_regtile0;      // first tile of every region of the most recent scan (+ one past the last)
-    DevBuf d_lead, d_regtile0;
     std::vector<TileGeo> h_geo;           // tile geometry of the most recent scan; re-uploaded only when it changes
     std::vector<int64_t> geo_key;         // the (start, end) list h_geo was built for
     DevBuf d_geo, d_lastrow;
@@ -240,7 +237,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
-                      &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_lead, &ctx->d_regtile0, &ctx->d_ev, &ctx->d_small,
+                      &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     net_free(ctx->net);
@@ -276,7 +273,7 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     if (!ctx || n_reads < 0 || (n_reads && (!reads || !cigars || !seq4))) return C3R_EINVAL;
     if (n_reads > INT32_MAX) return fail(ctx, C3R_EINVAL, "too many reads");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    ctx->h_reads.clear(); ctx->h_cigar.clear(); ctx->h_segs.clear(); ctx->h_lead.clear();
+    ctx->h_reads.clear(); ctx->h_cigar.clear(); ctx->h_segs.clear();
     ctx->h_reads.reserve((size_t)n_reads);
     ctx->h_cigar.reserve((size_t)n_cigar_ops);
     ctx->n_indel_ops = 0;
@@ -350,7 +347,6 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
                     if (k1 - k > 0xffff) return fail(ctx, C3R_EINVAL, "read %lld: more than 65535 CIGAR ops between two N ops", (long long)i);
                     g.n_cig = (uint16_t)(k1 - k);
                     g.ext_start = g.pos - (lead_indel ? 1 : 0);
-                    if (lead_indel) ctx->h_lead.push_back(LeadIndel{(int32_t)i, g.pos - 1, first_op == C3R_CIG_I ? 1 : 0, 0});
                     g.end = (int32_t)std::max<int64_t>(x, (int64_t)g.ext_start + 1);
                     ctx->h_segs.push_back(g);
                 }
@@ -376,7 +372,6 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     if ((rc = upload(ctx, ctx->d_cigar, ctx->h_cigar.data(), ctx->h_cigar.size()))) return rc;
     if ((rc = upload(ctx, ctx->d_seq, ctx->h_seq.data(), ctx->h_seq.size()))) return rc;
     if ((rc = upload(ctx, ctx->d_segs, ctx->h_segs.data(), ctx->h_segs.size()))) return rc;
-    if ((rc = upload(ctx, ctx->d_lead, ctx->h_lead.data(), ctx->h_lead.size()))) return rc;
     if ((rc = upload_prefmax(ctx))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return C3R_OK;
@@ -472,9 +467,8 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     }
     bool geo_changed = key != ctx->geo_key;
     if (geo_changed) {
-        ctx->h_geo.clear(); ctx->h_regtile0.clear();
+        ctx->h_geo.clear();
         for (int r = 0; r < n_regions; ++r) {
-            ctx->h_regtile0.push_back((int32_t)ctx->h_geo.size());
             int64_t es = ctg_starts[r] - C3R_WINDOW, ee = ctg_ends[r] + C3R_WINDOW;
             if (es < 1) es = 1;
             const int32_t beg0 = (int32_t)(es - 1), end0 = (int32_t)ee;
@@ -482,7 +476,6 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
             ctx->h_geo.push_back(TileGeo{end0, end0, r, 0});          // guard tile
             if (r == 0) { ctx->reg_beg0 = beg0; ctx->reg_end0 = end0; }
         }
-        ctx->h_regtile0.push_back((int32_t)ctx->h_geo.size());
         if ((int64_t)ctx->h_geo.size() * TILE > INT32_MAX - TILE) return fail(ctx, C3R_EINVAL, "regions too large for one scan (2^31 slots)");
         ctx->geo_key = key;
     }
@@ -496,7 +489,6 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     const int n_cblocks = (int)((n_pos + CMP_BLOCK - 1) / CMP_BLOCK);
     int rc;
     if (geo_changed && (rc = upload(ctx, ctx->d_geo, ctx->h_geo.data(), ctx->h_geo.size()))) return rc;
-    if (geo_changed && (rc = upload(ctx, ctx->d_regtile0, ctx->h_regtile0.data(), ctx->h_regtile0.size()))) return rc;
     if ((rc = ensure(ctx, ctx->d_lastrow, (size_t)n_regions * 4 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_cols, (size_t)n_pos * C * 4))) return rc;
     if ((rc = ensure(ctx, ctx->d_depth, (size_t)n_pos * 4))) return rc;
@@ -544,16 +536,13 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
         if (C == C3R_CH) hipLaunchKernelGGL(k_scan_tiles<C3R_CH>, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
         else hipLaunchKernelGGL(k_scan_tiles<C3R_CH_PHASED>, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
     }
-    if (a.n_reads > 0 && C == C3R_CH_PHASED && !ctx->h_lead.empty()) {
-        PhaseFixArgs f;
-        f.items = (const LeadIndel *)ctx->d_lead.p; f.n_items = (int32_t)ctx->h_lead.size();
-        f.reg_tile0 = (const int32_t *)ctx->d_regtile0.p; f.n_regions = n_regions; f.geo = a.geo;
-        f.reads = a.reads; f.prefmax_end = a.prefmax_end; f.n_reads = a.n_reads;
-        f.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.rseg_first = (const uint32_t *)ctx->d_rseg_first.p; f.cigar = a.cigar; f.seq = a.seq;
-        f.flags = a.flags; f.cols = a.cols; f.min_mq = a.min_mq; f.excl_flags = a.excl_flags;
-        const int64_t nthr = (int64_t)f.n_items * n_regions;
-        Launch L(ctx, "k_phase_fix");
-        hipLaunchKernelGGL(k_phase_fix, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, ctx->stream, f);
+    if (a.n_reads > 0 && C == C3R_CH_PHASED) {
+        PhaseArgs f;
+        f.tile_list = a.tile_list; f.n_tile_list = a.n_tile_list; f.tile_rng = a.tile_rng; f.geo = a.geo;
+        f.reads = a.reads; f.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.rseg_first = (const uint32_t *)ctx->d_rseg_first.p;
+        f.cigar = a.cigar; f.seq = a.seq; f.flags = a.flags; f.cols = a.cols; f.min_mq = a.min_mq; f.excl_flags = a.excl_flags;
+        Launch L(ctx, "k_phase_recompute");
+        hipLaunchKernelGGL(k_phase_recompute, dim3(n_tiles), dim3(TILE), 0, ctx->stream, f);
     }
     if (a.n_reads > 0 && a.splice) {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_skipmax.p, 0, (size_t)n_pos * 4, ctx->stream));

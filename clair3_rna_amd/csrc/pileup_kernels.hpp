@@ -109,7 +109,7 @@ struct ScanArgs {
     int32_t *cols;                // [n_pos][C]
     int32_t *depth;               // [n_pos]
     int32_t *ncov;                // [n_pos] number of reads covering (incl. ref-skips)
-    uint8_t *flags;               // [n_pos] bit0 row, bit1 candidate gate, bit2 emitted
+    uint8_t *flags;               // [n_pos] bit0 row, bit1 candidate gate, bit2 emitted, bit3 phased channels to be recomputed in order
     const int32_t *lbed; int32_t n_lbed;   // -l column filter (merged, sorted, half-open 0-based)
     const int32_t *cbed; int32_t n_cbed;   // confident bed
     const int32_t *sites; int32_t n_sites; // genotyping mode (sorted, 1-based)
@@ -192,6 +192,7 @@ struct TileLds {
     int32_t *maxdel;   // [TILE]
     uint32_t *first;   // [TILE][6] first-seen token index per class A,C,G,T,I,D
     uint8_t *amb;      // [TILE]
+    uint8_t *odd;      // [TILE] phased mode: the column's haplotype channels need the ordered recompute (k_phase_recompute)
 };
 
 // Coverage of the tile from whole-read spans (incl. introns): header-only, one lane per read.
@@ -259,13 +260,18 @@ __device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, 
                     if (q0 < rd.l_seq) __builtin_memcpy(&w, a.seq + rd.seq_off + (q0 >> 1), 8);   // (a CIGAR may claim more bases than SEQ holds)
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
-                        if (u >= nb) break;
+                        if (u >= nb) continue;
                         const int ni = odd + u;                                  // nibble index inside w (high nibble first)
                         int code = (int)((w >> (8 * (ni >> 1) + ((ni & 1) ? 0 : 4))) & 15u);
                         if (q0 + (uint32_t)u >= rd.l_seq) code = 15;
                         const int bi = acgt_index(code);
-                        if (bi < 0) continue;
                         const int pl = pb + u - t0;
+                        if (bi < 0) {
+                            // '=' / IUPAC letters are ignored by the reference's token scan WITHOUT consuming their HP entry: every
+                            // later read of the column is then phased with its predecessor's tag (:116-145)
+                            if (C == C3R_CH_PHASED && MODE == ACCUM && code != 15) s.odd[pl] = 1;
+                            continue;
+                        }
                         if (MODE == ACCUM) {
                             atomicAdd(&s.cnt[pl * C + (rev ? 9 + bi : bi)], 1);
                             if (C == C3R_CH_PHASED) {
@@ -293,6 +299,8 @@ __device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, 
                 if (anchor >= t0 && anchor < t1) {
                     const int pl = anchor - t0;
                     if (MODE == ACCUM) {
+                        // an indel on a ref-skip column takes the haplotype of the previous token-list ENTRY (:183,189)
+                        if (C == C3R_CH_PHASED && prev == C3R_CIG_N) s.odd[pl] = 1;
                         int ch;
                         if (is_ins) {
                             const int fc = base_code(a.seq, rd.seq_off, (uint32_t)qstart, rd.l_seq);
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     __shared__ int32_t s_maxdel[TILE];
     __shared__ uint32_t s_first[TILE * 6];
     __shared__ uint8_t s_amb[TILE];
+    __shared__ uint8_t s_odd[TILE];
     __shared__ int s_misc[8];
     __shared__ unsigned long long s_evbase;
 
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     const int lo = rng.x, hi = rng.y;       // reads whose span can overlap [t0,t1)
     const int slo = rng.z, shi = rng.w;     // aligned segments that can touch it
 
-    TileLds s{s_cnt, s_cov, s_evoff, s_evfill, s_maxdel, s_first, s_amb};
+    TileLds s{s_cnt, s_cov, s_evoff, s_evfill, s_maxdel, s_first, s_amb, s_odd};
     s_cov[tid] = 0; if (tid == 0) s_cov[TILE] = 0;
     if (slo >= shi) {
         // intron-only tile: rows exist (ref-skip columns) but every count is zero.  Only the flags are written; the
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     }
     for (int i = tid; i < TILE * C; i += SCAN_THREADS) s_cnt[i] = 0;
     for (int i = tid; i < TILE * 6; i += SCAN_THREADS) s_first[i] = 0xffffffffu;
-    s_evfill[tid] = 0; s_maxdel[tid] = 0; s_amb[tid] = 0;
+    s_evfill[tid] = 0; s_maxdel[tid] = 0; s_amb[tid] = 0; s_odd[tid] = 0;
     __syncthreads();
 
     if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1);
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         const int gi = slot0 + tid;
         a.depth[gi] = depth;
         a.ncov[gi] = is_row ? my_cov : 0;
-        a.flags[gi] = (uint8_t)((is_row ? 1 : 0) | (cand ? 2 : 0));
+        a.flags[gi] = (uint8_t)((is_row ? 1 : 0) | (cand ? 2 : 0) | ((is_row && s_odd[tid]) ? 8 : 0));
     }
     if (a.head_tail) {
         int mx = is_row ? slot0 + tid : -1;
@@ -964,50 +973,62 @@ __global__ __launch_bounds__(256) void k_tokens(const TokArgs t) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Phased channels of an indel that follows a ref-skip directly (N then I / D: the indel sits on the read's last intron
-// column).  The reference gives an indel token the haplotype of phasing[idx-1], the PREVIOUS entry of the column's token
-// list (src/create_tensor_pileup.py:183,189): normally the carrying read's own base, but a ref-skip read has no base
-// entry, so the haplotype comes from whatever the previous read contributed last — its indel token ('0': no count), else
-// its base / deleted-base token (its HP), reads showing a ref-skip or an ignored IUPAC base contributing nothing.
-// k_scan_tiles counted the carrying read's own HP; this pass (30 channels only, one thread per such indel and region)
-// moves the count.  Such alignments are rare, so the backward search over the covering reads is affordable.
-struct LeadIndel { int32_t read_idx; int32_t anchor; int32_t is_ins; int32_t pad; };
-struct PhaseFixArgs {
-    const LeadIndel *items; int32_t n_items;
-    const int32_t *reg_tile0; int32_t n_regions;       // first tile of every region (+ one past the last)
-    const TileGeo *geo;
-    const DevRead *reads; const int32_t *prefmax_end; int32_t n_reads;
-    const DevSeg *rsegs; const uint32_t *rseg_first; const uint32_t *cigar; const uint8_t *seq;
+// Phased channels, the two places where the ORDER of the column's token list matters (src/create_tensor_pileup.py:113-145,
+// :180-217).  The reference walks the column's reads in BAM order with an index into the HP list that advances on base
+// tokens (ACGTN acgtn * #) and on ref-skips, but NOT on letters it ignores ('=' / IUPAC): after such a read every later
+// read of the column is phased with its predecessor's tag.  And an indel token takes phasing[idx-1], the previous list
+// ENTRY: its own read's base normally, but for an indel sitting on a ref-skip column whatever came before ('0' if that
+// was another indel token).  k_scan_tiles counts haplotypes with unordered atomics (each read's own tag) and flags the
+// columns where either case occurs (flags bit 3); here one thread per flagged column redoes the 12 haplotype channels
+// in order.  Both cases are rare (aligners do not emit them), so the serial walk over the column's reads is affordable.
+struct PhaseArgs {
+    const int32_t *tile_list; const int32_t *n_tile_list; const int4 *tile_rng; const TileGeo *geo;
+    const DevRead *reads; const DevSeg *rsegs; const uint32_t *rseg_first; const uint32_t *cigar; const uint8_t *seq;
     const uint8_t *flags; int32_t *cols;
     int32_t min_mq, excl_flags;
 };
-__global__ void k_phase_fix(const PhaseFixArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.n_items * a.n_regions) return;
-    const LeadIndel it = a.items[idx / a.n_regions];
-    const int reg = idx % a.n_regions;
-    const int t0 = a.reg_tile0[reg], t1 = a.reg_tile0[reg + 1] - 1;      // last tile of a region is its guard tile
-    const int beg0 = a.geo[t0].p0, end0 = a.geo[t1].p0, p = it.anchor;
-    if (p < beg0 || p >= end0) return;
-    const int slot = t0 * TILE + (p - beg0);
-    if (!(a.flags[slot] & 1)) return;
-    const DevRead me = a.reads[it.read_idx];
-    if (!read_passes(me, a.min_mq, a.excl_flags)) return;
-    int32_t *c = a.cols + (size_t)slot * C3R_CH_PHASED;
-    if (me.hp == 1) atomicAdd(&c[it.is_ins ? C3R_IP : C3R_DP], -1);
-    else if (me.hp == 2) atomicAdd(&c[it.is_ins ? C3R_IM : C3R_DM], -1);
-    const int lo = upper_bound_gt(a.prefmax_end, a.n_reads, p);
-    for (int r = it.read_idx - 1; r >= lo; --r) {
+__global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
+    if ((int)blockIdx.x >= *a.n_tile_list) return;
+    const int tile = a.tile_list[blockIdx.x];
+    const int slot = tile * TILE + (int)threadIdx.x;
+    if (!(a.flags[slot] & 8)) return;
+    const int p = a.geo[tile].p0 + (int)threadIdx.x;
+    const int4 rng = a.tile_rng[tile];
+    auto next_cov = [&](int r) {            // next read after r (BAM order) that passes the filters and covers p
+        for (++r; r < rng.y; ++r) {
+            const DevRead rd = a.reads[r];
+            if (read_passes(rd, a.min_mq, a.excl_flags) && rd.pos <= p && rd.end > p) break;
+        }
+        return r;
+    };
+    int cnt[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) cnt[k] = 0;
+    int r2 = next_cov(rng.x - 1);           // cursor into the HP list (one entry per covering read)
+    int prev = 0; bool have_prev = false;
+    for (int r = next_cov(rng.x - 1); r < rng.y; r = next_cov(r)) {
         const DevRead rd = a.reads[r];
-        if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.pos > p || rd.end <= p) continue;
         const TokenAt tk = token_at(rd, r, p, a.rsegs, a.rseg_first, a.cigar, a.seq);
-        if (tk.indel != 0) return;                                        // previous entry is an indel token: phasing '0'
-        const bool listed = tk.base == 16 || acgt_index(tk.base) >= 0 || tk.base == 15;   // * / #, A C G T, N
-        if (!listed) continue;                                            // ref-skip or ignored letter: no entry
-        if (rd.hp == 1) atomicAdd(&c[it.is_ins ? C3R_IP : C3R_DP], 1);
-        else if (rd.hp == 2) atomicAdd(&c[it.is_ins ? C3R_IM : C3R_DM], 1);
-        return;
+        const int bi = acgt_index(tk.base);
+        if (tk.base == 16 || tk.base == 15 || bi >= 0) {          // * / #, N, A C G T: a list entry that consumes a tag
+            const int hp = r2 < rng.y ? (int)a.reads[r2].hp : 0;
+            r2 = next_cov(r2);
+            if (bi >= 0) { if (hp == 1) cnt[bi]++; else if (hp == 2) cnt[6 + bi]++; }
+            prev = hp; have_prev = true;
+        } else if (tk.base == 17) {
+            r2 = next_cov(r2);                                    // a ref-skip consumes a tag, adds no entry
+        }
+        if (tk.indel != 0) {
+            if (have_prev) {
+                const int k = tk.indel > 0 ? 4 : 5;               // IP / DP (+6: IM / DM)
+                if (prev == 1) cnt[k]++; else if (prev == 2) cnt[6 + k]++;
+            }
+            prev = 0; have_prev = true;                           // the indel token's own entry is phased '0'
+        }
     }
+    int32_t *c = a.cols + (size_t)slot * C3R_CH_PHASED + C3R_AP;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) c[k] = cnt[k];
 }
 
 }  // namespace c3r
