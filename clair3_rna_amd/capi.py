@@ -22,7 +22,8 @@ C3R_ERRORS = {-1: "EINVAL", -2: "ENODEVICE", -3: "EHIP", -4: "ENOMEM", -5: "EUNS
 class Params(C.Structure):
     _fields_ = [("channels", C.c_int32), ("min_mq", C.c_int32), ("excl_flags", C.c_int32), ("min_coverage", C.c_int32),
                 ("snp_min_af", C.c_double), ("indel_min_af", C.c_double), ("head_tail", C.c_int32),
-                ("splice_padding", C.c_int32), ("genotyping_mode", C.c_int32), ("max_depth_rescale", C.c_int32)]
+                ("splice_padding", C.c_int32), ("genotyping_mode", C.c_int32), ("max_depth_rescale", C.c_int32),
+                ("max_depth", C.c_int32), ("reserved", C.c_int32)]
 
 
 class C3RError(RuntimeError):

@@ -1,6 +1,7 @@
 // c3r_lib.hip — host side of libc3r.so: the C-ABI of include/c3r.h over the gfx950 kernels.
 // No CPU fallback: every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <queue>
 #include <chrono>
 
 #include <algorithm>
@@ -62,6 +63,10 @@ struct c3r_ctx {
     // ---- scan state
     int32_t reg_beg0 = 0, reg_end0 = 0;   // first region of the most recent scan (c3r_get_columns)
     int64_t n_pos = 0;                    // position slots of the most recent scan (all regions, tile-padded)
+    std::vector<int32_t> h_prefmax;       // host copy of the prefix max of read ends (passing reads)
+    int32_t max_cover = 0;                // most passing reads covering one position: below max_depth / 2 the cap cannot bite
+    std::vector<uint32_t> h_drop;         // depth cap of the most recent scan: [n_regions][drop_words] bit per read
+    DevBuf d_drop;
     std::vector<TileGeo> h_geo;           // tile geometry of the most recent scan; re-uploaded only when it changes
     std::vector<int64_t> geo_key;         // the (start, end) list h_geo was built for
     DevBuf d_geo, d_lastrow;
@@ -164,10 +169,21 @@ void recompute_prefmax(c3r_ctx *ctx, std::vector<int32_t> &pm) {
 
 int upload_prefmax(c3r_ctx *ctx) {
     if (ctx->h_reads.empty()) return C3R_OK;
-    std::vector<int32_t> pm;
+    std::vector<int32_t> &pm = ctx->h_prefmax;
     recompute_prefmax(ctx, pm);
     int rc = upload(ctx, ctx->d_prefmax, pm.data(), pm.size());
     if (rc) return rc;
+    {   // deepest coverage by passing reads (one sweep with a min-heap of ends)
+        std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> live;
+        size_t mx = 0;
+        for (const DevRead &r : ctx->h_reads) {
+            if ((r.flag & ctx->prm.excl_flags) || (r.flag & 4) || r.mapq < ctx->prm.min_mq || r.end <= r.pos) continue;
+            while (!live.empty() && live.top() <= r.pos) live.pop();
+            live.push(r.end);
+            mx = std::max(mx, live.size());
+        }
+        ctx->max_cover = (int32_t)std::min<size_t>(mx, INT32_MAX);
+    }
     std::vector<int32_t> sm(ctx->h_segs.size());
     int32_t m = INT_MIN;
     for (size_t i = 0; i < ctx->h_segs.size(); ++i) {
@@ -203,6 +219,7 @@ const char *c3r_version(void) { return "c3r 0.1 (gfx950, HIP)"; }
 
 void c3r_default_params(c3r_params_t *p) {
     memset(p, 0, sizeof *p);
+    p->max_depth = 8000;
     p->channels = C3R_CH;
     p->min_mq = 5;
     p->excl_flags = 2316;
@@ -237,7 +254,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
-                      &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_ev, &ctx->d_small,
+                      &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     net_free(ctx->net);
@@ -508,7 +525,47 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     HIPCHK(ctx, hipMemsetAsync(ctx->d_flags.p, 0, (size_t)n_pos, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cols.p, 0, (size_t)n_tiles, ctx->stream));
 
+    // samtools mpileup -d (default 8000), restated from htslib's bam_plp_push / bam_plp_next (third-party, absent: parity
+    // unpinned; the oracle restates the same rule independently): reads arrive in file order, filtered, and only those
+    // overlapping the region; a read is discarded iff it is not the first read pushed for its start position and the
+    // engine's list — the kept reads with exclusive end > start - 1 — holds more than max_depth reads.  Sequential by
+    // nature, so it runs here on the host, per region, and only when the data can reach the cap at all.
+    const uint32_t *d_drop = nullptr;
+    const int drop_words = (int)((ctx->h_reads.size() + 31) / 32);
+    if (ctx->prm.max_depth > 0 && (int64_t)ctx->max_cover * 2 > ctx->prm.max_depth) {
+        ctx->h_drop.assign((size_t)n_regions * drop_words, 0u);
+        bool any = false;
+        for (int r = 0; r < n_regions; ++r) {
+            int64_t es = ctg_starts[r] - C3R_WINDOW, ee = ctg_ends[r] + C3R_WINDOW;
+            if (es < 1) es = 1;
+            const int32_t beg0 = (int32_t)(es - 1), end0 = (int32_t)ee;                // rows for [beg0, end0)
+            std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> live;
+            int32_t last_pos = INT_MIN;
+            size_t i = (size_t)(std::upper_bound(ctx->h_prefmax.begin(), ctx->h_prefmax.end(), beg0) - ctx->h_prefmax.begin());
+            for (; i < ctx->h_reads.size(); ++i) {
+                const DevRead &rd = ctx->h_reads[i];
+                if (rd.pos >= end0) break;
+                if ((rd.flag & ctx->prm.excl_flags) || (rd.flag & 4) || rd.mapq < ctx->prm.min_mq || rd.end <= rd.pos) continue;
+                if (rd.end <= beg0) continue;                                            // not fetched for this region
+                while (!live.empty() && live.top() <= rd.pos - 1) live.pop();
+                const bool first = rd.pos != last_pos;
+                last_pos = rd.pos;
+                if (!first && (int64_t)live.size() > ctx->prm.max_depth) {
+                    ctx->h_drop[(size_t)r * drop_words + (i >> 5)] |= 1u << (i & 31);
+                    any = true;
+                    continue;
+                }
+                live.push(rd.end);
+            }
+        }
+        if (any) {
+            if ((rc = upload(ctx, ctx->d_drop, ctx->h_drop.data(), ctx->h_drop.size()))) return rc;
+            d_drop = (const uint32_t *)ctx->d_drop.p;
+        }
+    }
+
     ScanArgs a;
+    a.drop = d_drop; a.drop_words = drop_words;
     a.reads = (const DevRead *)ctx->d_reads.p; a.cigar = (const uint32_t *)ctx->d_cigar.p; a.seq = (const uint8_t *)ctx->d_seq.p;
     a.prefmax_end = (const int32_t *)ctx->d_prefmax.p; a.n_reads = (int32_t)ctx->h_reads.size();
     a.segs = (const DevSeg *)ctx->d_segs.p; a.seg_prefmax = (const int32_t *)ctx->d_seg_prefmax.p; a.n_segs = (int32_t)ctx->h_segs.size();
@@ -541,6 +598,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
         f.tile_list = a.tile_list; f.n_tile_list = a.n_tile_list; f.tile_rng = a.tile_rng; f.geo = a.geo;
         f.reads = a.reads; f.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.rseg_first = (const uint32_t *)ctx->d_rseg_first.p;
         f.cigar = a.cigar; f.seq = a.seq; f.flags = a.flags; f.cols = a.cols; f.min_mq = a.min_mq; f.excl_flags = a.excl_flags;
+        f.drop = a.drop; f.drop_words = a.drop_words;
         Launch L(ctx, "k_phase_recompute");
         hipLaunchKernelGGL(k_phase_recompute, dim3(n_tiles), dim3(TILE), 0, ctx->stream, f);
     }
@@ -599,6 +657,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
         t.rsegs = (const DevSeg *)ctx->d_rsegs.p; t.rseg_first = (const uint32_t *)ctx->d_rseg_first.p;
         t.cand_idx = (const int32_t *)ctx->d_cand.p; t.n_cand = n_cand; t.geo = (const TileGeo *)ctx->d_geo.p;
         t.tile_rng = (const int4 *)ctx->d_tile_rng.p;
+        t.drop = a.drop; t.drop_words = a.drop_words;
         t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
         t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;
         t.min_mq = a.min_mq; t.excl_flags = a.excl_flags;

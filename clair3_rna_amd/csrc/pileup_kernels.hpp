@@ -119,6 +119,8 @@ struct ScanArgs {
     EvRec *ev;                    // scratch, one slot per I/D op in the loaded reads (+ padding)
     unsigned long long *ev_cursor;
     int32_t *last_row;            // [n_regions] atomicMax of the last SLOT (index into the position arrays) with a row
+    const uint32_t *drop;         // mpileup depth cap: [n_regions][drop_words] bit per read = discarded in that region; null: none
+    int32_t drop_words;
     int32_t splice;               // --enable_padding_in_splice_junction_regions: also produce skipmax[], materialise every tile
     int32_t *skipmax;             // [n_pos] max(#read starts, #read ends, #fwd ref-skips, #rev ref-skips) of the row
 };
@@ -133,6 +135,9 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
+__device__ __forceinline__ bool read_dropped(const uint32_t *drop, int words, int region, int r) {
+    return drop != nullptr && ((drop[(size_t)region * words + (r >> 5)] >> (r & 31)) & 1u);
+}
 __device__ __forceinline__ bool read_passes(const DevRead &r, int min_mq, int excl) {
     return !(r.flag & excl) && !(r.flag & 4) && r.mapq >= min_mq && r.end > r.pos;
 }
@@ -196,10 +201,11 @@ struct TileLds {
 };
 
 // Coverage of the tile from whole-read spans (incl. introns): header-only, one lane per read.
-__device__ void cover_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1) {
+__device__ void cover_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, int region) {
     for (int r = lo + (int)threadIdx.x; r < hi; r += SCAN_THREADS) {
         const DevRead rd = a.reads[r];
         if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.pos >= t1) continue;
+        if (read_dropped(a.drop, a.drop_words, region, r)) continue;
         atomicAdd(&s.cov[max(rd.pos, t0) - t0], 1);
         if (rd.end < t1) atomicAdd(&s.cov[rd.end - t0], -1);
     }
@@ -222,12 +228,13 @@ __device__ __forceinline__ int grp_incl_scan(int v) {
 }
 
 template <int C, int MODE>
-__device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, unsigned long long ev_base) {
+__device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, unsigned long long ev_base, int region) {
     const int lane = threadIdx.x & (GRP - 1);
     const int grp = threadIdx.x / GRP;
     for (int si = lo + grp; si < hi; si += NGRP) {
         const DevSeg rd = a.segs[si];
         if (!seg_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.ext_start >= t1) continue;
+        if (read_dropped(a.drop, a.drop_words, region, (int)rd.read_idx)) continue;
         const bool rev = (rd.flag & 16) != 0;
         const int r = (int)rd.read_idx;
         int ref_carry = 0, q_carry = (int)rd.qstart, prev_carry = rd.lead_n ? (int)C3R_CIG_N : 15;
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         // intron-only tile: rows exist (ref-skip columns) but every count is zero.  Only the flags are written; the
         // gather treats the columns of such a tile as zeros (tile_cols stays 0).
         __syncthreads();
-        cover_reads(a, s, lo, hi, t0, t1);
+        cover_reads(a, s, lo, hi, t0, t1, tg.region);
         __syncthreads();
         int tot;
         const int d = s_cov[tid];
@@ -456,8 +463,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     s_evfill[tid] = 0; s_maxdel[tid] = 0; s_amb[tid] = 0; s_odd[tid] = 0;
     __syncthreads();
 
-    if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1);
-    if (!(a.abl & 1)) walk_reads<C, ACCUM>(a, s, slo, shi, t0, t1, 0ull);
+    if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1, tg.region);
+    if (!(a.abl & 1)) walk_reads<C, ACCUM>(a, s, slo, shi, t0, t1, 0ull, tg.region);
     __syncthreads();
 
     // coverage: inclusive scan of the difference array; indel events: exclusive scan of per-position counts
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         if (tid == 0) s_evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
         __syncthreads();
         const unsigned long long evb = s_evbase;
-        walk_reads<C, SCATTER>(a, s, slo, shi, t0, t1, evb);
+        walk_reads<C, SCATTER>(a, s, slo, shi, t0, t1, evb, tg.region);
         __threadfence_block();
         __syncthreads();
         // max multiplicity of one allele per (position, channel): I1 / i1 / D1 / d1
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     }
     s_amb[tid] = ambiguous ? 1 : 0;
     if (__syncthreads_or(ambiguous ? 1 : 0)) {
-        walk_reads<C, FIRSTSEEN>(a, s, slo, shi, t0, t1, 0ull);
+        walk_reads<C, FIRSTSEEN>(a, s, slo, shi, t0, t1, 0ull, tg.region);
         __syncthreads();
         if (ambiguous) {
             int m = 0;
@@ -611,6 +618,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) 
     for (int r = rng.x + tid; r < rng.y; r += SCAN_THREADS) {
         const DevRead rd = a.reads[r];
         if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.pos >= t1) continue;
+        if (read_dropped(a.drop, a.drop_words, tg.region, r)) continue;
         const int st = (rd.flag & 16) ? 1 : 0;
         atomicAdd(&s_cov[st][max(rd.pos, t0) - t0], 1);
         if (rd.end < t1) atomicAdd(&s_cov[st][rd.end - t0], -1);
@@ -620,6 +628,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) 
     for (int g = rng.z + tid; g < rng.w; g += SCAN_THREADS) {
         const DevSeg sg = a.segs[g];
         if (!seg_passes(sg, a.min_mq, a.excl_flags) || sg.end <= t0 || sg.pos >= t1 || sg.end <= sg.pos) continue;
+        if (read_dropped(a.drop, a.drop_words, tg.region, (int)sg.read_idx)) continue;
         const int st = (sg.flag & 16) ? 1 : 0;
         atomicAdd(&s_seg[st][max(sg.pos, t0) - t0], 1);
         if (sg.end < t1) atomicAdd(&s_seg[st][sg.end - t0], -1);
@@ -939,6 +948,7 @@ struct TokArgs {
     const uint32_t *rseg_first;    // [n_reads+1] first segment of each read in rsegs
     const int32_t *cand_idx; int32_t n_cand; const TileGeo *geo;
     const int4 *tile_rng;          // from k_tile_ranges: the reads whose span can overlap the candidate's tile
+    const uint32_t *drop; int32_t drop_words;   // depth cap (see ScanArgs)
     const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
     int32_t tok_base;              // tokens already resident from earlier scans of the batch
     int32_t min_mq, excl_flags;
@@ -960,7 +970,10 @@ __global__ __launch_bounds__(256) void k_tokens(const TokArgs t) {
         const int r = rb + lane;
         bool cov = false;
         DevRead rd;
-        if (r < hi) { rd = t.reads[r]; cov = read_passes(rd, t.min_mq, t.excl_flags) && rd.pos <= p && rd.end > p; }
+        if (r < hi) {
+            rd = t.reads[r];
+            cov = read_passes(rd, t.min_mq, t.excl_flags) && rd.pos <= p && rd.end > p && !read_dropped(t.drop, t.drop_words, t.geo[ci / TILE].region, r);
+        }
         const unsigned long long m = __ballot(cov);
         if (cov) {
             const int rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -986,6 +999,7 @@ struct PhaseArgs {
     const DevRead *reads; const DevSeg *rsegs; const uint32_t *rseg_first; const uint32_t *cigar; const uint8_t *seq;
     const uint8_t *flags; int32_t *cols;
     int32_t min_mq, excl_flags;
+    const uint32_t *drop; int32_t drop_words;
 };
 __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
     if ((int)blockIdx.x >= *a.n_tile_list) return;
@@ -997,7 +1011,7 @@ __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
     auto next_cov = [&](int r) {            // next read after r (BAM order) that passes the filters and covers p
         for (++r; r < rng.y; ++r) {
             const DevRead rd = a.reads[r];
-            if (read_passes(rd, a.min_mq, a.excl_flags) && rd.pos <= p && rd.end > p) break;
+            if (read_passes(rd, a.min_mq, a.excl_flags) && rd.pos <= p && rd.end > p && !read_dropped(a.drop, a.drop_words, a.geo[tile].region, r)) break;
         }
         return r;
     };

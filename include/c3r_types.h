@@ -59,6 +59,10 @@ typedef struct c3r_params {
     int32_t  splice_padding;  /* --enable_padding_in_splice_junction_regions                       */
     int32_t  genotyping_mode; /* 1: candidates = the supplied site list (--vcf_fn), gates ignored  */
     int32_t  max_depth_rescale; /* 144 (param_p.py:14); windows with depth > 1.5x are rescaled     */
+    int32_t  max_depth;       /* samtools mpileup -d: reads beyond this many live reads are discarded (htslib's
+                                 rule, see c3r_pileup_scan); default 8000 = mpileup's own default, which the reference
+                                 leaves in force (src/create_tensor_pileup.py:442); 0 = no cap                  */
+    int32_t  reserved;        /* must be 0                                                          */
 } c3r_params_t;
 
 /* One emitted candidate site (the non-tensor fields of a create_tensor output line,

@@ -160,9 +160,50 @@ static int bed_contains(const int32_t *bed, int n_bed, int64_t pos0) {
 /* reads must be sorted by pos (BAM order).  beg1/end1: 1-based inclusive region (-r).  bed: the
  * `-l` file's intervals for this contig (NULL = none).  Returns text rows
  * "ctg\tpos\tN\tn\tBASES\tQUALS[\tHP,...]\n". */
+char *orc_mpileup_d(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *cigar_in, const uint8_t *seq,
+                    const char *ctg, int64_t beg1, int64_t end1, int min_mq, int excl_flags,
+                    const int32_t *bed, int n_bed, int with_hp, int max_depth, int64_t *out_len);
+
+/* samtools mpileup's default -d 8000 (the reference passes --max-depth only on request, src/create_tensor_pileup.py:442) */
 char *orc_mpileup(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *cigar_in, const uint8_t *seq,
                   const char *ctg, int64_t beg1, int64_t end1, int min_mq, int excl_flags,
                   const int32_t *bed, int n_bed, int with_hp, int64_t *out_len) {
+    return orc_mpileup_d(reads_in, n_reads, cigar_in, seq, ctg, beg1, end1, min_mq, excl_flags, bed, n_bed, with_hp, 8000, out_len);
+}
+
+/* Depth cap, restated from htslib's pileup engine (bam_plp_push / bam_plp_next; third-party, absent here: parity unpinned).
+ * Reads reach the engine in file order, already filtered by flag / MAPQ, and only those overlapping the region.  A read is
+ * discarded iff it starts at the position the engine currently stands on — i.e. it is NOT the first read pushed for its start
+ * position — and the engine's read list holds more than max_depth reads at that moment.  The list holds every kept read that
+ * has not been retired yet; a read is retired while the column at or after its (exclusive) end is processed, and all columns
+ * left of the new read's start have been processed by then: the list is the kept reads with exclusive end > start - 1.
+ * max_depth <= 0: no cap.  Marks dropped[i] = 1. */
+static void depth_cap(const c3r_read_t *reads, int64_t n_reads, const uint32_t *cigar, int64_t beg0, int64_t end0_incl,
+                      int min_mq, int excl_flags, int max_depth, uint8_t *dropped) {
+    memset(dropped, 0, (size_t)(n_reads > 0 ? n_reads : 1));
+    if (max_depth <= 0) return;
+    int64_t *ends = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_reads > 0 ? n_reads : 1));   /* exclusive ends of kept reads */
+    int64_t n_live = 0, last_pos = INT64_MIN;
+    for (int64_t i = 0; i < n_reads; ++i) {
+        const c3r_read_t *r = &reads[i];
+        if (r->pos > end0_incl) break;
+        if ((r->flag & excl_flags) || (r->flag & 4) || r->mapq < min_mq || r->n_cigar == 0) continue;
+        const int64_t rl = cigar_rlen(cigar + r->cigar_off, r->n_cigar);
+        if (rl <= 0 || r->pos + rl <= beg0) continue;                 /* not fetched for this region */
+        int64_t w = 0;                                                /* retire: keep exclusive end > pos - 1 */
+        for (int64_t k = 0; k < n_live; ++k) if (ends[k] > (int64_t)r->pos - 1) ends[w++] = ends[k];
+        n_live = w;
+        const int first = (r->pos != last_pos);
+        last_pos = r->pos;
+        if (!first && n_live > max_depth) { dropped[i] = 1; continue; }
+        ends[n_live++] = r->pos + rl;
+    }
+    free(ends);
+}
+
+char *orc_mpileup_d(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *cigar_in, const uint8_t *seq,
+                    const char *ctg, int64_t beg1, int64_t end1, int min_mq, int excl_flags,
+                    const int32_t *bed, int n_bed, int with_hp, int max_depth, int64_t *out_len) {
     /* Zero-length CIGAR ops are dropped before the walk (conscious deviation): BAM writers do not emit
      * them, and what htslib's cursor does with them is an accident of its peek-next-op logic (e.g. `3M0I2D` loses the
      * deletion marker, `3M0D2I` the insertion).  The product path drops them at load, so the checker does too. */
@@ -182,6 +223,8 @@ char *orc_mpileup(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *c
             reads[i].n_cigar = (uint32_t)(w - reads[i].cigar_off);
         }
     }
+    uint8_t *dropped = (uint8_t *)malloc((size_t)(n_reads > 0 ? n_reads : 1));
+    depth_cap(reads, n_reads, cigar, beg1 - 1, end1 - 1, min_mq, excl_flags, max_depth, dropped);
     sbuf out = {0}, bases = {0}, hps = {0};
     sb_reserve(&out, 1);
     out.p[0] = 0;
@@ -193,7 +236,7 @@ char *orc_mpileup(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *c
         /* admit reads starting at or before pos */
         while (next < n_reads && reads[next].pos <= pos) {
             const c3r_read_t *r = &reads[next];
-            int ok = !(r->flag & excl_flags) && !(r->flag & 4) && r->mapq >= min_mq && r->n_cigar > 0;
+            int ok = !(r->flag & excl_flags) && !(r->flag & 4) && r->mapq >= min_mq && r->n_cigar > 0 && !dropped[next];
             if (ok) {
                 int64_t rl = cigar_rlen(cigar + r->cigar_off, r->n_cigar);
                 if (rl > 0 && r->pos + rl - 1 >= pos) {
@@ -258,7 +301,7 @@ char *orc_mpileup(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *c
         }
         ++pos;
     }
-    free(act); free(bases.p); free(hps.p); free(reads); free(cigar);
+    free(act); free(bases.p); free(hps.p); free(reads); free(cigar); free(dropped);
     if (out_len) *out_len = (int64_t)out.n;
     return out.p;
 }

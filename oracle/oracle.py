@@ -45,6 +45,9 @@ def lib():
         L.orc_mpileup.restype = C.c_void_p
         L.orc_mpileup.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_int64,
                                   C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+        L.orc_mpileup_d.restype = C.c_void_p
+        L.orc_mpileup_d.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_int64,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
         L.orc_generate_tensor.restype = C.c_void_p
         L.orc_generate_tensor.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_char,
                                           C.c_double, C.c_double, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -71,7 +74,7 @@ def _arr_ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def mpileup(reads, cigar, seq, ctg, beg1, end1, min_mq=5, excl_flags=2316, bed=None, with_hp=False):
+def mpileup(reads, cigar, seq, ctg, beg1, end1, min_mq=5, excl_flags=2316, bed=None, with_hp=False, max_depth=8000):
     """A1: reads -> mpileup text rows (list of str)."""
     reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
     cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
@@ -80,8 +83,8 @@ def mpileup(reads, cigar, seq, ctg, beg1, end1, min_mq=5, excl_flags=2316, bed=N
     if bed is not None:
         bedarr = np.ascontiguousarray(np.asarray(sorted(bed), dtype=np.int32).reshape(-1, 2))
     n = C.c_int64(0)
-    p = lib().orc_mpileup(_arr_ptr(reads), len(reads), _arr_ptr(cigar), _arr_ptr(seq), ctg.encode(), beg1, end1,
-                          min_mq, excl_flags, _arr_ptr(bedarr), 0 if bedarr is None else len(bedarr), int(with_hp), C.byref(n))
+    p = lib().orc_mpileup_d(_arr_ptr(reads), len(reads), _arr_ptr(cigar), _arr_ptr(seq), ctg.encode(), beg1, end1,
+                            min_mq, excl_flags, _arr_ptr(bedarr), 0 if bedarr is None else len(bedarr), int(with_hp), int(max_depth), C.byref(n))
     text = _take_str(p)
     rows = text.split("\n")
     if rows and rows[-1] == "":

@@ -222,3 +222,49 @@ def test_random_cigars_decode_rows_cpp_equals_python_and_regions(eng):
         assert np.array_equal(X1, eng.tensors()) and S1.tobytes() == eng.sites().tobytes() and T1.tobytes() == eng.tokens().tobytes(), (seed, chunks)
     assert n_rows > 1500 and {"0/0", "0/1", "1/1"} <= kinds, (n_rows, kinds)
     eng.set_params()
+
+
+@pytest.mark.parametrize("channels", [18, 30])
+def test_mpileup_depth_cap(eng, channels):
+    """samtools mpileup -d (default 8000, in force in the reference): htslib discards a read that is not the first pushed
+    for its start position while more than max_depth reads are live.  Small caps on replicated random read sets make the
+    rule bite; the discarded reads must vanish from counts, coverage, tokens, haplotype channels and skip counts alike, and
+    per region (a read may survive in one chunk's scan and not in its neighbour's)."""
+    from clair3_rna_amd import capi
+    from clair3_rna_amd.reads import ReadSet
+    n_dropped_cases = 0
+    for seed in range(40):
+        rng = random.Random(4000 + seed)
+        ref, recs = _case(60000 + seed, phased=(channels == 30))
+        rep = rng.randint(3, 7)
+        recs = [dict(r) for r in recs for _ in range(rep)]
+        recs.sort(key=lambda r: r["pos"])
+        rs = ReadSet.from_records(recs)
+        L = len(ref)
+        cap = rng.choice([8, 20, 60, 150])
+        kw = dict(min_coverage=2, max_depth=cap, splice_padding=seed % 2, head_tail=(seed // 2) % 2)
+        eng.params = capi.default_params()
+        eng.set_bed(0, None); eng.set_bed(1, None)
+        eng.set_params(channels=channels, **kw)
+        a = rng.randint(1, L // 3); b = rng.randint(2 * L // 3, L)
+        got = H.engine_chunk(eng, rs, ref, 1, a, b)
+        exp = H.oracle_chunk(rs, ref, 1, a, b, channels=channels, min_coverage=2, max_depth=cap, splice_padding=bool(seed % 2),
+                             head_tail=bool((seed // 2) % 2))
+        nocap = H.oracle_chunk(rs, ref, 1, a, b, channels=channels, min_coverage=2, max_depth=0, splice_padding=bool(seed % 2),
+                               head_tail=bool((seed // 2) % 2))
+        n_dropped_cases += int(exp["lines"] != nocap["lines"])
+        assert got["lines"] == exp["lines"], (seed, cap, H.first_diff(got["lines"], exp["lines"]))
+        assert np.array_equal(got["X"], exp["X"])
+        # the same through a two-region scan (masks are per region)
+        mid = (a + b) // 2
+        eng.begin_batch(); eng.scan(a, mid); eng.scan(mid, b); eng.end_batch()
+        X1, S1 = eng.tensors(), eng.sites()
+        eng.begin_batch(); eng.scan_regions([(a, mid), (mid, b)]); eng.end_batch()
+        assert np.array_equal(X1, eng.tensors()) and S1.tobytes() == eng.sites().tobytes()
+        e1 = H.oracle_chunk(rs, ref, 1, a, mid, channels=channels, min_coverage=2, max_depth=cap, splice_padding=bool(seed % 2), head_tail=bool((seed // 2) % 2))
+        e2 = H.oracle_chunk(rs, ref, 1, mid, b, channels=channels, min_coverage=2, max_depth=cap, splice_padding=bool(seed % 2), head_tail=bool((seed // 2) % 2))
+        assert [int(l.split("\t")[1]) for l in e1["lines"] + e2["lines"]] == S1["pos"].tolist()
+        assert np.array_equal(X1, np.concatenate([e1["X"], e2["X"]])) if len(S1) else True
+    assert n_dropped_cases > 25, n_dropped_cases          # the cap changed the output in most cases
+    eng.params = capi.default_params()
+    eng.set_params()
