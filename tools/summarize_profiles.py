@@ -47,7 +47,7 @@ def main():
         text = open(st[0]).read()
         open(os.path.join(out, "%s_kernel_stats_%s.csv" % (tag, prec)), "w").write(
             "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
-            "--precision %s   (MI355X; durations in ns; two contexts: 1 priming + 1 warm-up + 2 timed passes each)\n" % prec + text)
+            "--no_overlap --precision %s   (MI355X; durations in ns; one context: 1 priming + 1 warm-up + 2 timed passes)\n" % prec + text)
     # 2. PMC
     rows = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
