@@ -2,9 +2,12 @@
 """gpurun_out/prof/<prec>/ (tools/profile_bench.sh) -> profiles/<tag>_kernel_stats_<prec>.csv, <tag>_pmc_<prec>.csv,
 <tag>_bench_<prec>.json and profiles/pmc_traffic.json (per-launch HBM bytes read by bench.py).
 
-HBM bytes = (FETCH_SIZE + WRITE_SIZE) KB * 1024, raw: MI355X_MICROARCH.md notes that FETCH_SIZE under-reports wide coalesced
-streaming reads 2x on gfx950; the calibration for this code (layer 2 must read the y1 hi/lo planes once per direction)
-shows the raw counter is right for its 16-byte-per-lane gathers, so no factor is applied."""
+HBM bytes per launch = (fetch_factor * FETCH_SIZE + WRITE_SIZE) KB * 1024.  MI355X_MICROARCH.md (HBM section): on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 B per lane, global_load and buffer_load..lds
+alike) and has to be doubled; other access patterns and WRITE_SIZE are uncalibrated.  The split-f16 layer-2 kernel streams the
+y1 planes exactly that way (LDS-DMA, 1 KiB contiguous per wave-instruction): fetch_factor = 2 there — 2 x 7.5 GB = 15.0 GB
+against 13.65 GB of algorithmic reads (the planes once per direction) plus the weight/L4 slices that miss L2.  Every other
+kernel is reported raw (fetch_factor = 1) and flagged uncalibrated."""
 import collections
 import csv
 import glob
@@ -58,14 +61,15 @@ def main():
     traffic = {}
     with open(os.path.join(out, "%s_pmc_%s.csv" % (tag, prec)), "w") as f:
         f.write("# rocprofv3 --pmc <set> --kernel-trace, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), same bench command; per-launch averages.\n"
-                "# hbm_bytes = (FETCH_SIZE + WRITE_SIZE) KB * 1024 (raw, see tools/summarize_profiles.py); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+                "# hbm_bytes = (fetch_factor * FETCH_SIZE + WRITE_SIZE) KB * 1024; fetch_factor = 2 for the split-f16 k_lstm2 (wide coalesced streaming reads, MI355X_MICROARCH.md), 1 = raw/uncalibrated elsewhere (tools/summarize_profiles.py); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                 "(1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); clock_GHz needs the kernel duration and is quoted in DESIGN.md.\n")
         f.write("kernel,launches," + ",".join(hdr) + ",hbm_bytes_per_launch,mfma_busy\n")
         for k in sorted(rows):
             r = rows[k]
             vals = [r.get(h, (0.0, 0))[0] for h in hdr]
             n = max(v[1] for v in r.values())
-            hbm = (vals[0] + vals[1]) * 1024
+            ff = 2.0 if (k == "k_lstm2" and prec == "f16x3") else 1.0
+            hbm = (ff * vals[0] + vals[1]) * 1024
             busy = vals[2] / (1024 * vals[3] / 8) if vals[3] else 0.0
             traffic[k] = int(hbm)
             f.write("%s,%d,%s,%d,%.3f\n" % (k, n, ",".join("%.4g" % v for v in vals), hbm, busy))
