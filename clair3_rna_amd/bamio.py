@@ -10,7 +10,7 @@ import numpy as np
 from .reads import READ_DTYPE, ReadSet
 
 EXPORTS = ["c3r_bam_open", "c3r_bam_close", "c3r_bam_last_error", "c3r_bam_n_contigs", "c3r_bam_contig", "c3r_bam_has_index",
-           "c3r_bam_fetch", "c3r_bam_copy", "c3r_bam_index_build"]
+           "c3r_bam_fetch", "c3r_bam_copy", "c3r_bam_index_build", "c3r_vcf_merge", "c3r_vcf_compress"]
 _LIB = None
 
 
@@ -32,6 +32,9 @@ def load_library():
         L.c3r_bam_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64] + [C.POINTER(C.c_int64)] * 3
         L.c3r_bam_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.c3r_bam_index_build.argtypes = [C.c_char_p, C.c_char_p]
+        L.c3r_vcf_merge.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int64,
+                                    C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.c3r_vcf_compress.argtypes = [C.c_char_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -91,3 +94,41 @@ def index_build(bam_path, bai_path=None):
     if rc != 0:
         raise IOError("c3r_bam_index_build(%s) failed with %d (is the file coordinate-sorted?)" % (bam_path, rc))
     return bai_path
+
+
+def vcf_merge(rows, qual=2, show_ref=False, edits=None, want_no_tagging=False):
+    """c3r_vcf_merge on the records of one contig (bytes).  edits: [(pos, ref, alt), ...] REDIportal entries of the contig or
+    None.  -> (merged bytes, merged-without-tagging bytes or None, (n_read, n_kept, n_tagged))."""
+    L = load_library()
+    n_edit = len(edits) if edits else 0
+    if n_edit:
+        edits = sorted(edits)
+        epos = np.ascontiguousarray([e[0] for e in edits], dtype=np.int32)
+        eref = (C.c_char_p * n_edit)(*[e[1].encode() for e in edits])
+        ealt = (C.c_char_p * n_edit)(*[e[2].encode() for e in edits])
+        epos_p = epos.ctypes.data
+    else:
+        eref = ealt = None
+        epos_p = None
+    n, n_nt, counts = C.c_int64(), C.c_int64(), (C.c_int64 * 3)()
+    nt_len = C.byref(n_nt) if want_no_tagging else None
+    out = C.create_string_buffer(len(rows) + 16 * (n_edit + 1) + 64)       # a relabel adds at most 7 bytes to a record
+    out_nt = C.create_string_buffer(len(out)) if want_no_tagging else None
+    rc = L.c3r_vcf_merge(rows, len(rows), int(qual or 0), int(bool(show_ref)), epos_p, eref, ealt, n_edit, out, len(out), C.byref(n),
+                         out_nt, len(out) if want_no_tagging else 0, nt_len, counts)
+    if rc == -6:                                                             # C3R_EOVERFLOW: sizes are known now
+        out = C.create_string_buffer(n.value + 1)
+        out_nt = C.create_string_buffer(n_nt.value + 1) if want_no_tagging else None
+        rc = L.c3r_vcf_merge(rows, len(rows), int(qual or 0), int(bool(show_ref)), epos_p, eref, ealt, n_edit, out, len(out), C.byref(n),
+                             out_nt, len(out_nt) if want_no_tagging else 0, nt_len, counts)
+    if rc != 0:
+        raise IOError("c3r_vcf_merge failed with %d (malformed VCF record?)" % rc)
+    return out.raw[:n.value], (out_nt.raw[:n_nt.value] if want_no_tagging else None), tuple(counts)
+
+
+def vcf_compress(path, threads=0):
+    """bgzip + tabix: <path> -> <path>.gz + <path>.gz.tbi, <path> removed."""
+    rc = load_library().c3r_vcf_compress(os.fsencode(path), threads)
+    if rc != 0:
+        raise IOError("c3r_vcf_compress(%s) failed with %d" % (path, rc))
+    return path + ".gz"

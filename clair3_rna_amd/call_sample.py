@@ -1,0 +1,352 @@
+"""Whole-sample pileup calling in ONE process: STEP 1 + STEP 2 of run_clair3_rna without the per-chunk processes and files.
+
+The reference runs `parallel ... clair3_rna.py call_var_bam ... :::: tmp/CHUNK_LIST` (run_clair3_rna:678-708: one Python +
+pypy + samtools process group per (contig, chunk_id, chunk_num) row, each writing tmp/pileup_output/pileup_{ctg}_{chunk}.vcf)
+and then `sort_vcf` over that directory (run_clair3_rna:710-726).  Here the same CHUNK_LIST (contig selection and chunk
+counts of run_clair3_rna:310-449) is walked contig by contig: all chunks of a contig go through the tensor build in one
+c3r_pileup_scan_regions call and through the network as one batch, the rows are decoded by libc3r's host threads and merged
+in memory by sort_vcf.SampleMerger.  The result — `<output_dir>/<output_prefix>.vcf.gz` (+ .tbi, + `_no_tagging`) — is
+byte-identical to running call_var_bam per CHUNK_LIST row and merging with sort_vcf (tests/test_gpu_sample.py).
+
+One thing is pinned that the reference leaves open.  Adjacent chunks overlap by the 33 bp halo; the seam position itself is
+emitted by both, and with head/tail calling both also emit the candidates inside the halo — from different windows (one
+chunk's stream ends there, the other's begins).  sort_vcf keeps the row of whichever per-chunk file os.listdir returns last
+(src/sort_vcf.py:204-236), i.e. an arbitrary one.  Here the LATER chunk's row is kept, always.
+
+Three host stages overlap on threads (the GIL is released inside libc3r / libc3r_io):
+    fetch   BAM region fetch + reference slice of contig i+1, i+2      (libc3r_io.so, FASTA read)
+    device  load / scan / network of contig i                          (libc3r.so, one of two contexts)
+    decode  alt_info + genotype decode + row text of contig i-1        (libc3r.so host threads)
+
+Not covered (use the reference's own orchestration around call_var_bam for these): whatshap/longphase phasing between the
+two passes (external tools), gVCF.  `--enable_phasing_model` here expects an already haplotagged BAM (HP tags) and runs the
+30-channel pass only — the second half of run_clair3_rna:729-852.
+
+    python -m clair3_rna_amd.call_sample --bam_fn x.bam --ref_fn ref.fa --pileup_model_path W --output_dir out
+"""
+import argparse
+import os
+import sys
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from time import time
+
+from . import io, sort_vcf, vcf
+from .call_var_bam import existing, resolve_region
+
+MAJOR_CONTIGS_ORDER = ["chr" + str(a) for a in list(range(1, 23)) + ["X", "Y"]] + [str(a) for a in list(range(1, 23)) + ["X", "Y"]]
+CHUNK_SIZE = 5000000            # shared/param_p.py:91
+EXPAND = 33                     # param.no_of_positions: split_extend_bed widens every interval by one window
+
+
+def _bed_contigs(bed_fn):
+    names = []
+    with io._open_text(bed_fn) as f:
+        for row in f:
+            if row.strip() and row[0] != "#":
+                c = row.split()[0]
+                if c not in names:
+                    names.append(c)
+    return names
+
+
+def _vcf_contigs(vcf_fn):
+    names = set()
+    with io._open_text(vcf_fn) as f:
+        for row in f:
+            if row[0] != "#":
+                names.add(row.split(None, 1)[0])
+    return names
+
+
+def plan_chunks(ref_fn, ctg_name=None, include_all_ctgs=False, bed_fn=None, vcf_fn=None, chunk_size=CHUNK_SIZE, chunk_num=None):
+    """-> ([contig, ...] in calling order, {contig: chunk_num}): run_clair3_rna:310-389 + :441-449 (CHUNK_LIST)."""
+    listed = set(ctg_name.split(",")) if ctg_name else None
+    in_bed = set(_bed_contigs(bed_fn)) if bed_fn else None
+    in_vcf = _vcf_contigs(vcf_fn) if vcf_fn else None
+    contig_set = set(listed) if listed else set()
+    if listed:
+        if in_bed is not None:
+            contig_set &= in_bed
+        if in_vcf is not None:
+            contig_set &= in_vcf
+    else:
+        if in_bed is not None:
+            contig_set |= in_bed
+        if in_vcf is not None:
+            contig_set |= in_vcf
+    restricted = bool(in_bed is not None or listed or in_vcf is not None)
+    chunks = {}
+    for name, length, _o, _b, _w in io.read_fai(ref_fn):
+        if not include_all_ctgs and not restricted and name not in MAJOR_CONTIGS_ORDER:
+            continue
+        if in_bed is not None and name not in in_bed:
+            continue
+        if (listed or in_vcf is not None) and name not in contig_set:
+            continue
+        contig_set.add(name)
+        n = length // chunk_size + 1 if length % chunk_size else length // chunk_size
+        chunks[name] = chunk_num if chunk_num else max(n, 1)
+    order = MAJOR_CONTIGS_ORDER + sorted(contig_set - set(MAJOR_CONTIGS_ORDER))
+    contigs = sorted((c for c in contig_set if c in chunks), key=order.index)
+    return contigs, chunks
+
+
+def split_extend_bed(bed_fn, out_dir, contig_set):
+    """run_clair3_rna:268-296: per-contig BED files with every interval widened by 33 bp on both sides."""
+    per = {}
+    with io._open_text(bed_fn) as f:
+        for i, row in enumerate(f):
+            if not row.strip() or row[0] == "#":
+                continue
+            c = row.strip().split()
+            if contig_set and c[0] not in contig_set:
+                continue
+            s, e = int(c[1]), int(c[2])
+            if e < s or s < 0 or e < 0:
+                sys.exit("[ERROR] Invalid BED input at the %d-th row %s %d %d" % (i + 1, c[0], s, e))
+            per.setdefault(c[0], []).append("%s %d %d" % (c[0], max(0, s - EXPAND), max(0, e + EXPAND)))
+    os.makedirs(out_dir, exist_ok=True)
+    for name, rows in per.items():
+        with open(os.path.join(out_dir, name), "w") as f:
+            f.write("\n".join(rows))
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Clair3-RNA pileup calling of a whole sample on MI355X (in-process STEP 1 + STEP 2 of run_clair3_rna)")
+    a = p.add_argument
+    a("-b", "--bam_fn", type=str, required=True)
+    a("-f", "--ref_fn", type=str, required=True)
+    a("-o", "--output_dir", type=str, required=True)
+    a("-p", "--platform", type=str, default="ont")
+    a("--pileup_model_path", type=str, required=True, help="checkpoint prefix (…/variables), as passed to call_var_bam --chkpnt_fn")
+    a("--phased_pileup_model_path", type=str, default=None)
+    a("--enable_phasing_model", action="store_true", help="30-channel pass on an already haplotagged BAM")
+    a("-c", "--ctg_name", type=str, default=None)
+    a("--bed_fn", type=str, default=None)
+    a("--genotyping_mode_vcf_fn", type=str, default=None)
+    a("-q", "--qual", type=int, default=None)
+    a("--snp_min_af", type=float, default=0.08)
+    a("--indel_min_af", type=float, default=0.15)
+    a("--min_coverage", type=int, default=4)
+    a("--min_mq", type=int, default=5)
+    a("--chunk_size", type=int, default=CHUNK_SIZE)
+    a("--chunk_num", type=int, default=None)
+    a("-s", "--sample_name", type=str, default="SAMPLE")
+    a("--output_prefix", type=str, default="output")
+    a("--include_all_ctgs", action="store_true")
+    a("--print_ref_calls", action="store_true")
+    a("--enable_variant_calling_at_sequence_head_and_tail", action="store_true")
+    a("--enable_padding_in_splice_junction_regions", action="store_true")
+    a("--tag_variant_using_readiportal", action="store_true")
+    a("--readiportal_source_fn", type=str, default=None)
+    a("--readiportal_database_filter_tag", type=str, default=None)
+    a("--no_compress", action="store_true", help="leave <prefix>.vcf uncompressed (tests)")
+    a("--gpu_id", type=int, default=int(os.environ.get("C3R_DEVICE", "0")))
+    a("--fetch_threads", type=int, default=4)
+    return p
+
+
+class _Fetcher(object):
+    """Stage 1: whole-contig read fetch + reference slice, one BAM handle per worker thread."""
+
+    def __init__(self, bam_fn, ref_fn):
+        self.bam_fn, self.ref_fn, self.tls = bam_fn, ref_fn, threading.local()
+        self.handles = []
+
+    def __call__(self, ctg, length):
+        t0 = time()
+        if self.bam_fn.endswith(".npz"):
+            rs = io.load_reads(self.bam_fn, ctg)
+        else:
+            from . import bamio
+            bf = getattr(self.tls, "bf", None)
+            if bf is None:
+                bf = self.tls.bf = bamio.BamFile(self.bam_fn)
+                self.handles.append(bf)
+            rs = bf.fetch(ctg)
+        ref = io.fetch_reference(self.ref_fn, ctg, 1, length) if len(rs.reads) else ""
+        return rs, ref, time() - t0
+
+    def close(self):
+        for bf in self.handles:
+            bf.close()
+
+
+def Run(args, log=None):
+    from . import capi
+    log = log or (lambda m: print(m, file=sys.stderr))
+    t_all = time()
+    for need in (args.bam_fn, args.ref_fn):
+        if not os.path.isfile(need):
+            sys.exit("[ERROR] file %s not found" % need)
+    bed_fn, vcf_fn = existing(args.bed_fn), existing(args.genotyping_mode_vcf_fn)
+    channels = 30 if args.enable_phasing_model else 18
+    model = args.phased_pileup_model_path if args.enable_phasing_model else args.pileup_model_path
+    if model is None:
+        sys.exit("[ERROR] --phased_pileup_model_path is required with --enable_phasing_model")
+    out_dir = args.output_dir
+    os.makedirs(os.path.join(out_dir, "tmp"), exist_ok=True)
+    suffix = "_enable_phasing" if args.enable_phasing_model else ""
+    out_fn = os.path.join(out_dir, args.output_prefix + suffix + ".vcf")
+    out_nt_fn = os.path.join(out_dir, args.output_prefix + "_no_tagging" + suffix + ".vcf")
+
+    contigs, chunk_nums = plan_chunks(args.ref_fn, args.ctg_name, args.include_all_ctgs, bed_fn, vcf_fn, args.chunk_size, args.chunk_num)
+    if not contigs:
+        log("[WARNING] Exit calling because no contig was found in BAM!")
+        return 0
+    fai = {n: L for n, L, _o, _b, _w in io.read_fai(args.ref_fn)}
+    split_dir = os.path.join(out_dir, "tmp", "split_beds")
+    if bed_fn:
+        split_extend_bed(bed_fn, split_dir, set(contigs))
+    cmd_fn = os.path.join(out_dir, "tmp", "CMD")                        # run_clair3_rna:613-667: stamped into the VCF header
+    if not os.path.exists(cmd_fn):
+        with open(cmd_fn, "w") as f:
+            f.write(" ".join(sys.argv) + "\n")
+    with open(os.path.join(out_dir, "tmp", "CHUNK_LIST"), "w") as f:
+        for c in contigs:
+            for k in range(1, chunk_nums[c] + 1):
+                f.write("%s %d %d\n" % (c, k, chunk_nums[c]))
+
+    table = None
+    if args.tag_variant_using_readiportal:
+        src = args.readiportal_source_fn
+        if src is None or src.upper() == "NONE" or not os.path.exists(src):
+            log("[WARNING] Enabled tagging variant using readiportal, but --readiportal_source_fn %s file not found, skip tagging!" % src)
+            table = {}
+        else:
+            tags = set(args.readiportal_database_filter_tag.split(":")) if args.readiportal_database_filter_tag is not None else None
+            table = sort_vcf.load_rediportal(src, contigs, tags)
+
+    weights = io.load_weights(model, channels)
+    engines = [capi.Engine(args.gpu_id) for _ in range(2)]
+    for e in engines:
+        e.load_weights(weights, channels)
+    qual_rows = args.qual if args.qual is not None else 2              # call_variants.py:1827 (STEP 1 never passes --qual)
+    qual_merge = args.qual if args.qual is not None else 2             # sort_vcf's own default
+    header = vcf.header(args.ref_fn, cmd_fn, args.sample_name) + "\n"
+    merger = sort_vcf.SampleMerger(out_fn, header, qual_merge, args.print_ref_calls, table, out_nt_fn)
+
+    def device_stage(eng, ctg, rs, ref):
+        """-> number of candidates left resident in `eng` (rows are produced by decode_stage)."""
+        extend_bed = existing(os.path.join(split_dir, ctg)) if bed_fn else None
+        regions, site_sets, ext_iv = [], [], []
+        for k in range(1, chunk_nums[ctg] + 1):
+            a, b, sites, ext_iv = resolve_region(fai[ctg], ctg, k, chunk_nums[ctg], None, None, bed_fn, extend_bed, vcf_fn)
+            if sites is not None and not sites:
+                continue
+            regions.append((a, b))
+            site_sets.append(sites)
+        if not regions:
+            return 0
+        eng.params = capi.default_params()
+        eng.set_bed(0, ext_iv if extend_bed else None)
+        eng.set_bed(1, io.read_bed(bed_fn, ctg)[0] if bed_fn else None)
+        eng.set_params(channels=channels, min_mq=args.min_mq, min_coverage=args.min_coverage, snp_min_af=args.snp_min_af,
+                       indel_min_af=args.indel_min_af, head_tail=int(args.enable_variant_calling_at_sequence_head_and_tail),
+                       splice_padding=int(args.enable_padding_in_splice_junction_regions), genotyping_mode=int(vcf_fn is not None))
+        t = [time()]
+        eng.load_reads(rs); t.append(time())
+        eng.set_reference(1, ref); t.append(time())
+        if vcf_fn is None:
+            eng.begin_batch()
+            n = eng.scan_regions(regions)
+            eng.end_batch()
+            n = eng.n_candidates
+            t.append(time())
+            if n:
+                eng.infer(fetch=False)
+            t.append(time())
+            if os.environ.get("C3R_TIMING"):
+                log("[device_stage %s] load_reads %.0f ms, set_reference %.0f ms, scan %.0f ms, infer launch %.0f ms (%d reads, %d sites)"
+                    % (ctg, 1e3 * (t[1] - t[0]), 1e3 * (t[2] - t[1]), 1e3 * (t[3] - t[2]), 1e3 * (t[4] - t[3]), len(rs.reads), n))
+            return n
+        return [(r, s) for r, s in zip(regions, site_sets)]            # genotyping mode: one scan per chunk (its own site list)
+
+    def decode_stage(eng, ctg, todo):
+        if isinstance(todo, list):
+            rows = b""
+            for (a, b), sites in todo:
+                eng.set_sites(sites)
+                if eng.scan(a, b):
+                    eng.infer(fetch=False)
+                    rows += eng.call_rows_text(ctg, qual=qual_rows, show_ref=args.print_ref_calls)[0]
+            return rows
+        rows = eng.call_rows_text(ctg, qual=qual_rows, show_ref=args.print_ref_calls)[0] if todo else b""
+        dump = getattr(args, "debug_dump", None)
+        if dump is not None and todo:                                  # tests / debugging: what the rows were made from
+            dump[ctg] = dict(sites=eng.sites(), tokens=eng.tokens(), probs=eng.fetch_probs(todo), tensors=eng.tensors(), rows=rows)
+        return rows
+
+    def decode_and_merge(eng, ctg, todo):
+        rows = decode_stage(eng, ctg, todo)
+        t0 = time()
+        merger.add_contig(ctg, rows)          # one decode worker => contigs reach the merger in calling order
+        return time() - t0
+
+    fetcher = _Fetcher(args.bam_fn, args.ref_fn)
+    t_setup = time() - t_all
+    n_sites = 0
+    t_fetch = t_dev = 0.0
+    with ThreadPoolExecutor(max(1, args.fetch_threads)) as fetch_pool, ThreadPoolExecutor(1) as decode_pool:
+        fetched = [fetch_pool.submit(fetcher, c, fai[c]) for c in contigs]
+        pending = [None, None]                                         # decode future of each engine
+        results = []
+        for i, ctg in enumerate(contigs):
+            rs, ref, dt = fetched[i].result()
+            fetched[i] = None
+            t_fetch += dt
+            if not len(rs.reads):
+                log("[WARNING] Contig name %s provided but no mapped reads found in BAM, skip!" % ctg)
+                continue
+            eng = engines[i & 1]
+            if pending[i & 1] is not None:
+                pending[i & 1].result()                                # the context is reused: its previous decode must be done
+            t0 = time()
+            todo = device_stage(eng, ctg, rs, ref)
+            t_dev += time() - t0
+            n_sites += todo if isinstance(todo, int) else 0
+            fut = decode_pool.submit(decode_and_merge, eng, ctg, todo)
+            pending[i & 1] = fut
+            results.append((ctg, fut))
+        t_merge = sum(fut.result() for _c, fut in results)
+    fetcher.close()
+    n_read, n_kept, n_tag = merger.close(log)
+    # tmp/CONTIGS and tmp/CHUNK_LIST as run_clair3_rna leaves them (:436-449): contigs without reads are dropped by its
+    # `samtools idxstats` check (:184-210) before they are written; here that is known once the contig has been fetched
+    called = [c for c, _f in results]
+    with open(os.path.join(out_dir, "tmp", "CONTIGS"), "w") as f:
+        f.write("\n".join(called))
+    with open(os.path.join(out_dir, "tmp", "CHUNK_LIST"), "w") as f:
+        for c in called:
+            for k in range(1, chunk_nums[c] + 1):
+                f.write("%s %d %d\n" % (c, k, chunk_nums[c]))
+    t0 = time()
+    if not args.no_compress:
+        sort_vcf.compress_vcf(out_fn)
+        if table is not None and n_kept:
+            sort_vcf.compress_vcf(out_nt_fn)
+    if table is not None:
+        log("[INFO] Dataset size:%d, total variants tagged by REDIportal dataset: %d" % (len(table), n_tag))
+    for e in engines:
+        e.close()
+    log("[INFO] %d contigs, %d candidate sites, %d records written to %s%s" % (len(contigs), n_sites, n_kept, out_fn, "" if args.no_compress else ".gz"))
+    t_gz = time() - t0
+    log("[INFO] set-up %.2f s, fetch %.2f s (overlapped), device stage %.2f s, merge %.2f s, bgzip+tabix %.2f s, total %.2f s"
+        % (t_setup, t_fetch, t_dev, t_merge, t_gz, time() - t_all))
+    return 0
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    try:
+        return Run(args)
+    except SystemExit:
+        raise
+    except Exception as e:       # fail loudly: there is no CPU fallback
+        print("[ERROR] call_sample (MI355X path) failed: %s" % e, file=sys.stderr)
+        return 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -51,6 +51,30 @@ def chunk_region(contig_len, chunk_id, chunk_num, bed_start=None, bed_end=None):
     return start, start + size
 
 
+def resolve_region(contig_len, ctg, chunk_id, chunk_num, ctg_start=None, ctg_end=None, bed_fn=None, extend_bed=None, vcf_fn=None):
+    """(ctg_start, ctg_end, sites or None, extend-BED intervals) of one CHUNK_LIST row, 1-based inclusive, exactly as
+    src/create_tensor_pileup.py:375-422 derives them; `sites` == [] means the chunk holds no known site (nothing to do)."""
+    ext_iv, bed_start, bed_end = (io.read_bed(extend_bed, ctg) if extend_bed else ([], None, None))
+    sites = None
+    if bed_fn is None and chunk_id is not None:
+        ctg_start, ctg_end = chunk_region(contig_len, chunk_id, chunk_num)
+    if bed_fn is not None and chunk_id is not None:
+        if bed_start is None:
+            sys.exit("[ERROR] ctg_name %s not exists in bed file(%s)." % (ctg, bed_fn))
+        ctg_start, ctg_end = chunk_region(0, chunk_id, chunk_num, bed_start, bed_end)
+    if vcf_fn is not None and chunk_id is not None:
+        all_sites = io.read_vcf_sites(vcf_fn, ctg)
+        n = len(all_sites)
+        size = n // chunk_num if n % chunk_num == 0 else n // chunk_num + 1
+        sites = all_sites[(chunk_id - 1) * size:(chunk_id - 1) * size + size]
+        if not sites:
+            return ctg_start, ctg_end, sites, ext_iv
+        ctg_start, ctg_end = min(sites), max(sites)
+    if ctg_start is None or ctg_end is None:
+        ctg_start, ctg_end = 1, contig_len
+    return ctg_start, ctg_end, sites, ext_iv
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="Clair3-RNA per-chunk pileup calling on MI355X (drop-in for call_var_bam)")
     a = p.add_argument
@@ -124,25 +148,10 @@ def Run(args, engine=None):
     fai = {n: L for n, L, _o, _b, _w in io.read_fai(args.ref_fn)}
 
     # ---- A4: chunk -> coordinates (src/create_tensor_pileup.py:375-422)
-    ctg_start, ctg_end = args.ctgStart, args.ctgEnd
-    ext_iv, bed_start, bed_end = (io.read_bed(extend_bed, ctg) if extend_bed else ([], None, None))
-    sites = None
-    if bed_fn is None and args.chunk_id is not None:
-        ctg_start, ctg_end = chunk_region(fai.get(ctg, 0), args.chunk_id, args.chunk_num)
-    if bed_fn is not None and args.chunk_id is not None:
-        if bed_start is None:
-            sys.exit("[ERROR] ctg_name %s not exists in bed file(%s)." % (ctg, bed_fn))
-        ctg_start, ctg_end = chunk_region(0, args.chunk_id, args.chunk_num, bed_start, bed_end)
-    if vcf_fn is not None and args.chunk_id is not None:
-        all_sites = io.read_vcf_sites(vcf_fn, ctg)
-        n = len(all_sites)
-        size = n // args.chunk_num if n % args.chunk_num == 0 else n // args.chunk_num + 1
-        sites = all_sites[(args.chunk_id - 1) * size:(args.chunk_id - 1) * size + size]
-        if not sites:
-            return 0
-        ctg_start, ctg_end = min(sites), max(sites)
-    if ctg_start is None or ctg_end is None:
-        ctg_start, ctg_end = 1, fai.get(ctg, 0)
+    ctg_start, ctg_end, sites, ext_iv = resolve_region(fai.get(ctg, 0), ctg, args.chunk_id, args.chunk_num, args.ctgStart, args.ctgEnd,
+                                                       bed_fn, extend_bed, vcf_fn)
+    if sites is not None and not sites:
+        return 0
     extend_start, extend_end = max(1, ctg_start - 33), ctg_end + 33
     ref_start = max(1, ctg_start - 1000)
     ref_seq = io.fetch_reference(args.ref_fn, ctg, ref_start, ctg_end + 1000)

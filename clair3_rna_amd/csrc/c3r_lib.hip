@@ -105,12 +105,20 @@ int fail(c3r_ctx *ctx, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, C3R_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// Debug aid (tests/test_gpu_poison.py): C3R_POISON=<byte> fills every fresh device allocation with that byte, so that a
+// kernel reading memory nobody wrote shows up as a parity failure instead of depending on what the allocator handed out.
+inline int poison_byte() {
+    static const int v = [] { const char *e = getenv("C3R_POISON"); return e && *e ? atoi(e) & 0xff : -1; }();
+    return v;
+}
+
 int ensure(c3r_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return C3R_OK;
     size_t want = std::max(bytes, (size_t)256);
     want = want + want / 4;   // grow-only with slack so steady-state steps never reallocate
     if (b.p) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     HIPCHK(ctx, hipMalloc(&b.p, want));
+    if (poison_byte() >= 0) { HIPCHK(ctx, hipMemsetAsync(b.p, poison_byte(), want, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
     b.cap = want;
     return C3R_OK;
 }
@@ -122,6 +130,7 @@ int ensure_keep(c3r_ctx *ctx, DevBuf &b, size_t bytes, size_t used) {
     size_t want = bytes + bytes / 2;
     void *np_ = nullptr;
     HIPCHK(ctx, hipMalloc(&np_, want));
+    if (poison_byte() >= 0) HIPCHK(ctx, hipMemsetAsync(np_, poison_byte(), want, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(np_, b.p, used, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipFree(b.p));

@@ -1170,14 +1170,20 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
 
 inline int net_reserve(NetState &s, int64_t n, hipStream_t st, std::string &err) {
     const int64_t need = (n + 127) / 128 * 128;    // the y1 planes are stored with the site stride rounded up to 128
-    if (need <= s.cap_sites) return C3R_OK;
-    const int64_t cap = need + need / 4 + 256;
+    const bool want_y2 = s.precision != 1;         // split-f16 fuses L4 into layer 2: y2 (42 KB per site) is never materialised
+    if (need <= s.cap_sites && (!want_y2 || s.d_y2)) return C3R_OK;
+    const bool grow = need > s.cap_sites;
+    const int64_t cap = grow ? need + need / 4 + 256 : s.cap_sites;
     NET_HIP(hipStreamSynchronize(st));
     float **bufs[] = {&s.d_y1, &s.d_y2, &s.d_a4, &s.d_probs};
     const size_t sizes[] = {(size_t)cap * NET_T * 2 * NET_H1, (size_t)cap * NET_T * 2 * NET_H2, (size_t)cap * NET_L4 * 2, (size_t)cap * C3R_NPROB};
     for (int i = 0; i < 4; ++i) {
+        const bool is_y2 = i == 1;
+        if (!grow && !is_y2) continue;                                   // only y2 is missing (precision switched to fp32)
         if (*bufs[i]) { (void)hipFree(*bufs[i]); *bufs[i] = nullptr; }
+        if (is_y2 && !want_y2) continue;
         NET_HIP(hipMalloc((void **)bufs[i], sizes[i] * sizeof(float)));
+        if (const char *e = getenv("C3R_POISON")) if (*e) { NET_HIP(hipMemsetAsync(*bufs[i], atoi(e) & 0xff, sizes[i] * sizeof(float), st)); NET_HIP(hipStreamSynchronize(st)); }
     }
     s.cap_sites = cap;
     return C3R_OK;

@@ -1,0 +1,301 @@
+// vcfio.cpp — output side of libc3r_io.so: the merge step and the compressed, indexed VCF (include/c3r_io.h).
+//
+//   c3r_vcf_merge     rows of one contig, as its chunks produced them -> the records `sort_vcf` writes for that contig
+//                     (src/sort_vcf.py:190-262: RefCall rows dropped unless --show_ref, QUAL <= --qual relabelled LowQual,
+//                     REDIportal tagging, duplicate positions last-one-wins, sorted by position)
+//   c3r_vcf_compress  `bgzip -f` + `tabix -f -p vcf` (src/sort_vcf.py:70-75): BGZF blocks deflated on threads + TBI v1 index
+//
+// Host-only C++ (zlib).  clair3_rna_amd/sort_vcf.py holds the same two steps in Python; they are the checkers: the merge is
+// pinned on golden G6 (outputs of the reference's sort_vcf), and the compressor must reproduce the Python writer's bytes
+// (tests/test_sort_vcf.py).
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/c3r_io.h"
+
+#define C3R_OK 0
+#define C3R_EINVAL (-1)
+#define C3R_EOVERFLOW (-6)
+
+namespace {
+
+struct Field { const char *p; size_t n; };
+
+// Python str.split(None, maxsplit) on one line without its newline: runs of blanks separate, leading blanks skipped.
+inline int split_ws(const char *s, size_t n, Field *f, int max_fields) {
+    size_t i = 0; int k = 0;
+    auto blank = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\f' || c == '\v' || c == '\n'; };
+    while (k < max_fields) {
+        while (i < n && blank(s[i])) ++i;
+        if (i >= n) break;
+        const size_t b = i;
+        if (k == max_fields - 1) { f[k++] = Field{s + b, n - b}; break; }     // the rest (Python keeps it unsplit)
+        while (i < n && !blank(s[i])) ++i;
+        f[k++] = Field{s + b, i - b};
+    }
+    return k;
+}
+
+inline bool contains(const char *s, size_t n, const char *pat) {
+    const size_t m = strlen(pat);
+    if (m > n) return false;
+    for (size_t i = 0; i + m <= n; ++i) if (!memcmp(s + i, pat, m)) return true;
+    return false;
+}
+
+// row.split("\t")[k] spans; returns the number of tab-separated fields found (up to max)
+inline int split_tabs(const char *s, size_t n, Field *f, int max_fields) {
+    int k = 0; size_t b = 0;
+    for (size_t i = 0; i <= n && k < max_fields; ++i) {
+        if (i == n || s[i] == '\t') { f[k++] = Field{s + b, i - b}; b = i + 1; }
+    }
+    return k;
+}
+
+struct Kept { int32_t pos; uint32_t order; std::string row; };
+
+void replace_all(std::string &s, const char *from, const char *to) {
+    const size_t lf = strlen(from), lt = strlen(to);
+    for (size_t p = s.find(from); p != std::string::npos; p = s.find(from, p + lt)) s.replace(p, lf, to);
+}
+
+}  // namespace
+
+extern "C" {
+
+int c3r_vcf_merge(const char *rows, int64_t n_bytes, int qual, int show_ref, const int32_t *edit_pos, const char *const *edit_ref,
+                  const char *const *edit_alt, int64_t n_edit, char *out, int64_t cap, int64_t *out_len, char *out_nt, int64_t cap_nt,
+                  int64_t *out_nt_len, int64_t *counts) {
+    if (n_bytes < 0 || (n_bytes && !rows) || !out_len || (n_edit && (!edit_pos || !edit_ref || !edit_alt))) return C3R_EINVAL;
+    int64_t n_read = 0, n_kept = 0, n_tag = 0;
+    std::vector<Kept> kept;
+    const char *p = rows, *end = rows + n_bytes;
+    uint32_t order = 0;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;                 // the line without '\n'
+        const size_t ln = (size_t)(le - p);
+        const char *next = nl ? nl + 1 : end;
+        if (ln == 0) { p = next; continue; }
+        ++n_read;
+        Field c[7];
+        if (split_ws(p, ln, c, 7) < 6) return C3R_EINVAL;
+        const int32_t pos = (int32_t)strtol(std::string(c[1].p, c[1].n).c_str(), nullptr, 10);
+        const double q = strtod(std::string(c[5].p, c[5].n).c_str(), nullptr);
+        const bool is_ref = (c[4].n == 1 && c[4].p[0] == '.') || (c[3].n == c[4].n && !memcmp(c[3].p, c[4].p, c[3].n));
+        p = next;
+        if (is_ref && !show_ref) continue;
+        std::string row(le - ln, ln);
+        row += '\n';
+        if (!is_ref && qual && q <= (double)qual) {     // _relabel: row.split("\t")[6] = "LowQual"
+            Field f[8];
+            if (split_tabs(row.data(), row.size(), f, 8) >= 7) row.replace((size_t)(f[6].p - row.data()), f[6].n, "LowQual");
+        }
+        if (n_edit) {
+            const int32_t *e = std::lower_bound(edit_pos, edit_pos + n_edit, pos);
+            if (e != edit_pos + n_edit && *e == pos && !contains(row.data(), row.size(), "Germline") &&
+                !contains(row.data(), row.size(), "RefCall")) {
+                const int64_t k = e - edit_pos;
+                Field f[9];
+                if (split_tabs(row.data(), row.size(), f, 9) >= 7 && f[3].n == strlen(edit_ref[k]) && !memcmp(f[3].p, edit_ref[k], f[3].n) &&
+                    f[4].n == strlen(edit_alt[k]) && !memcmp(f[4].p, edit_alt[k], f[4].n)) {
+                    row.replace((size_t)(f[6].p - row.data()), f[6].n, "RNAEditing");
+                    ++n_tag;
+                }
+            }
+        }
+        kept.push_back(Kept{pos, order++, std::move(row)});
+        ++n_kept;                                       // (the reference counts overwritten duplicates as kept, too)
+    }
+    // by_pos[pos] = row: the last row of a position wins; output sorted by position
+    std::stable_sort(kept.begin(), kept.end(), [](const Kept &a, const Kept &b) { return a.pos < b.pos; });
+    size_t total = 0, total_nt = 0;
+    std::vector<const Kept *> outv;
+    for (size_t i = 0; i < kept.size(); ++i) {
+        if (i + 1 < kept.size() && kept[i + 1].pos == kept[i].pos) continue;
+        outv.push_back(&kept[i]);
+        total += kept[i].row.size();
+    }
+    *out_len = (int64_t)total;
+    if (counts) { counts[0] = n_read; counts[1] = n_kept; counts[2] = n_tag; }
+    std::string nt;
+    if (out_nt_len) {
+        for (const Kept *k : outv) {
+            if (k->row.find("RNAEditing") != std::string::npos) { std::string r = k->row; replace_all(r, "RNAEditing", "PASS"); nt += r; }
+            else nt += k->row;
+        }
+        total_nt = nt.size();
+        *out_nt_len = (int64_t)total_nt;
+    }
+    if (!out || cap < (int64_t)total || (out_nt_len && (!out_nt || cap_nt < (int64_t)total_nt))) return C3R_EOVERFLOW;
+    char *o = out;
+    for (const Kept *k : outv) { memcpy(o, k->row.data(), k->row.size()); o += k->row.size(); }
+    if (out_nt_len) memcpy(out_nt, nt.data(), nt.size());
+    return C3R_OK;
+}
+
+}  // extern "C"
+
+namespace {
+const uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+const size_t BLK = 0xff00;
+
+bool deflate_block(const uint8_t *src, size_t n, std::vector<uint8_t> &dst) {
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    std::vector<uint8_t> body(deflateBound(&zs, (uLong)n) + 16);
+    zs.next_in = const_cast<Bytef *>(src); zs.avail_in = (uInt)n;
+    zs.next_out = body.data(); zs.avail_out = (uInt)body.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = body.size() - zs.avail_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || clen + 26 > 0x10000) return false;
+    static const uint8_t head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0};
+    dst.assign(head, head + 16);
+    const uint16_t bsize = (uint16_t)(clen + 25);
+    dst.push_back((uint8_t)(bsize & 0xff)); dst.push_back((uint8_t)(bsize >> 8));
+    dst.insert(dst.end(), body.begin(), body.begin() + (long)clen);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n), isz = (uint32_t)n;
+    for (int k = 0; k < 4; ++k) dst.push_back((uint8_t)(crc >> (8 * k)));
+    for (int k = 0; k < 4; ++k) dst.push_back((uint8_t)(isz >> (8 * k)));
+    return true;
+}
+
+// data -> BGZF (blocks of 0xff00 bytes, deflated on `threads` threads) in `out`; coffs[i] = file offset of block i
+bool bgzf_compress(const uint8_t *data, size_t n, int threads, std::vector<uint8_t> &out, std::vector<uint64_t> &coffs) {
+    const size_t nb = (n + BLK - 1) / BLK;
+    std::vector<std::vector<uint8_t>> blocks(nb);
+    std::atomic<size_t> next(0);
+    std::atomic<bool> bad(false);
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= nb) break;
+            if (!deflate_block(data + i * BLK, std::min(BLK, n - i * BLK), blocks[i])) bad = true;
+        }
+    };
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), nb));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad) return false;
+    coffs.resize(nb);
+    size_t total = 0;
+    for (size_t i = 0; i < nb; ++i) { coffs[i] = total; total += blocks[i].size(); }
+    out.resize(total);
+    for (size_t i = 0; i < nb; ++i) memcpy(out.data() + coffs[i], blocks[i].data(), blocks[i].size());
+    return true;
+}
+
+inline int reg2bin_vcf(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+bool write_file(const std::string &path, const uint8_t *a, size_t na, const uint8_t *b, size_t nb) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    bool ok = (na == 0 || fwrite(a, 1, na, f) == na) && (nb == 0 || fwrite(b, 1, nb, f) == nb);
+    ok = (fclose(f) == 0) && ok;
+    return ok;
+}
+
+template <typename T> void put(std::vector<uint8_t> &v, T x) { const uint8_t *p = (const uint8_t *)&x; v.insert(v.end(), p, p + sizeof(T)); }
+}  // namespace
+
+extern "C" {
+
+int c3r_vcf_compress(const char *path, int threads) {
+    if (!path) return C3R_EINVAL;
+    FILE *f = fopen(path, "rb");
+    if (!f) return C3R_EINVAL;
+    std::vector<uint8_t> data;
+    {
+        uint8_t buf[1 << 16]; size_t k;
+        while ((k = fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + k);
+        fclose(f);
+    }
+    if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<uint8_t> gz; std::vector<uint64_t> coffs;
+    if (!bgzf_compress(data.data(), data.size(), threads, gz, coffs)) return C3R_EINVAL;
+    const uint64_t end_coff = gz.size();
+    const std::string gz_path = std::string(path) + ".gz";
+    if (!write_file(gz_path, gz.data(), gz.size(), BGZF_EOF, sizeof BGZF_EOF)) return C3R_EINVAL;
+    auto voff = [&](size_t u) -> uint64_t {         // a position at a block's end belongs to the next block
+        if (u >= data.size()) return end_coff << 16;
+        return (coffs[u / BLK] << 16) | (uint64_t)(u % BLK);
+    };
+    // TBI v1, VCF preset (format 2, col_seq 1, col_beg 2, col_end 0, meta '#', skip 0): UCSC bins + 16 kb linear index
+    struct Ctg { std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins; std::vector<uint64_t> lin; };
+    std::vector<std::string> names; std::map<std::string, size_t> which; std::vector<Ctg> idx;
+    size_t u = 0;
+    const size_t n = data.size();
+    while (u <= n) {
+        const uint8_t *nl = u < n ? (const uint8_t *)memchr(data.data() + u, '\n', n - u) : nullptr;
+        const size_t le = nl ? (size_t)(nl - data.data()) : n;
+        const size_t ln = le - u, step = ln + 1;                  // Python: for line in data.split(b"\n"): n = len(line) + 1
+        if (ln > 0 && data[u] != '#') {
+            Field c[6];
+            const char *s = (const char *)data.data() + u;
+            // line.split(b"\t", 5)
+            int k = 0; size_t b = 0;
+            for (size_t i = 0; i <= ln && k < 5; ++i) if (i == ln || s[i] == '\t') { c[k++] = Field{s + b, i - b}; b = i + 1; }
+            if (k >= 4) {
+                const std::string ctg(c[0].p, c[0].n);
+                const int64_t beg = strtoll(std::string(c[1].p, c[1].n).c_str(), nullptr, 10) - 1;
+                const int64_t end = beg + (int64_t)std::max<size_t>(1, c[3].n);
+                auto it = which.find(ctg);
+                if (it == which.end()) { it = which.emplace(ctg, names.size()).first; names.push_back(ctg); idx.emplace_back(); }
+                Ctg &x = idx[it->second];
+                const uint64_t v0 = voff(u), v1 = voff(u + step);
+                auto &ch = x.bins[(uint32_t)reg2bin_vcf(beg, end)];
+                if (!ch.empty() && ch.back().second == v0) ch.back().second = v1;
+                else ch.emplace_back(v0, v1);
+                const size_t w1 = (size_t)((end - 1) >> 14);
+                if (x.lin.size() <= w1) x.lin.resize(w1 + 1, 0);
+                for (size_t w = (size_t)(beg >> 14); w <= w1; ++w) if (x.lin[w] == 0) x.lin[w] = v0;
+            }
+        }
+        u += step;
+        if (!nl) break;
+    }
+    std::vector<uint8_t> tbi = {'T', 'B', 'I', 1};
+    std::string nm;
+    for (auto &s : names) { nm += s; nm += '\0'; }
+    const int32_t hdr[8] = {(int32_t)names.size(), 2, 1, 2, 0, '#', 0, (int32_t)nm.size()};
+    for (int32_t h : hdr) put(tbi, h);
+    tbi.insert(tbi.end(), nm.begin(), nm.end());
+    for (Ctg &x : idx) {
+        for (size_t w = 1; w < x.lin.size(); ++w) if (x.lin[w] == 0) x.lin[w] = x.lin[w - 1];
+        put(tbi, (int32_t)x.bins.size());
+        for (auto &kv : x.bins) {
+            put(tbi, (uint32_t)kv.first); put(tbi, (int32_t)kv.second.size());
+            for (auto &c : kv.second) { put(tbi, c.first); put(tbi, c.second); }
+        }
+        put(tbi, (int32_t)x.lin.size());
+        for (uint64_t v : x.lin) put(tbi, v);
+    }
+    std::vector<uint8_t> tgz; std::vector<uint64_t> tco;
+    if (!bgzf_compress(tbi.data(), tbi.size(), 1, tgz, tco)) return C3R_EINVAL;
+    if (!write_file(gz_path + ".tbi", tgz.data(), tgz.size(), BGZF_EOF, sizeof BGZF_EOF)) return C3R_EINVAL;
+    remove(path);
+    return C3R_OK;
+}
+
+}  // extern "C"

@@ -64,6 +64,26 @@ def _relabel(row, label):
     return "\t".join(f)
 
 
+def _filter_row(row, c, contig, qual, show_ref, rediportal):
+    """One record of a per-chunk VCF -> (pos, row as written, tagged 0/1), or None when sort_vcf drops it
+    (src/sort_vcf.py:204-236: RefCall rows unless --show_ref, LowQual relabel at QUAL <= --qual, REDIportal tagging)."""
+    pos, q, ref, alt = int(c[1]), float(c[5]), c[3], c[4]
+    is_ref = alt == "." or ref == alt
+    if is_ref and not show_ref:
+        return None
+    if not is_ref and qual and q <= qual:
+        row = _relabel(row, "LowQual")
+    tagged = 0
+    hit = rediportal.get((contig, pos)) if rediportal is not None else None
+    if hit is not None and "Germline" not in row and "RefCall" not in row:
+        f9 = row.split("\t", 8)
+        if f9[3] == hit[0] and f9[4] == hit[1]:
+            f9[6] = "RNAEditing"
+            row = "\t".join(f9)
+            tagged = 1
+    return pos, row, tagged
+
+
 def merge_chunk_vcfs(input_dir, output_fn, contigs, prefix="pileup", suffix=".vcf", qual=2, show_ref=False,
                      rediportal=None, output_no_tagging_fn=None, listing=None, log=print):
     """Returns (rows_read, rows_written, rows_tagged).  `listing` pins the directory order (tests); default os.listdir."""
@@ -94,20 +114,11 @@ def merge_chunk_vcfs(input_dir, output_fn, contigs, prefix="pileup", suffix=".vc
                     c = row.strip().split(None, 6)
                     if c[0] != contig:
                         break                      # a file of another contig whose name merely contains this one
-                    pos, q, ref, alt = int(c[1]), float(c[5]), c[3], c[4]
-                    is_ref = alt == "." or ref == alt
-                    if is_ref and not show_ref:
+                    kept = _filter_row(row, c, contig, qual, show_ref, rediportal)
+                    if kept is None:
                         continue
-                    if not is_ref and qual and q <= qual:
-                        row = _relabel(row, "LowQual")
-                    hit = rediportal.get((contig, pos)) if tagging else None
-                    if hit is not None and "Germline" not in row and "RefCall" not in row:
-                        f9 = row.split("\t", 8)
-                        if f9[3] == hit[0] and f9[4] == hit[1]:
-                            f9[6] = "RNAEditing"
-                            row = "\t".join(f9)
-                            n_tagged += 1
-                    by_pos[pos] = row
+                    by_pos[kept[0]] = kept[1]
+                    n_tagged += kept[2]
                     n_kept += 1
         if not header_done and header:
             out.write("".join(header))
@@ -125,6 +136,82 @@ def merge_chunk_vcfs(input_dir, output_fn, contigs, prefix="pileup", suffix=".vc
         open(output_fn, "w").close()
         log("[WARNING] No %s found, output empty vcf file" % ("vcf file" if n_read == 0 else "variant"))
     return n_read, n_kept, n_tagged
+
+
+class SampleMerger(object):
+    """In-process form of the same merge for the whole-sample driver (call_sample.py): contigs are added in output order,
+    each as the newline-terminated rows its chunks produced (any order, duplicates at chunk seams allowed); the files written
+    are byte-identical to merge_chunk_vcfs over the per-chunk files."""
+
+    def __init__(self, output_fn, header_text, qual=2, show_ref=False, rediportal=None, output_no_tagging_fn=None, native=True):
+        self.output_fn, self.header = output_fn, header_text
+        self.native, self._edits = native, None
+        self.qual, self.show_ref, self.rediportal = qual, show_ref, rediportal
+        self.out = open(output_fn, "w")
+        self.out_nt_fn = output_no_tagging_fn if rediportal is not None else None
+        self.out_nt = open(self.out_nt_fn, "w") if self.out_nt_fn else None
+        self.n_read = self.n_kept = self.n_tagged = 0
+        self.header_done = False
+
+    def add_contig(self, contig, rows):
+        """rows: bytes (or str) of newline-terminated records of `contig`.  The work is done by c3r_vcf_merge
+        (csrc/vcfio.cpp); add_contig_py below is the same in Python and is what the golden tests compare it with."""
+        if self.native is False:
+            return self.add_contig_py(contig, rows)
+        from . import bamio
+        blob = rows.encode() if isinstance(rows, str) else bytes(rows)
+        if not blob:
+            return
+        edits = None
+        if self.rediportal:
+            if self._edits is None:                       # one pass over the table: per-contig entry lists
+                self._edits = {}
+                for (c, pos), hit in self.rediportal.items():
+                    self._edits.setdefault(c, []).append((pos, hit[0], hit[1]))
+            edits = self._edits.get(contig)
+        merged, merged_nt, (n_read, n_kept, n_tag) = bamio.vcf_merge(blob, self.qual, self.show_ref, edits, self.out_nt is not None)
+        self._header()
+        self.n_read += n_read
+        self.n_kept += n_kept
+        self.n_tagged += n_tag
+        self.out.write(merged.decode())
+        if self.out_nt:
+            self.out_nt.write(merged_nt.decode())
+
+    def _header(self):
+        if not self.header_done:
+            self.out.write(self.header)
+            if self.out_nt:
+                self.out_nt.write(self.header)
+            self.header_done = True
+
+    def add_contig_py(self, contig, rows):
+        text = rows.decode() if isinstance(rows, (bytes, bytearray)) else rows
+        if not text:
+            return
+        self._header()
+        by_pos = {}
+        for row in text.splitlines(True):
+            self.n_read += 1
+            kept = _filter_row(row, row.strip().split(None, 6), contig, self.qual, self.show_ref, self.rediportal)
+            if kept is None:
+                continue
+            by_pos[kept[0]] = kept[1]
+            self.n_tagged += kept[2]
+            self.n_kept += 1
+        for pos in sorted(by_pos):
+            self.out.write(by_pos[pos])
+            if self.out_nt:
+                self.out_nt.write(by_pos[pos].replace("RNAEditing", "PASS"))
+
+    def close(self, log=print):
+        self.out.close()
+        if self.out_nt:
+            self.out_nt.close()
+        if self.n_read == 0 or self.n_kept == 0:
+            open(self.output_fn, "w").close()
+            log("[WARNING] No %s found, output empty vcf file" % ("vcf file" if self.n_read == 0 else "variant"))
+        return self.n_read, self.n_kept, self.n_tagged
 
 
 def merge_stream(lines, output_fn):
@@ -155,7 +242,14 @@ def _reg2bin(beg, end):
     return 0
 
 
-def compress_vcf(path):
+def compress_vcf(path, threads=0):
+    """`bgzip -f` + `tabix -f -p vcf` (src/sort_vcf.py:70-75) through c3r_vcf_compress (csrc/vcfio.cpp: blocks deflated on
+    threads); compress_vcf_py is the single-threaded Python twin whose bytes it must reproduce."""
+    from . import bamio
+    return bamio.vcf_compress(path, threads)
+
+
+def compress_vcf_py(path):
     """`bgzip -f` + `tabix -f -p vcf` equivalent (src/sort_vcf.py:70-75): <path> -> <path>.gz (BGZF) + <path>.gz.tbi, original
     removed.  The index follows the tabix format description (TBI v1: VCF preset, UCSC bins, 16 kb linear index); tabix
     itself is not in the image, so it is checked against the format and by reading records back through it
@@ -250,7 +344,8 @@ def build_parser():
     return p
 
 
-def main(argv=None):
+def main(argv=None, listing=None):
+    """`listing`: file names of --input_dir in the order to read them (tests; default os.listdir order like the reference)."""
     args = build_parser().parse_args(argv)
     if args.input_dir is None:
         merge_stream(sys.stdin, args.output_fn)
@@ -271,7 +366,7 @@ def main(argv=None):
             tags = set(args.readiportal_database_filter_tag.split(":")) if args.readiportal_database_filter_tag is not None else None
             table = load_rediportal(src, contigs, tags)
     n_read, n_kept, n_tag = merge_chunk_vcfs(args.input_dir, args.output_fn, contigs, args.vcf_fn_prefix, args.vcf_fn_suffix, args.qual,
-                                             args.show_ref, table, args.output_no_tagging_fn)
+                                             args.show_ref, table, args.output_no_tagging_fn, listing=listing)
     if args.compress_vcf:
         compress_vcf(args.output_fn)
         if table is not None and args.output_no_tagging_fn and n_kept:

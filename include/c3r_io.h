@@ -1,4 +1,5 @@
-/* c3r_io.h — C ABI of libc3r_io.so: BAM/BGZF/BAI -> the flat read records c3r_load_reads takes.
+/* c3r_io.h — C ABI of libc3r_io.so: BAM/BGZF/BAI -> the flat read records c3r_load_reads takes; merged, bgzipped,
+ * tabix-indexed VCF out.
  *
  * Replaces the input side of the reference's `samtools mpileup <bam> -r ctg:beg-end` subprocess
  * (src/create_tensor_pileup.py:436-451; region set-up :409-428): open the BAM, use its .bai to find the
@@ -47,6 +48,25 @@ int c3r_bam_copy(c3r_bam *b, c3r_read_t *reads, uint32_t *cigar, uint8_t *seq);
 /* `samtools index` equivalent (samtools is not a dependency of this path): write a .bai for a
  * coordinate-sorted BAM. */
 int c3r_bam_index_build(const char *bam_path, const char *bai_path);
+
+/* ---- output side (csrc/vcfio.cpp): what `sort_vcf` does after the per-chunk calls (src/sort_vcf.py:123-292).
+ *
+ * c3r_vcf_merge: `rows` = the newline-terminated VCF records of ONE contig in the order its chunks produced them.
+ * Applies src/sort_vcf.py:204-236 to every record — dropped when ALT is "." or equals REF unless show_ref; FILTER set
+ * to LowQual when it is a variant, qual != 0 and QUAL <= qual; FILTER set to RNAEditing when (pos, REF, ALT) is in the
+ * REDIportal entries of this contig (edit_pos ascending, edit_ref / edit_alt parallel to it; n_edit 0 = no tagging)
+ * and the record holds neither "Germline" nor "RefCall" — then keeps the LAST record of every position and writes them
+ * in position order to out[cap].  out_nt / out_nt_len (may be NULL): the same records with RNAEditing shown as PASS
+ * (the reference's *_no_tagging.vcf).  counts[3] = records read, kept (before the duplicate rule), tagged.
+ * Returns C3R_EOVERFLOW with *out_len / *out_nt_len set when a buffer is too small (call twice). */
+int c3r_vcf_merge(const char *rows, int64_t n_bytes, int qual, int show_ref, const int32_t *edit_pos, const char *const *edit_ref,
+                  const char *const *edit_alt, int64_t n_edit, char *out, int64_t cap, int64_t *out_len, char *out_nt, int64_t cap_nt,
+                  int64_t *out_nt_len, int64_t *counts);
+
+/* `bgzip -f <path>` + `tabix -f -p vcf <path>.gz` (src/sort_vcf.py:70-75): writes <path>.gz (BGZF, 0xff00-byte blocks
+ * deflated on `threads` threads, <= 0: hardware concurrency up to 32) and <path>.gz.tbi (TBI v1, VCF preset), removes
+ * <path>. */
+int c3r_vcf_compress(const char *path, int threads);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,91 @@
+"""Host logic of the whole-sample driver (clair3_rna_amd/call_sample.py): contig / chunk planning of run_clair3_rna:310-449,
+split_extend_bed (:268-296) and the in-memory merge against golden G6 (outputs of the reference's own sort_vcf).  CPU-only."""
+import gzip
+import json
+import os
+
+import pytest
+
+from clair3_rna_amd import call_sample, io, sort_vcf
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = json.load(gzip.open(os.path.join(HERE, "golden", "g6_sortvcf.json.gz"), "rt"))
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["c3r_vcf_merge", "python"])
+@pytest.mark.parametrize("ci", range(len(CASES) - 1))
+def test_sample_merger_matches_reference_sort_vcf(ci, native, tmp_path):
+    """Rows handed over per contig (chunk files concatenated in listing order, as the driver's decode stage returns them)."""
+    case = CASES[ci]
+    a = case["args"]
+    table = None
+    if a.get("tag"):
+        table = {}
+        if case["rediportal"] is not None:
+            redi = tmp_path / "redi.txt.gz"
+            with gzip.open(str(redi), "wt") as f:
+                f.write(case["rediportal"])
+            tags = set(a["filter_tag"].split(":")) if a.get("filter_tag") else None
+            table = sort_vcf.load_rediportal(str(redi), case["contigs"], tags)
+    names = [n for n in case["listing"] if n.startswith("pileup") and n.endswith(".vcf")]
+    header = []
+    per = {}
+    for contig in sort_vcf._contig_order(case["contigs"], case["contigs"]):
+        rows = []
+        for n in (n for n in names if contig in n):
+            for row in case["files"][n].splitlines(True):
+                if row[0] == "#":
+                    if row not in header:
+                        header.append(row)
+                    continue
+                if row.split(None, 1)[0] != contig:
+                    break
+                rows.append(row)
+        per[contig] = "".join(rows)
+    out, out_nt = str(tmp_path / "o.vcf"), str(tmp_path / "o_nt.vcf")
+    m = sort_vcf.SampleMerger(out, "".join(header), a["qual"], a["show_ref"], table, out_nt, native=native)
+    for contig in sort_vcf._contig_order(case["contigs"], case["contigs"]):
+        m.add_contig(contig, per[contig].encode())
+    m.close(log=lambda *_: None)
+    assert open(out).read() == case["out"]
+    if case["out_no_tagging"] is not None:
+        assert open(out_nt).read() == case["out_no_tagging"]
+
+
+@pytest.fixture
+def ref_fa(tmp_path):
+    fa = str(tmp_path / "ref.fa")
+    names = ["chr2", "chr1", "chrX", "chrUn_1", "20", "chrM", "HLA-A"]
+    io.write_fasta(fa, [(n, "ACGT" * (250 * (i + 1))) for i, n in enumerate(names)])     # 1000, 2000, ... bp
+    return fa
+
+
+def test_plan_default_is_major_contigs_in_reference_order(ref_fa):
+    contigs, chunks = call_sample.plan_chunks(ref_fa, chunk_size=900)
+    assert contigs == ["chr1", "chr2", "chrX", "20"]                       # chr1..22,X,Y first, then 1..22,X,Y
+    assert chunks == {"chr2": 2, "chr1": 3, "chrX": 4, "20": 6}            # ceil(len / chunk_size)
+    assert call_sample.plan_chunks(ref_fa, chunk_size=1000)[1]["chr2"] == 1
+    assert call_sample.plan_chunks(ref_fa, chunk_size=900, chunk_num=7)[1] == {"chr2": 7, "chr1": 7, "chrX": 7, "20": 7}
+
+
+def test_plan_include_all_ctg_name_bed_and_vcf(ref_fa, tmp_path):
+    contigs, _ = call_sample.plan_chunks(ref_fa, include_all_ctgs=True)
+    assert contigs[:4] == ["chr1", "chr2", "chrX", "20"] and sorted(contigs[4:]) == ["HLA-A", "chrM", "chrUn_1"]
+    assert call_sample.plan_chunks(ref_fa, ctg_name="chrM,chr2,nope")[0] == ["chr2", "chrM"]
+    bed = str(tmp_path / "a.bed")
+    open(bed, "w").write("#h\nchrUn_1\t10\t500\nchr1\t0\t40\nchr1\t300\t300\nabsent\t1\t2\n")
+    assert call_sample.plan_chunks(ref_fa, bed_fn=bed)[0] == ["chr1", "chrUn_1"]            # BED contigs, major or not
+    assert call_sample.plan_chunks(ref_fa, bed_fn=bed, ctg_name="chr1,chr2")[0] == ["chr1"]  # --ctg_name intersects the BED
+    vcf = str(tmp_path / "k.vcf")
+    open(vcf, "w").write("##x\n#CHROM\tPOS\nchrX\t5\t.\tA\tC\nchrM\t9\t.\tA\tC\n")
+    assert call_sample.plan_chunks(ref_fa, vcf_fn=vcf)[0] == ["chrX", "chrM"]
+    assert call_sample.plan_chunks(ref_fa, vcf_fn=vcf, bed_fn=bed)[0] == ["chr1", "chrUn_1"]  # union; the BED filters the .fai rows
+    d = str(tmp_path / "split")
+    call_sample.split_extend_bed(bed, d, {"chr1", "chrUn_1"})
+    assert sorted(os.listdir(d)) == ["chr1", "chrUn_1"]
+    assert open(os.path.join(d, "chr1")).read() == "chr1 0 73\nchr1 267 333"
+    assert io.read_bed(os.path.join(d, "chr1"), "chr1") == ([(0, 73), (267, 333)], 0, 333)
+    bad = str(tmp_path / "bad.bed")
+    open(bad, "w").write("chr1\t50\t10\n")
+    with pytest.raises(SystemExit):
+        call_sample.split_extend_bed(bad, d, None)

@@ -1,0 +1,141 @@
+"""Whole-sample driver (clair3_rna_amd/call_sample.py) against the reference's own flow on the same inputs: call_var_bam once per
+CHUNK_LIST row (run_clair3_rna:678-708) + sort_vcf over the per-chunk files (run_clair3_rna:710-726).  Files must be byte-identical."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample(tmp, phased=False):
+    from clair3_rna_amd import bam, bamio, io, synth
+    spec = [("chr1", 50000, 3), ("chr2", 30000, 5), ("chrX", 26000, 7), ("scaffold_7", 20000, 9), ("chr5", 15000, 11)]
+    contigs, reads = [], {}
+    for name, L, seed in spec:
+        ref, rs, _ = synth.small_case(seed=seed, ref_len=L, n_genes=max(3, L // 5000), depth=18, phased=phased)
+        contigs.append((name, ref))
+        if name != "chr5":                       # a contig of the reference without any read in the BAM
+            reads[name] = rs
+    fa, bm, wfn = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "in.bam"), os.path.join(tmp, "model")
+    io.write_fasta(fa, contigs)
+    bam.write_bam(bm, [(n, len(r)) for n, r in contigs], reads)
+    bamio.index_build(bm)
+    np.save(wfn + ".c3rw.npy", synth.random_weights(30 if phased else 18, seed=5))
+    return fa, bm, wfn, dict(contigs)
+
+
+def _reference_flow(tmp, fa, bm, wfn, out_dir, extra_chunk=(), extra_merge=None, phased=False):
+    """call_var_bam per CHUNK_LIST row + sort_vcf, with the files call_sample left in out_dir/tmp (CHUNK_LIST, CONTIGS, CMD,
+    split_beds) — the same files run_clair3_rna writes before STEP 1."""
+    from clair3_rna_amd import call_var_bam, capi, sort_vcf
+    pdir = os.path.join(tmp, "pileup_output")
+    os.makedirs(pdir)
+    eng = capi.Engine(0)
+    for row in open(os.path.join(out_dir, "tmp", "CHUNK_LIST")):
+        ctg, cid, cnum = row.split()
+        argv = ["--chkpnt_fn", wfn, "--bam_fn", bm, "--call_fn", os.path.join(pdir, "pileup_%s_%s.vcf" % (ctg, cid)), "--sampleName", "SAMPLE",
+                "--ref_fn", fa, "--extend_bed", os.path.join(out_dir, "tmp", "split_beds", ctg), "--ctgName", ctg, "--chunk_id", cid,
+                "--chunk_num", cnum, "--platform", "ont", "--snp_min_af", "0.08", "--indel_min_af", "0.15", "--minMQ", "5",
+                "--minCoverage", "4", "--pileup", "--cmd_fn", os.path.join(out_dir, "tmp", "CMD")] + list(extra_chunk)
+        if phased:
+            argv += ["--enable_phasing_model", "True"]
+        assert call_var_bam.Run(call_var_bam.build_parser().parse_args(argv), engine=eng) == 0
+    eng.close()
+    exp = os.path.join(tmp, "expected.vcf")
+    argv = ["--input_dir", pdir, "--vcf_fn_prefix", "pileup", "--output_fn", exp, "--ref_fn", fa, "--contigs_fn",
+            os.path.join(out_dir, "tmp", "CONTIGS"), "--cmd_fn", os.path.join(out_dir, "tmp", "CMD")] + list(extra_merge or [])
+    # Where chunks overlap (the +-33 bp halo; with head/tail calling both neighbours emit the halo candidates, from different
+    # windows) the reference keeps the row of whichever file os.listdir returns last (src/sort_vcf.py:204-236) — arbitrary.
+    # call_sample keeps the later chunk's row, so the comparison pins that order.
+    names = sorted(os.listdir(pdir), key=lambda n: (n.rsplit("_", 1)[0], int(n.rsplit("_", 1)[1].split(".")[0])))
+    assert sort_vcf.main(argv, listing=names) == 0
+    return exp
+
+
+def _run_sample(out_dir, fa, bm, wfn, extra=()):
+    from clair3_rna_amd import call_sample
+    argv = ["--bam_fn", bm, "--ref_fn", fa, "--output_dir", out_dir, "--pileup_model_path", wfn, "--chunk_size", "12000", "--no_compress"] + list(extra)
+    assert call_sample.Run(call_sample.build_parser().parse_args(argv)) == 0
+    return os.path.join(out_dir, "output.vcf")
+
+
+def test_sample_equals_per_chunk_flow(tmp_path):
+    tmp = str(tmp_path)
+    fa, bm, wfn, _ = _sample(tmp)
+    got = _run_sample(os.path.join(tmp, "out"), fa, bm, wfn)
+    assert open(os.path.join(tmp, "out", "tmp", "CONTIGS")).read().split("\n") == ["chr1", "chr2", "chrX"]     # scaffold_7: not a major contig; chr5: no reads
+    rows = [r.split() for r in open(os.path.join(tmp, "out", "tmp", "CHUNK_LIST"))]
+    assert [r for r in rows if r[0] == "chr1"] == [["chr1", str(k), "5"] for k in range(1, 6)]
+    exp = _reference_flow(tmp, fa, bm, wfn, os.path.join(tmp, "out"))
+    a, b = open(got).read(), open(exp).read()
+    assert a == b
+    recs = [r for r in a.split("\n") if r and r[0] != "#"]
+    assert len(recs) > 50 and {r.split("\t")[0] for r in recs} == {"chr1", "chr2", "chrX"}
+    assert all(r.split("\t")[4] != "." for r in recs)                  # RefCall rows are dropped without --print_ref_calls
+
+
+def test_sample_options_bed_refcalls_all_contigs_tagging(tmp_path):
+    """--bed_fn (chunks follow the BED extent, split_beds), --print_ref_calls, --include_all_ctgs is implied by the BED contigs,
+    head/tail + splice padding, --qual and REDIportal tagging incl. the _no_tagging twin."""
+    tmp = str(tmp_path)
+    fa, bm, wfn, refs = _sample(tmp)
+    bed = os.path.join(tmp, "conf.bed")
+    with open(bed, "w") as f:
+        f.write("#track\nchr1\t2000\t31000\nchr1\t33000\t47000\nscaffold_7\t100\t19000\nchrX\t5000\t5000\nchrX\t9000\t25000\n")
+    first = _run_sample(os.path.join(tmp, "probe"), fa, bm, wfn, ["--bed_fn", bed])
+    var = [r.split("\t") for r in open(first) if r[0] != "#"]
+    snps = [v for v in var if len(v[3]) == 1 and len(v[4]) == 1][:12]
+    assert len(snps) >= 6
+    redi = os.path.join(tmp, "redi.tsv.gz")
+    with gzip.open(redi, "wt") as f:
+        f.write("Region\tPosition\tRef\tEd\tStrand\tdb\n")
+        for v in snps:
+            f.write("%s\t%s\t%s\t%s\t+\tA,R\n" % (v[0], v[1], v[3], v[4]))
+    opts = ["--bed_fn", bed, "--print_ref_calls", "--qual", "8", "--enable_variant_calling_at_sequence_head_and_tail",
+            "--enable_padding_in_splice_junction_regions", "--tag_variant_using_readiportal", "--readiportal_source_fn", redi]
+    got = _run_sample(os.path.join(tmp, "out"), fa, bm, wfn, opts)
+    assert open(os.path.join(tmp, "out", "tmp", "CONTIGS")).read().split("\n") == ["chr1", "chrX", "scaffold_7"]
+    exp = _reference_flow(tmp, fa, bm, wfn, os.path.join(tmp, "out"),
+                          extra_chunk=["--bed_fn", bed, "--enable_variant_calling_at_sequence_head_and_tail", "True",
+                                       "--enable_padding_in_splice_junction_regions", "True"],
+                          extra_merge=["--show_ref", "True", "--qual", "8", "--tag_variant_using_readiportal", "True",
+                                       "--readiportal_source_fn", redi, "--output_no_tagging_fn", os.path.join(tmp, "expected_nt.vcf")])
+    a = open(got).read()
+    assert a == open(exp).read()
+    assert open(os.path.join(tmp, "out", "output_no_tagging.vcf")).read() == open(os.path.join(tmp, "expected_nt.vcf")).read()
+    assert a.count("\tRNAEditing\t") >= 4 and "\tRefCall\t" in a and "\tLowQual\t" in a
+
+
+def test_sample_phased_genotyping_and_compressed_output(tmp_path):
+    """30-channel pass on a haplotagged BAM, --genotyping_mode_vcf_fn (one scan per chunk with its own site list), --ctg_name,
+    and the default bgzip + tabix output."""
+    from clair3_rna_amd import call_sample
+    tmp = str(tmp_path)
+    fa, bm, wfn, _ = _sample(tmp, phased=True)
+    out = os.path.join(tmp, "probe")
+    argv = ["--bam_fn", bm, "--ref_fn", fa, "--output_dir", out, "--pileup_model_path", "unused", "--phased_pileup_model_path", wfn,
+            "--enable_phasing_model", "--chunk_size", "12000", "--no_compress", "--ctg_name", "chr2,chrX"]
+    assert call_sample.Run(call_sample.build_parser().parse_args(argv)) == 0
+    got = os.path.join(out, "output_enable_phasing.vcf")
+    exp = _reference_flow(tmp, fa, bm, wfn, out, phased=True)
+    a = open(got).read()
+    assert a == open(exp).read() and a.count("\n") > 60
+    # genotyping mode on the sites just called (+ a few uncovered positions)
+    sites = [r.split("\t")[:2] for r in a.split("\n") if r and r[0] != "#"][::2]
+    known = os.path.join(tmp, "known.vcf")
+    with open(known, "w") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\n")
+        for c, p in sites:
+            f.write("%s\t%s\t.\tA\tC\n" % (c, p))
+        f.write("chr2\t29990\t.\tA\tC\n")
+    out2 = os.path.join(tmp, "geno")
+    argv2 = ["--bam_fn", bm, "--ref_fn", fa, "--output_dir", out2, "--pileup_model_path", "unused", "--phased_pileup_model_path", wfn,
+             "--enable_phasing_model", "--chunk_size", "12000", "--genotyping_mode_vcf_fn", known, "--print_ref_calls"]
+    assert call_sample.Run(call_sample.build_parser().parse_args(argv2)) == 0
+    os.rename(os.path.join(tmp, "pileup_output"), os.path.join(tmp, "pileup_output_1"))
+    exp2 = _reference_flow(tmp, fa, bm, wfn, out2, extra_chunk=["--vcf_fn", known], extra_merge=["--show_ref", "True"], phased=True)
+    gz = os.path.join(out2, "output_enable_phasing.vcf.gz")
+    assert os.path.exists(gz + ".tbi") and not os.path.exists(gz[:-3])
+    assert gzip.open(gz, "rt").read() == open(exp2).read()

@@ -142,3 +142,71 @@ def test_bgzf_and_tabix_index_read_back(tmp_path):
                             got.add(line + "\n")
         want = set(r[3] for r in recs if r[0] == ctg and r[1] - 1 < end and r[1] - 1 + len(r[2]) > beg)
         assert got == want, (ctg, beg, end, len(got), len(want))
+
+
+def _random_vcf(rng, n_scale=1):
+    hdr = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"
+    recs = []
+    for ctg, n in (("chr1", 4000 * n_scale), ("chr2", 2500 * n_scale), ("chrM", 3)):
+        for p in sorted(rng.sample(range(1, 3000000), n)):
+            ref = "ACGT"[p % 4] + "".join(rng.choice("ACGT") for _ in range(rng.choice([0, 0, 0, 1, 5, 40])))
+            recs.append("%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ\t0/1:%d\n" % (ctg, p, ref, rng.choice("ACGT"), rng.random() * 40, rng.randint(0, 30)))
+    return hdr, recs
+
+
+@pytest.mark.parametrize("case", ["big", "empty", "header_only", "one_block_exact"])
+def test_native_bgzip_tabix_reproduces_the_python_writer(case, tmp_path):
+    """c3r_vcf_compress (threads) must write the very bytes compress_vcf_py writes: same blocks, same deflate stream, same .tbi."""
+    import random
+    rng = random.Random(11)
+    hdr, recs = _random_vcf(rng)
+    text = {"big": hdr + "".join(recs), "empty": "", "header_only": hdr,
+            "one_block_exact": (hdr + "".join(recs))[:0xff00 * 2]}[case]
+    if case == "one_block_exact":
+        text = text[:text.rfind("\n") + 1]
+        text += "chr2\t2999999\t.\t" + "A" * (0xff00 * 2 - len(text) - 60) + "\tC\t9.00\tPASS\t.\tGT\t0/1\n"
+    a, b = str(tmp_path / "a.vcf"), str(tmp_path / "b.vcf")
+    open(a, "w").write(text); open(b, "w").write(text)
+    sort_vcf.compress_vcf_py(a)
+    sort_vcf.compress_vcf(b, threads=5)
+    assert not os.path.exists(a) and not os.path.exists(b)
+    assert open(a + ".gz", "rb").read() == open(b + ".gz", "rb").read()
+    assert open(a + ".gz.tbi", "rb").read() == open(b + ".gz.tbi", "rb").read()
+    assert gzip.open(b + ".gz", "rt").read() == text
+
+
+def test_native_merge_equals_python_merge_on_random_records(tmp_path):
+    """c3r_vcf_merge against SampleMerger.add_contig_py: duplicates at seams, RefCall rows, LowQual boundary (QUAL == qual),
+    tagging incl. rows that must not be tagged (RefCall / REF-ALT mismatch), every qual / show_ref combination."""
+    import random
+    rng = random.Random(3)
+    rows = []
+    for p in sorted(rng.sample(range(1, 200000), 3000)):
+        ref = rng.choice("ACGT") + "".join(rng.choice("ACGT") for _ in range(rng.choice([0, 0, 0, 2])))
+        kind = rng.random()
+        if kind < 0.3:
+            rows.append("chr7\t%d\t.\t%s\t.\t%.2f\tRefCall\t.\tGT:GQ:DP:AD:AF\t0/0:3:20:18:0.9000\n" % (p, ref[0], rng.choice([0.0, 2.0, 7.13])))
+        else:
+            q = rng.choice([0.0, 1.99, 2.0, 2.01, 8.0, 22.47])
+            rows.append("chr7\t%d\t.\t%s\t%s\t%.2f\t%s\t.\tGT:GQ:DP:AD:AF\t0/1:%d:20:9,9:0.4500\n" % (p, ref, rng.choice(["A", "C", "G,T", "GA"]), q, "PASS" if q >= 2 else "LowQual", int(q)))
+    dup = rng.sample(rows, 150)                                   # seam duplicates: the same positions again, later in the list, other content
+    rows_in = rows[:2000] + [r.replace("\t0/1:", "\t1/1:").replace("\t0/0:", "\t0/0:9") for r in dup] + rows[2000:]
+    blob = "".join(rows_in).encode()
+    var = [r.split("\t") for r in rows if "RefCall" not in r]
+    table = {("chr7", int(v[1])): (v[3], v[4], "A") for v in var[::7]}
+    table.update({("chr7", int(v[1])): (v[3], "N", "A") for v in var[3::70]})          # wrong ALT: not tagged
+    table.update({("chr8", int(v[1])): (v[3], v[4], "A") for v in var[1::9]})          # other contig
+    hdr = "##h\n"
+    for qual in (0, 2, 8):
+        for show_ref in (False, True):
+            for tab in (None, table, {}):
+                outs = []
+                for native in (True, False):
+                    o, o_nt = str(tmp_path / ("m%d.vcf" % native)), str(tmp_path / ("m%d_nt.vcf" % native))
+                    m = sort_vcf.SampleMerger(o, hdr, qual, show_ref, tab, o_nt, native=native)
+                    m.add_contig("chr7", blob)
+                    m.add_contig("chr9", b"")
+                    counts = m.close(log=lambda *_: None)
+                    outs.append((open(o).read(), open(o_nt).read() if tab is not None else None, counts))
+                assert outs[0] == outs[1], (qual, show_ref, tab is not None)
+    assert outs[0][0].count("\n") > 1500
