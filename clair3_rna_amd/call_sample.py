@@ -165,7 +165,7 @@ class _Fetcher(object):
                 bf = self.tls.bf = bamio.BamFile(self.bam_fn)
                 self.handles.append(bf)
             rs = bf.fetch(ctg)
-        ref = io.fetch_reference(self.ref_fn, ctg, 1, length) if len(rs.reads) else ""
+        ref = io.fetch_reference(self.ref_fn, ctg, 1, length, raw=True) if len(rs.reads) else b""
         return rs, ref, time() - t0
 
     def close(self):
@@ -284,7 +284,22 @@ def Run(args, log=None):
         merger.add_contig(ctg, rows)          # one decode worker => contigs reach the merger in calling order
         return time() - t0
 
-    fetcher = _Fetcher(args.bam_fn, args.ref_fn)
+    bam_fn = args.bam_fn
+    if bam_fn.endswith(".bam"):
+        from . import bamio
+        with bamio.BamFile(bam_fn) as probe:
+            indexed = probe.has_index
+        if not indexed:
+            # without an index every contig would cost a pass over the whole file: build one next to a link in tmp/
+            # (run_clair3_rna insists on an existing index, :469-477; samtools is not a dependency here)
+            link = os.path.join(out_dir, "tmp", "input.bam")
+            if os.path.lexists(link):
+                os.remove(link)
+            os.symlink(os.path.abspath(bam_fn), link)
+            log("[INFO] %s has no .bai: building %s.bai" % (bam_fn, link))
+            bamio.index_build(link)
+            bam_fn = link
+    fetcher = _Fetcher(bam_fn, args.ref_fn)
     t_setup = time() - t_all
     n_sites = 0
     t_fetch = t_dev = 0.0

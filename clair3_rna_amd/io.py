@@ -35,22 +35,25 @@ def read_fai(ref_fn):
     return out
 
 
-def fetch_reference(ref_fn, ctg, start1, end1):
-    """Upper-cased bases of ctg:start1-end1 (1-based inclusive, clamped to the contig), like `samtools faidx`."""
+def fetch_reference(ref_fn, ctg, start1, end1, raw=False):
+    """Upper-cased bases of ctg:start1-end1 (1-based inclusive, clamped to the contig), like `samtools faidx`.
+    raw=True: the bytes as they stand in the file (line ends removed, case kept — c3r_set_reference upper-cases on its own),
+    which spares a 60 MB contig two passes in Python."""
     for name, length, offset, linebases, linewidth in read_fai(ref_fn):
         if name != ctg:
             continue
         start1 = max(1, start1)
         end1 = min(length, end1)
         if end1 < start1:
-            return ""
+            return b"" if raw else ""
         b0, b1 = start1 - 1, end1           # 0-based half-open
         fo = offset + (b0 // linebases) * linewidth + b0 % linebases
         lo = offset + ((b1 - 1) // linebases) * linewidth + (b1 - 1) % linebases + 1
         with open(ref_fn, "rb") as f:
             f.seek(fo)
-            raw = f.read(lo - fo)
-        return raw.replace(b"\n", b"").replace(b"\r", b"").decode().upper()
+            data = f.read(lo - fo)
+        data = data.replace(b"\n", b"").replace(b"\r", b"")
+        return data if raw else data.decode().upper()
     raise KeyError("contig %s not in %s.fai" % (ctg, ref_fn))
 
 

@@ -15,6 +15,8 @@ def _sample(tmp, phased=False):
     contigs, reads = [], {}
     for name, L, seed in spec:
         ref, rs, _ = synth.small_case(seed=seed, ref_len=L, n_genes=max(3, L // 5000), depth=18, phased=phased)
+        if name == "chr2":
+            ref = ref[:5000] + ref[5000:9000].lower() + ref[9000:]       # soft-masked stretch: both flows must upper-case it
         contigs.append((name, ref))
         if name != "chr5":                       # a contig of the reference without any read in the BAM
             reads[name] = rs
@@ -74,6 +76,11 @@ def test_sample_equals_per_chunk_flow(tmp_path):
     recs = [r for r in a.split("\n") if r and r[0] != "#"]
     assert len(recs) > 50 and {r.split("\t")[0] for r in recs} == {"chr1", "chr2", "chrX"}
     assert all(r.split("\t")[4] != "." for r in recs)                  # RefCall rows are dropped without --print_ref_calls
+    # a BAM without .bai: the driver indexes a link under tmp/ instead of scanning the whole file once per contig
+    os.remove(bm + ".bai")
+    again = _run_sample(os.path.join(tmp, "out_noindex"), fa, bm, wfn)
+    assert open(again).read() == a and os.path.exists(os.path.join(tmp, "out_noindex", "tmp", "input.bam.bai"))
+    assert not os.path.exists(bm + ".bai")
 
 
 def test_sample_options_bed_refcalls_all_contigs_tagging(tmp_path):
