@@ -142,7 +142,7 @@ def build_parser():
     a("--readiportal_source_fn", type=str, default=None)
     a("--readiportal_database_filter_tag", type=str, default=None)
     a("--no_compress", action="store_true", help="leave <prefix>.vcf uncompressed (tests)")
-    a("--gpu_id", type=int, default=int(os.environ.get("C3R_DEVICE", "0")))
+    a("--gpu_id", type=int, default=None, help="default: $C3R_DEVICE, else LOCAL_RANK under torch.distributed.run, else 0")
     a("--fetch_threads", type=int, default=4)
     return p
 
@@ -177,6 +177,19 @@ def Run(args, log=None):
     from . import capi
     log = log or (lambda m: print(m, file=sys.stderr))
     t_all = time()
+    # one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m clair3_rna_amd.call_sample ...`): contigs are
+    # dealt to the ranks largest-first, every rank leaves the merged records of its contigs under tmp/parts/, rank 0 puts the
+    # file together.  No data-path collective: torch.distributed (gloo) is the barrier, nothing else.
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")
+        if args.gpu_id is None:
+            args.gpu_id = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if args.gpu_id is None:
+        args.gpu_id = int(os.environ.get("C3R_DEVICE", "0"))
     for need in (args.bam_fn, args.ref_fn):
         if not os.path.isfile(need):
             sys.exit("[ERROR] file %s not found" % need)
@@ -196,17 +209,23 @@ def Run(args, log=None):
         log("[WARNING] Exit calling because no contig was found in BAM!")
         return 0
     fai = {n: L for n, L, _o, _b, _w in io.read_fai(args.ref_fn)}
-    split_dir = os.path.join(out_dir, "tmp", "split_beds")
+    priv = os.path.join(out_dir, "tmp") if rank == 0 else os.path.join(out_dir, "tmp", "rank%d" % rank)
+    os.makedirs(priv, exist_ok=True)
+    split_dir = os.path.join(priv, "split_beds")
     if bed_fn:
         split_extend_bed(bed_fn, split_dir, set(contigs))
     cmd_fn = os.path.join(out_dir, "tmp", "CMD")                        # run_clair3_rna:613-667: stamped into the VCF header
-    if not os.path.exists(cmd_fn):
+    if rank == 0 and not os.path.exists(cmd_fn):
         with open(cmd_fn, "w") as f:
             f.write(" ".join(sys.argv) + "\n")
-    with open(os.path.join(out_dir, "tmp", "CHUNK_LIST"), "w") as f:
-        for c in contigs:
-            for k in range(1, chunk_nums[c] + 1):
-                f.write("%s %d %d\n" % (c, k, chunk_nums[c]))
+    all_contigs = contigs
+    parts_dir = os.path.join(out_dir, "tmp", "parts")
+    if world > 1:
+        from . import shard
+        os.makedirs(parts_dir, exist_ok=True)
+        dist.barrier()                                                  # CMD is in place before anybody builds the header
+        mine = shard.lpt_assign([fai[c] for c in all_contigs], world)[rank]
+        contigs = [all_contigs[i] for i in mine]
 
     table = None
     if args.tag_variant_using_readiportal:
@@ -225,7 +244,7 @@ def Run(args, log=None):
     qual_rows = args.qual if args.qual is not None else 2              # call_variants.py:1827 (STEP 1 never passes --qual)
     qual_merge = args.qual if args.qual is not None else 2             # sort_vcf's own default
     header = vcf.header(args.ref_fn, cmd_fn, args.sample_name) + "\n"
-    merger = sort_vcf.SampleMerger(out_fn, header, qual_merge, args.print_ref_calls, table, out_nt_fn)
+    merger = sort_vcf.SampleMerger(out_fn, header, qual_merge, args.print_ref_calls, table, out_nt_fn) if rank == 0 else None
 
     def device_stage(eng, ctg, rs, ref):
         """-> number of candidates left resident in `eng` (rows are produced by decode_stage)."""
@@ -278,10 +297,22 @@ def Run(args, log=None):
             dump[ctg] = dict(sites=eng.sites(), tokens=eng.tokens(), probs=eng.fetch_probs(todo), tensors=eng.tensors(), rows=rows)
         return rows
 
+    part_counts = {}
+
     def decode_and_merge(eng, ctg, todo):
         rows = decode_stage(eng, ctg, todo)
         t0 = time()
-        merger.add_contig(ctg, rows)          # one decode worker => contigs reach the merger in calling order
+        if world == 1:
+            merger.add_contig(ctg, rows)      # one decode worker => contigs reach the merger in calling order
+        else:                                 # this contig's records on their own; rank 0 concatenates in calling order
+            k = all_contigs.index(ctg)
+            m = sort_vcf.SampleMerger(os.path.join(parts_dir, "%05d.vcf" % k), "", qual_merge, args.print_ref_calls, table,
+                                      os.path.join(parts_dir, "%05d_nt.vcf" % k))
+            m.add_contig(ctg, rows)
+            m.out.close()
+            if m.out_nt:
+                m.out_nt.close()
+            part_counts[k] = (m.n_read, m.n_kept, m.n_tagged)
         return time() - t0
 
     bam_fn = args.bam_fn
@@ -326,10 +357,35 @@ def Run(args, log=None):
             results.append((ctg, fut))
         t_merge = sum(fut.result() for _c, fut in results)
     fetcher.close()
+    called = [c for c, _f in results]
+    for e in engines:
+        e.close()
+    if world > 1:
+        import json
+        with open(os.path.join(parts_dir, "rank%d.json" % rank), "w") as f:
+            json.dump(dict(counts={str(k): v for k, v in part_counts.items()}, called=called, n_sites=n_sites), f)
+        dist.barrier()
+        if rank != 0:
+            dist.barrier()                                              # leave only when rank 0 has written the result
+            return 0
+        called_set, n_sites = set(), 0
+        for r in range(world):
+            j = json.load(open(os.path.join(parts_dir, "rank%d.json" % r)))
+            called_set.update(j["called"])
+            n_sites += j["n_sites"]
+            for k, (a, b, c) in j["counts"].items():
+                merger.n_read += a; merger.n_kept += b; merger.n_tagged += c
+        called = [c for c in all_contigs if c in called_set]
+        for k, c in enumerate(all_contigs):
+            fn = os.path.join(parts_dir, "%05d.vcf" % k)
+            if c in called_set and os.path.exists(fn) and os.path.getsize(fn):
+                merger._header()
+                merger.out.write(open(fn).read())
+                if merger.out_nt:
+                    merger.out_nt.write(open(os.path.join(parts_dir, "%05d_nt.vcf" % k)).read())
     n_read, n_kept, n_tag = merger.close(log)
     # tmp/CONTIGS and tmp/CHUNK_LIST as run_clair3_rna leaves them (:436-449): contigs without reads are dropped by its
     # `samtools idxstats` check (:184-210) before they are written; here that is known once the contig has been fetched
-    called = [c for c, _f in results]
     with open(os.path.join(out_dir, "tmp", "CONTIGS"), "w") as f:
         f.write("\n".join(called))
     with open(os.path.join(out_dir, "tmp", "CHUNK_LIST"), "w") as f:
@@ -343,12 +399,12 @@ def Run(args, log=None):
             sort_vcf.compress_vcf(out_nt_fn)
     if table is not None:
         log("[INFO] Dataset size:%d, total variants tagged by REDIportal dataset: %d" % (len(table), n_tag))
-    for e in engines:
-        e.close()
-    log("[INFO] %d contigs, %d candidate sites, %d records written to %s%s" % (len(contigs), n_sites, n_kept, out_fn, "" if args.no_compress else ".gz"))
+    log("[INFO] %d contigs, %d candidate sites, %d records written to %s%s" % (len(called), n_sites, n_kept, out_fn, "" if args.no_compress else ".gz"))
     t_gz = time() - t0
     log("[INFO] set-up %.2f s, fetch %.2f s (overlapped), device stage %.2f s, merge %.2f s, bgzip+tabix %.2f s, total %.2f s"
         % (t_setup, t_fetch, t_dev, t_merge, t_gz, time() - t_all))
+    if world > 1:
+        dist.barrier()
     return 0
 
 

@@ -810,6 +810,7 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
         int rc = ensure(ctx, ctx->d_raw, (size_t)n * C3R_WINDOW * C * 4);
         if (rc) return rc;
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_raw.p, tensors, (size_t)n * C3R_WINDOW * C * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!probs) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the caller's buffer must be free to go when we return
         d_x = (const int32_t *)ctx->d_raw.p;
     }
     if (n == 0) return C3R_OK;

@@ -146,3 +146,46 @@ def test_sample_phased_genotyping_and_compressed_output(tmp_path):
     gz = os.path.join(out2, "output_enable_phasing.vcf.gz")
     assert os.path.exists(gz + ".tbi") and not os.path.exists(gz[:-3])
     assert gzip.open(gz, "rt").read() == open(exp2).read()
+
+
+def test_two_ranks_share_the_contigs_and_rank0_assembles_the_same_file(tmp_path):
+    """One process per GPU (here: two ranks on the one GPU of the box): contigs dealt largest-first, per-contig parts under
+    tmp/parts, rank 0 concatenates — the result must be the single-process file, incl. tagging and the _no_tagging twin."""
+    import socket
+    import subprocess
+    import sys
+    tmp = str(tmp_path)
+    fa, bm, wfn, _ = _sample(tmp)
+    one = _run_sample(os.path.join(tmp, "one"), fa, bm, wfn, ["--include_all_ctgs", "--print_ref_calls"])
+    var = [r.split("\t") for r in open(one) if r[0] != "#" and r.split("\t")[4] != "."]
+    redi = os.path.join(tmp, "redi.tsv")
+    with open(redi, "w") as f:
+        f.write("Region\tPosition\tRef\tEd\tStrand\tdb\n")
+        for v in var[::40]:
+            f.write("%s\t%s\t%s\t%s\t+\tA\n" % (v[0], v[1], v[3], v[4]))
+    opts = ["--include_all_ctgs", "--print_ref_calls", "--tag_variant_using_readiportal", "--readiportal_source_fn", redi]
+    one = _run_sample(os.path.join(tmp, "one_t"), fa, bm, wfn, opts)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    out2 = os.path.join(tmp, "two")
+    argv = [sys.executable, "-m", "clair3_rna_amd.call_sample", "--bam_fn", bm, "--ref_fn", fa, "--output_dir", out2, "--pileup_model_path", wfn,
+            "--chunk_size", "12000", "--no_compress", "--gpu_id", "0"] + opts
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(argv, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    def body(fn):                                                   # (the ##cmdline header line names the launching command)
+        return [r for r in open(fn).read().split("\n") if not r.startswith("##cmdline=")]
+    assert body(os.path.join(out2, "output.vcf")) == body(one)
+    assert body(os.path.join(out2, "output_no_tagging.vcf")) == body(os.path.join(tmp, "one_t", "output_no_tagging.vcf"))
+    assert open(os.path.join(out2, "tmp", "CONTIGS")).read() == open(os.path.join(tmp, "one_t", "tmp", "CONTIGS")).read()
+    parts = [n for n in os.listdir(os.path.join(out2, "tmp", "parts")) if n.endswith(".json")]
+    assert sorted(parts) == ["rank0.json", "rank1.json"]
+    import json
+    c0, c1 = (json.load(open(os.path.join(out2, "tmp", "parts", n)))["called"] for n in sorted(parts))
+    assert c0 and c1 and not set(c0) & set(c1)                      # both ranks worked, on different contigs
