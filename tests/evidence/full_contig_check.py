@@ -1,6 +1,6 @@
 # One-off evidence run on the GPU box: the WHOLE synthetic chr20 (BASELINE.json configs[1]) through the HIP path and through
 # the oracle, chunk by chunk — every line (position, ref33, 594 ints, ordered alt_info) and every rescaled tensor identical,
-# probabilities within 1e-4.  ~3 min of host time (the oracle's text stages are single-threaded).  python tools/full_contig_check.py
+# probabilities within 1e-4.  ~3 min of host time (the oracle's text stages are single-threaded).  python tests/evidence/full_contig_check.py
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
