@@ -13,10 +13,12 @@ emitted by both, and with head/tail calling both also emit the candidates inside
 chunk's stream ends there, the other's begins).  sort_vcf keeps the row of whichever per-chunk file os.listdir returns last
 (src/sort_vcf.py:204-236), i.e. an arbitrary one.  Here the LATER chunk's row is kept, always.
 
-Three host stages overlap on threads (the GIL is released inside libc3r / libc3r_io):
-    fetch   BAM region fetch + reference slice of contig i+1, i+2      (libc3r_io.so, FASTA read)
-    device  load / scan / network of contig i                          (libc3r.so, one of two contexts)
-    decode  alt_info + genotype decode + row text of contig i-1        (libc3r.so host threads)
+The host stages overlap on threads (the GIL is released inside libc3r / libc3r_io):
+    fetch    BAM region fetch + reference slice of the next contigs          (libc3r_io.so, FASTA read; --fetch_threads)
+    context  per contig, on one of --contexts GPU contexts, each with its own thread and HIP stream: read normalisation +
+             uploads, tensor build, network, alt_info + genotype decode + row text (libc3r.so) — while one context waits
+             for its kernels the others prepare or decode
+    merge    per-record rules + order, in calling order as the contigs come out (libc3r_io.so)
 
 Not covered (use the reference's own orchestration around call_var_bam for these): whatshap/longphase phasing between the
 two passes (external tools), gVCF.  `--enable_phasing_model` here expects an already haplotagged BAM (HP tags) and runs the
@@ -144,6 +146,7 @@ def build_parser():
     a("--no_compress", action="store_true", help="leave <prefix>.vcf uncompressed (tests)")
     a("--gpu_id", type=int, default=None, help="default: $C3R_DEVICE, else LOCAL_RANK under torch.distributed.run, else 0")
     a("--fetch_threads", type=int, default=4)
+    a("--contexts", type=int, default=1, help="GPU contexts (each with its own host thread and HIP stream) working side by side; more than one pays off once contigs are plentiful and large (every context sizes its own device buffers on its first contigs)")
     return p
 
 
@@ -238,7 +241,7 @@ def Run(args, log=None):
             table = sort_vcf.load_rediportal(src, contigs, tags)
 
     weights = io.load_weights(model, channels)
-    engines = [capi.Engine(args.gpu_id) for _ in range(2)]
+    engines = [capi.Engine(args.gpu_id) for _ in range(max(1, args.contexts))]
     for e in engines:
         e.load_weights(weights, channels)
     qual_rows = args.qual if args.qual is not None else 2              # call_variants.py:1827 (STEP 1 never passes --qual)
@@ -299,11 +302,9 @@ def Run(args, log=None):
 
     part_counts = {}
 
-    def decode_and_merge(eng, ctg, todo):
-        rows = decode_stage(eng, ctg, todo)
-        t0 = time()
+    def merge_contig(ctg, rows):
         if world == 1:
-            merger.add_contig(ctg, rows)      # one decode worker => contigs reach the merger in calling order
+            merger.add_contig(ctg, rows)
         else:                                 # this contig's records on their own; rank 0 concatenates in calling order
             k = all_contigs.index(ctg)
             m = sort_vcf.SampleMerger(os.path.join(parts_dir, "%05d.vcf" % k), "", qual_merge, args.print_ref_calls, table,
@@ -313,7 +314,6 @@ def Run(args, log=None):
             if m.out_nt:
                 m.out_nt.close()
             part_counts[k] = (m.n_read, m.n_kept, m.n_tagged)
-        return time() - t0
 
     bam_fn = args.bam_fn
     if bam_fn.endswith(".bam"):
@@ -332,30 +332,54 @@ def Run(args, log=None):
             bam_fn = link
     fetcher = _Fetcher(bam_fn, args.ref_fn)
     t_setup = time() - t_all
-    n_sites = 0
-    t_fetch = t_dev = 0.0
-    with ThreadPoolExecutor(max(1, args.fetch_threads)) as fetch_pool, ThreadPoolExecutor(1) as decode_pool:
-        fetched = [fetch_pool.submit(fetcher, c, fai[c]) for c in contigs]
-        pending = [None, None]                                         # decode future of each engine
-        results = []
-        for i, ctg in enumerate(contigs):
-            rs, ref, dt = fetched[i].result()
-            fetched[i] = None
-            t_fetch += dt
+    n_ctx = len(engines)
+    slots = threading.BoundedSemaphore(n_ctx + 2)                      # contigs fetched but not yet through their context
+    stats = dict(fetch=0.0, dev=0.0, sites=0)
+    lock = threading.Lock()
+
+    def fetch_task(ctg):
+        slots.acquire()
+        return fetcher(ctg, fai[ctg])
+
+    def context_task(eng, ctg, fut):
+        """One contig on one context, on that context's own thread: host preparation + uploads, tensor build, network, decode.
+        Contexts work side by side — while one waits for its kernels another normalises CIGARs or decodes."""
+        try:
+            rs, ref, dt = fut.result()
             if not len(rs.reads):
-                log("[WARNING] Contig name %s provided but no mapped reads found in BAM, skip!" % ctg)
-                continue
-            eng = engines[i & 1]
-            if pending[i & 1] is not None:
-                pending[i & 1].result()                                # the context is reused: its previous decode must be done
+                return None
             t0 = time()
             todo = device_stage(eng, ctg, rs, ref)
-            t_dev += time() - t0
-            n_sites += todo if isinstance(todo, int) else 0
-            fut = decode_pool.submit(decode_and_merge, eng, ctg, todo)
-            pending[i & 1] = fut
-            results.append((ctg, fut))
-        t_merge = sum(fut.result() for _c, fut in results)
+            t1 = time()
+            rows = decode_stage(eng, ctg, todo)
+            with lock:
+                stats["fetch"] += dt
+                stats["dev"] += t1 - t0
+                stats["sites"] += todo if isinstance(todo, int) else 0
+            return rows
+        finally:
+            slots.release()
+
+    t_merge = 0.0
+    results = []
+    ctx_pools = [ThreadPoolExecutor(1) for _ in engines]
+    with ThreadPoolExecutor(max(1, args.fetch_threads)) as fetch_pool:
+        fetched = [fetch_pool.submit(fetch_task, c) for c in contigs]
+        tasks = [ctx_pools[i % n_ctx].submit(context_task, engines[i % n_ctx], c, fetched[i]) for i, c in enumerate(contigs)]
+        del fetched
+        for i, ctg in enumerate(contigs):                              # merge in calling order as the contigs come out
+            rows = tasks[i].result()
+            tasks[i] = None
+            if rows is None:
+                log("[WARNING] Contig name %s provided but no mapped reads found in BAM, skip!" % ctg)
+                continue
+            t0 = time()
+            merge_contig(ctg, rows)
+            t_merge += time() - t0
+            results.append((ctg, None))
+    for p_ in ctx_pools:
+        p_.shutdown()
+    n_sites, t_fetch, t_dev = stats["sites"], stats["fetch"], stats["dev"]
     fetcher.close()
     called = [c for c, _f in results]
     for e in engines:

@@ -116,8 +116,16 @@ int ensure(c3r_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return C3R_OK;
     size_t want = std::max(bytes, (size_t)256);
     want = want + want / 4;   // grow-only with slack so steady-state steps never reallocate
+    const bool timing = getenv("C3R_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     if (b.p) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const auto t1 = std::chrono::steady_clock::now();
     HIPCHK(ctx, hipMalloc(&b.p, want));
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        const double a = std::chrono::duration<double, std::milli>(t1 - t0).count(), m = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        if (a + m > 1.0) fprintf(stderr, "[ensure %p] %.1f MB: sync+free %.1f ms, malloc %.1f ms\n", (void *)ctx, want / 1e6, a, m);
+    }
     if (poison_byte() >= 0) { HIPCHK(ctx, hipMemsetAsync(b.p, poison_byte(), want, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
     b.cap = want;
     return C3R_OK;

@@ -20,6 +20,7 @@
 //   * 4 wavefronts split the 4H/32 row blocks evenly (H=128: 4 each, H=160: 5 each).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <type_traits>
 #include <stdint.h>
 
@@ -1174,6 +1175,7 @@ inline int net_reserve(NetState &s, int64_t n, hipStream_t st, std::string &err)
     if (need <= s.cap_sites && (!want_y2 || s.d_y2)) return C3R_OK;
     const bool grow = need > s.cap_sites;
     const int64_t cap = grow ? need + need / 4 + 256 : s.cap_sites;
+    const auto t0_ = std::chrono::steady_clock::now();
     NET_HIP(hipStreamSynchronize(st));
     float **bufs[] = {&s.d_y1, &s.d_y2, &s.d_a4, &s.d_probs};
     const size_t sizes[] = {(size_t)cap * NET_T * 2 * NET_H1, (size_t)cap * NET_T * 2 * NET_H2, (size_t)cap * NET_L4 * 2, (size_t)cap * C3R_NPROB};
@@ -1186,6 +1188,7 @@ inline int net_reserve(NetState &s, int64_t n, hipStream_t st, std::string &err)
         if (const char *e = getenv("C3R_POISON")) if (*e) { NET_HIP(hipMemsetAsync(*bufs[i], atoi(e) & 0xff, sizes[i] * sizeof(float), st)); NET_HIP(hipStreamSynchronize(st)); }
     }
     s.cap_sites = cap;
+    if (getenv("C3R_TIMING")) fprintf(stderr, "[net_reserve] %lld sites: %.1f ms\n", (long long)cap, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
     return C3R_OK;
 }
 

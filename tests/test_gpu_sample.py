@@ -78,7 +78,7 @@ def test_sample_equals_per_chunk_flow(tmp_path):
     assert all(r.split("\t")[4] != "." for r in recs)                  # RefCall rows are dropped without --print_ref_calls
     # a BAM without .bai: the driver indexes a link under tmp/ instead of scanning the whole file once per contig
     os.remove(bm + ".bai")
-    again = _run_sample(os.path.join(tmp, "out_noindex"), fa, bm, wfn)
+    again = _run_sample(os.path.join(tmp, "out_noindex"), fa, bm, wfn, ["--contexts", "3", "--fetch_threads", "2"])   # and three contexts side by side
     assert open(again).read() == a and os.path.exists(os.path.join(tmp, "out_noindex", "tmp", "input.bam.bai"))
     assert not os.path.exists(bm + ".bai")
 

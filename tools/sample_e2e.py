@@ -12,6 +12,7 @@ GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 1593
 ap = argparse.ArgumentParser()
 ap.add_argument("--contigs", type=int, default=6); ap.add_argument("--scale", type=float, default=0.25)
 ap.add_argument("--depth", type=float, default=20.0); ap.add_argument("--repeat", type=int, default=2)
+ap.add_argument("--contexts", type=int, default=None); ap.add_argument("--fetch_threads", type=int, default=None)
 ap.add_argument("--chr20", action="store_true", help="one contig: the full synthetic chr20 of BASELINE.json configs[1]")
 ap.add_argument("--check", action="store_true", help="also run call_var_bam per CHUNK_LIST row + sort_vcf and compare the files byte for byte")
 a = ap.parse_args()
@@ -36,6 +37,8 @@ del contigs, reads
 for rep in range(a.repeat):
     out = os.path.join(tmp, "out%d" % rep)
     argv = ["--bam_fn", bm, "--ref_fn", fa, "--output_dir", out, "--pileup_model_path", wfn]
+    if a.contexts: argv += ["--contexts", str(a.contexts)]
+    if a.fetch_threads: argv += ["--fetch_threads", str(a.fetch_threads)]
     msgs = []
     t1 = time.time()
     call_sample.Run(call_sample.build_parser().parse_args(argv), log=msgs.append)
