@@ -337,9 +337,17 @@ def Run(args, log=None):
     stats = dict(fetch=0.0, dev=0.0, sites=0)
     lock = threading.Lock()
 
+    timeline = os.environ.get("C3R_TIMING") is not None
+    def mark(ctg, what, t0):
+        if timeline:
+            log("[timeline] %-6s %-8s %7.3f -> %7.3f s" % (ctg, what, t0 - t_all, time() - t_all))
+
     def fetch_task(ctg):
         slots.acquire()
-        return fetcher(ctg, fai[ctg])
+        t0 = time()
+        r = fetcher(ctg, fai[ctg])
+        mark(ctg, "fetch", t0)
+        return r
 
     def context_task(eng, ctg, fut):
         """One contig on one context, on that context's own thread: host preparation + uploads, tensor build, network, decode.
@@ -351,7 +359,9 @@ def Run(args, log=None):
             t0 = time()
             todo = device_stage(eng, ctg, rs, ref)
             t1 = time()
+            mark(ctg, "device", t0)
             rows = decode_stage(eng, ctg, todo)
+            mark(ctg, "decode", t1)
             with lock:
                 stats["fetch"] += dt
                 stats["dev"] += t1 - t0
@@ -376,6 +386,7 @@ def Run(args, log=None):
             t0 = time()
             merge_contig(ctg, rows)
             t_merge += time() - t0
+            mark(ctg, "merge", t0)
             results.append((ctg, None))
     for p_ in ctx_pools:
         p_.shutdown()

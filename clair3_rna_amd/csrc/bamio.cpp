@@ -317,62 +317,27 @@ int load_bai(c3r_bam *b, const std::string &p) {
     return rc;
 }
 
-int fetch_indexed(c3r_bam *b, int tid, int64_t beg, int64_t end) {
-    const RefIndex &ri = b->bai[tid];
-    std::vector<uint32_t> bins;
-    reg2bins(beg, end, bins);
-    uint64_t min_off = 0;
-    const size_t w = (size_t)(beg >> 14);
-    if (!ri.linear.empty()) min_off = ri.linear[std::min(w, ri.linear.size() - 1)];
-    std::vector<std::pair<uint64_t, uint64_t>> chunks;
-    for (uint32_t bin : bins) {
-        auto it = ri.bins.find(bin);
-        if (it == ri.bins.end()) continue;
-        for (auto &c : it->second) if (c.second > min_off) chunks.emplace_back(std::max(c.first, min_off), c.second);
-    }
-    std::sort(chunks.begin(), chunks.end());
-    // merge overlapping / adjacent chunks so that no record is read twice
-    std::vector<std::pair<uint64_t, uint64_t>> merged;
-    for (auto &c : chunks) {
-        if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second);
-        else merged.push_back(c);
-    }
-    BgzfCursor cur; cur.f = b->file.p; cur.n = b->file.n;
-    std::vector<uint8_t> rec;
-    for (auto &c : merged) {
-        if (!cur.seek(c.first)) return failb(b, C3R_EINVAL, "%s: index points outside the file", b->path.c_str());
-        for (;;) {
-            if (cur.upos == cur.buf.size() && cur.coff + cur.bsize < cur.n && !cur.load(cur.coff + cur.bsize))
-                return failb(b, C3R_EINVAL, "%s: corrupt BGZF block", b->path.c_str());
-            if (cur.tell() >= c.second) break;
-            uint8_t h[4];
-            const int g = cur.read(h, 4);
-            if (g == 0) break;
-            if (g < 0) return failb(b, C3R_EINVAL, "%s: truncated record", b->path.c_str());
-            const size_t bs = le32(h);
-            rec.resize(bs);
-            if (cur.read(rec.data(), bs) != 1) return failb(b, C3R_EINVAL, "%s: truncated record", b->path.c_str());
-            if (take_record(b, rec.data(), bs, tid, beg, end) == 2) return C3R_OK;   // sorted: nothing further can overlap
-        }
-    }
-    return C3R_OK;
-}
-
 struct BlockRef { size_t off, payload, bsize, isize; };
 
-// Whole-file pass: batches of blocks inflated in parallel, records handed to `visit(rec, block_size, voff_begin, voff_end)`
-// in file order; visit returns false to stop.
-template <class F>
-int scan_all(c3r_bam *b, F visit) {
+// BGZF blocks of the file range [off0, off1) (off1 = a block boundary or the file size)
+int list_blocks(c3r_bam *b, size_t off0, size_t off1, std::vector<BlockRef> &blocks) {
     const uint8_t *f = b->file.p; const size_t n = b->file.n;
-    std::vector<BlockRef> blocks;
-    for (size_t off = 0; off < n;) {
+    for (size_t off = off0; off < off1 && off < n;) {
         size_t pl;
         const size_t bs = bgzf_block_size(f, n, off, &pl);
         if (!bs) return failb(b, C3R_EINVAL, "%s: corrupt BGZF block at %zu", b->path.c_str(), off);
         blocks.push_back({off, pl, bs, le32(f + off + bs - 4)});
         off += bs;
     }
+    return C3R_OK;
+}
+
+// Pass over consecutive blocks: batches inflated in parallel, the first `skip` uncompressed bytes ignored (header, or the
+// in-block offset of an index chunk), records handed to `visit(rec, block_size, voff_begin, voff_end)` in file order; visit
+// returns false to stop.
+template <class F>
+int scan_blocks(c3r_bam *b, const std::vector<BlockRef> &blocks, size_t skip, F visit, bool *truncated = nullptr) {
+    const uint8_t *f = b->file.p;
     size_t BATCH = 512;                   // blocks inflated per round (<= 32 MB of records in memory)
     if (const char *e = getenv("C3R_IO_BATCH")) BATCH = (size_t)std::max(1, atoi(e));   // tests: force records across rounds
     const int nt = std::max(1, b->n_threads);
@@ -380,7 +345,6 @@ int scan_all(c3r_bam *b, F visit) {
     uint64_t carry_first_voff = 0;
     std::vector<uint8_t> buf;
     std::vector<size_t> uoff;
-    size_t skip = b->header_bytes;        // uncompressed bytes of header still to skip
     bool stop = false;
     for (size_t b0 = 0; b0 < blocks.size() && !stop; b0 += BATCH) {
         const size_t b1 = std::min(blocks.size(), b0 + BATCH);
@@ -434,6 +398,88 @@ int scan_all(c3r_bam *b, F visit) {
             const size_t bs = le32(buf.data() + u);
             if (!visit(buf.data() + u + 4, bs, voff_of(u), voff_of(u + 4 + bs))) { stop = true; break; }
             u += 4 + bs;
+        }
+    }
+    if (truncated) *truncated = !stop && !carry.empty();      // the listed blocks end inside a record
+    return C3R_OK;
+}
+
+// Whole-file pass (no index, or building one).
+template <class F>
+int scan_all(c3r_bam *b, F visit) {
+    std::vector<BlockRef> blocks;
+    const int rc = list_blocks(b, 0, b->file.n, blocks);
+    if (rc) return rc;
+    return scan_blocks(b, blocks, b->header_bytes, visit);
+}
+
+int fetch_indexed(c3r_bam *b, int tid, int64_t beg, int64_t end) {
+    const RefIndex &ri = b->bai[tid];
+    std::vector<uint32_t> bins;
+    reg2bins(beg, end, bins);
+    uint64_t min_off = 0;
+    const size_t w = (size_t)(beg >> 14);
+    if (!ri.linear.empty()) min_off = ri.linear[std::min(w, ri.linear.size() - 1)];
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    for (uint32_t bin : bins) {
+        auto it = ri.bins.find(bin);
+        if (it == ri.bins.end()) continue;
+        for (auto &c : it->second) if (c.second > min_off) chunks.emplace_back(std::max(c.first, min_off), c.second);
+    }
+    std::sort(chunks.begin(), chunks.end());
+    // merge overlapping / adjacent chunks so that no record is read twice
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    for (auto &c : chunks) {
+        if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second);
+        else merged.push_back(c);
+    }
+    BgzfCursor cur; cur.f = b->file.p; cur.n = b->file.n;
+    std::vector<uint8_t> rec;
+    for (auto &c : merged) {
+        // a long chunk (a whole contig, typically): inflate its blocks on all threads instead of one by one.  A record that
+        // begins before c.second may end blocks later, so blocks are listed a margin past it, and further if that was short.
+        const size_t c0 = (size_t)(c.first >> 16), c1 = (size_t)(c.second >> 16);
+        size_t par_min = (size_t)1 << 20, margin0 = (size_t)4 << 20;
+        if (const char *e = getenv("C3R_IO_PAR_MIN")) par_min = (size_t)atoll(e);       // tests: force either path
+        if (const char *e = getenv("C3R_IO_MARGIN")) margin0 = (size_t)std::max(1LL, atoll(e));
+        if (b->n_threads > 1 && c1 - c0 >= par_min) {
+            bool done = false, past = false;
+            for (size_t margin = margin0; !done; margin *= 4) {
+                std::vector<BlockRef> blocks;
+                const size_t lim = std::min(b->file.n, c1 + margin);
+                int rc = list_blocks(b, c0, lim, blocks);
+                if (rc) return rc;
+                const size_t n_reads0 = b->reads.size(), n_cig0 = b->cigar.size(), n_seq0 = b->seq.size();
+                bool truncated = false;
+                past = false;
+                rc = scan_blocks(b, blocks, (size_t)(c.first & 0xffff), [&](const uint8_t *r, size_t bs, uint64_t v0, uint64_t) {
+                    if (v0 >= c.second) return false;
+                    if (take_record(b, r, bs, tid, beg, end) == 2) { past = true; return false; }
+                    return true;
+                }, &truncated);
+                if (rc) return rc;
+                if (truncated && lim < b->file.n) {        // start over with more blocks (rare: a record longer than the margin)
+                    b->reads.resize(n_reads0); b->cigar.resize(n_cig0); b->seq.resize(n_seq0);
+                    continue;
+                }
+                done = true;
+            }
+            if (past) return C3R_OK;                       // sorted: nothing further can overlap
+            continue;
+        }
+        if (!cur.seek(c.first)) return failb(b, C3R_EINVAL, "%s: index points outside the file", b->path.c_str());
+        for (;;) {
+            if (cur.upos == cur.buf.size() && cur.coff + cur.bsize < cur.n && !cur.load(cur.coff + cur.bsize))
+                return failb(b, C3R_EINVAL, "%s: corrupt BGZF block", b->path.c_str());
+            if (cur.tell() >= c.second) break;
+            uint8_t h[4];
+            const int g = cur.read(h, 4);
+            if (g == 0) break;
+            if (g < 0) return failb(b, C3R_EINVAL, "%s: truncated record", b->path.c_str());
+            const size_t bs = le32(h);
+            rec.resize(bs);
+            if (cur.read(rec.data(), bs) != 1) return failb(b, C3R_EINVAL, "%s: truncated record", b->path.c_str());
+            if (take_record(b, rec.data(), bs, tid, beg, end) == 2) return C3R_OK;   // sorted: nothing further can overlap
         }
     }
     return C3R_OK;

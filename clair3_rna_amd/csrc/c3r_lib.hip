@@ -845,7 +845,7 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
 int c3r_get_probs(c3r_ctx *ctx, float *probs, int64_t n) {
     if (!ctx || !probs || n < 0) return C3R_EINVAL;
     if (n == 0) return C3R_OK;
-    if (!ctx->net.d_probs || n > ctx->net.cap_sites) return fail(ctx, C3R_EINVAL, "no probabilities resident for %lld sites", (long long)n);
+    if (!ctx->net.d_probs || n > ctx->net.cap_probs) return fail(ctx, C3R_EINVAL, "no probabilities resident for %lld sites", (long long)n);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, (size_t)n * C3R_NPROB * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -874,7 +874,7 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
     const int64_t n = ctx->n_cand;
     *out_len = 0; if (n_rows) *n_rows = 0;
     if (n == 0) return C3R_OK;
-    if (!ctx->net.d_probs || n > ctx->net.cap_sites) return fail(ctx, C3R_EINVAL, "c3r_infer must run before c3r_call_rows");
+    if (!ctx->net.d_probs || n > ctx->net.cap_probs) return fail(ctx, C3R_EINVAL, "c3r_infer must run before c3r_call_rows");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool timing = getenv("C3R_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };

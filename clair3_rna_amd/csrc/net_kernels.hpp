@@ -949,6 +949,7 @@ struct NetState {
     half8 *d_w1h = nullptr, *d_w2h = nullptr, *d_w4h = nullptr, *d_w4f = nullptr;   // d_w4f: L4 packed per (dir, t) for the fused path   // split-f16 packed weights (hi/lo, x 2^12)
     int precision = 1;            // 0 = fp32 MFMA, 1 = split-f16 (f16x3, fp32-equivalent)
     float *d_y1 = nullptr, *d_y2 = nullptr, *d_a4 = nullptr, *d_probs = nullptr;
+    int64_t cap_probs = 0;           // sites d_probs holds (the whole batch); cap_sites bounds one network slice
     int64_t cap_sites = 0;
 };
 
@@ -1169,17 +1170,31 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
     return C3R_OK;
 }
 
-inline int net_reserve(NetState &s, int64_t n, hipStream_t st, std::string &err) {
+// The network runs over the batch in slices of at most NET_SLICE sites: the layer-1 output is 33.8 KB per site (a 0.8 M-site
+// contig would take 27 GB, and sizing that buffer cost 1.2 s), a slice of 2^18 sites is 1024 workgroup rounds of layer 2 —
+// far beyond what the launch needs to fill the chip — and BASELINE's chr20 batch (201,945 sites) is still one slice.
+constexpr int64_t NET_SLICE = 262144;
+
+inline int net_reserve(NetState &s, int64_t n_total, hipStream_t st, std::string &err) {
+    const int64_t n = std::min(n_total, NET_SLICE);
     const int64_t need = (n + 127) / 128 * 128;    // the y1 planes are stored with the site stride rounded up to 128
     const bool want_y2 = s.precision != 1;         // split-f16 fuses L4 into layer 2: y2 (42 KB per site) is never materialised
+    if (n_total > s.cap_probs) {
+        NET_HIP(hipStreamSynchronize(st));
+        if (s.d_probs) { (void)hipFree(s.d_probs); s.d_probs = nullptr; }
+        const int64_t cap = n_total + n_total / 4 + 256;
+        NET_HIP(hipMalloc((void **)&s.d_probs, (size_t)cap * C3R_NPROB * sizeof(float)));
+        if (const char *e = getenv("C3R_POISON")) if (*e) { NET_HIP(hipMemsetAsync(s.d_probs, atoi(e) & 0xff, (size_t)cap * C3R_NPROB * sizeof(float), st)); NET_HIP(hipStreamSynchronize(st)); }
+        s.cap_probs = cap;
+    }
     if (need <= s.cap_sites && (!want_y2 || s.d_y2)) return C3R_OK;
     const bool grow = need > s.cap_sites;
-    const int64_t cap = grow ? need + need / 4 + 256 : s.cap_sites;
+    const int64_t cap = grow ? std::min((need + need / 4 + 256 + 127) / 128 * 128, NET_SLICE) : s.cap_sites;
     const auto t0_ = std::chrono::steady_clock::now();
     NET_HIP(hipStreamSynchronize(st));
-    float **bufs[] = {&s.d_y1, &s.d_y2, &s.d_a4, &s.d_probs};
-    const size_t sizes[] = {(size_t)cap * NET_T * 2 * NET_H1, (size_t)cap * NET_T * 2 * NET_H2, (size_t)cap * NET_L4 * 2, (size_t)cap * C3R_NPROB};
-    for (int i = 0; i < 4; ++i) {
+    float **bufs[] = {&s.d_y1, &s.d_y2, &s.d_a4};
+    const size_t sizes[] = {(size_t)cap * NET_T * 2 * NET_H1, (size_t)cap * NET_T * 2 * NET_H2, (size_t)cap * NET_L4 * 2};
+    for (int i = 0; i < 3; ++i) {
         const bool is_y2 = i == 1;
         if (!grow && !is_y2) continue;                                   // only y2 is missing (precision switched to fp32)
         if (*bufs[i]) { (void)hipFree(*bufs[i]); *bufs[i] = nullptr; }
@@ -1188,15 +1203,28 @@ inline int net_reserve(NetState &s, int64_t n, hipStream_t st, std::string &err)
         if (const char *e = getenv("C3R_POISON")) if (*e) { NET_HIP(hipMemsetAsync(*bufs[i], atoi(e) & 0xff, sizes[i] * sizeof(float), st)); NET_HIP(hipStreamSynchronize(st)); }
     }
     s.cap_sites = cap;
-    if (getenv("C3R_TIMING")) fprintf(stderr, "[net_reserve] %lld sites: %.1f ms\n", (long long)cap, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
+    if (getenv("C3R_TIMING")) fprintf(stderr, "[net_reserve] %lld sites per slice: %.1f ms\n", (long long)cap, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count());
     return C3R_OK;
 }
 
 // d_x: device int32 [n][33][C].  prof(name, 0|1) brackets each kernel for optional event timing.
+inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *d_probs, hipStream_t st,
+                             const std::function<void(const char *, int)> &prof, std::string &err);
+
 inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t st,
                        const std::function<void(const char *, int)> &prof, std::string &err) {
     int rc = net_reserve(s, n, st, err);
     if (rc) return rc;
+    const int64_t step = std::min(n, NET_SLICE);
+    for (int64_t off = 0; off < n; off += step) {
+        const int64_t m = std::min(step, n - off);
+        if ((rc = net_forward_slice(s, d_x + (size_t)off * NET_T * s.channels, m, s.d_probs + (size_t)off * C3R_NPROB, st, prof, err))) return rc;
+    }
+    return C3R_OK;
+}
+
+inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *d_probs, hipStream_t st,
+                             const std::function<void(const char *, int)> &prof, std::string &err) {
     const int nb = (int)((n + NET_SITES - 1) / NET_SITES);
     const dim3 grid((unsigned)((n + LSTM_SITES - 1) / LSTM_SITES), 2), block(256);
     int heads_parts = 1;
@@ -1253,7 +1281,7 @@ inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t s
     }
     prof("k_heads", 0);
     hipLaunchKernelGGL(k_heads, dim3((unsigned)((n + HEAD_SITES - 1) / HEAD_SITES)), block, 0, st, (const float *)s.d_a4, heads_parts, (const float *)s.d_b4, (const float *)s.d_w5,
-                       (const float *)s.d_b5, (const float *)s.d_wo, (const float *)s.d_bo, s.d_probs, (int)n);
+                       (const float *)s.d_b5, (const float *)s.d_wo, (const float *)s.d_bo, d_probs, (int)n);
     prof("k_heads", 1);
     NET_HIP(hipGetLastError());
     return C3R_OK;

@@ -198,3 +198,30 @@ def test_unsorted_file_is_refused_by_the_indexer(tmp_path):
     open(str(tmp_path / "junk.bam"), "wb").write(b"not a bam at all")
     with pytest.raises(IOError):
         bamio.BamFile(str(tmp_path / "junk.bam"))
+
+
+@pytest.mark.parametrize("margin,batch", [("1", "3"), ("70000", "512"), ("4194304", "1")])
+def test_long_index_chunks_inflate_in_parallel(bam_case, margin, batch, monkeypatch):
+    """Indexed fetches whose chunk is long (a whole contig) inflate their blocks on threads (scan_blocks) instead of through the
+    one-block cursor.  Forced here on a small file: every chunk takes the parallel path, with a margin so short that records
+    run past the listed blocks (the fetch must start over with more), and with batches of 1-3 blocks (records across rounds)."""
+    rs, rs2 = bam_case["rs"], bam_case["rs2"]
+    end = _ref_end(rs)
+    pos = rs.reads["pos"].astype(np.int64)
+    bai = bamio.index_build(bam_case["path"])
+    try:
+        monkeypatch.setenv("C3R_IO_PAR_MIN", str(1 << 40))            # cursor path: the reference result
+        with bamio.BamFile(bam_case["path"], threads=4) as bf:
+            want = [bf.fetch("chr20"), bf.fetch("chr21"), bf.fetch("chr20", 123456, 234567), bf.fetch("chr20", 590000, 600000)]
+        monkeypatch.setenv("C3R_IO_PAR_MIN", "0")
+        monkeypatch.setenv("C3R_IO_MARGIN", margin)
+        monkeypatch.setenv("C3R_IO_BATCH", batch)
+        with bamio.BamFile(bam_case["path"], threads=4) as bf:
+            got = [bf.fetch("chr20"), bf.fetch("chr21"), bf.fetch("chr20", 123456, 234567), bf.fetch("chr20", 590000, 600000)]
+            assert len(bf.fetch("chrEmpty")) == 0
+        for g, w in zip(got, want):
+            _same(g, w)
+        _same(got[0], rs); _same(got[1], rs2)
+        _same(got[2], _subset(rs, (pos < 234567) & (end > 123456)))
+    finally:
+        os.remove(bai)

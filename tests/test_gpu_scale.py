@@ -173,3 +173,27 @@ def test_two_contexts_on_two_streams_like_the_bench(eng):
             assert np.array_equal(g, want)          # same kernels, same data: bitwise equal
     finally:
         e2.close()
+
+
+def test_network_slices_a_batch_larger_than_one_slice(eng):
+    """net_forward runs the network over at most NET_SLICE (2^18) sites at a time; a batch above that must give, site by site,
+    what the same windows give in small batches (the kernels are position-independent), in both precisions."""
+    from clair3_rna_amd import capi, synth
+    rng = np.random.default_rng(5)
+    base = rng.integers(-40, 60, size=(4096, 33, 18), dtype=np.int32)
+    n = 262144 + 70000 + 37                        # two slices, the second ragged
+    X = base[rng.integers(0, len(base), size=n)]
+    w = synth.random_weights(18, seed=11)
+    eng.load_weights(w, 18)
+    for mode in ("f16x3", "f32"):
+        eng.set_precision(mode)
+        p_small = eng.infer(base)
+        idx = rng.integers(0, n, size=3000)
+        idx[:6] = [0, 262143, 262144, 262145, n - 1, n - 38]
+        # map back: which base window each sampled site is
+        p_big = eng.infer(X)
+        for i in idx[:50]:
+            k = int(np.nonzero((base == X[i]).all(axis=(1, 2)))[0][0])
+            assert np.array_equal(p_big[i], p_small[k]), (mode, int(i))
+        assert np.isfinite(p_big).all() and np.allclose(p_big.sum(axis=1)[:, None] > 0, True)
+    eng.set_precision("f16x3")

@@ -46,7 +46,7 @@ for rep in range(a.repeat):
     n_sites = int([m for m in msgs if "candidate sites" in m][0].split(" contigs, ")[1].split(" candidate")[0])
     print("run %d: BAM -> %s in %.2f s : %.0f candidate sites, %.2f M sites/s host-inclusive" % (rep, os.path.basename(out) + "/output.vcf.gz", dt, n_sites, n_sites / dt / 1e6))
     for m in msgs:
-        if "device_stage" in m or m is msgs[-1]: print("   ", m)
+        if "device_stage" in m or "timeline" in m or m is msgs[-1]: print("   ", m)
 
 if a.check:
     from clair3_rna_amd import call_var_bam, capi, sort_vcf
