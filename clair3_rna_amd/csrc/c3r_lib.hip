@@ -307,88 +307,132 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     if (!ctx || n_reads < 0 || (n_reads && (!reads || !cigars || !seq4))) return C3R_EINVAL;
     if (n_reads > INT32_MAX) return fail(ctx, C3R_EINVAL, "too many reads");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool timing = getenv("C3R_TIMING") != nullptr;
+    std::vector<std::chrono::steady_clock::time_point> tp;
+    auto tick = [&] { if (timing) tp.push_back(std::chrono::steady_clock::now()); };
+    tick();
     ctx->h_reads.clear(); ctx->h_cigar.clear(); ctx->h_segs.clear();
-    ctx->h_reads.reserve((size_t)n_reads);
-    ctx->h_cigar.reserve((size_t)n_cigar_ops);
     ctx->n_indel_ops = 0;
-    int32_t prev_pos = INT_MIN;
-    for (int64_t i = 0; i < n_reads; ++i) {
-        const c3r_read_t &r = reads[i];
-        if (r.pos < prev_pos) return fail(ctx, C3R_EINVAL, "reads must be sorted by pos (read %lld)", (long long)i);
-        prev_pos = r.pos;
-        if ((int64_t)r.cigar_off + r.n_cigar > n_cigar_ops) return fail(ctx, C3R_EINVAL, "cigar range of read %lld out of bounds", (long long)i);
-        if ((int64_t)r.seq_off + (r.l_seq + 1) / 2 > n_seq_bytes) return fail(ctx, C3R_EINVAL, "seq range of read %lld out of bounds", (long long)i);
-        DevRead d;
-        d.pos = r.pos; d.cig_off = (uint32_t)ctx->h_cigar.size(); d.seq_off = r.seq_off; d.flag = r.flag; d.mapq = r.mapq;
-        d.hp = r.hp; d.l_seq = r.l_seq;
-        int64_t rlen = 0;
-        // normalise: drop P/H/zero-length, fold =/X into M, merge adjacent equal ops (htslib merges runs of
-        // D and of I when it attaches an indel to a column, and skips pads)
-        for (uint32_t k = 0; k < r.n_cigar; ++k) {
-            uint32_t c = cigars[r.cigar_off + k];
-            uint32_t op = c & 15u, len = c >> 4;
-            if (op == C3R_CIG_EQ || op == C3R_CIG_X) op = C3R_CIG_M;
-            if (len == 0 || op == C3R_CIG_H) continue;
-            if (op == C3R_CIG_P) {
-                // htslib marks a deletion only when the D op IMMEDIATELY follows the M/N op that ends on the column (a pad
-                // in between hides it; insertions are found through pads).  So a pad is kept — as a 1-long op that consumes
-                // nothing — exactly when the next real op is a D; every other pad is dropped.
-                uint32_t k2 = k + 1;
-                while (k2 < r.n_cigar && ((cigars[r.cigar_off + k2] >> 4) == 0 || (cigars[r.cigar_off + k2] & 15u) == C3R_CIG_P ||
-                                          (cigars[r.cigar_off + k2] & 15u) == C3R_CIG_H)) ++k2;
-                if (k2 >= r.n_cigar || (cigars[r.cigar_off + k2] & 15u) != C3R_CIG_D) continue;
-                len = 1;
-            }
-            if (op > C3R_CIG_X) return fail(ctx, C3R_EINVAL, "bad cigar op in read %lld", (long long)i);
-            if (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) rlen += len;
-            if (ctx->h_cigar.size() > d.cig_off && (ctx->h_cigar.back() & 15u) == op) {
-                const uint64_t nl = (uint64_t)(ctx->h_cigar.back() >> 4) + len;
-                if (nl >= (1u << 28)) return fail(ctx, C3R_EINVAL, "cigar op too long in read %lld", (long long)i);
-                ctx->h_cigar.back() = (uint32_t)(nl << 4) | op;
-            } else {
-                ctx->h_cigar.push_back((len << 4) | op);
-            }
-        }
-        d.n_cig = (uint32_t)(ctx->h_cigar.size() - d.cig_off);
-        for (uint32_t k = 0; k < d.n_cig; ++k) {
-            const uint32_t op = ctx->h_cigar[d.cig_off + k] & 15u;
-            if (op == C3R_CIG_I || op == C3R_CIG_D) ctx->n_indel_ops++;
-        }
-        if ((int64_t)r.pos + rlen > INT32_MAX) return fail(ctx, C3R_EINVAL, "read %lld ends beyond 2^31", (long long)i);
-        d.end = (int32_t)(r.pos + rlen);
-        ctx->h_reads.push_back(d);
-        // aligned segments: the runs of ops between N ops
-        {
-            int64_t x = r.pos, y = 0;
-            uint32_t k = 0;
-            bool after_n = false;
-            while (k < d.n_cig) {
-                DevSeg g;
-                memset(&g, 0, sizeof g);
-                g.pos = (int32_t)x; g.cig_off = d.cig_off + k; g.qstart = (uint32_t)y; g.l_seq = d.l_seq; g.seq_off = d.seq_off;
-                g.read_idx = (uint32_t)i; g.flag = d.flag; g.mapq = d.mapq; g.hp = d.hp; g.lead_n = after_n ? 1 : 0;
-                const uint32_t first_op = ctx->h_cigar[d.cig_off + k] & 15u;
-                uint32_t k1 = k;
-                bool useful = false;
-                while (k1 < d.n_cig && (ctx->h_cigar[d.cig_off + k1] & 15u) != C3R_CIG_N) {
-                    const uint32_t c = ctx->h_cigar[d.cig_off + k1], op = c & 15u, len = c >> 4;
-                    if (op == C3R_CIG_M || op == C3R_CIG_D) { x += len; useful = true; }
-                    if (op == C3R_CIG_M || op == C3R_CIG_I || op == C3R_CIG_S) y += len;
-                    ++k1;
+    // Normalisation is per read; only the offsets into the flat cigar array depend on the reads before.  Slices of reads go to
+    // threads with private outputs (cig_off relative to the slice) and are stitched together afterwards.
+    struct Slice {
+        std::vector<DevRead> reads; std::vector<uint32_t> cigar; std::vector<DevSeg> segs; int64_t n_indel = 0; std::string err;
+        bool fail(const char *fmt, long long i) { char b[160]; snprintf(b, sizeof b, fmt, i); err = b; return false; }
+    };
+    auto norm = [&](int64_t i0, int64_t i1, Slice &o) -> bool {
+        o.reads.reserve((size_t)(i1 - i0));
+        int32_t prev_pos = i0 > 0 ? reads[i0 - 1].pos : INT_MIN;
+        for (int64_t i = i0; i < i1; ++i) {
+            const c3r_read_t &r = reads[i];
+            if (r.pos < prev_pos) return o.fail("reads must be sorted by pos (read %lld)", (long long)i);
+            prev_pos = r.pos;
+            if ((int64_t)r.cigar_off + r.n_cigar > n_cigar_ops) return o.fail("cigar range of read %lld out of bounds", (long long)i);
+            if ((int64_t)r.seq_off + (r.l_seq + 1) / 2 > n_seq_bytes) return o.fail("seq range of read %lld out of bounds", (long long)i);
+            DevRead d;
+            d.pos = r.pos; d.cig_off = (uint32_t)o.cigar.size(); d.seq_off = r.seq_off; d.flag = r.flag; d.mapq = r.mapq;
+            d.hp = r.hp; d.l_seq = r.l_seq;
+            int64_t rlen = 0;
+            // normalise: drop P/H/zero-length, fold =/X into M, merge adjacent equal ops (htslib merges runs of
+            // D and of I when it attaches an indel to a column, and skips pads)
+            for (uint32_t k = 0; k < r.n_cigar; ++k) {
+                uint32_t c = cigars[r.cigar_off + k];
+                uint32_t op = c & 15u, len = c >> 4;
+                if (op == C3R_CIG_EQ || op == C3R_CIG_X) op = C3R_CIG_M;
+                if (len == 0 || op == C3R_CIG_H) continue;
+                if (op == C3R_CIG_P) {
+                    // htslib marks a deletion only when the D op IMMEDIATELY follows the M/N op that ends on the column (a pad
+                    // in between hides it; insertions are found through pads).  So a pad is kept — as a 1-long op that consumes
+                    // nothing — exactly when the next real op is a D; every other pad is dropped.
+                    uint32_t k2 = k + 1;
+                    while (k2 < r.n_cigar && ((cigars[r.cigar_off + k2] >> 4) == 0 || (cigars[r.cigar_off + k2] & 15u) == C3R_CIG_P ||
+                                              (cigars[r.cigar_off + k2] & 15u) == C3R_CIG_H)) ++k2;
+                    if (k2 >= r.n_cigar || (cigars[r.cigar_off + k2] & 15u) != C3R_CIG_D) continue;
+                    len = 1;
                 }
-                const bool lead_indel = after_n && (first_op == C3R_CIG_I || first_op == C3R_CIG_D);
-                if (k1 > k && (useful || lead_indel)) {
-                    if (k1 - k > 0xffff) return fail(ctx, C3R_EINVAL, "read %lld: more than 65535 CIGAR ops between two N ops", (long long)i);
-                    g.n_cig = (uint16_t)(k1 - k);
-                    g.ext_start = g.pos - (lead_indel ? 1 : 0);
-                    g.end = (int32_t)std::max<int64_t>(x, (int64_t)g.ext_start + 1);
-                    ctx->h_segs.push_back(g);
+                if (op > C3R_CIG_X) return o.fail("bad cigar op in read %lld", (long long)i);
+                if (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) rlen += len;
+                if (o.cigar.size() > d.cig_off && (o.cigar.back() & 15u) == op) {
+                    const uint64_t nl = (uint64_t)(o.cigar.back() >> 4) + len;
+                    if (nl >= (1u << 28)) return o.fail("cigar op too long in read %lld", (long long)i);
+                    o.cigar.back() = (uint32_t)(nl << 4) | op;
+                } else {
+                    o.cigar.push_back((len << 4) | op);
                 }
-                if (k1 < d.n_cig) { x += ctx->h_cigar[d.cig_off + k1] >> 4; after_n = true; ++k1; }   // the N op itself
-                k = k1;
+            }
+            d.n_cig = (uint32_t)(o.cigar.size() - d.cig_off);
+            for (uint32_t k = 0; k < d.n_cig; ++k) {
+                const uint32_t op = o.cigar[d.cig_off + k] & 15u;
+                if (op == C3R_CIG_I || op == C3R_CIG_D) o.n_indel++;
+            }
+            if ((int64_t)r.pos + rlen > INT32_MAX) return o.fail("read %lld ends beyond 2^31", (long long)i);
+            d.end = (int32_t)(r.pos + rlen);
+            o.reads.push_back(d);
+            // aligned segments: the runs of ops between N ops
+            {
+                int64_t x = r.pos, y = 0;
+                uint32_t k = 0;
+                bool after_n = false;
+                while (k < d.n_cig) {
+                    DevSeg g;
+                    memset(&g, 0, sizeof g);
+                    g.pos = (int32_t)x; g.cig_off = d.cig_off + k; g.qstart = (uint32_t)y; g.l_seq = d.l_seq; g.seq_off = d.seq_off;
+                    g.read_idx = (uint32_t)i; g.flag = d.flag; g.mapq = d.mapq; g.hp = d.hp; g.lead_n = after_n ? 1 : 0;
+                    const uint32_t first_op = o.cigar[d.cig_off + k] & 15u;
+                    uint32_t k1 = k;
+                    bool useful = false;
+                    while (k1 < d.n_cig && (o.cigar[d.cig_off + k1] & 15u) != C3R_CIG_N) {
+                        const uint32_t c = o.cigar[d.cig_off + k1], op = c & 15u, len = c >> 4;
+                        if (op == C3R_CIG_M || op == C3R_CIG_D) { x += len; useful = true; }
+                        if (op == C3R_CIG_M || op == C3R_CIG_I || op == C3R_CIG_S) y += len;
+                        ++k1;
+                    }
+                    const bool lead_indel = after_n && (first_op == C3R_CIG_I || first_op == C3R_CIG_D);
+                    if (k1 > k && (useful || lead_indel)) {
+                        if (k1 - k > 0xffff) return o.fail("read %lld: more than 65535 CIGAR ops between two N ops", (long long)i);
+                        g.n_cig = (uint16_t)(k1 - k);
+                        g.ext_start = g.pos - (lead_indel ? 1 : 0);
+                        g.end = (int32_t)std::max<int64_t>(x, (int64_t)g.ext_start + 1);
+                        o.segs.push_back(g);
+                    }
+                    if (k1 < d.n_cig) { x += o.cigar[d.cig_off + k1] >> 4; after_n = true; ++k1; }   // the N op itself
+                    k = k1;
+                }
             }
         }
+        return true;
+    };
+    unsigned nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>({16, (int64_t)std::thread::hardware_concurrency(), n_reads / 8192}));
+    if (const char *e = getenv("C3R_THREADS")) nt = (unsigned)std::max(1, std::min(atoi(e), (int)std::max<int64_t>(1, n_reads)));
+    std::vector<Slice> sl(nt);
+    std::vector<char> ok(nt, 1);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back([&, t] { ok[t] = norm(n_reads * t / nt, n_reads * (t + 1) / nt, sl[t]); });
+        ok[0] = norm(0, n_reads / nt, sl[0]);
+        for (auto &x : th) x.join();
     }
+    for (unsigned t = 0; t < nt; ++t) if (!ok[t]) return fail(ctx, C3R_EINVAL, "%s", sl[t].err.c_str());
+    {
+        size_t nr = 0, nc = 0, ns = 0;
+        for (auto &o : sl) { nr += o.reads.size(); nc += o.cigar.size(); ns += o.segs.size(); }
+        if (nc > UINT32_MAX) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
+        ctx->h_reads.resize(nr); ctx->h_cigar.resize(nc); ctx->h_segs.resize(ns);
+        std::vector<size_t> br(nt + 1, 0), bc(nt + 1, 0), bs(nt + 1, 0);
+        for (unsigned t = 0; t < nt; ++t) { br[t + 1] = br[t] + sl[t].reads.size(); bc[t + 1] = bc[t] + sl[t].cigar.size(); bs[t + 1] = bs[t] + sl[t].segs.size(); }
+        auto stitch = [&](unsigned t) {
+            Slice &o = sl[t];
+            const uint32_t base = (uint32_t)bc[t];
+            for (size_t k = 0; k < o.reads.size(); ++k) { DevRead d = o.reads[k]; d.cig_off += base; ctx->h_reads[br[t] + k] = d; }
+            if (!o.cigar.empty()) memcpy(&ctx->h_cigar[bc[t]], o.cigar.data(), o.cigar.size() * 4);
+            for (size_t k = 0; k < o.segs.size(); ++k) { DevSeg g = o.segs[k]; g.cig_off += base; ctx->h_segs[bs[t] + k] = g; }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(stitch, t);
+        stitch(0);
+        for (auto &x : th) x.join();
+        for (auto &o : sl) ctx->n_indel_ops += o.n_indel;
+    }
+    tick();
     {   // read-order copy of the segments (for the per-candidate token kernel) before the global sort
         std::vector<uint32_t> first((size_t)n_reads + 1, 0);
         for (const DevSeg &g : ctx->h_segs) first[g.read_idx + 1]++;
@@ -398,16 +442,61 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
         if ((rc2 = upload(ctx, ctx->d_rseg_first, first.data(), first.size()))) return rc2;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    std::stable_sort(ctx->h_segs.begin(), ctx->h_segs.end(), [](const DevSeg &a, const DevSeg &b) { return a.ext_start < b.ext_start; });
+    tick();
+    {   // stable order by ext_start: sort (key, index) pairs — 8 bytes instead of the 48-byte records — then gather
+        const size_t ns = ctx->h_segs.size();
+        std::vector<uint64_t> key(ns);
+        for (size_t k = 0; k < ns; ++k) key[k] = ((uint64_t)(uint32_t)(ctx->h_segs[k].ext_start ^ INT32_MIN) << 32) | (uint32_t)k;
+        // runs sorted on threads, then merged pairwise (the keys are unique, so any correct sort is the stable one)
+        unsigned parts = 1;
+        while (parts < 8 && ns / (parts * 2) >= 65536) parts *= 2;
+        std::vector<size_t> cut(parts + 1);
+        for (unsigned q = 0; q <= parts; ++q) cut[q] = ns * q / parts;
+        {
+            std::vector<std::thread> th;
+            for (unsigned q = 1; q < parts; ++q) th.emplace_back([&, q] { std::sort(key.begin() + (long)cut[q], key.begin() + (long)cut[q + 1]); });
+            std::sort(key.begin(), key.begin() + (long)cut[1]);
+            for (auto &x : th) x.join();
+        }
+        std::vector<uint64_t> tmp(parts > 1 ? ns : 0);
+        for (unsigned w = 1; w < parts; w *= 2) {
+            std::vector<std::thread> th;
+            for (unsigned q = 0; q + w < parts + 0u; q += 2 * w)
+                th.emplace_back([&, q, w] {
+                    const size_t a = cut[q], m = cut[q + w], e = cut[std::min(q + 2 * w, parts)];
+                    std::merge(key.begin() + (long)a, key.begin() + (long)m, key.begin() + (long)m, key.begin() + (long)e, tmp.begin() + (long)a);
+                    std::copy(tmp.begin() + (long)a, tmp.begin() + (long)e, key.begin() + (long)a);
+                });
+            for (auto &x : th) x.join();
+        }
+        std::vector<DevSeg> sorted(ns);
+        {
+            auto gather = [&](size_t a, size_t e) { for (size_t k = a; k < e; ++k) sorted[k] = ctx->h_segs[(uint32_t)key[k]]; };
+            std::vector<std::thread> th;
+            for (unsigned q = 1; q < parts; ++q) th.emplace_back(gather, cut[q], cut[q + 1]);
+            gather(0, cut[1]);
+            for (auto &x : th) x.join();
+        }
+        ctx->h_segs.swap(sorted);
+    }
+    tick();
     ctx->h_seq.assign(seq4, seq4 + n_seq_bytes);
     ctx->h_seq.resize((size_t)n_seq_bytes + 16, 0);        // the walk reads the packed bases 8 bytes at a time
+    tick();
     int rc;
     if ((rc = upload(ctx, ctx->d_reads, ctx->h_reads.data(), ctx->h_reads.size()))) return rc;
     if ((rc = upload(ctx, ctx->d_cigar, ctx->h_cigar.data(), ctx->h_cigar.size()))) return rc;
     if ((rc = upload(ctx, ctx->d_seq, ctx->h_seq.data(), ctx->h_seq.size()))) return rc;
     if ((rc = upload(ctx, ctx->d_segs, ctx->h_segs.data(), ctx->h_segs.size()))) return rc;
+    tick();
     if ((rc = upload_prefmax(ctx))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    tick();
+    if (timing) {
+        auto ms = [&](int a, int b) { return std::chrono::duration<double, std::milli>(tp[b] - tp[a]).count(); };
+        fprintf(stderr, "[c3r_load_reads] %lld reads, %zu segments: normalise %.1f ms, read-order segments %.1f ms, sort %.1f ms, seq copy %.1f ms, uploads %.1f ms, prefix max %.1f ms\n",
+                (long long)n_reads, ctx->h_segs.size(), ms(0, 1), ms(1, 2), ms(2, 3), ms(3, 4), ms(4, 5), ms(5, 6));
+    }
     return C3R_OK;
 }
 
@@ -416,11 +505,19 @@ int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->h_ref.resize((size_t)len);
     {
-        char *dst = &ctx->h_ref[0];
-        for (int64_t i = 0; i < len; ++i) {          // branch-free, so the loop vectorises (64 MB per contig)
-            const unsigned char c = (unsigned char)ref[i];
-            dst[i] = (char)(c - (((unsigned)(c - 'a') < 26u) << 5));
-        }
+        char *dst = len ? &ctx->h_ref[0] : nullptr;
+        auto upper = [&](int64_t a, int64_t e) {
+            for (int64_t i = a; i < e; ++i) {        // branch-free, so the loop vectorises
+                const unsigned char c = (unsigned char)ref[i];
+                dst[i] = (char)(c - (((unsigned)(c - 'a') < 26u) << 5));
+            }
+        };
+        // a 250 MB chromosome is memory-bound work for one core: split it (first-touch of the fresh pages included)
+        const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({8, (int64_t)std::thread::hardware_concurrency(), len >> 23}));
+        std::vector<std::thread> th;
+        for (int64_t t = 1; t < nt; ++t) th.emplace_back(upper, len * t / nt, len * (t + 1) / nt);
+        upper(0, len / nt);
+        for (auto &x : th) x.join();
     }
     ctx->ref_start1 = ref_start;
     int rc = upload(ctx, ctx->d_ref, (const uint8_t *)ctx->h_ref.data(), ctx->h_ref.size());
