@@ -197,3 +197,31 @@ def test_network_slices_a_batch_larger_than_one_slice(eng):
             assert np.array_equal(p_big[i], p_small[k]), (mode, int(i))
         assert np.isfinite(p_big).all() and np.allclose(p_big.sum(axis=1)[:, None] > 0, True)
     eng.set_precision("f16x3")
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU), with the test hook that lets both
+    ranks share the box's single GPU and rendezvous over gloo: rank-seeded shards, barrier, max-over-ranks time, summed sites,
+    ONE JSON line from rank 0."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, C3R_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--contig_len", "4000000"]
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["unit"] == "sites/s" and j["higher_is_better"] is True and j["vs_baseline"] is None
+    per_rank = j["config"]["sites_per_step_per_rank"]
+    assert abs(j["value"] - 2 * per_rank / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-3        # whole-job aggregate over both ranks
+    assert j["roofline"]["kernel"] == "k_lstm2" and j.get("cpu_baseline") is None      # the CPU baseline is an N = 1 leg
