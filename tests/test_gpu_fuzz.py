@@ -1,5 +1,6 @@
 """Randomised parity: read sets with arbitrary (legal and odd) CIGARs through the HIP path vs the oracle, column by column
 and line by line.  Seeds are fixed; every case is small, so a failure message carries the whole input."""
+import os
 import random
 import re
 
@@ -17,6 +18,12 @@ def eng():
     e = capi.Engine(0)
     yield e
     e.close()
+
+
+def _seeds(n):
+    """CI runs seeds 0..n-1; a soak run sets C3R_FUZZ_BASE / C3R_FUZZ_SCALE to walk further seeds (tests/evidence/README.md)."""
+    base, scale = int(os.environ.get("C3R_FUZZ_BASE", "0")), int(os.environ.get("C3R_FUZZ_SCALE", "1"))
+    return range(base, base + n * scale)
 
 
 def _rand_cigar(rng, want_q):
@@ -99,7 +106,7 @@ def test_random_cigars_match_the_oracle(eng, kw):
     if "snp_min_af" in okw:
         okw["snp_af"] = okw.pop("snp_min_af")
     n_cases, n_lines = 0, 0
-    for seed in range(120):
+    for seed in _seeds(120):
         ref, recs = _case(1000 * len(kw) + seed, phased=(channels == 30))
         rs = ReadSet.from_records(recs)
         eng.params = capi.default_params()
@@ -122,7 +129,7 @@ def test_random_cigars_match_the_oracle(eng, kw):
                 assert col["depth"][i] == o["depth"], (seed, pos)
         n_cases += 1
         n_lines += len(exp["lines"])
-    assert n_cases == 120 and n_lines > 300, n_lines
+    assert n_cases == len(_seeds(120)) and n_lines > 300, n_lines
     eng.params = capi.default_params()
     eng.set_params()
 
@@ -134,7 +141,7 @@ def test_random_cigars_with_filters_and_regions(eng, mode):
     from clair3_rna_amd import capi
     from clair3_rna_amd.reads import ReadSet
     n_lines = 0
-    for seed in range(60):
+    for seed in _seeds(60):
         rng = random.Random(7000 + seed)
         ref, recs = _case(50000 + seed, phased=False)
         if mode == "deep":              # replicate the reads: depth 150-400 with identical alleles (I1/D1 multiplicities, rescale)
@@ -189,7 +196,7 @@ def test_random_cigars_decode_rows_cpp_equals_python_and_regions(eng):
     eng.load_weights(w, 18)
     eng.set_precision("f16x3")
     n_rows, kinds = 0, set()
-    for seed in range(60):
+    for seed in _seeds(60):
         rng = random.Random(9000 + seed)
         ref, recs = _case(80000 + seed, phased=False)
         rs = ReadSet.from_records(recs)
@@ -233,7 +240,7 @@ def test_mpileup_depth_cap(eng, channels):
     from clair3_rna_amd import capi
     from clair3_rna_amd.reads import ReadSet
     n_dropped_cases = 0
-    for seed in range(40):
+    for seed in _seeds(40):
         rng = random.Random(4000 + seed)
         ref, recs = _case(60000 + seed, phased=(channels == 30))
         rep = rng.randint(3, 7)
