@@ -7,12 +7,19 @@ import numpy as np
 import bench
 from clair3_rna_amd import capi, synth, altinfo
 from oracle import oracle as orc
-ref, rs, info = synth.generate_contig()
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--config3", action="store_true", help="BASELINE.json configs[3] flavour: MAS-Seq reads, depth 30, HP tags, 30 channels")
+ap.add_argument("--contig_len", type=int, default=synth.CHR20_LEN)
+opt = ap.parse_args()
+CH = 30 if opt.config3 else 18
+ref, rs, info = synth.generate_contig(contig_len=opt.contig_len, depth=30.0 if opt.config3 else 20.0, platform="hifi" if opt.config3 else "ont", phased=opt.config3)
 L = len(ref)
 refs = ref.decode()
 chunks = bench.chunk_list(L)
-eng = capi.Engine(0); eng.set_params(); eng.load_reads(rs); eng.set_reference(1, ref)
-w = synth.random_weights(18); eng.load_weights(w, 18)
+print('config3' if opt.config3 else 'config1', 'contig', L, 'reads', len(rs), 'channels', CH, flush=True)
+eng = capi.Engine(0); eng.set_params(channels=CH); eng.load_reads(rs); eng.set_reference(1, ref)
+w = synth.random_weights(CH); eng.load_weights(w, CH)
 t0 = time.time()
 n_tot, worst = 0, 0.0
 for ci, (a, b) in enumerate(chunks):
@@ -23,10 +30,10 @@ for ci, (a, b) in enumerate(chunks):
     refslice = refs[rstart - 1:b + 1000]
     lines = altinfo.format_lines("chr20", sites, raw, toks, rs, refslice.upper(), rstart) if n else []
     es, ee = max(1, a - 33), b + 33
-    rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, "chr20", es, ee)
-    exp = orc.create_tensor(rows, "chr20", refslice.upper(), rstart, orc.make_params())
+    rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, "chr20", es, ee, with_hp=opt.config3)
+    exp = orc.create_tensor(rows, "chr20", refslice.upper(), rstart, orc.make_params(phased=opt.config3))
     assert lines == exp, (ci, len(lines), len(exp))
-    Xo, _ = orc.batch_from_lines(exp, 18)
+    Xo, _ = orc.batch_from_lines(exp, CH)
     assert np.array_equal(X, Xo)
     if n:
         p = eng.infer(); po = orc.forward(w, Xo)
