@@ -89,3 +89,75 @@ def test_plan_include_all_ctg_name_bed_and_vcf(ref_fa, tmp_path):
     open(bad, "w").write("chr1\t50\t10\n")
     with pytest.raises(SystemExit):
         call_sample.split_extend_bed(bad, d, None)
+
+
+def _fake_sample(tmp):
+    """FASTA + BAM (+ .bai) + weights for the stand-in engine runs."""
+    import numpy as np
+    from clair3_rna_amd import bam, bamio, synth
+    spec = [("chr1", 40000, 3), ("chr2", 26000, 5), ("chr3", 30000, 6), ("chrX", 22000, 7), ("chr9", 9000, 11)]
+    contigs, reads = [], {}
+    for name, L, seed in spec:
+        ref, rs, _ = synth.small_case(seed=seed, ref_len=L, n_genes=max(3, L // 5000), depth=8)
+        contigs.append((name, ref))
+        if name != "chr9":
+            reads[name] = rs
+    fa, bm, wfn = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "in.bam"), os.path.join(tmp, "model")
+    io.write_fasta(fa, contigs)
+    bam.write_bam(bm, [(n, len(r)) for n, r in contigs], reads)
+    bamio.index_build(bm)
+    np.save(wfn + ".c3rw.npy", np.ones(8, dtype=np.float32))
+    return fa, bm, wfn
+
+
+def _launch(tmp, out, fa, bm, wfn, extra, world=1):
+    import socket
+    import subprocess
+    import sys
+    launcher = os.path.join(HERE, "support", "fake_engine_sample.py")
+    argv = [sys.executable, launcher, "--bam_fn", bm, "--ref_fn", fa, "--output_dir", out, "--pileup_model_path", wfn, "--chunk_size", "9000",
+            "--no_compress", "--gpu_id", "0"] + extra
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        if world > 1:
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        else:
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    return [r for r in open(os.path.join(out, "output.vcf")).read().split("\n") if not r.startswith("##cmdline=")]
+
+
+def test_driver_orchestration_single_and_two_ranks_gloo(tmp_path):
+    """call_sample end to end with a stand-in engine (tests/support/fake_engine_sample.py): planning, threads, merge order and
+    seam duplicates in one process; then the same job as two ranks over gloo (world_size 2, on CPU) — contigs dealt by LPT, parts
+    under tmp/parts, rank 0 assembling — must write the same file.  Also three contexts and one fetch thread."""
+    tmp = str(tmp_path)
+    fa, bm, wfn = _fake_sample(tmp)
+    one = _launch(tmp, os.path.join(tmp, "one"), fa, bm, wfn, ["--print_ref_calls"])
+    rec = [r.split("\t") for r in one if r and r[0] != "#"]
+    assert len(rec) > 100 and [c for c in dict.fromkeys(r[0] for r in rec)] == ["chr1", "chr2", "chr3", "chrX"]      # chr9: no reads
+    for ctg in ("chr1", "chr2", "chr3", "chrX"):
+        pos = [int(r[1]) for r in rec if r[0] == ctg]
+        assert pos == sorted(set(pos))                                  # ordered, seam duplicates resolved
+    # at a seam the later chunk's record survives: its sample field carries the chunk number
+    seams = [r for r in rec if r[0] == "chr1" and int(r[1]) in (8000, 16000, 24000, 32000)]
+    assert seams and all(r[9].endswith(":%d" % (int(r[1]) // 8000)) for r in seams)
+    assert open(os.path.join(tmp, "one", "tmp", "CONTIGS")).read().split("\n") == ["chr1", "chr2", "chr3", "chrX"]
+    two = _launch(tmp, os.path.join(tmp, "two"), fa, bm, wfn, ["--print_ref_calls"], world=2)
+    assert two == one
+    parts = sorted(n for n in os.listdir(os.path.join(tmp, "two", "tmp", "parts")) if n.endswith(".json"))
+    called = [json.load(open(os.path.join(tmp, "two", "tmp", "parts", n)))["called"] for n in parts]
+    assert parts == ["rank0.json", "rank1.json"] and called[0] and called[1] and not set(called[0]) & set(called[1])
+    assert sorted(called[0] + called[1]) == ["chr1", "chr2", "chr3", "chrX"]
+    three_ctx = _launch(tmp, os.path.join(tmp, "ctx3"), fa, bm, wfn, ["--print_ref_calls", "--contexts", "3", "--fetch_threads", "1"])
+    assert three_ctx == one
+    no_ref = _launch(tmp, os.path.join(tmp, "noref"), fa, bm, wfn, ["--qual", "10"], world=2)
+    kept = [r.split("\t") for r in no_ref if r and r[0] != "#"]
+    assert kept and all(r[4] != "." for r in kept) and all((r[6] == "LowQual") == (float(r[5]) <= 10) for r in kept)
