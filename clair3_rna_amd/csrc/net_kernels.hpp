@@ -768,7 +768,9 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
                 else al[G1 & 1][I / 2] = wg[(I / 2 * 2 + 1) * 64];
             } else {
                 constexpr int sb = I - 2 * NT;
-                if constexpr (G1 < NGX) {
+                if constexpr (G1 < NGX && (ABL & 8)) {
+                    bh[G1 & 1][sb] = (half8)(_Float16)(float)(G1 + sb);            // probe: no x operand traffic
+                } else if constexpr (G1 < NGX) {
                     // branch-free (a divergent guard would split the region): load from a clamped index, then select
                     const int32_t *xp = xin + xoff[gm][sb] + (size_t)tm * CIN;
                     const int k0 = 16 * G1 + 8 * hh;
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
         auto wptr = [&](int g) -> gptr_t {
             uintptr_t wbase = (uintptr_t)wl;
             asm volatile("" : "+v"(wbase));              // keeps hipcc from precomputing every group's addresses (k_lstm_h::ldw)
-            return (gptr_t)wbase + (size_t)g * NT * 2 * 64;
+            return (gptr_t)wbase + (size_t)((ABL & 16) ? 0 : g) * NT * 2 * 64;      // probe bit 16: one L1-hot k-group of weights
         };
         constexpr int NITEM = 2 * NT + SB;
         // one region = k-group G: its MFMAs, the prefetch of group G+1, and (GATE, G < NT*SB) the cell update of chunk G
