@@ -161,3 +161,21 @@ def test_driver_orchestration_single_and_two_ranks_gloo(tmp_path):
     no_ref = _launch(tmp, os.path.join(tmp, "noref"), fa, bm, wfn, ["--qual", "10"], world=2)
     kept = [r.split("\t") for r in no_ref if r and r[0] != "#"]
     assert kept and all(r[4] != "." for r in kept) and all((r[6] == "LowQual") == (float(r[5]) <= 10) for r in kept)
+
+
+def test_fetch_reference_slices_like_faidx(tmp_path):
+    """io.fetch_reference: 1-based inclusive slices across line ends, clamped to the contig, upper-cased like the reference's
+    reference_sequence_from (shared/utils.py:168-194) — or raw bytes (case kept) for c3r_set_reference, which upper-cases itself."""
+    fa = str(tmp_path / "r.fa")
+    seq1 = ("ACGTacgtNNry" * 37)[:431]
+    seq2 = "G" * 60 + "t" * 61
+    io.write_fasta(fa, [("c1", seq1), ("c2", seq2)], width=60)
+    for a, b in ((1, 431), (1, 1), (60, 61), (59, 121), (430, 431), (100, 99), (-5, 10), (400, 9999)):
+        lo, hi = max(1, a), min(431, b)
+        want = seq1[lo - 1:hi] if hi >= lo else ""
+        assert io.fetch_reference(fa, "c1", a, b) == want.upper()
+        assert io.fetch_reference(fa, "c1", a, b, raw=True) == want.encode()
+    assert io.fetch_reference(fa, "c2", 55, 70) == "GGGGGGTTTTTTTTTT"
+    assert io.fetch_reference(fa, "c2", 1, 10 ** 9, raw=True) == seq2.encode()
+    with pytest.raises(KeyError):
+        io.fetch_reference(fa, "nope", 1, 2)
