@@ -437,6 +437,19 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 if ((ABL & 16) && g > 0) continue;      // probe: weights register-stationary (no L1 traffic)
+                if constexpr ((ABL & 128) != 0) {
+                    // probe (timing only, wrong numbers): the lo halves as 8-bit values — 8 bytes per lane instead of 16, widened
+                    // with 4 VALU operations per fragment the way a packed fp8 -> f16 conversion would be
+                    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                    typedef const uint2v __attribute__((address_space(1))) *g8_t;
+                    ah[tt] = wg[(tt * 2 + 0) * 64];
+                    const uint2v q = *((g8_t)(wg + (tt * 2 + 1) * 64));
+                    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+                    uint4v e;
+                    e[0] = (q[0] & 0x00ff00ffu) << 4; e[1] = (q[0] >> 8) & 0x00ff00ffu; e[2] = (q[1] & 0x00ff00ffu) << 4; e[3] = (q[1] >> 8) & 0x00ff00ffu;
+                    al[tt] = __builtin_bit_cast(half8, e);
+                    continue;
+                }
                 ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64];
             }
         };

@@ -8,11 +8,11 @@
 #include "../clair3_rna_amd/csrc/net_kernels.hpp"
 using namespace c3r;
 static const half8 *g_w4; static float *g_a4;
-template <int H, int PD>
+template <int H, int PD, int ABL = 0>
 static float run(const _Float16 *x, const half8 *w, const float *b, _Float16 *y, int n, int reps) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     dim3 grid((n + 63) / 64, 2);
-    auto go = [&] { hipLaunchKernelGGL((k_lstm_h<256, 256, H, false, 2, 0, true, PD, true>), grid, dim3(256), 0, 0, (const void *)x, w, b, y, n, g_w4, g_a4, (n + 127) / 128 * 128); };
+    auto go = [&] { hipLaunchKernelGGL((k_lstm_h<256, 256, H, false, 2, ABL, true, PD, true>), grid, dim3(256), 0, 0, (const void *)x, w, b, y, n, g_w4, g_a4, (n + 127) / 128 * 128); };
     go(); hipDeviceSynchronize();
     hipEventRecord(e0);
     for (int r = 0; r < reps; ++r) go();
@@ -39,6 +39,8 @@ int main(int argc, char **argv) {
     struct R { const char *name; int H; float ms; };
     R r[] = {
         {"H160 NT5 PD2 (prod)", 160, run<160, 2>(x, w, b, y, n, 3)},
+        {"H160 PD2 lo weights 8-bit", 160, run<160, 2, 128>(x, w, b, y, n, 3)},
+        {"H160 PD2 no weight loads", 160, run<160, 2, 16>(x, w, b, y, n, 3)},
         {"H96  NT3 PD2", 96, run<96, 2>(x, w, b, y, n, 3)},
         {"H96  NT3 PD3", 96, run<96, 3>(x, w, b, y, n, 3)},
         {"H96  NT3 PD4", 96, run<96, 4>(x, w, b, y, n, 3)},
