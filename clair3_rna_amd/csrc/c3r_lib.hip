@@ -71,7 +71,7 @@ struct c3r_ctx {
     std::vector<int64_t> geo_key;         // the (start, end) list h_geo was built for
     DevBuf d_geo, d_lastrow;
     int32_t n_regions = 0;
-    DevBuf d_cols, d_depth, d_ncov, d_flags, d_skipmax, d_ev, d_small /* cursor,last_row,totals */, d_blockcnt;
+    DevBuf d_cols, d_depth, d_ncov, d_flags, d_skipmax, d_ev, d_small /* cursor,last_row,totals */, d_blockcnt, d_scan_tops;
     int64_t n_cand = 0, n_tok = 0;        // totals resident on the device (all scans of the current batch)
     int64_t last_cand = 0, last_base = 0; // candidates of the most recent scan and their offset in the batch
     bool batching = false;
@@ -272,7 +272,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
-                      &ctx->d_blockcnt, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
+                      &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     net_free(ctx->net);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -579,6 +579,23 @@ static int run_gather(c3r_ctx *ctx, int rescale, int32_t *dst, bool with_sites) 
     return C3R_OK;
 }
 
+// exclusive scan of n ints in place on the context's stream, total to *d_total: one block for short inputs, three launches for long
+static int device_excl_scan(c3r_ctx *ctx, int32_t *d, int n, int32_t *d_total) {
+    if (n <= 4 * SCAN_BLK) {
+        Launch L(ctx, "k_excl_scan");
+        hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, d, n, d_total);
+        return C3R_OK;
+    }
+    const int nb = (n + SCAN_BLK - 1) / SCAN_BLK;
+    int rc = ensure(ctx, ctx->d_scan_tops, (size_t)nb * 4 + 16);
+    if (rc) return rc;
+    Launch L(ctx, "k_excl_scan");
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(1024), 0, ctx->stream, d, n, (int32_t *)ctx->d_scan_tops.p);
+    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)ctx->d_scan_tops.p, nb, d_total);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, ctx->stream, d, n, (const int32_t *)ctx->d_scan_tops.p);
+    return C3R_OK;
+}
+
 int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n_candidates) {
     return c3r_pileup_scan_regions(ctx, 1, &ctg_start, &ctg_end, n_candidates);
 }
@@ -732,9 +749,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
                            (int32_t *)ctx->d_blockcnt.p);
     }
     {
-        Launch L(ctx, "k_excl_scan");
-        hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)ctx->d_blockcnt.p, n_cblocks,
-                           (int32_t *)((char *)ctx->d_small.p + 12));
+        if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_blockcnt.p, n_cblocks, (int32_t *)((char *)ctx->d_small.p + 12)))) return rc;
     }
     int32_t n_cand = 0;
     HIPCHK(ctx, hipMemcpyAsync(&n_cand, (char *)ctx->d_small.p + 12, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -756,9 +771,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     }
     if ((rc = run_gather(ctx, 1, (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_cand * tbytes), true))) return rc;
     {
-        Launch L(ctx, "k_excl_scan");
-        hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)ctx->d_tokcnt.p, (int)n_cand,
-                           (int32_t *)((char *)ctx->d_small.p + 16));
+        if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_tokcnt.p, (int)n_cand, (int32_t *)((char *)ctx->d_small.p + 16)))) return rc;
     }
     int32_t n_tok = 0;
     HIPCHK(ctx, hipMemcpyAsync(&n_tok, (char *)ctx->d_small.p + 16, 4, hipMemcpyDeviceToHost, ctx->stream));
