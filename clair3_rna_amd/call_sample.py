@@ -150,6 +150,19 @@ def build_parser():
     return p
 
 
+def _all_ranks_ok(dist, world, err, what):
+    """Rendezvous of all ranks that also carries a failure flag: a rank that failed still arrives, and then every rank raises.
+    (A rank that simply returned would leave the others in dist.barrier() until the gloo timeout.)"""
+    if world > 1:
+        import torch
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32)
+        dist.all_reduce(flag)
+        if err is None and int(flag.item()):
+            raise RuntimeError("another rank failed while %s" % what)
+    if err is not None:
+        raise err
+
+
 class _Fetcher(object):
     """Stage 1: whole-contig read fetch + reference slice, one BAM handle per worker thread."""
 
@@ -322,13 +335,29 @@ def Run(args, log=None):
             indexed = probe.has_index
         if not indexed:
             # without an index every contig would cost a pass over the whole file: build one next to a link in tmp/
-            # (run_clair3_rna insists on an existing index, :469-477; samtools is not a dependency here)
+            # (run_clair3_rna insists on an existing index, :469-477; samtools is not a dependency here).  Rank 0 alone builds it,
+            # under temporary names that are renamed into place, and the other ranks open the BAM only after the barrier: nobody
+            # ever sees a missing link or a half-written .bai
             link = os.path.join(out_dir, "tmp", "input.bam")
-            if os.path.lexists(link):
-                os.remove(link)
-            os.symlink(os.path.abspath(bam_fn), link)
-            log("[INFO] %s has no .bai: building %s.bai" % (bam_fn, link))
-            bamio.index_build(link)
+            build_err = None
+            if rank == 0:
+                try:
+                    tmp_link, tmp_bai = link + ".tmp%d" % os.getpid(), link + ".bai.tmp%d" % os.getpid()
+                    if os.path.lexists(tmp_link):
+                        os.remove(tmp_link)
+                    os.symlink(os.path.abspath(bam_fn), tmp_link)
+                    log("[INFO] %s has no .bai: building %s.bai" % (bam_fn, link))
+                    try:
+                        bamio.index_build(tmp_link, tmp_bai)
+                        os.replace(tmp_bai, link + ".bai")
+                        os.replace(tmp_link, link)
+                    finally:
+                        for t_ in (tmp_link, tmp_bai):
+                            if os.path.lexists(t_):
+                                os.remove(t_)
+                except Exception as e:           # the other ranks are waiting at the barrier: reach it, then fail together
+                    build_err = e
+            _all_ranks_ok(dist, world, build_err, "building the BAM index")
             bam_fn = link
     fetcher = _Fetcher(bam_fn, args.ref_fn)
     t_setup = time() - t_all
@@ -343,7 +372,6 @@ def Run(args, log=None):
             log("[timeline] %-6s %-8s %7.3f -> %7.3f s" % (ctg, what, t0 - t_all, time() - t_all))
 
     def fetch_task(ctg):
-        slots.acquire()
         t0 = time()
         r = fetcher(ctg, fai[ctg])
         mark(ctg, "fetch", t0)
@@ -370,76 +398,113 @@ def Run(args, log=None):
         finally:
             slots.release()
 
+    work_err = None
     t_merge = 0.0
     results = []
-    ctx_pools = [ThreadPoolExecutor(1) for _ in engines]
-    with ThreadPoolExecutor(max(1, args.fetch_threads)) as fetch_pool:
-        fetched = [fetch_pool.submit(fetch_task, c) for c in contigs]
-        tasks = [ctx_pools[i % n_ctx].submit(context_task, engines[i % n_ctx], c, fetched[i]) for i, c in enumerate(contigs)]
-        del fetched
-        for i, ctg in enumerate(contigs):                              # merge in calling order as the contigs come out
-            rows = tasks[i].result()
-            tasks[i] = None
-            if rows is None:
-                log("[WARNING] Contig name %s provided but no mapped reads found in BAM, skip!" % ctg)
-                continue
-            t0 = time()
-            merge_contig(ctg, rows)
-            t_merge += time() - t0
-            mark(ctg, "merge", t0)
-            results.append((ctg, None))
-    for p_ in ctx_pools:
-        p_.shutdown()
-    n_sites, t_fetch, t_dev = stats["sites"], stats["fetch"], stats["dev"]
-    fetcher.close()
-    called = [c for c, _f in results]
+    n_sites = t_fetch = t_dev = 0
+    called = []
+    try:
+        ctx_pools = [ThreadPoolExecutor(1) for _ in engines]
+        with ThreadPoolExecutor(max(1, args.fetch_threads)) as fetch_pool:
+            # A feeder takes the look-ahead slot BEFORE it submits a contig's fetch, strictly in calling order.  (Taken inside the
+            # fetch workers, a later contig could grab the last slot while the one its context needs next was still waiting for
+            # one — every context consumes its contigs in order, so nothing would ever have released a slot again.)
+            tasks = [None] * len(contigs)
+            submitted = [threading.Event() for _ in contigs]
+            feeder_err = []
+
+            def feeder():
+                try:
+                    for i, c in enumerate(contigs):
+                        slots.acquire()
+                        fut = fetch_pool.submit(fetch_task, c)
+                        tasks[i] = ctx_pools[i % n_ctx].submit(context_task, engines[i % n_ctx], c, fut)
+                        submitted[i].set()
+                except BaseException as e:          # (e.g. the pools were shut down by a failure below)
+                    feeder_err.append(e)
+                finally:
+                    for ev in submitted:
+                        ev.set()
+
+            feed = threading.Thread(target=feeder, name="c3r-feeder", daemon=True)
+            feed.start()
+            for i, ctg in enumerate(contigs):                              # merge in calling order as the contigs come out
+                submitted[i].wait()
+                if tasks[i] is None:
+                    raise RuntimeError("contig %s was never submitted: %r" % (ctg, feeder_err[:1]))
+                rows = tasks[i].result()
+                tasks[i] = None
+                if rows is None:
+                    log("[WARNING] Contig name %s provided but no mapped reads found in BAM, skip!" % ctg)
+                    continue
+                t0 = time()
+                merge_contig(ctg, rows)
+                t_merge += time() - t0
+                mark(ctg, "merge", t0)
+                results.append((ctg, None))
+        for p_ in ctx_pools:
+            p_.shutdown()
+        n_sites, t_fetch, t_dev = stats["sites"], stats["fetch"], stats["dev"]
+        fetcher.close()
+        called = [c for c, _f in results]
+    except Exception as e:               # with several ranks: reach the rendezvous first, then every rank fails
+        work_err = e
+        if world == 1:
+            raise
     for e in engines:
         e.close()
     if world > 1:
         import json
         with open(os.path.join(parts_dir, "rank%d.json" % rank), "w") as f:
             json.dump(dict(counts={str(k): v for k, v in part_counts.items()}, called=called, n_sites=n_sites), f)
-        dist.barrier()
+        _all_ranks_ok(dist, world, work_err, "calling its contigs")
         if rank != 0:
-            dist.barrier()                                              # leave only when rank 0 has written the result
+            _all_ranks_ok(dist, world, None, "assembling the output")  # leave only when rank 0 has written the result
             return 0
-        called_set, n_sites = set(), 0
-        for r in range(world):
-            j = json.load(open(os.path.join(parts_dir, "rank%d.json" % r)))
-            called_set.update(j["called"])
-            n_sites += j["n_sites"]
-            for k, (a, b, c) in j["counts"].items():
-                merger.n_read += a; merger.n_kept += b; merger.n_tagged += c
-        called = [c for c in all_contigs if c in called_set]
-        for k, c in enumerate(all_contigs):
-            fn = os.path.join(parts_dir, "%05d.vcf" % k)
-            if c in called_set and os.path.exists(fn) and os.path.getsize(fn):
-                merger._header()
-                merger.out.write(open(fn).read())
-                if merger.out_nt:
-                    merger.out_nt.write(open(os.path.join(parts_dir, "%05d_nt.vcf" % k)).read())
-    n_read, n_kept, n_tag = merger.close(log)
-    # tmp/CONTIGS and tmp/CHUNK_LIST as run_clair3_rna leaves them (:436-449): contigs without reads are dropped by its
-    # `samtools idxstats` check (:184-210) before they are written; here that is known once the contig has been fetched
-    with open(os.path.join(out_dir, "tmp", "CONTIGS"), "w") as f:
-        f.write("\n".join(called))
-    with open(os.path.join(out_dir, "tmp", "CHUNK_LIST"), "w") as f:
-        for c in called:
-            for k in range(1, chunk_nums[c] + 1):
-                f.write("%s %d %d\n" % (c, k, chunk_nums[c]))
-    t0 = time()
-    if not args.no_compress:
-        sort_vcf.compress_vcf(out_fn)
-        if table is not None and n_kept:
-            sort_vcf.compress_vcf(out_nt_fn)
-    if table is not None:
-        log("[INFO] Dataset size:%d, total variants tagged by REDIportal dataset: %d" % (len(table), n_tag))
-    log("[INFO] %d contigs, %d candidate sites, %d records written to %s%s" % (len(called), n_sites, n_kept, out_fn, "" if args.no_compress else ".gz"))
-    t_gz = time() - t0
-    log("[INFO] set-up %.2f s, fetch %.2f s (overlapped), device stage %.2f s, merge %.2f s, bgzip+tabix %.2f s, total %.2f s"
-        % (t_setup, t_fetch, t_dev, t_merge, t_gz, time() - t_all))
+    fin_err = None
+    try:
+        if world > 1:
+            called_set, n_sites = set(), 0
+            for r in range(world):
+                j = json.load(open(os.path.join(parts_dir, "rank%d.json" % r)))
+                called_set.update(j["called"])
+                n_sites += j["n_sites"]
+                for k, (a, b, c) in j["counts"].items():
+                    merger.n_read += a; merger.n_kept += b; merger.n_tagged += c
+            called = [c for c in all_contigs if c in called_set]
+            for k, c in enumerate(all_contigs):
+                fn = os.path.join(parts_dir, "%05d.vcf" % k)
+                if c in called_set and os.path.exists(fn) and os.path.getsize(fn):
+                    merger._header()
+                    merger.out.write(open(fn).read())
+                    if merger.out_nt:
+                        merger.out_nt.write(open(os.path.join(parts_dir, "%05d_nt.vcf" % k)).read())
+        n_read, n_kept, n_tag = merger.close(log)
+        # tmp/CONTIGS and tmp/CHUNK_LIST as run_clair3_rna leaves them (:436-449): contigs without reads are dropped by its
+        # `samtools idxstats` check (:184-210) before they are written; here that is known once the contig has been fetched
+        with open(os.path.join(out_dir, "tmp", "CONTIGS"), "w") as f:
+            f.write("\n".join(called))
+        with open(os.path.join(out_dir, "tmp", "CHUNK_LIST"), "w") as f:
+            for c in called:
+                for k in range(1, chunk_nums[c] + 1):
+                    f.write("%s %d %d\n" % (c, k, chunk_nums[c]))
+        t0 = time()
+        if not args.no_compress:
+            sort_vcf.compress_vcf(out_fn)
+            if table is not None and n_kept:
+                sort_vcf.compress_vcf(out_nt_fn)
+        if table is not None:
+            log("[INFO] Dataset size:%d, total variants tagged by REDIportal dataset: %d" % (len(table), n_tag))
+        log("[INFO] %d contigs, %d candidate sites, %d records written to %s%s" % (len(called), n_sites, n_kept, out_fn, "" if args.no_compress else ".gz"))
+        t_gz = time() - t0
+        log("[INFO] set-up %.2f s, fetch %.2f s (overlapped), device stage %.2f s, merge %.2f s, bgzip+tabix %.2f s, total %.2f s"
+            % (t_setup, t_fetch, t_dev, t_merge, t_gz, time() - t_all))
+    except Exception as e:               # rank 0 still meets the others at the last rendezvous, and all of them fail
+        fin_err = e
+        if world == 1:
+            raise
     if world > 1:
-        dist.barrier()
+        _all_ranks_ok(dist, world, fin_err, "assembling the output")
     return 0
 
 

@@ -9,7 +9,7 @@ import numpy as np
 from .reads import READ_DTYPE, ReadSet
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libc3r.so")
+LIB_PATH = os.environ.get("C3R_LIB") or os.path.join(HERE, "libc3r.so")        # C3R_LIB: A/B builds of the kernels (development)
 
 SITE_DTYPE = np.dtype([("pos", "<i4"), ("depth", "<i4"), ("ref33", "S36"), ("n_tok", "<i4"), ("tok_off", "<u4")], align=True)
 TOKEN_DTYPE = np.dtype([("read_idx", "<u4"), ("indel", "<i4"), ("qpos", "<u4"), ("base", "u1"), ("rev", "u1"), ("pad", "u1", (2,))],

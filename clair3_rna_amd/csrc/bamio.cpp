@@ -37,11 +37,11 @@ struct Mapped {
         fd = ::open(path, O_RDONLY);
         if (fd < 0) return false;
         struct stat st;
-        if (fstat(fd, &st) != 0) return false;
+        if (fstat(fd, &st) != 0) { ::close(fd); fd = -1; return false; }
         n = (size_t)st.st_size;
         if (n == 0) { p = nullptr; return true; }
         void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m == MAP_FAILED) return false;
+        if (m == MAP_FAILED) { ::close(fd); fd = -1; n = 0; return false; }
         p = (const uint8_t *)m;
         return true;
     }
@@ -169,6 +169,7 @@ struct c3r_bam {
     bool has_bai = false;
     std::vector<RefIndex> bai;
     int n_threads = 1;
+    bool malformed = false;             // the last fetch met a record whose fields do not fit its block (err holds the message)
     // result of the last fetch
     std::vector<c3r_read_t> reads;
     std::vector<uint32_t> cigar;
@@ -184,8 +185,16 @@ int failb(c3r_bam *b, int code, const char *fmt, ...) {
     return code;
 }
 
+// A record of the wanted contig whose declared fields run past its block: remember it (c3r_bam_fetch fails with C3R_EINVAL)
+// and tell the caller to stop.
+int malformed_record(c3r_bam *b, int32_t pos, const char *what) {
+    if (!b->malformed) failb(b, C3R_EINVAL, "%s: malformed alignment record at position %d (%s)", b->path.c_str(), pos + 1, what);
+    b->malformed = true;
+    return 2;
+}
+
 // Append one alignment (pointer to the 32 fixed bytes after block_size) if it belongs to (tid, [beg,end)).
-// Returns 1 appended, 0 skipped, 2 = past the region (sorted input: the caller may stop).
+// Returns 1 appended, 0 skipped, 2 = stop: past the region (sorted input) or a malformed record (b->malformed).
 int take_record(c3r_bam *b, const uint8_t *r, size_t block_size, int tid, int64_t beg, int64_t end) {
     if (block_size < 32) return 0;
     const int32_t ref_id = le32s(r), pos = le32s(r + 4);
@@ -197,7 +206,7 @@ int take_record(c3r_bam *b, const uint8_t *r, size_t block_size, int tid, int64_
     if (pos < 0) return 0;
     if (end > 0 && pos >= end) return 2;
     const size_t c0 = 32 + l_read_name, s0 = c0 + 4 * (size_t)n_cig, nb = ((size_t)l_seq + 1) / 2, a0 = s0 + nb + l_seq;
-    if (a0 > block_size) return 0;
+    if (a0 > block_size) return malformed_record(b, pos, "name / CIGAR / sequence longer than the record");
     const uint8_t *cig = r + c0;
     // aux: HP (any integer type) and CG:B,I (real CIGAR of reads with > 65535 ops, SAM spec §4.2.2)
     uint32_t hp = 0; const uint8_t *cg = nullptr; uint32_t cg_n = 0;
@@ -215,6 +224,7 @@ int take_record(c3r_bam *b, const uint8_t *r, size_t block_size, int tid, int64_
                 if (p + 5 > block_size) { p = block_size; continue; }
                 const uint8_t sub = r[p]; const uint32_t cnt = le32(r + p + 1);
                 const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                if ((size_t)cnt * es > block_size - (p + 5)) return malformed_record(b, pos, "B-array tag longer than the record");
                 if (t0 == 'C' && t1 == 'G' && sub == 'I') { cg = r + p + 5; cg_n = cnt; }
                 p += 5 + (size_t)cnt * es;
                 continue;
@@ -264,10 +274,12 @@ int parse_header(c3r_bam *b) {
     if (l_text > 0 && cur.read(tmp.data(), (size_t)l_text) != 1) return failb(b, C3R_EINVAL, "%s: truncated header", b->path.c_str());
     if (cur.read(h, 4) != 1) return failb(b, C3R_EINVAL, "%s: truncated header", b->path.c_str());
     const int32_t n_ref = le32s(h);
+    if (l_text < 0 || n_ref < 0) return failb(b, C3R_EINVAL, "%s: negative header length / reference count", b->path.c_str());
     size_t total = 12 + (size_t)std::max(l_text, 0);
     for (int i = 0; i < n_ref; ++i) {
         if (cur.read(h, 4) != 1) return failb(b, C3R_EINVAL, "%s: truncated reference list", b->path.c_str());
         const int32_t l_name = le32s(h);
+        if (l_name <= 0 || l_name > (1 << 20)) return failb(b, C3R_EINVAL, "%s: bad reference name length %d in the header", b->path.c_str(), l_name);
         std::vector<uint8_t> nm((size_t)l_name + 4);
         if (cur.read(nm.data(), (size_t)l_name + 4) != 1) return failb(b, C3R_EINVAL, "%s: truncated reference list", b->path.c_str());
         b->names.emplace_back((const char *)nm.data(), (size_t)std::max(l_name - 1, 0));
@@ -524,6 +536,7 @@ int c3r_bam_contig(c3r_bam *b, int i, const char **name, int64_t *length) {
 int c3r_bam_fetch(c3r_bam *b, const char *contig, int64_t beg0, int64_t end0, int64_t *n_reads, int64_t *n_cigar, int64_t *n_seq_bytes) {
     if (!b || !contig) return C3R_EINVAL;
     b->reads.clear(); b->cigar.clear(); b->seq.clear();
+    b->malformed = false;
     int tid = -1;
     for (size_t i = 0; i < b->names.size(); ++i) if (b->names[i] == contig) { tid = (int)i; break; }
     int rc = C3R_OK;
@@ -536,6 +549,7 @@ int c3r_bam_fetch(c3r_bam *b, const char *contig, int64_t beg0, int64_t end0, in
             rc = scan_all(b, [&](const uint8_t *r, size_t bs, uint64_t, uint64_t) { return take_record(b, r, bs, tid, beg0, end0) != 2; });
         }
     }
+    if (rc == C3R_OK && b->malformed) { rc = C3R_EINVAL; b->reads.clear(); b->cigar.clear(); b->seq.clear(); }
     if (n_reads) *n_reads = (int64_t)b->reads.size();
     if (n_cigar) *n_cigar = (int64_t)b->cigar.size();
     if (n_seq_bytes) *n_seq_bytes = (int64_t)b->seq.size();

@@ -49,6 +49,7 @@ struct c3r_ctx {
     std::vector<uint32_t> h_cigar;
     std::vector<uint8_t> h_seq;
     int64_t n_indel_ops = 0;
+    std::vector<int64_t> h_indel_prefix;  // [n_reads + 1] running count of I/D ops (normalised CIGARs): sizes the event scratch per scan
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
     std::vector<DevSeg> h_segs;            // aligned segments (CIGAR runs between N ops), sorted by ext_start
     DevBuf d_segs, d_seg_prefmax, d_tile_cols, d_tile_rng, d_tile_list, d_rsegs, d_rseg_first;
@@ -178,7 +179,7 @@ void recompute_prefmax(c3r_ctx *ctx, std::vector<int32_t> &pm) {
     int32_t m = INT_MIN;
     for (size_t i = 0; i < ctx->h_reads.size(); ++i) {
         const DevRead &r = ctx->h_reads[i];
-        const bool pass = !(r.flag & ctx->prm.excl_flags) && !(r.flag & 4) && r.mapq >= ctx->prm.min_mq && r.end > r.pos;
+        const bool pass = !flag_fails(r.flag, ctx->prm.excl_flags) && r.mapq >= ctx->prm.min_mq && r.end > r.pos;
         if (pass) m = std::max(m, r.end);
         pm[i] = m;
     }
@@ -194,7 +195,7 @@ int upload_prefmax(c3r_ctx *ctx) {
         std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> live;
         size_t mx = 0;
         for (const DevRead &r : ctx->h_reads) {
-            if ((r.flag & ctx->prm.excl_flags) || (r.flag & 4) || r.mapq < ctx->prm.min_mq || r.end <= r.pos) continue;
+            if (flag_fails(r.flag, ctx->prm.excl_flags) || r.mapq < ctx->prm.min_mq || r.end <= r.pos) continue;
             while (!live.empty() && live.top() <= r.pos) live.pop();
             live.push(r.end);
             mx = std::max(mx, live.size());
@@ -205,7 +206,7 @@ int upload_prefmax(c3r_ctx *ctx) {
     int32_t m = INT_MIN;
     for (size_t i = 0; i < ctx->h_segs.size(); ++i) {
         const DevSeg &g = ctx->h_segs[i];
-        const bool pass = !(g.flag & ctx->prm.excl_flags) && !(g.flag & 4) && g.mapq >= ctx->prm.min_mq;
+        const bool pass = !flag_fails(g.flag, ctx->prm.excl_flags) && g.mapq >= ctx->prm.min_mq;
         if (pass) m = std::max(m, g.end);
         sm[i] = m;
     }
@@ -316,7 +317,7 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     // Normalisation is per read; only the offsets into the flat cigar array depend on the reads before.  Slices of reads go to
     // threads with private outputs (cig_off relative to the slice) and are stitched together afterwards.
     struct Slice {
-        std::vector<DevRead> reads; std::vector<uint32_t> cigar; std::vector<DevSeg> segs; int64_t n_indel = 0; std::string err;
+        std::vector<DevRead> reads; std::vector<uint32_t> cigar; std::vector<DevSeg> segs; std::vector<uint32_t> nind; int64_t n_indel = 0; std::string err;
         bool fail(const char *fmt, long long i) { char b[160]; snprintf(b, sizeof b, fmt, i); err = b; return false; }
     };
     auto norm = [&](int64_t i0, int64_t i1, Slice &o) -> bool {
@@ -360,10 +361,13 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
                 }
             }
             d.n_cig = (uint32_t)(o.cigar.size() - d.cig_off);
+            uint32_t ni = 0;
             for (uint32_t k = 0; k < d.n_cig; ++k) {
                 const uint32_t op = o.cigar[d.cig_off + k] & 15u;
-                if (op == C3R_CIG_I || op == C3R_CIG_D) o.n_indel++;
+                if (op == C3R_CIG_I || op == C3R_CIG_D) ++ni;
             }
+            o.n_indel += ni;
+            o.nind.push_back(ni);
             if ((int64_t)r.pos + rlen > INT32_MAX) return o.fail("read %lld ends beyond 2^31", (long long)i);
             d.end = (int32_t)(r.pos + rlen);
             o.reads.push_back(d);
@@ -431,6 +435,9 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
         stitch(0);
         for (auto &x : th) x.join();
         for (auto &o : sl) ctx->n_indel_ops += o.n_indel;
+        ctx->h_indel_prefix.assign(nr + 1, 0);
+        size_t k = 0;
+        for (auto &o : sl) for (uint32_t v : o.nind) { ctx->h_indel_prefix[k + 1] = ctx->h_indel_prefix[k] + v; ++k; }
     }
     tick();
     {   // read-order copy of the segments (for the per-candidate token kernel) before the global sort
@@ -642,14 +649,29 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     if ((rc = ensure(ctx, ctx->d_depth, (size_t)n_pos * 4))) return rc;
     if ((rc = ensure(ctx, ctx->d_ncov, (size_t)n_pos * 4))) return rc;
     if ((rc = ensure(ctx, ctx->d_flags, (size_t)n_pos))) return rc;
-    if ((rc = ensure(ctx, ctx->d_ev, ((size_t)ctx->n_indel_ops * (size_t)std::min(n_regions, 2) + 16 * (size_t)n_tiles + 16) * sizeof(EvRec)))) return rc;
+    // indel-event scratch: a tile workgroup reserves (its events rounded up to 16) records.  An I/D op yields at most one
+    // event per region whose rows it falls into, and regions may overlap arbitrarily (the same region twice, chunks shorter than
+    // their +-33 bp halos): the capacity is the I/D ops of the reads inside each region's read range, summed over the regions
+    // (an upper bound: the range also holds reads that end before the region), plus the rounding slack of every tile.
+    size_t ev_cap = 16 * (size_t)n_tiles + 16;
+    for (int r = 0; r < n_regions && !ctx->h_reads.empty(); ++r) {
+        int64_t es = ctg_starts[r] - C3R_WINDOW, ee = ctg_ends[r] + C3R_WINDOW;
+        if (es < 1) es = 1;
+        const int32_t beg0 = (int32_t)(es - 1), end0 = (int32_t)ee;
+        // reads are sorted by pos: [first read that can reach beg0 (running max of the passing reads' ends), first read starting after end0)
+        // (one past the region on the right: an insertion / deletion right after the last row's base still belongs to that row)
+        const size_t lo = (size_t)(std::upper_bound(ctx->h_prefmax.begin(), ctx->h_prefmax.end(), beg0 - 1) - ctx->h_prefmax.begin());
+        const size_t hi = (size_t)(std::partition_point(ctx->h_reads.begin(), ctx->h_reads.end(), [&](const DevRead &d) { return d.pos <= end0; }) - ctx->h_reads.begin());
+        if (hi > lo) ev_cap += (size_t)(ctx->h_indel_prefix[hi] - ctx->h_indel_prefix[lo]);
+    }
+    if ((rc = ensure(ctx, ctx->d_ev, ev_cap * sizeof(EvRec)))) return rc;
     if ((rc = ensure(ctx, ctx->d_small, 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_cols, (size_t)n_tiles + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_blockcnt, (size_t)(n_cblocks + 1) * 4))) return rc;
     if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_skipmax, (size_t)n_pos * 4))) return rc;
-    // d_small: [0..7] ev_cursor (u64), [8..11] unused, [12..15] n_cand, [16..19] n_tok, [20..23] n_tile_list
+    // d_small: [0..7] ev_cursor (u64), [8..11] event-scratch overflow flag, [12..15] n_cand, [16..19] n_tok, [20..23] n_tile_list
     int32_t init[6] = {0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_small.p, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_lastrow.p, 0xff, (size_t)n_regions * 4, ctx->stream));      // -1
@@ -676,7 +698,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
             for (; i < ctx->h_reads.size(); ++i) {
                 const DevRead &rd = ctx->h_reads[i];
                 if (rd.pos >= end0) break;
-                if ((rd.flag & ctx->prm.excl_flags) || (rd.flag & 4) || rd.mapq < ctx->prm.min_mq || rd.end <= rd.pos) continue;
+                if (flag_fails(rd.flag, ctx->prm.excl_flags) || rd.mapq < ctx->prm.min_mq || rd.end <= rd.pos) continue;
                 if (rd.end <= beg0) continue;                                            // not fetched for this region
                 while (!live.empty() && live.top() <= rd.pos - 1) live.pop();
                 const bool first = rd.pos != last_pos;
@@ -714,6 +736,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.min_cov = ctx->prm.min_coverage;
     a.snp_af = ctx->prm.snp_min_af; a.indel_af = ctx->prm.indel_min_af;
     a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)ctx->d_small.p; a.last_row = (int32_t *)ctx->d_lastrow.p;
+    a.ev_cap = (unsigned long long)ev_cap; a.ev_overflow = (int32_t *)((char *)ctx->d_small.p + 8);
     a.splice = ctx->prm.splice_padding; a.skipmax = (int32_t *)ctx->d_skipmax.p;
     if (a.n_reads > 0) {
         Launch L(ctx, "k_tile_ranges");
@@ -751,10 +774,12 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     {
         if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_blockcnt.p, n_cblocks, (int32_t *)((char *)ctx->d_small.p + 12)))) return rc;
     }
-    int32_t n_cand = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&n_cand, (char *)ctx->d_small.p + 12, 4, hipMemcpyDeviceToHost, ctx->stream));
+    int32_t flag_cand[2] = {0, 0};       // event-scratch overflow flag, n_cand
+    HIPCHK(ctx, hipMemcpyAsync(flag_cand, (char *)ctx->d_small.p + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
+    if (flag_cand[0]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
+    const int32_t n_cand = flag_cand[1];
     ctx->last_cand = n_cand;
     if (n_candidates) *n_candidates = n_cand;
     if (n_cand == 0) return C3R_OK;

@@ -60,6 +60,15 @@ constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 #ifndef C3R_L2_ILV
 #define C3R_L2_ILV true
 #endif
+#ifndef C3R_W8_PD
+#define C3R_W8_PD 1          // prefetch distance (k-groups) of k_lstm2_w8's operand ring
+#endif
+#ifndef C3R_W8_PRIO
+#define C3R_W8_PRIO 0        // 1: s_setprio 1 for the 3-tile wavefronts, 2: for the 2-tile wavefronts
+#endif
+#ifndef C3R_L2_W8
+#define C3R_L2_W8 1          // layer 2 through k_lstm2_w8 (two wavefronts per SIMD) instead of k_lstm_h
+#endif
 constexpr int NET_FLAT = NET_T * 2 * NET_H2;   // 10560
 constexpr int NET_L4 = 128;
 
@@ -642,6 +651,285 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layer 2 (+ fused L4) with TWO wavefronts per SIMD: k_lstm2_w8, 512 threads, 64 sites x one direction per workgroup.
+//
+// k_lstm_h runs one wavefront per SIMD (its 160 accumulator registers + the L4 accumulators + the prefetch ring need the
+// whole 512-register file).  A wavefront issues in order, so everything that is not an MFMA — the weight and operand
+// loads the ring cannot cover, the cell update (5 exp2 + 3 rcp per unit), the L4 pass with its unprefetched loads, two
+// barriers — is time the matrix pipe sits out: 57 % busy.  Here the 20 gate-row tiles of a direction are dealt 3 + 2 to the
+// two wavefronts of each SIMD (waves w and w+4 share a SIMD): a wavefront's accumulators shrink to 96 / 64 registers, the
+// cell state returns to registers, and whenever one wavefront waits (loads, transcendental latency, barrier) its partner
+// keeps the matrix pipe fed.  Weight traffic is unchanged (each wavefront streams only its own rows); the B operands are
+// read from LDS by eight wavefronts instead of four (852 KB per step, a quarter of the LDS read rate).
+//   * the 2-tile wavefronts also own the fused L4 rows: W4[t-1, dir] x h_{t-1} rides in the recurrent part of step t as a
+//     third tile on the very same B fragments (h_{t-1} hi/lo) — no separate pass, its weights join the prefetch ring; in the
+//     recurrent part both wavefronts of a SIMD therefore carry three tiles each;
+//   * one barrier after the input part (x_t is dead from there on: each wavefront issues its share of the LDS-DMA of
+//     x_{t+1} after its recurrent part, and it lands under the cell update), one at the end of the step (h_t complete); h is
+//     double-buffered because a wavefront's cell update now runs while others still read h_{t-1}.  LDS: 2 x 42 KB (h hi/lo) + 64 KB (x tile) = 148 KB.
+//   Wp / W4p / bp / a4part layouts are k_lstm_h's (the 4-wave "quarter" s = wave & 3 indexes them).
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict__ xin, const half8 *__restrict__ Wp,
+                                                      const float *__restrict__ bp, int n, const half8 *__restrict__ W4p,
+                                                      float *__restrict__ a4part, int nstride) {
+    constexpr int INP = 2 * NET_H1, H = NET_H2, NGX = INP / 16, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NBLK = 4 * H / 32, NTQ = NBLK / 4;
+    constexpr int SB = 2, WG_SITES = 32 * SB, KC = INP / 8, PD = C3R_W8_PD;
+    static_assert(NTQ == 5 && NG == 26, "3 + 2 tile split of a quarter, 26 k-groups");
+    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 xs[2][KC][WG_SITES][8];      // [plane][k/8][site][8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int sq = wave & 3;                   // quarter of the gate rows (k_lstm_h's wave index)
+    const int dir = blockIdx.y;
+    const int site0 = blockIdx.x * WG_SITES;
+    const int ns = nstride ? nstride : n;
+    const size_t plane_in = (size_t)ns * NET_T * INP;
+
+    for (int i = tid; i < WG_SITES * HP; i += 512) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
+
+    int xsite = site0 + lane;
+    if (xsite >= n) xsite = n - 1;
+    // LDS-DMA of x_t: 2*KC = 64 rows of 1 KiB (one (plane, k/8) row of the 64 sites each), eight per wavefront
+    auto dma_x = [&](int tt_) {
+        typedef const _Float16 __attribute__((address_space(1))) *gp_t;
+        typedef _Float16 __attribute__((address_space(3))) *lp_t;
+#pragma unroll
+        for (int r = 0; r < 2 * KC / 8; ++r) {
+            const int row = wave * (2 * KC / 8) + r, pl = row / KC, kc = row % KC;
+            const _Float16 *src = xin + (size_t)pl * plane_in + (((size_t)tt_ * KC + kc) * ns + xsite) * 8;
+            __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)&xs[pl][kc][0][0], 16, 0, 0);
+        }
+    };
+    dma_x(dir ? NET_T - 1 : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // The whole recurrence of one wavefront: NT gate tiles starting at tile TOFF of its quarter; L4T: also the L4 rows.
+    auto body = [&](auto ntc, auto toffc, auto l4c) {
+        constexpr int NT = decltype(ntc)::value, TOFF = decltype(toffc)::value;
+        constexpr bool L4T = decltype(l4c)::value;
+        constexpr int NTH = NT + (L4T ? 1 : 0);          // tiles in the recurrent part
+        const half8 *wl = Wp + ((size_t)(dir * 4 + sq) * NG) * NTQ * 2 * 64 + (size_t)TOFF * 2 * 64 + lane;
+        float bias_a[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) bias_a[tt] = hh == 0 ? WSCALE * bp[((size_t)dir * NBLK + sq * NTQ + TOFF + tt) * 32 + j] : 0.f;
+        float cst[NT][SB][4];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cst[tt][sb][q] = 0.f;
+        floatx16 facc[L4T ? SB : 1];
+#pragma unroll
+        for (int sb = 0; sb < (L4T ? SB : 1); ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) facc[sb][r] = 0.f;
+
+        typedef const half8 __attribute__((address_space(1))) *gptr_t;
+        for (int step = 0; step < NET_T; ++step) {
+            const int t = dir ? NET_T - 1 - step : step;
+            const int tprev = step ? (dir ? t + 1 : t - 1) : t;      // step 0: h_{-1} = 0, any valid slice contributes nothing
+            const int cur = step & 1, nxt = cur ^ 1;
+
+            auto ldx = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+                    bh[sb] = *(const half8 *)&xs[0][2 * g + hh][32 * sb + j][0];
+                    bl[sb] = *(const half8 *)&xs[1][2 * g + hh][32 * sb + j][0];
+                }
+            };
+            auto ldh = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+                    bh[sb] = *(const half8 *)&hb_hi[cur][32 * sb + j][16 * g + 8 * hh];
+                    bl[sb] = *(const half8 *)&hb_lo[cur][32 * sb + j][16 * g + 8 * hh];
+                }
+            };
+            auto ldw = [&](int g, half8 (&ah)[NTH], half8 (&al)[NTH]) {
+                uintptr_t wbase = (uintptr_t)wl;                 // see k_lstm_h::ldw (address laundering, address_space(1))
+                asm volatile("" : "+v"(wbase));
+                const gptr_t wg = (gptr_t)wbase + (size_t)g * NTQ * 2 * 64;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    if ((ABL & 16) && g > 0) continue;
+                    ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64];
+                }
+                if constexpr (L4T) {
+                    if (g >= NGX && !((ABL & 16) && g > NGX)) {
+                        uintptr_t w4base = (uintptr_t)(W4p + (((size_t)(dir * NET_T + tprev) * 4 + sq) * NGH) * 2 * 64 + lane);
+                        asm volatile("" : "+v"(w4base));
+                        const gptr_t w4 = (gptr_t)w4base + (size_t)(g - NGX) * 2 * 64;
+                        ah[NT] = w4[0]; al[NT] = w4[64];
+                    }
+                }
+            };
+
+            floatx16 acc[NT][SB];
+            {
+                floatx16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[tt], 1.0f, z, 0, 0, 0);
+            }
+            auto mma = [&](const half8 (&ah)[NTH], const half8 (&al)[NTH], const half8 (&bh)[SB], const half8 (&bl)[SB], bool hpart) {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bh[sb], acc[tt][sb], 0, 0, 0);
+                if (L4T && hpart) {
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) facc[L4T ? sb : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[L4T ? NT : 0], bh[sb], facc[L4T ? sb : 0], 0, 0, 0);
+                }
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tt], bh[sb], acc[tt][sb], 0, 0, 0);
+                if (L4T && hpart) {
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) facc[L4T ? sb : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[L4T ? NT : 0], bh[sb], facc[L4T ? sb : 0], 0, 0, 0);
+                }
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bl[sb], acc[tt][sb], 0, 0, 0);
+                if (L4T && hpart) {
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) facc[L4T ? sb : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[L4T ? NT : 0], bl[sb], facc[L4T ? sb : 0], 0, 0, 0);
+                }
+            };
+            half8 ah[PD + 1][NTH], al[PD + 1][NTH], bh[PD + 1][SB], bl[PD + 1][SB];
+#define C3R_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define C3R_LOAD(G) do { ldw((G), ah[(G) % (PD + 1)], al[(G) % (PD + 1)]); \
+                         if ((G) < NGX) ldx((G), bh[(G) % (PD + 1)], bl[(G) % (PD + 1)]); \
+                         else ldh((G) - NGX, bh[(G) % (PD + 1)], bl[(G) % (PD + 1)]); } while (0)
+#define C3R_PRE(D) if constexpr ((D) < PD && (D) < NG) { C3R_LOAD(D); }
+#define C3R_STEP(G)                                                                                              \
+    if constexpr ((G) < NG) {                                                                                     \
+        C3R_FENCE();                                                                                              \
+        if constexpr ((G) + PD < NG) { C3R_LOAD((G) + PD); }                                                      \
+        mma(ah[(G) % (PD + 1)], al[(G) % (PD + 1)], bh[(G) % (PD + 1)], bl[(G) % (PD + 1)], (G) >= NGX);          \
+        if constexpr ((G) + PD < NG) {                                                                            \
+            constexpr int NMM = ((G) >= NGX ? NTH : NT) * SB * 3;                                                 \
+            sched_interleave<NMM, ((G) + PD >= NGX ? NTH : NT) * 2, SB * 2>();                                    \
+        }                                                                                                         \
+        if constexpr ((G) == NGX - 1) {                                                                           \
+            /* after this barrier every wavefront is done with x_t (the 2-tile wavefronts wait here for the     */ \
+            /* 3-tile ones, which then have the matrix pipe to themselves: no pipe time is lost)                */ \
+            C3R_FENCE();                                                                                          \
+            __syncthreads();                                                                                      \
+        }                                                                                                         \
+    }
+            C3R_PRE(0) C3R_PRE(1) C3R_PRE(2)
+            C3R_STEP(0) C3R_STEP(1) C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
+            C3R_STEP(10) C3R_STEP(11) C3R_STEP(12) C3R_STEP(13) C3R_STEP(14) C3R_STEP(15) C3R_STEP(16) C3R_STEP(17) C3R_STEP(18)
+            C3R_STEP(19) C3R_STEP(20) C3R_STEP(21) C3R_STEP(22) C3R_STEP(23) C3R_STEP(24) C3R_STEP(25)
+            C3R_FENCE();
+#undef C3R_PRE
+#undef C3R_STEP
+#undef C3R_LOAD
+#undef C3R_FENCE
+            // x_{t+1} by LDS-DMA now, so that no weight load queues behind it (vmcnt retires in order): it lands during the
+            // cell update
+            if (step + 1 < NET_T) dma_x(dir ? NET_T - 2 - step : step + 1);
+            // ---- lane-local cell update, one tile at a time (see k_lstm_h); cell state in registers
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int NU = 4 * SB;
+                constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
+                float cq[NU], ei[NU], ef[NU], eg[NU], eo[NU], hval[NU];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) cq[u] = cst[tt][u >> 2][u & 3];
+                if (ABL & 2) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) hval[u] = acc[tt][u >> 2][4 * (u & 3)] + acc[tt][u >> 2][4 * (u & 3) + 1] + acc[tt][u >> 2][4 * (u & 3) + 2] + acc[tt][u >> 2][4 * (u & 3) + 3];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) ei[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 0]), 1e18f);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 1]);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(K2 * acc[tt][u >> 2][4 * (u & 3) + 2]), 1e18f);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) eo[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 3]), 1e18f);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) ei[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + ei[u]) * (1.0f + eg[u]));
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_rcpf(1.0f + ef[u]);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) cq[u] = fmaf(ef[u], cq[u], ei[u]);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[u]), 1e18f);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) hval[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + eo[u]) * (1.0f + eg[u]));
+                }
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cst[tt][sb][q] = cq[4 * sb + q];
+                    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                    half4 vh, vl;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        vh[q] = (_Float16)hval[4 * sb + q];
+                        float d = hval[4 * sb + q] - (float)vh[q];
+                        asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
+                        vl[q] = (_Float16)d;
+                    }
+                    *(half4 *)&hb_hi[nxt][32 * sb + j][8 * (sq * NTQ + TOFF + tt) + 4 * hh] = vh;
+                    *(half4 *)&hb_lo[nxt][32 * sb + j][8 * (sq * NTQ + TOFF + tt) + 4 * hh] = vl;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // x_{t+1} has landed (LDS-DMA is tracked by vmcnt)
+            __syncthreads();                                       // h_t complete; everyone is done with h_{t-1}
+        }
+        if constexpr (L4T) {
+            // ---- the last step's h (buffer NET_T & 1) still owes its L4 contribution
+            const int tl = dir ? 0 : NET_T - 1, hbuf = NET_T & 1;
+            const half8 *w4 = W4p + (((size_t)(dir * NET_T + tl) * 4 + sq) * NGH) * 2 * 64 + lane;
+#pragma unroll 2
+            for (int g = 0; g < NGH; ++g) {
+                const half8 a_h = w4[(size_t)(g * 2 + 0) * 64], a_l = w4[(size_t)(g * 2 + 1) * 64];
+                half8 b_h[SB], b_l[SB];
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+                    b_h[sb] = *(const half8 *)&hb_hi[hbuf][32 * sb + j][16 * g + 8 * hh];
+                    b_l[sb] = *(const half8 *)&hb_lo[hbuf][32 * sb + j][16 * g + 8 * hh];
+                }
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, b_h[sb], facc[sb], 0, 0, 0);
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l, b_h[sb], facc[sb], 0, 0, 0);
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, b_l[sb], facc[sb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                const int sidx = site0 + 32 * sb + j;
+                if (sidx < n) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v = make_float4(facc[sb][4 * q] * WUNSCALE, facc[sb][4 * q + 1] * WUNSCALE, facc[sb][4 * q + 2] * WUNSCALE,
+                                               facc[sb][4 * q + 3] * WUNSCALE);
+                        *(float4 *)(a4part + ((size_t)sidx * 2 + dir) * NET_L4 + 32 * sq + 8 * q + 4 * hh) = v;
+                    }
+                }
+            }
+        }
+    };
+    if (C3R_W8_PRIO == 1 && wave < 4) __builtin_amdgcn_s_setprio(1);
+    if (C3R_W8_PRIO == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (wave < 4) body(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::false_type{});
+    else body(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::true_type{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1267,8 +1555,14 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
         prof("k_lstm1", 1);
         prof("k_lstm2", 0);
         // layer 2 with the L4 dense layer fused in: y2 is never materialised
+#if C3R_L2_W8
+        (void)y2h;
+        hipLaunchKernelGGL((k_lstm2_w8<0>), grid, dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const float *)s.d_b2, (int)n,
+                           (const half8 *)s.d_w4f, s.d_a4, ns);
+#else
         hipLaunchKernelGGL((k_lstm_h<2 * NET_H1, 2 * NET_H1, NET_H2, false, LSTM_SB, 0, true, C3R_L2_PD, C3R_L2_ILV>), grid, block, 0, st, (const void *)y1h,
                            (const half8 *)s.d_w2h, (const float *)s.d_b2, y2h, (int)n, (const half8 *)s.d_w4f, s.d_a4, ns);
+#endif
         prof("k_lstm2", 1);
         heads_parts = 2;
     } else {

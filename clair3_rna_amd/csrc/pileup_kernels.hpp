@@ -116,8 +116,10 @@ struct ScanArgs {
     int32_t has_lbed, has_cbed, genotyping;
     int32_t min_mq, excl_flags, min_cov;
     double snp_af, indel_af;
-    EvRec *ev;                    // scratch, one slot per I/D op in the loaded reads (+ padding)
+    EvRec *ev;                    // scratch: ev_cap records, bump-allocated per tile through ev_cursor
     unsigned long long *ev_cursor;
+    unsigned long long ev_cap;    // a reservation past it is refused: the tile skips its events and raises *ev_overflow
+    int32_t *ev_overflow;
     int32_t *last_row;            // [n_regions] atomicMax of the last SLOT (index into the position arrays) with a row
     const uint32_t *drop;         // mpileup depth cap: [n_regions][drop_words] bit per read = discarded in that region; null: none
     int32_t drop_words;
@@ -138,11 +140,17 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 __device__ __forceinline__ bool read_dropped(const uint32_t *drop, int words, int region, int r) {
     return drop != nullptr && ((drop[(size_t)region * words + (r >> 5)] >> (r & 31)) & 1u);
 }
+// samtools mpileup's read filter as the reference invokes it (src/create_tensor_pileup.py:436-451): --excl-flags (replaces the
+// default mask), unmapped reads, --min-MQ, and — because the reference never passes -A / --count-orphans — "anomalous read
+// pairs": reads with FLAG 0x1 (paired) set and 0x2 (proper pair) clear are skipped.
+__host__ __device__ __forceinline__ bool flag_fails(unsigned flag, int excl) {
+    return (flag & (unsigned)excl) || (flag & 4u) || ((flag & 1u) && !(flag & 2u));
+}
 __device__ __forceinline__ bool read_passes(const DevRead &r, int min_mq, int excl) {
-    return !(r.flag & excl) && !(r.flag & 4) && r.mapq >= min_mq && r.end > r.pos;
+    return !flag_fails(r.flag, excl) && r.mapq >= min_mq && r.end > r.pos;
 }
 __device__ __forceinline__ bool seg_passes(const DevSeg &g, int min_mq, int excl) {
-    return !(g.flag & excl) && !(g.flag & 4) && g.mapq >= min_mq;
+    return !flag_fails(g.flag, excl) && g.mapq >= min_mq;
 }
 __device__ __forceinline__ int lower_bound_seg(const DevSeg *g, int n, int v) {  // first i with g[i].ext_start >= v
     int lo = 0, hi = n;
@@ -354,14 +362,21 @@ __device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, 
     }
 }
 
+// Two indel events are the same allele iff their mpileup texts are equal (Counter keys, src/create_tensor_pileup.py:179): same
+// kind and length, same bases, and the same letter case = strand — except that '=' (BAM base code 0) has no case, so an
+// insertion made of '=' only reads the same on both strands (and lands on channel i for both: '=' is not upper-case, :221-230).
 __device__ __forceinline__ bool ev_equal(const ScanArgs &a, const EvRec &x, const EvRec &y) {
-    if (x.kind != y.kind || x.len != y.len || x.key != y.key) return false;
+    if (((x.kind ^ y.kind) & 2) || x.len != y.len || x.key != y.key) return false;
+    bool caseless = (x.kind & 2) && x.key == 0;
     if ((x.kind & 2) && x.len > 16) {
         const DevRead rx = a.reads[x.read_idx], ry = a.reads[y.read_idx];
-        for (uint32_t j = 16; j < x.len; ++j)
-            if (base_code(a.seq, rx.seq_off, x.qpos + j, rx.l_seq) != base_code(a.seq, ry.seq_off, y.qpos + j, ry.l_seq)) return false;
+        for (uint32_t j = 16; j < x.len; ++j) {
+            const int cx = base_code(a.seq, rx.seq_off, x.qpos + j, rx.l_seq);
+            if (cx != base_code(a.seq, ry.seq_off, y.qpos + j, ry.l_seq)) return false;
+            caseless = caseless && cx == 0;
+        }
     }
-    return true;
+    return !((x.kind ^ y.kind) & 1) || caseless;
 }
 
 // block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, *total = sum
@@ -482,6 +497,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         if (tid == 0) s_evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
         __syncthreads();
         const unsigned long long evb = s_evbase;
+        if (evb + (unsigned long long)((ev_total + 15) & ~15) > a.ev_cap) {
+            // cannot happen with the host's sizing (c3r_pileup_scan_regions); if it ever does, no write leaves the buffer and the
+            // scan call fails instead of corrupting device memory
+            if (tid == 0) *a.ev_overflow = 1;
+        } else {
         walk_reads<C, SCATTER>(a, s, slo, shi, t0, t1, evb, tg.region);
         __threadfence_block();
         __syncthreads();
@@ -498,6 +518,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
                 eq += ev_equal(a, me, o) ? 1 : 0;
             }
             atomicMax(&s_cnt[pl * C + me.ch], eq);
+        }
         }
         __syncthreads();
     }

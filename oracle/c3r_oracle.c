@@ -171,6 +171,14 @@ char *orc_mpileup(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *c
     return orc_mpileup_d(reads_in, n_reads, cigar_in, seq, ctg, beg1, end1, min_mq, excl_flags, bed, n_bed, with_hp, 8000, out_len);
 }
 
+/* The flag part of samtools mpileup's read filter as the reference runs it (src/create_tensor_pileup.py:436-451):
+ * --excl-flags replaces the default mask, unmapped reads never pile up, and since the reference never passes -A
+ * (--count-orphans) mpileup also skips "anomalous read pairs": FLAG 0x1 (paired) set with 0x2 (proper pair) clear
+ * (htslib-based mpileup, mplp_func; third-party, absent here: restated from its documented behaviour). */
+static int flag_fails(unsigned flag, int excl_flags) {
+    return (flag & (unsigned)excl_flags) || (flag & 4u) || ((flag & 1u) && !(flag & 2u));
+}
+
 /* Depth cap, restated from htslib's pileup engine (bam_plp_push / bam_plp_next; third-party, absent here: parity unpinned).
  * Reads reach the engine in file order, already filtered by flag / MAPQ, and only those overlapping the region.  A read is
  * discarded iff it starts at the position the engine currently stands on — i.e. it is NOT the first read pushed for its start
@@ -187,7 +195,7 @@ static void depth_cap(const c3r_read_t *reads, int64_t n_reads, const uint32_t *
     for (int64_t i = 0; i < n_reads; ++i) {
         const c3r_read_t *r = &reads[i];
         if (r->pos > end0_incl) break;
-        if ((r->flag & excl_flags) || (r->flag & 4) || r->mapq < min_mq || r->n_cigar == 0) continue;
+        if (flag_fails(r->flag, excl_flags) || r->mapq < min_mq || r->n_cigar == 0) continue;
         const int64_t rl = cigar_rlen(cigar + r->cigar_off, r->n_cigar);
         if (rl <= 0 || r->pos + rl <= beg0) continue;                 /* not fetched for this region */
         int64_t w = 0;                                                /* retire: keep exclusive end > pos - 1 */
@@ -236,7 +244,7 @@ char *orc_mpileup_d(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t 
         /* admit reads starting at or before pos */
         while (next < n_reads && reads[next].pos <= pos) {
             const c3r_read_t *r = &reads[next];
-            int ok = !(r->flag & excl_flags) && !(r->flag & 4) && r->mapq >= min_mq && r->n_cigar > 0 && !dropped[next];
+            int ok = !flag_fails(r->flag, excl_flags) && r->mapq >= min_mq && r->n_cigar > 0 && !dropped[next];
             if (ok) {
                 int64_t rl = cigar_rlen(cigar + r->cigar_off, r->n_cigar);
                 if (rl > 0 && r->pos + rl - 1 >= pos) {

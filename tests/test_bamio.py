@@ -200,6 +200,42 @@ def test_unsorted_file_is_refused_by_the_indexer(tmp_path):
         bamio.BamFile(str(tmp_path / "junk.bam"))
 
 
+def test_malformed_records_are_errors_not_overreads(tmp_path):
+    """A CG:B,I array (or any B array) that claims more elements than its record holds, and a record whose CIGAR / sequence
+    lengths run past its block, make the fetch fail with a message; nothing is read outside the record."""
+    M, N, S = 0, 3, 4
+    op = lambda ln, o: (ln << 4) | o
+    seq10 = [1, 2, 4, 8, 15, 1, 2, 4, 8, 1]
+    good = (0, 100, 60, 0, [op(10, M)], seq10, b"HPC\x01")
+    bad_cg = (0, 150, 60, 0, [op(10, S), op(57, N)], seq10, b"CGBI" + struct.pack("<I", 1 << 20) + b"\x00" * 8)
+    bad_b = (0, 150, 60, 0, [op(10, M)], seq10, b"ZZBs" + struct.pack("<I", 5000) + b"\x00" * 4)
+    for k, bad in enumerate((bad_cg, bad_b)):
+        p = str(tmp_path / ("m%d.bam" % k))
+        _raw_bam(p, [good, bad])
+        with bamio.BamFile(p) as bf:
+            with pytest.raises(IOError, match="malformed alignment record"):
+                bf.fetch("c1")
+            assert len(bf.fetch("c1", 0, 120).reads) == 1            # the record before it is still readable
+    # l_seq far beyond the record
+    p = str(tmp_path / "m2.bam")
+    _raw_bam(p, [good, (0, 150, 60, 0, [op(10, M)], seq10, b"")])
+    raw = bytearray(b"".join(bam._bgzf_blocks(p)))
+    off = raw.rfind(struct.pack("<ii", 0, 150)) + 16
+    raw[off:off + 4] = struct.pack("<i", 1 << 24)
+    with open(p, "wb") as f:
+        bam._bgzf_write(f, bytes(raw)); f.write(bam._BGZF_EOF)
+    with bamio.BamFile(p) as bf:
+        with pytest.raises(IOError, match="malformed alignment record"):
+            bf.fetch("c1")
+    # header with a negative reference-name length
+    hdr = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", -5) + b"\x00" * 16
+    p = str(tmp_path / "h.bam")
+    with open(p, "wb") as f:
+        bam._bgzf_write(f, hdr); f.write(bam._BGZF_EOF)
+    with pytest.raises(IOError, match="reference name length"):
+        bamio.BamFile(p)
+
+
 @pytest.mark.parametrize("margin,batch", [("1", "3"), ("70000", "512"), ("4194304", "1")])
 def test_long_index_chunks_inflate_in_parallel(bam_case, margin, batch, monkeypatch):
     """Indexed fetches whose chunk is long (a whole contig) inflate their blocks on threads (scan_blocks) instead of through the

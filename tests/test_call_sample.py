@@ -110,7 +110,7 @@ def _fake_sample(tmp):
     return fa, bm, wfn
 
 
-def _launch(tmp, out, fa, bm, wfn, extra, world=1):
+def _launch(tmp, out, fa, bm, wfn, extra, world=1, env_extra=None, expect_fail=False):
     import socket
     import subprocess
     import sys
@@ -128,8 +128,11 @@ def _launch(tmp, out, fa, bm, wfn, extra, world=1):
         else:
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
+        env.update(env_extra or {})
         procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
+    if expect_fail:
+        return [p.returncode for p in procs], outs
     assert all(p.returncode == 0 for p in procs), outs
     return [r for r in open(os.path.join(out, "output.vcf")).read().split("\n") if not r.startswith("##cmdline=")]
 
@@ -161,6 +164,31 @@ def test_driver_orchestration_single_and_two_ranks_gloo(tmp_path):
     no_ref = _launch(tmp, os.path.join(tmp, "noref"), fa, bm, wfn, ["--qual", "10"], world=2)
     kept = [r.split("\t") for r in no_ref if r and r[0] != "#"]
     assert kept and all(r[4] != "." for r in kept) and all((r[6] == "LowQual") == (float(r[5]) <= 10) for r in kept)
+
+
+def test_two_ranks_unindexed_bam_and_a_failing_rank(tmp_path):
+    """(1) An unindexed BAM under two ranks: rank 0 alone builds tmp/input.bam(.bai) (renamed into place), the other rank opens it
+    after the rendezvous, and the result equals the indexed single-process run.  (2) A contig whose device stage raises on one
+    rank: that rank still reaches the rendezvous, and BOTH ranks exit non-zero promptly instead of one of them waiting in a
+    barrier for the gloo timeout."""
+    import time
+    tmp = str(tmp_path)
+    fa, bm, wfn = _fake_sample(tmp)
+    one = _launch(tmp, os.path.join(tmp, "one"), fa, bm, wfn, ["--print_ref_calls"])
+    os.remove(bm + ".bai")
+    two = _launch(tmp, os.path.join(tmp, "two"), fa, bm, wfn, ["--print_ref_calls"], world=2)
+    assert two == one
+    made = sorted(os.listdir(os.path.join(tmp, "two", "tmp")))
+    assert "input.bam" in made and "input.bam.bai" in made and not [n for n in made if ".tmp" in n]
+    t0 = time.time()
+    codes, outs = _launch(tmp, os.path.join(tmp, "bad"), fa, bm, wfn, ["--print_ref_calls"], world=2,
+                          env_extra={"C3R_FAKE_FAIL_LEN": "30000"}, expect_fail=True)          # chr3
+    assert all(c != 0 for c in codes), (codes, outs)
+    assert time.time() - t0 < 120
+    assert any("injected failure" in o for o in outs) and any("another rank failed" in o for o in outs)
+    codes, outs = _launch(tmp, os.path.join(tmp, "bad1"), fa, bm, wfn, ["--print_ref_calls"], env_extra={"C3R_FAKE_FAIL_LEN": "30000"},
+                          expect_fail=True)
+    assert codes == [1] and "injected failure" in outs[0]
 
 
 def test_fetch_reference_slices_like_faidx(tmp_path):

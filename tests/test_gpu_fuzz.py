@@ -79,7 +79,7 @@ def _case(seed, phased):
         if rng.random() < 0.1:
             qlen = max(1, qlen - rng.randint(1, 3))          # query shorter than the CIGAR claims
         seq = "".join(rng.choice("ACGTACGTACGTACGTN=RY") for _ in range(qlen))
-        flag = (16 if rng.random() < 0.5 else 0) | rng.choice([0] * 14 + [256, 2048, 4, 1024, 512, 8])
+        flag = (16 if rng.random() < 0.5 else 0) | rng.choice([0] * 14 + [256, 2048, 4, 1024, 512, 8, 1, 3, 65, 131])
         mapq = rng.choice([60] * 8 + [0, 3, 5, 4, 20, 255])
         hp = rng.choice([0, 1, 2, 1, 2]) if phased else 0
         recs.append(dict(pos=pos, cigar=cg, seq=seq, flag=flag, mapq=mapq, hp=hp))

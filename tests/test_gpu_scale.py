@@ -138,6 +138,36 @@ def test_scan_regions_equals_successive_chunk_scans(eng, kw):
     eng.set_params()
 
 
+def test_scan_regions_with_heavily_overlapping_regions(eng):
+    """Regions may overlap arbitrarily: the same region several times, and chunks shorter than their +-33 bp halos (three and more
+    halos over one indel).  The indel-event scratch is sized from the reads inside every region (it used to assume pairwise
+    overlap) — the result must equal the chunk-by-chunk scans."""
+    from clair3_rna_amd import capi, synth
+    ref, rs, _ = synth.small_case(seed=77, ref_len=40000, n_genes=10, depth=60, err_ins=0.05, err_del=0.06)
+    L = len(ref)
+    eng.params = capi.default_params()
+    eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.set_params()
+    eng.load_reads(rs)
+    eng.set_reference(1, ref)
+    whole = (1, L)
+    assert eng.scan(1, L) > 50
+    mid = int(np.median(eng.sites()["pos"]))                               # where the candidates (and the reads' indels) are
+    tiny = [(a, min(a + 19, L)) for a in range(max(1, mid - 2000), min(L, mid + 2000), 20)]   # 200 chunks of 20 bp: ~4 halos over every position
+    for regions in ([whole] * 5, tiny, tiny + [whole, whole, whole]):
+        eng.begin_batch()
+        n_seq = sum(eng.scan(a, b) for a, b in regions)
+        eng.end_batch()
+        X1, S1, T1 = eng.tensors(), eng.sites(), eng.tokens()
+        eng.begin_batch()
+        n_one = eng.scan_regions(regions)
+        eng.end_batch()
+        X2, S2, T2 = eng.tensors(), eng.sites(), eng.tokens()
+        assert n_seq == n_one > 20, (n_seq, n_one, len(regions))
+        assert np.array_equal(X1, X2)
+        assert S1.tobytes() == S2.tobytes() and T1.tobytes() == T2.tobytes()
+
+
 def test_two_contexts_on_two_streams_like_the_bench(eng):
     """bench.py pipelines passes on two contexts (two HIP streams, one GPU): context B builds tensors while context A's
     persistent LSTM workgroups run.  Interleaved asynchronous use must give what one context gives synchronously."""

@@ -81,6 +81,11 @@ def test_filters_flags_and_mapq():
     assert bases([R(9, "2M", "AC", mapq=200)]) == {10: "^~A", 11: "C$"}
     # --min-MQ is a parameter
     assert bases([R(9, "2M", "AC", mapq=20), R(9, "2M", "GG", mapq=40)], min_mq=30) == {10: "^IG", 11: "G$"}
+    # no -A on the reference's command line: anomalous pairs (paired without the proper-pair bit) are skipped, proper pairs
+    # and single-end reads are kept, whatever their mate bits say
+    recs = [R(9, "2M", "AC", flag=1), R(9, "2M", "GG", flag=3), R(9, "2M", "TT", flag=1 | 64 | 16), R(9, "2M", "CA", flag=3 | 128 | 16),
+            R(9, "2M", "AT", flag=2)]
+    assert bases(recs) == {10: "^]G^]c^]A", 11: "G$a$T$"}
 
 
 def test_bam_order_and_depth_column():
