@@ -758,6 +758,26 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     if ((ABL & 16) && g > 0) continue;
+                    if constexpr ((ABL & 128) != 0) {
+                        // probe (timing only, wrong numbers): lo halves as 8-bit fixed point — 8 bytes per lane instead of 16, widened
+                        // the way a real decode would be (byte -> f16 through the 0x64xx magic: v_perm + v_pk_add_f16 per pair)
+                        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                        typedef const uint2v __attribute__((address_space(1))) *g8_t;
+                        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                        ah[tt] = wg[(tt * 2 + 0) * 64];
+                        const uint2v q = *((g8_t)(wg + (tt * 2 + 1) * 64));
+                        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+                        uint4v e;
+                        e[0] = __builtin_amdgcn_perm(q[0], 0x64646464u, 0x04010400u);
+                        e[1] = __builtin_amdgcn_perm(q[0], 0x64646464u, 0x04030402u);
+                        e[2] = __builtin_amdgcn_perm(q[1], 0x64646464u, 0x04010400u);
+                        e[3] = __builtin_amdgcn_perm(q[1], 0x64646464u, 0x04030402u);
+                        const half2v off = {(_Float16)-1152.f, (_Float16)-1152.f};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { half2v v = __builtin_bit_cast(half2v, e[c]); v = v + off; e[c] = __builtin_bit_cast(unsigned, v); }
+                        al[tt] = __builtin_bit_cast(half8, e);
+                        continue;
+                    }
                     ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64];
                 }
                 if constexpr (L4T) {
