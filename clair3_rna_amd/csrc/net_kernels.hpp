@@ -715,9 +715,21 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
         constexpr bool L4T = decltype(l4c)::value;
         constexpr int NTH = NT + (L4T ? 1 : 0);          // tiles in the recurrent part
         const half8 *wl = Wp + ((size_t)(dir * 4 + sq) * NG) * NTQ * 2 * 64 + (size_t)TOFF * 2 * 64 + lane;
-        float bias_a[NT];
+        // bias: one f16 MFMA per (tile, site block) and step — A = {hi, lo, 0...} of 2^12 b on the k-slots 0 and 1 (lane half 0),
+        // B = {1, 1, 0...}: 32 cycles instead of the 64 of the f32 MFMA k_lstm_h spends on it; hi + lo carries 22 bits like every
+        // other operand of this path
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        unsigned bias_hl[NT];
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) bias_a[tt] = hh == 0 ? WSCALE * bp[((size_t)dir * NBLK + sq * NTQ + TOFF + tt) * 32 + j] : 0.f;
+        for (int tt = 0; tt < NT; ++tt) {
+            const float bv = WSCALE * bp[((size_t)dir * NBLK + sq * NTQ + TOFF + tt) * 32 + j];
+            half2v hl;
+            hl[0] = (_Float16)bv;
+            hl[1] = (_Float16)(bv - (float)hl[0]);
+            bias_hl[tt] = hh == 0 ? __builtin_bit_cast(unsigned, hl) : 0u;
+        }
+        const half2v one2 = {(_Float16)1.f, (_Float16)1.f};
+        const unsigned ones_b = hh == 0 ? __builtin_bit_cast(unsigned, one2) : 0u;
         float cst[NT][SB][4];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
@@ -795,10 +807,15 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
                 floatx16 z;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+                const uint4v bb = {ones_b, 0u, 0u, 0u};
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
+                for (int tt = 0; tt < NT; ++tt) {
+                    const uint4v ba = {bias_hl[tt], 0u, 0u, 0u};
 #pragma unroll
-                    for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[tt], 1.0f, z, 0, 0, 0);
+                    for (int sb = 0; sb < SB; ++sb)
+                        acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ba), __builtin_bit_cast(half8, bb), z, 0, 0, 0);
+                }
             }
             auto mma = [&](const half8 (&ah)[NTH], const half8 (&al)[NTH], const half8 (&bh)[SB], const half8 (&bl)[SB], bool hpart) {
 #pragma unroll
@@ -981,9 +998,10 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
                                                                   // sites past n own (unused) slots, so stores need no guard
 
     const half8 *wl = Wp + ((size_t)(dir * 4 + wave) * NG) * NT * 2 * 64 + lane;
-    float bias_a[NT];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) bias_a[tt] = hh == 0 ? WSCALE * bp[((size_t)dir * 16 + wave * NT + tt) * 32 + j] : 0.f;
+    // bias: the input is padded from CIN to 32 k-slots; pack_lstm_dir_h puts the bias (hi/lo like any weight) on slot CIN and the
+    // loader below feeds a constant 1 there — no bias MFMA at all (k_lstm_h spends a 64-cycle f32 MFMA per tile, block and step)
+    static_assert(CIN < 32, "a free input slot for the bias");
+    (void)bp;
 
     // cell state in LDS ([group][site][unit], fp32): the two accumulator sets leave no registers for it
     constexpr int CP = H + 4;
@@ -1070,15 +1088,6 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
             }
 #undef C3R_Q
         };
-        if (MMA) {
-            floatx16 z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int sb = 0; sb < SB; ++sb) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[tt], 1.0f, z, 0, 0, 0);
-        }
         half8 ah[2][NT], al[2][NT], bh[2][SB], bl[2][SB];
         typedef const half8 __attribute__((address_space(1))) *gptr_t;     // see k_lstm_h::ldw
         // prefetch item I of k-group G1: items 0..2NT-1 = the weight fragments, then one B-operand item per site block
@@ -1099,7 +1108,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
                     for (int e = 0; e < 8; ++e) {
                         const int k = k0 + e;
                         const int32_t v = xp[k < CIN ? k : CIN - 1];
-                        bh[G1 & 1][sb][e] = (k < CIN) ? (_Float16)(float)v : (_Float16)0.f;
+                        bh[G1 & 1][sb][e] = (k < CIN) ? (_Float16)(float)v : (k == CIN ? (_Float16)1.f : (_Float16)0.f);    // slot CIN: bias
                     }
                 } else {
                     bh[G1 & 1][sb] = *(const half8 *)&hb_hi[gm][32 * sb + j][16 * (G1 - NGX) + 8 * hh];
@@ -1124,7 +1133,13 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
                 constexpr int m = decltype(mc)::value;
                 if constexpr (MMA) {
                     constexpr int p = m / (NT * SB), tt = (m % (NT * SB)) / SB, sb = m % SB;
-                    if constexpr (p == 0) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[G & 1][tt], bh[G & 1][sb], accM[tt][sb], 0, 0, 0);
+                    if constexpr (p == 0 && G == 0) {          // the step's first product of this accumulator starts from zero
+                        floatx16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[G & 1][tt], bh[G & 1][sb], z, 0, 0, 0);
+                    }
+                    if constexpr (p == 0 && G != 0) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[G & 1][tt], bh[G & 1][sb], accM[tt][sb], 0, 0, 0);
                     if constexpr (p == 1) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[G & 1][tt], bh[G & 1][sb], accM[tt][sb], 0, 0, 0);
                     if constexpr (p == 2) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[G & 1][tt], bl[G & 1][sb], accM[tt][sb], 0, 0, 0);
                     if constexpr (G + 1 < NG && m < NITEM) load_item(std::integral_constant<int, (G + 1 < NG ? G + 1 : G)>{}, mc, wg);
@@ -1328,11 +1343,12 @@ inline float h2f(uint16_t h) {
 inline void split_h(float v, uint16_t &hi, uint16_t &lo) { hi = f2h(v); lo = f2h(v - h2f(hi)); }
 
 // Split-f16 packing of one LSTM direction: [wave][g16][tile][hi|lo][lane][8 halves], weights x 2^12.
-inline void pack_lstm_dir_h(const float *Kin, int cin, int inp, const float *R, int H, std::vector<uint16_t> &wp) {
+// bias_slot != nullptr (layer 1): the bias rides on the first padded input slot (k = cin), see k_lstm1_skew.
+inline void pack_lstm_dir_h(const float *Kin, int cin, int inp, const float *R, int H, std::vector<uint16_t> &wp, const float *bias_slot = nullptr) {
     const int K = inp + H, NG = K / 16, NBLK = 4 * H / 32, NT = NBLK / 4;
     wp.assign((size_t)NBLK * NG * 2 * 64 * 8, 0);
     auto wcat = [&](int k, int col) -> float {
-        if (k < inp) return k < cin ? Kin[(size_t)k * 4 * H + col] : 0.f;
+        if (k < inp) return k < cin ? Kin[(size_t)k * 4 * H + col] : (bias_slot && k == cin ? bias_slot[col] : 0.f);
         return R[(size_t)(k - inp) * 4 * H + col];
     };
     for (int blk = 0; blk < NBLK; ++blk)
@@ -1412,7 +1428,7 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
         const float *b = q; q += 4 * NET_H1;
         pack_lstm_dir(Kin, C, inp1, R, b, NET_H1, tw, tb);
         w1.insert(w1.end(), tw.begin(), tw.end()); b1.insert(b1.end(), tb.begin(), tb.end());
-        pack_lstm_dir_h(Kin, C, inp1, R, NET_H1, th);
+        pack_lstm_dir_h(Kin, C, inp1, R, NET_H1, th, C3R_L1_SKEW ? b : nullptr);
         w1h.insert(w1h.end(), th.begin(), th.end());
     }
     for (int d = 0; d < 2; ++d) {

@@ -75,6 +75,20 @@ class Scheme:
         if self.name == "f16+2f6":
             d["w8"] = q6_block(W, 0)
             d["wl8"] = q6_block(W - wh, 0)
+        if self.name.startswith("f16x3wl8"):
+            # f16x3 with the weights' lo halves stored as 8-bit fixed point: one power-of-two scale per output column (= gate row of the
+            # transposed GEMM) "r", or per (column, block of 16 k) "b"
+            lo = W - wh
+            if self.name.endswith("r"):
+                m = lo.abs().amax(0, keepdim=True).clamp_min(1e-30)
+                E = torch.ceil(torch.log2(m / 127.0))
+                d["wl"] = torch.round(lo / torch.exp2(E)).clamp(-128, 127) * torch.exp2(E)
+            else:
+                K = lo.shape[0]; pad = (-K) % 16
+                lp = torch.nn.functional.pad(lo, (0, 0, 0, pad)).reshape(-1, 16, lo.shape[1])
+                m = lp.abs().amax(1, keepdim=True).clamp_min(1e-30)
+                E = torch.ceil(torch.log2(m / 127.0))
+                d["wl"] = (torch.round(lp / torch.exp2(E)).clamp(-128, 127) * torch.exp2(E)).reshape(-1, lo.shape[1])[:K]
         if self.name.startswith("f16+2i8"):
             # int8 corrections: w8 = rint(w * 127 / 2^E), wlo8 = rint(w_lo * 127 * 2^12 / 2^E); E per layer ("g"), per 32-row tile of
             # the permuted gate rows ("t": stand-in = per column block of 8 units) or per row ("r")
@@ -108,7 +122,7 @@ class Scheme:
             return x @ Wd["w"]
         xh = f16(x)
         xl = f16(x - xh)
-        if n == "f16x3":
+        if n == "f16x3" or n.startswith("f16x3wl8"):
             return xh @ Wd["wh"] + xl @ Wd["wh"] + xh @ Wd["wl"]
         if n == "f16x2a":
             return xh @ Wd["wh"] + xh @ Wd["wl"]
@@ -207,7 +221,7 @@ def main():
         blob = (L * gain).astype(np.float64)
     ref = forward(X, blob, C, Scheme("exact"))
     print("sites %d, weight gain %.2f, max P spread %.3f" % (n, gain, float(ref.max())))
-    for name in ("f16x3", "f16+2i8g", "f16+2i8t", "f16+2i8r", "f16+2f8", "f16+2f6", "f16x2a", "f16x2w", "f16x1"):
+    for name in ("f16x3", "f16x3wl8r", "f16x3wl8b", "f16+2i8g", "f16+2i8t", "f16+2i8r", "f16+2f8", "f16+2f6", "f16x2a", "f16x2w", "f16x1"):
         p = forward(X, blob, C, Scheme(name))
         d = (p - ref).abs()
         print("%-8s max|dP| %.3e   mean|dP| %.3e" % (name, float(d.max()), float(d.mean())))
