@@ -223,7 +223,7 @@ def main():
     sites_per_step_rank = sites / max(1, args.steps) / world
 
     # ---- per-kernel durations, live, with HIP events on the engine's stream (one extra untimed step)
-    roofline, kernels, stage_rates = None, {}, None
+    roofline, kernels, stage_rates, roofline_tb = None, {}, None, None
     if not args.no_profile:
         eng.set_profiling(True)
         eng.reset_kernel_stats()
@@ -263,6 +263,12 @@ def main():
                            inference_sites_per_s=round(n_prof / (net_ms * 1e-3), 1) if net_ms else None,
                            tensor_build_algorithmic_GBps=round(K1_BYTES_PER_SITE * n_prof / (k1_ms * 1e-3) / 1e9, 1) if k1_ms else None,
                            tensor_build_ms=round(k1_ms, 3), inference_ms=round(net_ms, 3))
+        # the tensor-build half against ITS roofline (HBM): SURVEY 8(d)'s algorithmic bytes per candidate over the summed device
+        # time of the tensor-build kernels of the profiled pass
+        tb_gbps = K1_BYTES_PER_SITE * n_prof / (k1_ms * 1e-3) / 1e9 if k1_ms else 0.0
+        roofline_tb = dict(kernels=sorted(k for k in kernels if k not in ("k_lstm1", "k_lstm2", "k_fc4", "k_heads")), bound="hbm",
+                           achieved=round(tb_gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(tb_gbps / PEAK_HBM_GBPS, 4),
+                           bytes_per_site=K1_BYTES_PER_SITE, ms=round(k1_ms, 3))
         traffic_fn = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
         if roofline and os.path.exists(traffic_fn):
             try:
@@ -282,7 +288,7 @@ def main():
                        "exonic_bp_per_rank": info["n_exonic"], "sites_per_step_per_rank": round(sites_per_step_rank, 1),
                        "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world,
                        "streams": len(engs)},
-            "roofline": roofline, "cpu_baseline": cpu, "stage_rates": stage_rates,
+            "roofline": roofline, "roofline_tensor_build": roofline_tb, "cpu_baseline": cpu, "stage_rates": stage_rates,
             "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
         }
         print(json.dumps(out), flush=True)

@@ -20,12 +20,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.search(r"k_lstm1_skew|k_lstm_h|k_lstm|k_[a-z0-9_]+", name)
+    m = re.search(r"k_lstm2_w8|k_lstm1_skew|k_lstm_h|k_lstm|k_[a-z0-9_]+", name)
     if not m:
         return name[:40]
     k = m.group(0)
     if k == "k_lstm1_skew":
         return "k_lstm1"
+    if k == "k_lstm2_w8":
+        return "k_lstm2"
     if k in ("k_lstm_h", "k_lstm"):
         return "k_lstm2" if ("ILi256E" in name or "Li160E" in name or re.search(r"k_lstm(_h)?<256,", name)) else "k_lstm1"
     return k
