@@ -146,7 +146,7 @@ def build_parser():
     a("--no_compress", action="store_true", help="leave <prefix>.vcf uncompressed (tests)")
     a("--gpu_id", type=int, default=None, help="default: $C3R_DEVICE, else LOCAL_RANK under torch.distributed.run, else 0")
     a("--fetch_threads", type=int, default=4)
-    a("--contexts", type=int, default=1, help="GPU contexts (each with its own host thread and HIP stream) working side by side; more than one pays off once contigs are plentiful and large (every context sizes its own device buffers on its first contigs)")
+    a("--contexts", type=int, default=2, help="GPU contexts (each with its own host thread and HIP stream) working side by side: while one waits for its kernels the other normalises reads or decodes (every context sizes its own device buffers on its first contig; first uses take turns)")
     return p
 
 
@@ -371,6 +371,8 @@ def Run(args, log=None):
         if timeline:
             log("[timeline] %-6s %-8s %7.3f -> %7.3f s" % (ctg, what, t0 - t_all, time() - t_all))
 
+    warm_lock, warmed = threading.Lock(), set()
+
     def fetch_task(ctg):
         t0 = time()
         r = fetcher(ctg, fai[ctg])
@@ -384,8 +386,21 @@ def Run(args, log=None):
             rs, ref, dt = fut.result()
             if not len(rs.reads):
                 return None
-            t0 = time()
-            todo = device_stage(eng, ctg, rs, ref)
+            # A context sizes its device buffers on its first contig (the largest it will see: contigs are called largest
+            # first).  hipMalloc of several GB under another context's running kernels is slow (58 ms idle, ~300-500 ms busy)
+            # and holds up every other HIP call of the process meanwhile, so first uses take turns, each on a quiet GPU.
+            first = id(eng) not in warmed
+            if first:
+                warm_lock.acquire()
+            try:
+                t0 = time()
+                todo = device_stage(eng, ctg, rs, ref)
+                if first:
+                    eng.synchronize()
+            finally:
+                if first:
+                    warmed.add(id(eng))
+                    warm_lock.release()
             t1 = time()
             mark(ctg, "device", t0)
             rows = decode_stage(eng, ctg, todo)

@@ -21,6 +21,7 @@ class FakeEngine(object):
         self._rows = []
 
     def close(self): pass
+    def synchronize(self): pass
     def load_weights(self, blob, channels=None): self.w = float(np.asarray(blob).sum())
     def set_bed(self, which, iv): pass
     def set_params(self, **kw): self.kw = kw
