@@ -66,6 +66,15 @@ constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 #ifndef C3R_W8_PRIO
 #define C3R_W8_PRIO 0        // 1: s_setprio 1 for the 3-tile wavefronts, 2: for the 2-tile wavefronts
 #endif
+#ifndef C3R_L1_W8_PD
+#define C3R_L1_W8_PD 0       // k_lstm1_w8: operand prefetch distance in k-groups (0: load, then use — the 4-waves-per-SIMD build has no registers for a ring)
+#endif
+#ifndef C3R_L1_W8_OCC
+#define C3R_L1_W8_OCC 4      // k_lstm1_w8: wavefronts per SIMD the register budget is cut for (4 = TWO workgroups per CU: 128 registers, 2 x 78 KB of LDS)
+#endif
+#ifndef C3R_L1_W8
+#define C3R_L1_W8 1          // layer 1 through k_lstm1_w8 (two wavefronts per SIMD, x staged once per workgroup) instead of k_lstm1_skew
+#endif
 #ifndef C3R_L2_W8
 #define C3R_L2_W8 1          // layer 2 through k_lstm2_w8 (two wavefronts per SIMD) instead of k_lstm_h
 #endif
@@ -1176,6 +1185,218 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Layer 1 with two wavefronts per SIMD: k_lstm1_w8, 512 threads, 64 sites x one direction per workgroup (the layer-1
+// counterpart of k_lstm2_w8).  The 16 gate-row tiles are dealt 2 + 2 to the wavefronts w and w+4 of a SIMD, cell state in
+// registers, h double-buffered in LDS, one barrier per step.  Two things differ from k_lstm1_skew:
+//   * x_t is staged ONCE per workgroup: the 64 sites' 18 (30) int32 counts of step t+1 are fetched at the top of step t by all
+//     512 threads (8-byte pieces of the [site][t][C] rows), converted to f16 and written to a 5 KB LDS tile at the end of the
+//     step; every wavefront then reads its B operands with ds_read_b128.  In k_lstm1_skew each wavefront gathered the same
+//     windows itself, 8 scattered dword loads per lane and k-group (1.6 of its 7.5 ms);
+//   * no phase skew inside a workgroup.  Two wavefronts of ONE workgroup meet at the step barrier and so run their K loops together
+//     and their cell updates together (measured: 7.2 ms, matrix pipe 43 % busy, the same as the skewed kernel).  The kernel is
+//     therefore cut to 128 registers (no operand ring: load, then use) and 78 KB of LDS so that TWO workgroups share a CU: their
+//     barriers are independent, they drift out of phase, and one workgroup's cell update runs under the other's MFMAs (6.9 ms).
+//     What is left is the cell update itself: without its 5 exp2 + 3 rcp per unit the kernel takes 4.9 ms at a 0.33 GHz higher
+//     clock (tools/lstm_probe_l1w8.hip).
+// Bias rides on input slot CIN (see k_lstm1_skew); Wp is k_lstm_h's layout ([dir][quarter][g][tile(4)][hi|lo][lane]).
+template <int CIN, int ABL = 0>
+__global__ __launch_bounds__(512, C3R_L1_W8_OCC) void k_lstm1_w8(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp,
+                                                      _Float16 *__restrict__ y, int n, int nstride) {
+    constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NTQ = 4, NT = 2, SB = 2, WG_SITES = 64, HV = H / 8, PD = C3R_L1_W8_PD;
+    constexpr int XP = 40;                     // x tile row stride in halves (80 B: conflict-free ds_read_b128)
+    constexpr int NPC = (CIN + 1) / 2;         // 8-byte pieces per (site, step) row of the int32 tensor
+    static_assert(CIN % 2 == 0 && CIN < 32, "even channel count, one free slot for the bias");
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 xs[2][WG_SITES][XP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int sq = wave & 3, toff = (wave >> 2) * NT;
+    const int dir = blockIdx.y;
+    const int site0 = blockIdx.x * WG_SITES;
+    const size_t plane_out = (size_t)nstride * NET_T * 2 * H;
+
+    for (int i = tid; i < WG_SITES * HP; i += 512) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
+    // constant part of both x tiles: slot CIN = 1 (bias), the padding = 0
+    for (int i = tid; i < 2 * WG_SITES * XP; i += 512) (&xs[0][0][0])[i] = ((i % XP) == CIN) ? (_Float16)1.f : (_Float16)0.f;
+
+    // x staging: piece q of this thread = 8 bytes (two int32 counts) of row (site, t)
+    constexpr int NPIECE = WG_SITES * NPC, PPT = (NPIECE + 511) / 512;
+    typedef int int2v __attribute__((ext_vector_type(2)));
+    int2v xr[PPT];
+    auto x_fetch = [&](int tt_) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int pc = tid + 512 * q;
+            if (pc < NPIECE) {
+                int sj = site0 + pc / NPC;
+                if (sj >= n) sj = n - 1;
+                xr[q] = *(const int2v *)(xin + ((size_t)sj * NET_T + tt_) * CIN + 2 * (pc % NPC));
+            }
+        }
+    };
+    auto x_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int pc = tid + 512 * q;
+            if (pc < NPIECE) {
+                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                half2v v;
+                v[0] = (_Float16)(float)xr[q][0]; v[1] = (_Float16)(float)xr[q][1];
+                *(half2v *)&xs[buf][pc / NPC][2 * (pc % NPC)] = v;
+            }
+        }
+    };
+    __syncthreads();
+    x_fetch(dir ? NET_T - 1 : 0);
+    x_store(0);
+    __syncthreads();
+
+    const half8 *wl = Wp + ((size_t)(dir * 4 + sq) * NG) * NTQ * 2 * 64 + (size_t)toff * 2 * 64 + lane;
+    float cst[NT][SB][4];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cst[tt][sb][q] = 0.f;
+    uint32_t yoff[SB];
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb) yoff[sb] = (uint32_t)(site0 + 32 * sb + j) * 8 + 4 * hh;
+
+    typedef const half8 __attribute__((address_space(1))) *gptr_t;
+    for (int step = 0; step < NET_T; ++step) {
+        const int t = dir ? NET_T - 1 - step : step;
+        const int cur = step & 1, nxt = cur ^ 1;
+        if (step + 1 < NET_T) x_fetch(dir ? NET_T - 2 - step : step + 1);       // lands under the K loop
+
+        auto ldb = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                if (g < NGX) {
+                    bh[sb] = *(const half8 *)&xs[cur][32 * sb + j][16 * g + 8 * hh];
+                } else {
+                    bh[sb] = *(const half8 *)&hb_hi[cur][32 * sb + j][16 * (g - NGX) + 8 * hh];
+                    bl[sb] = *(const half8 *)&hb_lo[cur][32 * sb + j][16 * (g - NGX) + 8 * hh];
+                }
+            }
+        };
+        auto ldw = [&](int g, half8 (&ah)[NT], half8 (&al)[NT]) {
+            uintptr_t wbase = (uintptr_t)wl;                 // see k_lstm_h::ldw
+            asm volatile("" : "+v"(wbase));
+            const gptr_t wg = (gptr_t)wbase + (size_t)((ABL & 16) ? 0 : g) * NTQ * 2 * 64;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) { ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64]; }
+        };
+        floatx16 acc[NT][SB];
+        auto mma = [&](auto gc, const half8 (&ah)[NT], const half8 (&al)[NT], const half8 (&bh)[SB], const half8 (&bl)[SB]) {
+            constexpr int G = decltype(gc)::value;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+                    if constexpr (G == 0) {                  // the step's first product starts each accumulator from zero
+                        floatx16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bh[sb], z, 0, 0, 0);
+                    } else {
+                        acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bh[sb], acc[tt][sb], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tt], bh[sb], acc[tt][sb], 0, 0, 0);
+            if constexpr (G >= NGX) {                        // (the int32 input has no lo half)
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bl[sb], acc[tt][sb], 0, 0, 0);
+            }
+        };
+        half8 ah[PD + 1][NT], al[PD + 1][NT], bh[PD + 1][SB], bl[PD + 1][SB];
+#define C3R_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define C3R_LOAD(G) do { ldw((G), ah[(G) % (PD + 1)], al[(G) % (PD + 1)]); ldb((G), bh[(G) % (PD + 1)], bl[(G) % (PD + 1)]); } while (0)
+#define C3R_STEP(G)                                                                                              \
+    if constexpr ((G) < NG) {                                                                                     \
+        C3R_FENCE();                                                                                              \
+        if constexpr (PD == 0 || (G) + PD < NG) { C3R_LOAD((G) + PD); }                                           \
+        mma(std::integral_constant<int, (G)>{}, ah[(G) % (PD + 1)], al[(G) % (PD + 1)], bh[(G) % (PD + 1)], bl[(G) % (PD + 1)]); \
+        if constexpr (PD > 0 && (G) + PD < NG) {                                                                  \
+            constexpr int NMM = NT * SB * ((G) < NGX ? 2 : 3);                                                    \
+            sched_interleave<NMM, NT * 2, ((G) + PD < NGX ? SB : SB * 2)>();                                      \
+        }                                                                                                         \
+    }
+        if constexpr (PD > 0) { C3R_LOAD(0); }
+        C3R_STEP(0) C3R_STEP(1) C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
+        static_assert(NG == 10, "extend the C3R_STEP list");
+        C3R_FENCE();
+#undef C3R_STEP
+#undef C3R_LOAD
+#undef C3R_FENCE
+        // ---- lane-local cell update, one tile at a time; h_t to LDS (both halves) and to the y1 planes, straight from registers
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int NU = 4 * SB;
+            constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
+            float cq[NU], ei[NU], ef[NU], eg[NU], eo[NU], hval[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) cq[u] = cst[tt][u >> 2][u & 3];
+            if (ABL & 2) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) hval[u] = acc[tt][u >> 2][4 * (u & 3)] + acc[tt][u >> 2][4 * (u & 3) + 1] + acc[tt][u >> 2][4 * (u & 3) + 2] + acc[tt][u >> 2][4 * (u & 3) + 3];
+            } else {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ei[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 0]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 1]);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(K2 * acc[tt][u >> 2][4 * (u & 3) + 2]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) eo[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 3]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ei[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + ei[u]) * (1.0f + eg[u]));
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_rcpf(1.0f + ef[u]);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) cq[u] = fmaf(ef[u], cq[u], ei[u]);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[u]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) hval[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + eo[u]) * (1.0f + eg[u]));
+            }
+            const int blk = sq * NTQ + toff + tt;
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cst[tt][sb][q] = cq[4 * sb + q];
+                half4 vh, vl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    vh[q] = (_Float16)hval[4 * sb + q];
+                    float d = hval[4 * sb + q] - (float)vh[q];
+                    asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
+                    vl[q] = (_Float16)d;
+                }
+                *(half4 *)&hb_hi[nxt][32 * sb + j][8 * blk + 4 * hh] = vh;
+                *(half4 *)&hb_lo[nxt][32 * sb + j][8 * blk + 4 * hh] = vl;
+                if (!(ABL & 4)) {
+                    _Float16 *yp = y + ((size_t)t * (2 * HV) + dir * HV + blk) * nstride * 8 + yoff[sb];
+                    *(half4 *)yp = vh;
+                    *(half4 *)(yp + plane_out) = vl;
+                }
+            }
+        }
+        if (step + 1 < NET_T) x_store(nxt);
+        __syncthreads();                                       // h_t and x_{t+1} complete; everyone is done with h_{t-1} and x_t
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // L4: a4[n][128] = selu(y2[n][10560] * W4 + b4).  grid = ceil(n/32), block = 256 (wave = 32-row block
 // of output units).  Same transposed MFMA scheme; B operand straight from global (each site row is
 // streamed sequentially, 16 B per lane).
@@ -1428,7 +1649,7 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
         const float *b = q; q += 4 * NET_H1;
         pack_lstm_dir(Kin, C, inp1, R, b, NET_H1, tw, tb);
         w1.insert(w1.end(), tw.begin(), tw.end()); b1.insert(b1.end(), tb.begin(), tb.end());
-        pack_lstm_dir_h(Kin, C, inp1, R, NET_H1, th, C3R_L1_SKEW ? b : nullptr);
+        pack_lstm_dir_h(Kin, C, inp1, R, NET_H1, th, (C3R_L1_SKEW || C3R_L1_W8) ? b : nullptr);
         w1h.insert(w1h.end(), th.begin(), th.end());
     }
     for (int d = 0; d < 2; ++d) {
@@ -1575,7 +1796,13 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
         const int ns = (int)((n + 127) / 128 * 128);
         const dim3 grid1((unsigned)(ns / 128), 2);
         prof("k_lstm1", 0);
-#if C3R_L1_SKEW
+#if C3R_L1_W8
+        (void)grid1;
+        if (s.channels == C3R_CH)
+            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH>), grid, dim3(512), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+        else
+            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH_PHASED>), grid, dim3(512), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+#elif C3R_L1_SKEW
         if (s.channels == C3R_CH)
             hipLaunchKernelGGL((k_lstm1_skew<C3R_CH>), grid1, block, 0, st, d_x, (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, ns);
         else
