@@ -913,7 +913,7 @@ int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t
         if (tc[t]) continue;
         const size_t p0 = t * TILE, p1 = std::min(n, p0 + TILE);
         if (cols) memset(cols + p0 * ctx->prm.channels, 0, (p1 - p0) * ctx->prm.channels * 4);
-        if (depth) for (size_t q = p0; q < p1; ++q) if (!flags || !(flags[q] & 1)) depth[q] = 0;
+        if (depth) for (size_t q = p0; q < p1; ++q) depth[q] = 0;        // (rows of such a tile show ref-skips only: depth 0)
     }
     return C3R_OK;
 }

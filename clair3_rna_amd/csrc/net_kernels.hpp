@@ -66,6 +66,9 @@ constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 #ifndef C3R_W8_PRIO
 #define C3R_W8_PRIO 0        // 1: s_setprio 1 for the 3-tile wavefronts, 2: for the 2-tile wavefronts
 #endif
+#ifndef C3R_HEADS_MFMA
+#define C3R_HEADS_MFMA 1     // heads through k_heads_mfma (f32 MFMA) instead of the scalar k_heads
+#endif
 #ifndef C3R_L1_W8_PD
 #define C3R_L1_W8_PD 0       // k_lstm1_w8: operand prefetch distance in k-groups (0: load, then use — the 4-waves-per-SIMD build has no registers for a ring)
 #endif
@@ -1496,6 +1499,94 @@ __global__ __launch_bounds__(256) void k_heads(const float *__restrict__ a4, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Heads on the fp32 matrix pipe (k_heads_mfma): the same arithmetic as k_heads — L4's selu, the two 128->128 selu branches, 21 + 3
+// logits with selu THEN softmax — as exact-f32 MFMAs (v_mfma_f32_32x32x2_f32 == an fmaf chain), 32 sites per workgroup.  k_heads
+// spent 0.39 ms of a chr20 pass on 14 GFLOP of scalar fmaf; the transposed scheme of k_fc4 (rows = output units, cols = sites)
+// does it at the f32 MFMA rate.  The 24 logits are ONE 32-row tile over K = 256: rows 0..20 read the L5_1 half of a5, rows 21..23
+// the L5_2 half (zero weights elsewhere); its K range is split over the four wavefronts and summed through LDS.
+//   W5p: [blk(8)][g(16)][lane] float4 = W5[8g + 4kh + s][32 blk + r];   Wcp: [g(32)][lane] float4, rows >= 24 zero
+__global__ __launch_bounds__(256) void k_heads_mfma(const float *__restrict__ a4, int parts, const float *__restrict__ b4,
+                                                    const float4 *__restrict__ W5p, const float *__restrict__ b5,
+                                                    const float4 *__restrict__ Wcp, const float *__restrict__ bo,
+                                                    float *__restrict__ probs, int n) {
+    constexpr int S = 32, P4 = 128 + 4, P5 = 256 + 4;
+    __shared__ __attribute__((aligned(16))) float s_a4[S][P4];      // later: the four K-slices' partial logits [4][32 rows][33]
+    __shared__ __attribute__((aligned(16))) float s_a5[S][P5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int site0 = blockIdx.x * S;
+    for (int i = tid; i < S * 128; i += 256) {
+        const int sl = i >> 7, u = i & 127, sg = site0 + sl;
+        float v = 0.f;
+        if (sg < n) v = parts == 2 ? selu(a4[((size_t)sg * 2) * 128 + u] + a4[((size_t)sg * 2 + 1) * 128 + u] + b4[u]) : a4[(size_t)sg * 128 + u];
+        s_a4[sl][u] = v;
+    }
+    __syncthreads();
+    {   // L5_1 | L5_2: 256 output rows = 8 tiles, two per wavefront, K = 128
+        floatx16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        const float4 *w0 = W5p + (size_t)(2 * wave) * 16 * 64 + lane, *w1 = w0 + 16 * 64;
+#pragma unroll 4
+        for (int g = 0; g < 16; ++g) {
+            const float4 b = *(const float4 *)&s_a4[j][8 * g + 4 * hh];
+            const float4 a0 = w0[g * 64], a1 = w1[g * 64];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;      // C/D layout of the 32x32 tiles
+            const int u0 = 64 * wave + row, u1 = u0 + 32;
+            s_a5[j][u0] = selu(acc0[r] + b5[u0]);
+            s_a5[j][u1] = selu(acc1[r] + b5[u1]);
+        }
+    }
+    __syncthreads();
+    float(*s_part)[32][33] = (float(*)[32][33]) & s_a4[0][0];       // 4 x 32 x 33 floats = 16.9 KB: fits the a4 tile's space
+    {   // 24 logits as one tile, K = 256 split over the wavefronts
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float4 *wc = Wcp + (size_t)(8 * wave) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 b = *(const float4 *)&s_a5[j][8 * (8 * wave + g) + 4 * hh];
+            const float4 a = wc[g * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_part[wave][(r & 3) + 8 * (r >> 2) + 4 * hh][j] = acc[r];
+    }
+    __syncthreads();
+    if (tid < S * 2) {
+        const int sl = tid >> 1, part = tid & 1;
+        const int o0 = part ? 21 : 0, o1 = part ? 24 : 21;
+        if (site0 + sl < n) {
+            float lg[21];
+            float m = -1e30f;
+            for (int o = o0; o < o1; ++o) {
+                const float v = selu(((s_part[0][o][sl] + s_part[1][o][sl]) + (s_part[2][o][sl] + s_part[3][o][sl])) + bo[o]);
+                lg[o - o0] = v;
+                m = fmaxf(m, v);
+            }
+            float sum = 0.f;
+            for (int o = o0; o < o1; ++o) sum += __expf(lg[o - o0] - m);
+            for (int o = o0; o < o1; ++o) probs[(size_t)(site0 + sl) * C3R_NPROB + o] = __expf(lg[o - o0] - m) / sum;
+        }
+    }
+}
+
 // ================================================================================================ host
 struct NetState {
     bool loaded = false;
@@ -1505,6 +1596,7 @@ struct NetState {
     float4 *d_w2 = nullptr; float *d_b2 = nullptr;     // packed LSTM2
     float4 *d_w4 = nullptr; float *d_b4 = nullptr;     // packed L4
     float *d_w5 = nullptr, *d_b5 = nullptr, *d_wo = nullptr, *d_bo = nullptr;
+    float4 *d_w5p = nullptr, *d_wcp = nullptr;          // heads in MFMA fragment order (k_heads_mfma)
     half8 *d_w1h = nullptr, *d_w2h = nullptr, *d_w4h = nullptr, *d_w4f = nullptr;   // d_w4f: L4 packed per (dir, t) for the fused path   // split-f16 packed weights (hi/lo, x 2^12)
     int precision = 1;            // 0 = fp32 MFMA, 1 = split-f16 (f16x3, fp32-equivalent)
     float *d_y1 = nullptr, *d_y2 = nullptr, *d_a4 = nullptr, *d_probs = nullptr;
@@ -1524,7 +1616,7 @@ inline int64_t net_weight_count(int C) {
 
 inline void net_free(NetState &s) {
     void *ptrs[] = {s.d_w1, s.d_b1, s.d_w2, s.d_b2, s.d_w4, s.d_b4, s.d_w5, s.d_b5, s.d_wo, s.d_bo, s.d_y1, s.d_y2, s.d_a4, s.d_probs,
-                    s.d_w1h, s.d_w2h, s.d_w4h, s.d_w4f};
+                    s.d_w1h, s.d_w2h, s.d_w4h, s.d_w4f, s.d_w5p, s.d_wcp};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     s = NetState();
 }
@@ -1719,7 +1811,26 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
     }
     for (int o = 0; o < 21; ++o) bo[o] = bg[o];
     for (int o = 0; o < 3; ++o) bo[21 + o] = bz[o];
+    // heads for k_heads_mfma: W5 = [L5_1 | L5_2] as 8 row tiles; the 24 logits as one tile over K = 256 (block structure)
+    std::vector<float> w5p((size_t)8 * 16 * 64 * 4), wcp((size_t)32 * 64 * 4, 0.f);
+    for (int blk = 0; blk < 8; ++blk)
+        for (int g = 0; g < 16; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int r = lane & 31, kh = lane >> 5;
+                    w5p[(((size_t)blk * 16 + g) * 64 + lane) * 4 + sidx] = w5[(size_t)(8 * g + 4 * kh + sidx) * 256 + 32 * blk + r];
+                }
+    for (int g = 0; g < 32; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int r = lane & 31, kh = lane >> 5, k = 8 * g + 4 * kh + sidx;       // k indexes a5 = [L5_1 | L5_2]
+                float v = 0.f;
+                if (r < 21 && k < 128) v = wo[(size_t)k * 24 + r];
+                else if (r >= 21 && r < 24 && k >= 128) v = wo[(size_t)(k - 128) * 24 + r];
+                wcp[((size_t)g * 64 + lane) * 4 + sidx] = v;
+            }
     int rc;
+    if ((rc = net_upload(s.d_w5p, w5p, st, err)) || (rc = net_upload(s.d_wcp, wcp, st, err))) return rc;
     if ((rc = net_upload(s.d_w1, w1, st, err)) || (rc = net_upload(s.d_b1, b1, st, err)) || (rc = net_upload(s.d_w2, w2, st, err)) ||
         (rc = net_upload(s.d_b2, b2, st, err)) || (rc = net_upload(s.d_w4, w4, st, err)) || (rc = net_upload(s.d_b4, vb4, st, err)) ||
         (rc = net_upload(s.d_w5, w5, st, err)) || (rc = net_upload(s.d_b5, b5, st, err)) || (rc = net_upload(s.d_wo, wo, st, err)) ||
@@ -1852,8 +1963,13 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
     prof("k_fc4", 1);
     }
     prof("k_heads", 0);
+#if C3R_HEADS_MFMA
+    hipLaunchKernelGGL(k_heads_mfma, dim3((unsigned)((n + 31) / 32)), block, 0, st, (const float *)s.d_a4, heads_parts, (const float *)s.d_b4,
+                       (const float4 *)s.d_w5p, (const float *)s.d_b5, (const float4 *)s.d_wcp, (const float *)s.d_bo, d_probs, (int)n);
+#else
     hipLaunchKernelGGL(k_heads, dim3((unsigned)((n + HEAD_SITES - 1) / HEAD_SITES)), block, 0, st, (const float *)s.d_a4, heads_parts, (const float *)s.d_b4, (const float *)s.d_w5,
                        (const float *)s.d_b5, (const float *)s.d_wo, (const float *)s.d_bo, d_probs, (int)n);
+#endif
     prof("k_heads", 1);
     NET_HIP(hipGetLastError());
     return C3R_OK;

@@ -453,7 +453,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         if (p < t1 && cov > 0) is_row = !a.has_lbed || intervals_overlap(a.lbed, a.n_lbed, p, p + 1);
         if (p < t1) {
             const int gi = slot0 + tid;
-            a.depth[gi] = 0; a.ncov[gi] = is_row ? cov : 0;
+            // depth / ncov of a position are read for candidates (rescale, token count) and, in splice-padding mode, for window
+            // slots.  An intron-only tile has candidates only in genotyping mode, so in the plain mode its 2 KB of depth / ncov
+            // stay unwritten (230 k such tiles per chr20 pass = 0.47 GB of stores nobody reads)
+            if (a.genotyping || a.splice) { a.depth[gi] = 0; a.ncov[gi] = is_row ? cov : 0; }
             bool cand = false;
             if (is_row && a.genotyping) cand = sorted_contains(a.sites, a.n_sites, p + 1);
             a.flags[gi] = (uint8_t)((is_row ? 1 : 0) | (cand ? 2 : 0));
