@@ -92,6 +92,13 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
 __device__ __forceinline__ float fast_tanh(float x) {
     return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.0f);
 }
+// (1 - b) / ((1 + a)(1 + b)) with a, b = clamped exp2 values: sigmoid(i) * tanh(g) and sigmoid(o) * tanh(c) of the cell update.
+// Written with explicit FMAs — t = 1 + a, d = t * b + t, r = 1 / d, r - b * r — 3 VALU operations + 1 rcp instead of 5 + 1.
+__device__ __forceinline__ float gate_frac(float a, float b) {
+    const float t = 1.0f + a;
+    const float r = __builtin_amdgcn_rcpf(fmaf(t, b, t));
+    return fmaf(-b, r, r);
+}
 __device__ __forceinline__ float selu(float x) {
     const float scale = 1.0507009873554805f, alpha = 1.6732632423543772f;
     return x > 0.f ? scale * x : scale * alpha * (__expf(x) - 1.0f);
@@ -911,7 +918,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 #pragma unroll
                     for (int u = 0; u < NU; ++u) eo[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 3]), 1e18f);
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) ei[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + ei[u]) * (1.0f + eg[u]));
+                    for (int u = 0; u < NU; ++u) ei[u] = gate_frac(ei[u], eg[u]);
 #pragma unroll
                     for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_rcpf(1.0f + ef[u]);
 #pragma unroll
@@ -919,7 +926,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 #pragma unroll
                     for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[u]), 1e18f);
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) hval[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + eo[u]) * (1.0f + eg[u]));
+                    for (int u = 0; u < NU; ++u) hval[u] = gate_frac(eo[u], eg[u]);
                 }
 #pragma unroll
                 for (int sb = 0; sb < SB; ++sb) {
@@ -1362,7 +1369,7 @@ __global__ __launch_bounds__(512, C3R_L1_W8_OCC) void k_lstm1_w8(const int32_t *
 #pragma unroll
                 for (int u = 0; u < NU; ++u) eo[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 3]), 1e18f);
 #pragma unroll
-                for (int u = 0; u < NU; ++u) ei[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + ei[u]) * (1.0f + eg[u]));
+                for (int u = 0; u < NU; ++u) ei[u] = gate_frac(ei[u], eg[u]);
 #pragma unroll
                 for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_rcpf(1.0f + ef[u]);
 #pragma unroll
@@ -1370,7 +1377,7 @@ __global__ __launch_bounds__(512, C3R_L1_W8_OCC) void k_lstm1_w8(const int32_t *
 #pragma unroll
                 for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[u]), 1e18f);
 #pragma unroll
-                for (int u = 0; u < NU; ++u) hval[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + eo[u]) * (1.0f + eg[u]));
+                for (int u = 0; u < NU; ++u) hval[u] = gate_frac(eo[u], eg[u]);
             }
             const int blk = sq * NTQ + toff + tt;
 #pragma unroll

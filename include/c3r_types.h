@@ -51,7 +51,8 @@ typedef struct c3r_read {
 typedef struct c3r_params {
     int32_t  channels;        /* 18, or 30 when --enable_phasing_model / --add_phasing_feature   */
     int32_t  min_mq;          /* --minMQ, default 5 (param_p.py:20)                                */
-    int32_t  excl_flags;      /* samtools --excl-flags, 2316 (param_p.py:41)                       */
+    int32_t  excl_flags;      /* samtools --excl-flags, 2316 (param_p.py:41); unmapped reads and anomalous pairs
+                                 (FLAG 0x1 without 0x2: mpileup without -A) are always skipped            */
     int32_t  min_coverage;    /* --minCoverage, default 4 (param_p.py:90)                          */
     double   snp_min_af;      /* --snp_min_af, default 0.08 (param_p.py:88)                        */
     double   indel_min_af;    /* --indel_min_af, default 0.15 (param_p.py:89)                      */

@@ -387,6 +387,24 @@ def test_network_result_does_not_depend_on_batch_position(eng):
     eng.set_precision("f16x3")
 
 
+def test_network_slices_of_a_long_batch(eng):
+    """The network runs over a batch in slices of at most 2^18 sites (net_kernels.hpp, NET_SLICE).  A batch longer than one slice —
+    a short block of windows repeated — must give every copy the probabilities of the short batch, bit for bit, including
+    across the slice seam and in the ragged last workgroup."""
+    from clair3_rna_amd import synth
+    rng = np.random.RandomState(5)
+    m, reps = 1111, 240                            # 266,640 sites > 262,144
+    X = rng.randint(-30, 50, size=(m, 33, 18)).astype(np.int32)
+    w = synth.random_weights(18, seed=78)
+    eng.load_weights(w, 18)
+    eng.set_precision("f16x3")
+    base = eng.infer(tensors=X).copy()
+    assert np.isfinite(base).all() and np.allclose(base[:, :21].sum(1), 1, atol=1e-5)
+    big = eng.infer(tensors=np.tile(X, (reps, 1, 1)))
+    assert big.shape == (m * reps, 24)
+    assert np.array_equal(big.reshape(reps, m, 24), np.broadcast_to(base, (reps, m, 24)))
+
+
 def test_error_codes_and_messages(eng):
     """Every misuse returns a negative C3R_E* code with a message (C3RError), never a crash or a silent fallback."""
     from clair3_rna_amd import capi, synth
