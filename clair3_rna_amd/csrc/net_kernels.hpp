@@ -785,7 +785,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
             auto ldw = [&](int g, half8 (&ah)[NTH], half8 (&al)[NTH]) {
                 uintptr_t wbase = (uintptr_t)wl;                 // see k_lstm_h::ldw (address laundering, address_space(1))
                 asm volatile("" : "+v"(wbase));
-                const gptr_t wg = (gptr_t)wbase + (size_t)g * NTQ * 2 * 64;
+                const gptr_t wg = (gptr_t)wbase + (size_t)((ABL & 1) ? 0 : g) * NTQ * 2 * 64;      // probe bit 1: one L1-hot k-group
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     if ((ABL & 16) && g > 0) continue;

@@ -1,6 +1,6 @@
 // lstm_probe_w8.hip — timing-only ablation of k_lstm2_w8 (layer 2 + fused L4, two wavefronts per SIMD) on random operands.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lstm_probe_w8.hip -o tools/lstm_probe_w8
-//   ABL bits: 2 = no gate math (cell update replaced by 3 adds), 16 = weights loaded for the first k-group only
+//   ABL bits: 1 = every weight load hits one L1-hot k-group (L1 -> register traffic kept, L2 -> L1 traffic gone), 2 = no gate math (cell update replaced by 3 adds), 16 = weights loaded for the first k-group only
 //   (register-stationary afterwards: no L2 -> L1 weight stream), 64 = no x DMA after the first step
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -54,6 +54,7 @@ int main(int argc, char **argv) {
         {"w8 no weight stream", run<16>(x, w, b, n, 3)},
         {"w8 no gate, no weights", run<18>(x, w, b, n, 3)},
         {"w8 8-bit lo weights", run<128>(x, w, b, n, 3)},
+        {"w8 weights L1-hot", run<1>(x, w, b, n, 3)},
         {"w8 full (again)", run<0>(x, w, b, n, 3)},
     };
     for (auto &e : r) printf("%-26s %8.3f ms  %7.1f algorithmic TFLOP/s (x3 executed = %6.1f = %4.1f %% of 2500)\n", e.name, e.ms, flop / e.ms / 1e9,
