@@ -771,6 +771,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
             auto ldx = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
 #pragma unroll
                 for (int sb = 0; sb < SB; ++sb) {
+                    if ((ABL & 32) && g > 0) continue;          // probe: no B-operand reads from LDS after the first k-group
                     bh[sb] = *(const half8 *)&xs[0][2 * g + hh][32 * sb + j][0];
                     bl[sb] = *(const half8 *)&xs[1][2 * g + hh][32 * sb + j][0];
                 }
@@ -778,6 +779,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
             auto ldh = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
 #pragma unroll
                 for (int sb = 0; sb < SB; ++sb) {
+                    if (ABL & 32) continue;
                     bh[sb] = *(const half8 *)&hb_hi[cur][32 * sb + j][16 * g + 8 * hh];
                     bl[sb] = *(const half8 *)&hb_lo[cur][32 * sb + j][16 * g + 8 * hh];
                 }
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 #undef C3R_FENCE
             // x_{t+1} by LDS-DMA now, so that no weight load queues behind it (vmcnt retires in order): it lands during the
             // cell update
-            if (step + 1 < NET_T) dma_x(dir ? NET_T - 2 - step : step + 1);
+            if (step + 1 < NET_T && !(ABL & 64)) dma_x(dir ? NET_T - 2 - step : step + 1);
             // ---- lane-local cell update, one tile at a time (see k_lstm_h); cell state in registers
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {

@@ -55,6 +55,8 @@ int main(int argc, char **argv) {
         {"w8 no gate, no weights", run<18>(x, w, b, n, 3)},
         {"w8 8-bit lo weights", run<128>(x, w, b, n, 3)},
         {"w8 weights L1-hot", run<1>(x, w, b, n, 3)},
+        {"w8 no LDS operand reads", run<32>(x, w, b, n, 3)},
+        {"w8 no x DMA", run<64>(x, w, b, n, 3)},
         {"w8 full (again)", run<0>(x, w, b, n, 3)},
     };
     for (auto &e : r) printf("%-26s %8.3f ms  %7.1f algorithmic TFLOP/s (x3 executed = %6.1f = %4.1f %% of 2500)\n", e.name, e.ms, flop / e.ms / 1e9,
