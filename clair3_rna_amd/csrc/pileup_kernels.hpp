@@ -966,25 +966,36 @@ __device__ __forceinline__ TokenAt token_at(const DevRead &rd, int r, int p, con
             else if (op0 == C3R_CIG_D) tk.indel = -len0;
             break;
         }
-        for (uint32_t k = 0; k < sg.n_cig; ++k) {
-            const uint32_t c = cigar[sg.cig_off + k];
-            const int op = (int)(c & 15u), len = (int)(c >> 4);
-            if (op == C3R_CIG_M || op == C3R_CIG_D) {
-                if (p < x + len) {
-                    if (op == C3R_CIG_M) tk.base = (uint8_t)base_code(seq, rd.seq_off, (uint32_t)(y + (p - x)), rd.l_seq);
-                    else tk.base = 16;
-                    if (p == x + len - 1 && k + 1 < sg.n_cig) {
-                        const uint32_t c2 = cigar[sg.cig_off + k + 1];
-                        const int op2 = (int)(c2 & 15u), len2 = (int)(c2 >> 4);
-                        if (op2 == C3R_CIG_I) { tk.indel = len2; tk.qpos = (uint32_t)(y + (op == C3R_CIG_M ? len : 0)); }
-                        else if (op2 == C3R_CIG_D && op != C3R_CIG_D) tk.indel = -len2;
+        // ops five at a time: the loads of a batch are independent of each other (one load latency per batch instead of one per
+        // op); the fifth is the op the fourth may have to peek at
+        const uint32_t nc = sg.n_cig;
+        bool done = false;
+        for (uint32_t k0 = 0; k0 < nc && !done; k0 += 4) {
+            uint32_t cc[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) cc[i] = cigar[sg.cig_off + min(k0 + (uint32_t)i, nc - 1)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t k = k0 + (uint32_t)i;
+                if (done || k >= nc) break;
+                const int op = (int)(cc[i] & 15u), len = (int)(cc[i] >> 4);
+                if (op == C3R_CIG_M || op == C3R_CIG_D) {
+                    if (p < x + len) {
+                        if (op == C3R_CIG_M) tk.base = (uint8_t)base_code(seq, rd.seq_off, (uint32_t)(y + (p - x)), rd.l_seq);
+                        else tk.base = 16;
+                        if (p == x + len - 1 && k + 1 < nc) {
+                            const int op2 = (int)(cc[i + 1] & 15u), len2 = (int)(cc[i + 1] >> 4);
+                            if (op2 == C3R_CIG_I) { tk.indel = len2; tk.qpos = (uint32_t)(y + (op == C3R_CIG_M ? len : 0)); }
+                            else if (op2 == C3R_CIG_D && op != C3R_CIG_D) tk.indel = -len2;
+                        }
+                        done = true;
+                        break;
                     }
-                    break;
+                    x += len;
+                    if (op == C3R_CIG_M) y += len;
+                } else if (op == C3R_CIG_I || op == C3R_CIG_S) {
+                    y += len;
                 }
-                x += len;
-                if (op == C3R_CIG_M) y += len;
-            } else if (op == C3R_CIG_I || op == C3R_CIG_S) {
-                y += len;
             }
         }
         break;
