@@ -63,6 +63,9 @@ constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 #ifndef C3R_W8_PD
 #define C3R_W8_PD 1          // prefetch distance (k-groups) of k_lstm2_w8's operand ring
 #endif
+#ifndef C3R_W8_MAP
+#define C3R_W8_MAP 0         // k_lstm2_w8: which wavefronts pair up on a SIMD — 0: w and w+4 (round-robin placement; measured 19.3 ms), 1: 2w and 2w+1 (20.5 ms)
+#endif
 #ifndef C3R_W8_PRIO
 #define C3R_W8_PRIO 0        // 1: s_setprio 1 for the 3-tile wavefronts, 2: for the 2-tile wavefronts
 #endif
@@ -703,7 +706,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
-    const int sq = wave & 3;                   // quarter of the gate rows (k_lstm_h's wave index)
+    const int sq = C3R_W8_MAP ? (wave >> 1) : (wave & 3);      // quarter of the gate rows (k_lstm_h's wave index)
+    const bool heavy3 = C3R_W8_MAP ? !(wave & 1) : (wave < 4); // the 3-tile wavefront of its SIMD pair
     const int dir = blockIdx.y;
     const int site0 = blockIdx.x * WG_SITES;
     const int ns = nstride ? nstride : n;
@@ -984,9 +988,9 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
             }
         }
     };
-    if (C3R_W8_PRIO == 1 && wave < 4) __builtin_amdgcn_s_setprio(1);
-    if (C3R_W8_PRIO == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    if (wave < 4) body(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::false_type{});
+    if (C3R_W8_PRIO == 1 && heavy3) __builtin_amdgcn_s_setprio(1);
+    if (C3R_W8_PRIO == 2 && !heavy3) __builtin_amdgcn_s_setprio(1);
+    if (heavy3) body(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::false_type{});
     else body(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::true_type{});
 }
 
