@@ -52,7 +52,9 @@ struct c3r_ctx {
     std::vector<int64_t> h_indel_prefix;  // [n_reads + 1] running count of I/D ops (normalised CIGARs): sizes the event scratch per scan
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
     std::vector<DevSeg> h_segs;            // aligned segments (CIGAR runs between N ops), sorted by ext_start
-    DevBuf d_segs, d_seg_prefmax, d_tile_cols, d_tile_rng, d_tile_list, d_rsegs, d_rseg_first;
+    DevBuf d_segs, d_seg_prefmax, d_tile_cols, d_tile_rng, d_tile_list, d_tile_list2, d_rsegs, d_rseg_first;
+    ScanArgs last_scan;                    // arguments of the most recent scan (c3r_get_columns completes the pruned tiles with them)
+    bool last_scan_pruned = false;
     std::string h_ref; int64_t ref_start1 = 1;
     DevBuf d_ref;
     std::vector<int32_t> h_bed[2];
@@ -271,7 +273,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+    DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -669,10 +671,12 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     if ((rc = ensure(ctx, ctx->d_tile_cols, (size_t)n_tiles + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tile_list2, (size_t)n_tiles * 4 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_blockcnt, (size_t)(n_cblocks + 1) * 4))) return rc;
     if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_skipmax, (size_t)n_pos * 4))) return rc;
-    // d_small: [0..7] ev_cursor (u64), [8..11] event-scratch overflow flag, [12..15] n_cand, [16..19] n_tok, [20..23] n_tile_list
-    int32_t init[6] = {0, 0, 0, 0, 0, 0};
+    // d_small: [0..7] ev_cursor (u64), [8..11] event-scratch overflow flag, [12..15] n_cand, [16..19] n_tok, [20..23] n_tile_list,
+    //          [24..27] n_tile_list2 (pruned intron-only tiles)
+    int32_t init[7] = {0, 0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_small.p, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_lastrow.p, 0xff, (size_t)n_regions * 4, ctx->stream));      // -1
     HIPCHK(ctx, hipMemsetAsync(ctx->d_flags.p, 0, (size_t)n_pos, ctx->stream));
@@ -725,6 +729,10 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     a.tile_cols = (uint8_t *)ctx->d_tile_cols.p;
     a.tile_rng = (int4 *)ctx->d_tile_rng.p; a.tile_list = (int32_t *)ctx->d_tile_list.p;
     a.n_tile_list = (int32_t *)((char *)ctx->d_small.p + 20); a.n_tiles = n_tiles;
+    // rows of intron-only tiles far from every aligned segment only matter to the end-of-stream rule (head/tail), to splice
+    // padding and to genotyping sites: in the plain mode they are left out of the scan
+    a.prune = (!ctx->prm.head_tail && !ctx->prm.splice_padding && !ctx->prm.genotyping_mode && !getenv("C3R_NO_PRUNE")) ? 1 : 0;
+    a.tile_list2 = (int32_t *)ctx->d_tile_list2.p; a.n_tile_list2 = (int32_t *)((char *)ctx->d_small.p + 24);
     a.head_tail = ctx->prm.head_tail;
     { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
     a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->h_ref.size();
@@ -738,6 +746,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)ctx->d_small.p; a.last_row = (int32_t *)ctx->d_lastrow.p;
     a.ev_cap = (unsigned long long)ev_cap; a.ev_overflow = (int32_t *)((char *)ctx->d_small.p + 8);
     a.splice = ctx->prm.splice_padding; a.skipmax = (int32_t *)ctx->d_skipmax.p;
+    ctx->last_scan = a; ctx->last_scan_pruned = a.prune && a.n_reads > 0;
     if (a.n_reads > 0) {
         Launch L(ctx, "k_tile_ranges");
         hipLaunchKernelGGL(k_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
@@ -761,15 +770,17 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
         Launch L(ctx, "k_skip_counts");
         hipLaunchKernelGGL(k_skip_counts, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
     }
+    // candidates live in tiles that hold aligned bases — except in genotyping mode, where any row of the site list is one
+    const uint8_t *heavy = ctx->prm.genotyping_mode ? nullptr : (const uint8_t *)ctx->d_tile_cols.p;
     {
         Launch L(ctx, "k_select");
         hipLaunchKernelGGL(k_select, dim3((unsigned)((n_pos + 255) / 256)), dim3(256), 0, ctx->stream, (uint8_t *)ctx->d_flags.p,
-                           (int)n_pos, (const TileGeo *)ctx->d_geo.p, ctx->prm.head_tail, (const int32_t *)ctx->d_lastrow.p);
+                           (int)n_pos, (const TileGeo *)ctx->d_geo.p, ctx->prm.head_tail, (const int32_t *)ctx->d_lastrow.p, heavy);
     }
     {
         Launch L(ctx, "k_compact_count");
         hipLaunchKernelGGL(k_compact_count, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
-                           (int32_t *)ctx->d_blockcnt.p);
+                           (int32_t *)ctx->d_blockcnt.p, heavy);
     }
     {
         if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_blockcnt.p, n_cblocks, (int32_t *)((char *)ctx->d_small.p + 12)))) return rc;
@@ -792,7 +803,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     {
         Launch L(ctx, "k_compact_write");
         hipLaunchKernelGGL(k_compact_write, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
-                           (const int32_t *)ctx->d_blockcnt.p, (int32_t *)ctx->d_cand.p);
+                           (const int32_t *)ctx->d_blockcnt.p, (int32_t *)ctx->d_cand.p, heavy);
     }
     if ((rc = run_gather(ctx, 1, (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_cand * tbytes), true))) return rc;
     {
@@ -900,6 +911,14 @@ int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t
     if (!cols && !depth && !flags) return C3R_OK;
     if (cap_pos < npos0) return fail(ctx, C3R_EOVERFLOW, "need room for %lld positions", (long long)npos0);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->last_scan_pruned) {
+        // the scan skipped intron-only tiles that no candidate window can reach: compute their row flags now
+        ScanArgs a = ctx->last_scan;
+        a.tile_list = a.tile_list2; a.n_tile_list = a.n_tile_list2;
+        if (ctx->prm.channels == C3R_CH) hipLaunchKernelGGL(k_scan_tiles<C3R_CH>, dim3(a.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_scan_tiles<C3R_CH_PHASED>, dim3(a.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
+        ctx->last_scan_pruned = false;
+    }
     const size_t n = (size_t)npos0;
     if (cols) HIPCHK(ctx, hipMemcpyAsync(cols, ctx->d_cols.p, n * ctx->prm.channels * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (depth) HIPCHK(ctx, hipMemcpyAsync(depth, ctx->d_depth.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -99,6 +99,11 @@ struct ScanArgs {
     int4 *tile_rng;               // [n_tiles] {lo, hi, slo, shi} from k_tile_ranges
     int32_t *tile_list;           // compact list of tiles covered by at least one read span
     int32_t *n_tile_list;
+    // prune: intron-only tiles with no aligned segment within 16 bp are not scanned at all (their rows cannot be in any candidate's
+    // window); they go to tile_list2, which c3r_get_columns completes on demand
+    int32_t prune;
+    int32_t *tile_list2;
+    int32_t *n_tile_list2;
     int32_t n_tiles;
     int32_t head_tail;            // last_row (end of the row stream) is only needed for the head/tail flush rule
     int32_t abl;                  // timing-only ablation bits (env C3R_SCAN_ABL, 0 in production)
@@ -396,20 +401,47 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wave_tot /* LDS [WAVE
 // One thread per tile: the four binary searches that bound the tile's reads and segments.  Done here, thousands at a
 // time, instead of by one lane at the head of every tile workgroup (64 dependent global loads = tens of microseconds
 // of pure latency per tile).  Tiles that no read span covers are dropped from the work list.
+// Append `value` to a global list for the lanes with `pred`: ONE returning atomic per wavefront (ballot + popcount), whatever the
+// control flow around it.  (Two atomicAdd sites on different counters get merged by hipcc into one atomic with a per-lane
+// address, which its wave-level atomic aggregation then skips: 250 k serialised L2 atomics = 2.4 ms instead of 0.07.)
+__device__ __forceinline__ void wave_append(int32_t *list, int32_t *counter, bool pred, int32_t value) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return;
+    const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (pred) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
 __global__ void k_tile_ranges(const ScanArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.n_tiles) return;
-    const TileGeo tg = a.geo[t];
-    const int t0 = tg.p0, t1 = tg.p1;
-    if (t1 <= t0) return;                 // guard tile
-    int4 r;
-    r.x = upper_bound_gt(a.prefmax_end, a.n_reads, t0);
-    r.y = lower_bound_pos(a.reads, a.n_reads, t1);
-    if (r.x >= r.y) return;
-    r.z = upper_bound_gt(a.seg_prefmax, a.n_segs, t0);
-    r.w = lower_bound_seg(a.segs, a.n_segs, t1);
-    a.tile_rng[t] = r;
-    a.tile_list[atomicAdd(a.n_tile_list, 1)] = t;
+    bool listed = false, pruned = false;
+    if (t < a.n_tiles) {
+        const TileGeo tg = a.geo[t];
+        const int t0 = tg.p0, t1 = tg.p1;
+        if (t1 > t0) {                        // (not a guard tile)
+            int4 r;
+            r.x = upper_bound_gt(a.prefmax_end, a.n_reads, t0);
+            r.y = lower_bound_pos(a.reads, a.n_reads, t1);
+            if (r.x < r.y) {
+                r.z = upper_bound_gt(a.seg_prefmax, a.n_segs, t0);
+                r.w = lower_bound_seg(a.segs, a.n_segs, t1);
+                a.tile_rng[t] = r;
+                listed = true;
+                if (a.prune && r.z >= r.w) {
+                    // intron-only tile.  A candidate is a position with aligned bases (depth > 0) and its window reaches 16
+                    // positions to either side: this tile's rows matter only if an aligned segment comes within 16 bp of it (a
+                    // superset test: the segments' ext_start / prefix-max ends, filters not applied)
+                    const int z = upper_bound_gt(a.seg_prefmax, a.n_segs, t0 - C3R_FLANK - 1);
+                    const int w = lower_bound_seg(a.segs, a.n_segs, t1 + C3R_FLANK);
+                    if (z >= w) { listed = false; pruned = true; }
+                }
+            }
+        }
+    }
+    wave_append(a.tile_list, a.n_tile_list, listed, t);
+    if (a.prune) wave_append(a.tile_list2, a.n_tile_list2, pruned, t);
 }
 
 template <int C>
@@ -678,7 +710,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) 
 // the 33 positions centre-16..centre+16 are contiguous rows; with head_tail the ring is pre-filled
 // with zero columns after every gap (left side always OK) and the stream end is flushed with 16
 // zero columns (right side OK only when the run reaches the last row of the stream).
-__global__ void k_select(uint8_t *flags, int n_pos, const TileGeo *geo, int head_tail, const int32_t *last_row) {
+// heavy: null, or tile_cols — outside genotyping mode only tiles that hold aligned bases (tile_cols = 1) can have candidates, and
+// 93 % of an RNA contig's covered tiles are intron-only: the three kernels below leave their blocks early there instead of
+// reading 64 MB of flags each.
+__global__ void k_select(uint8_t *flags, int n_pos, const TileGeo *geo, int head_tail, const int32_t *last_row, const uint8_t *heavy) {
+    static_assert(TILE == 256, "one 256-thread block per tile");
+    if (heavy && !heavy[blockIdx.x]) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pos) return;
     const uint8_t f = flags[i];
@@ -700,7 +737,18 @@ constexpr int CMP_THREADS = 256;
 constexpr int CMP_ITEMS = 4;                      // positions per thread
 constexpr int CMP_BLOCK = CMP_THREADS * CMP_ITEMS;
 
-__global__ __launch_bounds__(CMP_THREADS) void k_compact_count(const uint8_t *flags, int n_pos, int32_t *block_cnt) {
+__device__ __forceinline__ bool cmp_block_empty(const uint8_t *heavy, int n_pos) {
+    if (!heavy) return false;
+    const int t0 = blockIdx.x * (CMP_BLOCK / TILE), nt = (n_pos + TILE - 1) / TILE;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < CMP_BLOCK / TILE; ++k) if (t0 + k < nt && heavy[t0 + k]) any = true;
+    return !any;
+}
+
+__global__ __launch_bounds__(CMP_THREADS) void k_compact_count(const uint8_t *flags, int n_pos, int32_t *block_cnt, const uint8_t *heavy) {
+    static_assert(CMP_BLOCK % TILE == 0, "a compaction block covers whole tiles");
+    if (cmp_block_empty(heavy, n_pos)) { if (threadIdx.x == 0) block_cnt[blockIdx.x] = 0; return; }
     const int base = blockIdx.x * CMP_BLOCK + threadIdx.x * CMP_ITEMS;
     int c = 0;
 #pragma unroll
@@ -776,8 +824,9 @@ __global__ __launch_bounds__(1024) void k_scan_add(int32_t *data, int n, const i
 }
 
 __global__ __launch_bounds__(CMP_THREADS) void k_compact_write(const uint8_t *flags, int n_pos, const int32_t *block_off,
-                                                                 int32_t *cand_idx /* region-relative index */) {
+                                                                 int32_t *cand_idx /* region-relative index */, const uint8_t *heavy) {
     __shared__ int wsum[CMP_THREADS / 64];
+    if (cmp_block_empty(heavy, n_pos)) return;
     const int base = blockIdx.x * CMP_BLOCK + threadIdx.x * CMP_ITEMS;
     int c = 0;
 #pragma unroll
