@@ -7,7 +7,7 @@ PREC=${1:-f16x3}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof/$PREC
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 # --no_overlap: one context, so that a kernel's traced duration is its own run time (with two pipelined contexts a launch also
 # waits for CUs the other context's persistent workgroups hold) and agrees with the avg_launch_ms bench.py measures
 ARGS="$R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile --no_overlap --precision $PREC"
