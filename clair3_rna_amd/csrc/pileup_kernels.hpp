@@ -874,14 +874,19 @@ __device__ __forceinline__ void gather_window(const GatherArgs &g, int w, int ci
     int32_t *out = g.tensors + (size_t)w * C3R_WINDOW * C;
     int32_t *raw = g.raw ? g.raw + (size_t)w * C3R_WINDOW * C : nullptr;
     const int first = ci - C3R_FLANK;
-    for (int i = lane; i < C3R_WINDOW * C; i += 64) {
-        const int q = first + i / C;
-        int v = 0;
-        if (q >= lo_valid && q <= hi_valid && g.tile_cols[q / TILE]) v = g.cols[(size_t)q * C + (i % C)];
-        else if (zcol && q < lo_valid) v = zcol[i % C];      // the run's shared pre-fill column (splice padding edits it)
-        if (raw) raw[i] = v;
-        if (scale) v = (int32_t)((double)v / sf);
-        out[i] = v;
+    // two channels (8 bytes) per lane and round: C is even, so a pair never straddles two columns, and every window, column and
+    // tensor starts on an 8-byte boundary (C * 4 = 72 / 120 bytes per column)
+    static_assert(C % 2 == 0, "channel pairs");
+    typedef int int2v __attribute__((ext_vector_type(2)));
+    for (int i2 = lane; i2 < C3R_WINDOW * C / 2; i2 += 64) {
+        const int i = 2 * i2;
+        const int q = first + i / C, ch = i % C;
+        int2v v = {0, 0};
+        if (q >= lo_valid && q <= hi_valid && g.tile_cols[q / TILE]) v = *(const int2v *)(g.cols + (size_t)q * C + ch);
+        else if (zcol && q < lo_valid) { v[0] = zcol[ch]; v[1] = zcol[ch + 1]; }      // the run's shared pre-fill column (splice padding edits it)
+        if (raw) *(int2v *)(raw + i) = v;
+        if (scale) { v[0] = (int32_t)((double)v[0] / sf); v[1] = (int32_t)((double)v[1] / sf); }
+        *(int2v *)(out + i) = v;
     }
     if (g.sites) {
         c3r_site_t *s = &g.sites[w];
