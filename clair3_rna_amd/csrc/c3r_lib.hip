@@ -52,6 +52,7 @@ struct c3r_ctx {
     std::vector<int64_t> h_indel_prefix;  // [n_reads + 1] running count of I/D ops (normalised CIGARs): sizes the event scratch per scan
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
     std::vector<DevSeg> h_segs;            // aligned segments (CIGAR runs between N ops), sorted by ext_start
+    DevBuf d_ops, d_seg_op_off;            // expanded op records of the sorted segments (pileup_kernels.hpp, OpRec) and each segment's first record
     DevBuf d_segs, d_seg_prefmax, d_tile_cols, d_tile_rng, d_tile_list, d_tile_list2, d_rsegs, d_rseg_first;
     ScanArgs last_scan;                    // arguments of the most recent scan (c3r_get_columns completes the pruned tiles with them)
     bool last_scan_pruned = false;
@@ -233,6 +234,8 @@ void merge_intervals(std::vector<int32_t> &iv) {
 
 }  // namespace
 
+static int device_excl_scan(c3r_ctx *ctx, int32_t *d, int n, int32_t *d_total);
+
 extern "C" {
 
 const char *c3r_version(void) { return "c3r 0.1 (gfx950, HIP)"; }
@@ -273,7 +276,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+    DevBuf *bufs[] = {&ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -500,11 +503,30 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     tick();
     if ((rc = upload_prefmax(ctx))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    {   // expanded op table of the sorted segments, built on the device: count -> exclusive scan -> write
+        const int ns = (int)ctx->h_segs.size();
+        if ((rc = ensure(ctx, ctx->d_seg_op_off, (size_t)(ns + 1) * 4 + 16))) return rc;
+        if ((rc = ensure(ctx, ctx->d_small, 64))) return rc;
+        int32_t *off = (int32_t *)ctx->d_seg_op_off.p, *d_total = (int32_t *)((char *)ctx->d_small.p + 28);
+        hipLaunchKernelGGL(k_ops_count, dim3((unsigned)(ns / 256 + 1)), dim3(256), 0, ctx->stream, (const DevSeg *)ctx->d_segs.p, ns,
+                           (const uint32_t *)ctx->d_cigar.p, off);
+        if ((rc = device_excl_scan(ctx, off, ns + 1, d_total))) return rc;
+        int32_t total = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (total < 0) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
+        if ((rc = ensure(ctx, ctx->d_ops, (size_t)total * sizeof(OpRec) + 64))) return rc;
+        if (ns > 0)
+            hipLaunchKernelGGL(k_ops_write, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, (const DevSeg *)ctx->d_segs.p, ns,
+                               (const uint32_t *)ctx->d_cigar.p, (const int32_t *)off, (OpRec *)ctx->d_ops.p);
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipGetLastError());
+    }
     tick();
     if (timing) {
         auto ms = [&](int a, int b) { return std::chrono::duration<double, std::milli>(tp[b] - tp[a]).count(); };
-        fprintf(stderr, "[c3r_load_reads] %lld reads, %zu segments: normalise %.1f ms, read-order segments %.1f ms, sort %.1f ms, seq copy %.1f ms, uploads %.1f ms, prefix max %.1f ms\n",
-                (long long)n_reads, ctx->h_segs.size(), ms(0, 1), ms(1, 2), ms(2, 3), ms(3, 4), ms(4, 5), ms(5, 6));
+        fprintf(stderr, "[c3r_load_reads] %lld reads, %zu segments: normalise %.1f ms, read-order segments %.1f ms, sort %.1f ms, seq copy %.1f ms, uploads %.1f ms, prefix max %.1f ms, op table %.1f ms\n",
+                (long long)n_reads, ctx->h_segs.size(), ms(0, 1), ms(1, 2), ms(2, 3), ms(3, 4), ms(4, 5), ms(5, 6), ms(6, 7));
     }
     return C3R_OK;
 }
@@ -726,6 +748,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     a.reads = (const DevRead *)ctx->d_reads.p; a.cigar = (const uint32_t *)ctx->d_cigar.p; a.seq = (const uint8_t *)ctx->d_seq.p;
     a.prefmax_end = (const int32_t *)ctx->d_prefmax.p; a.n_reads = (int32_t)ctx->h_reads.size();
     a.segs = (const DevSeg *)ctx->d_segs.p; a.seg_prefmax = (const int32_t *)ctx->d_seg_prefmax.p; a.n_segs = (int32_t)ctx->h_segs.size();
+    a.ops = (const OpRec *)ctx->d_ops.p; a.seg_op_off = (const int32_t *)ctx->d_seg_op_off.p;
     a.tile_cols = (uint8_t *)ctx->d_tile_cols.p;
     a.tile_rng = (int4 *)ctx->d_tile_rng.p; a.tile_list = (int32_t *)ctx->d_tile_list.p;
     a.n_tile_list = (int32_t *)((char *)ctx->d_small.p + 20); a.n_tiles = n_tiles;

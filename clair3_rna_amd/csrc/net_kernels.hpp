@@ -81,6 +81,9 @@ constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 #ifndef C3R_L1_W8
 #define C3R_L1_W8 1          // layer 1 through k_lstm1_w8 (two wavefronts per SIMD, x staged once per workgroup) instead of k_lstm1_skew
 #endif
+#ifndef C3R_L1_TEAMS
+#define C3R_L1_TEAMS 1       // k_lstm1_w8: 2 = one 1024-thread workgroup of two 64-site teams held half a step apart by phase barriers
+#endif
 #ifndef C3R_L2_W8
 #define C3R_L2_W8 1          // layer 2 through k_lstm2_w8 (two wavefronts per SIMD) instead of k_lstm_h
 #endif
@@ -1215,23 +1218,27 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
 //     What is left is the cell update itself: without its 5 exp2 + 3 rcp per unit the kernel takes 4.9 ms at a 0.33 GHz higher
 //     clock (tools/lstm_probe_l1w8.hip).
 // Bias rides on input slot CIN (see k_lstm1_skew); Wp is k_lstm_h's layout ([dir][quarter][g][tile(4)][hi|lo][lane]).
-template <int CIN, int ABL = 0>
-__global__ __launch_bounds__(512, C3R_L1_W8_OCC) void k_lstm1_w8(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp,
+template <int CIN, int ABL = 0, int TEAMS = 1>
+__global__ __launch_bounds__(512 * TEAMS, C3R_L1_W8_OCC) void k_lstm1_w8(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp,
                                                       _Float16 *__restrict__ y, int n, int nstride) {
     constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NTQ = 4, NT = 2, SB = 2, WG_SITES = 64, HV = H / 8, PD = C3R_L1_W8_PD;
     constexpr int XP = 40;                     // x tile row stride in halves (80 B: conflict-free ds_read_b128)
     constexpr int NPC = (CIN + 1) / 2;         // 8-byte pieces per (site, step) row of the int32 tensor
     static_assert(CIN % 2 == 0 && CIN < 32, "even channel count, one free slot for the bias");
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
-    __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][WG_SITES][HP];
-    __shared__ __attribute__((aligned(16))) _Float16 xs[2][WG_SITES][XP];
+    __shared__ __attribute__((aligned(16))) _Float16 hb_hi_[TEAMS][2][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 hb_lo_[TEAMS][2][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 xs_[TEAMS][2][WG_SITES][XP];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int team = TEAMS > 1 ? (int)(threadIdx.x >> 9) : 0;
+    auto &hb_hi = hb_hi_[team];
+    auto &hb_lo = hb_lo_[team];
+    auto &xs = xs_[team];
+    const int tid = threadIdx.x & 511, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
     const int sq = wave & 3, toff = (wave >> 2) * NT;
     const int dir = blockIdx.y;
-    const int site0 = blockIdx.x * WG_SITES;
+    const int site0 = (blockIdx.x * TEAMS + team) * WG_SITES;
     const size_t plane_out = (size_t)nstride * NET_T * 2 * H;
 
     for (int i = tid; i < WG_SITES * HP; i += 512) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
@@ -1283,6 +1290,9 @@ __global__ __launch_bounds__(512, C3R_L1_W8_OCC) void k_lstm1_w8(const int32_t *
     for (int sb = 0; sb < SB; ++sb) yoff[sb] = (uint32_t)(site0 + 32 * sb + j) * 8 + 4 * hh;
 
     typedef const half8 __attribute__((address_space(1))) *gptr_t;
+    // TEAMS == 2: the two teams of eight wavefronts run half a step apart — one team's cell update (VALU, transcendentals) under
+    // the other's K loop (matrix pipe) — and every phase ends in a workgroup-wide barrier that keeps them there
+    if (TEAMS > 1 && team == 1) __syncthreads();
     for (int step = 0; step < NET_T; ++step) {
         const int t = dir ? NET_T - 1 - step : step;
         const int cur = step & 1, nxt = cur ^ 1;
@@ -1353,6 +1363,7 @@ __global__ __launch_bounds__(512, C3R_L1_W8_OCC) void k_lstm1_w8(const int32_t *
 #undef C3R_STEP
 #undef C3R_LOAD
 #undef C3R_FENCE
+        if (TEAMS > 1) __syncthreads();                        // phase boundary: K loop -> cell update
         // ---- lane-local cell update, one tile at a time; h_t to LDS (both halves) and to the y1 planes, straight from registers
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
@@ -1408,7 +1419,8 @@ __global__ __launch_bounds__(512, C3R_L1_W8_OCC) void k_lstm1_w8(const int32_t *
             }
         }
         if (step + 1 < NET_T) x_store(nxt);
-        __syncthreads();                                       // h_t and x_{t+1} complete; everyone is done with h_{t-1} and x_t
+        if (!(TEAMS > 1 && team == 1 && step == NET_T - 1))
+            __syncthreads();                                   // h_t and x_{t+1} complete; everyone is done with h_{t-1} and x_t
     }
 }
 
@@ -1921,11 +1933,11 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
         const dim3 grid1((unsigned)(ns / 128), 2);
         prof("k_lstm1", 0);
 #if C3R_L1_W8
-        (void)grid1;
+        const dim3 gridw = C3R_L1_TEAMS == 2 ? grid1 : grid;
         if (s.channels == C3R_CH)
-            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH>), grid, dim3(512), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH, 0, C3R_L1_TEAMS>), gridw, dim3(512 * C3R_L1_TEAMS), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
         else
-            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH_PHASED>), grid, dim3(512), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH_PHASED, 0, C3R_L1_TEAMS>), gridw, dim3(512 * C3R_L1_TEAMS), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
 #elif C3R_L1_SKEW
         if (s.channels == C3R_CH)
             hipLaunchKernelGGL((k_lstm1_skew<C3R_CH>), grid1, block, 0, st, d_x, (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, ns);

@@ -62,6 +62,27 @@ struct DevSeg {
 };
 static_assert(sizeof(DevSeg) == 48, "DevSeg must be 48 bytes");
 
+// One CIGAR op of an aligned segment with everything a lane needs to process it on its own: absolute reference and query
+// offsets (no prefix sums over the segment's ops at scan time) and the read's filter / strand / haplotype fields.  Built on the
+// device when the reads are loaded (k_ops_count / k_ops_write), segment after segment in the sorted order of `segs`, so that
+// seg_op_off[s] .. seg_op_off[s + 1] are the records of segment s.  M ops are cut into pieces of at most OP_CHOP bases: one
+// 16-byte load of packed bases covers a piece, and a low-error read's few-hundred-base M ops spread over several lanes.
+// S ops leave no record (they only advance the query offset); `prev` still names them for the op that follows.
+struct OpRec {
+    int32_t rstart;     // 0-based reference position of the op's first base (I: of the base that follows the insertion)
+    uint32_t lenop;     // len << 4 | op   (op: C3R_CIG_M / _I / _D / _P)
+    uint64_t seq_off;   // the read's packed bases
+    uint32_t qstart;    // query offset of the op's first base
+    uint32_t l_seq;
+    uint32_t read_idx;
+    uint16_t flag;
+    uint8_t mapq;
+    uint8_t misc;       // bits 0-1: haplotype (1, 2, else 0); bits 2-5: the previous op of the read (15: none; N for the first op after a
+                        // ref-skip; M for the later pieces of a cut M op); bit 6: last record of its segment
+};
+static_assert(sizeof(OpRec) == 32, "OpRec must be 32 bytes");
+constexpr int OP_CHOP = 30;    // 30 bases + an odd start nibble fit the 32 nibbles of a 16-byte load
+
 struct EvRec {          // one indel event, bucketed by position inside a tile
     uint64_t key;       // insertion: first <=16 base codes, 4 bits each; deletion: 0
     uint32_t len;
@@ -95,6 +116,8 @@ struct ScanArgs {
     const DevSeg *segs;           // aligned segments sorted by ext_start
     const int32_t *seg_prefmax;   // inclusive prefix max of segment `end` over passing segments
     int32_t n_segs;
+    const OpRec *ops;             // expanded ops of the sorted segments
+    const int32_t *seg_op_off;    // [n_segs + 1] first record of each segment
     uint8_t *tile_cols;           // [n_tiles] 1 = this tile's columns were written (0: implicitly all-zero)
     int4 *tile_rng;               // [n_tiles] {lo, hi, slo, shi} from k_tile_ranges
     int32_t *tile_list;           // compact list of tiles covered by at least one read span
@@ -140,6 +163,20 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
         if (lane >= off) v += t;
     }
     return v;
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, *total = sum
+__device__ __forceinline__ int block_excl_scan(int v, int *wave_tot /* LDS [WAVES] */, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(v);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { const int t = wave_tot[w]; if (w < wave) base += t; tot += t; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
 }
 
 __device__ __forceinline__ bool read_dropped(const uint32_t *drop, int words, int region, int r) {
@@ -214,7 +251,7 @@ struct TileLds {
 };
 
 // Coverage of the tile from whole-read spans (incl. introns): header-only, one lane per read.
-__device__ void cover_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, int region) {
+__device__ __forceinline__ void cover_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, int region) {
     for (int r = lo + (int)threadIdx.x; r < hi; r += SCAN_THREADS) {
         const DevRead rd = a.reads[r];
         if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.pos >= t1) continue;
@@ -224,146 +261,248 @@ __device__ void cover_reads(const ScanArgs &a, const TileLds &s, int lo, int hi,
     }
 }
 
-// Walk every aligned segment overlapping the tile.  One 16-lane group per segment (segments are exon-sized: a dozen
-// CIGAR ops), one lane per CIGAR op: 16 segments in flight per workgroup hide the header -> CIGAR -> bases latency
-// chain four times better than one segment per wavefront.
-constexpr int GRP = 16;                       // lanes per segment
-constexpr int NGRP = SCAN_THREADS / GRP;      // segments in flight per workgroup
-
-__device__ __forceinline__ int grp_incl_scan(int v) {
-    const int gl = threadIdx.x & (GRP - 1);
-#pragma unroll
-    for (int off = 1; off < GRP; off <<= 1) {
-        int t = __shfl_up(v, off, GRP);
-        if (gl >= off) v += t;
+// ---- expanded op table (built once per c3r_load_reads, outside the scans)
+// What segment g expands to; out == nullptr: count only.
+__device__ __forceinline__ int seg_expand(const DevSeg &g, const uint32_t *cigar, OpRec *out) {
+    int n = 0, x = g.pos, prev = g.lead_n ? (int)C3R_CIG_N : 15;
+    uint32_t y = g.qstart;
+    OpRec o;
+    o.seq_off = g.seq_off; o.l_seq = g.l_seq; o.read_idx = g.read_idx; o.flag = g.flag; o.mapq = g.mapq;
+    const uint8_t hp2 = g.hp == 1 ? 1 : g.hp == 2 ? 2 : 0;
+    for (uint32_t k = 0; k < g.n_cig; ++k) {
+        const uint32_t c = cigar[g.cig_off + k];
+        const int op = (int)(c & 15u), len = (int)(c >> 4);
+        if (op == C3R_CIG_M) {
+            for (int d = 0; d < len; d += OP_CHOP) {
+                if (out) {
+                    o.rstart = x + d; o.lenop = ((uint32_t)min(OP_CHOP, len - d) << 4) | (uint32_t)C3R_CIG_M; o.qstart = y + (uint32_t)d;
+                    o.misc = (uint8_t)(hp2 | ((d ? (int)C3R_CIG_M : prev) << 2));
+                    out[n] = o;
+                }
+                ++n;
+            }
+            x += len; y += (uint32_t)len;
+        } else if (op == C3R_CIG_D || op == C3R_CIG_I) {
+            if (out) { o.rstart = x; o.lenop = c; o.qstart = y; o.misc = (uint8_t)(hp2 | (prev << 2)); out[n] = o; }
+            ++n;
+            if (op == C3R_CIG_D) x += len; else y += (uint32_t)len;
+        } else if (op == C3R_CIG_S) {
+            y += (uint32_t)len;
+        }
+        prev = op;
     }
-    return v;
+    if (out && n > 0) out[n - 1].misc |= 64;
+    return n;
+}
+__global__ void k_ops_count(const DevSeg *segs, int n_segs, const uint32_t *cigar, int32_t *cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_segs) cnt[i] = seg_expand(segs[i], cigar, nullptr);
+    else if (i == n_segs) cnt[i] = 0;
+}
+__global__ void k_ops_write(const DevSeg *segs, int n_segs, const uint32_t *cigar, const int32_t *off, OpRec *ops) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_segs) seg_expand(segs[i], cigar, ops + off[i]);
+}
+
+// ---- the tile's walk, two levels.
+// Level 1 (list_segments): one lane per segment of the tile's range [slo, shi) — filters, overlap test — appends the op range
+// of every segment that touches the tile to a list in LDS; an exclusive scan over the list's op counts follows.
+// Level 2 (walk_list): one lane per op of the listed segments (entry by binary search in the scanned counts): an independent
+// 32-byte record, then for an M piece one 16-byte load of bases and the LDS atomics.  Three dependent cold misses per tile
+// (segment headers -> op records -> bases) whatever the tile holds, where the 16-lane-per-segment walk this replaces paid
+// three per round of 16 segments and again for every 16 ops of a segment.
+constexpr int LCAP = 512;                     // list entries per level-1 round (longer ranges take several rounds)
+struct SegList { uint32_t begin[LCAP]; int32_t cum[LCAP]; int n; int wtot[WAVES]; };   // lives in LDS
+
+__device__ __forceinline__ void list_segments(const ScanArgs &a, SegList &L, int sb, int se, int t0, int t1, int region) {
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    if (tid == 0) L.n = 0;
+    __syncthreads();
+    for (int base = sb; base < se; base += SCAN_THREADS) {
+        const int si = base + tid;
+        bool ok = false;
+        uint32_t ob = 0; int oc = 0;
+        if (si < se) {
+            const DevSeg *g = &a.segs[si];
+            const int es = g->ext_start, en = g->end;
+            const unsigned fl = g->flag; const int mq = g->mapq;
+            ob = (uint32_t)a.seg_op_off[si]; oc = a.seg_op_off[si + 1] - (int)ob;
+            ok = !flag_fails(fl, a.excl_flags) && mq >= a.min_mq && en > t0 && es < t1 && oc > 0;
+            if (ok && a.drop) ok = !read_dropped(a.drop, a.drop_words, region, (int)g->read_idx);
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            int at = 0;
+            if (lane == leader) at = atomicAdd(&L.n, __popcll(m));
+            at = __shfl(at, leader, 64);
+            if (ok) { const int e = at + __popcll(m & ((1ull << lane) - 1ull)); L.begin[e] = ob; L.cum[e] = oc; }
+        }
+    }
+    __syncthreads();
+}
+
+// exclusive scan of the list's op counts in place (LCAP = 2 * SCAN_THREADS entries); returns the total
+__device__ __forceinline__ int scan_list(SegList &L) {
+    static_assert(LCAP == 2 * SCAN_THREADS, "two list entries per thread");
+    const int tid = (int)threadIdx.x, n = L.n;
+    const int c0 = 2 * tid < n ? L.cum[2 * tid] : 0, c1 = 2 * tid + 1 < n ? L.cum[2 * tid + 1] : 0;
+    int tot;
+    const int ex = block_excl_scan(c0 + c1, L.wtot, &tot);
+    if (2 * tid < n) L.cum[2 * tid] = ex;
+    if (2 * tid + 1 < n) L.cum[2 * tid + 1] = ex + c0;
+    __syncthreads();
+    return tot;
 }
 
 template <int C, int MODE>
-__device__ void walk_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, unsigned long long ev_base, int region) {
-    const int lane = threadIdx.x & (GRP - 1);
-    const int grp = threadIdx.x / GRP;
-    for (int si = lo + grp; si < hi; si += NGRP) {
-        const DevSeg rd = a.segs[si];
-        if (!seg_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.ext_start >= t1) continue;
-        if (read_dropped(a.drop, a.drop_words, region, (int)rd.read_idx)) continue;
-        const bool rev = (rd.flag & 16) != 0;
-        const int r = (int)rd.read_idx;
-        int ref_carry = 0, q_carry = (int)rd.qstart, prev_carry = rd.lead_n ? (int)C3R_CIG_N : 15;
-        for (uint32_t kb = 0; kb < rd.n_cig; kb += GRP) {
-            const uint32_t k = kb + lane;
-            const bool valid = k < rd.n_cig;
-            const uint32_t c = valid ? a.cigar[rd.cig_off + k] : 15u;
-            const int op = (int)(c & 15u);
-            const int len = valid ? (int)(c >> 4) : 0;
-            const int rl = (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) ? len : 0;
-            const int ql = (op == C3R_CIG_M || op == C3R_CIG_I || op == C3R_CIG_S) ? len : 0;   // (segments hold no N ops)
-            const int rincl = grp_incl_scan(rl);
-            const int qincl = grp_incl_scan(ql);
-            const int rstart = rd.pos + ref_carry + rincl - rl;
-            const int qstart = q_carry + qincl - ql;
-            int prev = __shfl_up(op, 1, GRP);
-            if (lane == 0) prev = prev_carry;
-
-            if (op == C3R_CIG_M && MODE != SCATTER) {
-                const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
-                // up to 16 bases per round from ONE 8-byte load (the query bases of an M op are consecutive nibbles; the
-                // packed-base buffer is padded so that the load may run past a read's last byte): one load latency per 16
-                // bases instead of eight byte loads per 8
-                int pb = b0;
-                while (pb < b1) {
-                    const uint32_t q0 = (uint32_t)(qstart + (pb - rstart));
-                    const int odd = (int)(q0 & 1u);
-                    const int nb = min(b1 - pb, 16 - odd);
-                    uint64_t w = 0;
-                    if (q0 < rd.l_seq) __builtin_memcpy(&w, a.seq + rd.seq_off + (q0 >> 1), 8);   // (a CIGAR may claim more bases than SEQ holds)
+__device__ __forceinline__ void walk_op(const ScanArgs &a, const TileLds &s, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int t0, int t1,
+                                        unsigned long long ev_base) {
+    // the record's two 16-byte halves: {rstart, lenop, seq_off}, {qstart, l_seq, read_idx, flag | mapq << 16 | misc << 24}
+    const int op = (int)((uint32_t)ra.y & 15u), len = (int)((uint32_t)ra.y >> 4);
+    const int rstart = ra.x, qstart = rb.x, r = rb.z;
+    const uint64_t seq_off = (uint64_t)(uint32_t)ra.z | ((uint64_t)(uint32_t)ra.w << 32);
+    const uint32_t l_seq = (uint32_t)rb.y;
+    const bool rev = ((uint32_t)rb.w & 16u) != 0;
+    const int hp = (int)(((uint32_t)rb.w >> 24) & 3u), prev = (int)(((uint32_t)rb.w >> 26) & 15u);
+    if (op == C3R_CIG_M) {
+        if (MODE == SCATTER) return;
+        const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
+        if (b0 >= b1) return;
+        const uint32_t q0 = (uint32_t)(qstart + (b0 - rstart));
+        const int odd = (int)(q0 & 1u), nb = b1 - b0;
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        if (u >= nb) continue;
-                        const int ni = odd + u;                                  // nibble index inside w (high nibble first)
-                        int code = (int)((w >> (8 * (ni >> 1) + ((ni & 1) ? 0 : 4))) & 15u);
-                        if (q0 + (uint32_t)u >= rd.l_seq) code = 15;
-                        const int bi = acgt_index(code);
-                        const int pl = pb + u - t0;
-                        if (bi < 0) {
-                            // '=' / IUPAC letters are ignored by the reference's token scan WITHOUT consuming their HP entry: every
-                            // later read of the column is then phased with its predecessor's tag (:116-145)
-                            if (C == C3R_CH_PHASED && MODE == ACCUM && code != 15) s.odd[pl] = 1;
-                            continue;
-                        }
-                        if (MODE == ACCUM) {
-                            atomicAdd(&s.cnt[pl * C + (rev ? 9 + bi : bi)], 1);
-                            if (C == C3R_CH_PHASED) {
-                                if (rd.hp == 1) atomicAdd(&s.cnt[pl * C + C3R_AP + bi], 1);
-                                else if (rd.hp == 2) atomicAdd(&s.cnt[pl * C + C3R_AM + bi], 1);
-                            }
-                        } else if (MODE == FIRSTSEEN) {
-                            if (s.amb[pl]) atomicMin(&s.first[pl * 6 + bi], 2u * (uint32_t)r);
-                        }
-                    }
-                    pb += nb;
-                }
-            } else if (op == C3R_CIG_D && MODE == ACCUM) {
-                const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
-                for (int p = b0; p < b1; ++p) atomicAdd(&s.cnt[(p - t0) * C + (rev ? C3R_HASH : C3R_STAR)], 1);
+        for (int u = 0; u < OP_CHOP; ++u) {
+            if (u >= nb) continue;
+            const int ni = odd + u;                                  // nibble index inside w0:w1 (high nibble of a byte first)
+            const uint64_t w = ni < 16 ? w0 : w1;
+            int code = (int)((w >> (8 * ((ni & 15) >> 1) + ((ni & 1) ? 0 : 4))) & 15u);
+            if (q0 + (uint32_t)u >= l_seq) code = 15;              // (a CIGAR may claim more bases than SEQ holds)
+            const int bi = acgt_index(code);
+            const int pl = b0 + u - t0;
+            if (bi < 0) {
+                // '=' / IUPAC letters are ignored by the reference's token scan WITHOUT consuming their HP entry: every
+                // later read of the column is then phased with its predecessor's tag (:116-145)
+                if (C == C3R_CH_PHASED && MODE == ACCUM && code != 15) s.odd[pl] = 1;
+                continue;
             }
-            // indel attached to the column BEFORE the op (htslib: peek the next op at the last
-            // position of the current one).  After normalisation: I needs a ref-consuming predecessor,
-            // D needs an M or N predecessor.
-            const bool prev_ref = (prev == C3R_CIG_M || prev == C3R_CIG_D || prev == C3R_CIG_N);
-            const bool is_ins = (op == C3R_CIG_I) && prev_ref;
-            const bool is_del = (op == C3R_CIG_D) && (prev == C3R_CIG_M || prev == C3R_CIG_N);
-            if (is_ins || is_del) {
-                const int anchor = rstart - 1;
-                if (anchor >= t0 && anchor < t1) {
-                    const int pl = anchor - t0;
-                    if (MODE == ACCUM) {
-                        // an indel on a ref-skip column takes the haplotype of the previous token-list ENTRY (:183,189)
-                        if (C == C3R_CH_PHASED && prev == C3R_CIG_N) s.odd[pl] = 1;
-                        int ch;
-                        if (is_ins) {
-                            const int fc = base_code(a.seq, rd.seq_off, (uint32_t)qstart, rd.l_seq);
-                            // 'I' iff the first inserted char is one of "ACGTN*" (upper case => forward strand),
-                            // src/create_tensor_pileup.py:227-232
-                            ch = (!rev && (acgt_index(fc) >= 0 || fc == 15)) ? C3R_I : C3R_i;
-                        } else {
-                            ch = rev ? C3R_d : C3R_D;
-                            atomicMax(&s.maxdel[pl], len);
-                        }
-                        atomicAdd(&s.cnt[pl * C + ch], 1);
-                        if (C == C3R_CH_PHASED) {
-                            if (rd.hp == 1) atomicAdd(&s.cnt[pl * C + (is_ins ? C3R_IP : C3R_DP)], 1);
-                            else if (rd.hp == 2) atomicAdd(&s.cnt[pl * C + (is_ins ? C3R_IM : C3R_DM)], 1);
-                        }
-                    } else if (MODE == SCATTER) {
-                        EvRec e;
-                        e.key = 0;
-                        int ch;
-                        if (is_ins) {
-                            const int nk = len < 16 ? len : 16;
-                            for (int j = 0; j < nk; ++j)
-                                e.key |= (uint64_t)base_code(a.seq, rd.seq_off, (uint32_t)(qstart + j), rd.l_seq) << (4 * j);
-                            const int fc = (int)(e.key & 15u);
-                            ch = (!rev && (acgt_index(fc) >= 0 || fc == 15)) ? C3R_I1 : C3R_i1;
-                        } else {
-                            ch = rev ? C3R_d1 : C3R_D1;
-                        }
-                        e.len = (uint32_t)len; e.read_idx = (uint32_t)r; e.qpos = (uint32_t)qstart;
-                        e.pl = (uint16_t)pl; e.kind = (uint8_t)((rev ? 1 : 0) | (is_ins ? 2 : 0)); e.ch = (uint8_t)ch;
-                        const int slot = s.evoff[pl] + atomicAdd(&s.evfill[pl], 1);
-                        a.ev[ev_base + (unsigned)slot] = e;
-                    } else {  // FIRSTSEEN
-                        if (s.amb[pl]) atomicMin(&s.first[pl * 6 + (is_ins ? 4 : 5)], 2u * (uint32_t)r + 1u);
-                    }
+            if (MODE == ACCUM) {
+                atomicAdd(&s.cnt[pl * C + (rev ? 9 + bi : bi)], 1);
+                if (C == C3R_CH_PHASED) {
+                    if (hp == 1) atomicAdd(&s.cnt[pl * C + C3R_AP + bi], 1);
+                    else if (hp == 2) atomicAdd(&s.cnt[pl * C + C3R_AM + bi], 1);
                 }
+            } else if (MODE == FIRSTSEEN) {
+                if (s.amb[pl]) atomicMin(&s.first[pl * 6 + bi], 2u * (uint32_t)r);
             }
-            ref_carry += __shfl(rincl, GRP - 1, GRP);
-            q_carry += __shfl(qincl, GRP - 1, GRP);
-            prev_carry = __shfl(op, GRP - 1, GRP);
-            // '>' not '>=': an I/D op starting exactly at t1 is attached to column t1-1, which is ours
-            if (rd.pos + ref_carry > t1) break;
         }
+        return;
+    }
+    if (op == C3R_CIG_D && MODE == ACCUM) {
+        const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
+        for (int p = b0; p < b1; ++p) atomicAdd(&s.cnt[(p - t0) * C + (rev ? C3R_HASH : C3R_STAR)], 1);
+    }
+    // indel attached to the column BEFORE the op (htslib: peek the next op at the last position of the current one).
+    // After normalisation: I needs a ref-consuming predecessor, D needs an M or N predecessor.
+    const bool prev_ref = (prev == C3R_CIG_M || prev == C3R_CIG_D || prev == C3R_CIG_N);
+    const bool is_ins = (op == C3R_CIG_I) && prev_ref;
+    const bool is_del = (op == C3R_CIG_D) && (prev == C3R_CIG_M || prev == C3R_CIG_N);
+    if (!(is_ins || is_del)) return;
+    const int anchor = rstart - 1;
+    if (anchor < t0 || anchor >= t1) return;
+    const int pl = anchor - t0;
+    if (MODE == ACCUM) {
+        // an indel on a ref-skip column takes the haplotype of the previous token-list ENTRY (:183,189)
+        if (C == C3R_CH_PHASED && prev == C3R_CIG_N) s.odd[pl] = 1;
+        int ch;
+        if (is_ins) {
+            const int fc = base_code(a.seq, seq_off, (uint32_t)qstart, l_seq);
+            // 'I' iff the first inserted char is one of "ACGTN*" (upper case => forward strand), src/create_tensor_pileup.py:227-232
+            ch = (!rev && (acgt_index(fc) >= 0 || fc == 15)) ? C3R_I : C3R_i;
+        } else {
+            ch = rev ? C3R_d : C3R_D;
+            atomicMax(&s.maxdel[pl], len);
+        }
+        atomicAdd(&s.cnt[pl * C + ch], 1);
+        if (C == C3R_CH_PHASED) {
+            if (hp == 1) atomicAdd(&s.cnt[pl * C + (is_ins ? C3R_IP : C3R_DP)], 1);
+            else if (hp == 2) atomicAdd(&s.cnt[pl * C + (is_ins ? C3R_IM : C3R_DM)], 1);
+        }
+    } else if (MODE == SCATTER) {
+        EvRec e;
+        e.key = 0;
+        int ch;
+        if (is_ins) {
+            const int nk = len < 16 ? len : 16;
+            for (int j = 0; j < nk; ++j) e.key |= (uint64_t)base_code(a.seq, seq_off, (uint32_t)(qstart + j), l_seq) << (4 * j);
+            const int fc = (int)(e.key & 15u);
+            ch = (!rev && (acgt_index(fc) >= 0 || fc == 15)) ? C3R_I1 : C3R_i1;
+        } else {
+            ch = rev ? C3R_d1 : C3R_D1;
+        }
+        e.len = (uint32_t)len; e.read_idx = (uint32_t)r; e.qpos = (uint32_t)qstart;
+        e.pl = (uint16_t)pl; e.kind = (uint8_t)((rev ? 1 : 0) | (is_ins ? 2 : 0)); e.ch = (uint8_t)ch;
+        const int slot = s.evoff[pl] + atomicAdd(&s.evfill[pl], 1);
+        a.ev[ev_base + (unsigned)slot] = e;
+    } else {  // FIRSTSEEN
+        if (s.amb[pl]) atomicMin(&s.first[pl * 6 + (is_ins ? 4 : 5)], 2u * (uint32_t)r + 1u);
+    }
+}
+
+// All ops of the listed segments, WALK_UNR records per lane and round: their loads (record, then bases) are issued together.
+constexpr int WALK_UNR = 2;
+template <int C, int MODE>
+__device__ __forceinline__ void walk_list(const ScanArgs &a, const TileLds &s, const SegList &L, int total, int t0, int t1, unsigned long long ev_base) {
+    const int tid = (int)threadIdx.x, n_list = L.n;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    for (int base = 0; base < total; base += SCAN_THREADS * WALK_UNR) {
+        int4 ra[WALK_UNR], rb[WALK_UNR];
+        bool have[WALK_UNR];
+#pragma unroll
+        for (int u = 0; u < WALK_UNR; ++u) {
+            const int iu = base + u * SCAN_THREADS + tid;
+            have[u] = iu < total;
+            const int i = have[u] ? iu : total - 1;          // (idle lanes re-read the last record)
+            int lo = 0, hi = n_list;                         // the entry that holds op i: last e with cum[e] <= i
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.cum[mid] <= i) lo = mid; else hi = mid; }
+            const int4 *rec = reinterpret_cast<const int4 *>(a.ops + (L.begin[lo] + (uint32_t)(i - L.cum[lo])));
+            ra[u] = rec[0]; rb[u] = rec[1];
+        }
+        uint64_t w0[WALK_UNR], w1[WALK_UNR];
+#pragma unroll
+        for (int u = 0; u < WALK_UNR; ++u) {
+            w0[u] = 0; w1[u] = 0;
+            if (MODE != SCATTER && have[u] && ((uint32_t)ra[u].y & 15u) == C3R_CIG_M) {
+                const int b0 = max(ra[u].x, t0);
+                const uint32_t q0 = (uint32_t)rb[u].x + (uint32_t)(b0 - ra[u].x);
+                if (b0 < min(ra[u].x + (int)((uint32_t)ra[u].y >> 4), t1) && q0 < (uint32_t)rb[u].y) {
+                    const uint64_t so = (uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32);
+                    u64x2 w;                                 // (the packed-base buffer is padded: the load may run past a read's last byte)
+                    __builtin_memcpy(&w, a.seq + so + (q0 >> 1), 16);
+                    w0[u] = w[0]; w1[u] = w[1];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WALK_UNR; ++u)
+            if (have[u]) walk_op<C, MODE>(a, s, ra[u], rb[u], w0[u], w1[u], t0, t1, ev_base);
+    }
+}
+
+// One mode's pass over the tile's segments [slo, shi).  A range of at most LCAP segments is listed once (by the first pass)
+// and the list is re-used by the later passes; longer ranges are listed LCAP segments at a time in every pass.
+template <int C, int MODE>
+__device__ __forceinline__ void walk_tile(const ScanArgs &a, const TileLds &s, SegList &L, int slo, int shi, int t0, int t1, int region,
+                          unsigned long long ev_base, bool &listed, int &total) {
+    const bool single = shi - slo <= LCAP;
+    for (int sb = slo; sb < shi; sb += LCAP) {
+        if (!(single && listed)) {
+            list_segments(a, L, sb, min(shi, sb + LCAP), t0, t1, region);
+            total = scan_list(L);
+            listed = true;
+        }
+        walk_list<C, MODE>(a, s, L, total, t0, t1, ev_base);
+        if (!single) __syncthreads();                        // the next round rewrites the list
     }
 }
 
@@ -382,20 +521,6 @@ __device__ __forceinline__ bool ev_equal(const ScanArgs &a, const EvRec &x, cons
         }
     }
     return !((x.kind ^ y.kind) & 1) || caseless;
-}
-
-// block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, *total = sum
-__device__ __forceinline__ int block_excl_scan(int v, int *wave_tot /* LDS [WAVES] */, int *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int incl = wave_incl_scan(v);
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) { const int t = wave_tot[w]; if (w < wave) base += t; tot += t; }
-    __syncthreads();
-    *total = tot;
-    return base + incl - v;
 }
 
 // One thread per tile: the four binary searches that bound the tile's reads and segments.  Done here, thousands at a
@@ -451,11 +576,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     __shared__ int32_t s_evoff[TILE];
     __shared__ int32_t s_evfill[TILE];
     __shared__ int32_t s_maxdel[TILE];
-    __shared__ uint32_t s_first[TILE * 6];
     __shared__ uint8_t s_amb[TILE];
     __shared__ uint8_t s_odd[TILE];
     __shared__ int s_misc[8];
     __shared__ unsigned long long s_evbase;
+    __shared__ SegList L;
+    // first-seen words [TILE][6] (24 bytes per position) are only needed by the rare tie-break pass, which runs after the columns
+    // have been stored: they take the place of the accumulators
+    static_assert(C * 4 >= 24, "first-seen words alias the accumulators");
+    uint32_t *s_first = reinterpret_cast<uint32_t *>(s_cnt);
 
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= *a.n_tile_list) return;          // the grid is sized for the worst case
@@ -470,6 +599,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     const int slo = rng.z, shi = rng.w;     // aligned segments that can touch it
 
     TileLds s{s_cnt, s_cov, s_evoff, s_evfill, s_maxdel, s_first, s_amb, s_odd};
+    bool listed = false;
+    int n_ops = 0;
     s_cov[tid] = 0; if (tid == 0) s_cov[TILE] = 0;
     if (slo >= shi) {
         // intron-only tile: rows exist (ref-skip columns) but every count is zero.  Only the flags are written; the
@@ -509,12 +640,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         return;
     }
     for (int i = tid; i < TILE * C; i += SCAN_THREADS) s_cnt[i] = 0;
-    for (int i = tid; i < TILE * 6; i += SCAN_THREADS) s_first[i] = 0xffffffffu;
     s_evfill[tid] = 0; s_maxdel[tid] = 0; s_amb[tid] = 0; s_odd[tid] = 0;
     __syncthreads();
 
     if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1, tg.region);
-    if (!(a.abl & 1)) walk_reads<C, ACCUM>(a, s, slo, shi, t0, t1, 0ull, tg.region);
+    if (!(a.abl & 1)) walk_tile<C, ACCUM>(a, s, L, slo, shi, t0, t1, tg.region, 0ull, listed, n_ops);
     __syncthreads();
 
     // coverage: inclusive scan of the difference array; indel events: exclusive scan of per-position counts
@@ -537,7 +667,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
             // scan call fails instead of corrupting device memory
             if (tid == 0) *a.ev_overflow = 1;
         } else {
-        walk_reads<C, SCATTER>(a, s, slo, shi, t0, t1, evb, tg.region);
+        walk_tile<C, SCATTER>(a, s, L, slo, shi, t0, t1, tg.region, evb, listed, n_ops);
         __threadfence_block();
         __syncthreads();
         // max multiplicity of one allele per (position, channel): I1 / i1 / D1 / d1
@@ -615,8 +745,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         c[ch_lo] = -lw;
     }
     s_amb[tid] = ambiguous ? 1 : 0;
-    if (__syncthreads_or(ambiguous ? 1 : 0)) {
-        walk_reads<C, FIRSTSEEN>(a, s, slo, shi, t0, t1, 0ull, tg.region);
+    const bool any_amb = __syncthreads_or(ambiguous ? 1 : 0) != 0;
+
+    // ---- write the tile's columns, coalesced
+    const int npos = t1 - t0;
+    int32_t *gcol = a.cols + (size_t)slot0 * C;
+    if (!(a.abl & 8))
+    for (int i = tid; i < npos * C; i += SCAN_THREADS) gcol[i] = s_cnt[i];
+    if (tid == 0) a.tile_cols[tile] = 1;
+
+    if (any_amb) {
+        // "top allele != reference" with a tie at the top: the reference's stable sort keeps the class seen first in the column
+        __syncthreads();                  // the column store has read the accumulators: the first-seen words may take their place
+        for (int i = tid; i < TILE * 6; i += SCAN_THREADS) s_first[i] = 0xffffffffu;
+        __syncthreads();
+        walk_tile<C, FIRSTSEEN>(a, s, L, slo, shi, t0, t1, tg.region, 0ull, listed, n_ops);
         __syncthreads();
         if (ambiguous) {
             int m = 0;
@@ -628,14 +771,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
             cand = gates_ok && top_ne_ref;
         }
     }
-    __syncthreads();
 
-    // ---- write the tile: columns coalesced, then per-position metadata
-    const int npos = t1 - t0;
-    int32_t *gcol = a.cols + (size_t)slot0 * C;
-    if (!(a.abl & 8))
-    for (int i = tid; i < npos * C; i += SCAN_THREADS) gcol[i] = s_cnt[i];
-    if (tid == 0) a.tile_cols[tile] = 1;
+    // ---- per-position metadata
     if (p < t1) {
         const int gi = slot0 + tid;
         a.depth[gi] = depth;

@@ -7,16 +7,16 @@
 #include "../clair3_rna_amd/csrc/net_kernels.hpp"
 using namespace c3r;
 
-template <int ABL>
+template <int ABL, int TEAMS = 1>
 static float run(const int32_t *x, const half8 *w, _Float16 *y, int n, int reps) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    dim3 grid((n + 63) / 64, 2);
+    dim3 grid((n + 64 * TEAMS - 1) / (64 * TEAMS), 2);
     const int ns = (n + 127) / 128 * 128;
-    hipLaunchKernelGGL((k_lstm1_w8<18, ABL>), grid, dim3(512), 0, 0, x, w, y, n, ns);
+    hipLaunchKernelGGL((k_lstm1_w8<18, ABL, TEAMS>), grid, dim3(512 * TEAMS), 0, 0, x, w, y, n, ns);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_lstm1_w8<18, ABL>), grid, dim3(512), 0, 0, x, w, y, n, ns);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_lstm1_w8<18, ABL, TEAMS>), grid, dim3(512 * TEAMS), 0, 0, x, w, y, n, ns);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -47,6 +47,10 @@ int main(int argc, char **argv) {
         {"l1w8 no gate, no store", run<6>(x, w, y, n, 3)},
         {"l1w8 all three", run<22>(x, w, y, n, 3)},
         {"l1w8 full (again)", run<0>(x, w, y, n, 3)},
+        {"l1w8 two teams", run<0, 2>(x, w, y, n, 3)},
+        {"l1w8 two teams no gate", run<2, 2>(x, w, y, n, 3)},
+        {"l1w8 two teams no store", run<4, 2>(x, w, y, n, 3)},
+        {"l1w8 two teams (again)", run<0, 2>(x, w, y, n, 3)},
     };
     for (auto &e : r) printf("%-26s %8.3f ms  executed %6.1f TFLOP/s\n", e.name, e.ms, 3 * flop / e.ms / 1e9);
     return 0;
