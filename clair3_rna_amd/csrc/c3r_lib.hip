@@ -52,6 +52,8 @@ struct c3r_ctx {
     std::vector<int64_t> h_indel_prefix;  // [n_reads + 1] running count of I/D ops (normalised CIGARs): sizes the event scratch per scan
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
     std::vector<DevSeg> h_segs;            // aligned segments (CIGAR runs between N ops), sorted by ext_start
+    DevBuf d_dbg;                          // C3R_SCAN_DBG: phase timers of k_scan_tiles
+    DevBuf d_tile_cand;                    // [n_tiles] {first candidate, count} of the most recent scan (k_compact_write -> k_tile_tokens)
     DevBuf d_ops, d_seg_op_off;            // expanded op records of the sorted segments (pileup_kernels.hpp, OpRec) and each segment's first record
     DevBuf d_segs, d_seg_prefmax, d_tile_cols, d_tile_rng, d_tile_list, d_tile_list2, d_rsegs, d_rseg_first;
     ScanArgs last_scan;                    // arguments of the most recent scan (c3r_get_columns completes the pruned tiles with them)
@@ -276,7 +278,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+    DevBuf *bufs[] = {&ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -694,6 +696,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     if ((rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_list2, (size_t)n_tiles * 4 + 16))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tile_cand, (size_t)n_tiles * 8 + 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_blockcnt, (size_t)(n_cblocks + 1) * 4))) return rc;
     if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_skipmax, (size_t)n_pos * 4))) return rc;
     // d_small: [0..7] ev_cursor (u64), [8..11] event-scratch overflow flag, [12..15] n_cand, [16..19] n_tok, [20..23] n_tile_list,
@@ -703,6 +706,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     HIPCHK(ctx, hipMemsetAsync(ctx->d_lastrow.p, 0xff, (size_t)n_regions * 4, ctx->stream));      // -1
     HIPCHK(ctx, hipMemsetAsync(ctx->d_flags.p, 0, (size_t)n_pos, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cols.p, 0, (size_t)n_tiles, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cand.p, 0, (size_t)n_tiles * 8, ctx->stream));
 
     // samtools mpileup -d (default 8000), restated from htslib's bam_plp_push / bam_plp_next (third-party, absent: parity
     // unpinned; the oracle restates the same rule independently): reads arrive in file order, filtered, and only those
@@ -758,6 +762,12 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     a.tile_list2 = (int32_t *)ctx->d_tile_list2.p; a.n_tile_list2 = (int32_t *)((char *)ctx->d_small.p + 24);
     a.head_tail = ctx->prm.head_tail;
     { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
+    a.dbg = nullptr;
+    if (getenv("C3R_SCAN_DBG")) {
+        if ((rc = ensure(ctx, ctx->d_dbg, 16 * 8))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg.p, 0, 16 * 8, ctx->stream));
+        a.dbg = (unsigned long long *)ctx->d_dbg.p;
+    }
     a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->h_ref.size();
     a.geo = (const TileGeo *)ctx->d_geo.p;
     a.cols = (int32_t *)ctx->d_cols.p; a.depth = (int32_t *)ctx->d_depth.p; a.ncov = (int32_t *)ctx->d_ncov.p; a.flags = (uint8_t *)ctx->d_flags.p;
@@ -812,6 +822,13 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     HIPCHK(ctx, hipMemcpyAsync(flag_cand, (char *)ctx->d_small.p + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
+    if (a.dbg) {
+        unsigned long long d[16];
+        HIPCHK(ctx, hipMemcpy(d, ctx->d_dbg.p, sizeof d, hipMemcpyDeviceToHost));
+        const double nt = d[15] ? (double)d[15] : 1.0;
+        fprintf(stderr, "[k_scan_tiles] %llu heavy tiles; per tile: segments in range %.1f, listed %.1f, ops %.1f; us per tile: zero %.2f | cover+list+walk %.2f | scans %.2f | events %.2f | gates %.2f | store %.2f | first-seen %.2f\n",
+                d[15], d[13] / nt, d[12] / nt, d[14] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[5] / nt / 100, d[6] / nt / 100);
+    }
     if (flag_cand[0]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
     const int32_t n_cand = flag_cand[1];
     ctx->last_cand = n_cand;
@@ -826,7 +843,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     {
         Launch L(ctx, "k_compact_write");
         hipLaunchKernelGGL(k_compact_write, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
-                           (const int32_t *)ctx->d_blockcnt.p, (int32_t *)ctx->d_cand.p, heavy);
+                           (const int32_t *)ctx->d_blockcnt.p, (int32_t *)ctx->d_cand.p, heavy, (int2 *)ctx->d_tile_cand.p);
     }
     if ((rc = run_gather(ctx, 1, (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_cand * tbytes), true))) return rc;
     {
@@ -837,7 +854,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = ensure_keep(ctx, ctx->d_tok, std::max<size_t>((size_t)(base_tok + n_tok) * sizeof(c3r_token_t), 16),
                           (size_t)base_tok * sizeof(c3r_token_t)))) return rc;
-    {
+    if (getenv("C3R_OLD_TOKENS")) {
         TokArgs t;
         t.reads = a.reads; t.cigar = a.cigar; t.seq = a.seq; t.prefmax_end = a.prefmax_end; t.n_reads = a.n_reads;
         t.rsegs = (const DevSeg *)ctx->d_rsegs.p; t.rseg_first = (const uint32_t *)ctx->d_rseg_first.p;
@@ -849,6 +866,14 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
         t.min_mq = a.min_mq; t.excl_flags = a.excl_flags;
         Launch L(ctx, "k_tokens");
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)(((int64_t)n_cand * 64 + 255) / 256)), dim3(256), 0, ctx->stream, t);
+    } else {
+        TileTokArgs t;
+        t.a = a;
+        t.cand_idx = (const int32_t *)ctx->d_cand.p; t.tile_cand = (const int2 *)ctx->d_tile_cand.p;
+        t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
+        t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;
+        Launch L(ctx, "k_tokens");
+        hipLaunchKernelGGL(k_tile_tokens, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, t);
     }
     ctx->tokens_ready = true;
     ctx->n_cand = base_cand + n_cand;

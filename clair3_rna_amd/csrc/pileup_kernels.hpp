@@ -130,6 +130,7 @@ struct ScanArgs {
     int32_t n_tiles;
     int32_t head_tail;            // last_row (end of the row stream) is only needed for the head/tail flush rule
     int32_t abl;                  // timing-only ablation bits (env C3R_SCAN_ABL, 0 in production)
+    unsigned long long *dbg;      // null in production; env C3R_SCAN_DBG: per-phase wall-clock sums of k_scan_tiles' heavy tiles (100 MHz ticks)
     const uint8_t *ref;           // upper-cased reference slice
     int32_t ref_beg0;             // 0-based position of ref[0]
     int32_t ref_len;
@@ -639,13 +640,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         }
         return;
     }
+    unsigned long long tprev = a.dbg ? wall_clock64() : 0ull;
+#define C3R_PHASE(K) do { if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[K], now_ - tprev); tprev = now_; } } while (0)
     for (int i = tid; i < TILE * C; i += SCAN_THREADS) s_cnt[i] = 0;
     s_evfill[tid] = 0; s_maxdel[tid] = 0; s_amb[tid] = 0; s_odd[tid] = 0;
     __syncthreads();
 
+    C3R_PHASE(0);
     if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1, tg.region);
     if (!(a.abl & 1)) walk_tile<C, ACCUM>(a, s, L, slo, shi, t0, t1, tg.region, 0ull, listed, n_ops);
     __syncthreads();
+    C3R_PHASE(1);
 
     // coverage: inclusive scan of the difference array; indel events: exclusive scan of per-position counts
     int *wave_tot = &s_misc[2];
@@ -658,6 +663,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     int ev_total;
     const int ev_ex = block_excl_scan(nev, wave_tot, &ev_total);
     s_evoff[tid] = ev_ex;
+    C3R_PHASE(2);
     if (ev_total > 0 && !(a.abl & 2)) {
         if (tid == 0) s_evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
         __syncthreads();
@@ -688,6 +694,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         __syncthreads();
     }
 
+    C3R_PHASE(3);
     // ---- per-position gates (src/create_tensor_pileup.py:259-299, :536-556)
     const int p = t0 + tid;
     bool is_row = false, cand = false, ambiguous = false;
@@ -746,6 +753,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     }
     s_amb[tid] = ambiguous ? 1 : 0;
     const bool any_amb = __syncthreads_or(ambiguous ? 1 : 0) != 0;
+    C3R_PHASE(4);
 
     // ---- write the tile's columns, coalesced
     const int npos = t1 - t0;
@@ -753,6 +761,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     if (!(a.abl & 8))
     for (int i = tid; i < npos * C; i += SCAN_THREADS) gcol[i] = s_cnt[i];
     if (tid == 0) a.tile_cols[tile] = 1;
+    C3R_PHASE(5);
 
     if (any_amb) {
         // "top allele != reference" with a tie at the top: the reference's stable sort keeps the class seen first in the column
@@ -772,6 +781,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         }
     }
 
+    C3R_PHASE(6);
+    if (a.dbg && tid == 0) { atomicAdd(&a.dbg[14], (unsigned long long)n_ops); atomicAdd(&a.dbg[15], 1ull); atomicAdd(&a.dbg[13], (unsigned long long)(shi - slo)); atomicAdd(&a.dbg[12], (unsigned long long)L.n); }
+#undef C3R_PHASE
     // ---- per-position metadata
     if (p < t1) {
         const int gi = slot0 + tid;
@@ -960,8 +972,11 @@ __global__ __launch_bounds__(1024) void k_scan_add(int32_t *data, int n, const i
     for (int k = 0; k < SCAN_IT; ++k) if (i0 + k < n) data[i0 + k] += off;
 }
 
+// tile_cand[tile] = {index of the tile's first candidate in cand_idx, number of candidates}: a wavefront's 64 x 4 positions are
+// exactly one tile (zeroed beforehand: blocks without aligned bases leave early)
 __global__ __launch_bounds__(CMP_THREADS) void k_compact_write(const uint8_t *flags, int n_pos, const int32_t *block_off,
-                                                                 int32_t *cand_idx /* region-relative index */, const uint8_t *heavy) {
+                                                                 int32_t *cand_idx /* region-relative index */, const uint8_t *heavy, int2 *tile_cand) {
+    static_assert(64 * CMP_ITEMS == TILE, "one wavefront per tile");
     __shared__ int wsum[CMP_THREADS / 64];
     if (cmp_block_empty(heavy, n_pos)) return;
     const int base = blockIdx.x * CMP_BLOCK + threadIdx.x * CMP_ITEMS;
@@ -974,6 +989,7 @@ __global__ __launch_bounds__(CMP_THREADS) void k_compact_write(const uint8_t *fl
     __syncthreads();
     int off = block_off[blockIdx.x] + incl - c;
     for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (lane == 0 && base < n_pos) tile_cand[base / TILE] = make_int2(off, wsum[wave]);
 #pragma unroll
     for (int j = 0; j < CMP_ITEMS; ++j) { const int i = base + j; if (i < n_pos && (flags[i] & 4)) cand_idx[off++] = i; }
 }
@@ -1238,6 +1254,205 @@ __global__ __launch_bounds__(256) void k_tokens(const TokArgs t) {
             t.tok[base_off + written + rank] = tk;
         }
         written += __popcll(m);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Alt tokens, one workgroup per tile that holds candidates (replaces k_tokens' one wavefront per candidate, each of which
+// re-scanned its tile's reads and walked one read's CIGAR per lane, serially).  A token's slot is its read's rank among the
+// reads covering the candidate, in BAM order; per batch of TK_NB candidates and chunk of TK_RCH reads:
+//   1. cover pass  — one wavefront per candidate: ballots over the staged read spans give a 64-read cover mask and the running
+//                    rank per block, kept in LDS;
+//   2. op pass     — one lane per expanded op record of the tile's segments (the scan's two-level walk): every candidate the op
+//                    covers gets its token (base / deleted base, the indel the next record attaches to the op's last column)
+//                    written at  rank = prefix of its block + popcount of the mask below the read's bit, and the read's bit
+//                    is set in a "done" mask;
+//   3. ref-skip pass — covering reads not done show a ref-skip ('>' / '<'): their default tokens fill the remaining slots.
+// Every slot is written exactly once.
+struct TileTokArgs {
+    ScanArgs a;                    // the scan's own arguments (reads, segments, op table, tile list and ranges, filters, depth cap)
+    const int32_t *cand_idx; const int2 *tile_cand; const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
+    int32_t tok_base;              // tokens already resident from earlier scans of the batch
+};
+constexpr int TK_NB = 32, TK_RCH = 1024, TK_MAXB = TK_RCH / 64;
+struct TokLds {
+    int32_t pos[TK_RCH], end[TK_RCH];
+    uint8_t rev[TK_RCH];
+    unsigned long long mask[TK_NB][TK_MAXB], done[TK_NB][TK_MAXB];
+    int32_t pre[TK_NB][TK_MAXB];
+    int32_t lpos[TK_NB], toff[TK_NB], rank0[TK_NB], rank1[TK_NB];
+};
+
+__device__ __forceinline__ void tok_emit(const TileTokArgs &t, TokLds &K, int c, int ri, int r, int indel, uint32_t qpos, int base, bool rev) {
+    const int b = ri >> 6, bit = ri & 63;
+    const unsigned long long m = K.mask[c][b];
+    if (!((m >> bit) & 1ull)) return;                         // (not a covering read by its header: nothing to place)
+    const int slot = K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << bit) - 1ull));
+    int4 v;
+    v.x = r; v.y = indel; v.z = (int)qpos; v.w = base | ((rev ? 1 : 0) << 8);
+    *reinterpret_cast<int4 *>(&t.tok[slot]) = v;
+    atomicOr(&K.done[c][b], 1ull << bit);
+}
+
+__device__ __forceinline__ void tok_op(const TileTokArgs &t, TokLds &K, uint32_t idx, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1,
+                                       int t0, int t1, int nb, int rc, int re) {
+    const int op = (int)((uint32_t)ra.y & 15u), len = (int)((uint32_t)ra.y >> 4);
+    const int rstart = ra.x, r = rb.z;
+    if (r < rc || r >= re) return;                            // (its read belongs to another chunk of the tile's reads)
+    const uint32_t qstart = (uint32_t)rb.x, l_seq = (uint32_t)rb.y;
+    const bool rev = ((uint32_t)rb.w & 16u) != 0, last = (((uint32_t)rb.w >> 30) & 1u) != 0;
+    const int prev = (int)(((uint32_t)rb.w >> 26) & 15u);
+    if (op == C3R_CIG_M || op == C3R_CIG_D) {
+        const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
+        if (b0 < b1) {
+            const uint32_t q0 = qstart + (uint32_t)(b0 - rstart);
+            const int odd = (int)(q0 & 1u);
+            for (int c = 0; c < nb; ++c) {
+                const int p = t0 + K.lpos[c];
+                if (p < b0) continue;
+                if (p >= b1) break;                           // (candidates ascend)
+                int base = 16;
+                if (op == C3R_CIG_M) {
+                    const int ni = odd + (p - b0);
+                    const uint64_t w = ni < 16 ? w0 : w1;
+                    base = (int)((w >> (8 * ((ni & 15) >> 1) + ((ni & 1) ? 0 : 4))) & 15u);
+                    if (q0 + (uint32_t)(p - b0) >= l_seq) base = 15;
+                }
+                int indel = 0; uint32_t qpos = 0;
+                if (p == rstart + len - 1 && !last) {
+                    // htslib: the op after the one that ends on the column (same rules as the scan's walk_op)
+                    const int4 *nx = reinterpret_cast<const int4 *>(t.a.ops + (idx + 1));
+                    const int4 na = nx[0], nbv = nx[1];
+                    const int op2 = (int)((uint32_t)na.y & 15u), len2 = (int)((uint32_t)na.y >> 4), prev2 = (int)(((uint32_t)nbv.w >> 26) & 15u);
+                    if (op2 == C3R_CIG_I && (prev2 == C3R_CIG_M || prev2 == C3R_CIG_D || prev2 == C3R_CIG_N)) { indel = len2; qpos = (uint32_t)nbv.x; }
+                    else if (op2 == C3R_CIG_D && (prev2 == C3R_CIG_M || prev2 == C3R_CIG_N)) indel = -len2;
+                }
+                tok_emit(t, K, c, r - rc, r, indel, qpos, base, rev);
+            }
+        }
+    }
+    if ((op == C3R_CIG_I || op == C3R_CIG_D) && prev == C3R_CIG_N) {
+        // I / D right after a ref-skip: attached to the last intron column, which shows the ref-skip itself
+        const int anchor = rstart - 1;
+        if (anchor >= t0 && anchor < t1)
+            for (int c = 0; c < nb; ++c)
+                if (t0 + K.lpos[c] == anchor) tok_emit(t, K, c, r - rc, r, op == C3R_CIG_I ? len : -len, op == C3R_CIG_I ? qstart : 0u, 17, rev);
+    }
+}
+
+__device__ __forceinline__ void tok_walk_list(const TileTokArgs &t, TokLds &K, const SegList &L, int total, int t0, int t1, int nb, int rc, int re) {
+    const ScanArgs &a = t.a;
+    const int tid = (int)threadIdx.x, n_list = L.n;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    for (int base = 0; base < total; base += SCAN_THREADS * WALK_UNR) {
+        int4 ra[WALK_UNR], rb[WALK_UNR];
+        uint32_t idx[WALK_UNR];
+        bool have[WALK_UNR];
+#pragma unroll
+        for (int u = 0; u < WALK_UNR; ++u) {
+            const int iu = base + u * SCAN_THREADS + tid;
+            have[u] = iu < total;
+            const int i = have[u] ? iu : total - 1;
+            int lo = 0, hi = n_list;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.cum[mid] <= i) lo = mid; else hi = mid; }
+            idx[u] = L.begin[lo] + (uint32_t)(i - L.cum[lo]);
+            const int4 *rec = reinterpret_cast<const int4 *>(a.ops + idx[u]);
+            ra[u] = rec[0]; rb[u] = rec[1];
+        }
+        uint64_t w0[WALK_UNR], w1[WALK_UNR];
+#pragma unroll
+        for (int u = 0; u < WALK_UNR; ++u) {
+            w0[u] = 0; w1[u] = 0;
+            if (have[u] && ((uint32_t)ra[u].y & 15u) == C3R_CIG_M) {
+                const int b0 = max(ra[u].x, t0);
+                const uint32_t q0 = (uint32_t)rb[u].x + (uint32_t)(b0 - ra[u].x);
+                if (b0 < min(ra[u].x + (int)((uint32_t)ra[u].y >> 4), t1) && q0 < (uint32_t)rb[u].y) {
+                    const uint64_t so = (uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32);
+                    u64x2 w;
+                    __builtin_memcpy(&w, a.seq + so + (q0 >> 1), 16);
+                    w0[u] = w[0]; w1[u] = w[1];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WALK_UNR; ++u)
+            if (have[u]) tok_op(t, K, idx[u], ra[u], rb[u], w0[u], w1[u], t0, t1, nb, rc, re);
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_tile_tokens(const TileTokArgs t) {
+    __shared__ SegList L;
+    __shared__ TokLds K;
+    const ScanArgs &a = t.a;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= *a.n_tile_list) return;
+    const int tile = a.tile_list[blockIdx.x];
+    const int2 tc = t.tile_cand[tile];
+    if (tc.y <= 0) return;
+    const TileGeo tg = a.geo[tile];
+    const int t0 = tg.p0, t1 = tg.p1, slot0 = tile * TILE;
+    const int4 rng = a.tile_rng[tile];
+    const int lo = rng.x, hi = rng.y, slo = rng.z, shi = rng.w;
+    const bool single = shi - slo <= LCAP;
+    bool listed = false;
+    int total = 0;
+    for (int cb = 0; cb < tc.y; cb += TK_NB) {
+        const int nb = min(TK_NB, tc.y - cb);
+        __syncthreads();
+        if (tid < nb) {
+            const int w = tc.x + cb + tid;
+            const int off = t.tok_base + t.tok_off[w];
+            K.lpos[tid] = t.cand_idx[w] - slot0; K.toff[tid] = off; K.rank0[tid] = 0;
+            t.sites[w].tok_off = (uint32_t)off;
+        }
+        for (int rc = lo; rc < hi; rc += TK_RCH) {
+            const int re = min(hi, rc + TK_RCH), nr = re - rc, nblk = (nr + 63) >> 6;
+            __syncthreads();
+            for (int i = tid; i < nr; i += SCAN_THREADS) {
+                const DevRead rd = a.reads[rc + i];
+                const bool pass = read_passes(rd, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, tg.region, rc + i);
+                K.pos[i] = rd.pos; K.end[i] = pass ? rd.end : INT32_MIN; K.rev[i] = (rd.flag & 16) ? 1 : 0;
+            }
+            for (int i = tid; i < TK_NB * TK_MAXB; i += SCAN_THREADS) (&K.done[0][0])[i] = 0ull;
+            __syncthreads();
+            for (int c = wave; c < nb; c += WAVES) {
+                const int p = t0 + K.lpos[c];
+                int run = K.rank0[c];
+                for (int b = 0; b < nblk; ++b) {
+                    const int i = 64 * b + lane;
+                    const bool cov = i < nr && K.pos[i] <= p && K.end[i] > p;
+                    const unsigned long long m = __ballot(cov);
+                    if (lane == 0) { K.mask[c][b] = m; K.pre[c][b] = run; }
+                    run += __popcll(m);
+                }
+                if (lane == 0) K.rank1[c] = run;
+            }
+            __syncthreads();
+            if (slo < shi)
+            for (int sb = slo; sb < shi; sb += LCAP) {
+                if (!(single && listed)) {
+                    list_segments(a, L, sb, min(shi, sb + LCAP), t0, t1, tg.region);
+                    total = scan_list(L);
+                    listed = true;
+                }
+                tok_walk_list(t, K, L, total, t0, t1, nb, rc, re);
+                if (!single) __syncthreads();
+            }
+            __syncthreads();
+            for (int c = wave; c < nb; c += WAVES) {
+                for (int b = 0; b < nblk; ++b) {
+                    const unsigned long long m = K.mask[c][b], rest = m & ~K.done[c][b];
+                    if ((rest >> lane) & 1ull) {
+                        const int i = 64 * b + lane;
+                        const int slot = K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << lane) - 1ull));
+                        int4 v;
+                        v.x = rc + i; v.y = 0; v.z = 0; v.w = 17 | ((int)K.rev[i] << 8);
+                        *reinterpret_cast<int4 *>(&t.tok[slot]) = v;
+                    }
+                }
+                if (lane == 0) K.rank0[c] = K.rank1[c];
+            }
+        }
     }
 }
 

@@ -49,6 +49,20 @@ def test_config3_masseq_phased_30_channels(eng):
         assert np.abs(eng.infer() - po).max() < 1e-4, mode
 
 
+@pytest.mark.parametrize("channels", [18, 30])
+def test_deep_tiles_where_every_position_is_a_candidate(eng, channels):
+    """AF gates off at ~1500x: a tile then holds hundreds of candidates (several batches of the token kernel) whose covering reads
+    span several read chunks, and far more segments than one list round takes — the loops of k_tile_tokens / the tile walk nest."""
+    from clair3_rna_amd import synth
+    ref, rs, _ = synth.small_case(seed=4040 + channels, ref_len=9000, n_genes=3, depth=1500, mean_len=500, phased=(channels == 30))
+    _fresh(eng, channels=channels, snp_min_af=0.0, min_coverage=2)
+    got = H.engine_chunk(eng, rs, ref, 1, 1, len(ref))
+    exp = H.oracle_chunk(rs, ref, 1, 1, len(ref), channels=channels, snp_af=0.0, min_coverage=2)
+    assert len(exp["lines"]) > 300 and exp["depth"].max() > 1100
+    assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
+    assert np.array_equal(got["X"], exp["X"])
+
+
 @pytest.mark.parametrize("depth", [144, 216, 230, 500, 2000])
 def test_config4_high_depth_windows(eng, depth):
     from clair3_rna_amd import synth
