@@ -237,6 +237,7 @@ void merge_intervals(std::vector<int32_t> &iv) {
 }  // namespace
 
 static int device_excl_scan(c3r_ctx *ctx, int32_t *d, int n, int32_t *d_total);
+static int list_grid() { static const int v = [] { const char *e = getenv("C3R_LIST_GRID"); return e && atoi(e) > 0 ? atoi(e) : LIST_GRID; }(); return v; }
 
 extern "C" {
 
@@ -786,8 +787,8 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     }
     if (a.n_reads > 0) {
         Launch L(ctx, "k_scan_tiles");
-        if (C == C3R_CH) hipLaunchKernelGGL(k_scan_tiles<C3R_CH>, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(k_scan_tiles<C3R_CH_PHASED>, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
+        if (C == C3R_CH) hipLaunchKernelGGL(k_scan_tiles<C3R_CH>, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_scan_tiles<C3R_CH_PHASED>, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, a);
     }
     if (a.n_reads > 0 && C == C3R_CH_PHASED) {
         PhaseArgs f;
@@ -796,19 +797,20 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
         f.cigar = a.cigar; f.seq = a.seq; f.flags = a.flags; f.cols = a.cols; f.min_mq = a.min_mq; f.excl_flags = a.excl_flags;
         f.drop = a.drop; f.drop_words = a.drop_words;
         Launch L(ctx, "k_phase_recompute");
-        hipLaunchKernelGGL(k_phase_recompute, dim3(n_tiles), dim3(TILE), 0, ctx->stream, f);
+        hipLaunchKernelGGL(k_phase_recompute, dim3(std::min(n_tiles, list_grid())), dim3(TILE), 0, ctx->stream, f);
     }
     if (a.n_reads > 0 && a.splice) {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_skipmax.p, 0, (size_t)n_pos * 4, ctx->stream));
         Launch L(ctx, "k_skip_counts");
-        hipLaunchKernelGGL(k_skip_counts, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_skip_counts, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, a);
     }
     // candidates live in tiles that hold aligned bases — except in genotyping mode, where any row of the site list is one
     const uint8_t *heavy = ctx->prm.genotyping_mode ? nullptr : (const uint8_t *)ctx->d_tile_cols.p;
     {
         Launch L(ctx, "k_select");
-        hipLaunchKernelGGL(k_select, dim3((unsigned)((n_pos + 255) / 256)), dim3(256), 0, ctx->stream, (uint8_t *)ctx->d_flags.p,
-                           (int)n_pos, (const TileGeo *)ctx->d_geo.p, ctx->prm.head_tail, (const int32_t *)ctx->d_lastrow.p, heavy);
+        hipLaunchKernelGGL(k_select, dim3(std::min(n_tiles, list_grid())), dim3(TILE), 0, ctx->stream, (uint8_t *)ctx->d_flags.p,
+                           (int)n_pos, (const TileGeo *)ctx->d_geo.p, ctx->prm.head_tail, (const int32_t *)ctx->d_lastrow.p, heavy,
+                           (const int32_t *)ctx->d_tile_list.p, (const int32_t *)((char *)ctx->d_small.p + 20));
     }
     {
         Launch L(ctx, "k_compact_count");
@@ -873,7 +875,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
         t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
         t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;
         Launch L(ctx, "k_tokens");
-        hipLaunchKernelGGL(k_tile_tokens, dim3(n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, t);
+        hipLaunchKernelGGL(k_tile_tokens, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, t);
     }
     ctx->tokens_ready = true;
     ctx->n_cand = base_cand + n_cand;
@@ -963,8 +965,8 @@ int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t
         // the scan skipped intron-only tiles that no candidate window can reach: compute their row flags now
         ScanArgs a = ctx->last_scan;
         a.tile_list = a.tile_list2; a.n_tile_list = a.n_tile_list2;
-        if (ctx->prm.channels == C3R_CH) hipLaunchKernelGGL(k_scan_tiles<C3R_CH>, dim3(a.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(k_scan_tiles<C3R_CH_PHASED>, dim3(a.n_tiles), dim3(SCAN_THREADS), 0, ctx->stream, a);
+        if (ctx->prm.channels == C3R_CH) hipLaunchKernelGGL(k_scan_tiles<C3R_CH>, dim3(std::min((int)a.n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_scan_tiles<C3R_CH_PHASED>, dim3(std::min((int)a.n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, a);
         ctx->last_scan_pruned = false;
     }
     const size_t n = (size_t)npos0;

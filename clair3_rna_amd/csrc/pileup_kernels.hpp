@@ -312,7 +312,7 @@ __global__ void k_ops_write(const DevSeg *segs, int n_segs, const uint32_t *ciga
 // 32-byte record, then for an M piece one 16-byte load of bases and the LDS atomics.  Three dependent cold misses per tile
 // (segment headers -> op records -> bases) whatever the tile holds, where the 16-lane-per-segment walk this replaces paid
 // three per round of 16 segments and again for every 16 ops of a segment.
-constexpr int LCAP = 512;                     // list entries per level-1 round (longer ranges take several rounds)
+constexpr int LCAP = 256;                     // list entries per level-1 round (longer ranges take several rounds)
 struct SegList { uint32_t begin[LCAP]; int32_t cum[LCAP]; int n; int wtot[WAVES]; };   // lives in LDS
 
 __device__ __forceinline__ void list_segments(const ScanArgs &a, SegList &L, int sb, int se, int t0, int t1, int region) {
@@ -343,22 +343,21 @@ __device__ __forceinline__ void list_segments(const ScanArgs &a, SegList &L, int
     __syncthreads();
 }
 
-// exclusive scan of the list's op counts in place (LCAP = 2 * SCAN_THREADS entries); returns the total
+// exclusive scan of the list's op counts in place (one entry per thread); returns the total
 __device__ __forceinline__ int scan_list(SegList &L) {
-    static_assert(LCAP == 2 * SCAN_THREADS, "two list entries per thread");
+    static_assert(LCAP == SCAN_THREADS, "one list entry per thread");
     const int tid = (int)threadIdx.x, n = L.n;
-    const int c0 = 2 * tid < n ? L.cum[2 * tid] : 0, c1 = 2 * tid + 1 < n ? L.cum[2 * tid + 1] : 0;
+    const int c0 = tid < n ? L.cum[tid] : 0;
     int tot;
-    const int ex = block_excl_scan(c0 + c1, L.wtot, &tot);
-    if (2 * tid < n) L.cum[2 * tid] = ex;
-    if (2 * tid + 1 < n) L.cum[2 * tid + 1] = ex + c0;
+    const int ex = block_excl_scan(c0, L.wtot, &tot);
+    if (tid < n) L.cum[tid] = ex;
     __syncthreads();
     return tot;
 }
 
 template <int C, int MODE>
 __device__ __forceinline__ void walk_op(const ScanArgs &a, const TileLds &s, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int t0, int t1,
-                                        unsigned long long ev_base) {
+                                        EvRec *ev) {
     // the record's two 16-byte halves: {rstart, lenop, seq_off}, {qstart, l_seq, read_idx, flag | mapq << 16 | misc << 24}
     const int op = (int)((uint32_t)ra.y & 15u), len = (int)((uint32_t)ra.y >> 4);
     const int rstart = ra.x, qstart = rb.x, r = rb.z;
@@ -444,7 +443,7 @@ __device__ __forceinline__ void walk_op(const ScanArgs &a, const TileLds &s, con
         e.len = (uint32_t)len; e.read_idx = (uint32_t)r; e.qpos = (uint32_t)qstart;
         e.pl = (uint16_t)pl; e.kind = (uint8_t)((rev ? 1 : 0) | (is_ins ? 2 : 0)); e.ch = (uint8_t)ch;
         const int slot = s.evoff[pl] + atomicAdd(&s.evfill[pl], 1);
-        a.ev[ev_base + (unsigned)slot] = e;
+        ev[slot] = e;
     } else {  // FIRSTSEEN
         if (s.amb[pl]) atomicMin(&s.first[pl * 6 + (is_ins ? 4 : 5)], 2u * (uint32_t)r + 1u);
     }
@@ -453,7 +452,7 @@ __device__ __forceinline__ void walk_op(const ScanArgs &a, const TileLds &s, con
 // All ops of the listed segments, WALK_UNR records per lane and round: their loads (record, then bases) are issued together.
 constexpr int WALK_UNR = 2;
 template <int C, int MODE>
-__device__ __forceinline__ void walk_list(const ScanArgs &a, const TileLds &s, const SegList &L, int total, int t0, int t1, unsigned long long ev_base) {
+__device__ __forceinline__ void walk_list(const ScanArgs &a, const TileLds &s, const SegList &L, int total, int t0, int t1, EvRec *ev) {
     const int tid = (int)threadIdx.x, n_list = L.n;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     for (int base = 0; base < total; base += SCAN_THREADS * WALK_UNR) {
@@ -486,7 +485,7 @@ __device__ __forceinline__ void walk_list(const ScanArgs &a, const TileLds &s, c
         }
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u)
-            if (have[u]) walk_op<C, MODE>(a, s, ra[u], rb[u], w0[u], w1[u], t0, t1, ev_base);
+            if (have[u]) walk_op<C, MODE>(a, s, ra[u], rb[u], w0[u], w1[u], t0, t1, ev);
     }
 }
 
@@ -494,7 +493,7 @@ __device__ __forceinline__ void walk_list(const ScanArgs &a, const TileLds &s, c
 // and the list is re-used by the later passes; longer ranges are listed LCAP segments at a time in every pass.
 template <int C, int MODE>
 __device__ __forceinline__ void walk_tile(const ScanArgs &a, const TileLds &s, SegList &L, int slo, int shi, int t0, int t1, int region,
-                          unsigned long long ev_base, bool &listed, int &total) {
+                          EvRec *ev, bool &listed, int &total) {
     const bool single = shi - slo <= LCAP;
     for (int sb = slo; sb < shi; sb += LCAP) {
         if (!(single && listed)) {
@@ -502,7 +501,7 @@ __device__ __forceinline__ void walk_tile(const ScanArgs &a, const TileLds &s, S
             total = scan_list(L);
             listed = true;
         }
-        walk_list<C, MODE>(a, s, L, total, t0, t1, ev_base);
+        walk_list<C, MODE>(a, s, L, total, t0, t1, ev);
         if (!single) __syncthreads();                        // the next round rewrites the list
     }
 }
@@ -570,8 +569,13 @@ __global__ void k_tile_ranges(const ScanArgs a) {
     if (a.prune) wave_append(a.tile_list2, a.n_tile_list2, pruned, t);
 }
 
+// The tile kernels run over the compact tile list with a FIXED grid (LIST_GRID workgroups, each taking every LIST_GRID-th list
+// entry): the list's length lives on the device, and a grid of one workgroup per tile of the scan — 250 k for chr20, of which
+// 40 k are listed — spent ~0.09 ms per kernel dispatching workgroups that left at once.
+constexpr int LIST_GRID = 8192;
+
 template <int C>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
+__device__ __forceinline__ void scan_tile(const ScanArgs &a, const int tile) {
     __shared__ int32_t s_cnt[TILE * C];
     __shared__ int32_t s_cov[TILE + 1];
     __shared__ int32_t s_evoff[TILE];
@@ -582,14 +586,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     __shared__ int s_misc[8];
     __shared__ unsigned long long s_evbase;
     __shared__ SegList L;
+    // indel events of a tile stay in LDS when there are at most EV_LDS of them (a 20x ONT tile holds ~100); deeper tiles bump-allocate
+    // global scratch.  (30 channels: the accumulators leave no room at four workgroups per CU.)
+    constexpr int EV_LDS = C == C3R_CH ? 192 : 0;
+    __shared__ EvRec s_ev[EV_LDS > 0 ? EV_LDS : 1];
     // first-seen words [TILE][6] (24 bytes per position) are only needed by the rare tie-break pass, which runs after the columns
     // have been stored: they take the place of the accumulators
     static_assert(C * 4 >= 24, "first-seen words alias the accumulators");
     uint32_t *s_first = reinterpret_cast<uint32_t *>(s_cnt);
 
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= *a.n_tile_list) return;          // the grid is sized for the worst case
-    const int tile = a.tile_list[blockIdx.x];
     const TileGeo tg = a.geo[tile];
     const int t0 = tg.p0, t1 = tg.p1;
     const int slot0 = tile * TILE;        // index of the tile's first position in cols / depth / ncov / flags
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
 
     C3R_PHASE(0);
     if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1, tg.region);
-    if (!(a.abl & 1)) walk_tile<C, ACCUM>(a, s, L, slo, shi, t0, t1, tg.region, 0ull, listed, n_ops);
+    if (!(a.abl & 1)) walk_tile<C, ACCUM>(a, s, L, slo, shi, t0, t1, tg.region, nullptr, listed, n_ops);
     __syncthreads();
     C3R_PHASE(1);
 
@@ -665,31 +671,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     s_evoff[tid] = ev_ex;
     C3R_PHASE(2);
     if (ev_total > 0 && !(a.abl & 2)) {
-        if (tid == 0) s_evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
-        __syncthreads();
-        const unsigned long long evb = s_evbase;
-        if (evb + (unsigned long long)((ev_total + 15) & ~15) > a.ev_cap) {
-            // cannot happen with the host's sizing (c3r_pileup_scan_regions); if it ever does, no write leaves the buffer and the
-            // scan call fails instead of corrupting device memory
-            if (tid == 0) *a.ev_overflow = 1;
-        } else {
-        walk_tile<C, SCATTER>(a, s, L, slo, shi, t0, t1, tg.region, evb, listed, n_ops);
-        __threadfence_block();
-        __syncthreads();
-        // max multiplicity of one allele per (position, channel): I1 / i1 / D1 / d1
-        for (int e = tid; e < ev_total; e += SCAN_THREADS) {
-            const EvRec me = a.ev[evb + (unsigned)e];
-            const int pl = me.pl;
-            const int b = s_evoff[pl];
-            const int32_t *rw = &s_cnt[pl * C];
-            const int n = rw[C3R_I] + rw[C3R_i] + rw[C3R_D] + rw[C3R_d];
-            int eq = 0;
-            for (int j = 0; j < n; ++j) {
-                const EvRec o = a.ev[evb + (unsigned)(b + j)];
-                eq += ev_equal(a, me, o) ? 1 : 0;
+        // the tile's indel events, bucketed by position (counting sort through evoff / evfill), then the max multiplicity of one
+        // allele per (position, channel): I1 / i1 / D1 / d1
+        auto events = [&](EvRec *ev) __attribute__((always_inline)) {
+            walk_tile<C, SCATTER>(a, s, L, slo, shi, t0, t1, tg.region, ev, listed, n_ops);
+            __threadfence_block();
+            __syncthreads();
+            for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+                const EvRec me = ev[e];
+                const int pl = me.pl;
+                const int b = s_evoff[pl];
+                const int32_t *rw = &s_cnt[pl * C];
+                const int n = rw[C3R_I] + rw[C3R_i] + rw[C3R_D] + rw[C3R_d];
+                int eq = 0;
+                for (int j = 0; j < n; ++j) eq += ev_equal(a, me, ev[b + j]) ? 1 : 0;
+                atomicMax(&s_cnt[pl * C + me.ch], eq);
             }
-            atomicMax(&s_cnt[pl * C + me.ch], eq);
-        }
+        };
+        if (ev_total <= EV_LDS) {
+            events(s_ev);                  // the usual case: the events never leave LDS
+        } else {
+            if (tid == 0) s_evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
+            __syncthreads();
+            const unsigned long long evb = s_evbase;
+            if (evb + (unsigned long long)((ev_total + 15) & ~15) > a.ev_cap) {
+                // cannot happen with the host's sizing (c3r_pileup_scan_regions); if it ever does, no write leaves the buffer and the
+                // scan call fails instead of corrupting device memory
+                if (tid == 0) *a.ev_overflow = 1;
+            } else {
+                events(a.ev + evb);
+            }
         }
         __syncthreads();
     }
@@ -768,7 +779,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
         __syncthreads();                  // the column store has read the accumulators: the first-seen words may take their place
         for (int i = tid; i < TILE * 6; i += SCAN_THREADS) s_first[i] = 0xffffffffu;
         __syncthreads();
-        walk_tile<C, FIRSTSEEN>(a, s, L, slo, shi, t0, t1, tg.region, 0ull, listed, n_ops);
+        walk_tile<C, FIRSTSEEN>(a, s, L, slo, shi, t0, t1, tg.region, nullptr, listed, n_ops);
         __syncthreads();
         if (ambiguous) {
             int m = 0;
@@ -799,6 +810,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const ScanArgs a) {
     }
 }
 
+// (register budget = the occupancy LDS allows: five workgroups per CU at 18 channels, four at 30)
+template <int C>
+#ifndef C3R_SCAN_OCC30
+#define C3R_SCAN_OCC30 4
+#endif
+__global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) void k_scan_tiles(const ScanArgs a) {
+    const int n = *a.n_tile_list;
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        scan_tile<C>(a, a.tile_list[b]);
+        __syncthreads();                  // the next tile re-uses the LDS arrays
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Splice-junction padding, part 1 (src/create_tensor_pileup.py:151-178, :532-534): per row
 //   max_skip_count = max(#'$', #'^', #'<', #'>')
@@ -811,12 +835,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) 
     __shared__ int32_t s_start[TILE], s_end[TILE];
     __shared__ int s_w[WAVES];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= *a.n_tile_list) return;
-    const int tile = a.tile_list[blockIdx.x];
+    const int n_list = *a.n_tile_list;
+    for (int lb = blockIdx.x; lb < n_list; lb += gridDim.x) {
+    const int tile = a.tile_list[lb];
     const TileGeo tg = a.geo[tile];
     const int t0 = tg.p0, t1 = tg.p1;
     const int slot0 = tile * TILE;        // index of the tile's first position in cols / depth / ncov / flags
     const int4 rng = a.tile_rng[tile];
+    __syncthreads();
     for (int i = tid; i < 2 * (TILE + 1); i += SCAN_THREADS) { (&s_cov[0][0])[i] = 0; (&s_seg[0][0])[i] = 0; }
     s_start[tid] = 0; s_end[tid] = 0;
     __syncthreads();
@@ -852,6 +878,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) 
         m = max(m, max(v[0] - v[2], v[1] - v[3]));
         a.skipmax[gi] = (a.flags[gi] & 1) ? m : 0;
     }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -862,23 +889,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) 
 // heavy: null, or tile_cols — outside genotyping mode only tiles that hold aligned bases (tile_cols = 1) can have candidates, and
 // 93 % of an RNA contig's covered tiles are intron-only: the three kernels below leave their blocks early there instead of
 // reading 64 MB of flags each.
-__global__ void k_select(uint8_t *flags, int n_pos, const TileGeo *geo, int head_tail, const int32_t *last_row, const uint8_t *heavy) {
+__global__ __launch_bounds__(TILE) void k_select(uint8_t *flags, int n_pos, const TileGeo *geo, int head_tail, const int32_t *last_row, const uint8_t *heavy,
+                                                 const int32_t *tile_list, const int32_t *n_tile_list) {
     static_assert(TILE == 256, "one 256-thread block per tile");
-    if (heavy && !heavy[blockIdx.x]) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pos) return;
-    const uint8_t f = flags[i];
-    if (!(f & 2)) return;
-    bool ok = true;
-    if (!head_tail) {
-        if (i - C3R_FLANK < 0 || i + C3R_FLANK >= n_pos) ok = false;
-        else for (int q = i - C3R_FLANK; q <= i + C3R_FLANK; ++q) if (!(flags[q] & 1)) { ok = false; break; }
-    } else {
-        const int last = last_row[geo[i / TILE].region];
-        const int hi = min(i + C3R_FLANK, last);
-        for (int q = i + 1; q <= hi; ++q) if (!(flags[q] & 1)) { ok = false; break; }
+    const int n_list = *n_tile_list;
+    for (int lb = blockIdx.x; lb < n_list; lb += gridDim.x) {
+        const int tile = tile_list[lb];
+        if (heavy && !heavy[tile]) continue;
+        const int i = tile * TILE + (int)threadIdx.x;
+        if (i >= n_pos) continue;
+        const uint8_t f = flags[i];
+        if (!(f & 2)) continue;
+        bool ok = true;
+        if (!head_tail) {
+            if (i - C3R_FLANK < 0 || i + C3R_FLANK >= n_pos) ok = false;
+            else for (int q = i - C3R_FLANK; q <= i + C3R_FLANK; ++q) if (!(flags[q] & 1)) { ok = false; break; }
+        } else {
+            const int last = last_row[geo[tile].region];
+            const int hi = min(i + C3R_FLANK, last);
+            for (int q = i + 1; q <= hi; ++q) if (!(flags[q] & 1)) { ok = false; break; }
+        }
+        if (ok) flags[i] = f | 4;
     }
-    if (ok) flags[i] = f | 4;
 }
 
 // ordered stream compaction of emitted positions: count -> scan -> write
@@ -1028,18 +1060,32 @@ __device__ __forceinline__ void gather_window(const GatherArgs &g, int w, int ci
     int32_t *raw = g.raw ? g.raw + (size_t)w * C3R_WINDOW * C : nullptr;
     const int first = ci - C3R_FLANK;
     // two channels (8 bytes) per lane and round: C is even, so a pair never straddles two columns, and every window, column and
-    // tensor starts on an 8-byte boundary (C * 4 = 72 / 120 bytes per column)
+    // tensor starts on an 8-byte boundary (C * 4 = 72 / 120 bytes per column).  All rounds' loads are issued before the first store;
+    // a window touches at most two tiles, whose "columns exist" bytes are read once
     static_assert(C % 2 == 0, "channel pairs");
     typedef int int2v __attribute__((ext_vector_type(2)));
-    for (int i2 = lane; i2 < C3R_WINDOW * C / 2; i2 += 64) {
-        const int i = 2 * i2;
+    constexpr int NP = C3R_WINDOW * C / 2, NIT = (NP + 63) / 64;
+    const int tl = max(first, 0) / TILE, th = min(first + 2 * C3R_FLANK, g.n_pos - 1) / TILE;
+    const bool have_l = g.tile_cols[tl] != 0, have_h = g.tile_cols[th] != 0;
+    int2v v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = 2 * (lane + 64 * it);
         const int q = first + i / C, ch = i % C;
-        int2v v = {0, 0};
-        if (q >= lo_valid && q <= hi_valid && g.tile_cols[q / TILE]) v = *(const int2v *)(g.cols + (size_t)q * C + ch);
-        else if (zcol && q < lo_valid) { v[0] = zcol[ch]; v[1] = zcol[ch + 1]; }      // the run's shared pre-fill column (splice padding edits it)
-        if (raw) *(int2v *)(raw + i) = v;
-        if (scale) { v[0] = (int32_t)((double)v[0] / sf); v[1] = (int32_t)((double)v[1] / sf); }
-        *(int2v *)(out + i) = v;
+        v[it] = int2v{0, 0};
+        if (i < 2 * NP) {
+            if (q >= lo_valid && q <= hi_valid) { if (q / TILE == tl ? have_l : have_h) v[it] = *(const int2v *)(g.cols + (size_t)q * C + ch); }
+            else if (zcol && q < lo_valid) { v[it][0] = zcol[ch]; v[it][1] = zcol[ch + 1]; }      // the run's shared pre-fill column (splice padding edits it)
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = 2 * (lane + 64 * it);
+        if (i < 2 * NP) {
+            if (raw) *(int2v *)(raw + i) = v[it];
+            if (scale) { v[it][0] = (int32_t)((double)v[it][0] / sf); v[it][1] = (int32_t)((double)v[it][1] / sf); }
+            *(int2v *)(out + i) = v[it];
+        }
     }
     if (g.sites) {
         c3r_site_t *s = &g.sites[w];
@@ -1056,7 +1102,7 @@ __device__ __forceinline__ void gather_window(const GatherArgs &g, int w, int ci
 
 template <int C>
 __global__ __launch_bounds__(256) void k_gather(const GatherArgs g) {
-    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int w = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));      // (wave-uniform: scalar loads)
     const int lane = threadIdx.x & 63;
     if (w >= g.n_cand) return;
     gather_window<C>(g, w, g.cand_idx[w], lane);
@@ -1380,15 +1426,20 @@ __device__ __forceinline__ void tok_walk_list(const TileTokArgs &t, TokLds &K, c
     }
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_tile_tokens(const TileTokArgs t) {
+#ifndef C3R_TOK_OCC
+#define C3R_TOK_OCC 6
+#endif
+__global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const TileTokArgs t) {
     __shared__ SegList L;
     __shared__ TokLds K;
     const ScanArgs &a = t.a;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x >= *a.n_tile_list) return;
-    const int tile = a.tile_list[blockIdx.x];
+    const int n_list = *a.n_tile_list;
+    for (int lb = blockIdx.x; lb < n_list; lb += gridDim.x) {
+    const int tile = a.tile_list[lb];
     const int2 tc = t.tile_cand[tile];
-    if (tc.y <= 0) return;
+    if (tc.y <= 0) continue;
+    __syncthreads();
     const TileGeo tg = a.geo[tile];
     const int t0 = tg.p0, t1 = tg.p1, slot0 = tile * TILE;
     const int4 rng = a.tile_rng[tile];
@@ -1454,6 +1505,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_tile_tokens(const TileTokArgs 
             }
         }
     }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1473,10 +1525,11 @@ struct PhaseArgs {
     const uint32_t *drop; int32_t drop_words;
 };
 __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
-    if ((int)blockIdx.x >= *a.n_tile_list) return;
-    const int tile = a.tile_list[blockIdx.x];
+    const int n_list = *a.n_tile_list;
+    for (int lb = blockIdx.x; lb < n_list; lb += gridDim.x) {
+    const int tile = a.tile_list[lb];
     const int slot = tile * TILE + (int)threadIdx.x;
-    if (!(a.flags[slot] & 8)) return;
+    if (!(a.flags[slot] & 8)) continue;
     const int p = a.geo[tile].p0 + (int)threadIdx.x;
     const int4 rng = a.tile_rng[tile];
     auto next_cov = [&](int r) {            // next read after r (BAM order) that passes the filters and covers p
@@ -1514,6 +1567,7 @@ __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
     int32_t *c = a.cols + (size_t)slot * C3R_CH_PHASED + C3R_AP;
 #pragma unroll
     for (int k = 0; k < 12; ++k) c[k] = cnt[k];
+    }
 }
 
 }  // namespace c3r
