@@ -84,6 +84,9 @@ constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 #ifndef C3R_L1_TEAMS
 #define C3R_L1_TEAMS 1       // k_lstm1_w8: 2 = one 1024-thread workgroup of two 64-site teams held half a step apart by phase barriers
 #endif
+#ifndef C3R_DIR_ILV
+#define C3R_DIR_ILV 1        // k_lstm1_w8 / k_lstm2_w8: grid (2, groups) — the two directions of a site group are dispatched back to back
+#endif
 #ifndef C3R_L2_W8
 #define C3R_L2_W8 1          // layer 2 through k_lstm2_w8 (two wavefronts per SIMD) instead of k_lstm_h
 #endif
@@ -711,8 +714,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
     const int j = lane & 31, hh = lane >> 5;
     const int sq = C3R_W8_MAP ? (wave >> 1) : (wave & 3);      // quarter of the gate rows (k_lstm_h's wave index)
     const bool heavy3 = C3R_W8_MAP ? !(wave & 1) : (wave < 4); // the 3-tile wavefront of its SIMD pair
-    const int dir = blockIdx.y;
-    const int site0 = blockIdx.x * WG_SITES;
+    const int dir = C3R_DIR_ILV ? blockIdx.x : blockIdx.y;
+    const int site0 = (C3R_DIR_ILV ? blockIdx.y : blockIdx.x) * WG_SITES;
     const int ns = nstride ? nstride : n;
     const size_t plane_in = (size_t)ns * NET_T * INP;
 
@@ -1237,8 +1240,8 @@ __global__ __launch_bounds__(512 * TEAMS, C3R_L1_W8_OCC) void k_lstm1_w8(const i
     const int tid = threadIdx.x & 511, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
     const int sq = wave & 3, toff = (wave >> 2) * NT;
-    const int dir = blockIdx.y;
-    const int site0 = (blockIdx.x * TEAMS + team) * WG_SITES;
+    const int dir = C3R_DIR_ILV ? blockIdx.x : blockIdx.y;
+    const int site0 = ((C3R_DIR_ILV ? blockIdx.y : blockIdx.x) * TEAMS + team) * WG_SITES;
     const size_t plane_out = (size_t)nstride * NET_T * 2 * H;
 
     for (int i = tid; i < WG_SITES * HP; i += 512) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
@@ -1933,7 +1936,7 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
         const dim3 grid1((unsigned)(ns / 128), 2);
         prof("k_lstm1", 0);
 #if C3R_L1_W8
-        const dim3 gridw = C3R_L1_TEAMS == 2 ? grid1 : grid;
+        const dim3 gridn = C3R_L1_TEAMS == 2 ? grid1 : grid, gridw = C3R_DIR_ILV ? dim3(2, gridn.x) : gridn;
         if (s.channels == C3R_CH)
             hipLaunchKernelGGL((k_lstm1_w8<C3R_CH, 0, C3R_L1_TEAMS>), gridw, dim3(512 * C3R_L1_TEAMS), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
         else
@@ -1956,7 +1959,7 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
         // layer 2 with the L4 dense layer fused in: y2 is never materialised
 #if C3R_L2_W8
         (void)y2h;
-        hipLaunchKernelGGL((k_lstm2_w8<0>), grid, dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const float *)s.d_b2, (int)n,
+        hipLaunchKernelGGL((k_lstm2_w8<0>), (C3R_DIR_ILV ? dim3(2, grid.x) : grid), dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const float *)s.d_b2, (int)n,
                            (const half8 *)s.d_w4f, s.d_a4, ns);
 #else
         hipLaunchKernelGGL((k_lstm_h<2 * NET_H1, 2 * NET_H1, NET_H2, false, LSTM_SB, 0, true, C3R_L2_PD, C3R_L2_ILV>), grid, block, 0, st, (const void *)y1h,

@@ -11,7 +11,8 @@ template <int ABL, int TEAMS = 1>
 static float run(const int32_t *x, const half8 *w, _Float16 *y, int n, int reps) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    dim3 grid((n + 64 * TEAMS - 1) / (64 * TEAMS), 2);
+    const unsigned ng = (n + 64 * TEAMS - 1) / (64 * TEAMS);
+    dim3 grid = C3R_DIR_ILV ? dim3(2, ng) : dim3(ng, 2);
     const int ns = (n + 127) / 128 * 128;
     hipLaunchKernelGGL((k_lstm1_w8<18, ABL, TEAMS>), grid, dim3(512 * TEAMS), 0, 0, x, w, y, n, ns);
     hipDeviceSynchronize();

@@ -15,7 +15,7 @@ template <int ABL>
 static float run(const _Float16 *x, const half8 *w, const float *b, int n, int reps) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    dim3 grid((n + 63) / 64, 2);
+    dim3 grid = C3R_DIR_ILV ? dim3(2, (n + 63) / 64) : dim3((n + 63) / 64, 2);      // (k_lstm2_w8 reads the direction from blockIdx.x then)
     const int ns = (n + 127) / 128 * 128;
     hipLaunchKernelGGL((k_lstm2_w8<ABL>), grid, dim3(512), 0, 0, x, w, b, n, g_w4, g_a4, ns);
     hipDeviceSynchronize();
