@@ -234,7 +234,7 @@ class Engine(object):
 
     def set_precision(self, mode):
         """'f32' (fp32 MFMA) or 'f16x3' (split-f16, fp32-equivalent; default)."""
-        self._chk(self.L.c3r_set_precision(self.h, {"f32": 0, "f16x3": 1}[mode]))
+        self._chk(self.L.c3r_set_precision(self.h, {"f32": 0, "f16x3": 1, "f16+f8": 2}[mode]))
 
     def infer(self, tensors=None, n=None, fetch=True):
         if tensors is None:

@@ -1003,7 +1003,7 @@ int c3r_load_weights(c3r_ctx *ctx, const float *blob, int64_t n_floats, int chan
 }
 
 int c3r_set_precision(c3r_ctx *ctx, int mode) {
-    if (!ctx || (mode != 0 && mode != 1)) return C3R_EINVAL;
+    if (!ctx || mode < 0 || mode > 2) return C3R_EINVAL;
     ctx->net.precision = mode;
     return C3R_OK;
 }

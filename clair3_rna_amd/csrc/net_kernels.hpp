@@ -848,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
                         acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ba), __builtin_bit_cast(half8, bb), z, 0, 0, 0);
                 }
             }
-            auto mma = [&](const half8 (&ah)[NTH], const half8 (&al)[NTH], const half8 (&bh)[SB], const half8 (&bl)[SB], bool hpart) {
+            auto mma = [&](const half8 (&ah)[NTH], const half8 (&al)[NTH], const half8 (&bh)[SB], const half8 (&bl)[SB], bool hpart, bool odd) {
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
@@ -856,6 +856,30 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
                 if (L4T && hpart) {
 #pragma unroll
                     for (int sb = 0; sb < SB; ++sb) facc[L4T ? sb : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[L4T ? NT : 0], bh[sb], facc[L4T ? sb : 0], 0, 0, 0);
+                }
+                if constexpr ((ABL & 768) != 0) {
+                    // probe (timing only, wrong numbers): both correction terms of TWO k-groups as one block-scaled MFMA on the fp8 (bit
+                    // 256) or fp6 (bit 512) pipe, K = 64 = [w_hi | w_lo] x [x_lo ; x_hi] of 32 k's, issued with every second k-group;
+                    // operand bytes (weights: f16 hi + 8-bit hi + 8-bit lo = the 4 bytes per k streamed today) are unchanged
+                    typedef int intx8 __attribute__((ext_vector_type(8)));
+                    typedef int intx4 __attribute__((ext_vector_type(4)));
+                    constexpr int FMT = (ABL & 512) ? 2 : 0;       // cbsz / blgp: 0 = fp8 e4m3, 2 = fp6 e2m3
+                    if (odd) {
+#pragma unroll
+                        for (int tt = 0; tt < NTH; ++tt) {
+                            if (tt == NT && !(L4T && hpart)) continue;
+                            const intx4 a0 = __builtin_bit_cast(intx4, al[tt]), a1 = __builtin_bit_cast(intx4, ah[tt]);
+                            const intx8 a8 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+                            for (int sb = 0; sb < SB; ++sb) {
+                                const intx4 b0 = __builtin_bit_cast(intx4, bl[sb]), b1 = __builtin_bit_cast(intx4, bh[sb]);
+                                const intx8 b8 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                                if (tt < NT) acc[tt < NT ? tt : 0][sb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[tt < NT ? tt : 0][sb], FMT, FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                                else facc[L4T ? sb : 0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, facc[L4T ? sb : 0], FMT, FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                            }
+                        }
+                    }
+                    return;
                 }
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
@@ -884,9 +908,9 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
     if constexpr ((G) < NG) {                                                                                     \
         C3R_FENCE();                                                                                              \
         if constexpr ((G) + PD < NG) { C3R_LOAD((G) + PD); }                                                      \
-        mma(ah[(G) % (PD + 1)], al[(G) % (PD + 1)], bh[(G) % (PD + 1)], bl[(G) % (PD + 1)], (G) >= NGX);          \
+        mma(ah[(G) % (PD + 1)], al[(G) % (PD + 1)], bh[(G) % (PD + 1)], bl[(G) % (PD + 1)], (G) >= NGX, ((G) & 1) != 0);  \
         if constexpr ((G) + PD < NG) {                                                                            \
-            constexpr int NMM = ((G) >= NGX ? NTH : NT) * SB * 3;                                                 \
+            constexpr int NMM = ((G) >= NGX ? NTH : NT) * SB * ((ABL & 768) ? (((G) & 1) ? 2 : 1) : 3);          \
             sched_interleave<NMM, ((G) + PD >= NGX ? NTH : NT) * 2, SB * 2>();                                    \
         }                                                                                                         \
         if constexpr ((G) == NGX - 1) {                                                                           \
@@ -953,6 +977,12 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
                         asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
                         vl[q] = (_Float16)d;
                     }
+                    if constexpr ((ABL & 768) != 0) {       // probe: keep every byte a finite fp8 number (no NaN patterns on the MX pipe)
+                        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                        uint2v a = __builtin_bit_cast(uint2v, vh), b = __builtin_bit_cast(uint2v, vl);
+                        a[0] &= 0xBFBFBFBFu; a[1] &= 0xBFBFBFBFu; b[0] &= 0xBFBFBFBFu; b[1] &= 0xBFBFBFBFu;
+                        vh = __builtin_bit_cast(half4, a); vl = __builtin_bit_cast(half4, b);
+                    }
                     *(half4 *)&hb_hi[nxt][32 * sb + j][8 * (sq * NTQ + TOFF + tt) + 4 * hh] = vh;
                     *(half4 *)&hb_lo[nxt][32 * sb + j][8 * (sq * NTQ + TOFF + tt) + 4 * hh] = vl;
                 }
@@ -996,6 +1026,339 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
     };
     if (C3R_W8_PRIO == 1 && heavy3) __builtin_amdgcn_s_setprio(1);
     if (C3R_W8_PRIO == 2 && !heavy3) __builtin_amdgcn_s_setprio(1);
+    if (heavy3) body(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::false_type{});
+    else body(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::true_type{});
+}
+
+// ------------------------------------------------------------------------------------------------
+// Precision 2: layer 2 (+ fused L4) with both correction terms on the block-scaled fp8 pipe — k_lstm2_mx.
+// k_lstm2_w8's decomposition (512 threads, 64 sites x one direction, tiles dealt 3 + 2 (+ L4) to the two wavefronts of a SIMD, x_t by
+// LDS-DMA, h double-buffered).  Per block of 32 k's the three f16 products of the split-f16 path,
+//        w_hi x_hi + w_hi x_lo + w_lo x_hi        (6 MFMAs of 32 cycles per tile and site block),
+// become two f16 MFMAs for w_hi x_hi and ONE v_mfma_scale_f32_32x32x64_f8f6f4 (64 cycles) whose K = 64 is the concatenation
+//        [ fp8(w) | fp8(w - f16(w)) ]  x  [ fp8(x - f16(x)) ; fp8(x) ]
+// (a lane's bytes 0-15 belong to the instruction's first scale block, its bytes 16-31 to the second — tools/mx_scale_probe.hip — so
+// every lane carries 16 k's of each term; lanes 0-31 supply the first term's scales, lanes 32-63 the second's).
+// Weights carry one power-of-two scale per (gate row, block, term), folded with the 2^12 of the f16 operands; activations are in
+// (-1, 1), so FIXED scales do: x 2^6 and (x - f16(x)) 2^18.  The corrections are then good to ~2^-5 of themselves, i.e. the
+// pre-activations to ~2^-16 instead of f16x3's 2^-22: max |dP| 2-3e-5 on random weights (tolerance 1e-4), and NOT robust to
+// weights of 2-3x the norm (tools/precision_probe.py, scheme f16+2f8k) — which is why c3r_load_weights measures it (precision
+// "auto") before this path is used.
+//   xin: plane 0 = f16(x) [t][k/8][site][8 halves]; plane 1, same geometry, rows (kb, term, part) = kb * 4 + term * 2 + part of 16 bytes
+//        per site: fp8 of k = 32 kb + 16 part + 0..15, term 0 = (x - f16(x)) 2^18, term 1 = x 2^6   (written by k_lstm1_w8<.., YQ>)
+//   Wp / W4p: k_lstm2_w8's f16 fragments (only the hi halves are read); Wq / Wsc, W4q / W4sc: pack_mx
+__global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict__ xin, const half8 *__restrict__ Wp, const uint32_t *__restrict__ Wq,
+                                                      const uint32_t *__restrict__ Wsc, const float *__restrict__ bp, int n,
+                                                      const half8 *__restrict__ W4p, const uint32_t *__restrict__ W4q,
+                                                      const uint32_t *__restrict__ W4sc, float *__restrict__ a4part, int nstride) {
+    constexpr int INP = 2 * NET_H1, H = NET_H2, NGX = INP / 16, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NBLK = 4 * H / 32, NTQ = NBLK / 4;
+    constexpr int SB = 2, WG_SITES = 32 * SB, KC = INP / 8, PD = 1;
+    constexpr int NKB = NG / 2, NKBX = NGX / 2, NKBH = NGH / 2, NK4 = (NKB + 3) / 4, NK4L = (NKBH + 3) / 4;
+    static_assert(NTQ == 5 && NG == 26 && NGX % 2 == 0 && NGH % 2 == 0, "3 + 2 tile split of a quarter, whole 32-k blocks");
+    typedef int intx8 __attribute__((ext_vector_type(8)));
+    typedef int intx4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) intx4 hq[2][NKBH][2][2][WG_SITES];     // fp8 of h: [buffer][kb][term][part][site] 16 bytes
+    __shared__ __attribute__((aligned(16))) _Float16 xs[2][KC][WG_SITES][8];      // [plane][row][site][16 bytes]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int sq = wave & 3;                     // quarter of the gate rows
+    const bool heavy3 = wave < 4;                // the 3-tile wavefront of its SIMD pair (waves w and w + 4 share a SIMD)
+    const int dir = C3R_DIR_ILV ? blockIdx.x : blockIdx.y;
+    const int site0 = (C3R_DIR_ILV ? blockIdx.y : blockIdx.x) * WG_SITES;
+    const int ns = nstride ? nstride : n;
+    const size_t plane_in = (size_t)ns * NET_T * INP;
+
+    for (int i = tid; i < WG_SITES * HP; i += 512) (&hb_hi[0][0][0])[i] = (_Float16)0.f;
+    for (int i = tid; i < NKBH * 2 * 2 * WG_SITES; i += 512) (&hq[0][0][0][0][0])[i] = intx4{0, 0, 0, 0};
+
+    int xsite = site0 + lane;
+    if (xsite >= n) xsite = n - 1;
+    auto dma_x = [&](int tt_) {          // 64 rows of 1 KiB, eight per wavefront (see k_lstm2_w8)
+        typedef const _Float16 __attribute__((address_space(1))) *gp_t;
+        typedef _Float16 __attribute__((address_space(3))) *lp_t;
+#pragma unroll
+        for (int r = 0; r < 2 * KC / 8; ++r) {
+            const int row = wave * (2 * KC / 8) + r, pl = row / KC, kc = row % KC;
+            const _Float16 *src = xin + (size_t)pl * plane_in + (((size_t)tt_ * KC + kc) * ns + xsite) * 8;
+            __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)&xs[pl][kc][0][0], 16, 0, 0);
+        }
+    };
+    dma_x(dir ? NET_T - 1 : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto body = [&](auto ntc, auto toffc, auto l4c) {
+        constexpr int NT = decltype(ntc)::value, TOFF = decltype(toffc)::value;
+        constexpr bool L4T = decltype(l4c)::value;
+        constexpr int NTH = NT + (L4T ? 1 : 0);
+        const half8 *wl = Wp + ((size_t)(dir * 4 + sq) * NG) * NTQ * 2 * 64 + (size_t)TOFF * 2 * 64 + lane;
+        const intx8 *wq = reinterpret_cast<const intx8 *>(Wq) + ((size_t)(dir * 4 + sq) * NKB * NTQ + TOFF) * 64 + lane;
+        const uint32_t *wsc = Wsc + ((size_t)(dir * 4 + sq) * NK4 * NTQ + TOFF) * 64 + lane;
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        unsigned bias_hl[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const float bv = WSCALE * bp[((size_t)dir * NBLK + sq * NTQ + TOFF + tt) * 32 + j];
+            half2v hl;
+            hl[0] = (_Float16)bv;
+            hl[1] = (_Float16)(bv - (float)hl[0]);
+            bias_hl[tt] = hh == 0 ? __builtin_bit_cast(unsigned, hl) : 0u;
+        }
+        const half2v one2 = {(_Float16)1.f, (_Float16)1.f};
+        const unsigned ones_b = hh == 0 ? __builtin_bit_cast(unsigned, one2) : 0u;
+        const int sbc = hh ? 121 : 109;          // E8M0 scales of the activation bytes: x 2^6 (lanes 32-63), (x - f16(x)) 2^18 (lanes 0-31)
+        float cst[NT][SB][4];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cst[tt][sb][q] = 0.f;
+        floatx16 facc[L4T ? SB : 1];
+#pragma unroll
+        for (int sb = 0; sb < (L4T ? SB : 1); ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) facc[sb][r] = 0.f;
+
+        typedef const half8 __attribute__((address_space(1))) *gptr_t;
+        typedef const intx8 __attribute__((address_space(1))) *g8_t;
+        typedef const uint32_t __attribute__((address_space(1))) *gs_t;
+        for (int step = 0; step < NET_T; ++step) {
+            const int t = dir ? NET_T - 1 - step : step;
+            const int tprev = step ? (dir ? t + 1 : t - 1) : t;
+            const int cur = step & 1, nxt = cur ^ 1;
+
+            half8 ah[PD + 1][NTH], bh[PD + 1][SB];
+            intx8 a8[NTH], b8[SB];
+            int sc[NTH];
+            // operands of k-group G: the f16 hi fragments; with an odd G also the fp8 fragments (and every fourth block the scale words) of
+            // the 32-k block G / 2, consumed by the block-scaled MFMA that follows group G's f16 MFMAs
+            auto load = [&](auto gc, half8 (&ahr)[NTH], half8 (&bhr)[SB]) {
+                constexpr int G = decltype(gc)::value;
+                uintptr_t wbase = (uintptr_t)wl;                 // (address laundering, address_space(1): see k_lstm_h::ldw)
+                asm volatile("" : "+v"(wbase));
+                const gptr_t wg = (gptr_t)wbase + (size_t)G * NTQ * 2 * 64;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) ahr[tt] = wg[(tt * 2 + 0) * 64];
+                if constexpr (L4T && G >= NGX) {
+                    uintptr_t w4base = (uintptr_t)(W4p + (((size_t)(dir * NET_T + tprev) * 4 + sq) * NGH) * 2 * 64 + lane);
+                    asm volatile("" : "+v"(w4base));
+                    ahr[NT] = ((gptr_t)w4base)[(size_t)(G - NGX) * 2 * 64];
+                }
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+                    if constexpr (G < NGX) bhr[sb] = *(const half8 *)&xs[0][2 * G + hh][32 * sb + j][0];
+                    else bhr[sb] = *(const half8 *)&hb_hi[cur][32 * sb + j][16 * (G - NGX) + 8 * hh];
+                }
+                if constexpr ((G & 1) != 0) {
+                    constexpr int KB = G / 2;
+                    uintptr_t qbase = (uintptr_t)wq;
+                    asm volatile("" : "+v"(qbase));
+                    const g8_t qg = (g8_t)qbase + (size_t)KB * NTQ * 64;
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) a8[tt] = qg[tt * 64];
+                    if constexpr (KB % 4 == 0) {
+                        uintptr_t sbase = (uintptr_t)wsc;
+                        asm volatile("" : "+v"(sbase));
+                        const gs_t sg = (gs_t)sbase + (size_t)(KB / 4) * NTQ * 64;
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) sc[tt] = (int)sg[tt * 64];
+                    }
+                    if constexpr (L4T && KB >= NKBX) {
+                        constexpr int KL = KB - NKBX;
+                        uintptr_t q4 = (uintptr_t)(reinterpret_cast<const intx8 *>(W4q) + ((size_t)(dir * NET_T + tprev) * 4 + sq) * NKBH * 64 + lane);
+                        asm volatile("" : "+v"(q4));
+                        a8[L4T ? NT : 0] = ((g8_t)q4)[(size_t)KL * 64];
+                        if constexpr (KL % 4 == 0) {
+                            uintptr_t s4 = (uintptr_t)(W4sc + ((size_t)(dir * NET_T + tprev) * 4 + sq) * NK4L * 64 + lane);
+                            asm volatile("" : "+v"(s4));
+                            sc[L4T ? NT : 0] = (int)((gs_t)s4)[(size_t)(KL / 4) * 64];
+                        }
+                    }
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) {
+                        intx4 p0, p1;
+                        if constexpr (KB < NKBX) {
+                            p0 = *(const intx4 *)&xs[1][KB * 4 + 0 + hh][32 * sb + j][0];      // term 0, k = 16 hh + 0..15 of the block
+                            p1 = *(const intx4 *)&xs[1][KB * 4 + 2 + hh][32 * sb + j][0];      // term 1, the same k's
+                        } else {
+                            p0 = hq[cur][KB - NKBX][0][hh][32 * sb + j];
+                            p1 = hq[cur][KB - NKBX][1][hh][32 * sb + j];
+                        }
+                        b8[sb] = intx8{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                    }
+                }
+            };
+
+            floatx16 acc[NT][SB];
+            {   // bias (see k_lstm2_w8)
+                floatx16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+                const uint4v bb = {ones_b, 0u, 0u, 0u};
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const uint4v ba = {bias_hl[tt], 0u, 0u, 0u};
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb)
+                        acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ba), __builtin_bit_cast(half8, bb), z, 0, 0, 0);
+                }
+            }
+            auto mma = [&](auto gc, const half8 (&ahr)[NTH], const half8 (&bhr)[SB]) {
+                constexpr int G = decltype(gc)::value;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahr[tt], bhr[sb], acc[tt][sb], 0, 0, 0);
+                if constexpr (L4T && G >= NGX) {
+#pragma unroll
+                    for (int sb = 0; sb < SB; ++sb) facc[L4T ? sb : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahr[L4T ? NT : 0], bhr[sb], facc[L4T ? sb : 0], 0, 0, 0);
+                }
+                if constexpr ((G & 1) != 0) {
+                    constexpr int KB = G / 2;
+#ifdef C3R_MX_DBG
+                    constexpr bool skip_gates = ((C3R_MX_DBG & 4) && KB < NKBX) || ((C3R_MX_DBG & 8) && KB >= NKBX);
+#else
+                    constexpr bool skip_gates = false;
+#endif
+                    if constexpr (!skip_gates)
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                        for (int sb = 0; sb < SB; ++sb)
+                            acc[tt][sb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[tt], b8[sb], acc[tt][sb], 0, 0, KB % 4, sc[tt], 0, sbc);
+#ifdef C3R_MX_DBG
+                    if constexpr (!(C3R_MX_DBG & 16) && !((C3R_MX_DBG & 32) && (KB - NKBX) == ((C3R_MX_DBG >> 8) & 7)))
+#endif
+                    if constexpr (L4T && KB >= NKBX) {
+#pragma unroll
+                        for (int sb = 0; sb < SB; ++sb)
+                            facc[L4T ? sb : 0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[L4T ? NT : 0], b8[sb], facc[L4T ? sb : 0], 0, 0, (KB - NKBX) % 4,
+                                                                                                 sc[L4T ? NT : 0], 0, sbc);
+                    }
+                }
+            };
+#define C3R_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define C3R_STEP(G)                                                                                              \
+    if constexpr ((G) < NG) {                                                                                     \
+        C3R_FENCE();                                                                                              \
+        if constexpr ((G) + PD < NG) { load(std::integral_constant<int, (G) + PD>{}, ah[((G) + PD) % (PD + 1)], bh[((G) + PD) % (PD + 1)]); } \
+        mma(std::integral_constant<int, (G)>{}, ah[(G) % (PD + 1)], bh[(G) % (PD + 1)]);                          \
+        if constexpr ((G) + PD < NG) {                                                                            \
+            constexpr int NMM = ((G) >= NGX ? NTH : NT) * SB * (((G) & 1) ? 2 : 1);                               \
+            constexpr int NTL = ((G) + PD >= NGX ? NTH : NT);                                                     \
+            sched_interleave<NMM, NTL * ((((G) + PD) & 1) ? 3 : 1), SB * ((((G) + PD) & 1) ? 3 : 1)>();           \
+        }                                                                                                         \
+        if constexpr ((G) == NGX - 1) {                                                                           \
+            C3R_FENCE();                                                                                          \
+            __syncthreads();     /* every wavefront is done with x_t */                                           \
+        }                                                                                                         \
+    }
+            load(std::integral_constant<int, 0>{}, ah[0], bh[0]);
+            C3R_STEP(0) C3R_STEP(1) C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
+            C3R_STEP(10) C3R_STEP(11) C3R_STEP(12) C3R_STEP(13) C3R_STEP(14) C3R_STEP(15) C3R_STEP(16) C3R_STEP(17) C3R_STEP(18)
+            C3R_STEP(19) C3R_STEP(20) C3R_STEP(21) C3R_STEP(22) C3R_STEP(23) C3R_STEP(24) C3R_STEP(25)
+            C3R_FENCE();
+#undef C3R_STEP
+#undef C3R_FENCE
+            if (step + 1 < NET_T) dma_x(dir ? NET_T - 2 - step : step + 1);      // lands during the cell update
+            // ---- lane-local cell update (k_lstm2_w8's), h_t to LDS as f16 plus the two fp8 bytes per unit
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int NU = 4 * SB;
+                constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
+                float cq[NU], ei[NU], ef[NU], eg[NU], eo[NU], hval[NU];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) cq[u] = cst[tt][u >> 2][u & 3];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ei[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 0]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 1]);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(K2 * acc[tt][u >> 2][4 * (u & 3) + 2]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) eo[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 3]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ei[u] = gate_frac(ei[u], eg[u]);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_rcpf(1.0f + ef[u]);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) cq[u] = fmaf(ef[u], cq[u], ei[u]);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[u]), 1e18f);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) hval[u] = gate_frac(eo[u], eg[u]);
+                const int T = sq * NTQ + TOFF + tt;          // tile of the direction: units 8 T + 4 hh + q
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cst[tt][sb][q] = cq[4 * sb + q];
+                    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                    half4 vh;
+                    float lo[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        vh[q] = (_Float16)hval[4 * sb + q];
+                        float d = hval[4 * sb + q] - (float)vh[q];
+                        asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
+                        lo[q] = d * 262144.f;
+                    }
+                    *(half4 *)&hb_hi[nxt][32 * sb + j][8 * T + 4 * hh] = vh;
+                    int w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], 0, false);
+                    w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], w_lo, true);
+                    int w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[4 * sb + 0] * 64.f, hval[4 * sb + 1] * 64.f, 0, false);
+                    w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[4 * sb + 2] * 64.f, hval[4 * sb + 3] * 64.f, w_hi, true);
+                    // k = 8 T + 4 hh + q of the direction's 160: block T / 4, 16-byte part (T % 4) / 2, bytes 8 (T % 2) + 4 hh + q
+                    reinterpret_cast<int *>(&hq[nxt][T >> 2][0][(T & 3) >> 1][32 * sb + j])[2 * (T & 1) + hh] = w_lo;
+                    reinterpret_cast<int *>(&hq[nxt][T >> 2][1][(T & 3) >> 1][32 * sb + j])[2 * (T & 1) + hh] = w_hi;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // x_{t+1} has landed (LDS-DMA is tracked by vmcnt)
+            __syncthreads();                                       // h_t complete; everyone is done with h_{t-1}
+        }
+        if constexpr (L4T) {
+            // ---- the last step's h (buffer NET_T & 1) still owes its L4 contribution
+            const int tl = dir ? 0 : NET_T - 1, hbuf = NET_T & 1;
+            const half8 *w4 = W4p + (((size_t)(dir * NET_T + tl) * 4 + sq) * NGH) * 2 * 64 + lane;
+            const intx8 *q4 = reinterpret_cast<const intx8 *>(W4q) + ((size_t)(dir * NET_T + tl) * 4 + sq) * NKBH * 64 + lane;
+            const uint32_t *s4 = W4sc + ((size_t)(dir * NET_T + tl) * 4 + sq) * NK4L * 64 + lane;
+            static_for<0, NKBH>([&](auto pc) {
+                constexpr int P = decltype(pc)::value;
+                const half8 a0 = w4[(size_t)((2 * P) * 2) * 64], a1 = w4[(size_t)((2 * P + 1) * 2) * 64];
+                const intx8 aq = q4[(size_t)P * 64];
+                const int scl = (int)s4[(size_t)(P / 4) * 64];
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+                    const half8 b0 = *(const half8 *)&hb_hi[hbuf][32 * sb + j][16 * (2 * P) + 8 * hh];
+                    const half8 b1 = *(const half8 *)&hb_hi[hbuf][32 * sb + j][16 * (2 * P + 1) + 8 * hh];
+                    const intx4 p0 = hq[hbuf][P][0][hh][32 * sb + j], p1 = hq[hbuf][P][1][hh][32 * sb + j];
+                    const intx8 bq = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+                    facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, facc[sb], 0, 0, 0);
+                    facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, facc[sb], 0, 0, 0);
+#ifdef C3R_MX_DBG
+                    if (!(C3R_MX_DBG & 16) && !((C3R_MX_DBG & 32) && P == ((C3R_MX_DBG >> 8) & 7)) && !(C3R_MX_DBG & 64))
+#endif
+                    facc[sb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, bq, facc[sb], 0, 0, P % 4, scl, 0, sbc);
+                }
+            });
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                const int sidx = site0 + 32 * sb + j;
+                if (sidx < n) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v = make_float4(facc[sb][4 * q] * WUNSCALE, facc[sb][4 * q + 1] * WUNSCALE, facc[sb][4 * q + 2] * WUNSCALE,
+                                               facc[sb][4 * q + 3] * WUNSCALE);
+                        *(float4 *)(a4part + ((size_t)sidx * 2 + dir) * NET_L4 + 32 * sq + 8 * q + 4 * hh) = v;
+                    }
+                }
+            }
+        }
+    };
     if (heavy3) body(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::false_type{});
     else body(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::true_type{});
 }
@@ -1221,7 +1584,8 @@ __global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict
 //     What is left is the cell update itself: without its 5 exp2 + 3 rcp per unit the kernel takes 4.9 ms at a 0.33 GHz higher
 //     clock (tools/lstm_probe_l1w8.hip).
 // Bias rides on input slot CIN (see k_lstm1_skew); Wp is k_lstm_h's layout ([dir][quarter][g][tile(4)][hi|lo][lane]).
-template <int CIN, int ABL = 0, int TEAMS = 1>
+// YQ: the second y1 plane holds the fp8 bytes precision 2's layer 2 wants (k_lstm2_mx) instead of the f16 lo halves.
+template <int CIN, int ABL = 0, int TEAMS = 1, bool YQ = false>
 __global__ __launch_bounds__(512 * TEAMS, C3R_L1_W8_OCC) void k_lstm1_w8(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp,
                                                       _Float16 *__restrict__ y, int n, int nstride) {
     constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NTQ = 4, NT = 2, SB = 2, WG_SITES = 64, HV = H / 8, PD = C3R_L1_W8_PD;
@@ -1417,7 +1781,27 @@ __global__ __launch_bounds__(512 * TEAMS, C3R_L1_W8_OCC) void k_lstm1_w8(const i
                 if (!(ABL & 4)) {
                     _Float16 *yp = y + ((size_t)t * (2 * HV) + dir * HV + blk) * nstride * 8 + yoff[sb];
                     *(half4 *)yp = vh;
-                    *(half4 *)(yp + plane_out) = vl;
+                    if constexpr (!YQ) {
+                        *(half4 *)(yp + plane_out) = vl;
+                    } else {
+                        // units U = dir * 128 + 8 blk + 4 hh + q of y1's 256: 32-k block U / 32, 16-byte part (U % 32) / 16, bytes U % 16;
+                        // plane-1 row = block * 4 + term * 2 + part (term 0: (h - f16(h)) 2^18, term 1: h 2^6)
+                        float lo[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { float d = hval[4 * sb + q] - (float)vh[q]; asm volatile("" : "+v"(d)); lo[q] = d * 262144.f; }
+                        int w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], 0, false);
+                        w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], w_lo, true);
+                        int w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[4 * sb + 0] * 64.f, hval[4 * sb + 1] * 64.f, 0, false);
+                        w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[4 * sb + 2] * 64.f, hval[4 * sb + 3] * 64.f, w_hi, true);
+                        const int row0 = (dir * 4 + (blk >> 2)) * 4 + ((blk & 3) >> 1);
+                        _Float16 *qp = y + plane_out + ((size_t)t * (2 * HV) + row0) * nstride * 8 + (uint32_t)(site0 + 32 * sb + j) * 8 + 4 * (blk & 1) + 2 * hh;
+#ifdef C3R_MX_DBG
+                        if (C3R_MX_DBG & 1) w_lo = 0;
+                        if (C3R_MX_DBG & 2) w_hi = 0;
+#endif
+                        *(int *)qp = w_lo;
+                        *(int *)(qp + (size_t)2 * nstride * 8) = w_hi;
+                    }
                 }
             }
         }
@@ -1626,7 +2010,10 @@ struct NetState {
     float *d_w5 = nullptr, *d_b5 = nullptr, *d_wo = nullptr, *d_bo = nullptr;
     float4 *d_w5p = nullptr, *d_wcp = nullptr;          // heads in MFMA fragment order (k_heads_mfma)
     half8 *d_w1h = nullptr, *d_w2h = nullptr, *d_w4h = nullptr, *d_w4f = nullptr;   // d_w4f: L4 packed per (dir, t) for the fused path   // split-f16 packed weights (hi/lo, x 2^12)
-    int precision = 1;            // 0 = fp32 MFMA, 1 = split-f16 (f16x3, fp32-equivalent)
+    // precision 2 (MX corrections): fp8 (e4m3) fragments of w (lanes 0-31) and w - f16(w) (lanes 32-63) per block of 32 k, 32 bytes per
+    // lane, and their E8M0 block scales, four blocks per dword: layer 1 (recurrent part only), layer 2, fused L4
+    uint32_t *d_w1q = nullptr, *d_w1s = nullptr, *d_w2q = nullptr, *d_w2s = nullptr, *d_w4q = nullptr, *d_w4s = nullptr;
+    int precision = 1;            // 0 = fp32 MFMA, 1 = split-f16 (f16x3, fp32-equivalent), 2 = f16 main term + both corrections on the MX fp8 pipe
     float *d_y1 = nullptr, *d_y2 = nullptr, *d_a4 = nullptr, *d_probs = nullptr;
     int64_t cap_probs = 0;           // sites d_probs holds (the whole batch); cap_sites bounds one network slice
     int64_t cap_sites = 0;
@@ -1644,7 +2031,7 @@ inline int64_t net_weight_count(int C) {
 
 inline void net_free(NetState &s) {
     void *ptrs[] = {s.d_w1, s.d_b1, s.d_w2, s.d_b2, s.d_w4, s.d_b4, s.d_w5, s.d_b5, s.d_wo, s.d_bo, s.d_y1, s.d_y2, s.d_a4, s.d_probs,
-                    s.d_w1h, s.d_w2h, s.d_w4h, s.d_w4f, s.d_w5p, s.d_wcp};
+                    s.d_w1h, s.d_w2h, s.d_w4h, s.d_w4f, s.d_w5p, s.d_wcp, s.d_w1q, s.d_w1s, s.d_w2q, s.d_w2s, s.d_w4q, s.d_w4s};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     s = NetState();
 }
@@ -1709,6 +2096,58 @@ inline void pack_lstm_dir_h(const float *Kin, int cin, int inp, const float *R, 
         }
 }
 
+// ---- precision 2: the two correction terms on the block-scaled fp8 pipe (v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 = two terms x 32 k).
+// float -> OCP e4m3fn, round to nearest even, saturating (|v| < 256 by construction here)
+inline uint8_t f2e4m3(float v) {
+    const uint8_t sign = std::signbit(v) ? 0x80 : 0;
+    float a = std::fabs(v);
+    if (!(a == a)) return 0x7f;
+    if (a >= 464.f) return (uint8_t)(sign | 0x7e);
+    if (a < 0.015625f) {                                   // subnormal: multiples of 2^-9
+        const int q = (int)std::nearbyint(a * 512.f);
+        return (uint8_t)(sign | q);                        // q == 8 is the smallest normal (0x08)
+    }
+    int e;
+    const float fr = std::frexp(a, &e);                    // a = fr * 2^e, fr in [0.5, 1)
+    int q = (int)std::nearbyint((fr * 2.f - 1.f) * 8.f), ex = e - 1;
+    if (q == 8) { q = 0; ++ex; }
+    int code = ((ex + 7) << 3) | q;
+    if (code > 0x7e) code = 0x7e;
+    return (uint8_t)(sign | code);
+}
+// One fragment set: rows = NBLK tiles of 32 gate rows (row r of tile blk <-> column col(blk, r) of W), k = k0 .. k0 + 32 * nkb.
+// K order of the instruction (tools/mx_scale_probe.hip): a lane (r, g = lane / 32) holds k = 16 g + 0..15 of the FIRST scale block
+// in its bytes 0-15 and k = 32 + 16 g + 0..15, the second scale block, in its bytes 16-31; the scale byte of lane r covers the first
+// block of row r, that of lane 32 + r the second.  First block = term 0 (w), second = term 1 (w - f16(w)):
+//   q: [quarter][kb][tile][64 lanes][32 bytes]   lane = 32 g + r: bytes 0-15 = term 0, bytes 16-31 = term 1, both of k = k0 + 32 kb + 16 g + 0..15
+//   sc: [quarter][kb / 4][tile][64 lanes] u32    lane = 32 term + r, byte kb % 4 = E8M0 scale: 2^(sc - 127) * byte = 2^12 * value
+template <class WF>
+inline void pack_mx(WF &&w /* (k, blk, r) -> weight */, int NBLK, int NT, int k0, int nkb, std::vector<uint32_t> &q, std::vector<uint32_t> &sc) {
+    const int nk4 = (nkb + 3) / 4;
+    q.assign((size_t)NBLK * nkb * 64 * 8, 0u);
+    sc.assign((size_t)NBLK * nk4 * 64, 0x7f7f7f7fu);
+    uint8_t *qb = reinterpret_cast<uint8_t *>(q.data());
+    uint8_t *sb = reinterpret_cast<uint8_t *>(sc.data());
+    for (int blk = 0; blk < NBLK; ++blk)
+        for (int r = 0; r < 32; ++r)
+            for (int kb = 0; kb < nkb; ++kb)
+                for (int term = 0; term < 2; ++term) {
+                    float v[32], m = 0.f;
+                    for (int b = 0; b < 32; ++b) {
+                        const float x = w(k0 + 32 * kb + b, blk, r);
+                        v[b] = term ? x - h2f(f2h(WSCALE * x)) * WUNSCALE : x;       // (the f16 main term carries f16(2^12 w))
+                        m = std::max(m, std::fabs(v[b]));
+                    }
+                    int e = 0;                                                   // block scale 2^e: the block's maximum lands in [128, 256)
+                    if (m > 0.f) { int ex; (void)std::frexp(m, &ex); e = 8 - ex; }
+                    e = std::min(e, 139);                                        // (E8M0 byte = 139 - e >= 0)
+                    const size_t fo = (((size_t)(blk / NT) * nkb + kb) * NT + (blk % NT)) * 64;
+                    for (int b = 0; b < 32; ++b) qb[(fo + 32 * (b / 16) + r) * 32 + 16 * term + (b % 16)] = f2e4m3(std::ldexp(v[b], e));
+                    const size_t so = ((((size_t)(blk / NT) * nk4 + kb / 4) * NT + (blk % NT)) * 64 + 32 * term + r) * 4 + (kb % 4);
+                    sb[so] = (uint8_t)std::max(0, 127 + (int)WSCALE_LOG2 - e);
+                }
+}
+
 // Pack one LSTM direction: Wcat = [K_in (padded to INP rows) ; R] of shape [INP+H][4H] (Keras: [in][4H],
 // gate-major columns i|f|c|o) into MFMA fragment order [blk][g][lane][s] and bias into [blk][hh][q][m].
 inline void pack_lstm_dir(const float *Kin, int cin, int inp, const float *R, const float *b, int H,
@@ -1758,11 +2197,22 @@ inline int net_upload_h(half8 *&dst, const std::vector<uint16_t> &src, hipStream
     return C3R_OK;
 }
 
+inline int net_upload_u(uint32_t *&dst, const std::vector<uint32_t> &src, hipStream_t st, std::string &err) {
+    if (dst) { (void)hipFree(dst); dst = nullptr; }
+    NET_HIP(hipMalloc((void **)&dst, src.size() * 4));
+    NET_HIP(hipMemcpyAsync(dst, src.data(), src.size() * 4, hipMemcpyHostToDevice, st));
+    NET_HIP(hipStreamSynchronize(st));
+    return C3R_OK;
+}
+
 inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::string &err) {
     const float *q = blob;
     const int inp1 = 32;   // padded to an even number of 8-wide k-groups
     std::vector<float> w1, b1, w2, b2, tw, tb;
     std::vector<uint16_t> w1h, w2h, th;
+    std::vector<uint32_t> w1q, w1s, w2q, w2s, tq, ts;
+    // gate row r of tile blk <-> Keras column (pack_lstm_dir_h): r = 8 q + 4 hh + m -> unit 8 blk + 4 hh + q, gate m
+    auto gate_col = [](int blk, int r, int H) { const int qq = r >> 3, hh = (r >> 2) & 1, m = r & 3; return m * H + 8 * blk + 4 * hh + qq; };
     for (int d = 0; d < 2; ++d) {
         const float *Kin = q; q += (size_t)C * 4 * NET_H1;
         const float *R = q; q += (size_t)NET_H1 * 4 * NET_H1;
@@ -1771,6 +2221,9 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
         w1.insert(w1.end(), tw.begin(), tw.end()); b1.insert(b1.end(), tb.begin(), tb.end());
         pack_lstm_dir_h(Kin, C, inp1, R, NET_H1, th, (C3R_L1_SKEW || C3R_L1_W8) ? b : nullptr);
         w1h.insert(w1h.end(), th.begin(), th.end());
+        // (layer 1: the recurrent part only — the integer pileup counts are exact in f16 but not in fp8)
+        pack_mx([&](int k, int blk, int r) { return R[(size_t)k * 4 * NET_H1 + gate_col(blk, r, NET_H1)]; }, 4 * NET_H1 / 32, NET_H1 / 32, 0, NET_H1 / 32, tq, ts);
+        w1q.insert(w1q.end(), tq.begin(), tq.end()); w1s.insert(w1s.end(), ts.begin(), ts.end());
     }
     for (int d = 0; d < 2; ++d) {
         const float *Kin = q; q += (size_t)2 * NET_H1 * 4 * NET_H2;
@@ -1780,6 +2233,11 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
         w2.insert(w2.end(), tw.begin(), tw.end()); b2.insert(b2.end(), tb.begin(), tb.end());
         pack_lstm_dir_h(Kin, 2 * NET_H1, 2 * NET_H1, R, NET_H2, th);
         w2h.insert(w2h.end(), th.begin(), th.end());
+        pack_mx([&](int k, int blk, int r) {
+                    const int col = gate_col(blk, r, NET_H2);
+                    return k < 2 * NET_H1 ? Kin[(size_t)k * 4 * NET_H2 + col] : R[(size_t)(k - 2 * NET_H1) * 4 * NET_H2 + col];
+                }, 4 * NET_H2 / 32, 4 * NET_H2 / 128, 0, (2 * NET_H1 + NET_H2) / 32, tq, ts);
+        w2q.insert(w2q.end(), tq.begin(), tq.end()); w2s.insert(w2s.end(), ts.begin(), ts.end());
     }
     const float *W4 = q; q += (size_t)NET_FLAT * NET_L4;
     const float *b4 = q; q += NET_L4;
@@ -1828,6 +2286,13 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
                             w4f[(base + lane) * 8 + e] = hi;
                             w4f[(base + 64 + lane) * 8 + e] = lo;
                         }
+    // fused L4 on the MX pipe: per (dir, t) one fragment set [quarter(4)][kb(5)][lane][32 B] (one tile per quarter)
+    std::vector<uint32_t> w4q, w4s;
+    for (int d = 0; d < 2; ++d)
+        for (int t = 0; t < NET_T; ++t) {
+            pack_mx([&](int k, int blk, int r) { return W4[((size_t)t * 2 * NET_H2 + (size_t)d * NET_H2 + k) * NET_L4 + 32 * blk + r]; }, 4, 1, 0, NET_H2 / 32, tq, ts);
+            w4q.insert(w4q.end(), tq.begin(), tq.end()); w4s.insert(w4s.end(), ts.begin(), ts.end());
+        }
     std::vector<float> vb4(b4, b4 + NET_L4);
     std::vector<float> w5((size_t)128 * 256), b5(256), wo((size_t)128 * 24), bo(24);
     for (int k = 0; k < 128; ++k)
@@ -1863,7 +2328,9 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
         (rc = net_upload(s.d_b2, b2, st, err)) || (rc = net_upload(s.d_w4, w4, st, err)) || (rc = net_upload(s.d_b4, vb4, st, err)) ||
         (rc = net_upload(s.d_w5, w5, st, err)) || (rc = net_upload(s.d_b5, b5, st, err)) || (rc = net_upload(s.d_wo, wo, st, err)) ||
         (rc = net_upload(s.d_bo, bo, st, err)) || (rc = net_upload_h(s.d_w1h, w1h, st, err)) || (rc = net_upload_h(s.d_w2h, w2h, st, err)) ||
-        (rc = net_upload_h(s.d_w4h, w4h, st, err)) || (rc = net_upload_h(s.d_w4f, w4f, st, err)))
+        (rc = net_upload_h(s.d_w4h, w4h, st, err)) || (rc = net_upload_h(s.d_w4f, w4f, st, err)) ||
+        (rc = net_upload_u(s.d_w1q, w1q, st, err)) || (rc = net_upload_u(s.d_w1s, w1s, st, err)) || (rc = net_upload_u(s.d_w2q, w2q, st, err)) ||
+        (rc = net_upload_u(s.d_w2s, w2s, st, err)) || (rc = net_upload_u(s.d_w4q, w4q, st, err)) || (rc = net_upload_u(s.d_w4s, w4s, st, err)))
         return rc;
     s.channels = C; s.inp1 = inp1; s.loaded = true;
     return C3R_OK;
@@ -1877,7 +2344,7 @@ constexpr int64_t NET_SLICE = 262144;
 inline int net_reserve(NetState &s, int64_t n_total, hipStream_t st, std::string &err) {
     const int64_t n = std::min(n_total, NET_SLICE);
     const int64_t need = (n + 127) / 128 * 128;    // the y1 planes are stored with the site stride rounded up to 128
-    const bool want_y2 = s.precision != 1;         // split-f16 fuses L4 into layer 2: y2 (42 KB per site) is never materialised
+    const bool want_y2 = s.precision == 0;         // split-f16 fuses L4 into layer 2: y2 (42 KB per site) is never materialised
     if (n_total > s.cap_probs) {
         NET_HIP(hipStreamSynchronize(st));
         if (s.d_probs) { (void)hipFree(s.d_probs); s.d_probs = nullptr; }
@@ -1927,7 +2394,24 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
     const int nb = (int)((n + NET_SITES - 1) / NET_SITES);
     const dim3 grid((unsigned)((n + LSTM_SITES - 1) / LSTM_SITES), 2), block(256);
     int heads_parts = 1;
-    if (s.precision == 1) {
+    if (s.precision == 2) {
+        // f16 main term + both corrections on the block-scaled fp8 pipe (k_lstm2_mx): y1 = f16 plane + fp8 plane of the same geometry
+        _Float16 *y1h = (_Float16 *)s.d_y1;
+        const int ns = (int)((n + 127) / 128 * 128);
+        const dim3 g2(2, grid.x);
+        static_assert(C3R_DIR_ILV == 1, "the precision-2 kernels are launched on the (2, groups) grid");
+        prof("k_lstm1", 0);
+        if (s.channels == C3R_CH)
+            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH, 0, 1, true>), g2, dim3(512), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+        else
+            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH_PHASED, 0, 1, true>), g2, dim3(512), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+        prof("k_lstm1", 1);
+        prof("k_lstm2", 0);
+        hipLaunchKernelGGL(k_lstm2_mx, g2, dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const uint32_t *)s.d_w2q, (const uint32_t *)s.d_w2s,
+                           (const float *)s.d_b2, (int)n, (const half8 *)s.d_w4f, (const uint32_t *)s.d_w4q, (const uint32_t *)s.d_w4s, s.d_a4, ns);
+        prof("k_lstm2", 1);
+        heads_parts = 2;
+    } else if (s.precision == 1) {
         // split-f16 path: y1 / y2 hold hi and lo f16 planes (same bytes as one fp32 plane)
         _Float16 *y1h = (_Float16 *)s.d_y1, *y2h = (_Float16 *)s.d_y2;
         // layer 1: two 64-site groups per workgroup, phases skewed (k_lstm1_skew); the y1 planes use a site stride padded

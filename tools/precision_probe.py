@@ -9,6 +9,8 @@ same for every scheme and is measured separately by the GPU tests).
   f16x1   w_hi*x_hi
   f16+2f8 w_hi*x_hi + q8(w)*q8(x_lo) + q8(w_lo)*q8(x)           (corrections on the MX fp8 pipe, 2x the f16 rate)
   f16+2f6 the same with e2m3 fp6 and power-of-two scales per 32-k block (4x the f16 rate)
+  f16+2f8k the fp8 scheme exactly as a kernel would run it: e4m3 corrections with FIXED activation scales (h in (-1,1): x * 2^6,
+          x_lo * 2^18), one power-of-two weight scale per (gate row, block of 32 k), layer 1's integer inputs on two f16 terms
 
 usage: python tools/precision_probe.py [n_sites] [weight_gain]
 """
@@ -75,6 +77,15 @@ class Scheme:
         if self.name == "f16+2f6":
             d["w8"] = q6_block(W, 0)
             d["wl8"] = q6_block(W - wh, 0)
+        if self.name.startswith("f16+2f8k"):
+            def q8_block(v):          # e4m3, one power-of-two scale per (column, block of 32 rows): block max lands in [128, 256)
+                K = v.shape[0]; pad = (-K) % 32
+                b = torch.nn.functional.pad(v, (0, 0, 0, pad)).reshape(-1, 32, v.shape[1])
+                m = b.abs().amax(1, keepdim=True).clamp_min(1e-300)
+                sc = torch.exp2(torch.floor(torch.log2(256.0 / m)))
+                return ((b * sc).clamp(-448, 448).to(torch.float8_e4m3fn).to(D) / sc).reshape(-1, v.shape[1])[:K]
+            d["w8"] = q8_block(W)
+            d["wl8"] = q8_block(W - wh)
         if self.name.startswith("f16x3wl8"):
             # f16x3 with the weights' lo halves stored as 8-bit fixed point: one power-of-two scale per output column (= gate row of the
             # transposed GEMM) "r", or per (column, block of 16 k) "b"
@@ -112,9 +123,28 @@ class Scheme:
             d["wl8"] = torch.round((W - wh) * sw * 4096.0).clamp(-127, 127) / (sw * 4096.0)
         return d
 
-    def mm(self, x, Wd, nx=0):    # x [B, K] -> [B, N]; the first nx inputs are integers (layer 1): exact in f16, never int8
+    def mm(self, x, Wd, nx=0, nf=None):    # x [B, K] -> [B, N]; the first nx inputs are integers (layer 1): exact in f16, never int8
         n = self.name
-        if nx and n.startswith("f16+2i8"):
+        if n == "f16+2f8k_l2":     # layer 1 on f16x3, layer 2 and L4 with fp8 corrections (what k_lstm2_mx alone does)
+            if nx:
+                xh = f16(x); xl = f16(x - xh)
+                return xh @ Wd["wh"] + xl @ Wd["wh"] + xh @ Wd["wl"]
+            xh = f16(x)
+            return xh @ Wd["wh"] + q8(x - xh, 2.0 ** 18) @ Wd["w8"] + q8(x, 2.0 ** 6) @ Wd["wl8"]
+        if n in ("f16+2f8k_x", "f16+2f8k_x4"):
+            # fp8 corrections only where the operand is NOT part of a recurrence: layer 2's input projection (nf columns), and with
+            # "_x4" the L4 dense layer; everything else f16x3
+            xh = f16(x); xl = f16(x - xh)
+            if nf is None:
+                return xh @ Wd["wh"] + xl @ Wd["wh"] + xh @ Wd["wl"]
+            xf, xr = x[:, :nf], x[:, nf:]
+            xfh = f16(xf)
+            fast = xfh @ Wd["wh"][:nf] + q8(xf - xfh, 2.0 ** 18) @ Wd["w8"][:nf] + q8(xf, 2.0 ** 6) @ Wd["wl8"][:nf]
+            if xr.shape[1] == 0:
+                return fast
+            xrh = f16(xr); xrl = f16(xr - xrh)
+            return fast + xrh @ Wd["wh"][nf:] + xrl @ Wd["wh"][nf:] + xrh @ Wd["wl"][nf:]
+        if nx and (n.startswith("f16+2i8") or n.startswith("f16+2f8k")):
             xi, Wi = x[:, :nx], {k: v[:nx] for k, v in Wd.items()}
             xr, Wr = x[:, nx:], {k: v[nx:] for k, v in Wd.items()}
             return f16(xi) @ Wi["wh"] + f16(xi) @ Wi["wl"] + self.mm(xr, Wr)
@@ -135,6 +165,15 @@ class Scheme:
             x8 = q8(x, pow2_scale(x, 256.0))
             xl8 = q8(xlr, pow2_scale(xlr, 256.0)) if float(xlr.abs().max()) > 0 else xlr
             return xh @ Wd["wh"] + xl8 @ Wd["w8"] + x8 @ Wd["wl8"]
+        if n == "f16+2f8k":
+            xlr = x - xh
+            return xh @ Wd["wh"] + q8(xlr, 2.0 ** 18) @ Wd["w8"] + q8(x, 2.0 ** 6) @ Wd["wl8"]
+        if n == "f16+2f8k_a":      # only w_hi * x_lo on the fp8 pipe
+            xlr = x - xh
+            return xh @ Wd["wh"] + q8(xlr, 2.0 ** 18) @ Wd["w8"] + xh @ Wd["wl"]
+        if n == "f16+2f8k_b":      # only w_lo * x_hi on the fp8 pipe
+            xlr = x - xh
+            return xh @ Wd["wh"] + xl @ Wd["wh"] + q8(x, 2.0 ** 6) @ Wd["wl8"]
         if n.startswith("f16+2i8"):
             xlr = x - xh
             x8 = torch.round(x * 127.0).clamp(-127, 127) / 127.0
@@ -180,7 +219,7 @@ def forward(X, blob, C, sch):
             ys = [None] * 33
             order = range(33) if d == 0 else range(32, -1, -1)
             for t in order:
-                z = sch.mm(torch.cat([x[:, t, :], h], 1), Wd, nx=(Kw.shape[0] if li == 0 else 0)) + b
+                z = sch.mm(torch.cat([x[:, t, :], h], 1), Wd, nx=(Kw.shape[0] if li == 0 else 0), nf=(Kw.shape[0] if li == 1 else None)) + b
                 i, f, g, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
                 c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
                 h = torch.sigmoid(o) * torch.tanh(c)
@@ -189,7 +228,7 @@ def forward(X, blob, C, sch):
         x = torch.cat(outs, 2)
     flat = x.reshape(B, -1)
     selu = torch.nn.functional.selu
-    a4 = selu(sch.mm(flat, sch.prep_w(W4)) + b4)
+    a4 = selu(sch.mm(flat, sch.prep_w(W4), nf=(flat.shape[1] if sch.name == "f16+2f8k_x4" else None)) + b4)
     a51 = selu(a4 @ W51 + b51)
     a52 = selu(a4 @ W52 + b52)
     p1 = torch.softmax(selu(a51 @ Wg + bg), 1)
@@ -213,6 +252,9 @@ def main():
             X[s, t, 9 + k] = -(depth - fwd)
             for _ in range(rng.randint(0, 3)):
                 X[s, t, rng.randint(0, C)] += rng.randint(1, max(2, depth // 3))
+    if os.environ.get("PROBE_HARSH"):      # the GPU precision test's inputs: every channel uniform in +-216 / +-20
+        r2 = np.random.RandomState(11)
+        X = np.concatenate([r2.randint(-216, 217, size=(40, 33, C)), r2.randint(-20, 21, size=(60, 33, C)), np.zeros((3, 33, C), int)]).astype(np.int32)
     blob = synth.random_weights(C).astype(np.float64)
     # gain > 1 scales every kernel (not the biases): a stand-in for trained weights with larger norms
     blob = blob.copy()
@@ -221,7 +263,10 @@ def main():
         blob = (L * gain).astype(np.float64)
     ref = forward(X, blob, C, Scheme("exact"))
     print("sites %d, weight gain %.2f, max P spread %.3f" % (n, gain, float(ref.max())))
-    for name in ("f16x3", "f16x3wl8r", "f16x3wl8b", "f16+2i8g", "f16+2i8t", "f16+2i8r", "f16+2f8", "f16+2f6", "f16x2a", "f16x2w", "f16x1"):
+    names = ("f16x3", "f16x3wl8r", "f16x3wl8b", "f16+2i8g", "f16+2i8t", "f16+2i8r", "f16+2f8", "f16+2f8k", "f16+2f6", "f16x2a", "f16x2w", "f16x1")
+    if len(sys.argv) > 3:
+        names = tuple(sys.argv[3].split(","))
+    for name in names:
         p = forward(X, blob, C, Scheme(name))
         d = (p - ref).abs()
         print("%-8s max|dP| %.3e   mean|dP| %.3e" % (name, float(d.max()), float(d.mean())))
