@@ -106,9 +106,10 @@ def main():
     ap.add_argument("--contexts", type=int, default=2, help="engine contexts (HIP streams) whose passes are pipelined on the GPU")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--no_fast", action="store_true", help="skip the additional measurement in precision 'auto' (reported as fast_precision)")
     ap.add_argument("--no_overlap", action="store_true",
                     help="one context / one stream: tensor build and network strictly back to back")
-    ap.add_argument("--precision", choices=["f16x3", "f32", "f16+f8"], default="f16x3",
+    ap.add_argument("--precision", choices=["f16x3", "f32", "f16+f8", "auto"], default="f16x3",
                     help="network GEMM arithmetic: split-f16 (fp32-equivalent, default) or fp32 MFMA")
     args = ap.parse_args()
 
@@ -222,6 +223,37 @@ def main():
         sites = int(shard.reduce_sum(dist, sites, device=red_dev))   # whole-job aggregate
     sites_per_step_rank = sites / max(1, args.steps) / world
 
+    # ---- the same K steps once more in precision "auto" (f16 main term + fp8 correction terms where the library's calibration through
+    # the loaded weights allows it): an ADDITIONAL figure, never `value` — the headline stays on the fp32-equivalent arithmetic
+    fast = None
+    if args.precision == "f16x3" and not args.no_fast and args.steps > 0:
+        for e in engs:
+            e.set_precision("auto")
+        mode, cal = eng.precision()
+        if mode == "f16+f8":
+            barrier()
+            run_steps(2)
+            barrier()
+            t1 = time.perf_counter()
+            fsites = run_steps(args.steps)
+            for e in engs:
+                e.synchronize()
+            torch.cuda.synchronize()
+            fel = time.perf_counter() - t1
+            if dist is not None:
+                dist.barrier()
+                from clair3_rna_amd import shard
+                fel = shard.reduce_max(dist, fel, device=red_dev)
+                fsites = int(shard.reduce_sum(dist, fsites, device=red_dev))
+            fast = dict(value=round(fsites / fel, 1), unit="sites/s", ms_per_step=round(1e3 * fel / args.steps, 3), precision="auto -> f16+f8",
+                        dtype="f16 main term + fp8 (block-scaled) correction terms in layer 2 and L4, f32 accumulate",
+                        calibration_max_dP=cal, guard=4e-5,
+                        note="opt-in arithmetic, ~10x the error of f16x3 (max |dP| 2-3e-5 on these weights, tolerance 1e-4); not the headline")
+        else:
+            fast = dict(value=None, precision="auto -> " + mode, calibration_max_dP=cal, guard=4e-5)
+        for e in engs:
+            e.set_precision(args.precision)
+
     # ---- per-kernel durations, live, with HIP events on the engine's stream (one extra untimed step)
     roofline, kernels, stage_rates, roofline_tb = None, {}, None, None
     if not args.no_profile:
@@ -239,7 +271,7 @@ def main():
                 per_site += FLOP_PER_SITE["k_fc4"]          # the L4 dense layer is fused into the layer-2 kernel
             flops_per_launch = per_site * n_prof / st["launches"]
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            if args.precision == "f16+f8":
+            if args.precision in ("f16+f8", "auto"):
                 # algorithmic flops against the dense f16 peak; the kernel executes one f16 product plus two fp8 products (on the
                 # block-scaled pipe at twice the f16 rate) per algorithmic product = 2 f16-equivalents of matrix-pipe time
                 roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s",
@@ -290,7 +322,8 @@ def main():
             "value": round(sites / elapsed, 1), "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"f16x3": "f16 hi/lo split x3, f32 accumulate (fp32-equivalent)", "f32": "f32",
-                                         "f16+f8": "f16 main term + fp8 (MX) correction terms, f32 accumulate (max |dP| 2-3e-5, NOT fp32-equivalent)"}[args.precision],
+                                         "f16+f8": "f16 main term + fp8 (MX) correction terms, f32 accumulate (max |dP| 2-3e-5, NOT fp32-equivalent)",
+                                         "auto": "auto: f16+f8 where the calibration allows, else f16x3"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "synthetic ONT dRNA004 chr20 ~%dx (BASELINE.json configs[1])" % int(args.depth),
                        "contig_len": contig_len, "chunks": len(chunks), "channels": 18, "precision": args.precision, "reads_per_rank": info["n_reads"],
@@ -298,6 +331,7 @@ def main():
                        "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world,
                        "streams": len(engs)},
             "roofline": roofline, "roofline_tensor_build": roofline_tb, "cpu_baseline": cpu, "stage_rates": stage_rates,
+            "fast_precision": fast,
             "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
         }
         print(json.dumps(out), flush=True)

@@ -35,7 +35,7 @@ class C3RError(RuntimeError):
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
            "c3r_pileup_scan", "c3r_pileup_scan_regions", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
-           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
+           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
 _lib = None
@@ -81,6 +81,7 @@ def load_library():
     L.c3r_weight_count.restype = i64
     L.c3r_load_weights.argtypes = [vp, vp, i64, i32]
     L.c3r_set_precision.argtypes = [vp, i32]
+    L.c3r_get_precision.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
     L.c3r_infer.argtypes = [vp, vp, i64, vp]
     L.c3r_get_probs.argtypes = [vp, vp, i64]
     L.c3r_call_rows.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(i64), C.POINTER(i64)]
@@ -232,9 +233,18 @@ class Engine(object):
         w = np.ascontiguousarray(blob, dtype=np.float32)
         self._chk(self.L.c3r_load_weights(self.h, _ptr(w), w.size, channels))
 
+    PRECISIONS = {"f32": 0, "f16x3": 1, "f16+f8": 2, "auto": 3}
+
     def set_precision(self, mode):
-        """'f32' (fp32 MFMA) or 'f16x3' (split-f16, fp32-equivalent; default)."""
-        self._chk(self.L.c3r_set_precision(self.h, {"f32": 0, "f16x3": 1, "f16+f8": 2}[mode]))
+        """'f32' (fp32 MFMA), 'f16x3' (split-f16, fp32-equivalent; default), 'f16+f8' (f16 main term + fp8 corrections, opt-in) or
+        'auto' ('f16+f8' where a calibration run through the loaded weights agrees with 'f16x3' to 4e-5, else 'f16x3')."""
+        self._chk(self.L.c3r_set_precision(self.h, self.PRECISIONS[mode]))
+
+    def precision(self):
+        """(mode in use, calibration max |dP| or -1.0)."""
+        m, e = C.c_int32(0), C.c_double(-1.0)
+        self._chk(self.L.c3r_get_precision(self.h, C.byref(m), C.byref(e)))
+        return {v: k for k, v in self.PRECISIONS.items()}[m.value], e.value
 
     def infer(self, tensors=None, n=None, fetch=True):
         if tensors is None:

@@ -86,6 +86,8 @@ struct c3r_ctx {
 
     // ---- network
     NetState net;
+    int precision_req = 1;                 // what c3r_set_precision asked for (3 = auto); net.precision is what runs
+    double mx_calib_err = -1.0;            // max |dP| of precision 2 against precision 1 on the calibration windows (-1: not measured)
 
     // ---- host decode (A8)
     void *h_stage = nullptr; size_t h_stage_cap = 0;     // pinned staging buffer for sites + tokens + probabilities
@@ -990,6 +992,65 @@ int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t
 // ------------------------------------------------------------------------------------------------
 int64_t c3r_weight_count(int channels) { return net_weight_count(channels); }
 
+// Precision "auto" (3): the fp8-corrected path (precision 2) is ~10x less exact than the split-f16 path and its error grows fast with
+// the weights' norm, so it is used only where it has been MEASURED: both paths run on 2048 pileup-shaped
+// windows drawn from a fixed seed and the probabilities must agree to C3R_MX_GUARD, a 2.5x margin under the 1e-4 tolerance.
+static constexpr double C3R_MX_GUARD = 4e-5;
+static int calibrate_mx(c3r_ctx *ctx, double *err_out) {
+    const int C = ctx->net.channels, n = 2048;
+    std::vector<int32_t> X((size_t)n * C3R_WINDOW * C, 0);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&](uint32_t m) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)((st >> 11) % m); };
+    static const int depths[6] = {6, 12, 20, 40, 90, 216};
+    for (int s_ = 0; s_ < n; ++s_) {
+        const int depth = depths[rnd(6)];
+        for (int t = 0; t < C3R_WINDOW; ++t) {
+            int32_t *col = &X[((size_t)s_ * C3R_WINDOW + t) * C];
+            const int k = (int)rnd(4);
+            int fwd = 0;
+            for (int i = 0; i < depth; ++i) fwd += (int)rnd(2);
+            col[k] = -fwd; col[9 + k] = -(depth - fwd);                     // the reference-base channels carry minus the strand totals
+            for (int r = (int)rnd(3); r > 0; --r) col[rnd((uint32_t)C)] += 1 + (int)rnd((uint32_t)std::max(1, depth / 3));
+        }
+    }
+    int32_t *d_x = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_x, X.size() * 4));
+    std::vector<float> p1((size_t)n * C3R_NPROB), p2(p1.size());
+    auto run = [&](int mode, std::vector<float> &out) -> int {
+        ctx->net.precision = mode;
+        std::string e;
+        int rc = net_forward(ctx->net, d_x, n, ctx->stream, [](const char *, int) {}, e);
+        if (rc) return fail(ctx, rc, "%s", e.c_str());
+        HIPCHK(ctx, hipMemcpyAsync(out.data(), ctx->net.d_probs, out.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return C3R_OK;
+    };
+    int rc = C3R_OK;
+    if (hipMemcpyAsync(d_x, X.data(), X.size() * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = C3R_EHIP;
+    if (!rc) rc = run(1, p1);
+    if (!rc) rc = run(2, p2);
+    (void)hipFree(d_x);
+    if (rc) return rc;
+    double worst = 0.0;
+    for (size_t i = 0; i < p1.size(); ++i) {
+        const double d = std::fabs((double)p1[i] - (double)p2[i]);
+        worst = (d == d) ? std::max(worst, d) : 1.0;                          // (a NaN disqualifies)
+    }
+    *err_out = worst;
+    return C3R_OK;
+}
+static int apply_precision(c3r_ctx *ctx) {
+    if (ctx->precision_req != 3) { ctx->net.precision = ctx->precision_req; return C3R_OK; }
+    ctx->net.precision = 1;
+    if (!ctx->net.loaded) return C3R_OK;                                      // decided when the weights arrive
+    double err = -1.0;
+    const int rc = calibrate_mx(ctx, &err);
+    if (rc) { ctx->net.precision = 1; return rc; }
+    ctx->mx_calib_err = err;
+    ctx->net.precision = err <= C3R_MX_GUARD ? 2 : 1;
+    return C3R_OK;
+}
+
 int c3r_load_weights(c3r_ctx *ctx, const float *blob, int64_t n_floats, int channels) {
     if (!ctx || !blob) return C3R_EINVAL;
     if (channels != C3R_CH && channels != C3R_CH_PHASED) return fail(ctx, C3R_EINVAL, "channels must be 18 or 30");
@@ -999,12 +1060,21 @@ int c3r_load_weights(c3r_ctx *ctx, const float *blob, int64_t n_floats, int chan
     std::string e;
     int rc = net_load(ctx->net, blob, channels, ctx->stream, e);
     if (rc) return fail(ctx, rc, "%s", e.c_str());
-    return C3R_OK;
+    ctx->mx_calib_err = -1.0;
+    return apply_precision(ctx);
 }
 
 int c3r_set_precision(c3r_ctx *ctx, int mode) {
-    if (!ctx || mode < 0 || mode > 2) return C3R_EINVAL;
-    ctx->net.precision = mode;
+    if (!ctx || mode < 0 || mode > 3) return C3R_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->precision_req = mode;
+    return apply_precision(ctx);
+}
+
+int c3r_get_precision(c3r_ctx *ctx, int *mode_in_use, double *calibration_err) {
+    if (!ctx) return C3R_EINVAL;
+    if (mode_in_use) *mode_in_use = ctx->net.precision;
+    if (calibration_err) *calibration_err = ctx->mx_calib_err;
     return C3R_OK;
 }
 

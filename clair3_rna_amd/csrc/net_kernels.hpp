@@ -1052,7 +1052,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
                                                       const half8 *__restrict__ W4p, const uint32_t *__restrict__ W4q,
                                                       const uint32_t *__restrict__ W4sc, float *__restrict__ a4part, int nstride) {
     constexpr int INP = 2 * NET_H1, H = NET_H2, NGX = INP / 16, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NBLK = 4 * H / 32, NTQ = NBLK / 4;
-    constexpr int SB = 2, WG_SITES = 32 * SB, KC = INP / 8, PD = 1;
+    #ifndef C3R_MX_PD
+#define C3R_MX_PD 1
+#endif
+    constexpr int SB = 2, WG_SITES = 32 * SB, KC = INP / 8, PD = C3R_MX_PD;
     constexpr int NKB = NG / 2, NKBX = NGX / 2, NKBH = NGH / 2, NK4 = (NKB + 3) / 4, NK4L = (NKBH + 3) / 4;
     static_assert(NTQ == 5 && NG == 26 && NGX % 2 == 0 && NGH % 2 == 0, "3 + 2 tile split of a quarter, whole 32-k blocks");
     typedef int intx8 __attribute__((ext_vector_type(8)));
@@ -1245,9 +1248,9 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 #define C3R_STEP(G)                                                                                              \
     if constexpr ((G) < NG) {                                                                                     \
         C3R_FENCE();                                                                                              \
-        if constexpr ((G) + PD < NG) { load(std::integral_constant<int, (G) + PD>{}, ah[((G) + PD) % (PD + 1)], bh[((G) + PD) % (PD + 1)]); } \
+        if constexpr (PD == 0 || (G) + PD < NG) { load(std::integral_constant<int, (G) + PD>{}, ah[((G) + PD) % (PD + 1)], bh[((G) + PD) % (PD + 1)]); } \
         mma(std::integral_constant<int, (G)>{}, ah[(G) % (PD + 1)], bh[(G) % (PD + 1)]);                          \
-        if constexpr ((G) + PD < NG) {                                                                            \
+        if constexpr (PD > 0 && (G) + PD < NG) {                                                                  \
             constexpr int NMM = ((G) >= NGX ? NTH : NT) * SB * (((G) & 1) ? 2 : 1);                               \
             constexpr int NTL = ((G) + PD >= NGX ? NTH : NT);                                                     \
             sched_interleave<NMM, NTL * ((((G) + PD) & 1) ? 3 : 1), SB * ((((G) + PD) & 1) ? 3 : 1)>();           \
@@ -1257,7 +1260,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             __syncthreads();     /* every wavefront is done with x_t */                                           \
         }                                                                                                         \
     }
-            load(std::integral_constant<int, 0>{}, ah[0], bh[0]);
+            if constexpr (PD > 0) { load(std::integral_constant<int, 0>{}, ah[0], bh[0]); }
             C3R_STEP(0) C3R_STEP(1) C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
             C3R_STEP(10) C3R_STEP(11) C3R_STEP(12) C3R_STEP(13) C3R_STEP(14) C3R_STEP(15) C3R_STEP(16) C3R_STEP(17) C3R_STEP(18)
             C3R_STEP(19) C3R_STEP(20) C3R_STEP(21) C3R_STEP(22) C3R_STEP(23) C3R_STEP(24) C3R_STEP(25)

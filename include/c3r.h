@@ -118,8 +118,14 @@ int c3r_load_weights(c3r_ctx *ctx, const float *blob, int64_t n_floats, int chan
 int64_t c3r_weight_count(int channels);
 /* Arithmetic of the network GEMMs: 0 = fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32); 1 (default) = split-f16:
  * every fp32 operand carried as hi + lo halves, products hi*hi + hi*lo + lo*hi accumulated in fp32 on the f16 matrix
- * pipe (fp32-equivalent: both modes meet the 1e-4 probability tolerance against the fp32 oracle). */
+ * pipe (fp32-equivalent: both modes meet the 1e-4 probability tolerance against the fp32 oracle);
+ * 2 = f16 main term + both correction terms on the block-scaled fp8 pipe (v_mfma_scale_f32_32x32x64_f8f6f4): ~1.15x the
+ * throughput of mode 1, max |dP| 2-3e-5 on N(0, 0.05) weights but NOT robust to weights of 2-3x that norm — opt-in;
+ * 3 = auto: mode 2 if it agrees with mode 1 to 4e-5 on 2048 calibration windows run through the loaded weights (measured at
+ * c3r_load_weights / here), else mode 1.  Modes 2 and 3 need 18- or 30-channel weights like the others. */
 int c3r_set_precision(c3r_ctx *ctx, int mode);
+/* The mode the network runs in (after "auto" has decided) and the calibration's max |dP| (-1: not measured). */
+int c3r_get_precision(c3r_ctx *ctx, int *mode_in_use, double *calibration_err);
 /* Forward pass over tensors.  tensors==NULL: use the device-resident tensors of the last scan.
  * Otherwise `tensors` is a host int32 [n][33][C] array.  probs (host, [n][24]) may be NULL to keep
  * the result on the device only.  Replaces m.predict_on_batch (clair3_rna/call_variants.py:1505). */

@@ -11,6 +11,7 @@ import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument("--config3", action="store_true", help="BASELINE.json configs[3] flavour: MAS-Seq reads, depth 30, HP tags, 30 channels")
 ap.add_argument("--contig_len", type=int, default=synth.CHR20_LEN)
+ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16+f8", "auto"], help="network arithmetic (c3r_set_precision)")
 opt = ap.parse_args()
 CH = 30 if opt.config3 else 18
 ref, rs, info = synth.generate_contig(contig_len=opt.contig_len, depth=30.0 if opt.config3 else 20.0, platform="hifi" if opt.config3 else "ont", phased=opt.config3)
@@ -19,7 +20,8 @@ refs = ref.decode()
 chunks = bench.chunk_list(L)
 print('config3' if opt.config3 else 'config1', 'contig', L, 'reads', len(rs), 'channels', CH, flush=True)
 eng = capi.Engine(0); eng.set_params(channels=CH); eng.load_reads(rs); eng.set_reference(1, ref)
-w = synth.random_weights(CH); eng.load_weights(w, CH)
+w = synth.random_weights(CH); eng.load_weights(w, CH); eng.set_precision(opt.precision)
+print("precision", opt.precision, "->", eng.precision(), flush=True)
 t0 = time.time()
 n_tot, worst = 0, 0.0
 for ci, (a, b) in enumerate(chunks):
@@ -41,4 +43,4 @@ for ci, (a, b) in enumerate(chunks):
     n_tot += n
     print("chunk %2d/%d: %6d sites identical, max |dP| so far %.2e  (%.0f s)" % (ci + 1, len(chunks), n, worst, time.time() - t0), flush=True)
 assert worst < 1e-4
-print("FULL CONTIG OK: %d sites, %d reads, all lines and tensors identical, max |dP| = %.2e" % (n_tot, len(rs), worst))
+print("FULL CONTIG OK (%s): %d sites, %d reads, all lines and tensors identical, max |dP| = %.2e" % (opt.precision, n_tot, len(rs), worst))

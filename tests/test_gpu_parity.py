@@ -189,6 +189,59 @@ def test_network_both_precisions_meet_tolerance(eng):
     print("max |dP| per (channels, precision):", worst)
 
 
+def _pileup_like(n, C, seed):
+    """Windows shaped like the pileup tensor (tools/precision_probe.py): negative reference channels, a few alt counts, mixed depths."""
+    r = np.random.RandomState(seed)
+    X = np.zeros((n, 33, C), np.int32)
+    for s in range(n):
+        depth = int(r.choice([6, 12, 20, 40, 90, 216]))
+        for t in range(33):
+            k = r.randint(0, 4)
+            fwd = r.binomial(depth, 0.5)
+            X[s, t, k] = -fwd
+            X[s, t, 9 + k] = -(depth - fwd)
+            for _ in range(r.randint(0, 3)):
+                X[s, t, r.randint(0, C)] += r.randint(1, max(2, depth // 3))
+    return X
+
+
+def test_precision_f16_f8_opt_in_and_auto_guard(eng):
+    """Precision 2 (f16 main term + both corrections on the block-scaled fp8 pipe) is opt-in: within the 1e-4 tolerance of the fp32 oracle
+    on pileup-shaped windows and on the harsh random inputs, about ten times the split-f16 error.  'auto' takes it only where a
+    calibration run through the loaded weights agrees with split-f16 to 4e-5: yes for these weights, no for weights of three times the
+    norm (where its error passes 1e-4 and split-f16 stays within it)."""
+    from clair3_rna_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.RandomState(11)
+    try:
+        for C, wseed in ((18, 1234), (30, 99)):
+            w = synth.random_weights(C, seed=wseed)
+            X = np.concatenate([_pileup_like(300, C, 7 + C), rng.randint(-216, 217, size=(40, 33, C)).astype(np.int32),
+                                rng.randint(-20, 21, size=(60, 33, C)).astype(np.int32), np.zeros((3, 33, C), np.int32)])
+            po = orc.forward(w, X)
+            eng.set_precision("f16x3")
+            eng.load_weights(w, C)
+            e1 = float(np.abs(eng.infer(tensors=X) - po).max())
+            eng.set_precision("f16+f8")
+            assert eng.precision()[0] == "f16+f8"
+            e2 = float(np.abs(eng.infer(tensors=X) - po).max())
+            assert e1 < 1e-5 and e2 < 1e-4 and e2 < 6e-5, (C, e1, e2)
+            eng.set_precision("auto")
+            mode, cal = eng.precision()
+            assert mode == "f16+f8" and 0 <= cal <= 4e-5, (mode, cal)
+            assert np.array_equal(eng.infer(tensors=X), eng.infer(tensors=X))
+            # three times the norm: the guard must refuse, and what runs instead must still meet the tolerance
+            w3 = (3.0 * w).astype(np.float32)
+            eng.load_weights(w3, C)
+            mode3, cal3 = eng.precision()
+            assert mode3 == "f16x3" and cal3 > 4e-5, (mode3, cal3)
+            Xs = X[:120]
+            assert float(np.abs(eng.infer(tensors=Xs) - orc.forward(w3, Xs)).max()) < 1e-4
+            print("C=%d: max |dP| f16x3 %.2e, f16+f8 %.2e; calibration %.2e (norm x1), %.2e (norm x3)" % (C, e1, e2, cal, cal3))
+    finally:
+        eng.set_precision("f16x3")
+
+
 def test_network_30ch_and_ragged_batch(eng):
     from clair3_rna_amd import synth
     from oracle import oracle as orc
