@@ -1055,6 +1055,9 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
     #ifndef C3R_MX_PD
 #define C3R_MX_PD 1
 #endif
+#ifndef C3R_MX_EVEN_BURST
+#define C3R_MX_EVEN_BURST 0      // 1: the short even steps issue their loads (among them the next block's fp8 fragments) as one burst ahead of the MFMAs
+#endif
     constexpr int SB = 2, WG_SITES = 32 * SB, KC = INP / 8, PD = C3R_MX_PD;
     constexpr int NKB = NG / 2, NKBX = NGX / 2, NKBH = NGH / 2, NK4 = (NKB + 3) / 4, NK4L = (NKBH + 3) / 4;
     static_assert(NTQ == 5 && NG == 26 && NGX % 2 == 0 && NGH % 2 == 0, "3 + 2 tile split of a quarter, whole 32-k blocks");
@@ -1222,20 +1225,11 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
                 }
                 if constexpr ((G & 1) != 0) {
                     constexpr int KB = G / 2;
-#ifdef C3R_MX_DBG
-                    constexpr bool skip_gates = ((C3R_MX_DBG & 4) && KB < NKBX) || ((C3R_MX_DBG & 8) && KB >= NKBX);
-#else
-                    constexpr bool skip_gates = false;
-#endif
-                    if constexpr (!skip_gates)
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
                         for (int sb = 0; sb < SB; ++sb)
                             acc[tt][sb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[tt], b8[sb], acc[tt][sb], 0, 0, KB % 4, sc[tt], 0, sbc);
-#ifdef C3R_MX_DBG
-                    if constexpr (!(C3R_MX_DBG & 16) && !((C3R_MX_DBG & 32) && (KB - NKBX) == ((C3R_MX_DBG >> 8) & 7)))
-#endif
                     if constexpr (L4T && KB >= NKBX) {
 #pragma unroll
                         for (int sb = 0; sb < SB; ++sb)
@@ -1250,7 +1244,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
         C3R_FENCE();                                                                                              \
         if constexpr (PD == 0 || (G) + PD < NG) { load(std::integral_constant<int, (G) + PD>{}, ah[((G) + PD) % (PD + 1)], bh[((G) + PD) % (PD + 1)]); } \
         mma(std::integral_constant<int, (G)>{}, ah[(G) % (PD + 1)], bh[(G) % (PD + 1)]);                          \
-        if constexpr (PD > 0 && (G) + PD < NG) {                                                                  \
+        if constexpr (PD > 0 && (G) + PD < NG && (((G) & 1) || !C3R_MX_EVEN_BURST)) {                              \
             constexpr int NMM = ((G) >= NGX ? NTH : NT) * SB * (((G) & 1) ? 2 : 1);                               \
             constexpr int NTL = ((G) + PD >= NGX ? NTH : NT);                                                     \
             sched_interleave<NMM, NTL * ((((G) + PD) & 1) ? 3 : 1), SB * ((((G) + PD) & 1) ? 3 : 1)>();           \
@@ -1316,8 +1310,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
                     int w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[4 * sb + 0] * 64.f, hval[4 * sb + 1] * 64.f, 0, false);
                     w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[4 * sb + 2] * 64.f, hval[4 * sb + 3] * 64.f, w_hi, true);
                     // k = 8 T + 4 hh + q of the direction's 160: block T / 4, 16-byte part (T % 4) / 2, bytes 8 (T % 2) + 4 hh + q
+                    {
                     reinterpret_cast<int *>(&hq[nxt][T >> 2][0][(T & 3) >> 1][32 * sb + j])[2 * (T & 1) + hh] = w_lo;
                     reinterpret_cast<int *>(&hq[nxt][T >> 2][1][(T & 3) >> 1][32 * sb + j])[2 * (T & 1) + hh] = w_hi;
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // x_{t+1} has landed (LDS-DMA is tracked by vmcnt)
@@ -1342,9 +1338,6 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
                     const intx8 bq = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
                     facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, facc[sb], 0, 0, 0);
                     facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, facc[sb], 0, 0, 0);
-#ifdef C3R_MX_DBG
-                    if (!(C3R_MX_DBG & 16) && !((C3R_MX_DBG & 32) && P == ((C3R_MX_DBG >> 8) & 7)) && !(C3R_MX_DBG & 64))
-#endif
                     facc[sb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aq, bq, facc[sb], 0, 0, P % 4, scl, 0, sbc);
                 }
             });
@@ -1798,10 +1791,6 @@ __global__ __launch_bounds__(512 * TEAMS, C3R_L1_W8_OCC) void k_lstm1_w8(const i
                         w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[4 * sb + 2] * 64.f, hval[4 * sb + 3] * 64.f, w_hi, true);
                         const int row0 = (dir * 4 + (blk >> 2)) * 4 + ((blk & 3) >> 1);
                         _Float16 *qp = y + plane_out + ((size_t)t * (2 * HV) + row0) * nstride * 8 + (uint32_t)(site0 + 32 * sb + j) * 8 + 4 * (blk & 1) + 2 * hh;
-#ifdef C3R_MX_DBG
-                        if (C3R_MX_DBG & 1) w_lo = 0;
-                        if (C3R_MX_DBG & 2) w_hi = 0;
-#endif
                         *(int *)qp = w_lo;
                         *(int *)(qp + (size_t)2 * nstride * 8) = w_hi;
                     }
