@@ -145,6 +145,9 @@ def build_parser():
     a("--readiportal_database_filter_tag", type=str, default=None)
     a("--no_compress", action="store_true", help="leave <prefix>.vcf uncompressed (tests)")
     a("--gpu_id", type=int, default=None, help="default: $C3R_DEVICE, else LOCAL_RANK under torch.distributed.run, else 0")
+    a("--gpu_precision", type=str, default=os.environ.get("C3R_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16+f8", "auto"],
+      help="network arithmetic (c3r_set_precision): f16x3 = fp32-equivalent split-f16 (default); auto = the faster fp8-corrected path where a "
+           "calibration run through the loaded weights agrees with f16x3 to 4e-5, else f16x3")
     a("--fetch_threads", type=int, default=4)
     a("--contexts", type=int, default=2, help="GPU contexts (each with its own host thread and HIP stream) working side by side: while one waits for its kernels the other normalises reads or decodes (every context sizes its own device buffers on its first contig; first uses take turns)")
     return p
@@ -257,6 +260,9 @@ def Run(args, log=None):
     engines = [capi.Engine(args.gpu_id) for _ in range(max(1, args.contexts))]
     for e in engines:
         e.load_weights(weights, channels)
+        e.set_precision(args.gpu_precision)
+    if args.gpu_precision != "f16x3":
+        log("[INFO] network arithmetic: %s -> %s (calibration max |dP| %s)" % ((args.gpu_precision,) + tuple(engines[0].precision())))
     qual_rows = args.qual if args.qual is not None else 2              # call_variants.py:1827 (STEP 1 never passes --qual)
     qual_merge = args.qual if args.qual is not None else 2             # sort_vcf's own default
     header = vcf.header(args.ref_fn, cmd_fn, args.sample_name) + "\n"

@@ -111,6 +111,9 @@ def build_parser():
     a('--delay', type=int, default=0)
     a('--use_gpu', type=str2bool, default=True)
     a('--gpu_id', type=int, default=int(os.environ.get("C3R_DEVICE", "0")))
+    a('--gpu_precision', type=str, default=os.environ.get("C3R_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16+f8", "auto"],
+      help="network arithmetic (include/c3r.h, c3r_set_precision): f16x3 = fp32-equivalent split-f16 (default); auto = the faster fp8-corrected "
+           "path where a calibration run through the loaded weights agrees with f16x3 to 4e-5, else f16x3")
     a('--tensor_dump_fn', type=str, default=None, help="DEBUG: also write the create_tensor text lines here")
     for flag in ('--gvcf', '--fast_mode', '--call_snp_only', '--enable_long_indel', '--keep_iupac_bases'):
         a(flag, type=str2bool, default=False)
@@ -173,6 +176,7 @@ def Run(args, engine=None):
     eng.load_reads(rs)
     eng.set_reference(ref_start, ref_seq)
     eng.load_weights(io.load_weights(args.chkpnt_fn, channels), channels)
+    eng.set_precision(getattr(args, "gpu_precision", "f16x3"))
     n = eng.scan(ctg_start, ctg_end)
     rows = b""
     if n:

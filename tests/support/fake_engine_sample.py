@@ -23,6 +23,8 @@ class FakeEngine(object):
     def close(self): pass
     def synchronize(self): pass
     def load_weights(self, blob, channels=None): self.w = float(np.asarray(blob).sum())
+    def set_precision(self, mode): self.mode = mode
+    def precision(self): return getattr(self, "mode", "f16x3"), -1.0
     def set_bed(self, which, iv): pass
     def set_params(self, **kw): self.kw = kw
     def set_sites(self, sites): self.sites = list(sites)
