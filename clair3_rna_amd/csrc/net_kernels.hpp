@@ -1131,6 +1131,14 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
         typedef const half8 __attribute__((address_space(1))) *gptr_t;
         typedef const intx8 __attribute__((address_space(1))) *g8_t;
         typedef const uint32_t __attribute__((address_space(1))) *gs_t;
+        // a lane's 32 operand bytes: `p` counts 32-byte units per lane as if they were contiguous; in memory the two 16-byte halves of the
+        // 64 lanes are separate 1 KiB runs ([term][lane][16 B]): base of the set = p - lane, halves at + lane and + 64 + lane (in 16-byte units)
+        auto ld_q = [&](g8_t p) {
+            typedef const intx4 __attribute__((address_space(1))) *g4_t;
+            const g4_t h = (g4_t)(p - lane) + lane;
+            const intx4 lo = h[0], hi4 = h[64];
+            return intx8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        };
         for (int step = 0; step < NET_T; ++step) {
             const int t = dir ? NET_T - 1 - step : step;
             const int tprev = step ? (dir ? t + 1 : t - 1) : t;
@@ -1164,7 +1172,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
                     asm volatile("" : "+v"(qbase));
                     const g8_t qg = (g8_t)qbase + (size_t)KB * NTQ * 64;
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) a8[tt] = qg[tt * 64];
+                    for (int tt = 0; tt < NT; ++tt) a8[tt] = ld_q(qg + (size_t)tt * 64);
                     if constexpr (KB % 4 == 0) {
                         uintptr_t sbase = (uintptr_t)wsc;
                         asm volatile("" : "+v"(sbase));
@@ -1176,7 +1184,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
                         constexpr int KL = KB - NKBX;
                         uintptr_t q4 = (uintptr_t)(reinterpret_cast<const intx8 *>(W4q) + ((size_t)(dir * NET_T + tprev) * 4 + sq) * NKBH * 64 + lane);
                         asm volatile("" : "+v"(q4));
-                        a8[L4T ? NT : 0] = ((g8_t)q4)[(size_t)KL * 64];
+                        a8[L4T ? NT : 0] = ld_q((g8_t)q4 + (size_t)KL * 64);
                         if constexpr (KL % 4 == 0) {
                             uintptr_t s4 = (uintptr_t)(W4sc + ((size_t)(dir * NET_T + tprev) * 4 + sq) * NK4L * 64 + lane);
                             asm volatile("" : "+v"(s4));
@@ -1328,7 +1336,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             static_for<0, NKBH>([&](auto pc) {
                 constexpr int P = decltype(pc)::value;
                 const half8 a0 = w4[(size_t)((2 * P) * 2) * 64], a1 = w4[(size_t)((2 * P + 1) * 2) * 64];
-                const intx8 aq = q4[(size_t)P * 64];
+                const intx8 aq = ld_q((g8_t)(q4 + (size_t)P * 64));
                 const int scl = (int)s4[(size_t)(P / 4) * 64];
 #pragma unroll
                 for (int sb = 0; sb < SB; ++sb) {
@@ -2111,7 +2119,7 @@ inline uint8_t f2e4m3(float v) {
 // K order of the instruction (tools/mx_scale_probe.hip): a lane (r, g = lane / 32) holds k = 16 g + 0..15 of the FIRST scale block
 // in its bytes 0-15 and k = 32 + 16 g + 0..15, the second scale block, in its bytes 16-31; the scale byte of lane r covers the first
 // block of row r, that of lane 32 + r the second.  First block = term 0 (w), second = term 1 (w - f16(w)):
-//   q: [quarter][kb][tile][64 lanes][32 bytes]   lane = 32 g + r: bytes 0-15 = term 0, bytes 16-31 = term 1, both of k = k0 + 32 kb + 16 g + 0..15
+//   q: [quarter][kb][tile][term][64 lanes][16 bytes]   lane = 32 g + r: k = k0 + 32 kb + 16 g + 0..15; a lane's operand = its term-0 bytes then its term-1 bytes
 //   sc: [quarter][kb / 4][tile][64 lanes] u32    lane = 32 term + r, byte kb % 4 = E8M0 scale: 2^(sc - 127) * byte = 2^12 * value
 template <class WF>
 inline void pack_mx(WF &&w /* (k, blk, r) -> weight */, int NBLK, int NT, int k0, int nkb, std::vector<uint32_t> &q, std::vector<uint32_t> &sc) {
@@ -2134,7 +2142,8 @@ inline void pack_mx(WF &&w /* (k, blk, r) -> weight */, int NBLK, int NT, int k0
                     if (m > 0.f) { int ex; (void)std::frexp(m, &ex); e = 8 - ex; }
                     e = std::min(e, 139);                                        // (E8M0 byte = 139 - e >= 0)
                     const size_t fo = (((size_t)(blk / NT) * nkb + kb) * NT + (blk % NT)) * 64;
-                    for (int b = 0; b < 32; ++b) qb[(fo + 32 * (b / 16) + r) * 32 + 16 * term + (b % 16)] = f2e4m3(std::ldexp(v[b], e));
+                    // (each 16-byte half of a lane's 32 bytes is stored as its own 1 KiB run of the 64 lanes: two fully coalesced loads)
+                    for (int b = 0; b < 32; ++b) qb[((fo * 2 + (size_t)term * 64) + 32 * (b / 16) + r) * 16 + (b % 16)] = f2e4m3(std::ldexp(v[b], e));
                     const size_t so = ((((size_t)(blk / NT) * nk4 + kb / 4) * NT + (blk % NT)) * 64 + 32 * term + r) * 4 + (kb % 4);
                     sb[so] = (uint8_t)std::max(0, 127 + (int)WSCALE_LOG2 - e);
                 }
