@@ -20,13 +20,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.search(r"k_lstm2_w8|k_lstm1_skew|k_lstm_h|k_lstm|k_[a-z0-9_]+", name)
+    m = re.search(r"k_lstm2_mx|k_lstm2_w8|k_lstm1_skew|k_lstm_h|k_lstm|k_[a-z0-9_]+", name)
     if not m:
         return name[:40]
     k = m.group(0)
     if k == "k_lstm1_skew":
         return "k_lstm1"
-    if k == "k_lstm2_w8":
+    if k in ("k_lstm2_w8", "k_lstm2_mx"):
         return "k_lstm2"
     if k in ("k_lstm_h", "k_lstm"):
         return "k_lstm2" if ("ILi256E" in name or "Li160E" in name or re.search(r"k_lstm(_h)?<256,", name)) else "k_lstm1"
@@ -70,7 +70,7 @@ def main():
             r = rows[k]
             vals = [r.get(h, (0.0, 0))[0] for h in hdr]
             n = max(v[1] for v in r.values())
-            ff = 2.0 if (k == "k_lstm2" and prec == "f16x3") else 1.0
+            ff = 2.0 if (k == "k_lstm2" and prec in ("f16x3", "f16+f8")) else 1.0      # (precision 2 streams y1 the same way)
             hbm = (ff * vals[0] + vals[1]) * 1024
             busy = vals[2] / (1024 * vals[3] / 8) if vals[3] else 0.0
             traffic[k] = int(hbm)
