@@ -52,6 +52,7 @@ struct c3r_ctx {
     std::vector<int64_t> h_indel_prefix;  // [n_reads + 1] running count of I/D ops (normalised CIGARs): sizes the event scratch per scan
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
     std::vector<DevSeg> h_segs;            // aligned segments (CIGAR runs between N ops), sorted by ext_start
+    DevBuf d_bkt; int32_t n_bkt = 0;       // bucket index of the sorted read / segment arrays (k_bucket_index)
     DevBuf d_dbg;                          // C3R_SCAN_DBG: phase timers of k_scan_tiles
     DevBuf d_tile_cand;                    // [n_tiles] {first candidate, count} of the most recent scan (k_compact_write -> k_tile_tokens)
     DevBuf d_ops, d_seg_op_off;            // expanded op records of the sorted segments (pileup_kernels.hpp, OpRec) and each segment's first record
@@ -218,7 +219,17 @@ int upload_prefmax(c3r_ctx *ctx) {
         sm[i] = m;
     }
     if ((rc = upload(ctx, ctx->d_seg_prefmax, sm.data(), sm.size()))) return rc;
+    {   // bucket index for k_tile_ranges (the prefix maxima depend on the filters: rebuilt with them)
+        int32_t top = 0;
+        for (int32_t v : pm) top = std::max(top, v);
+        ctx->n_bkt = (int32_t)(((int64_t)top >> BKT_SHIFT) + 2);
+        if ((rc = ensure(ctx, ctx->d_bkt, (size_t)4 * ctx->n_bkt * 4 + 16))) return rc;
+        hipLaunchKernelGGL(k_bucket_index, dim3((unsigned)((ctx->n_bkt + 255) / 256)), dim3(256), 0, ctx->stream, (const DevRead *)ctx->d_reads.p, (int)ctx->h_reads.size(),
+                           (const int32_t *)ctx->d_prefmax.p, (const DevSeg *)ctx->d_segs.p, (int)ctx->h_segs.size(), (const int32_t *)ctx->d_seg_prefmax.p,
+                           (int)ctx->n_bkt, (int32_t *)ctx->d_bkt.p);
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // pm / sm are temporaries
+    HIPCHK(ctx, hipGetLastError());
     return C3R_OK;
 }
 
@@ -281,7 +292,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+    DevBuf *bufs[] = {&ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -756,6 +767,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     a.prefmax_end = (const int32_t *)ctx->d_prefmax.p; a.n_reads = (int32_t)ctx->h_reads.size();
     a.segs = (const DevSeg *)ctx->d_segs.p; a.seg_prefmax = (const int32_t *)ctx->d_seg_prefmax.p; a.n_segs = (int32_t)ctx->h_segs.size();
     a.ops = (const OpRec *)ctx->d_ops.p; a.seg_op_off = (const int32_t *)ctx->d_seg_op_off.p;
+    a.bkt = ctx->n_bkt > 0 && !getenv("C3R_NO_BUCKETS") ? (const int32_t *)ctx->d_bkt.p : nullptr; a.n_bkt = ctx->n_bkt;
     a.tile_cols = (uint8_t *)ctx->d_tile_cols.p;
     a.tile_rng = (int4 *)ctx->d_tile_rng.p; a.tile_list = (int32_t *)ctx->d_tile_list.p;
     a.n_tile_list = (int32_t *)((char *)ctx->d_small.p + 20); a.n_tiles = n_tiles;

@@ -116,6 +116,8 @@ struct ScanArgs {
     const DevSeg *segs;           // aligned segments sorted by ext_start
     const int32_t *seg_prefmax;   // inclusive prefix max of segment `end` over passing segments
     int32_t n_segs;
+    const int32_t *bkt;           // bucket index (k_bucket_index): [4][n_bkt] answers of the four searches of k_tile_ranges at every 256th position
+    int32_t n_bkt;
     const OpRec *ops;             // expanded ops of the sorted segments
     const int32_t *seg_op_off;    // [n_segs + 1] first record of each segment
     uint8_t *tile_cols;           // [n_tiles] 1 = this tile's columns were written (0: implicitly all-zero)
@@ -539,34 +541,78 @@ __device__ __forceinline__ void wave_append(int32_t *list, int32_t *counter, boo
     if (pred) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
-__global__ void k_tile_ranges(const ScanArgs a) {
+// Bucket index of the four sorted arrays k_tile_ranges searches (built when the reads are loaded / re-filtered): the answer at every
+// 256th position bounds the answer in between, so a tile's search runs over the reads (segments) that start inside one bucket — a few
+// steps instead of 16-18 dependent loads through the whole array.
+constexpr int BKT_SHIFT = 8;
+__global__ void k_bucket_index(const DevRead *reads, int n_reads, const int32_t *prefmax_end, const DevSeg *segs, int n_segs, const int32_t *seg_prefmax,
+                               int nb, int32_t *out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const int v = b << BKT_SHIFT;
+    out[b] = lower_bound_pos(reads, n_reads, v);
+    out[nb + b] = upper_bound_gt(prefmax_end, n_reads, v);
+    out[2 * nb + b] = lower_bound_seg(segs, n_segs, v);
+    out[3 * nb + b] = upper_bound_gt(seg_prefmax, n_segs, v);
+}
+// [lo, hi] that holds the answer for query q, from table row `tab` (answers at b << BKT_SHIFT, non-decreasing)
+__device__ __forceinline__ void bucket_bounds(const int32_t *tab, int nb, int n, int q, int &lo, int &hi) {
+    if (tab == nullptr) { lo = 0; hi = n; return; }
+    if (q <= 0) { lo = 0; hi = tab[0]; return; }
+    const int b = q >> BKT_SHIFT;
+    if (b >= nb - 1) { lo = tab[nb - 1]; hi = n; return; }
+    lo = tab[b]; hi = tab[b + 1];
+}
+
+__global__ __launch_bounds__(256) void k_tile_ranges(const ScanArgs a) {     // (256 threads: the list append below counts four wavefronts)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     bool listed = false, pruned = false;
     if (t < a.n_tiles) {
         const TileGeo tg = a.geo[t];
         const int t0 = tg.p0, t1 = tg.p1;
         if (t1 > t0) {                        // (not a guard tile)
+            const int32_t *T0 = a.bkt, *T1 = a.bkt ? a.bkt + a.n_bkt : nullptr, *T2 = a.bkt ? a.bkt + 2 * a.n_bkt : nullptr, *T3 = a.bkt ? a.bkt + 3 * a.n_bkt : nullptr;
+            auto ub_gt = [](const int32_t *arr, int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (arr[mid] > v) hi = mid; else lo = mid + 1; } return lo; };
+            auto lb_pos = [&](int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.reads[mid].pos >= v) hi = mid; else lo = mid + 1; } return lo; };
+            auto lb_seg = [&](int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.segs[mid].ext_start >= v) hi = mid; else lo = mid + 1; } return lo; };
+            int lo, hi;
             int4 r;
-            r.x = upper_bound_gt(a.prefmax_end, a.n_reads, t0);
-            r.y = lower_bound_pos(a.reads, a.n_reads, t1);
+            bucket_bounds(T1, a.n_bkt, a.n_reads, t0, lo, hi); r.x = ub_gt(a.prefmax_end, lo, hi, t0);
+            bucket_bounds(T0, a.n_bkt, a.n_reads, t1, lo, hi); r.y = lb_pos(lo, hi, t1);
             if (r.x < r.y) {
-                r.z = upper_bound_gt(a.seg_prefmax, a.n_segs, t0);
-                r.w = lower_bound_seg(a.segs, a.n_segs, t1);
+                bucket_bounds(T3, a.n_bkt, a.n_segs, t0, lo, hi); r.z = ub_gt(a.seg_prefmax, lo, hi, t0);
+                bucket_bounds(T2, a.n_bkt, a.n_segs, t1, lo, hi); r.w = lb_seg(lo, hi, t1);
                 a.tile_rng[t] = r;
                 listed = true;
                 if (a.prune && r.z >= r.w) {
                     // intron-only tile.  A candidate is a position with aligned bases (depth > 0) and its window reaches 16
                     // positions to either side: this tile's rows matter only if an aligned segment comes within 16 bp of it (a
                     // superset test: the segments' ext_start / prefix-max ends, filters not applied)
-                    const int z = upper_bound_gt(a.seg_prefmax, a.n_segs, t0 - C3R_FLANK - 1);
-                    const int w = lower_bound_seg(a.segs, a.n_segs, t1 + C3R_FLANK);
+                    bucket_bounds(T3, a.n_bkt, a.n_segs, t0 - C3R_FLANK - 1, lo, hi);
+                    const int z = ub_gt(a.seg_prefmax, lo, hi, t0 - C3R_FLANK - 1);
+                    bucket_bounds(T2, a.n_bkt, a.n_segs, t1 + C3R_FLANK, lo, hi);
+                    const int w = lb_seg(lo, hi, t1 + C3R_FLANK);
                     if (z >= w) { listed = false; pruned = true; }
                 }
             }
         }
     }
-    wave_append(a.tile_list, a.n_tile_list, listed, t);
-    if (a.prune) wave_append(a.tile_list2, a.n_tile_list2, pruned, t);
+    // both lists are appended with ONE atomic per workgroup and list (the ~4 k per-wavefront atomics on one counter were most of
+    // this kernel's time)
+    __shared__ int s_cnt[2][4], s_base[2];
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const unsigned long long m0 = __ballot(listed), m1 = __ballot(pruned);
+    if (lane == 0) { s_cnt[0][wave] = __popcll(m0); s_cnt[1][wave] = __popcll(m1); }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int w = (int)threadIdx.x, tot = s_cnt[w][0] + s_cnt[w][1] + s_cnt[w][2] + s_cnt[w][3];
+        s_base[w] = tot ? atomicAdd(w ? a.n_tile_list2 : a.n_tile_list, tot) : 0;
+    }
+    __syncthreads();
+    int b0 = s_base[0], b1 = s_base[1];
+    for (int w = 0; w < wave; ++w) { b0 += s_cnt[0][w]; b1 += s_cnt[1][w]; }
+    if (listed) a.tile_list[b0 + __popcll(m0 & ((1ull << lane) - 1ull))] = t;
+    if (pruned) a.tile_list2[b1 + __popcll(m1 & ((1ull << lane) - 1ull))] = t;
 }
 
 // The tile kernels run over the compact tile list with a FIXED grid (LIST_GRID workgroups, each taking every LIST_GRID-th list
