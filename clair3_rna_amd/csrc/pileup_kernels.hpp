@@ -528,19 +528,6 @@ __device__ __forceinline__ bool ev_equal(const ScanArgs &a, const EvRec &x, cons
 // One thread per tile: the four binary searches that bound the tile's reads and segments.  Done here, thousands at a
 // time, instead of by one lane at the head of every tile workgroup (64 dependent global loads = tens of microseconds
 // of pure latency per tile).  Tiles that no read span covers are dropped from the work list.
-// Append `value` to a global list for the lanes with `pred`: ONE returning atomic per wavefront (ballot + popcount), whatever the
-// control flow around it.  (Two atomicAdd sites on different counters get merged by hipcc into one atomic with a per-lane
-// address, which its wave-level atomic aggregation then skips: 250 k serialised L2 atomics = 2.4 ms instead of 0.07.)
-__device__ __forceinline__ void wave_append(int32_t *list, int32_t *counter, bool pred, int32_t value) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0) return;
-    const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(m));
-    base = __shfl(base, leader, 64);
-    if (pred) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
-}
-
 // Bucket index of the four sorted arrays k_tile_ranges searches (built when the reads are loaded / re-filtered): the answer at every
 // 256th position bounds the answer in between, so a tile's search runs over the reads (segments) that start inside one bucket — a few
 // steps instead of 16-18 dependent loads through the whole array.
