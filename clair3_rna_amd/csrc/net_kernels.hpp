@@ -1139,6 +1139,12 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             const intx4 lo = h[0], hi4 = h[64];
             return intx8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
         };
+#ifdef C3R_MX_TIMING
+        long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define C3R_TPH(K) do { const long long now_ = clock64(); tph[K] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define C3R_TPH(K) do {} while (0)
+#endif
         for (int step = 0; step < NET_T; ++step) {
             const int t = dir ? NET_T - 1 - step : step;
             const int tprev = step ? (dir ? t + 1 : t - 1) : t;
@@ -1259,7 +1265,9 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
         }                                                                                                         \
         if constexpr ((G) == NGX - 1) {                                                                           \
             C3R_FENCE();                                                                                          \
+            C3R_TPH(0);                                                                                           \
             __syncthreads();     /* every wavefront is done with x_t */                                           \
+            C3R_TPH(1);                                                                                           \
         }                                                                                                         \
     }
             if constexpr (PD > 0) { load(std::integral_constant<int, 0>{}, ah[0], bh[0]); }
@@ -1269,6 +1277,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             C3R_FENCE();
 #undef C3R_STEP
 #undef C3R_FENCE
+            C3R_TPH(2);
             if (step + 1 < NET_T) dma_x(dir ? NET_T - 2 - step : step + 1);      // lands during the cell update
             // ---- lane-local cell update (k_lstm2_w8's), h_t to LDS as f16 plus the two fp8 bytes per unit
 #pragma unroll
@@ -1324,9 +1333,19 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
                     }
                 }
             }
+            C3R_TPH(3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // x_{t+1} has landed (LDS-DMA is tracked by vmcnt)
+            C3R_TPH(4);
             __syncthreads();                                       // h_t complete; everyone is done with h_{t-1}
+            C3R_TPH(5);
         }
+#ifdef C3R_MX_TIMING
+        if (blockIdx.x == 0 && blockIdx.y == 7 && lane == 0) {
+            long long *sink = reinterpret_cast<long long *>(a4part + (size_t)n * 2 * NET_L4) + wave * 6;
+            for (int q = 0; q < 6; ++q) sink[q] = tph[q];
+        }
+#endif
+#undef C3R_TPH
         if constexpr (L4T) {
             // ---- the last step's h (buffer NET_T & 1) still owes its L4 contribution
             const int tl = dir ? 0 : NET_T - 1, hbuf = NET_T & 1;
@@ -1363,6 +1382,11 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             }
         }
     };
+#ifndef C3R_MX_PRIO
+#define C3R_MX_PRIO 0        // 1: s_setprio 1 for the 3-tile wavefronts, 2: for the 2-tile (+ L4) wavefronts
+#endif
+    if (C3R_MX_PRIO == 1 && heavy3) __builtin_amdgcn_s_setprio(1);
+    if (C3R_MX_PRIO == 2 && !heavy3) __builtin_amdgcn_s_setprio(1);
     if (heavy3) body(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::false_type{});
     else body(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::true_type{});
 }
