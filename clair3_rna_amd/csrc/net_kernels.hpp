@@ -699,6 +699,21 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
 //     x_{t+1} after its recurrent part, and it lands under the cell update), one at the end of the step (h_t complete); h is
 //     double-buffered because a wavefront's cell update now runs while others still read h_{t-1}.  LDS: 2 x 42 KB (h hi/lo) + 64 KB (x tile) = 148 KB.
 //   Wp / W4p / bp / a4part layouts are k_lstm_h's (the 4-wave "quarter" s = wave & 3 indexes them).
+#ifndef C3R_W8_ASYNC
+#define C3R_W8_ASYNC 1       // k_lstm2_w8: 1 = no workgroup barriers inside the time loop — the wavefronts meet through three LDS counters (x_t read by
+                             // all / x_{t+1} landed / h_t written by all), so that one wavefront's cell update runs under its SIMD partner's MFMAs
+#endif
+// Counters in LDS that only grow: arrive = release + one increment per wavefront, wait = spin until the count is reached, then acquire.
+__device__ __forceinline__ void lds_arrive(int *c) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) atomicAdd(c, 1);
+}
+__device__ __forceinline__ void lds_wait(int *c, int target) {
+    // (bounded: a protocol error shows up as wrong numbers in the parity tests, not as a hung GPU)
+    for (int it = 0; it < (1 << 20) && __atomic_load_n(c, __ATOMIC_RELAXED) < target; ++it) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 template <int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict__ xin, const half8 *__restrict__ Wp,
                                                       const float *__restrict__ bp, int n, const half8 *__restrict__ W4p,
@@ -709,6 +724,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
     __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
     __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][WG_SITES][HP];
     __shared__ __attribute__((aligned(16))) _Float16 xs[2][KC][WG_SITES][8];      // [plane][k/8][site][8]
+    __shared__ int s_ctr[4];        // C3R_W8_ASYNC: [0] wavefronts done reading x_t, [1] x DMAs landed, [2] wavefronts done writing h_t
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
@@ -720,6 +736,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
     const size_t plane_in = (size_t)ns * NET_T * INP;
 
     for (int i = tid; i < WG_SITES * HP; i += 512) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
+    if (tid < 4) s_ctr[tid] = 0;
 
     int xsite = site0 + lane;
     if (xsite >= n) xsite = n - 1;
@@ -730,6 +747,16 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 #pragma unroll
         for (int r = 0; r < 2 * KC / 8; ++r) {
             const int row = wave * (2 * KC / 8) + r, pl = row / KC, kc = row % KC;
+            const _Float16 *src = xin + (size_t)pl * plane_in + (((size_t)tt_ * KC + kc) * ns + xsite) * 8;
+            __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)&xs[pl][kc][0][0], 16, 0, 0);
+        }
+    };
+    auto dma_x16 = [&](int tt_) {          // C3R_W8_ASYNC: all 64 rows from the four 3-tile wavefronts (they finish their K loop first)
+        typedef const _Float16 __attribute__((address_space(1))) *gp_t;
+        typedef _Float16 __attribute__((address_space(3))) *lp_t;
+#pragma unroll
+        for (int r = 0; r < 2 * KC / 4; ++r) {
+            const int row = (wave & 3) * (2 * KC / 4) + r, pl = row / KC, kc = row % KC;
             const _Float16 *src = xin + (size_t)pl * plane_in + (((size_t)tt_ * KC + kc) * ns + xsite) * 8;
             __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)&xs[pl][kc][0][0], 16, 0, 0);
         }
@@ -833,6 +860,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
                 }
             };
 
+            if (C3R_W8_ASYNC && step > 0) lds_wait(&s_ctr[1], 4 * step);      // x_t has landed (four DMA wavefronts per step)
             floatx16 acc[NT][SB];
             {
                 floatx16 z;
@@ -907,6 +935,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 #define C3R_STEP(G)                                                                                              \
     if constexpr ((G) < NG) {                                                                                     \
         C3R_FENCE();                                                                                              \
+        if constexpr (C3R_W8_ASYNC && (G) + PD == NGX) { lds_wait(&s_ctr[2], 8 * step); C3R_FENCE(); }   /* h_{t-1} is complete */ \
         if constexpr ((G) + PD < NG) { C3R_LOAD((G) + PD); }                                                      \
         mma(ah[(G) % (PD + 1)], al[(G) % (PD + 1)], bh[(G) % (PD + 1)], bl[(G) % (PD + 1)], (G) >= NGX, ((G) & 1) != 0);  \
         if constexpr ((G) + PD < NG) {                                                                            \
@@ -917,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
             /* after this barrier every wavefront is done with x_t (the 2-tile wavefronts wait here for the     */ \
             /* 3-tile ones, which then have the matrix pipe to themselves: no pipe time is lost)                */ \
             C3R_FENCE();                                                                                          \
-            __syncthreads();                                                                                      \
+            if constexpr (C3R_W8_ASYNC) lds_arrive(&s_ctr[0]); else __syncthreads();                              \
         }                                                                                                         \
     }
             C3R_PRE(0) C3R_PRE(1) C3R_PRE(2)
@@ -931,7 +960,9 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 #undef C3R_FENCE
             // x_{t+1} by LDS-DMA now, so that no weight load queues behind it (vmcnt retires in order): it lands during the
             // cell update
-            if (step + 1 < NET_T && !(ABL & 64)) dma_x(dir ? NET_T - 2 - step : step + 1);
+            if constexpr (C3R_W8_ASYNC) {
+                if (!L4T && step + 1 < NET_T) { lds_wait(&s_ctr[0], 8 * (step + 1)); dma_x16(dir ? NET_T - 2 - step : step + 1); }      // (everyone is done with x_t)
+            } else if (step + 1 < NET_T && !(ABL & 64)) dma_x(dir ? NET_T - 2 - step : step + 1);
             // ---- lane-local cell update, one tile at a time (see k_lstm_h); cell state in registers
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
@@ -987,10 +1018,16 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
                     *(half4 *)&hb_lo[nxt][32 * sb + j][8 * (sq * NTQ + TOFF + tt) + 4 * hh] = vl;
                 }
             }
+            if constexpr (C3R_W8_ASYNC) {
+                lds_arrive(&s_ctr[2]);                                                  // my share of h_t is in LDS
+                if (!L4T && step + 1 < NET_T) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_arrive(&s_ctr[1]); }      // my share of x_{t+1} has landed
+            } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // x_{t+1} has landed (LDS-DMA is tracked by vmcnt)
             __syncthreads();                                       // h_t complete; everyone is done with h_{t-1}
+            }
         }
         if constexpr (L4T) {
+            if constexpr (C3R_W8_ASYNC) lds_wait(&s_ctr[2], 8 * NET_T);
             // ---- the last step's h (buffer NET_T & 1) still owes its L4 contribution
             const int tl = dir ? 0 : NET_T - 1, hbuf = NET_T & 1;
             const half8 *w4 = W4p + (((size_t)(dir * NET_T + tl) * 4 + sq) * NGH) * 2 * 64 + lane;
@@ -1066,6 +1103,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
     __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
     __shared__ __attribute__((aligned(16))) intx4 hq[2][NKBH][2][2][WG_SITES];     // fp8 of h: [buffer][kb][term][part][site] 16 bytes
     __shared__ __attribute__((aligned(16))) _Float16 xs[2][KC][WG_SITES][8];      // [plane][row][site][16 bytes]
+    __shared__ int s_ctr[4];        // C3R_W8_ASYNC (see k_lstm2_w8): [0] done reading x_t, [1] x DMAs landed, [2] done writing h_t
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
@@ -1078,6 +1116,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 
     for (int i = tid; i < WG_SITES * HP; i += 512) (&hb_hi[0][0][0])[i] = (_Float16)0.f;
     for (int i = tid; i < NKBH * 2 * 2 * WG_SITES; i += 512) (&hq[0][0][0][0][0])[i] = intx4{0, 0, 0, 0};
+    if (tid < 4) s_ctr[tid] = 0;
 
     int xsite = site0 + lane;
     if (xsite >= n) xsite = n - 1;
@@ -1087,6 +1126,16 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 #pragma unroll
         for (int r = 0; r < 2 * KC / 8; ++r) {
             const int row = wave * (2 * KC / 8) + r, pl = row / KC, kc = row % KC;
+            const _Float16 *src = xin + (size_t)pl * plane_in + (((size_t)tt_ * KC + kc) * ns + xsite) * 8;
+            __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)&xs[pl][kc][0][0], 16, 0, 0);
+        }
+    };
+    auto dma_x16 = [&](int tt_) {          // C3R_W8_ASYNC: all 64 rows from the four 3-tile wavefronts
+        typedef const _Float16 __attribute__((address_space(1))) *gp_t;
+        typedef _Float16 __attribute__((address_space(3))) *lp_t;
+#pragma unroll
+        for (int r = 0; r < 2 * KC / 4; ++r) {
+            const int row = (wave & 3) * (2 * KC / 4) + r, pl = row / KC, kc = row % KC;
             const _Float16 *src = xin + (size_t)pl * plane_in + (((size_t)tt_ * KC + kc) * ns + xsite) * 8;
             __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)&xs[pl][kc][0][0], 16, 0, 0);
         }
@@ -1150,6 +1199,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             const int tprev = step ? (dir ? t + 1 : t - 1) : t;
             const int cur = step & 1, nxt = cur ^ 1;
 
+            if (C3R_W8_ASYNC && step > 0) lds_wait(&s_ctr[1], 4 * step);      // x_t has landed
             half8 ah[PD + 1][NTH], bh[PD + 1][SB];
             intx8 a8[NTH], b8[SB];
             int sc[NTH];
@@ -1256,6 +1306,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 #define C3R_STEP(G)                                                                                              \
     if constexpr ((G) < NG) {                                                                                     \
         C3R_FENCE();                                                                                              \
+        if constexpr (C3R_W8_ASYNC && (G) + PD == NGX) { lds_wait(&s_ctr[2], 8 * step); C3R_FENCE(); }   /* h_{t-1} is complete */ \
         if constexpr (PD == 0 || (G) + PD < NG) { load(std::integral_constant<int, (G) + PD>{}, ah[((G) + PD) % (PD + 1)], bh[((G) + PD) % (PD + 1)]); } \
         mma(std::integral_constant<int, (G)>{}, ah[(G) % (PD + 1)], bh[(G) % (PD + 1)]);                          \
         if constexpr (PD > 0 && (G) + PD < NG && (((G) & 1) || !C3R_MX_EVEN_BURST)) {                              \
@@ -1266,7 +1317,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
         if constexpr ((G) == NGX - 1) {                                                                           \
             C3R_FENCE();                                                                                          \
             C3R_TPH(0);                                                                                           \
-            __syncthreads();     /* every wavefront is done with x_t */                                           \
+            if constexpr (C3R_W8_ASYNC) lds_arrive(&s_ctr[0]); else __syncthreads();     /* done with x_t */        \
             C3R_TPH(1);                                                                                           \
         }                                                                                                         \
     }
@@ -1278,7 +1329,9 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 #undef C3R_STEP
 #undef C3R_FENCE
             C3R_TPH(2);
-            if (step + 1 < NET_T) dma_x(dir ? NET_T - 2 - step : step + 1);      // lands during the cell update
+            if constexpr (C3R_W8_ASYNC) {
+                if (!L4T && step + 1 < NET_T) { lds_wait(&s_ctr[0], 8 * (step + 1)); dma_x16(dir ? NET_T - 2 - step : step + 1); }
+            } else if (step + 1 < NET_T) dma_x(dir ? NET_T - 2 - step : step + 1);      // lands during the cell update
             // ---- lane-local cell update (k_lstm2_w8's), h_t to LDS as f16 plus the two fp8 bytes per unit
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
@@ -1334,9 +1387,15 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
                 }
             }
             C3R_TPH(3);
+            if constexpr (C3R_W8_ASYNC) {
+                lds_arrive(&s_ctr[2]);
+                if (!L4T && step + 1 < NET_T) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_arrive(&s_ctr[1]); }
+                C3R_TPH(4);
+            } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // x_{t+1} has landed (LDS-DMA is tracked by vmcnt)
             C3R_TPH(4);
             __syncthreads();                                       // h_t complete; everyone is done with h_{t-1}
+            }
             C3R_TPH(5);
         }
 #ifdef C3R_MX_TIMING
@@ -1347,6 +1406,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 #endif
 #undef C3R_TPH
         if constexpr (L4T) {
+            if constexpr (C3R_W8_ASYNC) lds_wait(&s_ctr[2], 8 * NET_T);
             // ---- the last step's h (buffer NET_T & 1) still owes its L4 contribution
             const int tl = dir ? 0 : NET_T - 1, hbuf = NET_T & 1;
             const half8 *w4 = W4p + (((size_t)(dir * NET_T + tl) * 4 + sq) * NGH) * 2 * 64 + lane;
