@@ -710,7 +710,7 @@ __device__ __forceinline__ void lds_arrive(int *c) {
 }
 __device__ __forceinline__ void lds_wait(int *c, int target) {
     // (bounded: a protocol error shows up as wrong numbers in the parity tests, not as a hung GPU)
-    for (int it = 0; it < (1 << 20) && __atomic_load_n(c, __ATOMIC_RELAXED) < target; ++it) __builtin_amdgcn_s_sleep(1);
+    for (int it = 0; it < (1 << 24) && __atomic_load_n(c, __ATOMIC_RELAXED) < target; ++it) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
