@@ -1748,6 +1748,12 @@ __global__ __launch_bounds__(512 * TEAMS, C3R_L1_W8_OCC) void k_lstm1_w8(const i
     // TEAMS == 2: the two teams of eight wavefronts run half a step apart — one team's cell update (VALU, transcendentals) under
     // the other's K loop (matrix pipe) — and every phase ends in a workgroup-wide barrier that keeps them there
     if (TEAMS > 1 && team == 1) __syncthreads();
+#ifdef C3R_L1_TIMING
+    long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define C3R_TPH(K) do { const long long now_ = clock64(); tph[K] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define C3R_TPH(K) do {} while (0)
+#endif
     for (int step = 0; step < NET_T; ++step) {
         const int t = dir ? NET_T - 1 - step : step;
         const int cur = step & 1, nxt = cur ^ 1;
@@ -1811,14 +1817,16 @@ __global__ __launch_bounds__(512 * TEAMS, C3R_L1_W8_OCC) void k_lstm1_w8(const i
             sched_interleave<NMM, NT * 2, ((G) + PD < NGX ? SB : SB * 2)>();                                      \
         }                                                                                                         \
     }
+        C3R_TPH(0);
         if constexpr (PD > 0) { C3R_LOAD(0); }
-        C3R_STEP(0) C3R_STEP(1) C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
+        C3R_STEP(0) C3R_STEP(1) C3R_TPH(1); C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
         static_assert(NG == 10, "extend the C3R_STEP list");
         C3R_FENCE();
 #undef C3R_STEP
 #undef C3R_LOAD
 #undef C3R_FENCE
         if (TEAMS > 1) __syncthreads();                        // phase boundary: K loop -> cell update
+        C3R_TPH(2);
         // ---- lane-local cell update, one tile at a time; h_t to LDS (both halves) and to the y1 planes, straight from registers
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
@@ -1889,10 +1897,20 @@ __global__ __launch_bounds__(512 * TEAMS, C3R_L1_W8_OCC) void k_lstm1_w8(const i
                 }
             }
         }
+        C3R_TPH(3);
         if (step + 1 < NET_T) x_store(nxt);
+        C3R_TPH(4);
         if (!(TEAMS > 1 && team == 1 && step == NET_T - 1))
             __syncthreads();                                   // h_t and x_{t+1} complete; everyone is done with h_{t-1} and x_t
+        C3R_TPH(5);
     }
+#ifdef C3R_L1_TIMING
+    if (blockIdx.x == 0 && blockIdx.y == 7 && lane == 0) {      // probe build only: the sink sits behind the y1 planes (tools/lstm_probe_l1w8.hip)
+        long long *sink = reinterpret_cast<long long *>(y + 2 * plane_out) + wave * 6;
+        for (int q = 0; q < 6; ++q) sink[q] = tph[q];
+    }
+#endif
+#undef C3R_TPH
 }
 
 // ------------------------------------------------------------------------------------------------

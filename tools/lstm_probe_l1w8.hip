@@ -29,7 +29,7 @@ int main(int argc, char **argv) {
     const int ns = (n + 127) / 128 * 128;
     const size_t ny = (size_t)ns * 33 * 256 * 2, nw = (size_t)2 * 16 * 10 * 2 * 64;
     int32_t *x; _Float16 *y; half8 *w;
-    hipMalloc(&x, (size_t)n * 33 * 18 * 4); hipMalloc(&y, ny * 2); hipMalloc(&w, nw * 16);
+    hipMalloc(&x, (size_t)n * 33 * 18 * 4); hipMalloc(&y, ny * 2 + 4096); hipMalloc(&w, nw * 16);
     {
         std::vector<int32_t> h((size_t)n * 33 * 18);
         unsigned long long s = 12345;
@@ -54,5 +54,18 @@ int main(int argc, char **argv) {
         {"l1w8 two teams (again)", run<0, 2>(x, w, y, n, 3)},
     };
     for (auto &e : r) printf("%-26s %8.3f ms  executed %6.1f TFLOP/s\n", e.name, e.ms, 3 * flop / e.ms / 1e9);
+#ifdef C3R_L1_TIMING
+    {   // where one workgroup's eight wavefronts spend a step (the last launch was the full kernel, TEAMS = 1 ... re-run it)
+        (void)run<0>(x, w, y, n, 1);
+        long long t[48];
+        hipMemcpy(t, (char *)y + ny * 2, sizeof t, hipMemcpyDeviceToHost);
+        const char *nm[6] = {"top (x fetch)", "x part", "h part", "cell + y1", "x store", "barrier"};
+        printf("clocks per step (workgroup (dir 0, group 7)), by wavefront:\n%-14s", "");
+        for (int wv = 0; wv < 8; ++wv) printf("  wave %d", wv);
+        printf("\n");
+        for (int ph = 0; ph < 6; ++ph) { printf("%-14s", nm[ph]); for (int wv = 0; wv < 8; ++wv) printf(" %7lld", t[wv * 6 + ph] / 33); printf("\n"); }
+        printf("%-14s", "total"); for (int wv = 0; wv < 8; ++wv) { long long sm = 0; for (int ph = 0; ph < 6; ++ph) sm += t[wv * 6 + ph]; printf(" %7lld", sm / 33); } printf("\n");
+    }
+#endif
     return 0;
 }
