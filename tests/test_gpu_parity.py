@@ -230,6 +230,8 @@ def test_precision_f16_f8_opt_in_and_auto_guard(eng):
             mode, cal = eng.precision()
             assert mode == "f16+f8" and 0 <= cal <= 4e-5, (mode, cal)
             assert np.array_equal(eng.infer(tensors=X), eng.infer(tensors=X))
+            for nr in (1, 33, 70, 129):        # ragged batches: partial site blocks, partial workgroups
+                assert float(np.abs(eng.infer(tensors=X[:nr]) - po[:nr]).max()) < 1e-4, (C, nr)
             # three times the norm: the guard must refuse, and what runs instead must still meet the tolerance
             w3 = (3.0 * w).astype(np.float32)
             eng.load_weights(w3, C)
