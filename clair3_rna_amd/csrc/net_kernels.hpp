@@ -87,6 +87,9 @@ constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 #ifndef C3R_DIR_ILV
 #define C3R_DIR_ILV 1        // k_lstm1_w8 / k_lstm2_w8: grid (2, groups) — the two directions of a site group are dispatched back to back
 #endif
+#ifndef C3R_L1_RS
+#define C3R_L1_RS 1          // layer 1 through k_lstm1_rs (register-stationary weights, 16 wavefronts) instead of k_lstm1_w8
+#endif
 #ifndef C3R_L2_W8
 #define C3R_L2_W8 1          // layer 2 through k_lstm2_w8 (two wavefronts per SIMD) instead of k_lstm_h
 #endif
@@ -1914,6 +1917,149 @@ __global__ __launch_bounds__(512 * TEAMS, C3R_L1_W8_OCC) void k_lstm1_w8(const i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Layer 1 with REGISTER-STATIONARY weights: k_lstm1_rs, 1024 threads = 16 wavefronts (four per SIMD, 128 registers), 64 sites x one
+// direction per workgroup, one workgroup per CU.  Layer 1 is small enough for it: a wavefront owns ONE gate-row tile and loads that
+// tile's split-f16 weights — 10 k-groups x (hi, lo) = 80 registers — once, before the time loop; there is no weight stream at all.
+// k_lstm1_w8 at 128 registers has no room for a prefetch ring, so each of its k-groups is "load, wait an L2 round trip, use": 13-16 k
+// of a step's 21.7 k clocks (tools/lstm_probe_l1w8 -DC3R_L1_TIMING).  The price: the workgroup's two 32-site blocks go through one
+// accumulator one after the other (no registers for two), and every B fragment is read from LDS by sixteen wavefronts.
+// Same Wp layout as k_lstm1_w8 ([dir][quarter][g][tile(4)][hi|lo][lane]; tile blk = 4 quarter + tile), bias on input slot CIN.
+template <int CIN, bool YQ = false>
+__global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp, _Float16 *__restrict__ y, int n, int nstride) {
+    constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NTQ = 4, WG_SITES = 64, HV = H / 8, XP = 40;
+    constexpr int NPC = (CIN + 1) / 2;
+    static_assert(CIN % 2 == 0 && CIN < 32 && WG_SITES * NPC <= 1024, "even channel count, one free slot for the bias, one x piece per thread");
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][WG_SITES][HP];
+    __shared__ __attribute__((aligned(16))) _Float16 xs[2][WG_SITES][XP];
+    const int tid = threadIdx.x, lane = tid & 63, blk = tid >> 6;      // blk: the wavefront's tile of the direction (units 8 blk .. 8 blk + 7)
+    const int j = lane & 31, hh = lane >> 5;
+    const int dir = C3R_DIR_ILV ? blockIdx.x : blockIdx.y;
+    const int site0 = (C3R_DIR_ILV ? blockIdx.y : blockIdx.x) * WG_SITES;
+    const size_t plane_out = (size_t)nstride * NET_T * 2 * H;
+
+    for (int i = tid; i < WG_SITES * HP; i += 1024) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
+    for (int i = tid; i < 2 * WG_SITES * XP; i += 1024) (&xs[0][0][0])[i] = ((i % XP) == CIN) ? (_Float16)1.f : (_Float16)0.f;
+
+    half8 wh[NG], wl[NG];
+    {
+        const half8 *wb = Wp + (((size_t)(dir * 4 + (blk >> 2)) * NG) * NTQ + (blk & 3)) * 2 * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { wh[g] = wb[((size_t)g * NTQ * 2 + 0) * 64]; wl[g] = wb[((size_t)g * NTQ * 2 + 1) * 64]; }
+    }
+    float cst[2][4];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cst[sb][q] = 0.f;
+
+    // x staging: one 8-byte piece (two int32 counts of row (site, t)) per thread
+    typedef int int2v __attribute__((ext_vector_type(2)));
+    int2v xr = {0, 0};
+    const bool xmine = tid < WG_SITES * NPC;
+    auto x_fetch = [&](int tt_) {
+        if (xmine) {
+            int sj = site0 + tid / NPC;
+            if (sj >= n) sj = n - 1;
+            xr = *(const int2v *)(xin + ((size_t)sj * NET_T + tt_) * CIN + 2 * (tid % NPC));
+        }
+    };
+    auto x_store = [&](int buf) {
+        if (xmine) {
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            half2v v;
+            v[0] = (_Float16)(float)xr[0]; v[1] = (_Float16)(float)xr[1];
+            *(half2v *)&xs[buf][tid / NPC][2 * (tid % NPC)] = v;
+        }
+    };
+    __syncthreads();
+    x_fetch(dir ? NET_T - 1 : 0);
+    x_store(0);
+    __syncthreads();
+
+    for (int step = 0; step < NET_T; ++step) {
+        const int t = dir ? NET_T - 1 - step : step;
+        const int cur = step & 1, nxt = cur ^ 1;
+        if (step + 1 < NET_T) x_fetch(dir ? NET_T - 2 - step : step + 1);       // lands under the K loops
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            floatx16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g < NGX) {                                     // (the int32 input has no lo half)
+                    const half8 bh = *(const half8 *)&xs[cur][32 * sb + j][16 * g + 8 * hh];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[g], bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[g], bh, acc, 0, 0, 0);
+                } else {
+                    const half8 bh = *(const half8 *)&hb_hi[cur][32 * sb + j][16 * (g - NGX) + 8 * hh];
+                    const half8 bl = *(const half8 *)&hb_lo[cur][32 * sb + j][16 * (g - NGX) + 8 * hh];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[g], bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[g], bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[g], bl, acc, 0, 0, 0);
+                }
+            }
+            // ---- lane-local cell update of the block (k_lstm1_w8's arithmetic, four units per lane)
+            constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
+            float ei[4], ef[4], eg[4], eo[4], cq[4], hval[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cq[u] = cst[sb][u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ei[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[4 * u + 0]), 1e18f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ef[u] = __builtin_amdgcn_exp2f(K1 * acc[4 * u + 1]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(K2 * acc[4 * u + 2]), 1e18f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) eo[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[4 * u + 3]), 1e18f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ei[u] = gate_frac(ei[u], eg[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ef[u] = __builtin_amdgcn_rcpf(1.0f + ef[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cq[u] = fmaf(ef[u], cq[u], ei[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[u]), 1e18f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) hval[u] = gate_frac(eo[u], eg[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cst[sb][u] = cq[u];
+            half4 vh, vl;
+            float lo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                vh[q] = (_Float16)hval[q];
+                float d = hval[q] - (float)vh[q];
+                asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
+                vl[q] = (_Float16)d;
+                lo[q] = d * 262144.f;
+            }
+            *(half4 *)&hb_hi[nxt][32 * sb + j][8 * blk + 4 * hh] = vh;
+            *(half4 *)&hb_lo[nxt][32 * sb + j][8 * blk + 4 * hh] = vl;
+            _Float16 *yp = y + ((size_t)t * (2 * HV) + dir * HV + blk) * nstride * 8 + (uint32_t)(site0 + 32 * sb + j) * 8 + 4 * hh;
+            *(half4 *)yp = vh;
+            if constexpr (!YQ) {
+                *(half4 *)(yp + plane_out) = vl;
+            } else {                                     // the fp8 plane precision 2's layer 2 reads (see k_lstm1_w8)
+                int w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], 0, false);
+                w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], w_lo, true);
+                int w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[0] * 64.f, hval[1] * 64.f, 0, false);
+                w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[2] * 64.f, hval[3] * 64.f, w_hi, true);
+                const int row0 = (dir * 4 + (blk >> 2)) * 4 + ((blk & 3) >> 1);
+                _Float16 *qp = y + plane_out + ((size_t)t * (2 * HV) + row0) * nstride * 8 + (uint32_t)(site0 + 32 * sb + j) * 8 + 4 * (blk & 1) + 2 * hh;
+                *(int *)qp = w_lo;
+                *(int *)(qp + (size_t)2 * nstride * 8) = w_hi;
+            }
+        }
+        if (step + 1 < NET_T) x_store(nxt);
+        __syncthreads();                                       // h_t and x_{t+1} complete; everyone is done with h_{t-1} and x_t (LDS counters
+                                                               // instead of this barrier, as in layer 2, measured slower: 6.3 against 5.8 ms)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // L4: a4[n][128] = selu(y2[n][10560] * W4 + b4).  grid = ceil(n/32), block = 256 (wave = 32-row block
 // of output units).  Same transposed MFMA scheme; B operand straight from global (each site row is
 // streamed sequentially, 16 B per lane).
@@ -2504,7 +2650,10 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
         const dim3 g2(2, grid.x);
         static_assert(C3R_DIR_ILV == 1, "the precision-2 kernels are launched on the (2, groups) grid");
         prof("k_lstm1", 0);
-        if (s.channels == C3R_CH)
+        if (C3R_L1_RS) {
+            if (s.channels == C3R_CH) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+        } else if (s.channels == C3R_CH)
             hipLaunchKernelGGL((k_lstm1_w8<C3R_CH, 0, 1, true>), g2, dim3(512), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
         else
             hipLaunchKernelGGL((k_lstm1_w8<C3R_CH_PHASED, 0, 1, true>), g2, dim3(512), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
@@ -2524,6 +2673,10 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
         prof("k_lstm1", 0);
 #if C3R_L1_W8
         const dim3 gridn = C3R_L1_TEAMS == 2 ? grid1 : grid, gridw = C3R_DIR_ILV ? dim3(2, gridn.x) : gridn;
+        if (C3R_L1_RS) {
+            if (s.channels == C3R_CH) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH>), gridw, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED>), gridw, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+        } else
         if (s.channels == C3R_CH)
             hipLaunchKernelGGL((k_lstm1_w8<C3R_CH, 0, C3R_L1_TEAMS>), gridw, dim3(512 * C3R_L1_TEAMS), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
         else
