@@ -1933,6 +1933,9 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
     __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][WG_SITES][HP];
     __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][WG_SITES][HP];
     __shared__ __attribute__((aligned(16))) _Float16 xs[2][WG_SITES][XP];
+    // the cell state lives in LDS (one float4 per lane, block and wavefront: 32 KB of the 80 KB this workgroup leaves free): its 8 registers
+    // pay for the second B-operand buffer below
+    __shared__ __attribute__((aligned(16))) float4 s_c[16][2][64];
     const int tid = threadIdx.x, lane = tid & 63, blk = tid >> 6;      // blk: the wavefront's tile of the direction (units 8 blk .. 8 blk + 7)
     const int j = lane & 31, hh = lane >> 5;
     const int dir = C3R_DIR_ILV ? blockIdx.x : blockIdx.y;
@@ -1948,11 +1951,8 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
 #pragma unroll
         for (int g = 0; g < NG; ++g) { wh[g] = wb[((size_t)g * NTQ * 2 + 0) * 64]; wl[g] = wb[((size_t)g * NTQ * 2 + 1) * 64]; }
     }
-    float cst[2][4];
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cst[sb][q] = 0.f;
+    s_c[blk][0][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_c[blk][1][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // x staging: one 8-byte piece (two int32 counts of row (site, t)) per thread
     typedef int int2v __attribute__((ext_vector_type(2)));
@@ -1977,7 +1977,17 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
     x_fetch(dir ? NET_T - 1 : 0);
     x_store(0);
     __syncthreads();
+#ifndef C3R_L1_RS_PRIO
+#define C3R_L1_RS_PRIO 0     // k_lstm1_rs: raise the priority of the wavefronts that arrive last on their SIMD (blk >= this value; 0: off)
+#endif
+    if (C3R_L1_RS_PRIO > 0 && blk >= C3R_L1_RS_PRIO) __builtin_amdgcn_s_setprio(1);
 
+#ifdef C3R_L1_TIMING
+    long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define C3R_TPH(K) do { const long long now_ = clock64(); tph[K] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define C3R_TPH(K) do {} while (0)
+#endif
     for (int step = 0; step < NET_T; ++step) {
         const int t = dir ? NET_T - 1 - step : step;
         const int cur = step & 1, nxt = cur ^ 1;
@@ -1987,25 +1997,29 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
             floatx16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g < NGX) {                                     // (the int32 input has no lo half)
-                    const half8 bh = *(const half8 *)&xs[cur][32 * sb + j][16 * g + 8 * hh];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[g], bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[g], bh, acc, 0, 0, 0);
-                } else {
-                    const half8 bh = *(const half8 *)&hb_hi[cur][32 * sb + j][16 * (g - NGX) + 8 * hh];
-                    const half8 bl = *(const half8 *)&hb_lo[cur][32 * sb + j][16 * (g - NGX) + 8 * hh];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[g], bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[g], bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[g], bl, acc, 0, 0, 0);
-                }
-            }
+            // B operands double-buffered: group g + 1's fragments are requested before group g's MFMAs are issued
+            half8 bh[2], bl[2];
+            auto ldb = [&](auto gc, half8 &h, half8 &l) {
+                constexpr int G = decltype(gc)::value;
+                if constexpr (G < NGX) h = *(const half8 *)&xs[cur][32 * sb + j][16 * G + 8 * hh];
+                else { h = *(const half8 *)&hb_hi[cur][32 * sb + j][16 * (G - NGX) + 8 * hh]; l = *(const half8 *)&hb_lo[cur][32 * sb + j][16 * (G - NGX) + 8 * hh]; }
+            };
+            ldb(std::integral_constant<int, 0>{}, bh[0], bl[0]);
+            static_for<0, NG>([&](auto gc) {
+                constexpr int G = decltype(gc)::value;
+                if constexpr (G + 1 < NG) ldb(std::integral_constant<int, G + 1>{}, bh[(G + 1) & 1], bl[(G + 1) & 1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[G], bh[G & 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[G], bh[G & 1], acc, 0, 0, 0);
+                if constexpr (G >= NGX) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[G], bl[G & 1], acc, 0, 0, 0);      // (the int32 input has no lo half)
+            });
+            C3R_TPH(2 * sb);
             // ---- lane-local cell update of the block (k_lstm1_w8's arithmetic, four units per lane)
             constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
             float ei[4], ef[4], eg[4], eo[4], cq[4], hval[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cq[u] = cst[sb][u];
+            {
+                const float4 c4 = s_c[blk][sb][lane];
+                cq[0] = c4.x; cq[1] = c4.y; cq[2] = c4.z; cq[3] = c4.w;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) ei[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[4 * u + 0]), 1e18f);
 #pragma unroll
@@ -2024,8 +2038,7 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
             for (int u = 0; u < 4; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[u]), 1e18f);
 #pragma unroll
             for (int u = 0; u < 4; ++u) hval[u] = gate_frac(eo[u], eg[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cst[sb][u] = cq[u];
+            s_c[blk][sb][lane] = make_float4(cq[0], cq[1], cq[2], cq[3]);
             half4 vh, vl;
             float lo[4];
 #pragma unroll
@@ -2052,11 +2065,21 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
                 *(int *)qp = w_lo;
                 *(int *)(qp + (size_t)2 * nstride * 8) = w_hi;
             }
+            C3R_TPH(2 * sb + 1);
         }
+        C3R_TPH(4);
         if (step + 1 < NET_T) x_store(nxt);
         __syncthreads();                                       // h_t and x_{t+1} complete; everyone is done with h_{t-1} and x_t (LDS counters
                                                                // instead of this barrier, as in layer 2, measured slower: 6.3 against 5.8 ms)
+        C3R_TPH(5);
     }
+#ifdef C3R_L1_TIMING
+    if (blockIdx.x == 0 && blockIdx.y == 7 && lane == 0) {      // probe build only: the sink sits behind the y1 planes (tools/lstm_probe_l1rs.hip)
+        long long *sink = reinterpret_cast<long long *>(y + 2 * plane_out) + blk * 6;
+        for (int q = 0; q < 6; ++q) sink[q] = tph[q];
+    }
+#endif
+#undef C3R_TPH
 }
 
 // ------------------------------------------------------------------------------------------------
