@@ -36,6 +36,11 @@ from time import time
 from . import io, sort_vcf, vcf
 from .call_var_bam import existing, resolve_region
 
+
+def _env_precision():
+    from . import capi           # (ctypes declarations only: libc3r.so is opened when an Engine is made)
+    return capi.env_precision()
+
 MAJOR_CONTIGS_ORDER = ["chr" + str(a) for a in list(range(1, 23)) + ["X", "Y"]] + [str(a) for a in list(range(1, 23)) + ["X", "Y"]]
 CHUNK_SIZE = 5000000            # shared/param_p.py:91
 EXPAND = 33                     # param.no_of_positions: split_extend_bed widens every interval by one window
@@ -145,7 +150,7 @@ def build_parser():
     a("--readiportal_database_filter_tag", type=str, default=None)
     a("--no_compress", action="store_true", help="leave <prefix>.vcf uncompressed (tests)")
     a("--gpu_id", type=int, default=None, help="default: $C3R_DEVICE, else LOCAL_RANK under torch.distributed.run, else 0")
-    a("--gpu_precision", type=str, default=os.environ.get("C3R_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16+f8", "auto"],
+    a("--gpu_precision", type=str, default=_env_precision(), choices=["f32", "f16x3", "f16+f8", "auto"],
       help="network arithmetic (c3r_set_precision): f16x3 = fp32-equivalent split-f16 (default); auto = the faster fp8-corrected path where a "
            "calibration run through the loaded weights agrees with f16x3 to 4e-5, else f16x3")
     a("--fetch_threads", type=int, default=4)
@@ -424,8 +429,23 @@ def Run(args, log=None):
     results = []
     n_sites = t_fetch = t_dev = 0
     called = []
+    ctx_pools = [ThreadPoolExecutor(1) for _ in engines]
+    stop = threading.Event()
+
+    def stop_workers():
+        """Failure path: nothing may still be inside a c3r_* call (or queued to make one) when the engines are destroyed.  Queued
+        contigs are cancelled, the running ones finish, and the feeder — possibly parked on a look-ahead slot that a cancelled task
+        will never release — is told to stop and woken."""
+        stop.set()
+        for p_ in ctx_pools:
+            p_.shutdown(wait=True, cancel_futures=True)
+        for _ in range(len(contigs) + n_ctx + 2):
+            try:
+                slots.release()
+            except ValueError:           # (bounded semaphore: every slot is free again)
+                break
+
     try:
-        ctx_pools = [ThreadPoolExecutor(1) for _ in engines]
         with ThreadPoolExecutor(max(1, args.fetch_threads)) as fetch_pool:
             # A feeder takes the look-ahead slot BEFORE it submits a contig's fetch, strictly in calling order.  (Taken inside the
             # fetch workers, a later contig could grab the last slot while the one its context needs next was still waiting for
@@ -438,6 +458,8 @@ def Run(args, log=None):
                 try:
                     for i, c in enumerate(contigs):
                         slots.acquire()
+                        if stop.is_set():
+                            break
                         fut = fetch_pool.submit(fetch_task, c)
                         tasks[i] = ctx_pools[i % n_ctx].submit(context_task, engines[i % n_ctx], c, fut)
                         submitted[i].set()
@@ -449,20 +471,24 @@ def Run(args, log=None):
 
             feed = threading.Thread(target=feeder, name="c3r-feeder", daemon=True)
             feed.start()
-            for i, ctg in enumerate(contigs):                              # merge in calling order as the contigs come out
-                submitted[i].wait()
-                if tasks[i] is None:
-                    raise RuntimeError("contig %s was never submitted: %r" % (ctg, feeder_err[:1]))
-                rows = tasks[i].result()
-                tasks[i] = None
-                if rows is None:
-                    log("[WARNING] Contig name %s provided but no mapped reads found in BAM, skip!" % ctg)
-                    continue
-                t0 = time()
-                merge_contig(ctg, rows)
-                t_merge += time() - t0
-                mark(ctg, "merge", t0)
-                results.append((ctg, None))
+            try:
+                for i, ctg in enumerate(contigs):                          # merge in calling order as the contigs come out
+                    submitted[i].wait()
+                    if tasks[i] is None:
+                        raise RuntimeError("contig %s was never submitted: %r" % (ctg, feeder_err[:1]))
+                    rows = tasks[i].result()
+                    tasks[i] = None
+                    if rows is None:
+                        log("[WARNING] Contig name %s provided but no mapped reads found in BAM, skip!" % ctg)
+                        continue
+                    t0 = time()
+                    merge_contig(ctg, rows)
+                    t_merge += time() - t0
+                    mark(ctg, "merge", t0)
+                    results.append((ctg, None))
+            except BaseException:
+                stop_workers()           # before the fetch pool's own shutdown waits for fetches nobody will consume
+                raise
         for p_ in ctx_pools:
             p_.shutdown()
         n_sites, t_fetch, t_dev = stats["sites"], stats["fetch"], stats["dev"]
@@ -470,7 +496,10 @@ def Run(args, log=None):
         called = [c for c, _f in results]
     except Exception as e:               # with several ranks: reach the rendezvous first, then every rank fails
         work_err = e
+        stop_workers()                   # (idempotent) no thread is inside libc3r any more
         if world == 1:
+            for e_ in engines:
+                e_.close()
             raise
     for e in engines:
         e.close()

@@ -19,6 +19,11 @@ import numpy as np
 from . import altinfo, decode, io, vcf
 
 
+def _env_precision():
+    from . import capi           # (ctypes declarations only: libc3r.so is opened when an Engine is made)
+    return capi.env_precision()
+
+
 def str2bool(v):
     if isinstance(v, bool):
         return v
@@ -111,7 +116,7 @@ def build_parser():
     a('--delay', type=int, default=0)
     a('--use_gpu', type=str2bool, default=True)
     a('--gpu_id', type=int, default=int(os.environ.get("C3R_DEVICE", "0")))
-    a('--gpu_precision', type=str, default=os.environ.get("C3R_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16+f8", "auto"],
+    a('--gpu_precision', type=str, default=_env_precision(), choices=["f32", "f16x3", "f16+f8", "auto"],
       help="network arithmetic (include/c3r.h, c3r_set_precision): f16x3 = fp32-equivalent split-f16 (default); auto = the faster fp8-corrected "
            "path where a calibration run through the loaded weights agrees with f16x3 to 4e-5, else f16x3")
     a('--tensor_dump_fn', type=str, default=None, help="DEBUG: also write the create_tensor text lines here")

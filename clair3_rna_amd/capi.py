@@ -94,6 +94,15 @@ def load_library():
     return L
 
 
+def env_precision(default="f16x3"):
+    """The C3R_PRECISION environment default of the drivers' --gpu_precision flag, validated like the flag itself (argparse does
+    not run `choices` on defaults)."""
+    v = os.environ.get("C3R_PRECISION", default)
+    if v not in Engine.PRECISIONS:
+        raise SystemExit("C3R_PRECISION=%r: must be one of %s" % (v, ", ".join(sorted(Engine.PRECISIONS))))
+    return v
+
+
 def default_params():
     p = Params()
     load_library().c3r_default_params(C.byref(p))

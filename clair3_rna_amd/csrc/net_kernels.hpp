@@ -41,25 +41,7 @@ constexpr int NET_H2 = 160;
 constexpr int NET_T = C3R_WINDOW;          // 33 time steps
 constexpr int NET_SITES = 32;              // sites per MFMA column block
 constexpr int LSTM_SB = 2;                 // column blocks per wavefront in k_lstm
-constexpr int LSTM1H_SB = 2;               // layer 1 of the split-f16 path (3 measured slower: 9.9 vs 8.3 ms)
 constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
-// split-f16 K-loop schedule per layer: prefetch distance in k-groups, and whether the prefetch loads are interleaved
-// with the MFMAs (sched_group_barrier) or issued as one burst ahead of them.  Chosen by A/B runs of bench.py on one box.
-#ifndef C3R_L1_PD
-#define C3R_L1_PD 2
-#endif
-#ifndef C3R_L1_ILV
-#define C3R_L1_ILV false
-#endif
-#ifndef C3R_L1_SKEW
-#define C3R_L1_SKEW 1        // layer 1 through k_lstm1_skew (two site groups, skewed phases) instead of k_lstm_h
-#endif
-#ifndef C3R_L2_PD
-#define C3R_L2_PD 2
-#endif
-#ifndef C3R_L2_ILV
-#define C3R_L2_ILV true
-#endif
 #ifndef C3R_W8_PD
 #define C3R_W8_PD 1          // prefetch distance (k-groups) of k_lstm2_w8's operand ring
 #endif
@@ -69,29 +51,8 @@ constexpr int LSTM_SITES = NET_SITES * LSTM_SB;
 #ifndef C3R_W8_PRIO
 #define C3R_W8_PRIO 0        // 1: s_setprio 1 for the 3-tile wavefronts, 2: for the 2-tile wavefronts
 #endif
-#ifndef C3R_HEADS_MFMA
-#define C3R_HEADS_MFMA 1     // heads through k_heads_mfma (f32 MFMA) instead of the scalar k_heads
-#endif
-#ifndef C3R_L1_W8_PD
-#define C3R_L1_W8_PD 0       // k_lstm1_w8: operand prefetch distance in k-groups (0: load, then use — the 4-waves-per-SIMD build has no registers for a ring)
-#endif
-#ifndef C3R_L1_W8_OCC
-#define C3R_L1_W8_OCC 4      // k_lstm1_w8: wavefronts per SIMD the register budget is cut for (4 = TWO workgroups per CU: 128 registers, 2 x 78 KB of LDS)
-#endif
-#ifndef C3R_L1_W8
-#define C3R_L1_W8 1          // layer 1 through k_lstm1_w8 (two wavefronts per SIMD, x staged once per workgroup) instead of k_lstm1_skew
-#endif
-#ifndef C3R_L1_TEAMS
-#define C3R_L1_TEAMS 1       // k_lstm1_w8: 2 = one 1024-thread workgroup of two 64-site teams held half a step apart by phase barriers
-#endif
 #ifndef C3R_DIR_ILV
-#define C3R_DIR_ILV 1        // k_lstm1_w8 / k_lstm2_w8: grid (2, groups) — the two directions of a site group are dispatched back to back
-#endif
-#ifndef C3R_L1_RS
-#define C3R_L1_RS 1          // layer 1 through k_lstm1_rs (register-stationary weights, 16 wavefronts) instead of k_lstm1_w8
-#endif
-#ifndef C3R_L2_W8
-#define C3R_L2_W8 1          // layer 2 through k_lstm2_w8 (two wavefronts per SIMD) instead of k_lstm_h
+#define C3R_DIR_ILV 1        // k_lstm1_rs / k_lstm2_w8: grid (2, groups) — the two directions of a site group are dispatched back to back
 #endif
 constexpr int NET_FLAT = NET_T * 2 * NET_H2;   // 10560
 constexpr int NET_L4 = 128;
@@ -333,361 +294,21 @@ __device__ __forceinline__ void sched_interleave() {
     }
 }
 
-// Fused bidirectional LSTM layer on split-f16 operands.  Same decomposition as k_lstm (32-row gate blocks permuted for
-// a lane-local cell update, SB 32-site blocks per wavefront, h double-buffered in LDS, one barrier per step), with
-//   Wp : [dir][wave][g][tile][hi|lo][64 lanes] half8  (k-groups of 16; lane half hh owns k = 16g + 8hh + 0..7)
-//   xin: INT_IN ? int32 [n][33][CIN] (exact in f16, lo = 0)  :  hi plane then lo plane, each f16 [33][CIN/8][n][8]
-//   y  : hi plane then lo plane, each f16 [33][2H/8][n][8]
-// FC4 (layer 2 only): the flatten + Dense(128) layer L4 is fused in.  After every step the fresh h_t (already in LDS as
-// hi/lo halves) is multiplied by the [160 x 128] slice of W4 that belongs to (t, direction) and accumulated in
-// persistent registers; y2 is never written.  Each workgroup ends by storing its [sites][128] partial pre-activation
-// for its direction; k_heads adds the two directions and the bias and applies selu.
-//   W4p: [dir][t][blk(4)][g(H/16)][hi|lo][64 lanes] half8, x 2^12;   a4part: fp32 [n][2][128]
-template <int INP, int CIN, int H, bool INT_IN, int SB = 2, int ABL = 0, bool FC4 = false, int PD = 1, bool ILV = false>
-__global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin, const half8 *__restrict__ Wp,
-                                                    const float *__restrict__ bp, _Float16 *__restrict__ y, int n,
-                                                    const half8 *__restrict__ W4p = nullptr, float *__restrict__ a4part = nullptr,
-                                                    int nstride = 0 /* site stride of the [t][k/8][site][8] planes; 0 = n */) {
-    constexpr int NGX = INP / 16;
-    constexpr int NGH = H / 16;
-    constexpr int NG = NGX + NGH;
-    constexpr int HP = H + 8;              // LDS row stride in halves: (H+8)*2 B keeps ds_read_b128 conflict-free
-    constexpr int NBLK = 4 * H / 32;
-    constexpr int NT = NBLK / 4;
-    constexpr int WG_SITES = 32 * SB;
-    static_assert(INP % 32 == 0 && H % 32 == 0, "shape: even 16-wide k-group counts for the ping-pong pipeline");
-    // XLDS (layer 2): x_t is staged in LDS one step ahead by LDS-DMA (global_load_lds), shared by the four wavefronts.
-    // The y1 planes stream from HBM (15 GB per pass): fetched straight into registers two k-groups ahead their ~2 us
-    // loaded latency was exposed in every step, and every wavefront fetched the same 64 KB.  The LDS budget for the
-    // 64 KB tile comes from single-buffering h (a second barrier per step separates its readers from its writers).
-    constexpr bool XLDS = FC4 && !INT_IN && !(ABL & 64);
-    constexpr int NHB = XLDS ? 1 : 2;
-    constexpr int KC = CIN / 8;
-    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[NHB][WG_SITES][HP];
-    __shared__ __attribute__((aligned(16))) _Float16 hb_lo[NHB][WG_SITES][HP];
-    __shared__ __attribute__((aligned(16))) _Float16 xs[XLDS ? 2 : 1][XLDS ? KC : 1][XLDS ? WG_SITES : 1][8];   // [plane][k/8][site][8]
-    // cell state: registers, or LDS in the FC4 variant (its persistent L4 accumulators need the registers)
-    constexpr int CP = H + 4;
-    __shared__ __attribute__((aligned(16))) float cbuf[FC4 ? WG_SITES : 1][FC4 ? CP : 4];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hh = lane >> 5;
-    const int dir = blockIdx.y;
-    const int site0 = blockIdx.x * WG_SITES;
-    const int ns = nstride ? nstride : n;
-    const size_t plane_in = (size_t)ns * NET_T * CIN;        // halves per input plane
-    const size_t plane_out = (size_t)ns * NET_T * 2 * H;
-
-    const half8 *wl = Wp + ((size_t)(dir * 4 + wave) * NG) * NT * 2 * 64 + lane;
-    float bias_a[NT];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) bias_a[tt] = hh == 0 ? WSCALE * bp[((size_t)dir * NBLK + wave * NT + tt) * 32 + j] : 0.f;
-
-    float cst[FC4 ? 1 : NT][SB][4];
-    if (!FC4) {
-#pragma unroll
-        for (int tt = 0; tt < (FC4 ? 1 : NT); ++tt)
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cst[tt][sb][q] = 0.f;
-    } else {
-        for (int i = tid; i < WG_SITES * CP; i += 256) (&cbuf[0][0])[i] = 0.f;
-    }
-    floatx16 facc[FC4 ? SB : 1];
-#pragma unroll
-    for (int sb = 0; sb < (FC4 ? SB : 1); ++sb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) facc[sb][r] = 0.f;
-
-    for (int i = tid; i < WG_SITES * HP; i += 256) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
-    __syncthreads();
-
-    size_t xoff[SB];     // per-lane part of the x address (elements)
-#pragma unroll
-    for (int sb = 0; sb < SB; ++sb) {
-        int sj = site0 + 32 * sb + j;
-        if (sj >= n) sj = n - 1;
-        xoff[sb] = INT_IN ? (size_t)sj * NET_T * CIN : ((size_t)hh * ns + sj) * 8;
-    }
-
-    // LDS-DMA of x_t: one wave-instruction moves the 64 sites' 16-byte pieces of one (plane, k/8) row = 1 KiB, contiguous in
-    // the [t][k/8][site][8] planes and in xs; 2*KC rows per step, a quarter per wavefront
-    int xsite = site0 + lane;
-    if (xsite >= n) xsite = n - 1;
-    auto dma_x = [&](int tt_) {
-        if (XLDS) {
-            typedef const _Float16 __attribute__((address_space(1))) *gp_t;
-            typedef _Float16 __attribute__((address_space(3))) *lp_t;
-#pragma unroll
-            for (int r = 0; r < (XLDS ? 2 * KC / 4 : 0); ++r) {
-                const int row = wave * (2 * KC / 4) + r, pl = row / KC, kc = row % KC;
-                const _Float16 *src = (const _Float16 *)xin + (size_t)pl * plane_in + (((size_t)tt_ * KC + kc) * ns + xsite) * 8;
-                __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)&xs[XLDS ? pl : 0][XLDS ? kc : 0][0][0], 16, 0, 0);
-            }
-        }
-    };
-    if (XLDS) {
-        dma_x(dir ? NET_T - 1 : 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    for (int step = 0; step < NET_T; ++step) {
-        const int t = dir ? NET_T - 1 - step : step;
-        const int cur = XLDS ? 0 : (step & 1), nxt = XLDS ? 0 : (cur ^ 1);
-
-        auto ldx = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb) {
-                if ((ABL & 32) && g > 0) continue;      // probe: no x operand traffic
-                if (INT_IN) {
-                    const int32_t *xp = (const int32_t *)xin + xoff[sb] + (size_t)t * CIN;
-                    const int k0 = 16 * g + 8 * hh;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bh[sb][e] = (k0 + e < CIN) ? (_Float16)(float)xp[k0 + e] : (_Float16)0.f;
-                } else if (XLDS) {
-                    bh[sb] = *(const half8 *)&xs[0][XLDS ? 2 * g + hh : 0][XLDS ? 32 * sb + j : 0][0];
-                    bl[sb] = *(const half8 *)&xs[XLDS ? 1 : 0][XLDS ? 2 * g + hh : 0][XLDS ? 32 * sb + j : 0][0];
-                } else {
-                    // [t][k/8][site][8]: the 32 lanes of a half-wave read 32 consecutive 16-byte pieces (512 B), so a
-                    // wave load costs the L1 what a weight load costs (the [site][t][k] layout touched 32 cache lines)
-                    const _Float16 *xp = (const _Float16 *)xin + ((size_t)(t * (CIN / 8) + 2 * g) * ns) * 8 + xoff[sb];
-                    bh[sb] = *(const half8 *)xp;
-                    bl[sb] = *(const half8 *)(xp + plane_in);
-                }
-            }
-        };
-        auto ldh = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb) {
-                bh[sb] = *(const half8 *)&hb_hi[cur][32 * sb + j][16 * g + 8 * hh];
-                bl[sb] = *(const half8 *)&hb_lo[cur][32 * sb + j][16 * g + 8 * hh];
-            }
-        };
-        auto ldw = [&](int g, half8 (&ah)[NT], half8 (&al)[NT]) {
-            // the empty asm hides the pointer's provenance: with literal group numbers hipcc would otherwise precompute
-            // all NG*NT*2 load addresses outside the step loop (520 registers) and spill them
-            // (as an integer, re-typed as an address_space(1) pointer: an opaque generic pointer would become flat_load,
-            // which returns out of order and forces vmcnt(0) lgkmcnt(0) drains)
-            typedef const half8 __attribute__((address_space(1))) *gptr_t;
-            uintptr_t wbase = (uintptr_t)wl;
-            asm volatile("" : "+v"(wbase));
-            const gptr_t wg = (gptr_t)wbase + (size_t)((ABL & 1) ? 0 : g) * NT * 2 * 64;
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) {
-                if ((ABL & 16) && g > 0) continue;      // probe: weights register-stationary (no L1 traffic)
-                if constexpr ((ABL & 128) != 0) {
-                    // probe (timing only, wrong numbers): the lo halves as 8-bit values — 8 bytes per lane instead of 16, widened
-                    // with 4 VALU operations per fragment the way a packed fp8 -> f16 conversion would be
-                    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-                    typedef const uint2v __attribute__((address_space(1))) *g8_t;
-                    ah[tt] = wg[(tt * 2 + 0) * 64];
-                    const uint2v q = *((g8_t)(wg + (tt * 2 + 1) * 64));
-                    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-                    uint4v e;
-                    e[0] = (q[0] & 0x00ff00ffu) << 4; e[1] = (q[0] >> 8) & 0x00ff00ffu; e[2] = (q[1] & 0x00ff00ffu) << 4; e[3] = (q[1] >> 8) & 0x00ff00ffu;
-                    al[tt] = __builtin_bit_cast(half8, e);
-                    continue;
-                }
-                ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64];
-            }
-        };
-
-        floatx16 acc[NT][SB];
-        {
-            floatx16 z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[tt], 1.0f, z, 0, 0, 0);
-        }
-        // three f16 MFMAs per (tile, site block, k-group): hi*hi, hi*lo, lo*hi  (lo of the int32 pileup input is 0)
-        auto mma = [&](const half8 (&ah)[NT], const half8 (&al)[NT], const half8 (&bh)[SB], const half8 (&bl)[SB], bool xlo) {
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bh[sb], acc[tt][sb], 0, 0, 0);
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tt], bh[sb], acc[tt][sb], 0, 0, 0);
-            if (xlo) {
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bl[sb], acc[tt][sb], 0, 0, 0);
-            }
-        };
-        // Fully unrolled, software-pipelined K loop with prefetch distance PD k-groups and a ring of PD+1 register
-        // buffers.  With ONE wavefront per SIMD nothing else hides the L2 latency of the weight stream: the probe showed
-        // the kernel latency x concurrency bound (more reuse per fetch did not help, L1-hot weights did), so the fix is
-        // more bytes in flight, not fewer bytes.  sched_barrier(0) pins the load/MFMA order (hipcc otherwise clusters the
-        // loads and drains them with vmcnt(0)); full unrolling makes the ring slots and the x/h operand source
-        // compile-time constants (no flat loads).
-        constexpr bool XLO = !INT_IN;
-        half8 ah[PD + 1][NT], al[PD + 1][NT], bh[PD + 1][SB], bl[PD + 1][SB];
-#pragma unroll
-        for (int d = 0; d <= PD; ++d)
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb) bl[d][sb] = (half8)(_Float16)0.f;
-#define C3R_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define C3R_LOAD(G) do { ldw((G), ah[(G) % (PD + 1)], al[(G) % (PD + 1)]); \
-                         if ((G) < NGX) ldx((G), bh[(G) % (PD + 1)], bl[(G) % (PD + 1)]); \
-                         else ldh((G) - NGX, bh[(G) % (PD + 1)], bl[(G) % (PD + 1)]); } while (0)
-        // literal group numbers (macro expansion) guarantee compile-time ring slots: a `#pragma unroll` that the
-        // optimiser declines turns the ring into a scratch-memory array
-#define C3R_PRE(D) if constexpr ((D) < PD && (D) < NG) { C3R_LOAD(D); }
-#define C3R_STEP(G)                                                                                              \
-    if constexpr ((G) < NG) {                                                                                     \
-        C3R_FENCE();                                                                                              \
-        if constexpr ((G) + PD < NG) { C3R_LOAD((G) + PD); }                                                      \
-        if constexpr (!ILV) C3R_FENCE();                                                                          \
-        mma(ah[(G) % (PD + 1)], al[(G) % (PD + 1)], bh[(G) % (PD + 1)], bl[(G) % (PD + 1)], (G) < NGX ? XLO : true); \
-        if constexpr (ILV && (G) + PD < NG) {                                                                     \
-            constexpr bool LX = (G) + PD < NGX;        /* the prefetched group is an x group */                   \
-            constexpr int NMM = NT * SB * (((G) < NGX && !XLO) ? 2 : 3);                                          \
-            sched_interleave<NMM, NT * 2 + ((LX && !XLDS) ? (INT_IN ? 0 : SB * 2) : 0), (LX && !XLDS) ? 0 : SB * 2>(); \
-        }                                                                                                         \
-    }
-        C3R_PRE(0) C3R_PRE(1) C3R_PRE(2) C3R_PRE(3) C3R_PRE(4) C3R_PRE(5)
-        C3R_STEP(0) C3R_STEP(1) C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
-        C3R_STEP(10) C3R_STEP(11) C3R_STEP(12) C3R_STEP(13) C3R_STEP(14) C3R_STEP(15) C3R_STEP(16) C3R_STEP(17) C3R_STEP(18)
-        C3R_STEP(19) C3R_STEP(20) C3R_STEP(21) C3R_STEP(22) C3R_STEP(23) C3R_STEP(24) C3R_STEP(25) C3R_STEP(26) C3R_STEP(27)
-        static_assert(NG <= 28 && PD <= 6, "extend the C3R_STEP / C3R_PRE lists");
-        C3R_FENCE();
-#undef C3R_PRE
-#undef C3R_STEP
-#undef C3R_LOAD
-#undef C3R_FENCE
-        if (XLDS) {
-            __syncthreads();                                   // every wavefront is done reading x_t and h_{t-1}
-            if (step + 1 < NET_T) dma_x(dir ? NET_T - 2 - step : step + 1);      // lands during the cell update
-        }
-        // ---- lane-local cell update (acc holds 2^12 * z).  Written stage by stage over the NU = 4*SB independent
-        // (unit, site) values of a tile so that the dependent exp2 -> rcp -> fma chains of different units overlap
-        // (one wavefront per SIMD: there is no other wave to hide VALU / transcendental latency behind).
-        //   sigmoid(i) * tanh(g) = (1 - e_g) / ((1 + e_i)(1 + e_g)),  o * tanh(c) = (1 - e_c) / ((1 + e_o)(1 + e_c)):
-        //   5 exp2 + 3 rcp per unit instead of 5 + 5.  The clamp keeps the denominators finite when a gate saturates.
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            __builtin_amdgcn_sched_barrier(0);   // one tile at a time: bounds the accumulator values live in VGPRs
-            constexpr int NU = 4 * SB;
-            constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
-            float cq[NU], ei[NU], ef[NU], eg[NU], eo[NU], hval[NU];
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb) {
-                if (FC4) {
-                    const float4 cv = *(const float4 *)&cbuf[FC4 ? 32 * sb + j : 0][FC4 ? 8 * (wave * NT + tt) + 4 * hh : 0];
-                    cq[4 * sb] = cv.x; cq[4 * sb + 1] = cv.y; cq[4 * sb + 2] = cv.z; cq[4 * sb + 3] = cv.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cq[4 * sb + q] = cst[FC4 ? 0 : tt][sb][q];
-                }
-            }
-            if (ABL & 2) {
-#pragma unroll
-                for (int u = 0; u < NU; ++u) hval[u] = acc[tt][u >> 2][4 * (u & 3)] + acc[tt][u >> 2][4 * (u & 3) + 1] + acc[tt][u >> 2][4 * (u & 3) + 2] + acc[tt][u >> 2][4 * (u & 3) + 3];
-            } else {
-#pragma unroll
-                for (int u = 0; u < NU; ++u) ei[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 0]), 1e18f);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 1]);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(K2 * acc[tt][u >> 2][4 * (u & 3) + 2]), 1e18f);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) eo[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 3]), 1e18f);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) ei[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + ei[u]) * (1.0f + eg[u]));   // sig(i)*tanh(g)
-#pragma unroll
-                for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_rcpf(1.0f + ef[u]);                                          // sig(f)
-#pragma unroll
-                for (int u = 0; u < NU; ++u) cq[u] = fmaf(ef[u], cq[u], ei[u]);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[u]), 1e18f);            // e_c
-#pragma unroll
-                for (int u = 0; u < NU; ++u) hval[u] = (1.0f - eg[u]) * __builtin_amdgcn_rcpf((1.0f + eo[u]) * (1.0f + eg[u]));
-            }
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb) {
-                if (FC4) *(float4 *)&cbuf[FC4 ? 32 * sb + j : 0][FC4 ? 8 * (wave * NT + tt) + 4 * hh : 0] =
-                             make_float4(cq[4 * sb], cq[4 * sb + 1], cq[4 * sb + 2], cq[4 * sb + 3]);
-                else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cst[FC4 ? 0 : tt][sb][q] = cq[4 * sb + q];
-                }
-                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-                half4 vh, vl;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    vh[q] = (_Float16)hval[4 * sb + q];
-                    float d = hval[4 * sb + q] - (float)vh[q];
-                    asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
-                    vl[q] = (_Float16)d;
-                }
-                *(half4 *)&hb_hi[nxt][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vh;
-                *(half4 *)&hb_lo[nxt][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vl;
-            }
-        }
-        if (XLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // x_{t+1} has landed (LDS-DMA is tracked by vmcnt)
-        if (!(ABL & 8)) __syncthreads();
-        if (FC4) {
-            // ---- fused L4: facc[sb] += W4[t, dir][32 rows of this wave] x h_t^T   (K = H, B operand = h_t in LDS)
-            const half8 *w4 = W4p + (((size_t)(dir * NET_T + t) * 4 + wave) * NGH) * 2 * 64 + lane;
-            // products ordered so that consecutive MFMAs never share an accumulator (only SB chains exist here)
-#pragma unroll 2
-            for (int g = 0; g < NGH; ++g) {
-                const half8 ah = w4[(size_t)(g * 2 + 0) * 64], al = w4[(size_t)(g * 2 + 1) * 64];
-                half8 bh[SB], bl[SB];
-#pragma unroll
-                for (int sb = 0; sb < SB; ++sb) {
-                    bh[sb] = *(const half8 *)&hb_hi[nxt][32 * sb + j][16 * g + 8 * hh];
-                    bl[sb] = *(const half8 *)&hb_lo[nxt][32 * sb + j][16 * g + 8 * hh];
-                }
-#pragma unroll
-                for (int sb = 0; sb < SB; ++sb) facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[sb], facc[sb], 0, 0, 0);
-#pragma unroll
-                for (int sb = 0; sb < SB; ++sb) facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[sb], facc[sb], 0, 0, 0);
-#pragma unroll
-                for (int sb = 0; sb < SB; ++sb) facc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[sb], facc[sb], 0, 0, 0);
-            }
-        }
-        // ---- layer output planes y_hi / y_lo [t][(dir*H + u)/8][site][8 halves]: the layout the next layer's B-operand
-        // loads want (see ldx); consecutive threads store consecutive sites, 16 bytes each
-        constexpr int HV = H / 8;
-        if (!(ABL & 4) && !FC4)
-        for (int f = tid; f < WG_SITES * HV * 2; f += 256) {
-            const int pl = f / (WG_SITES * HV), rem = f % (WG_SITES * HV);
-            const int c8 = rem / WG_SITES, row = rem % WG_SITES;
-            const int s = site0 + row;
-            if (s < n) {
-                const half8 v = pl ? *(const half8 *)&hb_lo[nxt][row][8 * c8] : *(const half8 *)&hb_hi[nxt][row][8 * c8];
-                *(half8 *)(y + (size_t)pl * plane_out + (((size_t)t * (2 * HV) + dir * HV + c8) * ns + s) * 8) = v;
-            }
-        }
-    }
-    if (FC4) {
-#pragma unroll
-        for (int sb = 0; sb < SB; ++sb) {
-            const int sidx = site0 + 32 * sb + j;
-            if (sidx < n) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v = make_float4(facc[sb][4 * q] * WUNSCALE, facc[sb][4 * q + 1] * WUNSCALE, facc[sb][4 * q + 2] * WUNSCALE,
-                                           facc[sb][4 * q + 3] * WUNSCALE);
-                    *(float4 *)(a4part + ((size_t)sidx * 2 + dir) * NET_L4 + 32 * wave + 8 * q + 4 * hh) = v;
-                }
-            }
-        }
-    }
-}
+// Operand layouts of the split-f16 kernels (32-row gate blocks permuted for a lane-local cell update, see k_lstm):
+//   Wp  : [dir][quarter(4)][g][tile][hi|lo][64 lanes] half8  (k-groups of 16; lane half hh owns k = 16g + 8hh + 0..7; x 2^12)
+//   xin : layer 1: int32 [n][33][CIN] (exact in f16, lo = 0); layer 2: hi plane then lo plane, each f16 [33][CIN/8][nstride][8]
+//   y   : hi plane then lo plane, each f16 [33][2H/8][nstride][8]
+//   W4p : the flatten + Dense(128) layer L4, fused into layer 2: [dir][t][blk(4)][g(H/16)][hi|lo][64 lanes] half8, x 2^12; after every
+//         step the fresh h_t is multiplied by the [160 x 128] slice of W4 that belongs to (t, direction) and accumulated in
+//         registers; y2 is never written.  a4part: fp32 [n][2][128] partial pre-activations, one per direction (k_heads_mfma adds them)
+//   ldw : the weight loader launders its base pointer through an empty asm (with literal k-group numbers hipcc precomputes every
+//         load address: 520 registers -> scratch) and re-types it address_space(1) (a laundered GENERIC pointer becomes flat_load,
+//         which returns out of order and forces vmcnt(0) lgkmcnt(0) drains)
 
 // ------------------------------------------------------------------------------------------------
 // Layer 2 (+ fused L4) with TWO wavefronts per SIMD: k_lstm2_w8, 512 threads, 64 sites x one direction per workgroup.
 //
-// k_lstm_h runs one wavefront per SIMD (its 160 accumulator registers + the L4 accumulators + the prefetch ring need the
+// Round 1's kernel ran one wavefront per SIMD (its 160 accumulator registers + the L4 accumulators + the prefetch ring need the
 // whole 512-register file).  A wavefront issues in order, so everything that is not an MFMA — the weight and operand
 // loads the ring cannot cover, the cell update (5 exp2 + 3 rcp per unit), the L4 pass with its unprefetched loads, two
 // barriers — is time the matrix pipe sits out: 57 % busy.  Here the 20 gate-row tiles of a direction are dealt 3 + 2 to the
@@ -701,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void k_lstm_h(const void *__restrict__ xin,
 //   * one barrier after the input part (x_t is dead from there on: each wavefront issues its share of the LDS-DMA of
 //     x_{t+1} after its recurrent part, and it lands under the cell update), one at the end of the step (h_t complete); h is
 //     double-buffered because a wavefront's cell update now runs while others still read h_{t-1}.  LDS: 2 x 42 KB (h hi/lo) + 64 KB (x tile) = 148 KB.
-//   Wp / W4p / bp / a4part layouts are k_lstm_h's (the 4-wave "quarter" s = wave & 3 indexes them).
+//   Wp / W4p / bp / a4part: see "Operand layouts" above (the "quarter" sq = wave & 3 indexes them).
 #ifndef C3R_W8_ASYNC
 #define C3R_W8_ASYNC 1       // k_lstm2_w8: 1 = no workgroup barriers inside the time loop — the wavefronts meet through three LDS counters (x_t read by
                              // all / x_{t+1} landed / h_t written by all), so that one wavefront's cell update runs under its SIMD partner's MFMAs
@@ -711,9 +332,15 @@ __device__ __forceinline__ void lds_arrive(int *c) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63) == 0) atomicAdd(c, 1);
 }
+// A wait that gives up (2^24 polls, over a second, against real waits of microseconds) raises g_lstm_timeout instead of hanging the GPU:
+// the host checks the word whenever it fetches probabilities and fails the call (c3r_infer / c3r_get_probs) rather than hand out
+// numbers computed from a half-written h_t or x_t.
+__device__ int g_lstm_timeout = 0;
 __device__ __forceinline__ void lds_wait(int *c, int target) {
-    // (bounded: a protocol error shows up as wrong numbers in the parity tests, not as a hung GPU)
-    for (int it = 0; it < (1 << 24) && __atomic_load_n(c, __ATOMIC_RELAXED) < target; ++it) __builtin_amdgcn_s_sleep(1);
+    for (int it = 0; __atomic_load_n(c, __ATOMIC_RELAXED) < target; ++it) {
+        if (it >= (1 << 24)) { if ((threadIdx.x & 63) == 0) atomicOr(&g_lstm_timeout, 1); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
@@ -731,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
-    const int sq = C3R_W8_MAP ? (wave >> 1) : (wave & 3);      // quarter of the gate rows (k_lstm_h's wave index)
+    const int sq = C3R_W8_MAP ? (wave >> 1) : (wave & 3);      // quarter of the gate rows (the layouts' quarter index)
     const bool heavy3 = C3R_W8_MAP ? !(wave & 1) : (wave < 4); // the 3-tile wavefront of its SIMD pair
     const int dir = C3R_DIR_ILV ? blockIdx.x : blockIdx.y;
     const int site0 = (C3R_DIR_ILV ? blockIdx.y : blockIdx.x) * WG_SITES;
@@ -775,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
         constexpr int NTH = NT + (L4T ? 1 : 0);          // tiles in the recurrent part
         const half8 *wl = Wp + ((size_t)(dir * 4 + sq) * NG) * NTQ * 2 * 64 + (size_t)TOFF * 2 * 64 + lane;
         // bias: one f16 MFMA per (tile, site block) and step — A = {hi, lo, 0...} of 2^12 b on the k-slots 0 and 1 (lane half 0),
-        // B = {1, 1, 0...}: 32 cycles instead of the 64 of the f32 MFMA k_lstm_h spends on it; hi + lo carries 22 bits like every
+        // B = {1, 1, 0...}: 32 cycles instead of the 64 of an f32 MFMA; hi + lo carries 22 bits like every
         // other operand of this path
         typedef _Float16 half2v __attribute__((ext_vector_type(2)));
         unsigned bias_hl[NT];
@@ -825,32 +452,12 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
                 }
             };
             auto ldw = [&](int g, half8 (&ah)[NTH], half8 (&al)[NTH]) {
-                uintptr_t wbase = (uintptr_t)wl;                 // see k_lstm_h::ldw (address laundering, address_space(1))
+                uintptr_t wbase = (uintptr_t)wl;                 // address laundering, address_space(1): see "Operand layouts", ldw
                 asm volatile("" : "+v"(wbase));
                 const gptr_t wg = (gptr_t)wbase + (size_t)((ABL & 1) ? 0 : g) * NTQ * 2 * 64;      // probe bit 1: one L1-hot k-group
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     if ((ABL & 16) && g > 0) continue;
-                    if constexpr ((ABL & 128) != 0) {
-                        // probe (timing only, wrong numbers): lo halves as 8-bit fixed point — 8 bytes per lane instead of 16, widened
-                        // the way a real decode would be (byte -> f16 through the 0x64xx magic: v_perm + v_pk_add_f16 per pair)
-                        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-                        typedef const uint2v __attribute__((address_space(1))) *g8_t;
-                        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-                        ah[tt] = wg[(tt * 2 + 0) * 64];
-                        const uint2v q = *((g8_t)(wg + (tt * 2 + 1) * 64));
-                        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-                        uint4v e;
-                        e[0] = __builtin_amdgcn_perm(q[0], 0x64646464u, 0x04010400u);
-                        e[1] = __builtin_amdgcn_perm(q[0], 0x64646464u, 0x04030402u);
-                        e[2] = __builtin_amdgcn_perm(q[1], 0x64646464u, 0x04010400u);
-                        e[3] = __builtin_amdgcn_perm(q[1], 0x64646464u, 0x04030402u);
-                        const half2v off = {(_Float16)-1152.f, (_Float16)-1152.f};
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) { half2v v = __builtin_bit_cast(half2v, e[c]); v = v + off; e[c] = __builtin_bit_cast(unsigned, v); }
-                        al[tt] = __builtin_bit_cast(half8, e);
-                        continue;
-                    }
                     ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64];
                 }
                 if constexpr (L4T) {
@@ -888,30 +495,6 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 #pragma unroll
                     for (int sb = 0; sb < SB; ++sb) facc[L4T ? sb : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[L4T ? NT : 0], bh[sb], facc[L4T ? sb : 0], 0, 0, 0);
                 }
-                if constexpr ((ABL & 768) != 0) {
-                    // probe (timing only, wrong numbers): both correction terms of TWO k-groups as one block-scaled MFMA on the fp8 (bit
-                    // 256) or fp6 (bit 512) pipe, K = 64 = [w_hi | w_lo] x [x_lo ; x_hi] of 32 k's, issued with every second k-group;
-                    // operand bytes (weights: f16 hi + 8-bit hi + 8-bit lo = the 4 bytes per k streamed today) are unchanged
-                    typedef int intx8 __attribute__((ext_vector_type(8)));
-                    typedef int intx4 __attribute__((ext_vector_type(4)));
-                    constexpr int FMT = (ABL & 512) ? 2 : 0;       // cbsz / blgp: 0 = fp8 e4m3, 2 = fp6 e2m3
-                    if (odd) {
-#pragma unroll
-                        for (int tt = 0; tt < NTH; ++tt) {
-                            if (tt == NT && !(L4T && hpart)) continue;
-                            const intx4 a0 = __builtin_bit_cast(intx4, al[tt]), a1 = __builtin_bit_cast(intx4, ah[tt]);
-                            const intx8 a8 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-#pragma unroll
-                            for (int sb = 0; sb < SB; ++sb) {
-                                const intx4 b0 = __builtin_bit_cast(intx4, bl[sb]), b1 = __builtin_bit_cast(intx4, bh[sb]);
-                                const intx8 b8 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                                if (tt < NT) acc[tt < NT ? tt : 0][sb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[tt < NT ? tt : 0][sb], FMT, FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                                else facc[L4T ? sb : 0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, facc[L4T ? sb : 0], FMT, FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                            }
-                        }
-                    }
-                    return;
-                }
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
@@ -942,7 +525,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
         if constexpr ((G) + PD < NG) { C3R_LOAD((G) + PD); }                                                      \
         mma(ah[(G) % (PD + 1)], al[(G) % (PD + 1)], bh[(G) % (PD + 1)], bl[(G) % (PD + 1)], (G) >= NGX, ((G) & 1) != 0);  \
         if constexpr ((G) + PD < NG) {                                                                            \
-            constexpr int NMM = ((G) >= NGX ? NTH : NT) * SB * ((ABL & 768) ? (((G) & 1) ? 2 : 1) : 3);          \
+            constexpr int NMM = ((G) >= NGX ? NTH : NT) * SB * 3;         \
             sched_interleave<NMM, ((G) + PD >= NGX ? NTH : NT) * 2, SB * 2>();                                    \
         }                                                                                                         \
         if constexpr ((G) == NGX - 1) {                                                                           \
@@ -966,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
             if constexpr (C3R_W8_ASYNC) {
                 if (!L4T && step + 1 < NET_T) { lds_wait(&s_ctr[0], 8 * (step + 1)); dma_x16(dir ? NET_T - 2 - step : step + 1); }      // (everyone is done with x_t)
             } else if (step + 1 < NET_T && !(ABL & 64)) dma_x(dir ? NET_T - 2 - step : step + 1);
-            // ---- lane-local cell update, one tile at a time (see k_lstm_h); cell state in registers
+            // ---- lane-local cell update, one tile at a time; cell state in registers
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -1008,14 +591,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
                     for (int q = 0; q < 4; ++q) {
                         vh[q] = (_Float16)hval[4 * sb + q];
                         float d = hval[4 * sb + q] - (float)vh[q];
-                        asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
+                        asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16: it rounds differently)
                         vl[q] = (_Float16)d;
-                    }
-                    if constexpr ((ABL & 768) != 0) {       // probe: keep every byte a finite fp8 number (no NaN patterns on the MX pipe)
-                        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-                        uint2v a = __builtin_bit_cast(uint2v, vh), b = __builtin_bit_cast(uint2v, vl);
-                        a[0] &= 0xBFBFBFBFu; a[1] &= 0xBFBFBFBFu; b[0] &= 0xBFBFBFBFu; b[1] &= 0xBFBFBFBFu;
-                        vh = __builtin_bit_cast(half4, a); vl = __builtin_bit_cast(half4, b);
                     }
                     *(half4 *)&hb_hi[nxt][32 * sb + j][8 * (sq * NTQ + TOFF + tt) + 4 * hh] = vh;
                     *(half4 *)&hb_lo[nxt][32 * sb + j][8 * (sq * NTQ + TOFF + tt) + 4 * hh] = vl;
@@ -1085,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 // weights of 2-3x the norm (tools/precision_probe.py, scheme f16+2f8k) — which is why c3r_load_weights measures it (precision
 // "auto") before this path is used.
 //   xin: plane 0 = f16(x) [t][k/8][site][8 halves]; plane 1, same geometry, rows (kb, term, part) = kb * 4 + term * 2 + part of 16 bytes
-//        per site: fp8 of k = 32 kb + 16 part + 0..15, term 0 = (x - f16(x)) 2^18, term 1 = x 2^6   (written by k_lstm1_w8<.., YQ>)
+//        per site: fp8 of k = 32 kb + 16 part + 0..15, term 0 = (x - f16(x)) 2^18, term 1 = x 2^6   (written by k_lstm1_rs<.., YQ>)
 //   Wp / W4p: k_lstm2_w8's f16 fragments (only the hi halves are read); Wq / Wsc, W4q / W4sc: pack_mx
 __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict__ xin, const half8 *__restrict__ Wp, const uint32_t *__restrict__ Wq,
                                                       const uint32_t *__restrict__ Wsc, const float *__restrict__ bp, int n,
@@ -1191,12 +768,6 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             const intx4 lo = h[0], hi4 = h[64];
             return intx8{lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
         };
-#ifdef C3R_MX_TIMING
-        long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
-#define C3R_TPH(K) do { const long long now_ = clock64(); tph[K] += now_ - tlast; tlast = now_; } while (0)
-#else
-#define C3R_TPH(K) do {} while (0)
-#endif
         for (int step = 0; step < NET_T; ++step) {
             const int t = dir ? NET_T - 1 - step : step;
             const int tprev = step ? (dir ? t + 1 : t - 1) : t;
@@ -1210,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             // the 32-k block G / 2, consumed by the block-scaled MFMA that follows group G's f16 MFMAs
             auto load = [&](auto gc, half8 (&ahr)[NTH], half8 (&bhr)[SB]) {
                 constexpr int G = decltype(gc)::value;
-                uintptr_t wbase = (uintptr_t)wl;                 // (address laundering, address_space(1): see k_lstm_h::ldw)
+                uintptr_t wbase = (uintptr_t)wl;                 // (address laundering, address_space(1): see "Operand layouts", ldw)
                 asm volatile("" : "+v"(wbase));
                 const gptr_t wg = (gptr_t)wbase + (size_t)G * NTQ * 2 * 64;
 #pragma unroll
@@ -1319,9 +890,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
         }                                                                                                         \
         if constexpr ((G) == NGX - 1) {                                                                           \
             C3R_FENCE();                                                                                          \
-            C3R_TPH(0);                                                                                           \
             if constexpr (C3R_W8_ASYNC) lds_arrive(&s_ctr[0]); else __syncthreads();     /* done with x_t */        \
-            C3R_TPH(1);                                                                                           \
         }                                                                                                         \
     }
             if constexpr (PD > 0) { load(std::integral_constant<int, 0>{}, ah[0], bh[0]); }
@@ -1331,7 +900,6 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             C3R_FENCE();
 #undef C3R_STEP
 #undef C3R_FENCE
-            C3R_TPH(2);
             if constexpr (C3R_W8_ASYNC) {
                 if (!L4T && step + 1 < NET_T) { lds_wait(&s_ctr[0], 8 * (step + 1)); dma_x16(dir ? NET_T - 2 - step : step + 1); }
             } else if (step + 1 < NET_T) dma_x(dir ? NET_T - 2 - step : step + 1);      // lands during the cell update
@@ -1374,7 +942,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
                     for (int q = 0; q < 4; ++q) {
                         vh[q] = (_Float16)hval[4 * sb + q];
                         float d = hval[4 * sb + q] - (float)vh[q];
-                        asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
+                        asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16: it rounds differently)
                         lo[q] = d * 262144.f;
                     }
                     *(half4 *)&hb_hi[nxt][32 * sb + j][8 * T + 4 * hh] = vh;
@@ -1389,25 +957,14 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
                     }
                 }
             }
-            C3R_TPH(3);
             if constexpr (C3R_W8_ASYNC) {
                 lds_arrive(&s_ctr[2]);
                 if (!L4T && step + 1 < NET_T) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_arrive(&s_ctr[1]); }
-                C3R_TPH(4);
             } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // x_{t+1} has landed (LDS-DMA is tracked by vmcnt)
-            C3R_TPH(4);
             __syncthreads();                                       // h_t complete; everyone is done with h_{t-1}
             }
-            C3R_TPH(5);
         }
-#ifdef C3R_MX_TIMING
-        if (blockIdx.x == 0 && blockIdx.y == 7 && lane == 0) {
-            long long *sink = reinterpret_cast<long long *>(a4part + (size_t)n * 2 * NET_L4) + wave * 6;
-            for (int q = 0; q < 6; ++q) sink[q] = tph[q];
-        }
-#endif
-#undef C3R_TPH
         if constexpr (L4T) {
             if constexpr (C3R_W8_ASYNC) lds_wait(&s_ctr[2], 8 * NET_T);
             // ---- the last step's h (buffer NET_T & 1) still owes its L4 contribution
@@ -1455,475 +1012,13 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Layer 1 of the split-f16 path with the cell update hidden behind the matrix pipe.
-//
-// k_lstm_h spends 28 % of layer 1 in the lane-local cell update (5 exp2 + 3 rcp per unit: ~1000 VALU / transcendental
-// instructions per step) and 20 % storing y1, with the matrix pipe idle meanwhile: ONE wavefront per SIMD means nothing
-// else can issue.  Here a workgroup owns TWO groups of 64 sites, A and B, one step apart in phase:
-//      phase 2 of step s   : MFMAs of (B, s)   with the cell update + stores of (A, s)   interleaved between them
-//      phase 1 of step s+1 : MFMAs of (A, s+1) with the cell update + stores of (B, s)   interleaved
-// so the VALU work of one group always runs in the shadow of the other group's MFMAs (<= 5 single-issue instructions
-// hide behind a 32-cycle MFMA).  Weight traffic per site is unchanged (every phase still feeds 64 sites from one pass
-// over the weights).  A group's h is read (its MFMA phase) and rewritten (its update phase) in different phases with
-// a barrier between, so ONE LDS buffer per group is enough.  Accumulators: 2 x 128 registers.  y1 is stored straight
-// from registers (8 bytes per lane, 512 contiguous bytes per wave-store) in the [t][k/8][site][8] plane layout.
-template <int CIN, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void k_lstm1_skew(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp,
-                                                        const float *__restrict__ bp, _Float16 *__restrict__ y, int n, int nstride) {
-    constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NT = 4, SB = 2, GS = 32 * SB, HV = H / 8;
-    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) _Float16 hb_hi[2][GS][HP];
-    __shared__ __attribute__((aligned(16))) _Float16 hb_lo[2][GS][HP];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hh = lane >> 5;
-    const int dir = blockIdx.y;
-    const int site0 = blockIdx.x * 2 * GS;
-    const size_t plane_out = (size_t)nstride * NET_T * 2 * H;     // nstride = n rounded up to the workgroup's 128 sites:
-                                                                  // sites past n own (unused) slots, so stores need no guard
-
-    const half8 *wl = Wp + ((size_t)(dir * 4 + wave) * NG) * NT * 2 * 64 + lane;
-    // bias: the input is padded from CIN to 32 k-slots; pack_lstm_dir_h puts the bias (hi/lo like any weight) on slot CIN and the
-    // loader below feeds a constant 1 there — no bias MFMA at all (k_lstm_h spends a 64-cycle f32 MFMA per tile, block and step)
-    static_assert(CIN < 32, "a free input slot for the bias");
-    (void)bp;
-
-    // cell state in LDS ([group][site][unit], fp32): the two accumulator sets leave no registers for it
-    constexpr int CP = H + 4;
-    __shared__ __attribute__((aligned(16))) float cbuf[2][GS][CP];
-    for (int i = tid; i < 2 * GS * CP; i += 256) (&cbuf[0][0][0])[i] = 0.f;
-    for (int i = tid; i < 2 * GS * HP; i += 256) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
-    __syncthreads();
-
-    size_t xoff[2][SB];
-    uint32_t yoff[2][SB];       // per-lane element offset inside a [site][8] row block of the y planes
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int sb = 0; sb < SB; ++sb) {
-            const int sj = site0 + GS * g + 32 * sb + j;
-            yoff[g][sb] = (uint32_t)sj * 8 + 4 * hh;
-            xoff[g][sb] = (size_t)(sj < n ? sj : n - 1) * NET_T * CIN;
-        }
-
-    floatx16 accA[NT][SB], accB[NT][SB];
-
-    // One phase.  MMA: accumulate group gm's pre-activations of time index tm into accM.  GATE: cell update of group gg
-    // from accG (finished in the previous phase), writing h (LDS) and y1 (HBM) of time index tg.
-    auto phase = [&](auto mma_c, auto gate_c, floatx16 (&accM)[NT][SB], const int gm, const int tm,
-                     floatx16 (&accG)[NT][SB], const int gg, const int tg) {
-        constexpr bool MMA = decltype(mma_c)::value, GATE = decltype(gate_c)::value;
-        // ---- the cell update of one (tile, site block) = 4 units per lane, cut into NS short stages of 4 independent
-        // operations each.  A wavefront issues IN ORDER: an MFMA that finds the matrix pipe busy blocks everything behind
-        // it, so VALU work only hides if it sits BETWEEN consecutive MFMAs, a handful of instructions at a time
-        // (<= 5-7 single-issue instructions fit into the 32 cycles of one MFMA).  sched_group_barrier hints did not
-        // get the compiler there (gaps of 0..94 instructions); the regions below are therefore written slot by slot —
-        // one MFMA, one prefetch item, one or two stages, sched_barrier — which pins exactly that order.
-        constexpr int NS = 25;
-        float ei[4], ef[4], eg[4], eo[4], tq[4], cq[4], hv[4];
-        half4 vh, vl;
-        auto stage = [&](auto sc, const int tt, const int sb) {
-            // no implicit mul+add fusion: the phase lambda is instantiated several times (group A / B, with / without MFMAs,
-            // 16 / 24 / 25 slots) and which stages share a slot differs between them; a site's result must not depend on
-            // which copy it ran through (batch composition decides whether it lands in group A or B)
-#pragma clang fp contract(off)
-            constexpr int S = decltype(sc)::value;
-            constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
-            float4 *cp = (float4 *)&cbuf[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh];
-#define C3R_Q _Pragma("unroll") for (int q = 0; q < 4; ++q)
-            if constexpr (S == 0) { C3R_Q ei[q] = K1 * accG[tt][sb][4 * q + 0]; }
-            if constexpr (S == 1) { C3R_Q ei[q] = __builtin_amdgcn_exp2f(ei[q]); }
-            if constexpr (S == 2) { C3R_Q ei[q] = fminf(ei[q], 1e18f); }
-            if constexpr (S == 3) { C3R_Q ef[q] = K1 * accG[tt][sb][4 * q + 1]; }
-            if constexpr (S == 4) { C3R_Q ef[q] = __builtin_amdgcn_exp2f(ef[q]); }
-            if constexpr (S == 5) { C3R_Q eg[q] = K2 * accG[tt][sb][4 * q + 2]; }
-            if constexpr (S == 6) { C3R_Q eg[q] = __builtin_amdgcn_exp2f(eg[q]); }
-            if constexpr (S == 7) { C3R_Q eg[q] = fminf(eg[q], 1e18f); }
-            if constexpr (S == 8) { C3R_Q eo[q] = K1 * accG[tt][sb][4 * q + 3]; }
-            if constexpr (S == 9) { C3R_Q eo[q] = __builtin_amdgcn_exp2f(eo[q]); }
-            if constexpr (S == 10) { C3R_Q eo[q] = fminf(eo[q], 1e18f); }
-            if constexpr (S == 11) { C3R_Q tq[q] = (1.0f + ei[q]) * (1.0f + eg[q]); }
-            if constexpr (S == 12) { C3R_Q tq[q] = __builtin_amdgcn_rcpf(tq[q]); }
-            if constexpr (S == 13) { C3R_Q tq[q] = (1.0f - eg[q]) * tq[q]; }                       // sig(i) * tanh(g)
-            if constexpr (S == 14) { C3R_Q ef[q] = __builtin_amdgcn_rcpf(1.0f + ef[q]);            // sig(f)
-                                     const float4 cv = *cp; cq[0] = cv.x; cq[1] = cv.y; cq[2] = cv.z; cq[3] = cv.w; }
-            if constexpr (S == 15) { C3R_Q cq[q] = fmaf(ef[q], cq[q], tq[q]); *cp = make_float4(cq[0], cq[1], cq[2], cq[3]); }
-            if constexpr (S == 16) { C3R_Q eg[q] = __builtin_amdgcn_exp2f(-2.8853900817779268f * cq[q]); }   // e_c
-            if constexpr (S == 17) { C3R_Q eg[q] = fminf(eg[q], 1e18f); }
-            if constexpr (S == 18) { C3R_Q tq[q] = (1.0f + eo[q]) * (1.0f + eg[q]); }
-            if constexpr (S == 19) { C3R_Q tq[q] = __builtin_amdgcn_rcpf(tq[q]); }
-            if constexpr (S == 20) { C3R_Q hv[q] = (ABL & 2) ? accG[tt][sb][4 * q] + cq[q] : (1.0f - eg[q]) * tq[q]; }     // sig(o) * tanh(c)
-            if constexpr (S == 21) { C3R_Q vh[q] = (_Float16)hv[q]; }
-            if constexpr (S == 22) {
-                // the residual is pinned to "subtract in fp32, then convert": left alone the compiler picks v_fma_mixlo_f16
-                // in some copies of this lambda and v_sub + v_cvt in others, and the two treat f16-subnormal residuals
-                // (|h| < 0.12) differently — results would depend on which copy a site ran through
-                C3R_Q { float d = hv[q] - (float)vh[q]; asm volatile("" : "+v"(d)); vl[q] = (_Float16)d; }
-            }
-            if constexpr (S == 23) {
-                *(half4 *)&hb_hi[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vh;
-                *(half4 *)&hb_lo[gg][32 * sb + j][8 * (wave * NT + tt) + 4 * hh] = vl;
-            }
-            if constexpr (S == 24) {
-                if (!(ABL & 4)) {
-                    _Float16 *yp = y + ((size_t)tg * (2 * HV) + dir * HV + wave * NT + tt) * nstride * 8 + yoff[gg][sb];
-                    *(half4 *)yp = vh;
-                    *(half4 *)(yp + plane_out) = vl;
-                }
-            }
-#undef C3R_Q
-        };
-        half8 ah[2][NT], al[2][NT], bh[2][SB], bl[2][SB];
-        typedef const half8 __attribute__((address_space(1))) *gptr_t;     // see k_lstm_h::ldw
-        // prefetch item I of k-group G1: items 0..2NT-1 = the weight fragments, then one B-operand item per site block
-        auto load_item = [&](auto g1c, auto ic, gptr_t wg) {
-            constexpr int G1 = decltype(g1c)::value, I = decltype(ic)::value;
-            if constexpr (I < 2 * NT) {
-                if constexpr (I % 2 == 0) ah[G1 & 1][I / 2] = wg[(I / 2 * 2 + 0) * 64];
-                else al[G1 & 1][I / 2] = wg[(I / 2 * 2 + 1) * 64];
-            } else {
-                constexpr int sb = I - 2 * NT;
-                if constexpr (G1 < NGX && (ABL & 8)) {
-                    bh[G1 & 1][sb] = (half8)(_Float16)(float)(G1 + sb);            // probe: no x operand traffic
-                } else if constexpr (G1 < NGX) {
-                    // branch-free (a divergent guard would split the region): load from a clamped index, then select
-                    const int32_t *xp = xin + xoff[gm][sb] + (size_t)tm * CIN;
-                    const int k0 = 16 * G1 + 8 * hh;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int k = k0 + e;
-                        const int32_t v = xp[k < CIN ? k : CIN - 1];
-                        bh[G1 & 1][sb][e] = (k < CIN) ? (_Float16)(float)v : (k == CIN ? (_Float16)1.f : (_Float16)0.f);    // slot CIN: bias
-                    }
-                } else {
-                    bh[G1 & 1][sb] = *(const half8 *)&hb_hi[gm][32 * sb + j][16 * (G1 - NGX) + 8 * hh];
-                    bl[G1 & 1][sb] = *(const half8 *)&hb_lo[gm][32 * sb + j][16 * (G1 - NGX) + 8 * hh];
-                }
-            }
-        };
-        auto wptr = [&](int g) -> gptr_t {
-            uintptr_t wbase = (uintptr_t)wl;
-            asm volatile("" : "+v"(wbase));              // keeps hipcc from precomputing every group's addresses (k_lstm_h::ldw)
-            return (gptr_t)wbase + (size_t)((ABL & 16) ? 0 : g) * NT * 2 * 64;      // probe bit 16: one L1-hot k-group of weights
-        };
-        constexpr int NITEM = 2 * NT + SB;
-        // one region = k-group G: its MFMAs, the prefetch of group G+1, and (GATE, G < NT*SB) the cell update of chunk G
-        auto region = [&](auto gc) {
-            constexpr int G = decltype(gc)::value;
-            constexpr int NM = MMA ? NT * SB * (G < NGX ? 2 : 3) : NS;     // slots; without MFMAs one stage per slot
-            constexpr bool ST = GATE && G < NT * SB;
-            const gptr_t wg = wptr(G + 1 < NG ? G + 1 : G);
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, NM>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                if constexpr (MMA) {
-                    constexpr int p = m / (NT * SB), tt = (m % (NT * SB)) / SB, sb = m % SB;
-                    if constexpr (p == 0 && G == 0) {          // the step's first product of this accumulator starts from zero
-                        floatx16 z;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                        accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[G & 1][tt], bh[G & 1][sb], z, 0, 0, 0);
-                    }
-                    if constexpr (p == 0 && G != 0) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[G & 1][tt], bh[G & 1][sb], accM[tt][sb], 0, 0, 0);
-                    if constexpr (p == 1) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[G & 1][tt], bh[G & 1][sb], accM[tt][sb], 0, 0, 0);
-                    if constexpr (p == 2) accM[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[G & 1][tt], bl[G & 1][sb], accM[tt][sb], 0, 0, 0);
-                    if constexpr (G + 1 < NG && m < NITEM) load_item(std::integral_constant<int, (G + 1 < NG ? G + 1 : G)>{}, mc, wg);
-                }
-                if constexpr (ST) {
-                    constexpr int s0 = m * NS / NM, s1 = (m + 1) * NS / NM;
-                    static_for<s0, s1>([&](auto sc) { stage(sc, G >> 1, G & 1); });
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        };
-        if (MMA) {
-            const gptr_t w0 = wptr(0);
-            static_for<0, NITEM>([&](auto ic) { load_item(std::integral_constant<int, 0>{}, ic, w0); });
-        }
-        static_for<0, NG>(region);
-        static_assert(NG == 10 && NT * SB <= NG, "one cell-update chunk per k-group region");
-    };
-    const std::true_type yes{}; const std::false_type no{};
-    auto tix = [&](int step) { return dir ? NET_T - 1 - step : step; };
-
-    phase(yes, no, accA, 0, tix(0), accB, 1, 0);                       // (A, 0)
-    __syncthreads();
-#pragma unroll 1
-    for (int s = 0; s + 1 < NET_T; ++s) {
-        phase(yes, yes, accB, 1, tix(s), accA, 0, tix(s));             // MFMA (B, s)   | update (A, s)
-        __syncthreads();
-        phase(yes, yes, accA, 0, tix(s + 1), accB, 1, tix(s));         // MFMA (A, s+1) | update (B, s)
-        __syncthreads();
-    }
-    phase(yes, yes, accB, 1, tix(NET_T - 1), accA, 0, tix(NET_T - 1));
-    __syncthreads();
-    phase(no, yes, accA, 0, 0, accB, 1, tix(NET_T - 1));
-}
-
-// ------------------------------------------------------------------------------------------------
-// Layer 1 with two wavefronts per SIMD: k_lstm1_w8, 512 threads, 64 sites x one direction per workgroup (the layer-1
-// counterpart of k_lstm2_w8).  The 16 gate-row tiles are dealt 2 + 2 to the wavefronts w and w+4 of a SIMD, cell state in
-// registers, h double-buffered in LDS, one barrier per step.  Two things differ from k_lstm1_skew:
-//   * x_t is staged ONCE per workgroup: the 64 sites' 18 (30) int32 counts of step t+1 are fetched at the top of step t by all
-//     512 threads (8-byte pieces of the [site][t][C] rows), converted to f16 and written to a 5 KB LDS tile at the end of the
-//     step; every wavefront then reads its B operands with ds_read_b128.  In k_lstm1_skew each wavefront gathered the same
-//     windows itself, 8 scattered dword loads per lane and k-group (1.6 of its 7.5 ms);
-//   * no phase skew inside a workgroup.  Two wavefronts of ONE workgroup meet at the step barrier and so run their K loops together
-//     and their cell updates together (measured: 7.2 ms, matrix pipe 43 % busy, the same as the skewed kernel).  The kernel is
-//     therefore cut to 128 registers (no operand ring: load, then use) and 78 KB of LDS so that TWO workgroups share a CU: their
-//     barriers are independent, they drift out of phase, and one workgroup's cell update runs under the other's MFMAs (6.9 ms).
-//     What is left is the cell update itself: without its 5 exp2 + 3 rcp per unit the kernel takes 4.9 ms at a 0.33 GHz higher
-//     clock (tools/lstm_probe_l1w8.hip).
-// Bias rides on input slot CIN (see k_lstm1_skew); Wp is k_lstm_h's layout ([dir][quarter][g][tile(4)][hi|lo][lane]).
-// YQ: the second y1 plane holds the fp8 bytes precision 2's layer 2 wants (k_lstm2_mx) instead of the f16 lo halves.
-template <int CIN, int ABL = 0, int TEAMS = 1, bool YQ = false>
-__global__ __launch_bounds__(512 * TEAMS, C3R_L1_W8_OCC) void k_lstm1_w8(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp,
-                                                      _Float16 *__restrict__ y, int n, int nstride) {
-    constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NTQ = 4, NT = 2, SB = 2, WG_SITES = 64, HV = H / 8, PD = C3R_L1_W8_PD;
-    constexpr int XP = 40;                     // x tile row stride in halves (80 B: conflict-free ds_read_b128)
-    constexpr int NPC = (CIN + 1) / 2;         // 8-byte pieces per (site, step) row of the int32 tensor
-    static_assert(CIN % 2 == 0 && CIN < 32, "even channel count, one free slot for the bias");
-    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) _Float16 hb_hi_[TEAMS][2][WG_SITES][HP];
-    __shared__ __attribute__((aligned(16))) _Float16 hb_lo_[TEAMS][2][WG_SITES][HP];
-    __shared__ __attribute__((aligned(16))) _Float16 xs_[TEAMS][2][WG_SITES][XP];
-
-    const int team = TEAMS > 1 ? (int)(threadIdx.x >> 9) : 0;
-    auto &hb_hi = hb_hi_[team];
-    auto &hb_lo = hb_lo_[team];
-    auto &xs = xs_[team];
-    const int tid = threadIdx.x & 511, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hh = lane >> 5;
-    const int sq = wave & 3, toff = (wave >> 2) * NT;
-    const int dir = C3R_DIR_ILV ? blockIdx.x : blockIdx.y;
-    const int site0 = ((C3R_DIR_ILV ? blockIdx.y : blockIdx.x) * TEAMS + team) * WG_SITES;
-    const size_t plane_out = (size_t)nstride * NET_T * 2 * H;
-
-    for (int i = tid; i < WG_SITES * HP; i += 512) { (&hb_hi[0][0][0])[i] = (_Float16)0.f; (&hb_lo[0][0][0])[i] = (_Float16)0.f; }
-    // constant part of both x tiles: slot CIN = 1 (bias), the padding = 0
-    for (int i = tid; i < 2 * WG_SITES * XP; i += 512) (&xs[0][0][0])[i] = ((i % XP) == CIN) ? (_Float16)1.f : (_Float16)0.f;
-
-    // x staging: piece q of this thread = 8 bytes (two int32 counts) of row (site, t)
-    constexpr int NPIECE = WG_SITES * NPC, PPT = (NPIECE + 511) / 512;
-    typedef int int2v __attribute__((ext_vector_type(2)));
-    int2v xr[PPT];
-    auto x_fetch = [&](int tt_) {
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int pc = tid + 512 * q;
-            if (pc < NPIECE) {
-                int sj = site0 + pc / NPC;
-                if (sj >= n) sj = n - 1;
-                xr[q] = *(const int2v *)(xin + ((size_t)sj * NET_T + tt_) * CIN + 2 * (pc % NPC));
-            }
-        }
-    };
-    auto x_store = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int pc = tid + 512 * q;
-            if (pc < NPIECE) {
-                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-                half2v v;
-                v[0] = (_Float16)(float)xr[q][0]; v[1] = (_Float16)(float)xr[q][1];
-                *(half2v *)&xs[buf][pc / NPC][2 * (pc % NPC)] = v;
-            }
-        }
-    };
-    __syncthreads();
-    x_fetch(dir ? NET_T - 1 : 0);
-    x_store(0);
-    __syncthreads();
-
-    const half8 *wl = Wp + ((size_t)(dir * 4 + sq) * NG) * NTQ * 2 * 64 + (size_t)toff * 2 * 64 + lane;
-    float cst[NT][SB][4];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-        for (int sb = 0; sb < SB; ++sb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cst[tt][sb][q] = 0.f;
-    uint32_t yoff[SB];
-#pragma unroll
-    for (int sb = 0; sb < SB; ++sb) yoff[sb] = (uint32_t)(site0 + 32 * sb + j) * 8 + 4 * hh;
-
-    typedef const half8 __attribute__((address_space(1))) *gptr_t;
-    // TEAMS == 2: the two teams of eight wavefronts run half a step apart — one team's cell update (VALU, transcendentals) under
-    // the other's K loop (matrix pipe) — and every phase ends in a workgroup-wide barrier that keeps them there
-    if (TEAMS > 1 && team == 1) __syncthreads();
-#ifdef C3R_L1_TIMING
-    long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
-#define C3R_TPH(K) do { const long long now_ = clock64(); tph[K] += now_ - tlast; tlast = now_; } while (0)
-#else
-#define C3R_TPH(K) do {} while (0)
-#endif
-    for (int step = 0; step < NET_T; ++step) {
-        const int t = dir ? NET_T - 1 - step : step;
-        const int cur = step & 1, nxt = cur ^ 1;
-        if (step + 1 < NET_T) x_fetch(dir ? NET_T - 2 - step : step + 1);       // lands under the K loop
-
-        auto ldb = [&](int g, half8 (&bh)[SB], half8 (&bl)[SB]) {
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb) {
-                if (g < NGX) {
-                    bh[sb] = *(const half8 *)&xs[cur][32 * sb + j][16 * g + 8 * hh];
-                } else {
-                    bh[sb] = *(const half8 *)&hb_hi[cur][32 * sb + j][16 * (g - NGX) + 8 * hh];
-                    bl[sb] = *(const half8 *)&hb_lo[cur][32 * sb + j][16 * (g - NGX) + 8 * hh];
-                }
-            }
-        };
-        auto ldw = [&](int g, half8 (&ah)[NT], half8 (&al)[NT]) {
-            uintptr_t wbase = (uintptr_t)wl;                 // see k_lstm_h::ldw
-            asm volatile("" : "+v"(wbase));
-            const gptr_t wg = (gptr_t)wbase + (size_t)((ABL & 16) ? 0 : g) * NTQ * 2 * 64;
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) { ah[tt] = wg[(tt * 2 + 0) * 64]; al[tt] = wg[(tt * 2 + 1) * 64]; }
-        };
-        floatx16 acc[NT][SB];
-        auto mma = [&](auto gc, const half8 (&ah)[NT], const half8 (&al)[NT], const half8 (&bh)[SB], const half8 (&bl)[SB]) {
-            constexpr int G = decltype(gc)::value;
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int sb = 0; sb < SB; ++sb) {
-                    if constexpr (G == 0) {                  // the step's first product starts each accumulator from zero
-                        floatx16 z;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                        acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bh[sb], z, 0, 0, 0);
-                    } else {
-                        acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bh[sb], acc[tt][sb], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tt], bh[sb], acc[tt][sb], 0, 0, 0);
-            if constexpr (G >= NGX) {                        // (the int32 input has no lo half)
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int sb = 0; sb < SB; ++sb) acc[tt][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tt], bl[sb], acc[tt][sb], 0, 0, 0);
-            }
-        };
-        half8 ah[PD + 1][NT], al[PD + 1][NT], bh[PD + 1][SB], bl[PD + 1][SB];
-#define C3R_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define C3R_LOAD(G) do { ldw((G), ah[(G) % (PD + 1)], al[(G) % (PD + 1)]); ldb((G), bh[(G) % (PD + 1)], bl[(G) % (PD + 1)]); } while (0)
-#define C3R_STEP(G)                                                                                              \
-    if constexpr ((G) < NG) {                                                                                     \
-        C3R_FENCE();                                                                                              \
-        if constexpr (PD == 0 || (G) + PD < NG) { C3R_LOAD((G) + PD); }                                           \
-        mma(std::integral_constant<int, (G)>{}, ah[(G) % (PD + 1)], al[(G) % (PD + 1)], bh[(G) % (PD + 1)], bl[(G) % (PD + 1)]); \
-        if constexpr (PD > 0 && (G) + PD < NG) {                                                                  \
-            constexpr int NMM = NT * SB * ((G) < NGX ? 2 : 3);                                                    \
-            sched_interleave<NMM, NT * 2, ((G) + PD < NGX ? SB : SB * 2)>();                                      \
-        }                                                                                                         \
-    }
-        C3R_TPH(0);
-        if constexpr (PD > 0) { C3R_LOAD(0); }
-        C3R_STEP(0) C3R_STEP(1) C3R_TPH(1); C3R_STEP(2) C3R_STEP(3) C3R_STEP(4) C3R_STEP(5) C3R_STEP(6) C3R_STEP(7) C3R_STEP(8) C3R_STEP(9)
-        static_assert(NG == 10, "extend the C3R_STEP list");
-        C3R_FENCE();
-#undef C3R_STEP
-#undef C3R_LOAD
-#undef C3R_FENCE
-        if (TEAMS > 1) __syncthreads();                        // phase boundary: K loop -> cell update
-        C3R_TPH(2);
-        // ---- lane-local cell update, one tile at a time; h_t to LDS (both halves) and to the y1 planes, straight from registers
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            __builtin_amdgcn_sched_barrier(0);
-            constexpr int NU = 4 * SB;
-            constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
-            float cq[NU], ei[NU], ef[NU], eg[NU], eo[NU], hval[NU];
-#pragma unroll
-            for (int u = 0; u < NU; ++u) cq[u] = cst[tt][u >> 2][u & 3];
-            if (ABL & 2) {
-#pragma unroll
-                for (int u = 0; u < NU; ++u) hval[u] = acc[tt][u >> 2][4 * (u & 3)] + acc[tt][u >> 2][4 * (u & 3) + 1] + acc[tt][u >> 2][4 * (u & 3) + 2] + acc[tt][u >> 2][4 * (u & 3) + 3];
-            } else {
-#pragma unroll
-                for (int u = 0; u < NU; ++u) ei[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 0]), 1e18f);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 1]);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(K2 * acc[tt][u >> 2][4 * (u & 3) + 2]), 1e18f);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) eo[u] = fminf(__builtin_amdgcn_exp2f(K1 * acc[tt][u >> 2][4 * (u & 3) + 3]), 1e18f);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) ei[u] = gate_frac(ei[u], eg[u]);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) ef[u] = __builtin_amdgcn_rcpf(1.0f + ef[u]);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) cq[u] = fmaf(ef[u], cq[u], ei[u]);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) eg[u] = fminf(__builtin_amdgcn_exp2f(-2.8853900817779268f * cq[u]), 1e18f);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) hval[u] = gate_frac(eo[u], eg[u]);
-            }
-            const int blk = sq * NTQ + toff + tt;
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cst[tt][sb][q] = cq[4 * sb + q];
-                half4 vh, vl;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    vh[q] = (_Float16)hval[4 * sb + q];
-                    float d = hval[4 * sb + q] - (float)vh[q];
-                    asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
-                    vl[q] = (_Float16)d;
-                }
-                *(half4 *)&hb_hi[nxt][32 * sb + j][8 * blk + 4 * hh] = vh;
-                *(half4 *)&hb_lo[nxt][32 * sb + j][8 * blk + 4 * hh] = vl;
-                if (!(ABL & 4)) {
-                    _Float16 *yp = y + ((size_t)t * (2 * HV) + dir * HV + blk) * nstride * 8 + yoff[sb];
-                    *(half4 *)yp = vh;
-                    if constexpr (!YQ) {
-                        *(half4 *)(yp + plane_out) = vl;
-                    } else {
-                        // units U = dir * 128 + 8 blk + 4 hh + q of y1's 256: 32-k block U / 32, 16-byte part (U % 32) / 16, bytes U % 16;
-                        // plane-1 row = block * 4 + term * 2 + part (term 0: (h - f16(h)) 2^18, term 1: h 2^6)
-                        float lo[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { float d = hval[4 * sb + q] - (float)vh[q]; asm volatile("" : "+v"(d)); lo[q] = d * 262144.f; }
-                        int w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], 0, false);
-                        w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], w_lo, true);
-                        int w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[4 * sb + 0] * 64.f, hval[4 * sb + 1] * 64.f, 0, false);
-                        w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[4 * sb + 2] * 64.f, hval[4 * sb + 3] * 64.f, w_hi, true);
-                        const int row0 = (dir * 4 + (blk >> 2)) * 4 + ((blk & 3) >> 1);
-                        _Float16 *qp = y + plane_out + ((size_t)t * (2 * HV) + row0) * nstride * 8 + (uint32_t)(site0 + 32 * sb + j) * 8 + 4 * (blk & 1) + 2 * hh;
-                        *(int *)qp = w_lo;
-                        *(int *)(qp + (size_t)2 * nstride * 8) = w_hi;
-                    }
-                }
-            }
-        }
-        C3R_TPH(3);
-        if (step + 1 < NET_T) x_store(nxt);
-        C3R_TPH(4);
-        if (!(TEAMS > 1 && team == 1 && step == NET_T - 1))
-            __syncthreads();                                   // h_t and x_{t+1} complete; everyone is done with h_{t-1} and x_t
-        C3R_TPH(5);
-    }
-#ifdef C3R_L1_TIMING
-    if (blockIdx.x == 0 && blockIdx.y == 7 && lane == 0) {      // probe build only: the sink sits behind the y1 planes (tools/lstm_probe_l1w8.hip)
-        long long *sink = reinterpret_cast<long long *>(y + 2 * plane_out) + wave * 6;
-        for (int q = 0; q < 6; ++q) sink[q] = tph[q];
-    }
-#endif
-#undef C3R_TPH
-}
-
-// ------------------------------------------------------------------------------------------------
 // Layer 1 with REGISTER-STATIONARY weights: k_lstm1_rs, 1024 threads = 16 wavefronts (four per SIMD, 128 registers), 64 sites x one
 // direction per workgroup, one workgroup per CU.  Layer 1 is small enough for it: a wavefront owns ONE gate-row tile and loads that
 // tile's split-f16 weights — 10 k-groups x (hi, lo) = 80 registers — once, before the time loop; there is no weight stream at all.
-// k_lstm1_w8 at 128 registers has no room for a prefetch ring, so each of its k-groups is "load, wait an L2 round trip, use": 13-16 k
-// of a step's 21.7 k clocks (tools/lstm_probe_l1w8 -DC3R_L1_TIMING).  The price: the workgroup's two 32-site blocks go through one
+// Round 2's streaming kernel (k_lstm1_w8, in git history) had no registers for a prefetch ring at 128 registers, so each of its k-groups
+// was "load, wait an L2 round trip, use": 13-16 k of a step's 21.7 k clocks.  The price: the workgroup's two 32-site blocks go through one
 // accumulator one after the other (no registers for two), and every B fragment is read from LDS by sixteen wavefronts.
-// Same Wp layout as k_lstm1_w8 ([dir][quarter][g][tile(4)][hi|lo][lane]; tile blk = 4 quarter + tile), bias on input slot CIN.
+// Wp: [dir][quarter][g][tile(4)][hi|lo][lane] (tile blk = 4 quarter + tile); the bias rides on input slot CIN (x = 1 there).
 template <int CIN, bool YQ = false>
 __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp, _Float16 *__restrict__ y, int n, int nstride) {
     constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NTQ = 4, WG_SITES = 64, HV = H / 8, XP = 40;
@@ -1982,12 +1077,6 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
 #endif
     if (C3R_L1_RS_PRIO > 0 && blk >= C3R_L1_RS_PRIO) __builtin_amdgcn_s_setprio(1);
 
-#ifdef C3R_L1_TIMING
-    long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
-#define C3R_TPH(K) do { const long long now_ = clock64(); tph[K] += now_ - tlast; tlast = now_; } while (0)
-#else
-#define C3R_TPH(K) do {} while (0)
-#endif
     for (int step = 0; step < NET_T; ++step) {
         const int t = dir ? NET_T - 1 - step : step;
         const int cur = step & 1, nxt = cur ^ 1;
@@ -2012,8 +1101,7 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[G], bh[G & 1], acc, 0, 0, 0);
                 if constexpr (G >= NGX) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[G], bl[G & 1], acc, 0, 0, 0);      // (the int32 input has no lo half)
             });
-            C3R_TPH(2 * sb);
-            // ---- lane-local cell update of the block (k_lstm1_w8's arithmetic, four units per lane)
+            // ---- lane-local cell update of the block (four units per lane)
             constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
             float ei[4], ef[4], eg[4], eo[4], cq[4], hval[4];
             {
@@ -2045,7 +1133,7 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
             for (int q = 0; q < 4; ++q) {
                 vh[q] = (_Float16)hval[q];
                 float d = hval[q] - (float)vh[q];
-                asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16): see k_lstm1_skew
+                asm volatile("" : "+v"(d));            // subtract, then convert (never v_fma_mixlo_f16: it rounds differently)
                 vl[q] = (_Float16)d;
                 lo[q] = d * 262144.f;
             }
@@ -2055,7 +1143,7 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
             *(half4 *)yp = vh;
             if constexpr (!YQ) {
                 *(half4 *)(yp + plane_out) = vl;
-            } else {                                     // the fp8 plane precision 2's layer 2 reads (see k_lstm1_w8)
+            } else {                                     // the fp8 plane precision 2's layer 2 reads (k_lstm2_mx's x layout)
                 int w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], 0, false);
                 w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], w_lo, true);
                 int w_hi = __builtin_amdgcn_cvt_pk_fp8_f32(hval[0] * 64.f, hval[1] * 64.f, 0, false);
@@ -2065,21 +1153,11 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
                 *(int *)qp = w_lo;
                 *(int *)(qp + (size_t)2 * nstride * 8) = w_hi;
             }
-            C3R_TPH(2 * sb + 1);
         }
-        C3R_TPH(4);
         if (step + 1 < NET_T) x_store(nxt);
         __syncthreads();                                       // h_t and x_{t+1} complete; everyone is done with h_{t-1} and x_t (LDS counters
                                                                // instead of this barrier, as in layer 2, measured slower: 6.3 against 5.8 ms)
-        C3R_TPH(5);
     }
-#ifdef C3R_L1_TIMING
-    if (blockIdx.x == 0 && blockIdx.y == 7 && lane == 0) {      // probe build only: the sink sits behind the y1 planes (tools/lstm_probe_l1rs.hip)
-        long long *sink = reinterpret_cast<long long *>(y + 2 * plane_out) + blk * 6;
-        for (int q = 0; q < 6; ++q) sink[q] = tph[q];
-    }
-#endif
-#undef C3R_TPH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2128,63 +1206,8 @@ __global__ __launch_bounds__(256) void k_fc4(const float *__restrict__ y2, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// Heads: L5_1 / L5_2 (128->128 selu each), Y_gt21 (128->21) / Y_genotype (128->3) with selu THEN
-// softmax (clair3_rna/model.py:150-152,196-198).  0.15 % of the flops: plain VALU, 8 sites per block.
-constexpr int HEAD_SITES = 8;
-// parts == 2: a4 is [n][2][128] partial pre-activations of L4 (one per LSTM direction): a4 = selu(p0 + p1 + b4).
-__global__ __launch_bounds__(256) void k_heads(const float *__restrict__ a4, int parts, const float *__restrict__ b4,
-                                               const float *__restrict__ w5 /* [128][256] */,
-                                               const float *__restrict__ b5 /* [256] */, const float *__restrict__ wo /* [128][24] */,
-                                               const float *__restrict__ bo /* [24] */, float *__restrict__ probs, int n) {
-    __shared__ float s_a4[HEAD_SITES][128];
-    __shared__ float s_a5[HEAD_SITES][256];
-    __shared__ float s_lg[HEAD_SITES][24];
-    const int tid = threadIdx.x;
-    const int site0 = blockIdx.x * HEAD_SITES;
-    for (int i = tid; i < HEAD_SITES * 128; i += 256) {
-        const int s = site0 + i / 128, u = i % 128;
-        float v = 0.f;
-        if (s < n) v = parts == 2 ? selu(a4[((size_t)s * 2) * 128 + u] + a4[((size_t)s * 2 + 1) * 128 + u] + b4[u]) : a4[(size_t)s * 128 + u];
-        s_a4[i / 128][u] = v;
-    }
-    __syncthreads();
-    {
-        float acc[HEAD_SITES];
-#pragma unroll
-        for (int s = 0; s < HEAD_SITES; ++s) acc[s] = b5[tid];
-        for (int k = 0; k < 128; ++k) {
-            const float w = w5[k * 256 + tid];
-#pragma unroll
-            for (int s = 0; s < HEAD_SITES; ++s) acc[s] = fmaf(s_a4[s][k], w, acc[s]);
-        }
-#pragma unroll
-        for (int s = 0; s < HEAD_SITES; ++s) s_a5[s][tid] = selu(acc[s]);
-    }
-    __syncthreads();
-    if (tid < HEAD_SITES * 24) {
-        const int s = tid / 24, o = tid % 24;
-        const int off = o < 21 ? 0 : 128;     // gt21 reads the L5_1 half, genotype the L5_2 half
-        float acc = bo[o];
-        for (int k = 0; k < 128; ++k) acc = fmaf(s_a5[s][off + k], wo[k * 24 + o], acc);
-        s_lg[s][o] = selu(acc);
-    }
-    __syncthreads();
-    if (tid < HEAD_SITES * 2) {
-        const int s = tid >> 1, part = tid & 1;
-        const int o0 = part ? 21 : 0, o1 = part ? 24 : 21;
-        if (site0 + s < n) {
-            float m = -1e30f;
-            for (int o = o0; o < o1; ++o) m = fmaxf(m, s_lg[s][o]);
-            float sum = 0.f;
-            for (int o = o0; o < o1; ++o) sum += __expf(s_lg[s][o] - m);
-            for (int o = o0; o < o1; ++o) probs[(size_t)(site0 + s) * C3R_NPROB + o] = __expf(s_lg[s][o] - m) / sum;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Heads on the fp32 matrix pipe (k_heads_mfma): the same arithmetic as k_heads — L4's selu, the two 128->128 selu branches, 21 + 3
-// logits with selu THEN softmax — as exact-f32 MFMAs (v_mfma_f32_32x32x2_f32 == an fmaf chain), 32 sites per workgroup.  k_heads
+// Heads on the fp32 matrix pipe (k_heads_mfma): L4's selu, the two 128->128 selu branches, 21 + 3
+// logits with selu THEN softmax — as exact-f32 MFMAs (v_mfma_f32_32x32x2_f32 == an fmaf chain), 32 sites per workgroup.  A VALU version
 // spent 0.39 ms of a chr20 pass on 14 GFLOP of scalar fmaf; the transposed scheme of k_fc4 (rows = output units, cols = sites)
 // does it at the f32 MFMA rate.  The 24 logits are ONE 32-row tile over K = 256: rows 0..20 read the L5_1 half of a5, rows 21..23
 // the L5_2 half (zero weights elsewhere); its K range is split over the four wavefronts and summed through LDS.
@@ -2342,7 +1365,7 @@ inline float h2f(uint16_t h) {
 inline void split_h(float v, uint16_t &hi, uint16_t &lo) { hi = f2h(v); lo = f2h(v - h2f(hi)); }
 
 // Split-f16 packing of one LSTM direction: [wave][g16][tile][hi|lo][lane][8 halves], weights x 2^12.
-// bias_slot != nullptr (layer 1): the bias rides on the first padded input slot (k = cin), see k_lstm1_skew.
+// bias_slot != nullptr (layer 1): the bias rides on the first padded input slot (k = cin).
 inline void pack_lstm_dir_h(const float *Kin, int cin, int inp, const float *R, int H, std::vector<uint16_t> &wp, const float *bias_slot = nullptr) {
     const int K = inp + H, NG = K / 16, NBLK = 4 * H / 32, NT = NBLK / 4;
     wp.assign((size_t)NBLK * NG * 2 * 64 * 8, 0);
@@ -2491,7 +1514,7 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
         const float *b = q; q += 4 * NET_H1;
         pack_lstm_dir(Kin, C, inp1, R, b, NET_H1, tw, tb);
         w1.insert(w1.end(), tw.begin(), tw.end()); b1.insert(b1.end(), tb.begin(), tb.end());
-        pack_lstm_dir_h(Kin, C, inp1, R, NET_H1, th, (C3R_L1_SKEW || C3R_L1_W8) ? b : nullptr);
+        pack_lstm_dir_h(Kin, C, inp1, R, NET_H1, th, b);
         w1h.insert(w1h.end(), th.begin(), th.end());
         // (layer 1: the recurrent part only — the integer pileup counts are exact in f16 but not in fp8)
         pack_mx([&](int k, int blk, int r) { return R[(size_t)k * 4 * NET_H1 + gate_col(blk, r, NET_H1)]; }, 4 * NET_H1 / 32, NET_H1 / 32, 0, NET_H1 / 32, tq, ts);
@@ -2666,68 +1689,31 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
     const int nb = (int)((n + NET_SITES - 1) / NET_SITES);
     const dim3 grid((unsigned)((n + LSTM_SITES - 1) / LSTM_SITES), 2), block(256);
     int heads_parts = 1;
-    if (s.precision == 2) {
-        // f16 main term + both corrections on the block-scaled fp8 pipe (k_lstm2_mx): y1 = f16 plane + fp8 plane of the same geometry
+    if (s.precision == 1 || s.precision == 2) {
+        // split-f16 path: y1 holds a hi and a lo f16 plane (same bytes as one fp32 plane), stored with the site stride rounded up to 128
+        // so that layer 1 needs no bounds guard.  Precision 2 (f16 main term + both corrections on the block-scaled fp8 pipe,
+        // k_lstm2_mx): y1 = f16 plane + fp8 plane of the same geometry.  Layer 2 has the L4 dense layer fused in: y2 is never materialised.
+        static_assert(C3R_DIR_ILV == 1, "the split-f16 kernels are launched on the (2, groups) grid");
         _Float16 *y1h = (_Float16 *)s.d_y1;
         const int ns = (int)((n + 127) / 128 * 128);
         const dim3 g2(2, grid.x);
-        static_assert(C3R_DIR_ILV == 1, "the precision-2 kernels are launched on the (2, groups) grid");
+        const bool mx = s.precision == 2;
         prof("k_lstm1", 0);
-        if (C3R_L1_RS) {
-            if (s.channels == C3R_CH) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
-            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
-        } else if (s.channels == C3R_CH)
-            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH, 0, 1, true>), g2, dim3(512), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
-        else
-            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH_PHASED, 0, 1, true>), g2, dim3(512), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+        if (s.channels == C3R_CH) {
+            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+        } else {
+            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+        }
         prof("k_lstm1", 1);
         prof("k_lstm2", 0);
-        hipLaunchKernelGGL(k_lstm2_mx, g2, dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const uint32_t *)s.d_w2q, (const uint32_t *)s.d_w2s,
-                           (const float *)s.d_b2, (int)n, (const half8 *)s.d_w4f, (const uint32_t *)s.d_w4q, (const uint32_t *)s.d_w4s, s.d_a4, ns);
-        prof("k_lstm2", 1);
-        heads_parts = 2;
-    } else if (s.precision == 1) {
-        // split-f16 path: y1 / y2 hold hi and lo f16 planes (same bytes as one fp32 plane)
-        _Float16 *y1h = (_Float16 *)s.d_y1, *y2h = (_Float16 *)s.d_y2;
-        // layer 1: two 64-site groups per workgroup, phases skewed (k_lstm1_skew); the y1 planes use a site stride padded
-        // to the workgroup's 128 sites so that its stores need no bounds guard
-        const int ns = (int)((n + 127) / 128 * 128);
-        const dim3 grid1((unsigned)(ns / 128), 2);
-        prof("k_lstm1", 0);
-#if C3R_L1_W8
-        const dim3 gridn = C3R_L1_TEAMS == 2 ? grid1 : grid, gridw = C3R_DIR_ILV ? dim3(2, gridn.x) : gridn;
-        if (C3R_L1_RS) {
-            if (s.channels == C3R_CH) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH>), gridw, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
-            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED>), gridw, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
-        } else
-        if (s.channels == C3R_CH)
-            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH, 0, C3R_L1_TEAMS>), gridw, dim3(512 * C3R_L1_TEAMS), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+        if (mx)
+            hipLaunchKernelGGL(k_lstm2_mx, g2, dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const uint32_t *)s.d_w2q, (const uint32_t *)s.d_w2s,
+                               (const float *)s.d_b2, (int)n, (const half8 *)s.d_w4f, (const uint32_t *)s.d_w4q, (const uint32_t *)s.d_w4s, s.d_a4, ns);
         else
-            hipLaunchKernelGGL((k_lstm1_w8<C3R_CH_PHASED, 0, C3R_L1_TEAMS>), gridw, dim3(512 * C3R_L1_TEAMS), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
-#elif C3R_L1_SKEW
-        if (s.channels == C3R_CH)
-            hipLaunchKernelGGL((k_lstm1_skew<C3R_CH>), grid1, block, 0, st, d_x, (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, ns);
-        else
-            hipLaunchKernelGGL((k_lstm1_skew<C3R_CH_PHASED>), grid1, block, 0, st, d_x, (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, ns);
-#else
-        if (s.channels == C3R_CH)
-            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH, NET_H1, true, LSTM1H_SB, 0, false, C3R_L1_PD, C3R_L1_ILV>), grid, block, 0, st, (const void *)d_x,
-                               (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, nullptr, nullptr, ns);
-        else
-            hipLaunchKernelGGL((k_lstm_h<32, C3R_CH_PHASED, NET_H1, true, LSTM1H_SB, 0, false, C3R_L1_PD, C3R_L1_ILV>), grid, block, 0, st, (const void *)d_x,
-                               (const half8 *)s.d_w1h, (const float *)s.d_b1, y1h, (int)n, nullptr, nullptr, ns);
-#endif
-        prof("k_lstm1", 1);
-        prof("k_lstm2", 0);
-        // layer 2 with the L4 dense layer fused in: y2 is never materialised
-#if C3R_L2_W8
-        (void)y2h;
-        hipLaunchKernelGGL((k_lstm2_w8<0>), (C3R_DIR_ILV ? dim3(2, grid.x) : grid), dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const float *)s.d_b2, (int)n,
-                           (const half8 *)s.d_w4f, s.d_a4, ns);
-#else
-        hipLaunchKernelGGL((k_lstm_h<2 * NET_H1, 2 * NET_H1, NET_H2, false, LSTM_SB, 0, true, C3R_L2_PD, C3R_L2_ILV>), grid, block, 0, st, (const void *)y1h,
-                           (const half8 *)s.d_w2h, (const float *)s.d_b2, y2h, (int)n, (const half8 *)s.d_w4f, s.d_a4, ns);
-#endif
+            hipLaunchKernelGGL((k_lstm2_w8<0>), g2, dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const float *)s.d_b2, (int)n,
+                               (const half8 *)s.d_w4f, s.d_a4, ns);
         prof("k_lstm2", 1);
         heads_parts = 2;
     } else {
@@ -2754,13 +1740,8 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
     prof("k_fc4", 1);
     }
     prof("k_heads", 0);
-#if C3R_HEADS_MFMA
     hipLaunchKernelGGL(k_heads_mfma, dim3((unsigned)((n + 31) / 32)), block, 0, st, (const float *)s.d_a4, heads_parts, (const float *)s.d_b4,
                        (const float4 *)s.d_w5p, (const float *)s.d_b5, (const float4 *)s.d_wcp, (const float *)s.d_bo, d_probs, (int)n);
-#else
-    hipLaunchKernelGGL(k_heads, dim3((unsigned)((n + HEAD_SITES - 1) / HEAD_SITES)), block, 0, st, (const float *)s.d_a4, heads_parts, (const float *)s.d_b4, (const float *)s.d_w5,
-                       (const float *)s.d_b5, (const float *)s.d_wo, (const float *)s.d_bo, d_probs, (int)n);
-#endif
     prof("k_heads", 1);
     NET_HIP(hipGetLastError());
     return C3R_OK;

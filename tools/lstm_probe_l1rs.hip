@@ -1,6 +1,6 @@
-// lstm_probe_l1rs.hip — k_lstm1_rs (layer 1 with register-stationary weights) on random operands: kernel time and, built with
-// -DC3R_L1_TIMING, where the sixteen wavefronts of one workgroup spend a step's clocks.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DC3R_L1_TIMING tools/lstm_probe_l1rs.hip -o tools/lstm_probe_l1rs
+// lstm_probe_l1rs.hip — k_lstm1_rs (layer 1 with register-stationary weights) on random operands: kernel time.
+// (The per-wavefront phase clocks of round 2 needed instrumentation inside the production kernel: removed in round 3, git history 92c9aeb.)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lstm_probe_l1rs.hip -o tools/lstm_probe_l1rs
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -29,14 +29,5 @@ int main(int argc, char **argv) {
     hipEventRecord(e0); for (int r = 0; r < 3; ++r) go(); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     printf("k_lstm1_rs: %.3f ms per launch (%d sites)\n", ms / 3, n);
-#ifdef C3R_L1_TIMING
-    long long t[96];
-    hipMemcpy(t, (char *)y + ny * 2, sizeof t, hipMemcpyDeviceToHost);
-    const char *nm[6] = {"K loop blk 0", "cell blk 0", "K loop blk 1", "cell blk 1", "(x fetch)", "x store+barrier"};
-    printf("clocks per step (workgroup (dir 0, group 7)), wavefronts 0, 1, 4, 5, 8, 12, 15:\n");
-    const int wv[7] = {0, 1, 4, 5, 8, 12, 15};
-    for (int ph = 0; ph < 6; ++ph) { printf("%-16s", nm[ph]); for (int q = 0; q < 7; ++q) printf(" %7lld", t[wv[q] * 6 + ph] / 33); printf("\n"); }
-    printf("%-16s", "total"); for (int q = 0; q < 7; ++q) { long long sm = 0; for (int ph = 0; ph < 6; ++ph) sm += t[wv[q] * 6 + ph]; printf(" %7lld", sm / 33); } printf("\n");
-#endif
     return 0;
 }

@@ -1,6 +1,6 @@
-// lstm_probe_mx.hip — k_lstm2_mx (precision 2, layer 2 + fused L4) on random operands: kernel time and, built with -DC3R_MX_TIMING, where
-// the eight wavefronts of one workgroup spend their cycles (x part | mid barrier | h part | cell update | DMA wait | end barrier).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DC3R_MX_TIMING tools/lstm_probe_mx.hip -o tools/lstm_probe_mx
+// lstm_probe_mx.hip — k_lstm2_mx (precision 2, layer 2 + fused L4) on random operands: kernel time.
+// (The per-wavefront phase clocks of round 2 needed instrumentation inside the production kernel: removed in round 3, git history 92c9aeb.)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lstm_probe_mx.hip -o tools/lstm_probe_mx
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -31,15 +31,5 @@ int main(int argc, char **argv) {
     hipEventRecord(e0); for (int r = 0; r < 3; ++r) go(); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     printf("k_lstm2_mx: %.3f ms per launch (%d sites)\n", ms / 3, n);
-#ifdef C3R_MX_TIMING
-    long long t[48];
-    hipMemcpy(t, (char *)a4 + (size_t)n * 2 * 128 * 4, sizeof t, hipMemcpyDeviceToHost);
-    const char *nm[6] = {"x part", "mid barrier", "h part", "cell update", "DMA wait", "end barrier"};
-    printf("clocks per step (workgroup (dir 0, group 7)), by wavefront:\n%-12s", "");
-    for (int wv = 0; wv < 8; ++wv) printf("  wave %d", wv);
-    printf("\n");
-    for (int ph = 0; ph < 6; ++ph) { printf("%-12s", nm[ph]); for (int wv = 0; wv < 8; ++wv) printf(" %7lld", t[wv * 6 + ph] / 33); printf("\n"); }
-    printf("%-12s", "total"); for (int wv = 0; wv < 8; ++wv) { long long s = 0; for (int ph = 0; ph < 6; ++ph) s += t[wv * 6 + ph]; printf(" %7lld", s / 33); } printf("\n");
-#endif
     return 0;
 }

@@ -55,14 +55,10 @@ int main(int argc, char **argv) {
         {"w8 no gate math", run<2>(x, w, b, n, 3)},
         {"w8 no weight stream", run<16>(x, w, b, n, 3)},
         {"w8 no gate, no weights", run<18>(x, w, b, n, 3)},
-        {"w8 8-bit lo weights", run<128>(x, w, b, n, 3)},
         {"w8 weights L1-hot", run<1>(x, w, b, n, 3)},
         {"w8 no LDS operand reads", run<32>(x, w, b, n, 3)},
         {"w8 no x DMA", run<64>(x, w, b, n, 3)},
         {"w8 full (again)", run<0>(x, w, b, n, 3)},
-        {"w8 corrections on fp8 MX", run<256>(x, w, b, n, 3)},
-        {"w8 corrections on fp6 MX", run<512>(x, w, b, n, 3)},
-        {"w8 fp8 corr, no gate", run<258>(x, w, b, n, 3)},
         {"w8 full (3rd)", run<0>(x, w, b, n, 3)},
     };
     for (auto &e : r) printf("%-26s %8.3f ms  %7.1f algorithmic TFLOP/s (x3 executed = %6.1f = %4.1f %% of 2500)\n", e.name, e.ms, flop / e.ms / 1e9,
