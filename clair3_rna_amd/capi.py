@@ -94,12 +94,15 @@ def load_library():
     return L
 
 
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16+f8": 2, "auto": 3}          # c3r_set_precision modes
+
+
 def env_precision(default="f16x3"):
     """The C3R_PRECISION environment default of the drivers' --gpu_precision flag, validated like the flag itself (argparse does
     not run `choices` on defaults)."""
     v = os.environ.get("C3R_PRECISION", default)
-    if v not in Engine.PRECISIONS:
-        raise SystemExit("C3R_PRECISION=%r: must be one of %s" % (v, ", ".join(sorted(Engine.PRECISIONS))))
+    if v not in PRECISIONS:
+        raise SystemExit("C3R_PRECISION=%r: must be one of %s" % (v, ", ".join(sorted(PRECISIONS))))
     return v
 
 
@@ -242,7 +245,7 @@ class Engine(object):
         w = np.ascontiguousarray(blob, dtype=np.float32)
         self._chk(self.L.c3r_load_weights(self.h, _ptr(w), w.size, channels))
 
-    PRECISIONS = {"f32": 0, "f16x3": 1, "f16+f8": 2, "auto": 3}
+    PRECISIONS = PRECISIONS
 
     def set_precision(self, mode):
         """'f32' (fp32 MFMA), 'f16x3' (split-f16, fp32-equivalent; default), 'f16+f8' (f16 main term + fp8 corrections, opt-in) or
