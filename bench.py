@@ -5,10 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one full pass of the hot path over one synthetic chr20 (BASELINE.json configs[1]): for each of
-the 13 five-megabase chunks (shared/param_p.py:91) tensor build (CIGAR walk -> counts -> candidates -> window
-gather) + network forward + probabilities back on the host.  Reads, reference and weights are resident in
-HBM before the timed region.  Multi-GPU: every rank owns its own chr20-sized contig (weak scaling, the
+One "step" = one full pass of the hot path over one synthetic chr20 (BASELINE.json configs[1]), as SURVEY.md 8(d) defines
+the metric: from the contig's aligned-read records RESIDENT IN HOST MEMORY (flat c3r_read_t records, BAM-encoded CIGARs, 4-bit
+bases — what a BAM reader hands over, where the reference starts `samtools mpileup`, src/create_tensor_pileup.py:436-451) to the
+[n, 24] probabilities on the host: upload + CIGAR normalisation / segmentation / op table on the device (c3r_load_reads), tensor
+build over the 13 five-megabase chunks (shared/param_p.py:91: CIGAR walk -> counts -> candidates -> windows), network forward,
+probabilities back.  Only the reference sequence and the weights are resident in HBM before the timed region (they do not change
+from pass to pass).  The rate with the read tables already prepared on the device is reported beside it as `resident_inputs`.  Multi-GPU: every rank owns its own chr20-sized contig (weak scaling, the
 reference shards by contig/chunk with no exchange step: run_clair3_rna:681-706); no data-path collective.
 Rank 0 prints ONE JSON line.
 """
@@ -30,8 +33,59 @@ FLOP_PER_SITE = {"k_lstm1": 2.0 * (18 + 128) * 512 * 33 * 2, "k_lstm2": 2.0 * (2
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (never the 2:1-sparse figure)
 PEAK_HBM_GBPS = 8000.0
-# algorithmic bytes per emitted candidate for the tensor-build kernels (SURVEY.md §8d worked example, D = 20)
-K1_BYTES_PER_SITE = 773 + 2424
+NET_KERNELS = ("k_lstm1", "k_lstm2", "k_fc4", "k_heads")
+
+
+def k1_algorithmic_bytes(rs, centres, channels, min_mq=5, excl_flags=2316):
+    """ALGORITHMIC bytes of the tensor build for these candidates, SURVEY.md 8(d)'s formula evaluated on the data (not its worked
+    example): per candidate window [c-16, c+16], over the reads whose span overlaps it, 16 B of header + 4 B per CIGAR op that
+    intersects the window (at least one) + half a byte per query base consumed inside it, + 33 B of reference; out: 33 * C * 4 B of
+    int32 window + 48 B of site record.  Headers are counted for every read (the filters have to look at them), ops and bases for
+    the reads that pass them.  (The per-read round-up of the half bytes is taken as its mean, a quarter byte per read.)
+    centres: 1-based positions.  Returns total bytes."""
+    r = rs.reads
+    n = len(r)
+    if n == 0 or len(centres) == 0:
+        return 0
+    cig = rs.cigar.astype(np.int64)
+    op, ln = cig & 15, cig >> 4
+    rid = np.repeat(np.arange(n), r["n_cigar"].astype(np.int64))
+    # (the generator lays the CIGARs out back to back in read order)
+    assert int(r["cigar_off"][0]) == 0 and np.all(np.diff(r["cigar_off"].astype(np.int64)) == r["n_cigar"][:-1].astype(np.int64))
+    ref_len = np.where((op == 0) | (op == 2) | (op == 3) | (op == 7) | (op == 8), ln, 0)
+    cum = np.cumsum(ref_len) - ref_len
+    first = r["cigar_off"].astype(np.int64)
+    start = r["pos"].astype(np.int64)[rid] + cum - cum[first][rid]
+    end = start + ref_len
+    rend = np.zeros(n, np.int64)
+    np.maximum.at(rend, rid, end)
+    rend = np.maximum(rend, r["pos"].astype(np.int64))
+    flag = r["flag"].astype(np.int64)
+    ok = ((flag & excl_flags) == 0) & ((flag & 4) == 0) & ~(((flag & 1) != 0) & ((flag & 2) == 0)) & (r["mapq"] >= min_mq) & (rend > r["pos"])
+    c0 = np.asarray(centres, np.int64) - 1
+    w0, w1 = c0 - 16, c0 + 17
+    pos_sorted, end_sorted = np.sort(r["pos"].astype(np.int64)), np.sort(rend)
+    n_hdr = np.searchsorted(pos_sorted, w1, "left") - np.searchsorted(end_sorted, w0, "right")
+    keep = ok[rid] & (op != 5) & (op != 6) & (ln > 0)
+    s_k, e_k = start[keep], end[keep]
+    n_ops = np.searchsorted(np.sort(s_k), w1, "left") - np.searchsorted(np.sort(e_k), w0, "right")
+    n_pass = np.searchsorted(np.sort(r["pos"].astype(np.int64)[ok]), w1, "left") - np.searchsorted(np.sort(rend[ok]), w0, "right")
+    n_ops = np.maximum(n_ops, n_pass)
+
+    def bases_below(x, s_, e_):          # query bases of M-like ops that sit on reference positions < x
+        o1, o2 = np.argsort(s_, kind="stable"), np.argsort(e_, kind="stable")
+        ss, es = s_[o1], e_[o2]
+        a = np.searchsorted(ss, x, "left"); b = np.searchsorted(es, x, "right")
+        csa = np.concatenate([[0], np.cumsum(ss)]); csb = np.concatenate([[0], np.cumsum(s_[o2])]); clb = np.concatenate([[0], np.cumsum((e_ - s_)[o2])])
+        return clb[b] + x * (a - b) - (csa[a] - csb[b])
+    m = ok[rid] & ((op == 0) | (op == 7) | (op == 8))
+    bases = bases_below(w1, start[m], end[m]) - bases_below(w0, start[m], end[m])
+    ins = ok[rid] & (op == 1)
+    si = np.sort(start[ins]); ci = np.concatenate([[0], np.cumsum(ln[ins][np.argsort(start[ins], kind="stable")])])
+    bases = bases + ci[np.searchsorted(si, w1, "left")] - ci[np.searchsorted(si, w0, "right")]
+    total_in = 16 * n_hdr.sum() + 4 * n_ops.sum() + 0.5 * bases.sum() + 0.25 * n_pass.sum() + 33 * len(c0)
+    total_out = (33 * channels * 4 + 48) * len(c0)
+    return float(total_in + total_out)
 
 
 def chunk_list(contig_len, chunk=CHUNK):
@@ -106,6 +160,7 @@ def main():
     ap.add_argument("--contexts", type=int, default=2, help="engine contexts (HIP streams) whose passes are pipelined on the GPU")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--no_resident", action="store_true", help="skip the additional measurement with the read tables already on the device")
     ap.add_argument("--no_fast", action="store_true", help="skip the additional measurement in precision 'auto' (reported as fast_precision)")
     ap.add_argument("--no_overlap", action="store_true",
                     help="one context / one stream: tensor build and network strictly back to back")
@@ -143,9 +198,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     chunks = chunk_list(contig_len)
+    # the host-resident flat records of the contig, in page-locked memory (c3r_host_alloc) so that their upload is a DMA transfer
+    rs_host = capi.pinned_readset(rs)
     eng = capi.Engine(local_rank)
     eng.set_params()
-    eng.load_reads(rs)
+    eng.load_reads(rs_host)
     eng.set_reference(1, ref)
     eng.load_weights(weights, 18)
     eng.set_precision(args.precision)
@@ -159,8 +216,12 @@ def main():
         e.end_batch()
         return total
 
+    host_inputs = [True]     # False: the `resident_inputs` measurement (read tables prepared once, outside the timed region)
+
     def one_step():
         # ... and go through the network in ONE launch per layer (batch mode); probabilities come back to the host
+        if host_inputs[0]:
+            eng.load_reads(rs_host)
         total = tensor_build(eng)
         if total:
             eng.infer()
@@ -172,7 +233,7 @@ def main():
     engs = [eng]
     for _ in range(0 if args.no_overlap else max(1, args.contexts) - 1):
         e2 = capi.Engine(local_rank)
-        e2.set_params(); e2.load_reads(rs); e2.set_reference(1, ref); e2.load_weights(weights, 18); e2.set_precision(args.precision)
+        e2.set_params(); e2.load_reads(rs_host); e2.set_reference(1, ref); e2.load_weights(weights, 18); e2.set_precision(args.precision)
         engs.append(e2)
 
     def run_steps(k):
@@ -185,6 +246,8 @@ def main():
             e = engs[j]
             if pending[j] is not None:                            # results of pass i-ne (already long finished)
                 e.fetch_probs(pending[j])
+            if host_inputs[0]:
+                e.load_reads(rs_host)                             # host records -> device tables: part of the pass
             n = tensor_build(e)                                   # overlaps with the other contexts' network launches
             if n:
                 e.infer(fetch=False)
@@ -222,6 +285,29 @@ def main():
         elapsed = shard.reduce_max(dist, elapsed, device=red_dev)    # max over ranks
         sites = int(shard.reduce_sum(dist, sites, device=red_dev))   # whole-job aggregate
     sites_per_step_rank = sites / max(1, args.steps) / world
+
+    # ---- the same K steps with the read tables already prepared on the device (what rounds 1-2 reported as `value`): an ADDITIONAL
+    # figure that shows what handing the records over costs
+    resident = None
+    if args.steps > 0 and not args.no_resident:
+        host_inputs[0] = False
+        barrier()
+        run_steps(min(2, args.steps))
+        barrier()
+        t1 = time.perf_counter()
+        rsites = run_steps(args.steps)
+        for e in engs:
+            e.synchronize()
+        torch.cuda.synchronize()
+        rel = time.perf_counter() - t1
+        if dist is not None:
+            dist.barrier()
+            from clair3_rna_amd import shard
+            rel = shard.reduce_max(dist, rel, device=red_dev)
+            rsites = int(shard.reduce_sum(dist, rsites, device=red_dev))
+        resident = dict(value=round(rsites / rel, 1), unit="sites/s", ms_per_step=round(1e3 * rel / args.steps, 3),
+                        note="read tables (normalised CIGARs, segments, op table) prepared once outside the timed region; not the headline")
+        host_inputs[0] = True
 
     # ---- the same K steps once more in precision "auto" (f16 main term + fp8 correction terms where the library's calibration through
     # the loaded weights allows it): an ADDITIONAL figure, never `value` — the headline stays on the fp32-equivalent arithmetic
@@ -293,22 +379,26 @@ def main():
                                 frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
                                 launches=st["launches"])
         else:
-            gbps = K1_BYTES_PER_SITE * n_prof / st["launches"] / (avg_ms * 1e-3) / 1e9
-            roofline = dict(kernel=dom, bound="hbm", achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
-                            frac=round(gbps / PEAK_HBM_GBPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4), launches=st["launches"])
-        # the two halves on their own (device time of each half's kernels in the profiled pass)
-        net_ms = sum(v["total_ms"] for k, v in kernels.items() if k in ("k_lstm1", "k_lstm2", "k_fc4", "k_heads"))
+            roofline = dict(kernel=dom, bound="hbm", achieved=None, peak=PEAK_HBM_GBPS, unit="GB/s", frac=None, traffic=None,
+                            avg_launch_ms=round(avg_ms, 4), launches=st["launches"])
+        # the two halves on their own (device time of each half's kernels in the profiled pass).  The tensor-build half
+        # is everything that is not the network: read preparation (upload excluded: copies are not kernels), op table, scan, windows.
+        net_ms = sum(v["total_ms"] for k, v in kernels.items() if k in NET_KERNELS)
         k1_ms = sum(v["total_ms"] for k, v in kernels.items()) - net_ms
+        prep = ("k_reads_prep", "k_sort", "k_prefmax", "k_ops_table")
+        prep_ms = sum(v["total_ms"] for k, v in kernels.items() if k in prep)
+        k1_bytes = k1_algorithmic_bytes(rs, eng.sites()["pos"], 18) if n_prof else 0.0
+        tb_gbps = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms else 0.0
         stage_rates = dict(tensor_build_sites_per_s=round(n_prof / (k1_ms * 1e-3), 1) if k1_ms else None,
                            inference_sites_per_s=round(n_prof / (net_ms * 1e-3), 1) if net_ms else None,
-                           tensor_build_algorithmic_GBps=round(K1_BYTES_PER_SITE * n_prof / (k1_ms * 1e-3) / 1e9, 1) if k1_ms else None,
-                           tensor_build_ms=round(k1_ms, 3), inference_ms=round(net_ms, 3))
-        # the tensor-build half against ITS roofline (HBM): SURVEY 8(d)'s algorithmic bytes per candidate over the summed device
-        # time of the tensor-build kernels of the profiled pass
-        tb_gbps = K1_BYTES_PER_SITE * n_prof / (k1_ms * 1e-3) / 1e9 if k1_ms else 0.0
-        roofline_tb = dict(kernels=sorted(k for k in kernels if k not in ("k_lstm1", "k_lstm2", "k_fc4", "k_heads")), bound="hbm",
+                           tensor_build_algorithmic_GBps=round(tb_gbps, 1) if k1_ms else None,
+                           tensor_build_ms=round(k1_ms, 3), read_preparation_ms=round(prep_ms, 3), inference_ms=round(net_ms, 3))
+        # the tensor-build half against ITS roofline (HBM): SURVEY 8(d)'s algorithmic bytes, evaluated on this pass's candidates,
+        # over the summed device time of ALL tensor-build kernels of the profiled pass (read preparation and op table included)
+        roofline_tb = dict(kernels=sorted(k for k in kernels if k not in NET_KERNELS), bound="hbm",
                            achieved=round(tb_gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(tb_gbps / PEAK_HBM_GBPS, 4),
-                           bytes_per_site=K1_BYTES_PER_SITE, ms=round(k1_ms, 3))
+                           bytes_per_site=round(k1_bytes / n_prof, 1) if n_prof else None, bytes_per_pass=int(k1_bytes), ms=round(k1_ms, 3),
+                           note="bytes: SURVEY 8(d) formula evaluated on the pass's own candidates and reads (bench.k1_algorithmic_bytes)")
         traffic_fn = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
         if roofline and os.path.exists(traffic_fn):
             try:
@@ -326,12 +416,13 @@ def main():
                                          "auto": "auto: f16+f8 where the calibration allows, else f16x3"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "synthetic ONT dRNA004 chr20 ~%dx (BASELINE.json configs[1])" % int(args.depth),
+                       "inputs": "host-resident flat records (c3r_read_t + BAM CIGARs + 4-bit bases, page-locked); reference and weights resident in HBM",
                        "contig_len": contig_len, "chunks": len(chunks), "channels": 18, "precision": args.precision, "reads_per_rank": info["n_reads"],
                        "exonic_bp_per_rank": info["n_exonic"], "sites_per_step_per_rank": round(sites_per_step_rank, 1),
                        "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world,
                        "streams": len(engs)},
             "roofline": roofline, "roofline_tensor_build": roofline_tb, "cpu_baseline": cpu, "stage_rates": stage_rates,
-            "fast_precision": fast,
+            "resident_inputs": resident, "fast_precision": fast,
             "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
         }
         print(json.dumps(out), flush=True)

@@ -33,7 +33,7 @@ class C3RError(RuntimeError):
 
 
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
-           "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
+           "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_host_alloc", "c3r_host_free", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
            "c3r_pileup_scan", "c3r_pileup_scan_regions", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
            "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
@@ -64,6 +64,10 @@ def load_library():
     L.c3r_default_params.restype = None
     L.c3r_set_params.argtypes = [vp, C.POINTER(Params)]
     L.c3r_load_reads.argtypes = [vp, vp, i64, vp, i64, vp, i64]
+    L.c3r_host_alloc.argtypes = [C.c_size_t]
+    L.c3r_host_alloc.restype = vp
+    L.c3r_host_free.argtypes = [vp]
+    L.c3r_host_free.restype = None
     L.c3r_set_reference.argtypes = [vp, i64, C.c_char_p, i64]
     L.c3r_set_bed.argtypes = [vp, i32, vp, i64]
     L.c3r_set_sites.argtypes = [vp, vp, i64]
@@ -110,6 +114,30 @@ def default_params():
     p = Params()
     load_library().c3r_default_params(C.byref(p))
     return p
+
+
+def pinned_copy(a):
+    """A copy of numpy array `a` in page-locked host memory (c3r_host_alloc): uploads from it are asynchronous DMA transfers.
+    The block is freed when the last array that views it is collected."""
+    import weakref
+    a = np.ascontiguousarray(a)
+    L = load_library()
+    nbytes = max(1, a.nbytes)
+    p = L.c3r_host_alloc(nbytes)
+    if not p:
+        raise MemoryError("c3r_host_alloc(%d) failed" % nbytes)
+    flat = np.frombuffer((C.c_char * nbytes).from_address(p), dtype=np.uint8)      # every later view keeps `flat` alive as its base
+    weakref.finalize(flat, L.c3r_host_free, p)
+    out = flat[:a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+def pinned_readset(rs):
+    """ReadSet with its three arrays in page-locked memory."""
+    out = ReadSet.__new__(ReadSet)
+    out.reads, out.cigar, out.seq = pinned_copy(rs.reads), pinned_copy(rs.cigar), pinned_copy(rs.seq)
+    return out
 
 
 def _ptr(a):

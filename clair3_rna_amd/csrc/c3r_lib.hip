@@ -19,6 +19,8 @@
 #include "decode.hpp"
 #include "net_kernels.hpp"
 #include "pileup_kernels.hpp"
+#include "reads_kernels.hpp"
+#include <rocprim/device/device_radix_sort.hpp>
 
 using namespace c3r;
 
@@ -44,14 +46,19 @@ struct c3r_ctx {
     std::vector<std::string> kstat_names;   // stable storage for c3r_get_kernel_stats
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
-    // ---- inputs
-    std::vector<DevRead> h_reads;          // normalised, kept for alt-info formatting
-    std::vector<uint32_t> h_cigar;
-    std::vector<uint8_t> h_seq;
-    int64_t n_indel_ops = 0;
-    std::vector<int64_t> h_indel_prefix;  // [n_reads + 1] running count of I/D ops (normalised CIGARs): sizes the event scratch per scan
+    // ---- inputs: the device holds the read tables; host copies are fetched on demand (depth cap, decode)
+    int32_t n_reads = 0, n_segs = 0;       // of the loaded contig
+    int64_t n_indel_ops = 0;               // I + D ops of the normalised CIGARs: bounds the indel-event scratch of a scan
+    int64_t n_seq_bytes = 0;
+    DevBuf d_rawreads, d_rawcig;           // the caller's records as they arrived (c3r_read_t, BAM-encoded ops)
+    DevBuf d_rcnt, d_rend, d_pass, d_ekey, d_ekey2, d_skey, d_skey2, d_sval, d_sval2, d_sorttmp, d_s4tops, d_pmtops, d_stats;
+    LoadStats *h_stats = nullptr;          // pinned
+    std::vector<DevRead> h_reads;          // lazily: ensure_host_reads
+    std::vector<int32_t> h_prefmax;        // lazily: host copy of the prefix max of read ends (passing reads)
+    bool host_reads_valid = false;
+    std::vector<uint8_t> h_seq;            // lazily: ensure_host_seq (decode reads inserted bases)
+    bool host_seq_valid = false;
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
-    std::vector<DevSeg> h_segs;            // aligned segments (CIGAR runs between N ops), sorted by ext_start
     DevBuf d_bkt; int32_t n_bkt = 0;       // bucket index of the sorted read / segment arrays (k_bucket_index)
     DevBuf d_dbg;                          // C3R_SCAN_DBG: phase timers of k_scan_tiles
     DevBuf d_tile_cand;                    // [n_tiles] {first candidate, count} of the most recent scan (k_compact_write -> k_tile_tokens)
@@ -70,7 +77,6 @@ struct c3r_ctx {
     // ---- scan state
     int32_t reg_beg0 = 0, reg_end0 = 0;   // first region of the most recent scan (c3r_get_columns)
     int64_t n_pos = 0;                    // position slots of the most recent scan (all regions, tile-padded)
-    std::vector<int32_t> h_prefmax;       // host copy of the prefix max of read ends (passing reads)
     int32_t max_cover = 0;                // most passing reads covering one position: below max_depth / 2 the cap cannot bite
     std::vector<uint32_t> h_drop;         // depth cap of the most recent scan: [n_regions][drop_words] bit per read
     DevBuf d_drop;
@@ -182,54 +188,102 @@ struct Launch {
     }
 };
 
-void recompute_prefmax(c3r_ctx *ctx, std::vector<int32_t> &pm) {
-    pm.resize(ctx->h_reads.size());
-    int32_t m = INT_MIN;
-    for (size_t i = 0; i < ctx->h_reads.size(); ++i) {
-        const DevRead &r = ctx->h_reads[i];
-        const bool pass = !flag_fails(r.flag, ctx->prm.excl_flags) && r.mapq >= ctx->prm.min_mq && r.end > r.pos;
-        if (pass) m = std::max(m, r.end);
-        pm[i] = m;
+}  // namespace
+static int device_excl_scan(c3r_ctx *ctx, int32_t *d, int n, int32_t *d_total);
+namespace {
+
+// ---- the filter-dependent tables, all on the device (reads_kernels.hpp)
+// Part A: pass flags -> rank among the passing reads, their ends sorted, deepest coverage (into the device-side LoadStats).
+int filter_cover(c3r_ctx *ctx) {
+    const int n = ctx->n_reads;
+    if (n == 0) return C3R_OK;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_pass, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, ctx->d_ekey, (size_t)n * 4)) || (rc = ensure(ctx, ctx->d_ekey2, (size_t)n * 4))) return rc;
+    LoadStats *st = (LoadStats *)ctx->d_stats.p;
+    HIPCHK(ctx, hipMemsetAsync(&st->max_cover, 0, 4, ctx->stream));
+    {
+        Launch L(ctx, "k_reads_prep");
+        hipLaunchKernelGGL(k_reads_pass, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const c3r_read_t *)ctx->d_rawreads.p, (const int32_t *)ctx->d_rend.p, n,
+                           ctx->prm.min_mq, ctx->prm.excl_flags, (int32_t *)ctx->d_pass.p, (uint32_t *)ctx->d_ekey.p);
     }
+    if ((rc = ensure(ctx, ctx->d_small, 64))) return rc;
+    if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_pass.p, n + 1, (int32_t *)((char *)ctx->d_small.p + 32)))) return rc;
+    {
+        Launch L(ctx, "k_sort");
+        size_t tmp = 0;
+        HIPCHK(ctx, rocprim::radix_sort_keys(nullptr, tmp, (const uint32_t *)ctx->d_ekey.p, (uint32_t *)ctx->d_ekey2.p, (size_t)n, 0, 32, ctx->stream));
+        if ((rc = ensure(ctx, ctx->d_sorttmp, tmp + 16))) return rc;
+        HIPCHK(ctx, rocprim::radix_sort_keys(ctx->d_sorttmp.p, tmp, (const uint32_t *)ctx->d_ekey.p, (uint32_t *)ctx->d_ekey2.p, (size_t)n, 0, 32, ctx->stream));
+    }
+    {
+        Launch L(ctx, "k_reads_prep");
+        hipLaunchKernelGGL(k_cover_max, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const c3r_read_t *)ctx->d_rawreads.p, n, (const int32_t *)ctx->d_pass.p,
+                           (const uint32_t *)ctx->d_ekey2.p, st);
+    }
+    return C3R_OK;
 }
 
-int upload_prefmax(c3r_ctx *ctx) {
-    if (ctx->h_reads.empty()) return C3R_OK;
-    std::vector<int32_t> &pm = ctx->h_prefmax;
-    recompute_prefmax(ctx, pm);
-    int rc = upload(ctx, ctx->d_prefmax, pm.data(), pm.size());
+template <int WHAT>
+int device_prefmax(c3r_ctx *ctx, const void *items, int n, DevBuf &out) {
+    int rc = ensure(ctx, out, (size_t)std::max(n, 1) * 4 + 16);
+    if (rc || n == 0) return rc;
+    const int nb = (n + PM_BLK - 1) / PM_BLK;
+    if ((rc = ensure(ctx, ctx->d_pmtops, (size_t)nb * 4 + 16))) return rc;
+    Launch L(ctx, "k_prefmax");
+    hipLaunchKernelGGL(k_prefmax_local<WHAT>, dim3(nb), dim3(1024), 0, ctx->stream, items, n, ctx->prm.min_mq, ctx->prm.excl_flags, (int32_t *)out.p, (int32_t *)ctx->d_pmtops.p);
+    if (nb > 1) {
+        hipLaunchKernelGGL(k_prefmax_tops, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)ctx->d_pmtops.p, nb);
+        hipLaunchKernelGGL(k_prefmax_add, dim3(nb), dim3(1024), 0, ctx->stream, (int32_t *)out.p, n, (const int32_t *)ctx->d_pmtops.p);
+    }
+    return C3R_OK;
+}
+
+// Part B: prefix maxima of the passing reads' / segments' ends and the bucket index k_tile_ranges searches through.
+int filter_tables(c3r_ctx *ctx, int32_t max_end) {
+    ctx->host_reads_valid = false;
+    if (ctx->n_reads == 0) { ctx->n_bkt = 0; return C3R_OK; }
+    int rc;
+    if ((rc = device_prefmax<0>(ctx, ctx->d_reads.p, ctx->n_reads, ctx->d_prefmax))) return rc;
+    if ((rc = device_prefmax<1>(ctx, ctx->d_segs.p, ctx->n_segs, ctx->d_seg_prefmax))) return rc;
+    ctx->n_bkt = (int32_t)(((int64_t)std::max(max_end, 0) >> BKT_SHIFT) + 2);
+    if ((rc = ensure(ctx, ctx->d_bkt, (size_t)4 * ctx->n_bkt * 4 + 16))) return rc;
+    Launch L(ctx, "k_reads_prep");
+    hipLaunchKernelGGL(k_bucket_index, dim3((unsigned)((ctx->n_bkt + 255) / 256)), dim3(256), 0, ctx->stream, (const DevRead *)ctx->d_reads.p, ctx->n_reads,
+                       (const int32_t *)ctx->d_prefmax.p, (const DevSeg *)ctx->d_segs.p, ctx->n_segs, (const int32_t *)ctx->d_seg_prefmax.p,
+                       (int)ctx->n_bkt, (int32_t *)ctx->d_bkt.p);
+    return C3R_OK;
+}
+
+// New filters for the reads already loaded (c3r_set_params changed --min-MQ / --excl-flags).
+int refilter(c3r_ctx *ctx) {
+    if (ctx->n_reads == 0) return C3R_OK;
+    int rc = filter_cover(ctx);
     if (rc) return rc;
-    {   // deepest coverage by passing reads (one sweep with a min-heap of ends)
-        std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> live;
-        size_t mx = 0;
-        for (const DevRead &r : ctx->h_reads) {
-            if (flag_fails(r.flag, ctx->prm.excl_flags) || r.mapq < ctx->prm.min_mq || r.end <= r.pos) continue;
-            while (!live.empty() && live.top() <= r.pos) live.pop();
-            live.push(r.end);
-            mx = std::max(mx, live.size());
-        }
-        ctx->max_cover = (int32_t)std::min<size_t>(mx, INT32_MAX);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stats, ctx->d_stats.p, sizeof(LoadStats), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->max_cover = ctx->h_stats->max_cover;
+    return filter_tables(ctx, ctx->h_stats->max_end);
+}
+
+// Host copies, fetched only by the paths that walk reads on the host: mpileup's depth cap (sequential by nature) and the decoder
+// (inserted bases of the alt alleles).
+int ensure_host_reads(c3r_ctx *ctx) {
+    if (ctx->host_reads_valid) return C3R_OK;
+    ctx->h_reads.resize((size_t)ctx->n_reads); ctx->h_prefmax.resize((size_t)ctx->n_reads);
+    if (ctx->n_reads) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_reads.data(), ctx->d_reads.p, (size_t)ctx->n_reads * sizeof(DevRead), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_prefmax.data(), ctx->d_prefmax.p, (size_t)ctx->n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    std::vector<int32_t> sm(ctx->h_segs.size());
-    int32_t m = INT_MIN;
-    for (size_t i = 0; i < ctx->h_segs.size(); ++i) {
-        const DevSeg &g = ctx->h_segs[i];
-        const bool pass = !flag_fails(g.flag, ctx->prm.excl_flags) && g.mapq >= ctx->prm.min_mq;
-        if (pass) m = std::max(m, g.end);
-        sm[i] = m;
-    }
-    if ((rc = upload(ctx, ctx->d_seg_prefmax, sm.data(), sm.size()))) return rc;
-    {   // bucket index for k_tile_ranges (the prefix maxima depend on the filters: rebuilt with them)
-        int32_t top = 0;
-        for (int32_t v : pm) top = std::max(top, v);
-        ctx->n_bkt = (int32_t)(((int64_t)top >> BKT_SHIFT) + 2);
-        if ((rc = ensure(ctx, ctx->d_bkt, (size_t)4 * ctx->n_bkt * 4 + 16))) return rc;
-        hipLaunchKernelGGL(k_bucket_index, dim3((unsigned)((ctx->n_bkt + 255) / 256)), dim3(256), 0, ctx->stream, (const DevRead *)ctx->d_reads.p, (int)ctx->h_reads.size(),
-                           (const int32_t *)ctx->d_prefmax.p, (const DevSeg *)ctx->d_segs.p, (int)ctx->h_segs.size(), (const int32_t *)ctx->d_seg_prefmax.p,
-                           (int)ctx->n_bkt, (int32_t *)ctx->d_bkt.p);
-    }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // pm / sm are temporaries
-    HIPCHK(ctx, hipGetLastError());
+    ctx->host_reads_valid = true;
+    return C3R_OK;
+}
+int ensure_host_seq(c3r_ctx *ctx) {
+    if (ctx->host_seq_valid) return C3R_OK;
+    ctx->h_seq.resize((size_t)ctx->n_seq_bytes + 16);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_seq.data(), ctx->d_seq.p, ctx->h_seq.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->host_seq_valid = true;
     return C3R_OK;
 }
 
@@ -249,7 +303,6 @@ void merge_intervals(std::vector<int32_t> &iv) {
 
 }  // namespace
 
-static int device_excl_scan(c3r_ctx *ctx, int32_t *d, int n, int32_t *d_total);
 static int list_grid() { static const int v = [] { const char *e = getenv("C3R_LIST_GRID"); return e && atoi(e) > 0 ? atoi(e) : LIST_GRID; }(); return v; }
 
 extern "C" {
@@ -292,12 +345,14 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+    DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_rcnt, &ctx->d_rend, &ctx->d_pass, &ctx->d_ekey, &ctx->d_ekey2, &ctx->d_skey, &ctx->d_skey2, &ctx->d_sval, &ctx->d_sval2,
+                      &ctx->d_sorttmp, &ctx->d_s4tops, &ctx->d_pmtops, &ctx->d_stats, &ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     net_free(ctx->net);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -320,235 +375,138 @@ int c3r_set_params(c3r_ctx *ctx, const c3r_params_t *p) {
     const bool refilter = p->min_mq != ctx->prm.min_mq || p->excl_flags != ctx->prm.excl_flags;
     ctx->prm = *p;
     if (ctx->prm.max_depth_rescale <= 0) ctx->prm.max_depth_rescale = 144;
-    if (refilter) return upload_prefmax(ctx);
+    ctx->last_scan_pruned = false;
+    if (refilter) return ::refilter(ctx);
     return C3R_OK;
 }
 
 int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const uint32_t *cigars, int64_t n_cigar_ops,
                    const uint8_t *seq4, int64_t n_seq_bytes) {
-    if (!ctx || n_reads < 0 || (n_reads && (!reads || !cigars || !seq4))) return C3R_EINVAL;
-    if (n_reads > INT32_MAX) return fail(ctx, C3R_EINVAL, "too many reads");
+    if (!ctx || n_reads < 0 || n_cigar_ops < 0 || n_seq_bytes < 0 || (n_reads && (!reads || !cigars || !seq4))) return C3R_EINVAL;
+    if (n_reads >= INT32_MAX) return fail(ctx, C3R_EINVAL, "too many reads");
+    if (n_cigar_ops >= INT32_MAX) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool timing = getenv("C3R_TIMING") != nullptr;
-    std::vector<std::chrono::steady_clock::time_point> tp;
-    auto tick = [&] { if (timing) tp.push_back(std::chrono::steady_clock::now()); };
-    tick();
-    ctx->h_reads.clear(); ctx->h_cigar.clear(); ctx->h_segs.clear();
-    ctx->n_indel_ops = 0;
-    // Normalisation is per read; only the offsets into the flat cigar array depend on the reads before.  Slices of reads go to
-    // threads with private outputs (cig_off relative to the slice) and are stitched together afterwards.
-    struct Slice {
-        std::vector<DevRead> reads; std::vector<uint32_t> cigar; std::vector<DevSeg> segs; std::vector<uint32_t> nind; int64_t n_indel = 0; std::string err;
-        bool fail(const char *fmt, long long i) { char b[160]; snprintf(b, sizeof b, fmt, i); err = b; return false; }
-    };
-    auto norm = [&](int64_t i0, int64_t i1, Slice &o) -> bool {
-        o.reads.reserve((size_t)(i1 - i0));
-        int32_t prev_pos = i0 > 0 ? reads[i0 - 1].pos : INT_MIN;
-        for (int64_t i = i0; i < i1; ++i) {
-            const c3r_read_t &r = reads[i];
-            if (r.pos < prev_pos) return o.fail("reads must be sorted by pos (read %lld)", (long long)i);
-            prev_pos = r.pos;
-            if ((int64_t)r.cigar_off + r.n_cigar > n_cigar_ops) return o.fail("cigar range of read %lld out of bounds", (long long)i);
-            if ((int64_t)r.seq_off + (r.l_seq + 1) / 2 > n_seq_bytes) return o.fail("seq range of read %lld out of bounds", (long long)i);
-            DevRead d;
-            d.pos = r.pos; d.cig_off = (uint32_t)o.cigar.size(); d.seq_off = r.seq_off; d.flag = r.flag; d.mapq = r.mapq;
-            d.hp = r.hp; d.l_seq = r.l_seq;
-            int64_t rlen = 0;
-            // normalise: drop P/H/zero-length, fold =/X into M, merge adjacent equal ops (htslib merges runs of
-            // D and of I when it attaches an indel to a column, and skips pads)
-            for (uint32_t k = 0; k < r.n_cigar; ++k) {
-                uint32_t c = cigars[r.cigar_off + k];
-                uint32_t op = c & 15u, len = c >> 4;
-                if (op == C3R_CIG_EQ || op == C3R_CIG_X) op = C3R_CIG_M;
-                if (len == 0 || op == C3R_CIG_H) continue;
-                if (op == C3R_CIG_P) {
-                    // htslib marks a deletion only when the D op IMMEDIATELY follows the M/N op that ends on the column (a pad
-                    // in between hides it; insertions are found through pads).  So a pad is kept — as a 1-long op that consumes
-                    // nothing — exactly when the next real op is a D; every other pad is dropped.
-                    uint32_t k2 = k + 1;
-                    while (k2 < r.n_cigar && ((cigars[r.cigar_off + k2] >> 4) == 0 || (cigars[r.cigar_off + k2] & 15u) == C3R_CIG_P ||
-                                              (cigars[r.cigar_off + k2] & 15u) == C3R_CIG_H)) ++k2;
-                    if (k2 >= r.n_cigar || (cigars[r.cigar_off + k2] & 15u) != C3R_CIG_D) continue;
-                    len = 1;
-                }
-                if (op > C3R_CIG_X) return o.fail("bad cigar op in read %lld", (long long)i);
-                if (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) rlen += len;
-                if (o.cigar.size() > d.cig_off && (o.cigar.back() & 15u) == op) {
-                    const uint64_t nl = (uint64_t)(o.cigar.back() >> 4) + len;
-                    if (nl >= (1u << 28)) return o.fail("cigar op too long in read %lld", (long long)i);
-                    o.cigar.back() = (uint32_t)(nl << 4) | op;
-                } else {
-                    o.cigar.push_back((len << 4) | op);
-                }
-            }
-            d.n_cig = (uint32_t)(o.cigar.size() - d.cig_off);
-            uint32_t ni = 0;
-            for (uint32_t k = 0; k < d.n_cig; ++k) {
-                const uint32_t op = o.cigar[d.cig_off + k] & 15u;
-                if (op == C3R_CIG_I || op == C3R_CIG_D) ++ni;
-            }
-            o.n_indel += ni;
-            o.nind.push_back(ni);
-            if ((int64_t)r.pos + rlen > INT32_MAX) return o.fail("read %lld ends beyond 2^31", (long long)i);
-            d.end = (int32_t)(r.pos + rlen);
-            o.reads.push_back(d);
-            // aligned segments: the runs of ops between N ops
-            {
-                int64_t x = r.pos, y = 0;
-                uint32_t k = 0;
-                bool after_n = false;
-                while (k < d.n_cig) {
-                    DevSeg g;
-                    memset(&g, 0, sizeof g);
-                    g.pos = (int32_t)x; g.cig_off = d.cig_off + k; g.qstart = (uint32_t)y; g.l_seq = d.l_seq; g.seq_off = d.seq_off;
-                    g.read_idx = (uint32_t)i; g.flag = d.flag; g.mapq = d.mapq; g.hp = d.hp; g.lead_n = after_n ? 1 : 0;
-                    const uint32_t first_op = o.cigar[d.cig_off + k] & 15u;
-                    uint32_t k1 = k;
-                    bool useful = false;
-                    while (k1 < d.n_cig && (o.cigar[d.cig_off + k1] & 15u) != C3R_CIG_N) {
-                        const uint32_t c = o.cigar[d.cig_off + k1], op = c & 15u, len = c >> 4;
-                        if (op == C3R_CIG_M || op == C3R_CIG_D) { x += len; useful = true; }
-                        if (op == C3R_CIG_M || op == C3R_CIG_I || op == C3R_CIG_S) y += len;
-                        ++k1;
-                    }
-                    const bool lead_indel = after_n && (first_op == C3R_CIG_I || first_op == C3R_CIG_D);
-                    if (k1 > k && (useful || lead_indel)) {
-                        if (k1 - k > 0xffff) return o.fail("read %lld: more than 65535 CIGAR ops between two N ops", (long long)i);
-                        g.n_cig = (uint16_t)(k1 - k);
-                        g.ext_start = g.pos - (lead_indel ? 1 : 0);
-                        g.end = (int32_t)std::max<int64_t>(x, (int64_t)g.ext_start + 1);
-                        o.segs.push_back(g);
-                    }
-                    if (k1 < d.n_cig) { x += o.cigar[d.cig_off + k1] >> 4; after_n = true; ++k1; }   // the N op itself
-                    k = k1;
-                }
-            }
-        }
-        return true;
-    };
-    unsigned nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>({16, (int64_t)std::thread::hardware_concurrency(), n_reads / 8192}));
-    if (const char *e = getenv("C3R_THREADS")) nt = (unsigned)std::max(1, std::min(atoi(e), (int)std::max<int64_t>(1, n_reads)));
-    std::vector<Slice> sl(nt);
-    std::vector<char> ok(nt, 1);
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back([&, t] { ok[t] = norm(n_reads * t / nt, n_reads * (t + 1) / nt, sl[t]); });
-        ok[0] = norm(0, n_reads / nt, sl[0]);
-        for (auto &x : th) x.join();
-    }
-    for (unsigned t = 0; t < nt; ++t) if (!ok[t]) return fail(ctx, C3R_EINVAL, "%s", sl[t].err.c_str());
-    {
-        size_t nr = 0, nc = 0, ns = 0;
-        for (auto &o : sl) { nr += o.reads.size(); nc += o.cigar.size(); ns += o.segs.size(); }
-        if (nc > UINT32_MAX) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
-        ctx->h_reads.resize(nr); ctx->h_cigar.resize(nc); ctx->h_segs.resize(ns);
-        std::vector<size_t> br(nt + 1, 0), bc(nt + 1, 0), bs(nt + 1, 0);
-        for (unsigned t = 0; t < nt; ++t) { br[t + 1] = br[t] + sl[t].reads.size(); bc[t + 1] = bc[t] + sl[t].cigar.size(); bs[t + 1] = bs[t] + sl[t].segs.size(); }
-        auto stitch = [&](unsigned t) {
-            Slice &o = sl[t];
-            const uint32_t base = (uint32_t)bc[t];
-            for (size_t k = 0; k < o.reads.size(); ++k) { DevRead d = o.reads[k]; d.cig_off += base; ctx->h_reads[br[t] + k] = d; }
-            if (!o.cigar.empty()) memcpy(&ctx->h_cigar[bc[t]], o.cigar.data(), o.cigar.size() * 4);
-            for (size_t k = 0; k < o.segs.size(); ++k) { DevSeg g = o.segs[k]; g.cig_off += base; ctx->h_segs[bs[t] + k] = g; }
-        };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(stitch, t);
-        stitch(0);
-        for (auto &x : th) x.join();
-        for (auto &o : sl) ctx->n_indel_ops += o.n_indel;
-        ctx->h_indel_prefix.assign(nr + 1, 0);
-        size_t k = 0;
-        for (auto &o : sl) for (uint32_t v : o.nind) { ctx->h_indel_prefix[k + 1] = ctx->h_indel_prefix[k] + v; ++k; }
-    }
-    tick();
-    {   // read-order copy of the segments (for the per-candidate token kernel) before the global sort
-        std::vector<uint32_t> first((size_t)n_reads + 1, 0);
-        for (const DevSeg &g : ctx->h_segs) first[g.read_idx + 1]++;
-        for (int64_t i = 0; i < n_reads; ++i) first[i + 1] += first[i];
-        int rc2;
-        if ((rc2 = upload(ctx, ctx->d_rsegs, ctx->h_segs.data(), ctx->h_segs.size()))) return rc2;
-        if ((rc2 = upload(ctx, ctx->d_rseg_first, first.data(), first.size()))) return rc2;
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    tick();
-    {   // stable order by ext_start: sort (key, index) pairs — 8 bytes instead of the 48-byte records — then gather
-        const size_t ns = ctx->h_segs.size();
-        std::vector<uint64_t> key(ns);
-        for (size_t k = 0; k < ns; ++k) key[k] = ((uint64_t)(uint32_t)(ctx->h_segs[k].ext_start ^ INT32_MIN) << 32) | (uint32_t)k;
-        // runs sorted on threads, then merged pairwise (the keys are unique, so any correct sort is the stable one)
-        unsigned parts = 1;
-        while (parts < 8 && ns / (parts * 2) >= 65536) parts *= 2;
-        std::vector<size_t> cut(parts + 1);
-        for (unsigned q = 0; q <= parts; ++q) cut[q] = ns * q / parts;
-        {
-            std::vector<std::thread> th;
-            for (unsigned q = 1; q < parts; ++q) th.emplace_back([&, q] { std::sort(key.begin() + (long)cut[q], key.begin() + (long)cut[q + 1]); });
-            std::sort(key.begin(), key.begin() + (long)cut[1]);
-            for (auto &x : th) x.join();
-        }
-        std::vector<uint64_t> tmp(parts > 1 ? ns : 0);
-        for (unsigned w = 1; w < parts; w *= 2) {
-            std::vector<std::thread> th;
-            for (unsigned q = 0; q + w < parts + 0u; q += 2 * w)
-                th.emplace_back([&, q, w] {
-                    const size_t a = cut[q], m = cut[q + w], e = cut[std::min(q + 2 * w, parts)];
-                    std::merge(key.begin() + (long)a, key.begin() + (long)m, key.begin() + (long)m, key.begin() + (long)e, tmp.begin() + (long)a);
-                    std::copy(tmp.begin() + (long)a, tmp.begin() + (long)e, key.begin() + (long)a);
-                });
-            for (auto &x : th) x.join();
-        }
-        std::vector<DevSeg> sorted(ns);
-        {
-            auto gather = [&](size_t a, size_t e) { for (size_t k = a; k < e; ++k) sorted[k] = ctx->h_segs[(uint32_t)key[k]]; };
-            std::vector<std::thread> th;
-            for (unsigned q = 1; q < parts; ++q) th.emplace_back(gather, cut[q], cut[q + 1]);
-            gather(0, cut[1]);
-            for (auto &x : th) x.join();
-        }
-        ctx->h_segs.swap(sorted);
-    }
-    tick();
-    ctx->h_seq.assign(seq4, seq4 + n_seq_bytes);
-    ctx->h_seq.resize((size_t)n_seq_bytes + 16, 0);        // the walk reads the packed bases 8 bytes at a time
-    tick();
+    const auto t_begin = std::chrono::steady_clock::now();
+    // whatever happens below, the previous contig's tables are gone
+    ctx->n_reads = 0; ctx->n_segs = 0; ctx->n_indel_ops = 0; ctx->n_seq_bytes = 0; ctx->max_cover = 0; ctx->n_bkt = 0;
+    ctx->host_reads_valid = false; ctx->host_seq_valid = false; ctx->last_scan_pruned = false;
+    const int n = (int)n_reads;
     int rc;
-    if ((rc = upload(ctx, ctx->d_reads, ctx->h_reads.data(), ctx->h_reads.size()))) return rc;
-    if ((rc = upload(ctx, ctx->d_cigar, ctx->h_cigar.data(), ctx->h_cigar.size()))) return rc;
-    if ((rc = upload(ctx, ctx->d_seq, ctx->h_seq.data(), ctx->h_seq.size()))) return rc;
-    if ((rc = upload(ctx, ctx->d_segs, ctx->h_segs.data(), ctx->h_segs.size()))) return rc;
-    tick();
-    if ((rc = upload_prefmax(ctx))) return rc;
+    if (!ctx->h_stats) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_stats, sizeof(LoadStats), hipHostMallocDefault));
+    if ((rc = ensure(ctx, ctx->d_stats, sizeof(LoadStats))) || (rc = ensure(ctx, ctx->d_small, 64))) return rc;
+    // ---- the caller's records go up as they are (three copies; truly asynchronous when the caller's arrays are pinned, see
+    // c3r_host_alloc) and every table the tile kernels need is derived from them on the device
+    if ((rc = upload(ctx, ctx->d_rawreads, reads, (size_t)n)) || (rc = upload(ctx, ctx->d_rawcig, cigars, (size_t)n_cigar_ops))) return rc;
+    if ((rc = ensure(ctx, ctx->d_seq, (size_t)n_seq_bytes + 16))) return rc;
+    if (n_seq_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq.p, seq4, (size_t)n_seq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync((char *)ctx->d_seq.p + n_seq_bytes, 0, 16, ctx->stream));        // (the walk reads the packed bases 16 bytes at a time)
+    ctx->n_seq_bytes = n_seq_bytes;
+    if (n == 0) return C3R_OK;
+    LoadStats init;
+    memset(&init, 0, sizeof init);
+    init.err = ~0ull;
+    *ctx->h_stats = init;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stats.p, ctx->h_stats, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    LoadStats *st = (LoadStats *)ctx->d_stats.p;
+    // ---- pass 1: validation and counts, their prefix sums, and the deepest coverage
+    if ((rc = ensure(ctx, ctx->d_rcnt, (size_t)(n + 1) * sizeof(int4))) || (rc = ensure(ctx, ctx->d_rend, (size_t)n * 4))) return rc;
+    const int nb4 = (n + 1 + S4_BLK - 1) / S4_BLK;
+    if ((rc = ensure(ctx, ctx->d_s4tops, (size_t)nb4 * sizeof(int4) + 16))) return rc;
+    {
+        Launch L(ctx, "k_reads_prep");
+        hipLaunchKernelGGL(k_reads_count, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const c3r_read_t *)ctx->d_rawreads.p, n, (const uint32_t *)ctx->d_rawcig.p,
+                           (long long)n_cigar_ops, (long long)n_seq_bytes, (int4 *)ctx->d_rcnt.p, (int32_t *)ctx->d_rend.p, st);
+            hipLaunchKernelGGL(k_scan4_local, dim3(nb4), dim3(1024), 0, ctx->stream, (int4 *)ctx->d_rcnt.p, n + 1, (int4 *)ctx->d_s4tops.p);
+            hipLaunchKernelGGL(k_scan4_tops, dim3(1), dim3(1024), 0, ctx->stream, (int4 *)ctx->d_s4tops.p, nb4, (int4 *)&st->n_norm);
+        if (nb4 > 1) hipLaunchKernelGGL(k_scan4_add, dim3(nb4), dim3(1024), 0, ctx->stream, (int4 *)ctx->d_rcnt.p, n + 1, (const int4 *)ctx->d_s4tops.p);
+    }
+    ctx->n_reads = n;
+    if ((rc = filter_cover(ctx))) { ctx->n_reads = 0; return rc; }
+    ctx->n_reads = 0;
+    // ---- the one synchronisation: sizes, errors
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stats, ctx->d_stats.p, sizeof(LoadStats), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    {   // expanded op table of the sorted segments, built on the device: count -> exclusive scan -> write
-        const int ns = (int)ctx->h_segs.size();
-        if ((rc = ensure(ctx, ctx->d_seg_op_off, (size_t)(ns + 1) * 4 + 16))) return rc;
-        if ((rc = ensure(ctx, ctx->d_small, 64))) return rc;
+    HIPCHK(ctx, hipGetLastError());
+    const auto t_sync = std::chrono::steady_clock::now();
+    const LoadStats hs = *ctx->h_stats;
+    if (hs.err != ~0ull) {
+        const long long i = (long long)(hs.err >> 8);
+        switch ((int)(hs.err & 0xff)) {
+            case LD_UNSORTED: return fail(ctx, C3R_EINVAL, "reads must be sorted by pos (read %lld)", i);
+            case LD_CIGAR_RANGE: return fail(ctx, C3R_EINVAL, "cigar range of read %lld out of bounds", i);
+            case LD_SEQ_RANGE: return fail(ctx, C3R_EINVAL, "seq range of read %lld out of bounds", i);
+            case LD_BAD_OP: return fail(ctx, C3R_EINVAL, "bad cigar op in read %lld", i);
+            case LD_OP_LONG: return fail(ctx, C3R_EINVAL, "cigar op too long in read %lld", i);
+            case LD_END_2G: return fail(ctx, C3R_EINVAL, "read %lld ends beyond 2^31", i);
+            case LD_SEG_OPS: return fail(ctx, C3R_EINVAL, "read %lld: more than 65535 CIGAR ops between two N ops", i);
+            default: return fail(ctx, C3R_EINVAL, "invalid read %lld", i);
+        }
+    }
+    if (hs.n_norm < 0 || hs.n_segs < 0 || hs.n_oprec < 0) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
+    const int ns = hs.n_segs;
+    // ---- pass 2 (nothing below waits for the device): normalised CIGARs, headers, segments, their order, the op table
+    if ((rc = ensure(ctx, ctx->d_cigar, (size_t)hs.n_norm * 4 + 16)) || (rc = ensure(ctx, ctx->d_reads, (size_t)n * sizeof(DevRead))) ||
+        (rc = ensure(ctx, ctx->d_rsegs, (size_t)ns * sizeof(DevSeg) + 16)) || (rc = ensure(ctx, ctx->d_segs, (size_t)ns * sizeof(DevSeg) + 16)) ||
+        (rc = ensure(ctx, ctx->d_rseg_first, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, ctx->d_skey, (size_t)ns * 4 + 16)) || (rc = ensure(ctx, ctx->d_skey2, (size_t)ns * 4 + 16)) ||
+        (rc = ensure(ctx, ctx->d_sval, (size_t)ns * 4 + 16)) || (rc = ensure(ctx, ctx->d_sval2, (size_t)ns * 4 + 16)) ||
+        (rc = ensure(ctx, ctx->d_seg_op_off, (size_t)(ns + 1) * 4 + 16)) || (rc = ensure(ctx, ctx->d_ops, (size_t)hs.n_oprec * sizeof(OpRec) + 64)))
+        return rc;
+    {
+        Launch L(ctx, "k_reads_prep");
+        hipLaunchKernelGGL(k_reads_write, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const c3r_read_t *)ctx->d_rawreads.p, n, (const uint32_t *)ctx->d_rawcig.p,
+                           (const int4 *)ctx->d_rcnt.p, (const int32_t *)ctx->d_rend.p, (uint32_t *)ctx->d_cigar.p, (DevRead *)ctx->d_reads.p, (DevSeg *)ctx->d_rsegs.p,
+                           (uint32_t *)ctx->d_rseg_first.p, (uint32_t *)ctx->d_skey.p, (uint32_t *)ctx->d_sval.p);
+    }
+    if (ns > 0) {
+        {   // segment order by ext_start; equal starts keep read order (a radix sort is stable)
+            Launch L(ctx, "k_sort");
+            size_t tmp = 0;
+            HIPCHK(ctx, rocprim::radix_sort_pairs(nullptr, tmp, (const uint32_t *)ctx->d_skey.p, (uint32_t *)ctx->d_skey2.p, (const uint32_t *)ctx->d_sval.p,
+                                                  (uint32_t *)ctx->d_sval2.p, (size_t)ns, 0, 32, ctx->stream));
+            if ((rc = ensure(ctx, ctx->d_sorttmp, tmp + 16))) return rc;
+            HIPCHK(ctx, rocprim::radix_sort_pairs(ctx->d_sorttmp.p, tmp, (const uint32_t *)ctx->d_skey.p, (uint32_t *)ctx->d_skey2.p, (const uint32_t *)ctx->d_sval.p,
+                                                  (uint32_t *)ctx->d_sval2.p, (size_t)ns, 0, 32, ctx->stream));
+        }
+        Launch L(ctx, "k_reads_prep");
+        hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, (const DevSeg *)ctx->d_rsegs.p, (const uint32_t *)ctx->d_sval2.p, ns,
+                           (DevSeg *)ctx->d_segs.p);
+    }
+    ctx->n_reads = n; ctx->n_segs = ns; ctx->n_indel_ops = hs.n_indel; ctx->max_cover = hs.max_cover;
+    if ((rc = filter_tables(ctx, hs.max_end))) { ctx->n_reads = 0; return rc; }
+    {   // expanded op table of the sorted segments: count -> exclusive scan -> write (its size is known from pass 1)
         int32_t *off = (int32_t *)ctx->d_seg_op_off.p, *d_total = (int32_t *)((char *)ctx->d_small.p + 28);
-        hipLaunchKernelGGL(k_ops_count, dim3((unsigned)(ns / 256 + 1)), dim3(256), 0, ctx->stream, (const DevSeg *)ctx->d_segs.p, ns,
-                           (const uint32_t *)ctx->d_cigar.p, off);
-        if ((rc = device_excl_scan(ctx, off, ns + 1, d_total))) return rc;
-        int32_t total = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (total < 0) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
-        if ((rc = ensure(ctx, ctx->d_ops, (size_t)total * sizeof(OpRec) + 64))) return rc;
-        if (ns > 0)
+        {
+            Launch L(ctx, "k_ops_table");
+            hipLaunchKernelGGL(k_ops_count, dim3((unsigned)(ns / 256 + 1)), dim3(256), 0, ctx->stream, (const DevSeg *)ctx->d_segs.p, ns,
+                               (const uint32_t *)ctx->d_cigar.p, off);
+        }
+        if ((rc = device_excl_scan(ctx, off, ns + 1, d_total))) { ctx->n_reads = 0; return rc; }
+        if (ns > 0) {
+            Launch L(ctx, "k_ops_table");
             hipLaunchKernelGGL(k_ops_write, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, (const DevSeg *)ctx->d_segs.p, ns,
                                (const uint32_t *)ctx->d_cigar.p, (const int32_t *)off, (OpRec *)ctx->d_ops.p);
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        HIPCHK(ctx, hipGetLastError());
+        }
     }
-    tick();
+    HIPCHK(ctx, hipGetLastError());
     if (timing) {
-        auto ms = [&](int a, int b) { return std::chrono::duration<double, std::milli>(tp[b] - tp[a]).count(); };
-        fprintf(stderr, "[c3r_load_reads] %lld reads, %zu segments: normalise %.1f ms, read-order segments %.1f ms, sort %.1f ms, seq copy %.1f ms, uploads %.1f ms, prefix max %.1f ms, op table %.1f ms\n",
-                (long long)n_reads, ctx->h_segs.size(), ms(0, 1), ms(1, 2), ms(2, 3), ms(3, 4), ms(4, 5), ms(5, 6), ms(6, 7));
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[c3r_load_reads] %d reads, %d segments, %d op records: uploads + pass 1 until the sync %.2f ms, pass 2 queued in %.2f ms\n", n, ns, hs.n_oprec,
+                ms(t_begin, t_sync), ms(t_sync, std::chrono::steady_clock::now()));
     }
     return C3R_OK;
 }
 
+void *c3r_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void c3r_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t len) {
     if (!ctx || !ref || len < 0 || ref_start < 1) return C3R_EINVAL;
+    ctx->last_scan_pruned = false;       // (c3r_get_columns completes a pruned scan with the arguments of that scan: stale now)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->h_ref.resize((size_t)len);
     {
@@ -575,6 +533,7 @@ int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t 
 
 int c3r_set_bed(c3r_ctx *ctx, int which, const int32_t *pairs, int64_t n) {
     if (!ctx || which < 0 || which > 1 || n < 0 || (n && !pairs)) return C3R_EINVAL;
+    ctx->last_scan_pruned = false;       // (c3r_get_columns completes a pruned scan with the arguments of that scan: stale now)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->has_bed[which] = n > 0;
     ctx->h_bed[which].assign(pairs, pairs + 2 * n);
@@ -587,6 +546,7 @@ int c3r_set_bed(c3r_ctx *ctx, int which, const int32_t *pairs, int64_t n) {
 
 int c3r_set_sites(c3r_ctx *ctx, const int32_t *sites, int64_t n) {
     if (!ctx || n < 0 || (n && !sites)) return C3R_EINVAL;
+    ctx->last_scan_pruned = false;       // (c3r_get_columns completes a pruned scan with the arguments of that scan: stale now)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->h_sites.assign(sites, sites + n);
     std::sort(ctx->h_sites.begin(), ctx->h_sites.end());
@@ -693,16 +653,16 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     // event per region whose rows it falls into, and regions may overlap arbitrarily (the same region twice, chunks shorter than
     // their +-33 bp halos): the capacity is the I/D ops of the reads inside each region's read range, summed over the regions
     // (an upper bound: the range also holds reads that end before the region), plus the rounding slack of every tile.
+    // An upper bound that needs no host copy of the reads: (I / D ops of the whole contig) x (the most regions any one position
+    // falls into), plus the rounding slack of every tile.
     size_t ev_cap = 16 * (size_t)n_tiles + 16;
-    for (int r = 0; r < n_regions && !ctx->h_reads.empty(); ++r) {
-        int64_t es = ctg_starts[r] - C3R_WINDOW, ee = ctg_ends[r] + C3R_WINDOW;
-        if (es < 1) es = 1;
-        const int32_t beg0 = (int32_t)(es - 1), end0 = (int32_t)ee;
-        // reads are sorted by pos: [first read that can reach beg0 (running max of the passing reads' ends), first read starting after end0)
-        // (one past the region on the right: an insertion / deletion right after the last row's base still belongs to that row)
-        const size_t lo = (size_t)(std::upper_bound(ctx->h_prefmax.begin(), ctx->h_prefmax.end(), beg0 - 1) - ctx->h_prefmax.begin());
-        const size_t hi = (size_t)(std::partition_point(ctx->h_reads.begin(), ctx->h_reads.end(), [&](const DevRead &d) { return d.pos <= end0; }) - ctx->h_reads.begin());
-        if (hi > lo) ev_cap += (size_t)(ctx->h_indel_prefix[hi] - ctx->h_indel_prefix[lo]);
+    {
+        std::vector<std::pair<int64_t, int>> edge;
+        for (int r = 0; r < n_regions; ++r) { edge.push_back({ctg_starts[r] - C3R_WINDOW - 2, +1}); edge.push_back({ctg_ends[r] + C3R_WINDOW + 2, -1}); }
+        std::sort(edge.begin(), edge.end(), [](const std::pair<int64_t, int> &x, const std::pair<int64_t, int> &y) { return x.first != y.first ? x.first < y.first : x.second > y.second; });
+        int cur = 0, maxov = 0;
+        for (auto &e : edge) { cur += e.second; maxov = std::max(maxov, cur); }
+        ev_cap += (size_t)maxov * (size_t)ctx->n_indel_ops;
     }
     if ((rc = ensure(ctx, ctx->d_ev, ev_cap * sizeof(EvRec)))) return rc;
     if ((rc = ensure(ctx, ctx->d_small, 64))) return rc;
@@ -728,8 +688,9 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     // engine's list — the kept reads with exclusive end > start - 1 — holds more than max_depth reads.  Sequential by
     // nature, so it runs here on the host, per region, and only when the data can reach the cap at all.
     const uint32_t *d_drop = nullptr;
-    const int drop_words = (int)((ctx->h_reads.size() + 31) / 32);
+    const int drop_words = (int)(((size_t)ctx->n_reads + 31) / 32);
     if (ctx->prm.max_depth > 0 && (int64_t)ctx->max_cover * 2 > ctx->prm.max_depth) {
+        if ((rc = ensure_host_reads(ctx))) return rc;
         ctx->h_drop.assign((size_t)n_regions * drop_words, 0u);
         bool any = false;
         for (int r = 0; r < n_regions; ++r) {
@@ -764,8 +725,8 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     ScanArgs a;
     a.drop = d_drop; a.drop_words = drop_words;
     a.reads = (const DevRead *)ctx->d_reads.p; a.cigar = (const uint32_t *)ctx->d_cigar.p; a.seq = (const uint8_t *)ctx->d_seq.p;
-    a.prefmax_end = (const int32_t *)ctx->d_prefmax.p; a.n_reads = (int32_t)ctx->h_reads.size();
-    a.segs = (const DevSeg *)ctx->d_segs.p; a.seg_prefmax = (const int32_t *)ctx->d_seg_prefmax.p; a.n_segs = (int32_t)ctx->h_segs.size();
+    a.prefmax_end = (const int32_t *)ctx->d_prefmax.p; a.n_reads = ctx->n_reads;
+    a.segs = (const DevSeg *)ctx->d_segs.p; a.seg_prefmax = (const int32_t *)ctx->d_seg_prefmax.p; a.n_segs = ctx->n_segs;
     a.ops = (const OpRec *)ctx->d_ops.p; a.seg_op_off = (const int32_t *)ctx->d_seg_op_off.p;
     a.bkt = ctx->n_bkt > 0 && !getenv("C3R_NO_BUCKETS") ? (const int32_t *)ctx->d_bkt.p : nullptr; a.n_bkt = ctx->n_bkt;
     a.tile_cols = (uint8_t *)ctx->d_tile_cols.p;
@@ -1186,6 +1147,7 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
     HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, b_probs, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const auto t2 = now();
+    { int rc_ = ensure_host_reads(ctx); if (!rc_) rc_ = ensure_host_seq(ctx); if (rc_) return rc_; }
     const uint8_t *seq = ctx->h_seq.data();
     const std::vector<DevRead> &reads = ctx->h_reads;
     auto get_read = [&](uint32_t r) { return ReadView{seq, reads[r].seq_off, reads[r].l_seq}; };

@@ -59,11 +59,20 @@ void c3r_default_params(c3r_params_t *p);
 int c3r_set_params(c3r_ctx *ctx, const c3r_params_t *p);
 
 /* ---- inputs -------------------------------------------------------------------------------- */
-/* Upload one contig's aligned reads, sorted by pos (BAM order).  Replaces the BAM side of
- * `samtools mpileup <bam> -r ...` (src/create_tensor_pileup.py:446-451).  Filtering by
- * excl_flags / min_mq happens on the device.  cigars: BAM-encoded ops; seq4: 4-bit packed bases. */
+/* Hand over one contig's aligned reads, sorted by pos (BAM order), as flat host-resident records.  Replaces the BAM side of
+ * `samtools mpileup <bam> -r ...` (src/create_tensor_pileup.py:446-451): the records are copied to the device as they are and
+ * everything htslib's per-read CIGAR cursor would do while streaming them — dropping pads / hard clips / empty ops, folding
+ * = and X, the split at N ops into aligned segments with their reference / query offsets, the segment order, the expanded op
+ * table — happens there (csrc/reads_kernels.hpp), with one host synchronisation to report sizes and validation errors.
+ * Filtering by excl_flags / min_mq happens on the device too.  cigars: BAM-encoded ops; seq4: 4-bit packed bases.
+ * This call is part of the measured path (bench.py times it inside every step). */
 int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads,
                    const uint32_t *cigars, int64_t n_cigar_ops, const uint8_t *seq4, int64_t n_seq_bytes);
+/* Page-locked host memory for the arrays handed to c3r_load_reads: from such buffers the three uploads are truly asynchronous
+ * DMA transfers (~55 GB/s); from ordinary pageable memory the HIP runtime stages them through its own buffer first.  Optional —
+ * any host pointer works.  The caller frees with c3r_host_free. */
+void *c3r_host_alloc(size_t bytes);
+void c3r_host_free(void *p);
 /* Upload the reference slice covering the region.  ref[0] is 1-based position `ref_start`;
  * replaces reference_sequence_from / `samtools faidx` (shared/utils.py:168-194,
  * src/create_tensor_pileup.py:424-428).  Upper-cased on upload like the reference does. */

@@ -1,0 +1,115 @@
+"""c3r_load_reads on the device (csrc/reads_kernels.hpp): validation errors, filter changes, pinned and pageable callers, and the
+host copies the rare paths fetch on demand.  The CIGAR semantics themselves are covered by the parity and fuzz suites, which all
+enter through this call."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from clair3_rna_amd import capi
+    e = capi.Engine(0)
+    yield e
+    e.close()
+
+
+def _lines(e, rs, ref, **prm):
+    from clair3_rna_amd import altinfo
+    e.params = __import__("clair3_rna_amd.capi", fromlist=["x"]).default_params()
+    e.set_params(**prm)
+    e.set_bed(0, None); e.set_bed(1, None)
+    e.load_reads(rs); e.set_reference(1, ref)
+    e.scan(1, len(ref))
+    return altinfo.format_lines("chr20", e.sites(), e.tensors(rescaled=False), e.tokens(), rs, ref, 1)
+
+
+def test_validation_errors_name_the_first_bad_read(eng):
+    from clair3_rna_amd import capi
+    from clair3_rna_amd.reads import ReadSet
+    recs = [dict(pos=100 + 10 * k, cigar="50M", seq="ACGT" * 12 + "AC") for k in range(700)]
+
+    def rs_with(i, **kw):
+        rs = ReadSet.from_records(recs)
+        for k, v in kw.items():
+            rs.reads[k][i] = v
+        return rs
+    eng.set_params()
+    with pytest.raises(capi.C3RError, match=r"sorted by pos \(read 301\)"):
+        eng.load_reads(rs_with(301, pos=5))
+    with pytest.raises(capi.C3RError, match=r"cigar range of read 655 out of bounds"):
+        eng.load_reads(rs_with(655, n_cigar=99))
+    with pytest.raises(capi.C3RError, match=r"seq range of read 12 out of bounds"):
+        eng.load_reads(rs_with(12, l_seq=10 ** 6))
+    bad = ReadSet.from_records(recs)
+    bad.cigar[40] = (50 << 4) | 11                               # op code 11 does not exist
+    bad.cigar[400] = (50 << 4) | 12
+    with pytest.raises(capi.C3RError, match=r"bad cigar op in read 40"):      # the smallest failing read is reported
+        eng.load_reads(bad)
+    far = ReadSet.from_records([dict(pos=2 ** 31 - 40, cigar="50M", seq="A" * 50)])
+    with pytest.raises(capi.C3RError, match="beyond 2\\^31"):
+        eng.load_reads(far)
+    long_ops = ReadSet.from_records([dict(pos=10, cigar="1M1I" * 33000 + "1M", seq="A" * 66001)])
+    with pytest.raises(capi.C3RError, match="65535"):
+        eng.load_reads(long_ops)
+    merged = ReadSet.from_records([dict(pos=10, cigar="200000000N" + "100000000N", seq="")])
+    with pytest.raises(capi.C3RError, match="too long"):
+        eng.load_reads(merged)
+    # a failed load leaves an empty, usable context
+    eng.set_reference(1, "ACGT" * 100)
+    assert eng.scan(1, 300) == 0
+    eng.load_reads(ReadSet.from_records(recs))
+    eng.set_reference(1, "ACGT" * 2000)
+    eng.scan(1, 7000)
+
+
+def test_pinned_and_pageable_records_give_the_same_tables(eng):
+    from clair3_rna_amd import capi, synth
+    ref, rs, _ = synth.small_case(seed=11, ref_len=60000, n_genes=10, depth=25)
+    a = _lines(eng, rs, ref)
+    b = _lines(eng, capi.pinned_readset(rs), ref)
+    assert a == b and len(a) > 50
+
+
+def test_new_filters_rebuild_the_tables_on_the_device(eng):
+    """c3r_set_params with another --minMQ / --excl-flags re-derives pass flags, prefix maxima and bucket index without a reload."""
+    from clair3_rna_amd import capi, synth
+    ref, rs, _ = synth.small_case(seed=12, ref_len=50000, n_genes=8, depth=30)
+    rs.reads["mapq"][::3] = 17
+    rs.reads["flag"][1::5] |= 1024
+    want = {}
+    for prm in (dict(min_mq=5), dict(min_mq=20), dict(min_mq=5, excl_flags=2316 | 1024)):
+        e2 = capi.Engine(0)
+        want[tuple(sorted(prm.items()))] = _lines(e2, rs, ref, **prm)
+        e2.close()
+    assert len(set(map(tuple, want.values()))) == 3
+    eng.params = capi.default_params()
+    eng.set_params(); eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.load_reads(rs); eng.set_reference(1, ref)
+    from clair3_rna_amd import altinfo
+    for prm in (dict(min_mq=20), dict(min_mq=5, excl_flags=2316 | 1024), dict(min_mq=5, excl_flags=2316)):
+        eng.set_params(**prm)
+        eng.scan(1, len(ref))
+        got = altinfo.format_lines("chr20", eng.sites(), eng.tensors(rescaled=False), eng.tokens(), rs, ref, 1)
+        key = dict(min_mq=prm["min_mq"])
+        if prm.get("excl_flags", 2316) != 2316:
+            key["excl_flags"] = prm["excl_flags"]
+        assert got == want[tuple(sorted(key.items()))], prm
+
+
+def test_empty_and_filtered_out_inputs(eng):
+    from clair3_rna_amd import capi
+    from clair3_rna_amd.reads import ReadSet
+    eng.params = capi.default_params()
+    eng.set_params()
+    eng.load_reads(ReadSet.from_records([]))
+    eng.set_reference(1, "ACGT" * 500)
+    assert eng.scan(1, 1500) == 0
+    # reads that hold no aligned base at all (soft clips, inserts, ref-skips only) and unmapped records with pos -1
+    rs = ReadSet.from_records([dict(pos=-1, cigar="", seq="ACGT", flag=4), dict(pos=50, cigar="20S", seq="A" * 20), dict(pos=60, cigar="5I", seq="AAAAA"),
+                               dict(pos=70, cigar="100N", seq=""), dict(pos=80, cigar="10S100N5I", seq="A" * 15)])
+    eng.load_reads(rs)
+    assert eng.scan(1, 1500) == 0
+    cols = eng.columns()
+    assert not cols["depth"].any()          # (the insertion after the ref-skip still lands on the intron's last column: channel i only)
