@@ -66,6 +66,11 @@ struct c3r_ctx {
     DevBuf d_segs, d_seg_prefmax, d_tile_cols, d_tile_rng, d_tile_list, d_tile_list2, d_rsegs, d_rseg_first;
     ScanArgs last_scan;                    // arguments of the most recent scan (c3r_get_columns completes the pruned tiles with them)
     bool last_scan_pruned = false;
+    // the fused path (k_fused_tiles): look-back words and counters, region bounds, what the last scan covered
+    DevBuf d_lb, d_regb;
+    int32_t *h_scan = nullptr;             // pinned: {candidates, tokens, overflow bits, event-scratch overflow} of a fused scan
+    bool last_fused = false;
+    std::vector<int64_t> last_starts, last_ends;
     std::string h_ref; int64_t ref_start1 = 1;
     DevBuf d_ref;
     std::vector<int32_t> h_bed[2];
@@ -346,13 +351,14 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_rcnt, &ctx->d_rend, &ctx->d_pass, &ctx->d_ekey, &ctx->d_ekey2, &ctx->d_skey, &ctx->d_skey2, &ctx->d_sval, &ctx->d_sval2,
-                      &ctx->d_sorttmp, &ctx->d_s4tops, &ctx->d_pmtops, &ctx->d_stats, &ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+                      &ctx->d_sorttmp, &ctx->d_s4tops, &ctx->d_pmtops, &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     net_free(ctx->net);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
+    if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -603,6 +609,91 @@ static int device_excl_scan(c3r_ctx *ctx, int32_t *d, int n, int32_t *d_total) {
     return C3R_OK;
 }
 
+// Capacity of the indel-event scratch of one scan: a tile workgroup reserves (its events rounded up to 16) records.  An I / D op
+// yields at most one event per region whose rows it falls into, and regions may overlap arbitrarily (the same region twice, chunks
+// shorter than their +-33 bp halos): (I / D ops of the whole contig) x (the most regions any one position falls into), plus the
+// rounding slack of every tile.  An upper bound that needs no host copy of the reads.
+static size_t event_capacity(const c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int n_tiles, int spans_per_position) {
+    size_t ev_cap = 16 * (size_t)n_tiles + 16;
+    std::vector<std::pair<int64_t, int>> edge;
+    for (int r = 0; r < n_regions; ++r) { edge.push_back({ctg_starts[r] - C3R_WINDOW - 2, +1}); edge.push_back({ctg_ends[r] + C3R_WINDOW + 2, -1}); }
+    std::sort(edge.begin(), edge.end(), [](const std::pair<int64_t, int> &x, const std::pair<int64_t, int> &y) { return x.first != y.first ? x.first < y.first : x.second > y.second; });
+    int cur = 0, maxov = 0;
+    for (auto &e : edge) { cur += e.second; maxov = std::max(maxov, cur); }
+    // (fused path: a position lies in its own span and in the flank of at most one neighbour)
+    return ev_cap + (size_t)maxov * (size_t)spans_per_position * (size_t)ctx->n_indel_ops;
+}
+
+// samtools mpileup -d (default 8000), restated from htslib's bam_plp_push / bam_plp_next (third-party, absent: parity
+// unpinned; the oracle restates the same rule independently): reads arrive in file order, filtered, and only those
+// overlapping the region; a read is discarded iff it is not the first read pushed for its start position and the
+// engine's list — the kept reads with exclusive end > start - 1 — holds more than max_depth reads.  Sequential by
+// nature, so it runs here on the host, per region, and only when the data can reach the cap at all (then the reads'
+// headers are fetched back from the device).  *d_drop: the per-region bit masks on the device, or null when no read is discarded.
+static int depth_cap_mask(c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, const uint32_t **d_drop, int *drop_words_out) {
+    *d_drop = nullptr;
+    const int drop_words = (int)(((size_t)ctx->n_reads + 31) / 32);
+    *drop_words_out = drop_words;
+    if (!(ctx->prm.max_depth > 0 && (int64_t)ctx->max_cover * 2 > ctx->prm.max_depth)) return C3R_OK;
+    int rc;
+    if ((rc = ensure_host_reads(ctx))) return rc;
+    ctx->h_drop.assign((size_t)n_regions * drop_words, 0u);
+    bool any = false;
+    for (int r = 0; r < n_regions; ++r) {
+        int64_t es = ctg_starts[r] - C3R_WINDOW, ee = ctg_ends[r] + C3R_WINDOW;
+        if (es < 1) es = 1;
+        const int32_t beg0 = (int32_t)(es - 1), end0 = (int32_t)ee;                // rows for [beg0, end0)
+        std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> live;
+        int32_t last_pos = INT_MIN;
+        size_t i = (size_t)(std::upper_bound(ctx->h_prefmax.begin(), ctx->h_prefmax.end(), beg0) - ctx->h_prefmax.begin());
+        for (; i < ctx->h_reads.size(); ++i) {
+            const DevRead &rd = ctx->h_reads[i];
+            if (rd.pos >= end0) break;
+            if (flag_fails(rd.flag, ctx->prm.excl_flags) || rd.mapq < ctx->prm.min_mq || rd.end <= rd.pos) continue;
+            if (rd.end <= beg0) continue;                                            // not fetched for this region
+            while (!live.empty() && live.top() <= rd.pos - 1) live.pop();
+            const bool first = rd.pos != last_pos;
+            last_pos = rd.pos;
+            if (!first && (int64_t)live.size() > ctx->prm.max_depth) {
+                ctx->h_drop[(size_t)r * drop_words + (i >> 5)] |= 1u << (i & 31);
+                any = true;
+                continue;
+            }
+            live.push(rd.end);
+        }
+    }
+    if (any) {
+        if ((rc = upload(ctx, ctx->d_drop, ctx->h_drop.data(), ctx->h_drop.size()))) return rc;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));        // (h_drop is rebuilt by the next scan)
+        *d_drop = (const uint32_t *)ctx->d_drop.p;
+    }
+    return C3R_OK;
+}
+
+// the inputs every tile kernel sees (the output side is filled in by the two scan paths)
+static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int drop_words, int n_tiles) {
+    memset(&a, 0, sizeof a);
+    a.drop = d_drop; a.drop_words = drop_words;
+    a.reads = (const DevRead *)ctx->d_reads.p; a.cigar = (const uint32_t *)ctx->d_cigar.p; a.seq = (const uint8_t *)ctx->d_seq.p;
+    a.prefmax_end = (const int32_t *)ctx->d_prefmax.p; a.n_reads = ctx->n_reads;
+    a.segs = (const DevSeg *)ctx->d_segs.p; a.seg_prefmax = (const int32_t *)ctx->d_seg_prefmax.p; a.n_segs = ctx->n_segs;
+    a.ops = (const OpRec *)ctx->d_ops.p; a.seg_op_off = (const int32_t *)ctx->d_seg_op_off.p;
+    a.bkt = ctx->n_bkt > 0 && !getenv("C3R_NO_BUCKETS") ? (const int32_t *)ctx->d_bkt.p : nullptr; a.n_bkt = ctx->n_bkt;
+    a.n_tiles = n_tiles;
+    a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->h_ref.size();
+    a.geo = (const TileGeo *)ctx->d_geo.p;
+    a.lbed = (const int32_t *)ctx->d_bed[0].p; a.n_lbed = (int32_t)(ctx->h_bed[0].size() / 2); a.has_lbed = ctx->has_bed[0];
+    a.cbed = (const int32_t *)ctx->d_bed[1].p; a.n_cbed = (int32_t)(ctx->h_bed[1].size() / 2); a.has_cbed = ctx->has_bed[1];
+    a.sites = (const int32_t *)ctx->d_sites.p; a.n_sites = (int32_t)ctx->h_sites.size(); a.genotyping = ctx->prm.genotyping_mode;
+    a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.min_cov = ctx->prm.min_coverage;
+    a.snp_af = ctx->prm.snp_min_af; a.indel_af = ctx->prm.indel_min_af;
+    a.head_tail = ctx->prm.head_tail; a.splice = ctx->prm.splice_padding;
+    { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
+}
+
+static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int64_t *n_candidates, bool columns_only);
+static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int64_t *n_candidates, bool raw_rerun);
+
 int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n_candidates) {
     return c3r_pileup_scan_regions(ctx, 1, &ctg_start, &ctg_end, n_candidates);
 }
@@ -610,16 +701,33 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
 int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int64_t *n_candidates) {
     if (!ctx || n_regions < 1 || !ctg_starts || !ctg_ends) return C3R_EINVAL;
     if (ctx->h_ref.empty()) return fail(ctx, C3R_EINVAL, "c3r_set_reference must be called before c3r_pileup_scan");
+    for (int r = 0; r < n_regions; ++r) {
+        if (ctg_ends[r] < ctg_starts[r]) return C3R_EINVAL;
+        if (ctg_ends[r] + C3R_WINDOW > INT32_MAX - 1) return fail(ctx, C3R_EINVAL, "region beyond 2^31");
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n_candidates) *n_candidates = 0;
+    ctx->last_starts.assign(ctg_starts, ctg_starts + n_regions); ctx->last_ends.assign(ctg_ends, ctg_ends + n_regions);
+    ctx->last_scan_pruned = false;
+    // The plain mode runs in one fused tile kernel (k_fused_tiles).  Head/tail calling (the end-of-stream rule needs the last row of the
+    // whole region), splice padding (in-place column edits, candidate after candidate) and genotyping mode (candidates in intron-only
+    // spans) keep the column store and its selection / compaction / gather kernels.
+    const bool fused = !ctx->prm.head_tail && !ctx->prm.splice_padding && !ctx->prm.genotyping_mode && !getenv("C3R_NO_FUSE");
+    ctx->last_fused = fused;
+    return fused ? scan_fused(ctx, n_regions, ctg_starts, ctg_ends, n_candidates, false)
+                 : scan_column_store(ctx, n_regions, ctg_starts, ctg_ends, n_candidates, false);
+}
+
+// ---- the column-store path: columns, depth and flags of every position go to HBM (k_scan_tiles), then window selection, ordered
+// compaction, gather and tokens as separate kernels, with two host read-backs for sizes.  columns_only: c3r_get_columns after a
+// fused scan — the columns and flags of the given region, nothing else is touched.
+static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int64_t *n_candidates, bool columns_only) {
     const int C = ctx->prm.channels;
     // per region, rows: 1-based [max(1, ctg_start-33), ctg_end+33]  (src/create_tensor_pileup.py:411-415); slots: the regions
     // back to back, each padded to whole tiles plus one guard tile (pileup_kernels.hpp, TileGeo)
     std::vector<int64_t> key;
-    for (int r = 0; r < n_regions; ++r) {
-        if (ctg_ends[r] < ctg_starts[r]) return C3R_EINVAL;
-        if (ctg_ends[r] + C3R_WINDOW > INT32_MAX - 1) return fail(ctx, C3R_EINVAL, "region beyond 2^31");
-        key.push_back(ctg_starts[r]); key.push_back(ctg_ends[r]);
-    }
+    key.push_back(-1);                                                 // (geometry of the column store)
+    for (int r = 0; r < n_regions; ++r) { key.push_back(ctg_starts[r]); key.push_back(ctg_ends[r]); }
     bool geo_changed = key != ctx->geo_key;
     if (geo_changed) {
         ctx->h_geo.clear();
@@ -637,8 +745,10 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     ctx->n_regions = n_regions;
     const int n_tiles = (int)ctx->h_geo.size();
     ctx->n_pos = (int64_t)n_tiles * TILE;
-    if (!ctx->batching) { ctx->n_cand = 0; ctx->n_tok = 0; }
-    ctx->last_cand = 0; ctx->last_base = ctx->n_cand; ctx->tokens_ready = false;
+    if (!columns_only) {
+        if (!ctx->batching) { ctx->n_cand = 0; ctx->n_tok = 0; }
+        ctx->last_cand = 0; ctx->last_base = ctx->n_cand; ctx->tokens_ready = false;
+    }
     const int64_t base_cand = ctx->n_cand, base_tok = ctx->n_tok;
     const int64_t n_pos = ctx->n_pos;
     const int n_cblocks = (int)((n_pos + CMP_BLOCK - 1) / CMP_BLOCK);
@@ -649,21 +759,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     if ((rc = ensure(ctx, ctx->d_depth, (size_t)n_pos * 4))) return rc;
     if ((rc = ensure(ctx, ctx->d_ncov, (size_t)n_pos * 4))) return rc;
     if ((rc = ensure(ctx, ctx->d_flags, (size_t)n_pos))) return rc;
-    // indel-event scratch: a tile workgroup reserves (its events rounded up to 16) records.  An I/D op yields at most one
-    // event per region whose rows it falls into, and regions may overlap arbitrarily (the same region twice, chunks shorter than
-    // their +-33 bp halos): the capacity is the I/D ops of the reads inside each region's read range, summed over the regions
-    // (an upper bound: the range also holds reads that end before the region), plus the rounding slack of every tile.
-    // An upper bound that needs no host copy of the reads: (I / D ops of the whole contig) x (the most regions any one position
-    // falls into), plus the rounding slack of every tile.
-    size_t ev_cap = 16 * (size_t)n_tiles + 16;
-    {
-        std::vector<std::pair<int64_t, int>> edge;
-        for (int r = 0; r < n_regions; ++r) { edge.push_back({ctg_starts[r] - C3R_WINDOW - 2, +1}); edge.push_back({ctg_ends[r] + C3R_WINDOW + 2, -1}); }
-        std::sort(edge.begin(), edge.end(), [](const std::pair<int64_t, int> &x, const std::pair<int64_t, int> &y) { return x.first != y.first ? x.first < y.first : x.second > y.second; });
-        int cur = 0, maxov = 0;
-        for (auto &e : edge) { cur += e.second; maxov = std::max(maxov, cur); }
-        ev_cap += (size_t)maxov * (size_t)ctx->n_indel_ops;
-    }
+    const size_t ev_cap = event_capacity(ctx, n_regions, ctg_starts, ctg_ends, n_tiles, 1);
     if ((rc = ensure(ctx, ctx->d_ev, ev_cap * sizeof(EvRec)))) return rc;
     if ((rc = ensure(ctx, ctx->d_small, 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_cols, (size_t)n_tiles + 16))) return rc;
@@ -682,80 +778,30 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cols.p, 0, (size_t)n_tiles, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_tile_cand.p, 0, (size_t)n_tiles * 8, ctx->stream));
 
-    // samtools mpileup -d (default 8000), restated from htslib's bam_plp_push / bam_plp_next (third-party, absent: parity
-    // unpinned; the oracle restates the same rule independently): reads arrive in file order, filtered, and only those
-    // overlapping the region; a read is discarded iff it is not the first read pushed for its start position and the
-    // engine's list — the kept reads with exclusive end > start - 1 — holds more than max_depth reads.  Sequential by
-    // nature, so it runs here on the host, per region, and only when the data can reach the cap at all.
     const uint32_t *d_drop = nullptr;
-    const int drop_words = (int)(((size_t)ctx->n_reads + 31) / 32);
-    if (ctx->prm.max_depth > 0 && (int64_t)ctx->max_cover * 2 > ctx->prm.max_depth) {
-        if ((rc = ensure_host_reads(ctx))) return rc;
-        ctx->h_drop.assign((size_t)n_regions * drop_words, 0u);
-        bool any = false;
-        for (int r = 0; r < n_regions; ++r) {
-            int64_t es = ctg_starts[r] - C3R_WINDOW, ee = ctg_ends[r] + C3R_WINDOW;
-            if (es < 1) es = 1;
-            const int32_t beg0 = (int32_t)(es - 1), end0 = (int32_t)ee;                // rows for [beg0, end0)
-            std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> live;
-            int32_t last_pos = INT_MIN;
-            size_t i = (size_t)(std::upper_bound(ctx->h_prefmax.begin(), ctx->h_prefmax.end(), beg0) - ctx->h_prefmax.begin());
-            for (; i < ctx->h_reads.size(); ++i) {
-                const DevRead &rd = ctx->h_reads[i];
-                if (rd.pos >= end0) break;
-                if (flag_fails(rd.flag, ctx->prm.excl_flags) || rd.mapq < ctx->prm.min_mq || rd.end <= rd.pos) continue;
-                if (rd.end <= beg0) continue;                                            // not fetched for this region
-                while (!live.empty() && live.top() <= rd.pos - 1) live.pop();
-                const bool first = rd.pos != last_pos;
-                last_pos = rd.pos;
-                if (!first && (int64_t)live.size() > ctx->prm.max_depth) {
-                    ctx->h_drop[(size_t)r * drop_words + (i >> 5)] |= 1u << (i & 31);
-                    any = true;
-                    continue;
-                }
-                live.push(rd.end);
-            }
-        }
-        if (any) {
-            if ((rc = upload(ctx, ctx->d_drop, ctx->h_drop.data(), ctx->h_drop.size()))) return rc;
-            d_drop = (const uint32_t *)ctx->d_drop.p;
-        }
-    }
+    int drop_words = 0;
+    if ((rc = depth_cap_mask(ctx, n_regions, ctg_starts, ctg_ends, &d_drop, &drop_words))) return rc;
 
     ScanArgs a;
-    a.drop = d_drop; a.drop_words = drop_words;
-    a.reads = (const DevRead *)ctx->d_reads.p; a.cigar = (const uint32_t *)ctx->d_cigar.p; a.seq = (const uint8_t *)ctx->d_seq.p;
-    a.prefmax_end = (const int32_t *)ctx->d_prefmax.p; a.n_reads = ctx->n_reads;
-    a.segs = (const DevSeg *)ctx->d_segs.p; a.seg_prefmax = (const int32_t *)ctx->d_seg_prefmax.p; a.n_segs = ctx->n_segs;
-    a.ops = (const OpRec *)ctx->d_ops.p; a.seg_op_off = (const int32_t *)ctx->d_seg_op_off.p;
-    a.bkt = ctx->n_bkt > 0 && !getenv("C3R_NO_BUCKETS") ? (const int32_t *)ctx->d_bkt.p : nullptr; a.n_bkt = ctx->n_bkt;
+    scan_inputs(ctx, a, d_drop, drop_words, n_tiles);
     a.tile_cols = (uint8_t *)ctx->d_tile_cols.p;
     a.tile_rng = (int4 *)ctx->d_tile_rng.p; a.tile_list = (int32_t *)ctx->d_tile_list.p;
-    a.n_tile_list = (int32_t *)((char *)ctx->d_small.p + 20); a.n_tiles = n_tiles;
+    a.n_tile_list = (int32_t *)((char *)ctx->d_small.p + 20);
     // rows of intron-only tiles far from every aligned segment only matter to the end-of-stream rule (head/tail), to splice
     // padding and to genotyping sites: in the plain mode they are left out of the scan
-    a.prune = (!ctx->prm.head_tail && !ctx->prm.splice_padding && !ctx->prm.genotyping_mode && !getenv("C3R_NO_PRUNE")) ? 1 : 0;
+    a.prune = (!columns_only && !ctx->prm.head_tail && !ctx->prm.splice_padding && !ctx->prm.genotyping_mode && !getenv("C3R_NO_PRUNE")) ? 1 : 0;
     a.tile_list2 = (int32_t *)ctx->d_tile_list2.p; a.n_tile_list2 = (int32_t *)((char *)ctx->d_small.p + 24);
-    a.head_tail = ctx->prm.head_tail;
-    { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
     a.dbg = nullptr;
     if (getenv("C3R_SCAN_DBG")) {
         if ((rc = ensure(ctx, ctx->d_dbg, 16 * 8))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg.p, 0, 16 * 8, ctx->stream));
         a.dbg = (unsigned long long *)ctx->d_dbg.p;
     }
-    a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->h_ref.size();
-    a.geo = (const TileGeo *)ctx->d_geo.p;
     a.cols = (int32_t *)ctx->d_cols.p; a.depth = (int32_t *)ctx->d_depth.p; a.ncov = (int32_t *)ctx->d_ncov.p; a.flags = (uint8_t *)ctx->d_flags.p;
-    a.lbed = (const int32_t *)ctx->d_bed[0].p; a.n_lbed = (int32_t)(ctx->h_bed[0].size() / 2); a.has_lbed = ctx->has_bed[0];
-    a.cbed = (const int32_t *)ctx->d_bed[1].p; a.n_cbed = (int32_t)(ctx->h_bed[1].size() / 2); a.has_cbed = ctx->has_bed[1];
-    a.sites = (const int32_t *)ctx->d_sites.p; a.n_sites = (int32_t)ctx->h_sites.size(); a.genotyping = ctx->prm.genotyping_mode;
-    a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.min_cov = ctx->prm.min_coverage;
-    a.snp_af = ctx->prm.snp_min_af; a.indel_af = ctx->prm.indel_min_af;
     a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)ctx->d_small.p; a.last_row = (int32_t *)ctx->d_lastrow.p;
     a.ev_cap = (unsigned long long)ev_cap; a.ev_overflow = (int32_t *)((char *)ctx->d_small.p + 8);
-    a.splice = ctx->prm.splice_padding; a.skipmax = (int32_t *)ctx->d_skipmax.p;
-    ctx->last_scan = a; ctx->last_scan_pruned = a.prune && a.n_reads > 0;
+    a.skipmax = (int32_t *)ctx->d_skipmax.p;
+    if (!columns_only) { ctx->last_scan = a; ctx->last_scan_pruned = a.prune && a.n_reads > 0; }
     if (a.n_reads > 0) {
         Launch L(ctx, "k_tile_ranges");
         hipLaunchKernelGGL(k_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, ctx->stream, a);
@@ -787,6 +833,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
                            (int)n_pos, (const TileGeo *)ctx->d_geo.p, ctx->prm.head_tail, (const int32_t *)ctx->d_lastrow.p, heavy,
                            (const int32_t *)ctx->d_tile_list.p, (const int32_t *)((char *)ctx->d_small.p + 20));
     }
+    if (columns_only) { HIPCHK(ctx, hipGetLastError()); return C3R_OK; }
     {
         Launch L(ctx, "k_compact_count");
         hipLaunchKernelGGL(k_compact_count, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
@@ -848,7 +895,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
         t.a = a;
         t.cand_idx = (const int32_t *)ctx->d_cand.p; t.tile_cand = (const int2 *)ctx->d_tile_cand.p;
         t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
-        t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;
+        t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok; t.tok_cap = INT32_MAX; t.cand_cap = INT32_MAX;     // (sized exactly above)
         Launch L(ctx, "k_tokens");
         hipLaunchKernelGGL(k_tile_tokens, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, t);
     }
@@ -856,6 +903,141 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     ctx->n_cand = base_cand + n_cand;
     ctx->n_tok = base_tok + n_tok;
     HIPCHK(ctx, hipGetLastError());
+    return C3R_OK;
+}
+
+// ---- the fused path (pileup_kernels.hpp, k_fused_tiles): memset of the look-back words, k_tile_ranges_fused, k_fused_tiles,
+// k_tile_tokens, and ONE read-back at the end (totals + overflow flags).  Output buffers are sized from what earlier passes needed;
+// kernels never write past them, and when the totals say something did not fit the buffers grow and the scan is repeated (the first
+// pass of a context; steady-state passes run once, without talking to the host in between).
+// raw_rerun: c3r_get_tensors(rescaled = 0) — the same scan again, un-rescaled windows only, into d_raw.
+static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int64_t *n_candidates, bool raw_rerun) {
+    const int C = ctx->prm.channels;
+    // per region, rows: 1-based [max(1, ctg_start-33), ctg_end+33]  (src/create_tensor_pileup.py:411-415), cut into spans of FUSE_IN
+    // positions; a span's slots are tile * TILE + (p - p0)
+    std::vector<int64_t> key;
+    key.push_back(-2);                                                 // (geometry of the fused path)
+    for (int r = 0; r < n_regions; ++r) { key.push_back(ctg_starts[r]); key.push_back(ctg_ends[r]); }
+    const bool geo_changed = key != ctx->geo_key;
+    int rc;
+    if (geo_changed) {
+        ctx->h_geo.clear();
+        std::vector<int2> regb((size_t)n_regions);
+        for (int r = 0; r < n_regions; ++r) {
+            int64_t es = ctg_starts[r] - C3R_WINDOW, ee = ctg_ends[r] + C3R_WINDOW;
+            if (es < 1) es = 1;
+            const int32_t beg0 = (int32_t)(es - 1), end0 = (int32_t)ee;
+            for (int32_t p0 = beg0; p0 < end0; p0 += FUSE_IN) ctx->h_geo.push_back(TileGeo{p0, std::min(p0 + FUSE_IN, end0), r, 0});
+            regb[(size_t)r] = make_int2(beg0, end0);
+            if (r == 0) { ctx->reg_beg0 = beg0; ctx->reg_end0 = end0; }
+        }
+        if ((int64_t)ctx->h_geo.size() * TILE > INT32_MAX - TILE) { ctx->geo_key.clear(); return fail(ctx, C3R_EINVAL, "regions too large for one scan (2^31 slots)"); }
+        ctx->geo_key = key;
+        if ((rc = upload(ctx, ctx->d_geo, ctx->h_geo.data(), ctx->h_geo.size())) || (rc = upload(ctx, ctx->d_regb, regb.data(), regb.size()))) { ctx->geo_key.clear(); return rc; }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));               // (regb is a temporary)
+    }
+    ctx->n_regions = n_regions;
+    const int n_tiles = (int)ctx->h_geo.size();
+    ctx->n_pos = (int64_t)n_tiles * TILE;
+    if (!raw_rerun) {
+        if (!ctx->batching) { ctx->n_cand = 0; ctx->n_tok = 0; }
+        ctx->last_cand = 0; ctx->last_base = ctx->n_cand; ctx->tokens_ready = false;
+    }
+    const int64_t base_cand = raw_rerun ? 0 : ctx->n_cand, base_tok = raw_rerun ? 0 : ctx->n_tok;
+    if (ctx->n_reads == 0 || n_tiles == 0) return C3R_OK;
+    const size_t ev_cap = event_capacity(ctx, n_regions, ctg_starts, ctg_ends, n_tiles, 2);
+    const int nblk = (n_tiles + 255) / 256;
+    // d_lb: [0] ticket of k_tile_ranges_fused, [4] ticket of k_fused_tiles, [8] candidates, [12] tokens, [16] overflow bits, [20] listed
+    // spans, [24..31] event-scratch cursor, [32] event-scratch overflow; [64..] one word per block of 256 spans, then one per span
+    const size_t lb_bytes = 64 + (size_t)nblk * 8 + (size_t)n_tiles * 8;
+    if ((rc = ensure(ctx, ctx->d_ev, ev_cap * sizeof(EvRec))) || (rc = ensure(ctx, ctx->d_lb, lb_bytes)) || (rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16)) ||
+        (rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16)) || (rc = ensure(ctx, ctx->d_tile_cand, (size_t)n_tiles * 8 + 16)))
+        return rc;
+    if (!ctx->h_scan) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_scan, 32, hipHostMallocDefault));
+    const uint32_t *d_drop = nullptr;
+    int drop_words = 0;
+    if ((rc = depth_cap_mask(ctx, n_regions, ctg_starts, ctg_ends, &d_drop, &drop_words))) return rc;
+    char *lb = (char *)ctx->d_lb.p;
+    FusedArgs f;
+    memset(&f, 0, sizeof f);
+    ScanArgs &a = f.a;
+    scan_inputs(ctx, a, d_drop, drop_words, n_tiles);
+    a.tile_rng = (int4 *)ctx->d_tile_rng.p; a.tile_list = (int32_t *)ctx->d_tile_list.p; a.n_tile_list = (int32_t *)(lb + 20);
+    a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)(lb + 24); a.ev_cap = (unsigned long long)ev_cap; a.ev_overflow = (int32_t *)(lb + 32);
+    f.reg_bounds = (const int2 *)ctx->d_regb.p;
+    f.state = (unsigned long long *)(lb + 64 + (size_t)nblk * 8);
+    f.ticket = (int32_t *)(lb + 4); f.totals = (int32_t *)(lb + 8); f.overflow = (int32_t *)(lb + 16);
+    f.rescale = raw_rerun ? 0 : 1; f.max_depth = ctx->prm.max_depth_rescale;
+    f.ph.reads = a.reads; f.ph.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.ph.rseg_first = (const uint32_t *)ctx->d_rseg_first.p; f.ph.cigar = a.cigar; f.ph.seq = a.seq;
+    f.ph.min_mq = a.min_mq; f.ph.excl_flags = a.excl_flags; f.ph.drop = a.drop; f.ph.drop_words = a.drop_words;
+    const size_t tbytes = (size_t)C3R_WINDOW * C * 4;
+    // what this scan may write: candidates / tokens the buffers can take beyond what the batch already holds
+    int64_t want_c, want_t;
+    if (raw_rerun) { want_c = ctx->last_cand; want_t = 0; }
+    else {
+        want_c = std::min<int64_t>({(int64_t)(ctx->d_tensors.cap / tbytes) - base_cand, (int64_t)(ctx->d_sites_out.cap / sizeof(c3r_site_t)) - base_cand,
+                                    (int64_t)(ctx->d_cand.cap / 4), (int64_t)(ctx->d_tokcnt.cap / 4)});
+        want_t = (int64_t)(ctx->d_tok.cap / sizeof(c3r_token_t)) - base_tok;
+        if (want_c < 1024) want_c = 65536;
+        if (want_t < 1024) want_t = 32 * want_c;
+    }
+    int32_t n_cand = 0, n_tok = 0;
+    for (int attempt = 0;; ++attempt) {
+        if (raw_rerun) {
+            if ((rc = ensure(ctx, ctx->d_raw, std::max<size_t>((size_t)want_c * tbytes, 16)))) return rc;
+            f.tensors = (int32_t *)ctx->d_raw.p;
+        } else {
+            if ((rc = ensure(ctx, ctx->d_cand, (size_t)want_c * 4)) || (rc = ensure(ctx, ctx->d_tokcnt, (size_t)want_c * 4)) ||
+                (rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_cand + want_c) * tbytes, (size_t)base_cand * tbytes)) ||
+                (rc = ensure_keep(ctx, ctx->d_sites_out, (size_t)(base_cand + want_c) * sizeof(c3r_site_t), (size_t)base_cand * sizeof(c3r_site_t))) ||
+                (rc = ensure_keep(ctx, ctx->d_tok, (size_t)(base_tok + want_t) * sizeof(c3r_token_t), (size_t)base_tok * sizeof(c3r_token_t))))
+                return rc;
+            f.tensors = (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_cand * tbytes);
+            f.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
+            f.cand_idx = (int32_t *)ctx->d_cand.p; f.tok_off = (int32_t *)ctx->d_tokcnt.p; f.tile_cand = (int2 *)ctx->d_tile_cand.p;
+        }
+        f.cand_cap = (int32_t)std::min<int64_t>(want_c, INT32_MAX);
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_lb.p, 0, lb_bytes, ctx->stream));
+        {
+            Launch L(ctx, "k_tile_ranges");
+            hipLaunchKernelGGL(k_tile_ranges_fused, dim3(nblk), dim3(256), 0, ctx->stream, a, (int32_t *)lb, (unsigned long long *)(lb + 64), nblk);
+        }
+        {
+            Launch L(ctx, "k_fused_tiles");
+            const int grid = std::min(n_tiles, 2048);
+            if (C == C3R_CH) hipLaunchKernelGGL(k_fused_tiles<C3R_CH>, dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, f);
+            else hipLaunchKernelGGL(k_fused_tiles<C3R_CH_PHASED>, dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, f);
+        }
+        if (!raw_rerun) {
+            TileTokArgs t;
+            t.a = a;
+            t.cand_idx = (const int32_t *)ctx->d_cand.p; t.tile_cand = (const int2 *)ctx->d_tile_cand.p;
+            t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
+            t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;
+            t.tok_cap = (int32_t)std::min<int64_t>(base_tok + want_t, INT32_MAX); t.cand_cap = f.cand_cap;
+            Launch L(ctx, "k_tokens");
+            hipLaunchKernelGGL(k_tile_tokens, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, t);
+        }
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan, lb + 8, 28, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipGetLastError());
+        n_cand = ctx->h_scan[0]; n_tok = ctx->h_scan[1];
+        if (ctx->h_scan[6]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
+        if (n_cand < 0 || n_tok < 0) return fail(ctx, C3R_EOVERFLOW, "too many candidates or tokens for one scan");
+        if (raw_rerun) {
+            if (n_cand != ctx->last_cand) return fail(ctx, C3R_EINVAL, "internal: the raw re-run found %d candidates, the scan %lld", n_cand, (long long)ctx->last_cand);
+            return C3R_OK;
+        }
+        if (n_cand <= want_c && n_tok <= want_t && !(ctx->h_scan[2] & 1)) break;
+        if (attempt >= 2) return fail(ctx, C3R_EOVERFLOW, "internal: output buffers still too small after growing (%d candidates, %d tokens)", n_cand, n_tok);
+        want_c = std::max<int64_t>(want_c, (int64_t)n_cand + n_cand / 4 + 1024);
+        want_t = std::max<int64_t>(want_t, (int64_t)n_tok + n_tok / 4 + 1024);
+    }
+    ctx->last_cand = n_cand;
+    if (n_candidates) *n_candidates = n_cand;
+    ctx->tokens_ready = true;
+    ctx->n_cand = base_cand + n_cand;
+    ctx->n_tok = base_tok + n_tok;
     return C3R_OK;
 }
 
@@ -889,7 +1071,10 @@ int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_si
         // raw (un-rescaled) windows are re-gathered from the columns of the most recent scan only
         if (ctx->last_base != 0 || ctx->last_cand != ctx->n_cand)
             return fail(ctx, C3R_EINVAL, "raw tensors are only available for a single (non-batched) scan");
-        if (!ctx->prm.splice_padding) {     // (splice padding: the scan already kept the raw windows, the columns have moved on)
+        if (ctx->last_fused) {               // the fused path keeps no columns: the scan runs again, un-rescaled windows only
+            int rc = scan_fused(ctx, (int32_t)ctx->last_starts.size(), ctx->last_starts.data(), ctx->last_ends.data(), nullptr, true);
+            if (rc) return rc;
+        } else if (!ctx->prm.splice_padding) {     // (splice padding: the scan already kept the raw windows, the columns have moved on)
             int rc = ensure(ctx, ctx->d_raw, bytes);
             if (rc) return rc;
             if ((rc = run_gather(ctx, 0, (int32_t *)ctx->d_raw.p, false))) return rc;
@@ -936,6 +1121,13 @@ int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t
     if (!cols && !depth && !flags) return C3R_OK;
     if (cap_pos < npos0) return fail(ctx, C3R_EOVERFLOW, "need room for %lld positions", (long long)npos0);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->last_fused) {
+        // the fused path never materialises columns: build those of the scan's first region now, through the column store
+        if (ctx->last_starts.empty()) return fail(ctx, C3R_EINVAL, "no scan yet");
+        int rc = scan_column_store(ctx, 1, ctx->last_starts.data(), ctx->last_ends.data(), nullptr, true);
+        ctx->geo_key.clear();                // (the device now holds the column store's geometry)
+        if (rc) return rc;
+    }
     if (ctx->last_scan_pruned) {
         // the scan skipped intron-only tiles that no candidate window can reach: compute their row flags now
         ScanArgs a = ctx->last_scan;

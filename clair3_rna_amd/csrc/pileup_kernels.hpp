@@ -241,6 +241,7 @@ __device__ __forceinline__ bool sorted_contains(const int32_t *a, int n, int v) 
 }
 
 enum WalkMode { ACCUM = 0, SCATTER = 1, FIRSTSEEN = 2 };
+constexpr int FS_CAP = 32;     // positions per batch of the first-seen (tie-break) pass
 
 struct TileLds {
     int32_t *cnt;      // [TILE][C]
@@ -248,8 +249,8 @@ struct TileLds {
     int32_t *evoff;    // [TILE]
     int32_t *evfill;   // [TILE]
     int32_t *maxdel;   // [TILE]
-    uint32_t *first;   // [TILE][6] first-seen token index per class A,C,G,T,I,D
-    uint8_t *amb;      // [TILE]
+    uint32_t *first;   // [FS_CAP][6] first-seen token index per class A,C,G,T,I,D of the positions with a tie at the top
+    uint8_t *amb;      // [TILE] 0, or 1 + the position's row in `first` (current batch of the tie-break pass)
     uint8_t *odd;      // [TILE] phased mode: the column's haplotype channels need the ordered recompute (k_phase_recompute)
 };
 
@@ -395,7 +396,8 @@ __device__ __forceinline__ void walk_op(const ScanArgs &a, const TileLds &s, con
                     else if (hp == 2) atomicAdd(&s.cnt[pl * C + C3R_AM + bi], 1);
                 }
             } else if (MODE == FIRSTSEEN) {
-                if (s.amb[pl]) atomicMin(&s.first[pl * 6 + bi], 2u * (uint32_t)r);
+                const int ai = s.amb[pl];
+                if (ai) atomicMin(&s.first[(ai - 1) * 6 + bi], 2u * (uint32_t)r);
             }
         }
         return;
@@ -447,7 +449,8 @@ __device__ __forceinline__ void walk_op(const ScanArgs &a, const TileLds &s, con
         const int slot = s.evoff[pl] + atomicAdd(&s.evfill[pl], 1);
         ev[slot] = e;
     } else {  // FIRSTSEEN
-        if (s.amb[pl]) atomicMin(&s.first[pl * 6 + (is_ins ? 4 : 5)], 2u * (uint32_t)r + 1u);
+        const int ai = s.amb[pl];
+        if (ai) atomicMin(&s.first[(ai - 1) * 6 + (is_ins ? 4 : 5)], 2u * (uint32_t)r + 1u);
     }
 }
 
@@ -602,32 +605,267 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const ScanArgs a) {     // 
     if (pruned) a.tile_list2[b1 + __popcll(m1 & ((1ull << lane) - 1ull))] = t;
 }
 
+// look-back words are read and written at device scope (every XCD has its own L2)
+__device__ __forceinline__ unsigned long long lb_load(unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lb_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The fused path's list of spans (k_fused_tiles): only spans that hold aligned bases, in ASCENDING order (= output order), with the
+// read / segment ranges of the span plus C3R_FLANK on either side.  Workgroups take blocks of 256 spans by ticket and place their
+// listed spans behind those of the blocks before them (decoupled look-back over one word per block, as in k_fused_tiles).
+__global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int32_t *ticket, unsigned long long *rstate, int nblk) {
+    __shared__ int s_b, s_base, s_cnt[4];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_b = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int b = s_b;
+    const int t = b * 256 + tid;
+    bool listed = false;
+    if (t < a.n_tiles) {
+        const TileGeo tg = a.geo[t];
+        const int t0 = tg.p0, t1 = tg.p1;
+        if (t1 > t0) {
+            const int32_t *T0 = a.bkt, *T1 = a.bkt ? a.bkt + a.n_bkt : nullptr, *T2 = a.bkt ? a.bkt + 2 * a.n_bkt : nullptr, *T3 = a.bkt ? a.bkt + 3 * a.n_bkt : nullptr;
+            auto ub_gt = [](const int32_t *arr, int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (arr[mid] > v) hi = mid; else lo = mid + 1; } return lo; };
+            auto lb_pos = [&](int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.reads[mid].pos >= v) hi = mid; else lo = mid + 1; } return lo; };
+            auto lb_seg = [&](int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.segs[mid].ext_start >= v) hi = mid; else lo = mid + 1; } return lo; };
+            int lo, hi;
+            // a candidate needs aligned bases on its own position: spans whose own range meets no segment are not listed
+            bucket_bounds(T3, a.n_bkt, a.n_segs, t0, lo, hi); const int z = ub_gt(a.seg_prefmax, lo, hi, t0);
+            bucket_bounds(T2, a.n_bkt, a.n_segs, t1, lo, hi); const int w = lb_seg(lo, hi, t1);
+            if (z < w) {
+                const int e0 = t0 - C3R_FLANK, e1 = t1 + C3R_FLANK;
+                int4 r;
+                bucket_bounds(T1, a.n_bkt, a.n_reads, e0, lo, hi); r.x = ub_gt(a.prefmax_end, lo, hi, e0);
+                bucket_bounds(T0, a.n_bkt, a.n_reads, e1, lo, hi); r.y = lb_pos(lo, hi, e1);
+                bucket_bounds(T3, a.n_bkt, a.n_segs, e0, lo, hi); r.z = ub_gt(a.seg_prefmax, lo, hi, e0);
+                bucket_bounds(T2, a.n_bkt, a.n_segs, e1, lo, hi); r.w = lb_seg(lo, hi, e1);
+                a.tile_rng[t] = r;
+                listed = r.x < r.y;
+            }
+        }
+    }
+    const unsigned long long m = __ballot(listed);
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long mine = (unsigned long long)(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+        unsigned long long excl = 0;
+        if (b > 0) {
+            lb_store(&rstate[b], (1ull << 62) | mine);
+            for (int i = b - 1; i >= 0; --i) {
+                unsigned long long w;
+                while (((w = lb_load(&rstate[i])) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+                excl += w & 0x3fffffffffffffffull;
+                if ((w >> 62) == 2) break;
+            }
+        }
+        lb_store(&rstate[b], (2ull << 62) | (excl + mine));
+        s_base = (int)excl;
+        if (b == nblk - 1) *a.n_tile_list = (int32_t)(excl + mine);
+    }
+    __syncthreads();
+    int at = s_base;
+    for (int w = 0; w < wave; ++w) at += s_cnt[w];
+    if (listed) a.tile_list[at + __popcll(m & ((1ull << lane) - 1ull))] = t;
+}
+
 // The tile kernels run over the compact tile list with a FIXED grid (LIST_GRID workgroups, each taking every LIST_GRID-th list
 // entry): the list's length lives on the device, and a grid of one workgroup per tile of the scan — 250 k for chr20, of which
 // 40 k are listed — spent ~0.09 ms per kernel dispatching workgroups that left at once.
 constexpr int LIST_GRID = 8192;
 
+// LDS of one tile workgroup.  Indel events of a tile stay in LDS when there are at most EV_LDS of them (a 20x ONT tile holds ~100);
+// deeper tiles bump-allocate global scratch.  (30 channels: the accumulators leave no room at four workgroups per CU.)
 template <int C>
-__device__ __forceinline__ void scan_tile(const ScanArgs &a, const int tile) {
-    __shared__ int32_t s_cnt[TILE * C];
-    __shared__ int32_t s_cov[TILE + 1];
-    __shared__ int32_t s_evoff[TILE];
-    __shared__ int32_t s_evfill[TILE];
-    __shared__ int32_t s_maxdel[TILE];
-    __shared__ uint8_t s_amb[TILE];
-    __shared__ uint8_t s_odd[TILE];
-    __shared__ int s_misc[8];
-    __shared__ unsigned long long s_evbase;
-    __shared__ SegList L;
-    // indel events of a tile stay in LDS when there are at most EV_LDS of them (a 20x ONT tile holds ~100); deeper tiles bump-allocate
-    // global scratch.  (30 channels: the accumulators leave no room at four workgroups per CU.)
-    constexpr int EV_LDS = C == C3R_CH ? 192 : 0;
-    __shared__ EvRec s_ev[EV_LDS > 0 ? EV_LDS : 1];
-    // first-seen words [TILE][6] (24 bytes per position) are only needed by the rare tie-break pass, which runs after the columns
-    // have been stored: they take the place of the accumulators
-    static_assert(C * 4 >= 24, "first-seen words alias the accumulators");
-    uint32_t *s_first = reinterpret_cast<uint32_t *>(s_cnt);
+struct TileMem {
+    static constexpr int EV_LDS = C == C3R_CH ? 192 : 0;
+    int32_t cnt[TILE * C];
+    int32_t cov[TILE + 1];
+    int32_t evoff[TILE];
+    int32_t evfill[TILE];
+    int32_t maxdel[TILE];
+    uint32_t first[FS_CAP * 6];
+    uint8_t amb[TILE];
+    uint8_t odd[TILE];
+    int misc[8];
+    unsigned long long evbase;
+    SegList L;
+    EvRec ev[EV_LDS > 0 ? EV_LDS : 1];
+};
+struct TileOut { bool is_row, cand; int depth, cov; };
 
+// The columns of the positions [t0, t1) (at most TILE of them, thread tid <-> position t0 + tid) from the reads [lo, hi) and the aligned
+// segments [slo, shi): accumulators in LDS, indel alleles, the per-position gates (src/create_tensor_pileup.py:259-299, :536-556),
+// the reference-channel overwrite.  On return M.cnt holds the finished columns, M.odd the phased columns that need the ordered
+// recompute, and the thread its position's verdict.  Positions below pmin hold no rows (they lie before the region).
+// Used by the column-store kernel (k_scan_tiles) and by the fused kernel (k_fused_tiles), whose "tile" is a window-complete span.
+template <int C>
+__device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M, int t0, int t1, int pmin, int region, int lo, int hi, int slo, int shi,
+                                                int cand_lo, int cand_hi) {
+    constexpr int EV_LDS = TileMem<C>::EV_LDS;
+    const int tid = threadIdx.x;
+    TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd};
+    SegList &L = M.L;
+    bool listed = false;
+    int n_ops = 0;
+    unsigned long long tprev = a.dbg ? wall_clock64() : 0ull;
+#define C3R_PHASE(K) do { if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[K], now_ - tprev); tprev = now_; } } while (0)
+    M.cov[tid] = 0; if (tid == 0) M.cov[TILE] = 0;
+    for (int i = tid; i < TILE * C; i += SCAN_THREADS) M.cnt[i] = 0;
+    M.evfill[tid] = 0; M.maxdel[tid] = 0; M.amb[tid] = 0; M.odd[tid] = 0;
+    __syncthreads();
+
+    C3R_PHASE(0);
+    if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1, region);
+    if (!(a.abl & 1)) walk_tile<C, ACCUM>(a, s, L, slo, shi, t0, t1, region, nullptr, listed, n_ops);
+    __syncthreads();
+    C3R_PHASE(1);
+
+    // coverage: inclusive scan of the difference array; indel events: exclusive scan of per-position counts
+    int *wave_tot = &M.misc[2];
+    int tot;
+    const int my_cov_d = M.cov[tid];
+    const int cov_ex = block_excl_scan(my_cov_d, wave_tot, &tot);
+    const int my_cov = cov_ex + my_cov_d;
+    const int32_t *row = &M.cnt[tid * C];
+    const int nev = row[C3R_I] + row[C3R_i] + row[C3R_D] + row[C3R_d];
+    int ev_total;
+    const int ev_ex = block_excl_scan(nev, wave_tot, &ev_total);
+    M.evoff[tid] = ev_ex;
+    C3R_PHASE(2);
+    if (ev_total > 0 && !(a.abl & 2)) {
+        // the tile's indel events, bucketed by position (counting sort through evoff / evfill), then the max multiplicity of one
+        // allele per (position, channel): I1 / i1 / D1 / d1
+        auto events = [&](EvRec *ev) __attribute__((always_inline)) {
+            walk_tile<C, SCATTER>(a, s, L, slo, shi, t0, t1, region, ev, listed, n_ops);
+            __threadfence_block();
+            __syncthreads();
+            for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+                const EvRec me = ev[e];
+                const int pl = me.pl;
+                const int b = M.evoff[pl];
+                const int32_t *rw = &M.cnt[pl * C];
+                const int n = rw[C3R_I] + rw[C3R_i] + rw[C3R_D] + rw[C3R_d];
+                int eq = 0;
+                for (int j = 0; j < n; ++j) eq += ev_equal(a, me, ev[b + j]) ? 1 : 0;
+                atomicMax(&M.cnt[pl * C + me.ch], eq);
+            }
+        };
+        if (ev_total <= EV_LDS) {
+            events(M.ev);                  // the usual case: the events never leave LDS
+        } else {
+            if (tid == 0) M.evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
+            __syncthreads();
+            const unsigned long long evb = M.evbase;
+            if (evb + (unsigned long long)((ev_total + 15) & ~15) > a.ev_cap) {
+                // cannot happen with the host's sizing (c3r_pileup_scan_regions); if it ever does, no write leaves the buffer and the
+                // scan call fails instead of corrupting device memory
+                if (tid == 0) *a.ev_overflow = 1;
+            } else {
+                events(a.ev + evb);
+            }
+        }
+        __syncthreads();
+    }
+
+    C3R_PHASE(3);
+    // ---- per-position gates (src/create_tensor_pileup.py:259-299, :536-556)
+    const int p = t0 + tid;
+    bool is_row = false, cand = false, ambiguous = false;
+    int depth = 0, refi = 0;
+    int cls[6] = {0, 0, 0, 0, 0, 0};
+    bool gates_ok = false;
+    if (p >= pmin && p < t1 && my_cov > 0) {
+        is_row = !a.has_lbed || intervals_overlap(a.lbed, a.n_lbed, p, p + 1);
+    }
+    if (is_row) {
+        int32_t *c = &M.cnt[tid * C];
+        const int up = c[C3R_A] + c[C3R_C] + c[C3R_G] + c[C3R_T];
+        const int lw = c[C3R_a] + c[C3R_c] + c[C3R_g] + c[C3R_t];
+        depth = up + lw + c[C3R_STAR] + c[C3R_HASH];
+        const int rp = p - a.ref_beg0;
+        const uint8_t rb = (rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
+        const bool ref_acgt = (rb == 'A' || rb == 'C' || rb == 'G' || rb == 'T');
+        refi = ref_index(rb);
+        cls[0] = c[C3R_A] + c[C3R_a]; cls[1] = c[C3R_C] + c[C3R_c]; cls[2] = c[C3R_G] + c[C3R_g]; cls[3] = c[C3R_T] + c[C3R_t];
+        cls[4] = c[C3R_I] + c[C3R_i]; cls[5] = c[C3R_D] + c[C3R_d];
+        const bool may_be_cand = p >= cand_lo && p < cand_hi;       // (the fused kernel decides candidates for its inner span only)
+        const double denom = depth > 0 ? (double)depth : 1.0;
+        bool pass = false;
+        for (int x = 0; x < 4; ++x)
+            if (x != refi && cls[x] > 0 && (double)cls[x] / denom >= a.snp_af) pass = true;
+        if (cls[4] > 0 && (double)cls[4] / denom >= a.indel_af) pass = true;
+        if (cls[5] > 0 && (double)cls[5] / denom >= a.indel_af) pass = true;
+        if (depth > 0 && (a.snp_af == 0.0 || a.indel_af == 0.0)) pass = true;
+        if (!pass) {
+            // pileup_list[0][0] != reference_base: top class by count, ties broken by first occurrence
+            int m = 0;
+            for (int x = 0; x < 6; ++x) m = max(m, cls[x]);
+            if (m > 0) {
+                if (cls[refi] < m) pass = true;
+                else {
+                    for (int x = 0; x < 6; ++x) if (x != refi && cls[x] == m) ambiguous = true;
+                }
+            }
+        }
+        bool site_ok;
+        if (a.genotyping) site_ok = sorted_contains(a.sites, a.n_sites, p + 1);
+        else {
+            gates_ok = may_be_cand && ref_acgt && depth >= a.min_cov &&
+                       (!a.has_cbed || intervals_overlap(a.cbed, a.n_cbed, p, p + M.maxdel[tid] + 2));
+            site_ok = gates_ok && pass;
+            if (!gates_ok) ambiguous = false;
+        }
+        if (a.genotyping) ambiguous = false;
+        cand = site_ok && may_be_cand;
+        // reference-base channels are overwritten with minus the strand totals (:296-297).  BASE2INDEX is keyed by channel
+        // NAME, so an IUPAC 'D' (or an 'I') in the reference lands on the D / d (I / i) channels; other letters count as 'A'
+        // (the reference raises KeyError there)
+        const int ch_up = rb == 'D' ? (int)C3R_D : rb == 'I' ? (int)C3R_I : refi;
+        const int ch_lo = rb == 'D' ? (int)C3R_d : rb == 'I' ? (int)C3R_i : 9 + refi;
+        c[ch_up] = -up;
+        c[ch_lo] = -lw;
+    }
+    const bool any_amb = __syncthreads_or(ambiguous ? 1 : 0) != 0;
+    C3R_PHASE(4);
+
+    if (any_amb) {
+        // "top allele != reference" with a tie at the top: the reference's stable sort keeps the class seen first in the column.  A
+        // third walk records, for the tied positions only (FS_CAP at a time), the first read that shows each class
+        int n_amb;
+        const int arank = block_excl_scan(ambiguous ? 1 : 0, wave_tot, &n_amb);
+        for (int base = 0; base < n_amb; base += FS_CAP) {
+            const bool mine = ambiguous && arank >= base && arank < base + FS_CAP;
+            M.amb[tid] = mine ? (uint8_t)(1 + arank - base) : (uint8_t)0;
+            for (int i = tid; i < FS_CAP * 6; i += SCAN_THREADS) M.first[i] = 0xffffffffu;
+            __syncthreads();
+            walk_tile<C, FIRSTSEEN>(a, s, L, slo, shi, t0, t1, region, nullptr, listed, n_ops);
+            __syncthreads();
+            if (mine) {
+                int m = 0;
+                for (int x = 0; x < 6; ++x) m = max(m, cls[x]);
+                const uint32_t *fs = &M.first[(arank - base) * 6];
+                const uint32_t fr = fs[refi];
+                bool top_ne_ref = false;
+                for (int x = 0; x < 6; ++x)
+                    if (x != refi && cls[x] == m && fs[x] < fr) top_ne_ref = true;
+                cand = gates_ok && top_ne_ref;
+            }
+            __syncthreads();
+        }
+    }
+    C3R_PHASE(6);
+    if (a.dbg && tid == 0) { atomicAdd(&a.dbg[14], (unsigned long long)n_ops); atomicAdd(&a.dbg[15], 1ull); atomicAdd(&a.dbg[13], (unsigned long long)(shi - slo)); atomicAdd(&a.dbg[12], (unsigned long long)L.n); }
+#undef C3R_PHASE
+    TileOut o;
+    o.is_row = is_row; o.cand = cand; o.depth = depth; o.cov = my_cov;
+    return o;
+}
+
+// One tile of the column store (the path of head/tail calling, splice padding, genotyping mode and c3r_get_columns): the tile's
+// columns, depth, covering reads and flags go to HBM; selection, compaction and the window gather are separate kernels.
+template <int C>
+__device__ __forceinline__ void scan_tile(const ScanArgs &a, const int tile, TileMem<C> &M) {
     const int tid = threadIdx.x;
     const TileGeo tg = a.geo[tile];
     const int t0 = tg.p0, t1 = tg.p1;
@@ -637,20 +875,17 @@ __device__ __forceinline__ void scan_tile(const ScanArgs &a, const int tile) {
     if ((a.abl & 32) && rng.z < rng.w) return;    // ablation: skip tiles with aligned bases
     const int lo = rng.x, hi = rng.y;       // reads whose span can overlap [t0,t1)
     const int slo = rng.z, shi = rng.w;     // aligned segments that can touch it
-
-    TileLds s{s_cnt, s_cov, s_evoff, s_evfill, s_maxdel, s_first, s_amb, s_odd};
-    bool listed = false;
-    int n_ops = 0;
-    s_cov[tid] = 0; if (tid == 0) s_cov[TILE] = 0;
     if (slo >= shi) {
         // intron-only tile: rows exist (ref-skip columns) but every count is zero.  Only the flags are written; the
         // gather treats the columns of such a tile as zeros (tile_cols stays 0).
+        TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd};
+        M.cov[tid] = 0; if (tid == 0) M.cov[TILE] = 0;
         __syncthreads();
         cover_reads(a, s, lo, hi, t0, t1, tg.region);
         __syncthreads();
         int tot;
-        const int d = s_cov[tid];
-        const int cov = block_excl_scan(d, &s_misc[2], &tot) + d;
+        const int d = M.cov[tid];
+        const int cov = block_excl_scan(d, &M.misc[2], &tot) + d;
         const int p = t0 + tid;
         bool is_row = false;
         if (p < t1 && cov > 0) is_row = !a.has_lbed || intervals_overlap(a.lbed, a.n_lbed, p, p + 1);
@@ -679,164 +914,22 @@ __device__ __forceinline__ void scan_tile(const ScanArgs &a, const int tile) {
         }
         return;
     }
-    unsigned long long tprev = a.dbg ? wall_clock64() : 0ull;
-#define C3R_PHASE(K) do { if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[K], now_ - tprev); tprev = now_; } } while (0)
-    for (int i = tid; i < TILE * C; i += SCAN_THREADS) s_cnt[i] = 0;
-    s_evfill[tid] = 0; s_maxdel[tid] = 0; s_amb[tid] = 0; s_odd[tid] = 0;
-    __syncthreads();
-
-    C3R_PHASE(0);
-    if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1, tg.region);
-    if (!(a.abl & 1)) walk_tile<C, ACCUM>(a, s, L, slo, shi, t0, t1, tg.region, nullptr, listed, n_ops);
-    __syncthreads();
-    C3R_PHASE(1);
-
-    // coverage: inclusive scan of the difference array; indel events: exclusive scan of per-position counts
-    int *wave_tot = &s_misc[2];
-    int tot;
-    const int my_cov_d = s_cov[tid];
-    const int cov_ex = block_excl_scan(my_cov_d, wave_tot, &tot);
-    const int my_cov = cov_ex + my_cov_d;
-    const int32_t *row = &s_cnt[tid * C];
-    const int nev = row[C3R_I] + row[C3R_i] + row[C3R_D] + row[C3R_d];
-    int ev_total;
-    const int ev_ex = block_excl_scan(nev, wave_tot, &ev_total);
-    s_evoff[tid] = ev_ex;
-    C3R_PHASE(2);
-    if (ev_total > 0 && !(a.abl & 2)) {
-        // the tile's indel events, bucketed by position (counting sort through evoff / evfill), then the max multiplicity of one
-        // allele per (position, channel): I1 / i1 / D1 / d1
-        auto events = [&](EvRec *ev) __attribute__((always_inline)) {
-            walk_tile<C, SCATTER>(a, s, L, slo, shi, t0, t1, tg.region, ev, listed, n_ops);
-            __threadfence_block();
-            __syncthreads();
-            for (int e = tid; e < ev_total; e += SCAN_THREADS) {
-                const EvRec me = ev[e];
-                const int pl = me.pl;
-                const int b = s_evoff[pl];
-                const int32_t *rw = &s_cnt[pl * C];
-                const int n = rw[C3R_I] + rw[C3R_i] + rw[C3R_D] + rw[C3R_d];
-                int eq = 0;
-                for (int j = 0; j < n; ++j) eq += ev_equal(a, me, ev[b + j]) ? 1 : 0;
-                atomicMax(&s_cnt[pl * C + me.ch], eq);
-            }
-        };
-        if (ev_total <= EV_LDS) {
-            events(s_ev);                  // the usual case: the events never leave LDS
-        } else {
-            if (tid == 0) s_evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
-            __syncthreads();
-            const unsigned long long evb = s_evbase;
-            if (evb + (unsigned long long)((ev_total + 15) & ~15) > a.ev_cap) {
-                // cannot happen with the host's sizing (c3r_pileup_scan_regions); if it ever does, no write leaves the buffer and the
-                // scan call fails instead of corrupting device memory
-                if (tid == 0) *a.ev_overflow = 1;
-            } else {
-                events(a.ev + evb);
-            }
-        }
-        __syncthreads();
-    }
-
-    C3R_PHASE(3);
-    // ---- per-position gates (src/create_tensor_pileup.py:259-299, :536-556)
-    const int p = t0 + tid;
-    bool is_row = false, cand = false, ambiguous = false;
-    int depth = 0, refi = 0;
-    int cls[6] = {0, 0, 0, 0, 0, 0};
-    bool gates_ok = false;
-    if (p < t1 && my_cov > 0) {
-        is_row = !a.has_lbed || intervals_overlap(a.lbed, a.n_lbed, p, p + 1);
-    }
-    if (is_row) {
-        int32_t *c = &s_cnt[tid * C];
-        const int up = c[C3R_A] + c[C3R_C] + c[C3R_G] + c[C3R_T];
-        const int lw = c[C3R_a] + c[C3R_c] + c[C3R_g] + c[C3R_t];
-        depth = up + lw + c[C3R_STAR] + c[C3R_HASH];
-        const int rp = p - a.ref_beg0;
-        const uint8_t rb = (rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
-        const bool ref_acgt = (rb == 'A' || rb == 'C' || rb == 'G' || rb == 'T');
-        refi = ref_index(rb);
-        cls[0] = c[C3R_A] + c[C3R_a]; cls[1] = c[C3R_C] + c[C3R_c]; cls[2] = c[C3R_G] + c[C3R_g]; cls[3] = c[C3R_T] + c[C3R_t];
-        cls[4] = c[C3R_I] + c[C3R_i]; cls[5] = c[C3R_D] + c[C3R_d];
-        const double denom = depth > 0 ? (double)depth : 1.0;
-        bool pass = false;
-        for (int x = 0; x < 4; ++x)
-            if (x != refi && cls[x] > 0 && (double)cls[x] / denom >= a.snp_af) pass = true;
-        if (cls[4] > 0 && (double)cls[4] / denom >= a.indel_af) pass = true;
-        if (cls[5] > 0 && (double)cls[5] / denom >= a.indel_af) pass = true;
-        if (depth > 0 && (a.snp_af == 0.0 || a.indel_af == 0.0)) pass = true;
-        if (!pass) {
-            // pileup_list[0][0] != reference_base: top class by count, ties broken by first occurrence
-            int m = 0;
-            for (int x = 0; x < 6; ++x) m = max(m, cls[x]);
-            if (m > 0) {
-                if (cls[refi] < m) pass = true;
-                else {
-                    for (int x = 0; x < 6; ++x) if (x != refi && cls[x] == m) ambiguous = true;
-                }
-            }
-        }
-        bool site_ok;
-        if (a.genotyping) site_ok = sorted_contains(a.sites, a.n_sites, p + 1);
-        else {
-            gates_ok = ref_acgt && depth >= a.min_cov &&
-                       (!a.has_cbed || intervals_overlap(a.cbed, a.n_cbed, p, p + s_maxdel[tid] + 2));
-            site_ok = gates_ok && pass;
-            if (!gates_ok) ambiguous = false;
-        }
-        if (a.genotyping) ambiguous = false;
-        cand = site_ok;
-        // reference-base channels are overwritten with minus the strand totals (:296-297).  BASE2INDEX is keyed by channel
-        // NAME, so an IUPAC 'D' (or an 'I') in the reference lands on the D / d (I / i) channels; other letters count as 'A'
-        // (the reference raises KeyError there)
-        const int ch_up = rb == 'D' ? (int)C3R_D : rb == 'I' ? (int)C3R_I : refi;
-        const int ch_lo = rb == 'D' ? (int)C3R_d : rb == 'I' ? (int)C3R_i : 9 + refi;
-        c[ch_up] = -up;
-        c[ch_lo] = -lw;
-    }
-    s_amb[tid] = ambiguous ? 1 : 0;
-    const bool any_amb = __syncthreads_or(ambiguous ? 1 : 0) != 0;
-    C3R_PHASE(4);
-
+    const TileOut o = tile_columns<C>(a, M, t0, t1, t0, tg.region, lo, hi, slo, shi, t0, t1);
     // ---- write the tile's columns, coalesced
     const int npos = t1 - t0;
     int32_t *gcol = a.cols + (size_t)slot0 * C;
     if (!(a.abl & 8))
-    for (int i = tid; i < npos * C; i += SCAN_THREADS) gcol[i] = s_cnt[i];
+    for (int i = tid; i < npos * C; i += SCAN_THREADS) gcol[i] = M.cnt[i];
     if (tid == 0) a.tile_cols[tile] = 1;
-    C3R_PHASE(5);
-
-    if (any_amb) {
-        // "top allele != reference" with a tie at the top: the reference's stable sort keeps the class seen first in the column
-        __syncthreads();                  // the column store has read the accumulators: the first-seen words may take their place
-        for (int i = tid; i < TILE * 6; i += SCAN_THREADS) s_first[i] = 0xffffffffu;
-        __syncthreads();
-        walk_tile<C, FIRSTSEEN>(a, s, L, slo, shi, t0, t1, tg.region, nullptr, listed, n_ops);
-        __syncthreads();
-        if (ambiguous) {
-            int m = 0;
-            for (int x = 0; x < 6; ++x) m = max(m, cls[x]);
-            const uint32_t fr = s_first[tid * 6 + refi];
-            bool top_ne_ref = false;
-            for (int x = 0; x < 6; ++x)
-                if (x != refi && cls[x] == m && s_first[tid * 6 + x] < fr) top_ne_ref = true;
-            cand = gates_ok && top_ne_ref;
-        }
-    }
-
-    C3R_PHASE(6);
-    if (a.dbg && tid == 0) { atomicAdd(&a.dbg[14], (unsigned long long)n_ops); atomicAdd(&a.dbg[15], 1ull); atomicAdd(&a.dbg[13], (unsigned long long)(shi - slo)); atomicAdd(&a.dbg[12], (unsigned long long)L.n); }
-#undef C3R_PHASE
     // ---- per-position metadata
-    if (p < t1) {
+    if (t0 + tid < t1) {
         const int gi = slot0 + tid;
-        a.depth[gi] = depth;
-        a.ncov[gi] = is_row ? my_cov : 0;
-        a.flags[gi] = (uint8_t)((is_row ? 1 : 0) | (cand ? 2 : 0) | ((is_row && s_odd[tid]) ? 8 : 0));
+        a.depth[gi] = o.depth;
+        a.ncov[gi] = o.is_row ? o.cov : 0;
+        a.flags[gi] = (uint8_t)((o.is_row ? 1 : 0) | (o.cand ? 2 : 0) | ((o.is_row && M.odd[tid]) ? 8 : 0));
     }
     if (a.head_tail) {
-        int mx = is_row ? slot0 + tid : -1;
+        int mx = o.is_row ? slot0 + tid : -1;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
         if ((tid & 63) == 0 && mx > *(volatile int32_t *)&a.last_row[tg.region]) atomicMax(&a.last_row[tg.region], mx);
@@ -849,9 +942,10 @@ template <int C>
 #define C3R_SCAN_OCC30 4
 #endif
 __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) void k_scan_tiles(const ScanArgs a) {
+    __shared__ TileMem<C> M;
     const int n = *a.n_tile_list;
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
-        scan_tile<C>(a, a.tile_list[b]);
+        scan_tile<C>(a, a.tile_list[b], M);
         __syncthreads();                  // the next tile re-uses the LDS arrays
     }
 }
@@ -1352,6 +1446,8 @@ struct TileTokArgs {
     ScanArgs a;                    // the scan's own arguments (reads, segments, op table, tile list and ranges, filters, depth cap)
     const int32_t *cand_idx; const int2 *tile_cand; const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
     int32_t tok_base;              // tokens already resident from earlier scans of the batch
+    int32_t cand_cap;              // candidates (scan-relative) that cand_idx / tok_off / sites can hold: spans beyond it are skipped
+    int32_t tok_cap;               // capacity of tok[] (the fused scan sizes it from the previous pass: nothing is written past it)
 };
 constexpr int TK_NB = 32, TK_RCH = 1024, TK_MAXB = TK_RCH / 64;
 struct TokLds {
@@ -1367,6 +1463,7 @@ __device__ __forceinline__ void tok_emit(const TileTokArgs &t, TokLds &K, int c,
     const unsigned long long m = K.mask[c][b];
     if (!((m >> bit) & 1ull)) return;                         // (not a covering read by its header: nothing to place)
     const int slot = K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << bit) - 1ull));
+    if (slot >= t.tok_cap) return;
     int4 v;
     v.x = r; v.y = indel; v.z = (int)qpos; v.w = base | ((rev ? 1 : 0) << 8);
     *reinterpret_cast<int4 *>(&t.tok[slot]) = v;
@@ -1471,7 +1568,7 @@ __global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const
     for (int lb = blockIdx.x; lb < n_list; lb += gridDim.x) {
     const int tile = a.tile_list[lb];
     const int2 tc = t.tile_cand[tile];
-    if (tc.y <= 0) continue;
+    if (tc.y <= 0 || tc.x + tc.y > t.cand_cap) continue;
     __syncthreads();
     const TileGeo tg = a.geo[tile];
     const int t0 = tg.p0, t1 = tg.p1, slot0 = tile * TILE;
@@ -1487,7 +1584,7 @@ __global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const
             const int w = tc.x + cb + tid;
             const int off = t.tok_base + t.tok_off[w];
             K.lpos[tid] = t.cand_idx[w] - slot0; K.toff[tid] = off; K.rank0[tid] = 0;
-            t.sites[w].tok_off = (uint32_t)off;
+            if (t.sites) t.sites[w].tok_off = (uint32_t)off;
         }
         for (int rc = lo; rc < hi; rc += TK_RCH) {
             const int re = min(hi, rc + TK_RCH), nr = re - rc, nblk = (nr + 63) >> 6;
@@ -1529,6 +1626,7 @@ __global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const
                     if ((rest >> lane) & 1ull) {
                         const int i = 64 * b + lane;
                         const int slot = K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << lane) - 1ull));
+                        if (slot >= t.tok_cap) continue;
                         int4 v;
                         v.x = rc + i; v.y = 0; v.z = 0; v.w = 17 | ((int)K.rev[i] << 8);
                         *reinterpret_cast<int4 *>(&t.tok[slot]) = v;
@@ -1557,32 +1655,25 @@ struct PhaseArgs {
     int32_t min_mq, excl_flags;
     const uint32_t *drop; int32_t drop_words;
 };
-__global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
-    const int n_list = *a.n_tile_list;
-    for (int lb = blockIdx.x; lb < n_list; lb += gridDim.x) {
-    const int tile = a.tile_list[lb];
-    const int slot = tile * TILE + (int)threadIdx.x;
-    if (!(a.flags[slot] & 8)) continue;
-    const int p = a.geo[tile].p0 + (int)threadIdx.x;
-    const int4 rng = a.tile_rng[tile];
+// the 12 haplotype channels of position p, in order, from the reads [lo, hi)
+__device__ __forceinline__ void phase_column(const PhaseArgs &a, int p, int lo, int hi, int region, int (&cnt)[12]) {
     auto next_cov = [&](int r) {            // next read after r (BAM order) that passes the filters and covers p
-        for (++r; r < rng.y; ++r) {
+        for (++r; r < hi; ++r) {
             const DevRead rd = a.reads[r];
-            if (read_passes(rd, a.min_mq, a.excl_flags) && rd.pos <= p && rd.end > p && !read_dropped(a.drop, a.drop_words, a.geo[tile].region, r)) break;
+            if (read_passes(rd, a.min_mq, a.excl_flags) && rd.pos <= p && rd.end > p && !read_dropped(a.drop, a.drop_words, region, r)) break;
         }
         return r;
     };
-    int cnt[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) cnt[k] = 0;
-    int r2 = next_cov(rng.x - 1);           // cursor into the HP list (one entry per covering read)
+    int r2 = next_cov(lo - 1);              // cursor into the HP list (one entry per covering read)
     int prev = 0; bool have_prev = false;
-    for (int r = next_cov(rng.x - 1); r < rng.y; r = next_cov(r)) {
+    for (int r = next_cov(lo - 1); r < hi; r = next_cov(r)) {
         const DevRead rd = a.reads[r];
         const TokenAt tk = token_at(rd, r, p, a.rsegs, a.rseg_first, a.cigar, a.seq);
         const int bi = acgt_index(tk.base);
         if (tk.base == 16 || tk.base == 15 || bi >= 0) {          // * / #, N, A C G T: a list entry that consumes a tag
-            const int hp = r2 < rng.y ? (int)a.reads[r2].hp : 0;
+            const int hp = r2 < hi ? (int)a.reads[r2].hp : 0;
             r2 = next_cov(r2);
             if (bi >= 0) { if (hp == 1) cnt[bi]++; else if (hp == 2) cnt[6 + bi]++; }
             prev = hp; have_prev = true;
@@ -1597,9 +1688,152 @@ __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
             prev = 0; have_prev = true;                           // the indel token's own entry is phased '0'
         }
     }
+}
+__global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
+    const int n_list = *a.n_tile_list;
+    for (int lb = blockIdx.x; lb < n_list; lb += gridDim.x) {
+    const int tile = a.tile_list[lb];
+    const int slot = tile * TILE + (int)threadIdx.x;
+    if (!(a.flags[slot] & 8)) continue;
+    const int p = a.geo[tile].p0 + (int)threadIdx.x;
+    const int4 rng = a.tile_rng[tile];
+    int cnt[12];
+    phase_column(a, p, rng.x, rng.y, a.geo[tile].region, cnt);
     int32_t *c = a.cols + (size_t)slot * C3R_CH_PHASED + C3R_AP;
 #pragma unroll
     for (int k = 0; k < 12; ++k) c[k] = cnt[k];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// The plain mode (no head/tail calling, no splice padding, no genotyping list) in ONE tile kernel: k_fused_tiles.
+//
+// A workgroup takes a span of FUSE_IN = 224 positions that holds aligned bases and builds the columns of those positions plus
+// C3R_FLANK on either side — 256 positions, one per thread — in LDS (tile_columns).  Every candidate of the inner span then has its
+// whole 33-column window in LDS: the window rule (33 contiguous rows, :565-568), the rescale (clair3_rna/utils.py:88-92), the int32
+// window, the site record and the candidate's token count are produced right there, and the columns never go to HBM (round 2 wrote
+// 644 MB of columns per chr20 pass and read them back in k_gather: 2.6x the algorithmic bytes).  Output order = position order:
+// the spans are listed in ascending order (k_tile_ranges), workgroups take them by ticket, and a span's first output index is the
+// sum of the counts of the spans before it, found by decoupled look-back over one 64-bit word per span
+//     [63:62] 0 not ready / 1 this span's counts / 2 counts of all spans up to and including this one   [61:32] candidates   [31:0] tokens
+// so there is no count -> scan -> write sequence, no flag array, no host round trip for sizes: outputs are bounds-checked against
+// the buffers' capacity, and the host learns the totals (and whether anything did not fit: then it grows the buffers and repeats
+// the scan) from the single read-back at the end of the scan.
+constexpr int FUSE_IN = TILE - 2 * C3R_FLANK;     // 224
+struct FusedArgs {
+    ScanArgs a;                   // tile_list: spans with aligned bases, ascending; tile_rng: reads / segments of the span + flanks
+    const int2 *reg_bounds;       // [n_regions] {first position, end} (0-based): rows exist only inside their region
+    unsigned long long *state;    // [n listed spans] look-back words (zeroed by k_tile_ranges)
+    int32_t *ticket;              // next list entry to take
+    int32_t *totals;              // {candidates, tokens} of the scan, written by the last span
+    int32_t *overflow;            // bit 0: more candidates than cand_cap (nothing was written past it)
+    int32_t cand_cap;
+    int32_t rescale, max_depth;   // A5: windows with depth > 1.5 x max_depth are rescaled
+    int32_t *tensors;             // [cand_cap][33][C]
+    c3r_site_t *sites;            // [cand_cap] or null (raw re-run)
+    int32_t *cand_idx;            // [cand_cap] slot of the candidate (tile * TILE + offset in the inner span) or null
+    int32_t *tok_off;             // [cand_cap] first token of the candidate, relative to the scan, or null
+    int2 *tile_cand;              // [n_tiles] {first candidate, count} per span or null
+    PhaseArgs ph;                 // 30 channels: the ordered recompute of flagged columns
+};
+
+
+template <int C>
+__global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) void k_fused_tiles(const FusedArgs f) {
+    __shared__ TileMem<C> M;
+    __shared__ int s_ticket;
+    __shared__ unsigned long long s_prefix;
+    const ScanArgs &a = f.a;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = *a.n_tile_list;
+    for (;;) {
+        __syncthreads();                                  // (the previous span's LDS is free)
+        if (tid == 0) s_ticket = atomicAdd(f.ticket, 1);
+        __syncthreads();
+        const int b = s_ticket;
+        if (b >= n) break;
+        const int tile = a.tile_list[b];
+        const TileGeo tg = a.geo[tile];
+        const int2 rb = f.reg_bounds[tg.region];
+        const int x0 = tg.p0 - C3R_FLANK, x1 = min(tg.p1 + C3R_FLANK, rb.y);       // thread tid <-> position x0 + tid
+        const int4 rng = a.tile_rng[tile];
+        const TileOut o = tile_columns<C>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1);
+        if (C == C3R_CH_PHASED) {
+            // a column whose haplotype channels depend on the ORDER of the reads (see k_phase_recompute): redone in place, one thread
+            // per flagged column
+            if (o.is_row && M.odd[tid]) {
+                int cnt[12];
+                phase_column(f.ph, x0 + tid, rng.x, rng.y, tg.region, cnt);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) M.cnt[tid * C + C3R_AP + k] = cnt[k];
+            }
+        }
+        // ---- the window rule: 33 contiguous rows.  rowp[e] = rows among the positions before e (M.cov is free: coverage lives in o.cov)
+        int *wave_tot = &M.misc[2];
+        int n_rows;
+        const int rp = block_excl_scan(o.is_row ? 1 : 0, wave_tot, &n_rows);
+        M.cov[tid] = rp;
+        if (tid == 0) M.cov[TILE] = n_rows;
+        __syncthreads();
+        bool emit = false;
+        if (o.cand && tid >= C3R_FLANK && tid + C3R_FLANK < TILE) emit = M.cov[tid + C3R_FLANK + 1] - M.cov[tid - C3R_FLANK] == C3R_WINDOW;
+        int nc, nt;
+        const int rank = block_excl_scan(emit ? 1 : 0, wave_tot, &nc);
+        const int tpre = block_excl_scan(emit ? o.cov : 0, wave_tot, &nt);
+        // per candidate (by rank): position in the span, depth, covering reads, first token — the event arrays are free by now
+        if (emit) { M.amb[rank] = (uint8_t)tid; M.evfill[rank] = o.depth; M.evoff[rank] = o.cov; M.maxdel[rank] = tpre; }
+        // ---- where do this span's candidates and tokens start: counts of all spans before it
+        if (tid == 0) {
+            const unsigned long long mine = ((unsigned long long)(unsigned)nc << 32) | (unsigned)nt;
+            unsigned long long excl = 0;
+            if (b > 0) {
+                lb_store(&f.state[b], (1ull << 62) | mine);
+                for (int i = b - 1; i >= 0; --i) {
+                    unsigned long long w;
+                    while (((w = lb_load(&f.state[i])) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+                    excl += w & 0x3fffffffffffffffull;       // (the two counts add without carrying into each other below 2^30 / 2^32)
+                    if ((w >> 62) == 2) break;
+                }
+            }
+            lb_store(&f.state[b], (2ull << 62) | ((excl + mine) & 0x3fffffffffffffffull));
+            s_prefix = excl;
+            if (b == n - 1) { f.totals[0] = (int32_t)((excl + mine) >> 32); f.totals[1] = (int32_t)(unsigned)(excl + mine); }
+        }
+        __syncthreads();
+        const int cbase = (int)(s_prefix >> 32), tbase = (int)(unsigned)s_prefix;
+        if (f.tile_cand && tid == 0) f.tile_cand[tile] = make_int2(cbase, nc);
+        if (nc == 0) continue;
+        if (cbase + nc > f.cand_cap) { if (tid == 0) atomicOr(f.overflow, 1); continue; }
+        // ---- one wavefront per candidate: the 33 columns are one contiguous run of LDS
+        typedef int int2v __attribute__((ext_vector_type(2)));
+        constexpr int NP = C3R_WINDOW * C / 2;
+        for (int k = wave; k < nc; k += WAVES) {
+            const int e = M.amb[k], dep = M.evfill[k], w = cbase + k;
+            const bool scale = f.rescale && dep > 0 && (double)dep > (double)f.max_depth * 1.5;
+            const double sf = (double)dep / (double)f.max_depth;
+            const int2v *src = reinterpret_cast<const int2v *>(&M.cnt[(e - C3R_FLANK) * C]);
+            int2v *dst = reinterpret_cast<int2v *>(f.tensors + (size_t)w * C3R_WINDOW * C);
+            for (int i = lane; i < NP; i += 64) {
+                int2v v = src[i];
+                if (scale) { v[0] = (int32_t)((double)v[0] / sf); v[1] = (int32_t)((double)v[1] / sf); }
+                dst[i] = v;
+            }
+            const int pc = x0 + e;
+            if (f.sites) {
+                c3r_site_t *st = &f.sites[w];
+                if (lane < C3R_WINDOW) {
+                    const int rp2 = pc - C3R_FLANK + lane - a.ref_beg0;
+                    st->ref33[lane] = (rp2 >= 0 && rp2 < a.ref_len) ? (char)a.ref[rp2] : 'A';
+                } else if (lane < C3R_WINDOW + 3) {
+                    st->ref33[lane] = 0;
+                }
+                if (lane == 0) { st->pos = pc + 1; st->depth = dep; st->n_tok = M.evoff[k]; st->tok_off = 0; }
+            }
+            if (lane == 0) {
+                if (f.cand_idx) f.cand_idx[w] = tile * TILE + (e - C3R_FLANK);
+                if (f.tok_off) f.tok_off[w] = tbase + M.maxdel[k];
+            }
+        }
     }
 }
 
