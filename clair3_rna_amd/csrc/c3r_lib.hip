@@ -67,8 +67,10 @@ struct c3r_ctx {
     ScanArgs last_scan;                    // arguments of the most recent scan (c3r_get_columns completes the pruned tiles with them)
     bool last_scan_pruned = false;
     // the fused path (k_fused_tiles): look-back words and counters, region bounds, what the last scan covered
-    DevBuf d_lb, d_regb;
-    int32_t *h_scan = nullptr;             // pinned: {candidates, tokens, overflow bits, event-scratch overflow} of a fused scan
+    DevBuf d_lb, d_regb, d_span, d_spanbase, d_meta;
+    DevBuf d_winidx;                       // [resident candidates] row of the i-th site's window in d_tensors (the fused path writes windows as they arrive)
+    DevBuf d_rawidx, d_export;             // c3r_get_tensors: index of a raw re-run, windows gathered into position order
+    int32_t *h_scan = nullptr;             // pinned: what a fused scan reads back (totals, overflow flags)
     bool last_fused = false;
     std::vector<int64_t> last_starts, last_ends;
     std::string h_ref; int64_t ref_start1 = 1;
@@ -351,7 +353,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_rcnt, &ctx->d_rend, &ctx->d_pass, &ctx->d_ekey, &ctx->d_ekey2, &ctx->d_skey, &ctx->d_skey2, &ctx->d_sval, &ctx->d_sval2,
-                      &ctx->d_sorttmp, &ctx->d_s4tops, &ctx->d_pmtops, &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+                      &ctx->d_sorttmp, &ctx->d_s4tops, &ctx->d_pmtops, &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -870,6 +872,8 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
                            (const int32_t *)ctx->d_blockcnt.p, (int32_t *)ctx->d_cand.p, heavy, (int2 *)ctx->d_tile_cand.p);
     }
     if ((rc = run_gather(ctx, 1, (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_cand * tbytes), true))) return rc;
+    if ((rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + n_cand) * 4, (size_t)base_cand * 4))) return rc;
+    hipLaunchKernelGGL(k_iota, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, ctx->stream, (int32_t *)ctx->d_winidx.p + base_cand, (int)n_cand, (int)base_cand);      // (windows in site order)
     {
         if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_tokcnt.p, (int)n_cand, (int32_t *)((char *)ctx->d_small.p + 16)))) return rc;
     }
@@ -895,7 +899,7 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
         t.a = a;
         t.cand_idx = (const int32_t *)ctx->d_cand.p; t.tile_cand = (const int2 *)ctx->d_tile_cand.p;
         t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
-        t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok; t.tok_cap = INT32_MAX; t.cand_cap = INT32_MAX;     // (sized exactly above)
+        t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok; t.tok_cap = INT32_MAX; t.cand_cap = INT32_MAX; t.abort_flag = nullptr;     // (sized exactly above)
         Launch L(ctx, "k_tokens");
         hipLaunchKernelGGL(k_tile_tokens, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, t);
     }
@@ -947,13 +951,15 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     if (ctx->n_reads == 0 || n_tiles == 0) return C3R_OK;
     const size_t ev_cap = event_capacity(ctx, n_regions, ctg_starts, ctg_ends, n_tiles, 2);
     const int nblk = (n_tiles + 255) / 256;
-    // d_lb: [0] ticket of k_tile_ranges_fused, [4] ticket of k_fused_tiles, [8] candidates, [12] tokens, [16] overflow bits, [20] listed
-    // spans, [24..31] event-scratch cursor, [32] event-scratch overflow; [64..] one word per block of 256 spans, then one per span
-    const size_t lb_bytes = 64 + (size_t)nblk * 8 + (size_t)n_tiles * 8;
+    // d_lb: [0] ticket of k_tile_ranges_fused, [4] ticket of k_fused_tiles, [8] candidates, [12] tokens (k_order_spans), [16] overflow
+    // bits, [20] listed spans, [24..31] event-scratch cursor, [32] event-scratch overflow, [36] rows handed out, [40] ticket of
+    // k_order_spans; [64..] look-back words: one per block of 256 spans for k_tile_ranges_fused, then the same for k_order_spans
+    const size_t lb_bytes = 64 + (size_t)nblk * 16;
     if ((rc = ensure(ctx, ctx->d_ev, ev_cap * sizeof(EvRec))) || (rc = ensure(ctx, ctx->d_lb, lb_bytes)) || (rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16)) ||
-        (rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16)) || (rc = ensure(ctx, ctx->d_tile_cand, (size_t)n_tiles * 8 + 16)))
+        (rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16)) || (rc = ensure(ctx, ctx->d_tile_cand, (size_t)n_tiles * 8 + 16)) ||
+        (rc = ensure(ctx, ctx->d_span, (size_t)n_tiles * sizeof(int4) + 16)) || (rc = ensure(ctx, ctx->d_spanbase, (size_t)n_tiles * sizeof(int2) + 16)))
         return rc;
-    if (!ctx->h_scan) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_scan, 32, hipHostMallocDefault));
+    if (!ctx->h_scan) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_scan, 64, hipHostMallocDefault));
     const uint32_t *d_drop = nullptr;
     int drop_words = 0;
     if ((rc = depth_cap_mask(ctx, n_regions, ctg_starts, ctg_ends, &d_drop, &drop_words))) return rc;
@@ -965,9 +971,9 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     a.tile_rng = (int4 *)ctx->d_tile_rng.p; a.tile_list = (int32_t *)ctx->d_tile_list.p; a.n_tile_list = (int32_t *)(lb + 20);
     a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)(lb + 24); a.ev_cap = (unsigned long long)ev_cap; a.ev_overflow = (int32_t *)(lb + 32);
     f.reg_bounds = (const int2 *)ctx->d_regb.p;
-    f.state = (unsigned long long *)(lb + 64 + (size_t)nblk * 8);
-    f.ticket = (int32_t *)(lb + 4); f.totals = (int32_t *)(lb + 8); f.overflow = (int32_t *)(lb + 16);
+    f.ticket = (int32_t *)(lb + 4); f.arrived = (int32_t *)(lb + 36); f.overflow = (int32_t *)(lb + 16);
     f.rescale = raw_rerun ? 0 : 1; f.max_depth = ctx->prm.max_depth_rescale;
+    f.span_info = (int4 *)ctx->d_span.p;
     f.ph.reads = a.reads; f.ph.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.ph.rseg_first = (const uint32_t *)ctx->d_rseg_first.p; f.ph.cigar = a.cigar; f.ph.seq = a.seq;
     f.ph.min_mq = a.min_mq; f.ph.excl_flags = a.excl_flags; f.ph.drop = a.drop; f.ph.drop_words = a.drop_words;
     const size_t tbytes = (size_t)C3R_WINDOW * C * 4;
@@ -976,27 +982,37 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     if (raw_rerun) { want_c = ctx->last_cand; want_t = 0; }
     else {
         want_c = std::min<int64_t>({(int64_t)(ctx->d_tensors.cap / tbytes) - base_cand, (int64_t)(ctx->d_sites_out.cap / sizeof(c3r_site_t)) - base_cand,
-                                    (int64_t)(ctx->d_cand.cap / 4), (int64_t)(ctx->d_tokcnt.cap / 4)});
+                                    (int64_t)(ctx->d_winidx.cap / 4) - base_cand, (int64_t)(ctx->d_cand.cap / 4), (int64_t)(ctx->d_tokcnt.cap / 4),
+                                    (int64_t)(ctx->d_meta.cap / sizeof(CandMeta))});
         want_t = (int64_t)(ctx->d_tok.cap / sizeof(c3r_token_t)) - base_tok;
         if (want_c < 1024) want_c = 65536;
         if (want_t < 1024) want_t = 32 * want_c;
     }
     int32_t n_cand = 0, n_tok = 0;
     for (int attempt = 0;; ++attempt) {
+        FinalizeArgs z;
+        memset(&z, 0, sizeof z);
+        if ((rc = ensure(ctx, ctx->d_meta, std::max<size_t>((size_t)want_c * sizeof(CandMeta), 16)))) return rc;
         if (raw_rerun) {
-            if ((rc = ensure(ctx, ctx->d_raw, std::max<size_t>((size_t)want_c * tbytes, 16)))) return rc;
+            if ((rc = ensure(ctx, ctx->d_raw, std::max<size_t>((size_t)want_c * tbytes, 16))) || (rc = ensure(ctx, ctx->d_rawidx, std::max<size_t>((size_t)want_c * 4, 16)))) return rc;
             f.tensors = (int32_t *)ctx->d_raw.p;
+            z.win_idx = (int32_t *)ctx->d_rawidx.p; z.row_base = 0;
         } else {
             if ((rc = ensure(ctx, ctx->d_cand, (size_t)want_c * 4)) || (rc = ensure(ctx, ctx->d_tokcnt, (size_t)want_c * 4)) ||
                 (rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_cand + want_c) * tbytes, (size_t)base_cand * tbytes)) ||
                 (rc = ensure_keep(ctx, ctx->d_sites_out, (size_t)(base_cand + want_c) * sizeof(c3r_site_t), (size_t)base_cand * sizeof(c3r_site_t))) ||
+                (rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + want_c) * 4, (size_t)base_cand * 4)) ||
                 (rc = ensure_keep(ctx, ctx->d_tok, (size_t)(base_tok + want_t) * sizeof(c3r_token_t), (size_t)base_tok * sizeof(c3r_token_t))))
                 return rc;
             f.tensors = (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_cand * tbytes);
-            f.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
-            f.cand_idx = (int32_t *)ctx->d_cand.p; f.tok_off = (int32_t *)ctx->d_tokcnt.p; f.tile_cand = (int2 *)ctx->d_tile_cand.p;
+            z.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
+            z.cand_idx = (int32_t *)ctx->d_cand.p; z.tok_off = (int32_t *)ctx->d_tokcnt.p;
+            z.win_idx = (int32_t *)ctx->d_winidx.p + base_cand; z.row_base = (int32_t)base_cand;
         }
+        f.meta = (CandMeta *)ctx->d_meta.p;
         f.cand_cap = (int32_t)std::min<int64_t>(want_c, INT32_MAX);
+        z.meta = f.meta; z.span_info = f.span_info; z.span_base = (const int2 *)ctx->d_spanbase.p; z.arrived = f.arrived; z.overflow = f.overflow; z.cand_cap = f.cand_cap;
+        z.geo = a.geo; z.ref = a.ref; z.ref_beg0 = a.ref_beg0; z.ref_len = a.ref_len;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_lb.p, 0, lb_bytes, ctx->stream));
         {
             Launch L(ctx, "k_tile_ranges");
@@ -1008,24 +1024,30 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             if (C == C3R_CH) hipLaunchKernelGGL(k_fused_tiles<C3R_CH>, dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, f);
             else hipLaunchKernelGGL(k_fused_tiles<C3R_CH_PHASED>, dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, f);
         }
+        {
+            Launch L(ctx, "k_order_sites");
+            hipLaunchKernelGGL(k_order_spans, dim3(nblk), dim3(256), 0, ctx->stream, (const int4 *)ctx->d_span.p, (const int32_t *)(lb + 20), (int32_t *)(lb + 40),
+                               (unsigned long long *)(lb + 64 + (size_t)nblk * 8), (int2 *)ctx->d_spanbase.p, (int2 *)ctx->d_tile_cand.p, (int32_t *)(lb + 8));
+            hipLaunchKernelGGL(k_finalize_sites, dim3((unsigned)std::min<int64_t>((want_c + 3) / 4 + 1, 8192)), dim3(256), 0, ctx->stream, z);
+        }
         if (!raw_rerun) {
             TileTokArgs t;
             t.a = a;
             t.cand_idx = (const int32_t *)ctx->d_cand.p; t.tile_cand = (const int2 *)ctx->d_tile_cand.p;
             t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
             t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;
-            t.tok_cap = (int32_t)std::min<int64_t>(base_tok + want_t, INT32_MAX); t.cand_cap = f.cand_cap;
+            t.tok_cap = (int32_t)std::min<int64_t>(base_tok + want_t, INT32_MAX); t.cand_cap = f.cand_cap; t.abort_flag = f.overflow;
             Launch L(ctx, "k_tokens");
             hipLaunchKernelGGL(k_tile_tokens, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, t);
         }
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan, lb + 8, 28, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan, lb + 8, 32, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         n_cand = ctx->h_scan[0]; n_tok = ctx->h_scan[1];
         if (ctx->h_scan[6]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
         if (n_cand < 0 || n_tok < 0) return fail(ctx, C3R_EOVERFLOW, "too many candidates or tokens for one scan");
         if (raw_rerun) {
-            if (n_cand != ctx->last_cand) return fail(ctx, C3R_EINVAL, "internal: the raw re-run found %d candidates, the scan %lld", n_cand, (long long)ctx->last_cand);
+            if (n_cand != ctx->last_cand || (ctx->h_scan[2] & 1)) return fail(ctx, C3R_EINVAL, "internal: the raw re-run found %d candidates, the scan %lld", n_cand, (long long)ctx->last_cand);
             return C3R_OK;
         }
         if (n_cand <= want_c && n_tok <= want_t && !(ctx->h_scan[2] & 1)) break;
@@ -1065,21 +1087,34 @@ int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_si
     if (cap_sites < ctx->n_cand) return fail(ctx, C3R_EOVERFLOW, "need room for %lld sites", (long long)ctx->n_cand);
     if (ctx->n_cand == 0) return C3R_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const size_t bytes = (size_t)ctx->n_cand * C3R_WINDOW * ctx->prm.channels * 4;
+    const int row_ints = C3R_WINDOW * ctx->prm.channels;
+    const size_t bytes = (size_t)ctx->n_cand * row_ints * 4;
     const void *src = ctx->d_tensors.p;
+    const int32_t *idx = (const int32_t *)ctx->d_winidx.p;       // the fused path stores windows in arrival order
     if (!rescaled) {
-        // raw (un-rescaled) windows are re-gathered from the columns of the most recent scan only
+        // raw (un-rescaled) windows are rebuilt for the most recent scan only
         if (ctx->last_base != 0 || ctx->last_cand != ctx->n_cand)
             return fail(ctx, C3R_EINVAL, "raw tensors are only available for a single (non-batched) scan");
         if (ctx->last_fused) {               // the fused path keeps no columns: the scan runs again, un-rescaled windows only
             int rc = scan_fused(ctx, (int32_t)ctx->last_starts.size(), ctx->last_starts.data(), ctx->last_ends.data(), nullptr, true);
             if (rc) return rc;
-        } else if (!ctx->prm.splice_padding) {     // (splice padding: the scan already kept the raw windows, the columns have moved on)
-            int rc = ensure(ctx, ctx->d_raw, bytes);
-            if (rc) return rc;
-            if ((rc = run_gather(ctx, 0, (int32_t *)ctx->d_raw.p, false))) return rc;
+            idx = (const int32_t *)ctx->d_rawidx.p;
+        } else {
+            if (!ctx->prm.splice_padding) {     // (splice padding: the scan already kept the raw windows, the columns have moved on)
+                int rc = ensure(ctx, ctx->d_raw, bytes);
+                if (rc) return rc;
+                if ((rc = run_gather(ctx, 0, (int32_t *)ctx->d_raw.p, false))) return rc;
+            }
+            idx = nullptr;
         }
         src = ctx->d_raw.p;
+    }
+    if (idx) {
+        int rc = ensure(ctx, ctx->d_export, bytes);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)std::min<int64_t>((ctx->n_cand + 3) / 4, 8192)), dim3(256), 0, ctx->stream, (const int32_t *)src, idx, (int)ctx->n_cand, row_ints,
+                           (int32_t *)ctx->d_export.p);
+        src = ctx->d_export.p;
     }
     HIPCHK(ctx, hipMemcpyAsync(tensors, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1184,7 +1219,7 @@ static int calibrate_mx(c3r_ctx *ctx, double *err_out) {
     auto run = [&](int mode, std::vector<float> &out) -> int {
         ctx->net.precision = mode;
         std::string e;
-        int rc = net_forward(ctx->net, d_x, n, ctx->stream, [](const char *, int) {}, e);
+        int rc = net_forward(ctx->net, d_x, nullptr, n, ctx->stream, [](const char *, int) {}, e);
         if (rc) return fail(ctx, rc, "%s", e.c_str());
         HIPCHK(ctx, hipMemcpyAsync(out.data(), ctx->net.d_probs, out.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1248,11 +1283,12 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
     if (!ctx->net.loaded) return fail(ctx, C3R_EINVAL, "c3r_load_weights must be called before c3r_infer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int C = ctx->net.channels;
-    const int32_t *d_x = nullptr;
+    const int32_t *d_x = nullptr, *d_rows = nullptr;
     if (tensors == nullptr) {
         if (C != ctx->prm.channels) return fail(ctx, C3R_EINVAL, "weights are for %d channels, scan produced %d", C, ctx->prm.channels);
         if (n != ctx->n_cand) return fail(ctx, C3R_EINVAL, "n=%lld but %lld candidates are resident", (long long)n, (long long)ctx->n_cand);
         d_x = (const int32_t *)ctx->d_tensors.p;
+        d_rows = (const int32_t *)ctx->d_winidx.p;       // windows lie in arrival order (k_fused_tiles)
     } else if (n > 0) {
         int rc = ensure(ctx, ctx->d_raw, (size_t)n * C3R_WINDOW * C * 4);
         if (rc) return rc;
@@ -1271,7 +1307,7 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
             KStat &k = ctx->kstats[name]; k.ms += ms; k.n += 1;
         }
     };
-    int rc = net_forward(ctx->net, d_x, n, ctx->stream, prof, e);
+    int rc = net_forward(ctx->net, d_x, d_rows, n, ctx->stream, prof, e);
     if (rc) return fail(ctx, rc, "%s", e.c_str());
     if (probs) {
         HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, (size_t)n * C3R_NPROB * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

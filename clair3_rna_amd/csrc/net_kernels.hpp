@@ -90,7 +90,8 @@ __device__ __forceinline__ float selu(float x) {
 //      L2 weight stream, not the matrix pipe, limits SB = 1 (66 % of peak; 81 % with L1-hot weights).
 template <int INP, int CIN, int H, bool INT_IN, int SB = 2, int ABL = 0>
 __global__ __launch_bounds__(256, (SB == 1 ? 2 : 1)) void k_lstm(const void *__restrict__ xin, const float4 *__restrict__ Wp,
-                                                                  const float *__restrict__ bp, float *__restrict__ y, int n) {
+                                                                  const float *__restrict__ bp, float *__restrict__ y, int n,
+                                                                  const int32_t *__restrict__ row_idx = nullptr /* INT_IN: row of site i in xin (null: i) */) {
     constexpr int NGX = INP / 8;           // k-groups fed from the layer input (global memory)
     constexpr int NGH = H / 8;             // k-groups fed from h_{t-1} (LDS)
     constexpr int NG = NGX + NGH;
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256, (SB == 1 ? 2 : 1)) void k_lstm(const void *__r
     for (int sb = 0; sb < SB; ++sb) {
         int sj = site0 + 32 * sb + j;
         if (sj >= n) sj = n - 1;
+        if (INT_IN && row_idx) sj = row_idx[sj];
         xoff[sb] = (size_t)sj * NET_T * CIN;
     }
 
@@ -1020,7 +1022,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 // accumulator one after the other (no registers for two), and every B fragment is read from LDS by sixteen wavefronts.
 // Wp: [dir][quarter][g][tile(4)][hi|lo][lane] (tile blk = 4 quarter + tile); the bias rides on input slot CIN (x = 1 there).
 template <int CIN, bool YQ = false>
-__global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp, _Float16 *__restrict__ y, int n, int nstride) {
+__global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp, _Float16 *__restrict__ y, int n, int nstride,
+                                                   const int32_t *__restrict__ row_idx /* row of site i in xin (the tensor build writes windows as they arrive); null: i */) {
     constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NTQ = 4, WG_SITES = 64, HV = H / 8, XP = 40;
     constexpr int NPC = (CIN + 1) / 2;
     static_assert(CIN % 2 == 0 && CIN < 32 && WG_SITES * NPC <= 1024, "even channel count, one free slot for the bias, one x piece per thread");
@@ -1053,12 +1056,15 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
     typedef int int2v __attribute__((ext_vector_type(2)));
     int2v xr = {0, 0};
     const bool xmine = tid < WG_SITES * NPC;
+    size_t xrow = 0;
+    if (xmine) {
+        int sj = site0 + tid / NPC;
+        if (sj >= n) sj = n - 1;
+        if (row_idx) sj = row_idx[sj];
+        xrow = (size_t)sj * NET_T * CIN + 2 * (tid % NPC);
+    }
     auto x_fetch = [&](int tt_) {
-        if (xmine) {
-            int sj = site0 + tid / NPC;
-            if (sj >= n) sj = n - 1;
-            xr = *(const int2v *)(xin + ((size_t)sj * NET_T + tt_) * CIN + 2 * (tid % NPC));
-        }
+        if (xmine) xr = *(const int2v *)(xin + xrow + (size_t)tt_ * CIN);
     };
     auto x_store = [&](int buf) {
         if (xmine) {
@@ -1669,22 +1675,24 @@ inline int net_reserve(NetState &s, int64_t n_total, hipStream_t st, std::string
 }
 
 // d_x: device int32 [n][33][C].  prof(name, 0|1) brackets each kernel for optional event timing.
-inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *d_probs, hipStream_t st,
+inline int net_forward_slice(NetState &s, const int32_t *d_x, const int32_t *row_idx, int64_t n, float *d_probs, hipStream_t st,
                              const std::function<void(const char *, int)> &prof, std::string &err);
 
-inline int net_forward(NetState &s, const int32_t *d_x, int64_t n, hipStream_t st,
+// d_x: device int32 [rows][33][C]; site i of the batch reads row row_idx[i] (row_idx == nullptr: row i)
+inline int net_forward(NetState &s, const int32_t *d_x, const int32_t *row_idx, int64_t n, hipStream_t st,
                        const std::function<void(const char *, int)> &prof, std::string &err) {
     int rc = net_reserve(s, n, st, err);
     if (rc) return rc;
     const int64_t step = std::min(n, NET_SLICE);
     for (int64_t off = 0; off < n; off += step) {
         const int64_t m = std::min(step, n - off);
-        if ((rc = net_forward_slice(s, d_x + (size_t)off * NET_T * s.channels, m, s.d_probs + (size_t)off * C3R_NPROB, st, prof, err))) return rc;
+        const int32_t *x = row_idx ? d_x : d_x + (size_t)off * NET_T * s.channels;
+        if ((rc = net_forward_slice(s, x, row_idx ? row_idx + off : nullptr, m, s.d_probs + (size_t)off * C3R_NPROB, st, prof, err))) return rc;
     }
     return C3R_OK;
 }
 
-inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *d_probs, hipStream_t st,
+inline int net_forward_slice(NetState &s, const int32_t *d_x, const int32_t *row_idx, int64_t n, float *d_probs, hipStream_t st,
                              const std::function<void(const char *, int)> &prof, std::string &err) {
     const int nb = (int)((n + NET_SITES - 1) / NET_SITES);
     const dim3 grid((unsigned)((n + LSTM_SITES - 1) / LSTM_SITES), 2), block(256);
@@ -1700,11 +1708,11 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
         const bool mx = s.precision == 2;
         prof("k_lstm1", 0);
         if (s.channels == C3R_CH) {
-            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
-            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx);
         } else {
-            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
-            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns);
+            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx);
         }
         prof("k_lstm1", 1);
         prof("k_lstm2", 0);
@@ -1721,11 +1729,11 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, int64_t n, float *
     if (s.channels == C3R_CH) {
         constexpr int INP = 32;
         hipLaunchKernelGGL((k_lstm<INP, C3R_CH, NET_H1, true, LSTM_SB>), grid, block, 0, st, (const void *)d_x,
-                           (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n);
+                           (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n, row_idx);
     } else {
         constexpr int INP = 32;
         hipLaunchKernelGGL((k_lstm<INP, C3R_CH_PHASED, NET_H1, true, LSTM_SB>), grid, block, 0, st, (const void *)d_x,
-                           (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n);
+                           (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n, row_idx);
     }
     prof("k_lstm1", 1);
     prof("k_lstm2", 0);

@@ -608,6 +608,38 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const ScanArgs a) {     // 
 // look-back words are read and written at device scope (every XCD has its own L2)
 __device__ __forceinline__ unsigned long long lb_load(unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lb_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Decoupled look-back by one whole wavefront: entry b publishes its own counts (flag 1), sums the entries before it — 64 at a time, every
+// lane one uncached load — down to the nearest entry that already holds an inclusive prefix (flag 2), then publishes its own
+// inclusive prefix.  Returns the exclusive prefix (the 62 payload bits) to every lane.  A single thread walking the words one
+// round trip at a time met ~1000 not-yet-inclusive predecessors whenever the chip's resident workgroups finished together.
+__device__ __forceinline__ unsigned long long lb_lookback(unsigned long long *state, int b, unsigned long long mine) {
+    const int lane = (int)(threadIdx.x & 63);
+    constexpr unsigned long long PAY = 0x3fffffffffffffffull;
+    unsigned long long excl = 0;
+    if (b > 0) {
+        if (lane == 0) lb_store(&state[b], (1ull << 62) | mine);
+        for (int top = b - 1; top >= 0; top -= 64) {
+            const int i = top - lane;
+            unsigned long long w = 0;
+            bool incl_found = false;
+            for (;;) {
+                w = i >= 0 ? lb_load(&state[i]) : (2ull << 62);            // (before the first entry: an inclusive prefix of zero)
+                const unsigned long long not_ready = __ballot((w >> 62) == 0), incl = __ballot((w >> 62) == 2);
+                // lanes are ordered nearest predecessor first: everything up to the nearest inclusive entry must be there
+                const int first_incl = incl ? __ffsll((long long)incl) - 1 : 64;
+                const unsigned long long need = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
+                if (!(not_ready & need)) { incl_found = incl != 0; w = (lane <= first_incl) ? (w & PAY) : 0ull; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
+            excl += w;
+            if (incl_found) break;
+        }
+    }
+    if (lane == 0) lb_store(&state[b], (2ull << 62) | ((excl + mine) & PAY));
+    return excl;
+}
 
 // The fused path's list of spans (k_fused_tiles): only spans that hold aligned bases, in ASCENDING order (= output order), with the
 // read / segment ranges of the span plus C3R_FLANK on either side.  Workgroups take blocks of 256 spans by ticket and place their
@@ -647,21 +679,13 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
     const unsigned long long m = __ballot(listed);
     if (lane == 0) s_cnt[wave] = __popcll(m);
     __syncthreads();
-    if (tid == 0) {
+    if (wave == 0) {
         const unsigned long long mine = (unsigned long long)(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
-        unsigned long long excl = 0;
-        if (b > 0) {
-            lb_store(&rstate[b], (1ull << 62) | mine);
-            for (int i = b - 1; i >= 0; --i) {
-                unsigned long long w;
-                while (((w = lb_load(&rstate[i])) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
-                excl += w & 0x3fffffffffffffffull;
-                if ((w >> 62) == 2) break;
-            }
+        const unsigned long long excl = lb_lookback(rstate, b, mine);
+        if (lane == 0) {
+            s_base = (int)excl;
+            if (b == nblk - 1) *a.n_tile_list = (int32_t)(excl + mine);
         }
-        lb_store(&rstate[b], (2ull << 62) | (excl + mine));
-        s_base = (int)excl;
-        if (b == nblk - 1) *a.n_tile_list = (int32_t)(excl + mine);
     }
     __syncthreads();
     int at = s_base;
@@ -1446,6 +1470,7 @@ struct TileTokArgs {
     ScanArgs a;                    // the scan's own arguments (reads, segments, op table, tile list and ranges, filters, depth cap)
     const int32_t *cand_idx; const int2 *tile_cand; const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
     int32_t tok_base;              // tokens already resident from earlier scans of the batch
+    const int32_t *abort_flag;     // null, or the fused scan's overflow word: set = the candidate tables are incomplete, nothing to do
     int32_t cand_cap;              // candidates (scan-relative) that cand_idx / tok_off / sites can hold: spans beyond it are skipped
     int32_t tok_cap;               // capacity of tok[] (the fused scan sizes it from the previous pass: nothing is written past it)
 };
@@ -1564,6 +1589,7 @@ __global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const
     __shared__ TokLds K;
     const ScanArgs &a = t.a;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (t.abort_flag && *t.abort_flag) return;
     const int n_list = *a.n_tile_list;
     for (int lb = blockIdx.x; lb < n_list; lb += gridDim.x) {
     const int tile = a.tile_list[lb];
@@ -1710,41 +1736,42 @@ __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
 //
 // A workgroup takes a span of FUSE_IN = 224 positions that holds aligned bases and builds the columns of those positions plus
 // C3R_FLANK on either side — 256 positions, one per thread — in LDS (tile_columns).  Every candidate of the inner span then has its
-// whole 33-column window in LDS: the window rule (33 contiguous rows, :565-568), the rescale (clair3_rna/utils.py:88-92), the int32
-// window, the site record and the candidate's token count are produced right there, and the columns never go to HBM (round 2 wrote
-// 644 MB of columns per chr20 pass and read them back in k_gather: 2.6x the algorithmic bytes).  Output order = position order:
-// the spans are listed in ascending order (k_tile_ranges), workgroups take them by ticket, and a span's first output index is the
-// sum of the counts of the spans before it, found by decoupled look-back over one 64-bit word per span
-//     [63:62] 0 not ready / 1 this span's counts / 2 counts of all spans up to and including this one   [61:32] candidates   [31:0] tokens
-// so there is no count -> scan -> write sequence, no flag array, no host round trip for sizes: outputs are bounds-checked against
-// the buffers' capacity, and the host learns the totals (and whether anything did not fit: then it grows the buffers and repeats
-// the scan) from the single read-back at the end of the scan.
+// whole 33-column window in LDS: the window rule (33 contiguous rows, :565-568), the rescale (clair3_rna/utils.py:88-92) and the int32
+// window are produced right there, and the columns never go to HBM (round 2 wrote 644 MB of columns per chr20 pass and read them
+// back in k_gather: 2.6x the algorithmic bytes).
+// Order.  Candidates must come out in position order, but a span's first output index is the sum of the counts of all spans before
+// it, and a span's run time varies 10x with depth: making each span wait for its predecessors (decoupled look-back inside this
+// kernel, the first version) let the chip's ~1300 resident workgroups retire only as fast as the slowest of them — 1.35 ms per
+// chr20 pass against 0.61 ms without the ordering.  So the WINDOWS are written where they arrive: a span takes its rows with one
+// atomic add and notes (first row, candidates, tokens) in span_info and a 20-byte record per candidate in `meta`.  k_order_spans
+// then sums the notes in span order (uniform work: look-back costs nothing there), and k_finalize_sites writes everything that is
+// small — site records, token offsets, slots — in position order, plus win_idx[i] = the row of the i-th site's window, through
+// which layer 1 of the network (and c3r_get_tensors) reads the tensors.  No count -> scan -> write over flag arrays, no host
+// round trip for sizes: outputs are bounds-checked against the buffers' capacity, and the host learns the totals (and whether
+// anything did not fit: then it grows the buffers and repeats the scan) from the single read-back at the end of the scan.
 constexpr int FUSE_IN = TILE - 2 * C3R_FLANK;     // 224
+struct CandMeta { int32_t slot, depth, ncov, tpre, span; };      // per arrived candidate: slot (tile * TILE + offset), depth, covering reads,
+                                                                 // tokens of the span's earlier candidates, list index of its span
 struct FusedArgs {
     ScanArgs a;                   // tile_list: spans with aligned bases, ascending; tile_rng: reads / segments of the span + flanks
     const int2 *reg_bounds;       // [n_regions] {first position, end} (0-based): rows exist only inside their region
-    unsigned long long *state;    // [n listed spans] look-back words (zeroed by k_tile_ranges)
     int32_t *ticket;              // next list entry to take
-    int32_t *totals;              // {candidates, tokens} of the scan, written by the last span
-    int32_t *overflow;            // bit 0: more candidates than cand_cap (nothing was written past it)
+    int32_t *arrived;             // rows handed out so far (= candidates, once the kernel is done)
+    int32_t *overflow;            // bit 0: a span's candidates did not fit below cand_cap (nothing was written past it)
     int32_t cand_cap;
     int32_t rescale, max_depth;   // A5: windows with depth > 1.5 x max_depth are rescaled
-    int32_t *tensors;             // [cand_cap][33][C]
-    c3r_site_t *sites;            // [cand_cap] or null (raw re-run)
-    int32_t *cand_idx;            // [cand_cap] slot of the candidate (tile * TILE + offset in the inner span) or null
-    int32_t *tok_off;             // [cand_cap] first token of the candidate, relative to the scan, or null
-    int2 *tile_cand;              // [n_tiles] {first candidate, count} per span or null
+    int32_t *tensors;             // [cand_cap][33][C], rows in arrival order
+    int4 *span_info;              // [listed spans] {first row, candidates, tokens, tile}
+    CandMeta *meta;               // [cand_cap]
     PhaseArgs ph;                 // 30 channels: the ordered recompute of flagged columns
 };
-
 
 template <int C>
 __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) void k_fused_tiles(const FusedArgs f) {
     __shared__ TileMem<C> M;
-    __shared__ int s_ticket;
-    __shared__ unsigned long long s_prefix;
+    __shared__ int s_ticket, s_row0;
     const ScanArgs &a = f.a;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x;
     const int n = *a.n_tile_list;
     for (;;) {
         __syncthreads();                                  // (the previous span's LDS is free)
@@ -1780,61 +1807,131 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
         int nc, nt;
         const int rank = block_excl_scan(emit ? 1 : 0, wave_tot, &nc);
         const int tpre = block_excl_scan(emit ? o.cov : 0, wave_tot, &nt);
-        // per candidate (by rank): position in the span, depth, covering reads, first token — the event arrays are free by now
-        if (emit) { M.amb[rank] = (uint8_t)tid; M.evfill[rank] = o.depth; M.evoff[rank] = o.cov; M.maxdel[rank] = tpre; }
-        // ---- where do this span's candidates and tokens start: counts of all spans before it
+        // per candidate (by rank): position in the span and depth for the window copy — the event arrays are free by now
+        if (emit) { M.amb[rank] = (uint8_t)tid; M.evfill[rank] = o.depth; }
         if (tid == 0) {
-            const unsigned long long mine = ((unsigned long long)(unsigned)nc << 32) | (unsigned)nt;
-            unsigned long long excl = 0;
-            if (b > 0) {
-                lb_store(&f.state[b], (1ull << 62) | mine);
-                for (int i = b - 1; i >= 0; --i) {
-                    unsigned long long w;
-                    while (((w = lb_load(&f.state[i])) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
-                    excl += w & 0x3fffffffffffffffull;       // (the two counts add without carrying into each other below 2^30 / 2^32)
-                    if ((w >> 62) == 2) break;
-                }
-            }
-            lb_store(&f.state[b], (2ull << 62) | ((excl + mine) & 0x3fffffffffffffffull));
-            s_prefix = excl;
-            if (b == n - 1) { f.totals[0] = (int32_t)((excl + mine) >> 32); f.totals[1] = (int32_t)(unsigned)(excl + mine); }
+            s_row0 = nc ? atomicAdd(f.arrived, nc) : 0;
+            f.span_info[b] = make_int4(s_row0, nc, nt, tile);
         }
         __syncthreads();
-        const int cbase = (int)(s_prefix >> 32), tbase = (int)(unsigned)s_prefix;
-        if (f.tile_cand && tid == 0) f.tile_cand[tile] = make_int2(cbase, nc);
         if (nc == 0) continue;
-        if (cbase + nc > f.cand_cap) { if (tid == 0) atomicOr(f.overflow, 1); continue; }
-        // ---- one wavefront per candidate: the 33 columns are one contiguous run of LDS
-        typedef int int2v __attribute__((ext_vector_type(2)));
-        constexpr int NP = C3R_WINDOW * C / 2;
-        for (int k = wave; k < nc; k += WAVES) {
-            const int e = M.amb[k], dep = M.evfill[k], w = cbase + k;
-            const bool scale = f.rescale && dep > 0 && (double)dep > (double)f.max_depth * 1.5;
-            const double sf = (double)dep / (double)f.max_depth;
-            const int2v *src = reinterpret_cast<const int2v *>(&M.cnt[(e - C3R_FLANK) * C]);
-            int2v *dst = reinterpret_cast<int2v *>(f.tensors + (size_t)w * C3R_WINDOW * C);
-            for (int i = lane; i < NP; i += 64) {
-                int2v v = src[i];
-                if (scale) { v[0] = (int32_t)((double)v[0] / sf); v[1] = (int32_t)((double)v[1] / sf); }
-                dst[i] = v;
-            }
-            const int pc = x0 + e;
-            if (f.sites) {
-                c3r_site_t *st = &f.sites[w];
-                if (lane < C3R_WINDOW) {
-                    const int rp2 = pc - C3R_FLANK + lane - a.ref_beg0;
-                    st->ref33[lane] = (rp2 >= 0 && rp2 < a.ref_len) ? (char)a.ref[rp2] : 'A';
-                } else if (lane < C3R_WINDOW + 3) {
-                    st->ref33[lane] = 0;
-                }
-                if (lane == 0) { st->pos = pc + 1; st->depth = dep; st->n_tok = M.evoff[k]; st->tok_off = 0; }
-            }
-            if (lane == 0) {
-                if (f.cand_idx) f.cand_idx[w] = tile * TILE + (e - C3R_FLANK);
-                if (f.tok_off) f.tok_off[w] = tbase + M.maxdel[k];
-            }
+        const int row0 = s_row0;
+        if (row0 + nc > f.cand_cap) { if (tid == 0) atomicOr(f.overflow, 1); continue; }
+        if (emit) {
+            CandMeta m;
+            m.slot = tile * TILE + (tid - C3R_FLANK); m.depth = o.depth; m.ncov = o.cov; m.tpre = tpre; m.span = b;
+            f.meta[row0 + rank] = m;
+        }
+        // ---- the span's nc windows are ONE contiguous run of the output (rows [row0, row0 + nc) x 33 x C int32) and each window is
+        // one contiguous run of LDS: all threads copy the run, 16 bytes per lane and store (a window is 8 bytes short of a multiple
+        // of 16, so whole-window copies could only use 8-byte stores)
+        constexpr int WIN = C3R_WINDOW * C;
+        int32_t *out = f.tensors + (size_t)row0 * WIN;
+        const int total = nc * WIN;
+        const int head = min(total, (int)((16u - ((unsigned)(uintptr_t)out & 15u)) & 15u) >> 2);      // ints before the first 16-byte boundary
+        const int resc_thr = f.rescale ? 3 * f.max_depth : INT32_MAX;                                // depth > 1.5 x max_depth  <=>  2 depth > 3 max_depth
+        auto fetch = [&](int g) -> int {
+            const int k = g / WIN, oo = g - k * WIN;
+            int v = M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo];
+            const int dep = M.evfill[k];
+            if (2 * (long long)dep > (long long)resc_thr) v = (int32_t)((double)v / ((double)dep / (double)f.max_depth));
+            return v;
+        };
+        if (tid < head) out[tid] = fetch(tid);
+        const int n4 = (total - head) >> 2;
+        for (int c4 = tid; c4 < n4; c4 += SCAN_THREADS) {
+            const int g = head + 4 * c4;
+            int4 v;
+            v.x = fetch(g); v.y = fetch(g + 1); v.z = fetch(g + 2); v.w = fetch(g + 3);
+            *reinterpret_cast<int4 *>(out + g) = v;
+        }
+        const int gt = head + 4 * n4 + tid;
+        if (gt < total) out[gt] = fetch(gt);
+    }
+}
+
+// Spans in list order -> where each span's candidates and tokens start in position order.  256 spans per workgroup, taken by ticket;
+// the workgroups' sums meet by decoupled look-back (uniform, tiny work per workgroup: nobody waits for long).
+//   span_base[i] = {first candidate, first token};  tile_cand[tile] = {first candidate, candidates};  totals = {candidates, tokens}
+__global__ __launch_bounds__(256) void k_order_spans(const int4 *span_info, const int32_t *n_list_p, int32_t *ticket, unsigned long long *ostate,
+                                                     int2 *span_base, int2 *tile_cand, int32_t *totals) {
+    __shared__ int s_b, s_w[WAVES];
+    __shared__ unsigned long long s_excl;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = *n_list_p;
+    if (tid == 0) s_b = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int b = s_b;
+    if (b * 256 >= n) { if (n == 0 && b == 0 && tid == 0) { totals[0] = 0; totals[1] = 0; } return; }
+    const int i = b * 256 + tid;
+    int4 v = make_int4(0, 0, 0, 0);
+    if (i < n) v = span_info[i];
+    int tc, tt;
+    const int ec = block_excl_scan(v.y, s_w, &tc);
+    const int et = block_excl_scan(v.z, s_w, &tt);
+    if (wave == 0) {
+        const unsigned long long mine = ((unsigned long long)(unsigned)tc << 32) | (unsigned)tt;
+        const unsigned long long excl = lb_lookback(ostate, b, mine);
+        if (lane == 0) {
+            s_excl = excl;
+            if ((b + 1) * 256 >= n) { totals[0] = (int32_t)((excl + mine) >> 32); totals[1] = (int32_t)(unsigned)(excl + mine); }
         }
     }
+    __syncthreads();
+    if (i < n) {
+        const int cb = (int)(s_excl >> 32) + ec, tb = (int)(unsigned)s_excl + et;
+        span_base[i] = make_int2(cb, tb);
+        tile_cand[v.w] = make_int2(cb, v.y);
+    }
+}
+
+// Everything small about a candidate, in position order; one wavefront per arrived row.
+//   i = span_base[span].x + (row - first row of the span):  sites[i], cand_idx[i] = slot, tok_off[i] = first token (scan-relative),
+//   win_idx[i] = row_base + row
+struct FinalizeArgs {
+    const CandMeta *meta; const int4 *span_info; const int2 *span_base; const int32_t *arrived; const int32_t *overflow; int32_t cand_cap;
+    const TileGeo *geo; const uint8_t *ref; int32_t ref_beg0, ref_len;
+    c3r_site_t *sites; int32_t *cand_idx; int32_t *tok_off; int32_t *win_idx; int32_t row_base;
+};
+__global__ __launch_bounds__(256) void k_finalize_sites(const FinalizeArgs g) {
+    if (*g.overflow) return;                                  // (some rows were never written: the host repeats the scan with larger buffers)
+    const int n = min(*g.arrived, g.cand_cap);
+    const int lane = (int)(threadIdx.x & 63), nw = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); row < n; row += nw) {
+        const CandMeta m = g.meta[row];
+        const int i = g.span_base[m.span].x + (row - g.span_info[m.span].x);
+        const int pc = g.geo[m.slot / TILE].p0 + (m.slot % TILE);
+        if (g.sites) {
+            c3r_site_t *st = &g.sites[i];
+            if (lane < C3R_WINDOW) {
+                const int rp = pc - C3R_FLANK + lane - g.ref_beg0;
+                st->ref33[lane] = (rp >= 0 && rp < g.ref_len) ? (char)g.ref[rp] : 'A';
+            } else if (lane < C3R_WINDOW + 3) {
+                st->ref33[lane] = 0;
+            }
+            if (lane == 0) { st->pos = pc + 1; st->depth = m.depth; st->n_tok = m.ncov; st->tok_off = 0; }
+        }
+        if (lane == 0) {
+            if (g.cand_idx) g.cand_idx[i] = m.slot;
+            if (g.tok_off) g.tok_off[i] = g.span_base[m.span].y + m.tpre;
+            g.win_idx[i] = g.row_base + row;
+        }
+    }
+}
+
+// rows of a [n][row_ints] int32 table through an index (c3r_get_tensors: windows in position order), and the identity index the
+// column-store path leaves for its candidates
+__global__ __launch_bounds__(256) void k_gather_rows(const int32_t *src, const int32_t *idx, int n, int row_ints, int32_t *dst) {
+    const int lane = (int)(threadIdx.x & 63), nw = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); i < n; i += nw) {
+        const int32_t *s_ = src + (size_t)idx[i] * row_ints;
+        int32_t *d_ = dst + (size_t)i * row_ints;
+        for (int k = lane; k < row_ints; k += 64) d_[k] = s_[k];
+    }
+}
+__global__ __launch_bounds__(256) void k_iota(int32_t *dst, int n, int base) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = base + i;
 }
 
 }  // namespace c3r

@@ -23,7 +23,7 @@ int main(int argc, char **argv) {
         hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     }
     dim3 grid(2, (n + 63) / 64);
-    auto go = [&] { hipLaunchKernelGGL((k_lstm1_rs<18, false>), grid, dim3(1024), 0, 0, x, w, y, n, ns); };
+    auto go = [&] { hipLaunchKernelGGL((k_lstm1_rs<18, false>), grid, dim3(1024), 0, 0, x, w, y, n, ns, (const int32_t *)nullptr); };
     go(); hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0); for (int r = 0; r < 3; ++r) go(); hipEventRecord(e1); hipEventSynchronize(e1);
