@@ -150,6 +150,95 @@ def cpu_baseline(rs, ref, weights, contig_len):
                        % (min(n_regions * size, contig_len), workers, n_cpu, t1 - t0, cores, n_net, t2 - t1))
 
 
+def run_strong(args, rank, local_rank, world, one_gpu):
+    """--scaling strong: BASELINE.json configs[2] — the 24 GRCh38 contigs, sharded by contig over the ranks (LPT by length, the
+    reference's fan-out at run_clair3_rna:441-449,681-706), inputs host-resident.  One step = every rank takes ITS contigs from
+    host records (reads AND reference: both change from contig to contig) to probabilities; total work is fixed, so the N-rank
+    value measures load balance and the host feed, not N private copies.  No data-path collective."""
+    import torch
+    from clair3_rna_amd import capi, shard, synth
+    names = [n for n, _l in shard.GRCH38]
+    lens = [max(200000, int(l * args.genome_scale)) for _n, l in shard.GRCH38]
+    plan = shard.lpt_assign(lens, world)
+    mine = plan[rank]
+    depth = args.depth if args.depth != 20.0 else 30.0                       # configs[2]: ~30x
+    weights = synth.random_weights(18)
+    torch.cuda.set_device(local_rank)
+    dist, red_dev = None, "cuda"
+    if world > 1:
+        import torch.distributed as dist
+        if one_gpu:
+            dist.init_process_group("gloo"); red_dev = "cpu"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    data = []
+    for ci in mine:
+        ref, rs, info = synth.generate_contig(contig_len=lens[ci], seed=synth.SEED + 1000 + ci, depth=depth)
+        data.append((ci, ref, capi.pinned_readset(rs), chunk_list(lens[ci]), info))
+    engs = []
+    for _ in range(1 if args.no_overlap else max(1, args.contexts)):
+        e = capi.Engine(local_rank)
+        e.set_params(); e.load_weights(weights, 18); e.set_precision(args.precision)
+        engs.append(e)
+
+    def run_steps(k):
+        total, pending, ne = 0, [None] * len(engs), len(engs)
+        i = 0
+        for _ in range(k):
+            for (_ci, ref, rs, chunks, _info) in data:
+                j = i % ne; i += 1
+                e = engs[j]
+                if pending[j]:
+                    e.fetch_probs(pending[j])
+                e.set_reference(1, ref)
+                e.load_reads(rs)
+                e.begin_batch(); n = e.scan_regions(chunks); e.end_batch()
+                if n:
+                    e.infer(fetch=False)
+                pending[j] = n
+                total += n
+        for j in range(ne):
+            if pending[j]:
+                engs[j].fetch_probs(pending[j])
+        return total
+
+    def barrier():
+        for e in engs:
+            e.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+    run_steps(1)                                   # buffers sized (largest contig first in every rank's list? no: any order — one untimed pass)
+    barrier()
+    run_steps(max(args.warmup, 0))
+    barrier()
+    t0 = time.perf_counter()
+    sites = run_steps(args.steps)
+    for e in engs:
+        e.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    loads = [sum(lens[i] for i in p) for p in plan]
+    if dist is not None:
+        dist.barrier()
+        elapsed = shard.reduce_max(dist, elapsed, device=red_dev)
+        sites = int(shard.reduce_sum(dist, sites, device=red_dev))
+    if rank == 0:
+        out = {"metric": "candidate sites/sec (tensor build + inference)", "value": round(sites / elapsed, 1), "unit": "sites/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f16 hi/lo split x3, f32 accumulate (fp32-equivalent)" if args.precision == "f16x3" else args.precision,
+               "data": "synthetic",
+               "config": {"workload": "synthetic ONT dRNA004 whole genome ~%dx, 24 GRCh38 contigs x %.3g (BASELINE.json configs[2])" % (int(depth), args.genome_scale),
+                          "inputs": "host-resident flat records and reference per contig", "contigs": len(names), "genome_bp": int(sum(lens)),
+                          "parallelism": "contigs dealt largest-first to %d rank(s), no collective" % world, "lpt_imbalance": round(shard.imbalance(lens, plan), 4),
+                          "contigs_per_rank": [len(p) for p in plan], "bp_per_rank": loads, "sites_per_step": round(sites / max(1, args.steps), 1),
+                          "precision": args.precision, "streams": len(engs)},
+               "roofline": None, "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +249,10 @@ def main():
     ap.add_argument("--contexts", type=int, default=2, help="engine contexts (HIP streams) whose passes are pipelined on the GPU")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, what the driver runs): every rank owns one chr20-sized contig; strong: the 24 GRCh38 contigs of "
+                         "BASELINE.json configs[2] dealt to the ranks largest-first (LPT), total work fixed")
+    ap.add_argument("--genome_scale", type=float, default=1.0, help="--scaling strong: shrink every contig by this factor (quick runs)")
     ap.add_argument("--no_resident", action="store_true", help="skip the additional measurement with the read tables already on the device")
     ap.add_argument("--no_fast", action="store_true", help="skip the additional measurement in precision 'auto' (reported as fast_precision)")
     ap.add_argument("--no_overlap", action="store_true",
@@ -180,7 +273,11 @@ def main():
     one_gpu = os.environ.get("C3R_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
-    from clair3_rna_amd import capi, synth
+    from clair3_rna_amd import capi, shard, synth
+    if world > 1:
+        shard.host_budget(apply=True)         # this rank's share of the node's cores (its GPU's NUMA node), host thread counts to match
+    if args.scaling == "strong":
+        return run_strong(args, rank, local_rank, world, one_gpu)
     contig_len = args.contig_len or synth.CHR20_LEN
     ref, rs, info = synth.generate_contig(contig_len=contig_len, seed=synth.SEED + rank, depth=args.depth)
     weights = synth.random_weights(18)

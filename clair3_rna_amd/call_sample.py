@@ -212,6 +212,11 @@ def Run(args, log=None):
             dist.init_process_group("gloo")
         if args.gpu_id is None:
             args.gpu_id = int(os.environ.get("LOCAL_RANK", str(rank)))
+        # one process per GPU shares the node's cores with its peers: this rank's slice of them (its GPU's NUMA node when the
+        # topology says which), and thread counts cut to match — decode (C3R_THREADS), fetch, compression
+        from . import shard
+        n_thr, _cpus = shard.host_budget(apply=True)
+        args.fetch_threads = max(1, min(args.fetch_threads, n_thr // 2 or 1))
     if args.gpu_id is None:
         args.gpu_id = int(os.environ.get("C3R_DEVICE", "0"))
     for need in (args.bam_fn, args.ref_fn):

@@ -38,3 +38,114 @@ def reduce_sum(dist, value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+# GRCh38 primary contig lengths (chr1..22, X, Y): the genome BASELINE.json configs[2..3] shard by contig
+GRCH38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259), ("chr6", 170805979),
+          ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309),
+          ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285),
+          ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+
+
+def imbalance(costs, plan):
+    """max rank load / mean rank load of an assignment (1.0 = perfect)."""
+    loads = [sum(costs[i] for i in p) for p in plan]
+    mean = sum(loads) / float(len(loads))
+    return max(loads) / mean if mean > 0 else 1.0
+
+
+def local_world():
+    """(local_rank, local_world_size) of this process under torch.distributed.run (1 process per GPU); (0, 1) otherwise."""
+    import os
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return lr, max(1, lw)
+
+
+def _cpu_lists():
+    """[(numa node, [cpus])] from /sys; one pseudo-node with every allowed CPU when the topology is not exposed."""
+    import glob
+    import os
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    nodes = []
+    for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*"), key=lambda x: int(x.rsplit("node", 1)[1])):
+        try:
+            txt = open(os.path.join(d, "cpulist")).read().strip()
+        except OSError:
+            continue
+        cpus = []
+        for part in txt.split(","):
+            if not part:
+                continue
+            a, _, b = part.partition("-")
+            cpus.extend(range(int(a), int(b or a) + 1))
+        cpus = [c for c in cpus if c in set(allowed)]
+        if cpus:
+            nodes.append((int(d.rsplit("node", 1)[1]), cpus))
+    return nodes or [(0, allowed)]
+
+
+def _gpu_numa_node(local_rank):
+    """NUMA node of the local_rank-th GPU (KFD topology order = HIP device order), or None."""
+    import glob
+    import os
+    gpus = []
+    for d in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda x: int(os.path.basename(x))):
+        try:
+            props = dict(l.split(None, 1) for l in open(os.path.join(d, "properties")).read().splitlines() if " " in l)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:          # (CPU nodes have no SIMDs)
+            gpus.append(d)
+    if local_rank >= len(gpus):
+        return None
+    try:
+        links = glob.glob(os.path.join(gpus[local_rank], "io_links", "*", "properties"))
+        for fn in links:
+            props = dict(l.split(None, 1) for l in open(fn).read().splitlines() if " " in l)
+            to = int(props.get("node_to", "-1"))
+            if 0 <= to < 16 and int(props.get("type", "0")) == 2:   # PCIe link to a CPU node
+                return to
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def host_budget(local_rank=None, local_world_size=None, apply=False):
+    """Host side of one rank on a node shared with its peers (one process per GPU): the CPUs this rank may use and its thread
+    count.  Every rank gets an equal share of its GPU's NUMA node when the topology says which node that is, else an equal slice
+    of all CPUs (rank order = CPU order, which matches the usual GPU-to-socket wiring).  Without this, 8 ranks each spawn the
+    32 decode + fetch threads a single-process run would (~400 runnable threads on 256 hardware threads).
+    apply=True pins the process (sched_setaffinity) and exports C3R_THREADS / OMP_NUM_THREADS unless they are set already.
+    Returns (n_threads, cpus)."""
+    import os
+    if local_rank is None or local_world_size is None:
+        local_rank, local_world_size = local_world()
+    nodes = _cpu_lists()
+    every = [c for _n, cpus in nodes for c in cpus]
+    cpus = None
+    if local_world_size > 1:
+        node = _gpu_numa_node(local_rank)
+        by_node = dict(nodes)
+        if node in by_node and len(nodes) > 1:
+            # ranks whose GPUs hang off the same node share that node's CPUs evenly
+            peers = [r for r in range(local_world_size) if _gpu_numa_node(r) == node]
+            k = peers.index(local_rank) if local_rank in peers else 0
+            share = by_node[node]
+            n = max(1, len(share) // max(1, len(peers)))
+            cpus = share[k * n:(k + 1) * n] or share
+        else:
+            n = max(1, len(every) // local_world_size)
+            cpus = every[local_rank * n:(local_rank + 1) * n] or every
+    else:
+        cpus = every
+    n_threads = max(1, min(32, len(cpus)))
+    if apply:
+        if local_world_size > 1 and hasattr(os, "sched_setaffinity"):
+            try:
+                os.sched_setaffinity(0, cpus)
+            except OSError:
+                pass
+        os.environ.setdefault("C3R_THREADS", str(n_threads))
+        os.environ.setdefault("OMP_NUM_THREADS", str(n_threads))
+    return n_threads, cpus

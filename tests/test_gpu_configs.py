@@ -47,6 +47,13 @@ def test_config3_masseq_phased_30_channels(eng):
     for mode in ("f32", "f16x3"):
         eng.set_precision(mode)
         assert np.abs(eng.infer() - po).max() < 1e-4, mode
+    # precision "auto" on the 30-channel weights: whichever arithmetic the calibration picks must meet the same bar, and the choice
+    # must follow the measured figure (guard 4e-5)
+    eng.set_precision("auto")
+    used, cal = eng.precision()
+    assert used in ("f16x3", "f16+f8") and (used == "f16+f8") == (0 <= cal <= 4e-5), (used, cal)
+    assert np.abs(eng.infer() - po).max() < 1e-4, ("auto", used, cal)
+    eng.set_precision("f16x3")
 
 
 @pytest.mark.parametrize("channels", [18, 30])

@@ -102,6 +102,40 @@ def test_full_chr20_properties(eng):
     assert np.isfinite(P).all() and P.min() >= 0
 
 
+def test_one_full_chunk_of_configs1_is_bit_exact_against_the_oracle(eng):
+    """BASELINE.json configs[1] at full size, one of its thirteen 5-Mb chunks end to end: every create_tensor line (position, ref33,
+    594 ints, ordered alt_info) and every rescaled tensor of the chunk identical to the oracle's, probabilities within 1e-4.  (The
+    whole contig, all 201,945 sites, is the same loop in tests/evidence/full_contig_check.py: ~3 min of oracle time.)"""
+    import bench
+    from clair3_rna_amd import altinfo, capi, synth
+    from oracle import oracle as orc
+    ref, rs, _info = synth.generate_contig()
+    refs = ref.decode()
+    a, b = bench.chunk_list(len(ref))[6]
+    eng.params = capi.default_params()
+    eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.set_params()
+    eng.load_reads(capi.pinned_readset(rs))
+    eng.set_reference(1, ref)
+    w = synth.random_weights(18)
+    eng.load_weights(w, 18)
+    eng.set_precision("f16x3")
+    n = eng.scan(a, b)
+    raw, X = eng.tensors(rescaled=False), eng.tensors(rescaled=True)
+    sites, toks = eng.sites(), eng.tokens()
+    rstart = max(1, a - 1000)
+    refslice = refs[rstart - 1:b + 1000].upper()
+    lines = altinfo.format_lines("chr20", sites, raw, toks, rs, refslice, rstart)
+    rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, "chr20", max(1, a - 33), b + 33)
+    exp = orc.create_tensor(rows, "chr20", refslice, rstart, orc.make_params())
+    assert n == len(exp) > 10000
+    assert lines == exp
+    Xo, _ = orc.batch_from_lines(exp, 18)
+    assert np.array_equal(X, Xo)
+    p = eng.infer()
+    assert np.abs(p - orc.forward(w, Xo)).max() < 1e-4
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(head_tail=1), dict(splice_padding=1), dict(channels=30)])
 def test_scan_regions_equals_successive_chunk_scans(eng, kw):
     """c3r_pileup_scan_regions: all chunks of a contig in one set of launches == the chunk-by-chunk scans in batch mode

@@ -43,3 +43,33 @@ def test_two_rank_gloo_sharded_run_matches_single_process():
         total += len(exp)
     assert r["total"] == total > 0
     assert abs(r["tmax"] - max(r["elapsed"])) < 1e-9 and r["tmax"] >= r["elapsed"][0]
+
+
+def test_eight_ranks_share_grch38_and_the_host(tmp_path):
+    """world_size 8 (gloo, CPU): the contig shard of the whole-genome configs is a partition, its LPT imbalance stays under 5 %, every
+    rank derives the same plan, and the ranks' host budgets (CPUs, thread counts) split the node instead of each taking all of it."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("C3R_THREADS", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "mp_worker8.py")]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.split("\n") if l.startswith("MPRESULT ")][0][len("MPRESULT "):])
+    costs = [l for _n, l in shard.GRCH38]
+    assert r["world"] == 8 and abs(r["total"] - sum(costs)) < 1
+    mine = sorted(i for _rk, m, *_ in r["ranks"] for i in m)
+    assert mine == list(range(24))                                     # a partition of the contigs
+    assert r["worst"] / (sum(costs) / 8.0) < 1.05                       # LPT imbalance on GRCh38 at 8 ranks (1.036)
+    assert shard.imbalance(costs, shard.lpt_assign(costs, 8)) < 1.05
+    for w in (2, 4):
+        assert shard.imbalance(costs, shard.lpt_assign(costs, w)) < 1.02
+    n_cpu = len(os.sched_getaffinity(0))
+    cpu_sets = [set(c) for _rk, _m, _n, c, _t in r["ranks"]]
+    if n_cpu >= 8:
+        assert all(len(c) == n_cpu // 8 for c in cpu_sets)
+        assert len(set().union(*cpu_sets)) == 8 * (n_cpu // 8)          # disjoint slices
+    assert all(int(t) == n for _rk, _m, n, _c, t in r["ranks"]) and all(1 <= n <= max(1, n_cpu // 8) for _rk, _m, n, _c, _t in r["ranks"])

@@ -131,6 +131,16 @@ class Scheme:
                 return xh @ Wd["wh"] + xl @ Wd["wh"] + xh @ Wd["wl"]
             xh = f16(x)
             return xh @ Wd["wh"] + q8(x - xh, 2.0 ** 18) @ Wd["w8"] + q8(x, 2.0 ** 6) @ Wd["wl8"]
+        if n in ("f16x3_xa", "f16x3_xw"):
+            # two product terms instead of three on layer 2's input projection only (nf columns: y1, which is no part of a recurrence):
+            # "_xa" = layer 1's output stored as ONE f16 plane (drops w_hi * x_lo), "_xw" = its weights rounded to f16 (drops w_lo * x_hi)
+            xh = f16(x); xl = f16(x - xh)
+            if nf is None:
+                return xh @ Wd["wh"] + xl @ Wd["wh"] + xh @ Wd["wl"]
+            full = xh[:, nf:] @ Wd["wh"][nf:] + xl[:, nf:] @ Wd["wh"][nf:] + xh[:, nf:] @ Wd["wl"][nf:]
+            if n == "f16x3_xa":
+                return full + xh[:, :nf] @ Wd["wh"][:nf] + xh[:, :nf] @ Wd["wl"][:nf]
+            return full + xh[:, :nf] @ Wd["wh"][:nf] + xl[:, :nf] @ Wd["wh"][:nf]
         if n in ("f16+2f8k_x", "f16+2f8k_x4"):
             # fp8 corrections only where the operand is NOT part of a recurrence: layer 2's input projection (nf columns), and with
             # "_x4" the L4 dense layer; everything else f16x3
