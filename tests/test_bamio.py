@@ -261,3 +261,179 @@ def test_long_index_chunks_inflate_in_parallel(bam_case, margin, batch, monkeypa
         _same(got[2], _subset(rs, (pos < 234567) & (end > 123456)))
     finally:
         os.remove(bai)
+
+
+# ---- an independently written BAM + BAI (SAM spec sections 4.2, 5.1.1, 5.2; nothing below uses clair3_rna_amd/bam.py or the C++ indexer):
+# BGZF blocks cut at random byte offsets (records span blocks, many records per block, empty blocks in between), reads placed on the
+# 2^14 / 2^17 / 2^20 bin boundaries, a 70,000-op CIGAR behind a CG:B,I tag, and a .bai computed from the block table.
+def _reg2bin(beg, end):
+    end -= 1
+    for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return off + (beg >> shift)
+    return 0
+
+
+def _independent_bam_and_bai(path, recs, contig_len, seed):
+    import random
+    rng = random.Random(seed)
+    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c1\tLN:%d\n" % contig_len
+    stream = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1))
+    stream += struct.pack("<i", 3) + b"c1\x00" + struct.pack("<i", contig_len)
+    starts = []
+    for k, (pos, cig, codes, flag, mapq, hp) in enumerate(recs):
+        starts.append(len(stream))
+        qn = ("read%05d" % k).encode() + b"\x00"
+        l_seq = len(codes)
+        packed = bytearray((l_seq + 1) // 2)
+        for i, c in enumerate(codes):
+            packed[i >> 1] |= c << (0 if i & 1 else 4)
+        ref_len = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8))
+        aux = b""
+        in_rec = list(cig)
+        if len(cig) > 65535:                                    # SAM spec 4.2.2: real CIGAR in CG:B,I, placeholder <l_seq>S<ref_len>N
+            aux += b"CGBI" + struct.pack("<I", len(cig)) + np.asarray(cig, "<u4").tobytes()
+            in_rec = [(l_seq << 4) | 4, (ref_len << 4) | 3]
+        if hp:
+            aux += b"HPC" + struct.pack("<B", hp)
+        aux += b"NMi" + struct.pack("<i", k)                    # an unrelated tag after the ones that matter
+        body = struct.pack("<iiBBHHHiiii", 0, pos, len(qn), mapq, _reg2bin(pos, pos + max(1, ref_len)), len(in_rec), flag, l_seq, -1, -1, 0) + qn + \
+            np.asarray(in_rec, "<u4").tobytes() + bytes(packed) + bytes([30] * l_seq) + aux
+        stream += struct.pack("<i", len(body)) + body
+    starts.append(len(stream))
+    # BGZF: random cuts, some empty blocks, one maximal block
+    cuts, p = [0], 0
+    while p < len(stream):
+        r = rng.random()
+        step = 0 if r < 0.05 else (0xff00 if r < 0.08 else rng.randint(1, 3000))
+        p = min(len(stream), p + step)
+        cuts.append(p)
+    blocks, f = [], bytearray()                                 # (uncompressed start, compressed offset)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        chunk = bytes(stream[a:b])
+        co = zlib.compressobj(rng.choice([0, 1, 9]), zlib.DEFLATED, -15)
+        cdata = co.compress(chunk) + co.flush()
+        blocks.append((a, len(f), b - a))
+        f += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cdata) + 25) + cdata + \
+            struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+    eof_at = len(f)
+    f += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    open(path, "wb").write(bytes(f))
+
+    def voff(u):                                               # virtual offset of uncompressed offset u: the LAST block that starts at or before it and holds it
+        for (a, c, n) in reversed(blocks):
+            if a <= u < a + n:
+                return (c << 16) | (u - a)
+        return eof_at << 16                                     # one past the data: the EOF block
+    bins, lin = {}, {}
+    for k, (pos, cig, _codes, _flag, _mapq, _hp) in enumerate(recs):
+        ref_len = max(1, sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8)))
+        vb, ve = voff(starts[k]), voff(starts[k + 1])
+        ch = bins.setdefault(_reg2bin(pos, pos + ref_len), [])
+        if ch and ch[-1][1] == vb:
+            ch[-1][1] = ve
+        else:
+            ch.append([vb, ve])
+        for w in range(pos >> 14, ((pos + ref_len - 1) >> 14) + 1):
+            lin[w] = min(lin.get(w, vb), vb)
+    out = bytearray(b"BAI\x01" + struct.pack("<i", 1) + struct.pack("<i", len(bins)))
+    for b in sorted(bins):
+        out += struct.pack("<Ii", b, len(bins[b]))
+        for vb, ve in bins[b]:
+            out += struct.pack("<QQ", vb, ve)
+    n_intv = (max(lin) + 1) if lin else 0
+    out += struct.pack("<i", n_intv)
+    last = 0
+    for w in range(n_intv):                                     # empty windows carry the previous offset forward (samtools' convention) or 0
+        last = lin.get(w, last)
+        out += struct.pack("<Q", last)
+    open(path + ".bai", "wb").write(bytes(out))
+    return dict(starts=starts, voff=voff, blocks=blocks)
+
+
+def _parse_bai(path):
+    d = open(path, "rb").read()
+    assert d[:4] == b"BAI\x01"
+    n_ref, p = struct.unpack_from("<i", d, 4)[0], 8
+    refs = []
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", d, p)[0]; p += 4
+        bins = {}
+        for _b in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", d, p); p += 8
+            bins[b] = [struct.unpack_from("<QQ", d, p + 16 * i) for i in range(n_chunk)]; p += 16 * n_chunk
+        n_intv = struct.unpack_from("<i", d, p)[0]; p += 4
+        lin = list(struct.unpack_from("<%dQ" % n_intv, d, p)); p += 8 * n_intv
+        refs.append((bins, lin))
+    return refs
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_independent_writer_bin_boundaries_long_cigar_and_index(tmp_path, seed):
+    import random
+    rng = random.Random(100 + seed)
+    M, I, D, N, S = 0, 1, 2, 3, 4
+    op = lambda ln, o: (ln << 4) | o
+    L = 3 << 20
+    spots = [0, 5, 16383, 16384, 16385, (1 << 17) - 3, 1 << 17, (1 << 17) + 1, (1 << 20) - 40, 1 << 20, (2 << 20) - 1, L - 300]
+    recs = []
+    for s_ in spots:
+        for _ in range(rng.randint(1, 4)):
+            ln = rng.choice([1, 7, 30, 64, 200])
+            cig = [op(ln, M)] if rng.random() < 0.5 else [op(3, S), op(ln, M), op(rng.choice([1, 20000, 140000]), N), op(5, M), op(2, I), op(4, M)]
+            if s_ + sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3)) >= L:
+                cig = [op(ln, M)]
+            l_seq = sum(c >> 4 for c in cig if (c & 15) in (0, 1, 4))
+            recs.append((s_, cig, [rng.choice([1, 2, 4, 8, 15]) for _ in range(l_seq)], rng.choice([0, 16, 1024, 256]), rng.choice([60, 3, 0]), rng.choice([0, 1, 2])))
+    for _ in range(150):                                        # filler: many small records per block
+        pos = rng.randrange(0, L - 5000)
+        ln = rng.randint(20, 400)
+        recs.append((pos, [op(ln, M)], [rng.choice([1, 2, 4, 8]) for _ in range(ln)], 0, 60, 0))
+    big = []                                                    # 70,001 ops: 1M1I... (more than the 16-bit n_cigar_op field holds)
+    for _ in range(35000):
+        big += [op(1, M), op(1, I)]
+    big.append(op(1, M))
+    recs.append((40000, big, [rng.choice([1, 2, 4, 8]) for _ in range(70001)], 0, 60, 1))
+    recs.sort(key=lambda r: r[0])
+    p = str(tmp_path / "ind.bam")
+    info = _independent_bam_and_bai(p, recs, L, seed)
+    pos = np.array([r[0] for r in recs], np.int64)
+    end = np.array([r[0] + max(1, sum(c >> 4 for c in r[1] if (c & 15) in (0, 2, 3, 7, 8))) for r in recs], np.int64)
+    regions = [(0, 1), (16383, 16384), (16384, 16385), (16000, 17000), ((1 << 17) - 1, (1 << 17) + 1), (1 << 17, (1 << 17) + 1), ((1 << 20) - 1, 1 << 20),
+               (1 << 20, (1 << 20) + 1), (39999, 40001), (75000, 75001), (0, L), (L - 1, L), (2 << 20, (2 << 20) + 5), (200000, 900000)]
+
+    def check(bf):
+        for a, b in regions:
+            want = np.nonzero((pos < b) & (end > a))[0]
+            got = bf.fetch("c1", a, b)
+            assert len(got) == len(want), (a, b, len(got), len(want))
+            for g, k in zip(range(len(got)), want):
+                r = got.reads[g]
+                pos_k, cig_k, codes_k, flag_k, mapq_k, hp_k = recs[k]
+                assert (int(r["pos"]), int(r["flag"]), int(r["mapq"]), int(r["hp"]), int(r["l_seq"]), int(r["n_cigar"])) == (pos_k, flag_k, mapq_k, hp_k, len(codes_k), len(cig_k))
+                c = got.cigar[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
+                assert np.array_equal(c, np.asarray(cig_k, np.uint32))
+                if len(codes_k) <= 400:
+                    sq = got.seq[int(r["seq_off"]):int(r["seq_off"]) + (len(codes_k) + 1) // 2]
+                    assert [(int(sq[i >> 1]) >> (0 if i & 1 else 4)) & 15 for i in range(len(codes_k))] == codes_k
+    with bamio.BamFile(p) as bf:                                # 1. the C++ reader through the INDEPENDENT index
+        assert bf.has_index
+        check(bf)
+    mine = _parse_bai(p + ".bai")
+    os.remove(p + ".bai")
+    with bamio.BamFile(p) as bf:                                # 2. no index: linear scan
+        assert not bf.has_index
+        check(bf)
+    bamio.index_build(p)                                        # 3. the C++ indexer's own index, read back by independent code
+    with bamio.BamFile(p) as bf:
+        check(bf)
+    (bins, lin), (mbins, mlin) = _parse_bai(p + ".bai")[0], mine[0]
+    real = {b: c for b, c in bins.items() if b != 37450}        # (37450: samtools' optional metadata pseudo-bin)
+    assert set(real) == set(mbins)                              # the same bins are populated
+    for k, (pos_k, cig_k, *_rest) in enumerate(recs):
+        b = _reg2bin(pos_k, int(end[k]))
+        v = info["voff"](info["starts"][k])
+        assert any(cb <= v < ce for cb, ce in real[b]), (k, b)   # every record starts inside a chunk of its bin
+        for w in range(pos_k >> 14, ((int(end[k]) - 1) >> 14) + 1):
+            assert w < len(lin) and 0 < lin[w] <= v              # the linear index never points past an overlapping record
+    assert len(lin) == len(mlin)

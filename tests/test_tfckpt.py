@@ -58,3 +58,117 @@ def test_bundle_roundtrip_and_layer_matching(tmp_path, channels, style):
     tfckpt.write_bundle(prefix, named)
     with pytest.raises(ValueError):
         tfckpt.weights_from_bundle(prefix, channels)
+
+
+# ---- an INDEPENDENT statement of the formats (LevelDB table_format.md, tensor_bundle.proto, RFC 3720 CRC32C): nothing below calls into
+# tfckpt's own writer, so reader and writer cannot share one misreading.  Still "unverified against a TensorFlow-written file".
+def _crc32c_bitwise(data):
+    crc = 0xffffffff
+    for b in data:
+        crc ^= b
+        for _ in range(8):
+            crc = (crc >> 1) ^ (0x82f63b78 if crc & 1 else 0)       # reflected Castagnoli polynomial 0x1EDC6F41
+    return crc ^ 0xffffffff
+
+
+def _masked(crc):
+    return (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xffffffff
+
+
+def _vi(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7f
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def test_crc32c_rfc3720_vectors_and_bitwise_twin():
+    import struct
+    vec = [(bytes(range(32)), 0x46dd794e), (bytes(range(31, -1, -1)), 0x113fdb5c),
+           (bytes.fromhex("01c00000" "00000000" "00000000" "00000000" "14000000" "00000400" "00000014" "00000018" "28000000" "00000000" "02000000" "00000000"), 0xd9963a56)]
+    for data, want in vec:                                                   # RFC 3720 B.4: incrementing, decrementing, an iSCSI read PDU
+        assert tfckpt.crc32c(data) == want == _crc32c_bitwise(data)
+    rng = np.random.RandomState(3)
+    for n in (0, 1, 7, 64, 1000):
+        d = rng.randint(0, 256, n).astype(np.uint8).tobytes()
+        assert tfckpt.crc32c(d) == _crc32c_bitwise(d)
+        assert tfckpt.crc32c(d[n // 2:], tfckpt.crc32c(d[:n // 2])) == tfckpt.crc32c(d)      # incremental form
+    assert _masked(0) == 0xa282ead8 and struct.pack("<I", _masked(_crc32c_bitwise(b"a"))) != struct.pack("<I", _crc32c_bitwise(b"a"))
+
+
+def test_hand_built_prefix_compressed_multi_block_table(tmp_path):
+    """A bundle index written byte by byte from the format descriptions: sorted keys with long shared prefixes, restart interval 2
+    (so most keys are stored as deltas), four data blocks, index keys that are short separators (not block keys), an empty
+    metaindex block, a header entry under the empty key, masked CRC32C on every block and on every tensor."""
+    import struct
+    rng = np.random.RandomState(11)
+    tensors = {"LSTM1/forward_layer/cell/bias/.ATTRIBUTES/VARIABLE_VALUE": rng.randn(512).astype("<f4"),
+               "LSTM1/forward_layer/cell/kernel/.ATTRIBUTES/VARIABLE_VALUE": rng.randn(18, 512).astype("<f4"),
+               "LSTM1/forward_layer/cell/recurrent_kernel/.ATTRIBUTES/VARIABLE_VALUE": rng.randn(128, 512).astype("<f4"),
+               "L4/bias/.ATTRIBUTES/VARIABLE_VALUE": rng.randn(128).astype("<f4"),
+               "L4/kernel/.ATTRIBUTES/VARIABLE_VALUE": rng.randn(33, 128).astype("<f4"),
+               "_CHECKPOINTABLE_OBJECT_GRAPH": None,                                       # a DT_STRING entry: must be skipped
+               "save_counter/.ATTRIBUTES/VARIABLE_VALUE": np.array([7], "<i8")}             # DT_INT64: skipped too
+    data, entries = bytearray(), []
+    hdr = b"\x08\x01" + b"\x10\x00" + b"\x1a\x02\x08\x01"                                  # num_shards = 1, LITTLE, version {producer 1}
+    entries.append((b"", hdr))
+    for key in sorted(tensors):
+        a = tensors[key]
+        if a is None:
+            raw, dtype, shape = b"\x04graf", 7, []
+        else:
+            raw, dtype, shape = a.tobytes(), (1 if a.dtype == np.dtype("<f4") else 9), list(a.shape)
+        shp = b"".join(b"\x12" + _vi(len(d)) + d for d in (b"\x08" + _vi(s) for s in shape))
+        e = b"\x08" + _vi(dtype) + b"\x12" + _vi(len(shp)) + shp + b"\x20" + _vi(len(data)) + b"\x28" + _vi(len(raw)) + \
+            b"\x35" + struct.pack("<I", _masked(_crc32c_bitwise(raw)))
+        entries.append((key.encode(), e))
+        data += raw
+    def block(items, interval):
+        out, restarts, prev = bytearray(), [], b""
+        for i, (k, v) in enumerate(items):
+            shared = 0
+            if i % interval == 0:
+                restarts.append(len(out))
+            else:
+                while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
+                    shared += 1
+            out += _vi(shared) + _vi(len(k) - shared) + _vi(len(v)) + k[shared:] + v
+            prev = k
+        for r in restarts:
+            out += struct.pack("<I", r)
+        return bytes(out + struct.pack("<I", len(restarts)))
+    f, handles = bytearray(), []
+    def emit(b):
+        off = len(f)
+        f.extend(b + b"\x00" + struct.pack("<I", _masked(_crc32c_bitwise(b + b"\x00"))))
+        return off, len(b)
+    groups = [entries[0:2], entries[2:4], entries[4:6], entries[6:]]
+    for gi, g in enumerate(groups):
+        off, size = emit(block(g, 2))
+        last = g[-1][0]
+        nxt = groups[gi + 1][0][0] if gi + 1 < len(groups) else None
+        sep = last + b"\x00" if nxt is None else last[:next(i for i in range(len(last) + 1) if i == len(last) or last[i] != nxt[i]) + 1]
+        if not (last <= sep and (nxt is None or sep < nxt)):
+            sep = last                                                                    # (a separator must sort in [last, next))
+        handles.append((sep, _vi(off) + _vi(size)))
+    mo, ms = emit(block([], 1))
+    io_, is_ = emit(block(handles, 1))
+    foot = _vi(mo) + _vi(ms) + _vi(io_) + _vi(is_)
+    f += foot + b"\x00" * (40 - len(foot)) + struct.pack("<Q", 0xdb4775248b80fb57)
+    prefix = str(tmp_path / "variables")
+    open(prefix + ".index", "wb").write(bytes(f))
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    back = tfckpt.read_bundle(prefix)
+    floats = {k: v for k, v in tensors.items() if v is not None and v.dtype == np.dtype("<f4")}
+    assert set(back) == set(floats)
+    for k, v in floats.items():
+        assert back[k].shape == v.shape and np.array_equal(back[k], v)
+    # a flipped bit in ANY block (data, index) is caught
+    for where in (10, io_ + 2):
+        g = bytearray(f); g[where] ^= 0x10
+        open(prefix + ".index", "wb").write(bytes(g))
+        with pytest.raises(ValueError):
+            tfckpt.read_bundle(prefix)
