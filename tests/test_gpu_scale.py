@@ -102,6 +102,41 @@ def test_full_chr20_properties(eng):
     assert np.isfinite(P).all() and P.min() >= 0
 
 
+@pytest.mark.parametrize("channels", [18, 30])
+def test_fused_tile_kernel_equals_the_column_store_path(eng, channels, monkeypatch):
+    """The plain mode's two implementations — k_fused_tiles (windows straight from LDS, written where they arrive, indexed into
+    position order) and the column store with its selection / compaction / gather kernels (C3R_NO_FUSE=1) — give the same sites,
+    tensors, raw tensors, tokens and probabilities, byte for byte, also when the scans of a batch are appended."""
+    from clair3_rna_amd import capi, synth
+    L = 900000
+    ref, rs, _ = synth.generate_contig(contig_len=L, seed=501 + channels, depth=40.0, expressed_frac=0.06, intron_lo=80.0, intron_hi=6000.0,
+                                       phased=(channels == 30), platform="hifi" if channels == 30 else "ont")
+    ref = ref.decode()
+    w = synth.random_weights(channels, seed=9)
+    chunks = [(1, 300000), (300000, 600000), (600000, L)]
+
+    def run():
+        eng.params = capi.default_params()
+        eng.set_bed(0, None); eng.set_bed(1, None)
+        eng.set_params(channels=channels)
+        eng.load_reads(rs); eng.set_reference(1, ref); eng.load_weights(w, channels); eng.set_precision("f16x3")
+        eng.scan(1, L)
+        one = (eng.tensors().copy(), eng.tensors(rescaled=False).copy(), eng.sites().tobytes(), eng.tokens().tobytes(), eng.infer().copy())
+        eng.begin_batch()
+        for a, b in chunks:
+            eng.scan(a, b)
+        eng.end_batch()
+        many = (eng.tensors().copy(), eng.sites().tobytes(), eng.tokens().tobytes(), eng.infer().copy())
+        return one, many
+    fused = run()
+    monkeypatch.setenv("C3R_NO_FUSE", "1")
+    store = run()
+    monkeypatch.delenv("C3R_NO_FUSE")
+    assert len(fused[0][0]) > (50 if channels == 30 else 500) and len(fused[1][0]) >= len(fused[0][0])
+    for x, y in zip(fused[0] + fused[1], store[0] + store[1]):
+        assert np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y
+
+
 def test_one_full_chunk_of_configs1_is_bit_exact_against_the_oracle(eng):
     """BASELINE.json configs[1] at full size, one of its thirteen 5-Mb chunks end to end: every create_tensor line (position, ref33,
     594 ints, ordered alt_info) and every rescaled tensor of the chunk identical to the oracle's, probabilities within 1e-4.  (The
