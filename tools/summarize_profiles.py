@@ -20,16 +20,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.search(r"k_lstm2_mx|k_lstm2_w8|k_lstm1_skew|k_lstm_h|k_lstm|k_[a-z0-9_]+", name)
+    if "rocprim" in name:
+        return "rocprim_radix_sort"
+    m = re.search(r"k_lstm2_mx|k_lstm2_w8|k_lstm1_rs|k_lstm|k_[a-z0-9_]+", name)
     if not m:
         return name[:40]
     k = m.group(0)
-    if k == "k_lstm1_skew":
+    if k == "k_lstm1_rs":
         return "k_lstm1"
     if k in ("k_lstm2_w8", "k_lstm2_mx"):
         return "k_lstm2"
-    if k in ("k_lstm_h", "k_lstm"):
-        return "k_lstm2" if ("ILi256E" in name or "Li160E" in name or re.search(r"k_lstm(_h)?<256,", name)) else "k_lstm1"
+    if k == "k_lstm":
+        return "k_lstm2" if ("ILi256E" in name or "Li160E" in name or re.search(r"k_lstm<256,", name)) else "k_lstm1"
     return k
 
 
@@ -52,7 +54,8 @@ def main():
         text = open(st[0]).read()
         open(os.path.join(out, "%s_kernel_stats_%s.csv" % (tag, prec)), "w").write(
             "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
-            "--no_overlap --precision %s   (MI355X; durations in ns; one context: 1 priming + 1 warm-up + 2 timed passes)\n" % prec + text)
+            "--no_fast --no_resident --no_overlap --precision %s   (MI355X; durations in ns; one context: 1 priming + 1 warm-up + 2 timed passes, "
+            "c3r_load_reads inside every pass)\n" % prec + text)
     # 2. PMC
     rows = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
