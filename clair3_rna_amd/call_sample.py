@@ -378,7 +378,9 @@ def Run(args, log=None):
     fetcher = _Fetcher(bam_fn, args.ref_fn)
     t_setup = time() - t_all
     n_ctx = len(engines)
-    slots = threading.BoundedSemaphore(n_ctx + 2)                      # contigs fetched but not yet through their context
+    # contigs fetched (or being fetched) but not yet through their context: every context busy + every fetch thread running ahead.
+    # (n_ctx + 2 starved the contexts: a fetch takes ~100 ms, a context needs a new contig every ~35 ms)
+    slots = threading.BoundedSemaphore(n_ctx + max(2, args.fetch_threads))
     stats = dict(fetch=0.0, dev=0.0, sites=0)
     lock = threading.Lock()
 
@@ -444,7 +446,7 @@ def Run(args, log=None):
         stop.set()
         for p_ in ctx_pools:
             p_.shutdown(wait=True, cancel_futures=True)
-        for _ in range(len(contigs) + n_ctx + 2):
+        for _ in range(len(contigs) + n_ctx + args.fetch_threads + 2):
             try:
                 slots.release()
             except ValueError:           # (bounded semaphore: every slot is free again)

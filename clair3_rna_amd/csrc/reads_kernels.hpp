@@ -49,8 +49,18 @@ __device__ __forceinline__ int walk_norm(const uint32_t *cig, uint32_t n, Emit &
     bool have = false;
     uint32_t cop = 0;
     unsigned long long clen = 0;
+    // ops are fetched eight at a time: the loads of a batch are independent of each other, so a read's walk pays one memory round trip
+    // per eight ops instead of one per op (the kernels end when the longest read — several hundred ops — is done)
+    constexpr uint32_t NB = 8;
+    uint32_t buf[NB];
     for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t c = cig[k];
+        if ((k & (NB - 1)) == 0) {
+#pragma unroll
+            for (uint32_t j = 0; j < NB; ++j) buf[j] = (k + j < n) ? cig[k + j] : 0u;
+        }
+        uint32_t c = buf[0];
+#pragma unroll
+        for (uint32_t j = 1; j < NB; ++j) c = ((k & (NB - 1)) == j) ? buf[j] : c;
         uint32_t op = c & 15u, len = c >> 4;
         if (op == C3R_CIG_EQ || op == C3R_CIG_X) op = C3R_CIG_M;
         if (len == 0 || op == C3R_CIG_H) continue;
