@@ -73,7 +73,9 @@ struct c3r_ctx {
     int32_t *h_scan = nullptr;             // pinned: what a fused scan reads back (totals, overflow flags)
     bool last_fused = false;
     std::vector<int64_t> last_starts, last_ends;
-    std::string h_ref; int64_t ref_start1 = 1;
+    char *h_ref = nullptr; size_t h_ref_cap = 0, ref_len = 0;     // page-locked: upper-cased reference slice (upload source, decoder's view)
+    hipEvent_t ev_ref = nullptr;                                  // the upload of h_ref has been read
+    int64_t ref_start1 = 1;
     DevBuf d_ref;
     std::vector<int32_t> h_bed[2];
     DevBuf d_bed[2];
@@ -361,6 +363,8 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
+    if (ctx->h_ref) (void)hipHostFree(ctx->h_ref);
+    if (ctx->ev_ref) (void)hipEventDestroy(ctx->ev_ref);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -516,26 +520,41 @@ int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t 
     if (!ctx || !ref || len < 0 || ref_start < 1) return C3R_EINVAL;
     ctx->last_scan_pruned = false;       // (c3r_get_columns completes a pruned scan with the arguments of that scan: stale now)
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    ctx->h_ref.resize((size_t)len);
+    // The slice is upper-cased straight into a page-locked buffer the context keeps (one pass over the caller's bytes, on threads for a
+    // whole chromosome), which is both the source of an asynchronous DMA upload — nothing here waits for the device — and the decoder's
+    // view of the reference.  The previous upload must have left the buffer before it is overwritten.
+    if (!ctx->ev_ref) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_ref, hipEventDisableTiming));
+    else HIPCHK(ctx, hipEventSynchronize(ctx->ev_ref));
+    ctx->ref_len = 0;
+    if ((size_t)len + 16 > ctx->h_ref_cap) {
+        if (ctx->h_ref) (void)hipHostFree(ctx->h_ref);
+        ctx->h_ref = nullptr; ctx->h_ref_cap = 0;
+        const size_t cap = (size_t)len + (size_t)len / 8 + 4096;
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_ref, cap, hipHostMallocDefault));
+        ctx->h_ref_cap = cap;
+    }
     {
-        char *dst = len ? &ctx->h_ref[0] : nullptr;
+        char *dst = ctx->h_ref;
         auto upper = [&](int64_t a, int64_t e) {
             for (int64_t i = a; i < e; ++i) {        // branch-free, so the loop vectorises
                 const unsigned char c = (unsigned char)ref[i];
                 dst[i] = (char)(c - (((unsigned)(c - 'a') < 26u) << 5));
             }
         };
-        // a 250 MB chromosome is memory-bound work for one core: split it (first-touch of the fresh pages included)
-        const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({8, (int64_t)std::thread::hardware_concurrency(), len >> 23}));
+        // a 250 MB chromosome is memory-bound work for one core: split it
+        int64_t nt = std::max<int64_t>(1, std::min<int64_t>({8, (int64_t)std::thread::hardware_concurrency(), len >> 23}));
+        if (const char *e = getenv("C3R_THREADS")) nt = std::max<int64_t>(1, std::min<int64_t>(nt, atoi(e)));
         std::vector<std::thread> th;
         for (int64_t t = 1; t < nt; ++t) th.emplace_back(upper, len * t / nt, len * (t + 1) / nt);
         upper(0, len / nt);
         for (auto &x : th) x.join();
     }
     ctx->ref_start1 = ref_start;
-    int rc = upload(ctx, ctx->d_ref, (const uint8_t *)ctx->h_ref.data(), ctx->h_ref.size());
+    int rc = ensure(ctx, ctx->d_ref, std::max<size_t>((size_t)len, 16));
     if (rc) return rc;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (len) HIPCHK(ctx, hipMemcpyAsync(ctx->d_ref.p, ctx->h_ref, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_ref, ctx->stream));
+    ctx->ref_len = (size_t)len;
     return C3R_OK;
 }
 
@@ -572,7 +591,7 @@ static int run_gather(c3r_ctx *ctx, int rescale, int32_t *dst, bool with_sites) 
     g.cols = (const int32_t *)ctx->d_cols.p; g.depth = (const int32_t *)ctx->d_depth.p; g.ncov = (const int32_t *)ctx->d_ncov.p;
     g.flags = (const uint8_t *)ctx->d_flags.p; g.tile_cols = (const uint8_t *)ctx->d_tile_cols.p; g.cand_idx = (const int32_t *)ctx->d_cand.p; g.n_cand = (int32_t)ctx->last_cand;
     g.n_pos = (int32_t)ctx->n_pos; g.geo = (const TileGeo *)ctx->d_geo.p;
-    g.ref = (const uint8_t *)ctx->d_ref.p; g.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); g.ref_len = (int32_t)ctx->h_ref.size();
+    g.ref = (const uint8_t *)ctx->d_ref.p; g.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); g.ref_len = (int32_t)ctx->ref_len;
     g.head_tail = ctx->prm.head_tail; g.last_row = (const int32_t *)ctx->d_lastrow.p;
     g.rescale = rescale; g.max_depth = ctx->prm.max_depth_rescale;
     g.tensors = dst;
@@ -682,7 +701,7 @@ static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int d
     a.ops = (const OpRec *)ctx->d_ops.p; a.seg_op_off = (const int32_t *)ctx->d_seg_op_off.p;
     a.bkt = ctx->n_bkt > 0 && !getenv("C3R_NO_BUCKETS") ? (const int32_t *)ctx->d_bkt.p : nullptr; a.n_bkt = ctx->n_bkt;
     a.n_tiles = n_tiles;
-    a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->h_ref.size();
+    a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->ref_len;
     a.geo = (const TileGeo *)ctx->d_geo.p;
     a.lbed = (const int32_t *)ctx->d_bed[0].p; a.n_lbed = (int32_t)(ctx->h_bed[0].size() / 2); a.has_lbed = ctx->has_bed[0];
     a.cbed = (const int32_t *)ctx->d_bed[1].p; a.n_cbed = (int32_t)(ctx->h_bed[1].size() / 2); a.has_cbed = ctx->has_bed[1];
@@ -702,7 +721,7 @@ int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n
 
 int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int64_t *n_candidates) {
     if (!ctx || n_regions < 1 || !ctg_starts || !ctg_ends) return C3R_EINVAL;
-    if (ctx->h_ref.empty()) return fail(ctx, C3R_EINVAL, "c3r_set_reference must be called before c3r_pileup_scan");
+    if (ctx->ref_len == 0) return fail(ctx, C3R_EINVAL, "c3r_set_reference must be called before c3r_pileup_scan");
     for (int r = 0; r < n_regions; ++r) {
         if (ctg_ends[r] < ctg_starts[r]) return C3R_EINVAL;
         if (ctg_ends[r] + C3R_WINDOW > INT32_MAX - 1) return fail(ctx, C3R_EINVAL, "region beyond 2^31");
@@ -1378,6 +1397,7 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
     { int rc_ = ensure_host_reads(ctx); if (!rc_) rc_ = ensure_host_seq(ctx); if (rc_) return rc_; }
     const uint8_t *seq = ctx->h_seq.data();
     const std::vector<DevRead> &reads = ctx->h_reads;
+    const RefView refv{ctx->h_ref, ctx->ref_len};
     auto get_read = [&](uint32_t r) { return ReadView{seq, reads[r].seq_off, reads[r].l_seq}; };
     // host threads: C3R_THREADS, else up to 32 (one process per GPU shares the node's cores with its peers)
     unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
@@ -1390,7 +1410,7 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
         AltDict alt;
         for (int64_t i = a; i < b; ++i) {
             int depth_tok;
-            alt_from_tokens(toks + sites[(size_t)i].tok_off, sites[(size_t)i].n_tok, get_read, ctx->h_ref, ctx->ref_start1, sites[(size_t)i].pos,
+            alt_from_tokens(toks + sites[(size_t)i].tok_off, sites[(size_t)i].n_tok, get_read, refv, ctx->ref_start1, sites[(size_t)i].pos,
                             alt, depth_tok);
             if (vcf_row(ctg, sites[(size_t)i].pos, sites[(size_t)i].ref33, sites[(size_t)i].depth, alt, probs + (size_t)i * C3R_NPROB, qual,
                         show_ref != 0, part[t]))

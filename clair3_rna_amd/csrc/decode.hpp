@@ -66,8 +66,15 @@ static const char NT16_STR[] = "=ACMGRSVTWYHKDBN";
 
 // tokens of one site (BAM order) -> ordered alt dict (src/create_tensor_pileup.py:179,221-261)
 struct ReadView { const uint8_t *seq; uint64_t seq_off; uint32_t l_seq; };
+// the upper-cased reference slice as the library holds it (a page-locked buffer: the upload's source and the decoder's view)
+struct RefView {
+    const char *p; size_t n;
+    size_t size() const { return n; }
+    char operator[](size_t i) const { return p[i]; }
+    std::string substr(size_t a, size_t len) const { return std::string(p + a, len); }
+};
 template <typename GetRead>
-inline void alt_from_tokens(const c3r_token_t *tk, int n, GetRead get_read, const std::string &ref, int64_t ref_start1, int64_t pos1,
+inline void alt_from_tokens(const c3r_token_t *tk, int n, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
                             AltDict &alt, int &depth_out) {
     alt.clear();
     const int64_t ri = pos1 - ref_start1;
