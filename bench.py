@@ -502,7 +502,13 @@ def main():
         traffic_fn = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
         if roofline and os.path.exists(traffic_fn):
             try:
-                roofline["traffic"] = json.load(open(traffic_fn)).get(args.precision, {}).get(dom)
+                per_kernel = json.load(open(traffic_fn)).get(args.precision, {})
+                roofline["traffic"] = per_kernel.get(dom)
+                # counter bytes of one pass through every tensor-build kernel (launches per pass: one each, the three-launch scans and the
+                # library sort a handful — their per-launch averages are small): raw FETCH_SIZE + WRITE_SIZE, see profiles/*_pmc_*.csv
+                tb = {k: v for k, v in per_kernel.items() if k.startswith("k_") and not k.startswith(("k_lstm", "k_heads", "k_fc4"))}
+                roofline_tb["traffic"] = int(sum(tb.values()))
+                roofline_tb["traffic_note"] = "sum of per-launch HBM counter bytes of the tensor-build kernels (profiles/pmc_traffic.json); algorithmic bytes are bytes_per_pass"
             except Exception:
                 pass
 

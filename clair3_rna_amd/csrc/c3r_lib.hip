@@ -989,6 +989,11 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     scan_inputs(ctx, a, d_drop, drop_words, n_tiles);
     a.tile_rng = (int4 *)ctx->d_tile_rng.p; a.tile_list = (int32_t *)ctx->d_tile_list.p; a.n_tile_list = (int32_t *)(lb + 20);
     a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)(lb + 24); a.ev_cap = (unsigned long long)ev_cap; a.ev_overflow = (int32_t *)(lb + 32);
+    if (getenv("C3R_SCAN_DBG")) {          // phase clocks of tile_columns (timing aid, off in production)
+        if ((rc = ensure(ctx, ctx->d_dbg, 16 * 8))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg.p, 0, 16 * 8, ctx->stream));
+        a.dbg = (unsigned long long *)ctx->d_dbg.p;
+    }
     f.reg_bounds = (const int2 *)ctx->d_regb.p;
     f.ticket = (int32_t *)(lb + 4); f.arrived = (int32_t *)(lb + 36); f.overflow = (int32_t *)(lb + 16);
     f.rescale = raw_rerun ? 0 : 1; f.max_depth = ctx->prm.max_depth_rescale;
@@ -1063,6 +1068,13 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         n_cand = ctx->h_scan[0]; n_tok = ctx->h_scan[1];
+        if (a.dbg) {
+            unsigned long long d[16];
+            HIPCHK(ctx, hipMemcpy(d, ctx->d_dbg.p, sizeof d, hipMemcpyDeviceToHost));
+            const double nt = d[15] ? (double)d[15] : 1.0;
+            fprintf(stderr, "[k_fused_tiles] %llu spans; per span: segments in range %.1f, listed %.1f, ops %.1f; us per span: zero %.2f | cover+list+walk %.2f | scans %.2f | events %.2f | gates %.2f | first-seen %.2f | select+order+store %.2f\n",
+                    d[15], d[13] / nt, d[12] / nt, d[14] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[6] / nt / 100, d[7] / nt / 100);
+        }
         if (ctx->h_scan[6]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
         if (n_cand < 0 || n_tok < 0) return fail(ctx, C3R_EOVERFLOW, "too many candidates or tokens for one scan");
         if (raw_rerun) {

@@ -7,12 +7,15 @@
 //   sliding-window / candidate driver ......... src/create_tensor_pileup.py:463-637
 //   depth>216 rescale ......................... clair3_rna/utils.py:88-92,120
 //
-// Design: the region is cut into tiles of TILE reference positions.  One
-// 256-thread workgroup owns one tile: its per-position accumulators [TILE][C] int32 live in LDS, every
-// read overlapping the tile is walked by one 64-lane wavefront (lane = CIGAR op, prefix sums by DPP
-// shuffles, read records and CIGARs loaded coalesced), base/deletion/indel events are LDS atomics, and
-// the finished tile is written to HBM once, coalesced.  Windows are then a pure gather of 33
-// consecutive columns (one wavefront per candidate).
+// Design.  A workgroup of 256 threads owns a run of at most TILE reference positions, one per thread: per-position
+// accumulators [TILE][C] int32 live in LDS, the aligned segments that touch the run are walked through the expanded op table (one lane
+// per CIGAR op, reads_kernels.hpp builds the tables on the device), base / deletion / indel events are LDS atomics, the gates run
+// per position (tile_columns).  Two drivers sit on top of it:
+//   k_fused_tiles (plain mode): the run = a span of 224 positions + 16 on either side, so every candidate's 33-column window is in
+//     LDS; windows are written from there, in arrival order, and k_order_spans / k_finalize_sites put the small records in position
+//     order (win_idx maps sites to window rows);
+//   k_scan_tiles (head/tail calling, splice padding, genotyping, c3r_get_columns): the finished tile is written to HBM once,
+//     coalesced, and selection, ordered compaction and the window gather (one wavefront per candidate) are separate kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,7 +28,7 @@ constexpr int TILE = 256;      // reference positions per workgroup
 constexpr int SCAN_THREADS = 256;
 constexpr int WAVES = SCAN_THREADS / 64;
 
-// Host-prepared read header (normalised CIGAR: no P/H/zero-length ops, =/X folded into M, adjacent
+// Read header as k_reads_write leaves it (normalised CIGAR: no P/H/zero-length ops, =/X folded into M, adjacent
 // equal ops merged; `end` = pos + reference length).
 struct DevRead {
     int32_t pos;       // 0-based
@@ -40,7 +43,7 @@ struct DevRead {
 };
 static_assert(sizeof(DevRead) == 32, "DevRead must be 32 bytes");
 
-// One aligned segment of a read = the CIGAR ops between two N (ref-skip) ops, prepared on the host at load time and
+// One aligned segment of a read = the CIGAR ops between two N (ref-skip) ops, prepared on the device at load time (reads_kernels.hpp) and
 // sorted by ext_start.  Tiles walk SEGMENTS, so a read spanning a 100-kb intron costs nothing in the intron's tiles;
 // only coverage (which positions have a pileup row) still comes from the whole-read spans, header-only.
 struct DevSeg {
@@ -1785,6 +1788,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
         const int x0 = tg.p0 - C3R_FLANK, x1 = min(tg.p1 + C3R_FLANK, rb.y);       // thread tid <-> position x0 + tid
         const int4 rng = a.tile_rng[tile];
         const TileOut o = tile_columns<C>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1);
+        const unsigned long long t_tail = a.dbg ? wall_clock64() : 0ull;
         if (C == C3R_CH_PHASED) {
             // a column whose haplotype channels depend on the ORDER of the reads (see k_phase_recompute): redone in place, one thread
             // per flagged column
@@ -1847,6 +1851,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
         }
         const int gt = head + 4 * n4 + tid;
         if (gt < total) out[gt] = fetch(gt);
+        if (a.dbg && tid == 0) atomicAdd(&a.dbg[7], wall_clock64() - t_tail);
     }
 }
 
