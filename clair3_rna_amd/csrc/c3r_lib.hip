@@ -129,6 +129,27 @@ int fail(c3r_ctx *ctx, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, C3R_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// The layer-2 kernels meet their wavefronts through LDS counters with bounded waits (net_kernels.hpp, lds_wait): a wait that ever gives
+// up raises g_lstm_timeout instead of hanging the GPU.  Whoever hands probabilities to the host reads the word first — queued behind the
+// network on the same stream, so it costs no extra synchronisation — and fails the call rather than pass on numbers computed from a
+// half-written h_t.
+int queue_lstm_status(c3r_ctx *ctx, int32_t **slot) {
+    static thread_local int32_t *pinned = nullptr;
+    if (!pinned) HIPCHK(ctx, hipHostMalloc((void **)&pinned, 64, hipHostMallocDefault));
+    *pinned = 0;
+    HIPCHK(ctx, hipMemcpyFromSymbolAsync(pinned, HIP_SYMBOL(g_lstm_timeout), 4, 0, hipMemcpyDeviceToHost, ctx->stream));
+    *slot = pinned;
+    return C3R_OK;
+}
+int check_lstm_status(c3r_ctx *ctx, const int32_t *slot) {
+    if (slot && *slot) {
+        const int32_t zero = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_timeout), &zero, 4);
+        return fail(ctx, C3R_EHIP, "internal: a layer-2 wavefront rendezvous timed out — the probabilities of this batch are not valid");
+    }
+    return C3R_OK;
+}
+
 // Debug aid (tests/test_gpu_poison.py): C3R_POISON=<byte> fills every fresh device allocation with that byte, so that a
 // kernel reading memory nobody wrote shows up as a parity failure instead of depending on what the allocator handed out.
 inline int poison_byte() {
@@ -874,7 +895,7 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
         fprintf(stderr, "[k_scan_tiles] %llu heavy tiles; per tile: segments in range %.1f, listed %.1f, ops %.1f; us per tile: zero %.2f | cover+list+walk %.2f | scans %.2f | events %.2f | gates %.2f | store %.2f | first-seen %.2f\n",
                 d[15], d[13] / nt, d[12] / nt, d[14] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[5] / nt / 100, d[6] / nt / 100);
     }
-    if (flag_cand[0]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
+    if (flag_cand[0]) { ctx->last_scan_pruned = false; return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap); }
     const int32_t n_cand = flag_cand[1];
     ctx->last_cand = n_cand;
     if (n_candidates) *n_candidates = n_cand;
@@ -1201,6 +1222,7 @@ int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t
         if (ctx->prm.channels == C3R_CH) hipLaunchKernelGGL(k_scan_tiles<C3R_CH>, dim3(std::min((int)a.n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, a);
         else hipLaunchKernelGGL(k_scan_tiles<C3R_CH_PHASED>, dim3(std::min((int)a.n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, a);
         ctx->last_scan_pruned = false;
+        HIPCHK(ctx, hipGetLastError());
     }
     const size_t n = (size_t)npos0;
     if (cols) HIPCHK(ctx, hipMemcpyAsync(cols, ctx->d_cols.p, n * ctx->prm.channels * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1341,8 +1363,11 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
     int rc = net_forward(ctx->net, d_x, d_rows, n, ctx->stream, prof, e);
     if (rc) return fail(ctx, rc, "%s", e.c_str());
     if (probs) {
+        int32_t *st = nullptr;
+        if ((rc = queue_lstm_status(ctx, &st))) return rc;
         HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, (size_t)n * C3R_NPROB * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = check_lstm_status(ctx, st))) return rc;
     }
     HIPCHK(ctx, hipGetLastError());
     return C3R_OK;
@@ -1353,9 +1378,12 @@ int c3r_get_probs(c3r_ctx *ctx, float *probs, int64_t n) {
     if (n == 0) return C3R_OK;
     if (!ctx->net.d_probs || n > ctx->net.cap_probs) return fail(ctx, C3R_EINVAL, "no probabilities resident for %lld sites", (long long)n);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t *st = nullptr;
+    int rc = queue_lstm_status(ctx, &st);
+    if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, (size_t)n * C3R_NPROB * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return C3R_OK;
+    return check_lstm_status(ctx, st);
 }
 
 // ------------------------------------------------------------------------------------------------ A8 on the host
@@ -1403,8 +1431,11 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
     const auto t1 = now();
     HIPCHK(ctx, hipMemcpyAsync(sites, ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t), hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->n_tok) HIPCHK(ctx, hipMemcpyAsync(toks, ctx->d_tok.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream));
+    int32_t *lstm_st = nullptr;
+    { int rc_ = queue_lstm_status(ctx, &lstm_st); if (rc_) return rc_; }
     HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, b_probs, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc_ = check_lstm_status(ctx, lstm_st); if (rc_) return rc_; }
     const auto t2 = now();
     { int rc_ = ensure_host_reads(ctx); if (!rc_) rc_ = ensure_host_seq(ctx); if (rc_) return rc_; }
     const uint8_t *seq = ctx->h_seq.data();
