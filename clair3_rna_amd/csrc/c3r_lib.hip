@@ -67,7 +67,7 @@ struct c3r_ctx {
     ScanArgs last_scan;                    // arguments of the most recent scan (c3r_get_columns completes the pruned tiles with them)
     bool last_scan_pruned = false;
     // the fused path (k_fused_tiles): look-back words and counters, region bounds, what the last scan covered
-    DevBuf d_lb, d_regb, d_span, d_spanbase, d_meta;
+    DevBuf d_lb, d_regb, d_span, d_spanbase, d_meta, d_spanrec;
     DevBuf d_winidx;                       // [resident candidates] row of the i-th site's window in d_tensors (the fused path writes windows as they arrive)
     DevBuf d_rawidx, d_export;             // c3r_get_tensors: index of a raw re-run, windows gathered into position order
     int32_t *h_scan = nullptr;             // pinned: what a fused scan reads back (totals, overflow flags)
@@ -376,7 +376,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_rcnt, &ctx->d_rend, &ctx->d_pass, &ctx->d_ekey, &ctx->d_ekey2, &ctx->d_skey, &ctx->d_skey2, &ctx->d_sval, &ctx->d_sval2,
-                      &ctx->d_sorttmp, &ctx->d_s4tops, &ctx->d_pmtops, &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+                      &ctx->d_sorttmp, &ctx->d_s4tops, &ctx->d_pmtops, &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -993,11 +993,14 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     const int nblk = (n_tiles + 255) / 256;
     // d_lb: [0] ticket of k_tile_ranges_fused, [4] ticket of k_fused_tiles, [8] candidates, [12] tokens (k_order_spans), [16] overflow
     // bits, [20] listed spans, [24..31] event-scratch cursor, [32] event-scratch overflow, [36] rows handed out, [40] ticket of
-    // k_order_spans; [64..] look-back words: one per block of 256 spans for k_tile_ranges_fused, then the same for k_order_spans
-    const size_t lb_bytes = 64 + (size_t)nblk * 16;
+    // k_order_spans, [64..] the TICKET_Q ticket words of k_fused_tiles, 256 bytes apart; then look-back words: one per block of 256 spans for
+    // k_tile_ranges_fused, then the same for k_order_spans
+    const size_t lb_head = 64 + (size_t)TICKET_Q * TICKET_STRIDE * 4;
+    const size_t lb_bytes = lb_head + (size_t)nblk * 16;
     if ((rc = ensure(ctx, ctx->d_ev, ev_cap * sizeof(EvRec))) || (rc = ensure(ctx, ctx->d_lb, lb_bytes)) || (rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16)) ||
         (rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16)) || (rc = ensure(ctx, ctx->d_tile_cand, (size_t)n_tiles * 8 + 16)) ||
-        (rc = ensure(ctx, ctx->d_span, (size_t)n_tiles * sizeof(int4) + 16)) || (rc = ensure(ctx, ctx->d_spanbase, (size_t)n_tiles * sizeof(int2) + 16)))
+        (rc = ensure(ctx, ctx->d_span, (size_t)n_tiles * sizeof(int4) + 16)) || (rc = ensure(ctx, ctx->d_spanbase, (size_t)n_tiles * sizeof(int2) + 16)) ||
+        (rc = ensure(ctx, ctx->d_spanrec, (size_t)n_tiles * sizeof(SpanRec) + 16)))
         return rc;
     if (!ctx->h_scan) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_scan, 64, hipHostMallocDefault));
     const uint32_t *d_drop = nullptr;
@@ -1015,8 +1018,8 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg.p, 0, 16 * 8, ctx->stream));
         a.dbg = (unsigned long long *)ctx->d_dbg.p;
     }
-    f.reg_bounds = (const int2 *)ctx->d_regb.p;
-    f.ticket = (int32_t *)(lb + 4); f.arrived = (int32_t *)(lb + 36); f.overflow = (int32_t *)(lb + 16);
+    f.span_rec = (const SpanRec *)ctx->d_spanrec.p;
+    f.ticket = (int32_t *)(lb + 64); f.arrived = (int32_t *)(lb + 36); f.overflow = (int32_t *)(lb + 16);
     f.rescale = raw_rerun ? 0 : 1; f.max_depth = ctx->prm.max_depth_rescale;
     f.span_info = (int4 *)ctx->d_span.p;
     f.ph.reads = a.reads; f.ph.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.ph.rseg_first = (const uint32_t *)ctx->d_rseg_first.p; f.ph.cigar = a.cigar; f.ph.seq = a.seq;
@@ -1061,7 +1064,8 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         HIPCHK(ctx, hipMemsetAsync(ctx->d_lb.p, 0, lb_bytes, ctx->stream));
         {
             Launch L(ctx, "k_tile_ranges");
-            hipLaunchKernelGGL(k_tile_ranges_fused, dim3(nblk), dim3(256), 0, ctx->stream, a, (int32_t *)lb, (unsigned long long *)(lb + 64), nblk);
+            hipLaunchKernelGGL(k_tile_ranges_fused, dim3(nblk), dim3(256), 0, ctx->stream, a, (int32_t *)lb, (unsigned long long *)(lb + lb_head), nblk, (const int2 *)ctx->d_regb.p,
+                               (SpanRec *)ctx->d_spanrec.p);
         }
         {
             Launch L(ctx, "k_fused_tiles");
@@ -1072,7 +1076,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         {
             Launch L(ctx, "k_order_sites");
             hipLaunchKernelGGL(k_order_spans, dim3(nblk), dim3(256), 0, ctx->stream, (const int4 *)ctx->d_span.p, (const int32_t *)(lb + 20), (int32_t *)(lb + 40),
-                               (unsigned long long *)(lb + 64 + (size_t)nblk * 8), (int2 *)ctx->d_spanbase.p, (int2 *)ctx->d_tile_cand.p, (int32_t *)(lb + 8));
+                               (unsigned long long *)(lb + lb_head + (size_t)nblk * 8), (int2 *)ctx->d_spanbase.p, (int2 *)ctx->d_tile_cand.p, (int32_t *)(lb + 8));
             hipLaunchKernelGGL(k_finalize_sites, dim3((unsigned)std::min<int64_t>((want_c + 3) / 4 + 1, 8192)), dim3(256), 0, ctx->stream, z);
         }
         if (!raw_rerun) {

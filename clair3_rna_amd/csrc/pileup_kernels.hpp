@@ -647,7 +647,14 @@ __device__ __forceinline__ unsigned long long lb_lookback(unsigned long long *st
 // The fused path's list of spans (k_fused_tiles): only spans that hold aligned bases, in ASCENDING order (= output order), with the
 // read / segment ranges of the span plus C3R_FLANK on either side.  Workgroups take blocks of 256 spans by ticket and place their
 // listed spans behind those of the blocks before them (decoupled look-back over one word per block, as in k_fused_tiles).
-__global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int32_t *ticket, unsigned long long *rstate, int nblk) {
+// Everything a workgroup of k_fused_tiles needs to know about its span, in one 48-byte record indexed by LIST position: the tile
+// kernel's per-span start-up was a chain of dependent loads (ticket -> tile_list -> geo -> region bounds, tile ranges) = several
+// microseconds before the first useful instruction, 16 us of fixed latency per span in all (ablation: 0.26 of the kernel's 0.58 ms).
+struct SpanRec { int32_t tile, p0, p1, region; int4 rng; int32_t reg_lo, reg_hi, pad0, pad1; };
+static_assert(sizeof(SpanRec) == 48, "SpanRec must be 48 bytes");
+
+__global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int32_t *ticket, unsigned long long *rstate, int nblk, const int2 *reg_bounds,
+                                                           SpanRec *span_rec) {
     __shared__ int s_b, s_base, s_cnt[4];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_b = atomicAdd(ticket, 1);
@@ -655,6 +662,8 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
     const int b = s_b;
     const int t = b * 256 + tid;
     bool listed = false;
+    SpanRec rec;
+    rec.tile = 0;
     if (t < a.n_tiles) {
         const TileGeo tg = a.geo[t];
         const int t0 = tg.p0, t1 = tg.p1;
@@ -676,6 +685,9 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
                 bucket_bounds(T2, a.n_bkt, a.n_segs, e1, lo, hi); r.w = lb_seg(lo, hi, e1);
                 a.tile_rng[t] = r;
                 listed = r.x < r.y;
+                rec.tile = t; rec.p0 = t0; rec.p1 = t1; rec.region = tg.region; rec.rng = r;
+                const int2 rb = reg_bounds[tg.region];
+                rec.reg_lo = rb.x; rec.reg_hi = rb.y; rec.pad0 = 0; rec.pad1 = 0;
             }
         }
     }
@@ -693,7 +705,12 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
     __syncthreads();
     int at = s_base;
     for (int w = 0; w < wave; ++w) at += s_cnt[w];
-    if (listed) a.tile_list[at + __popcll(m & ((1ull << lane) - 1ull))] = t;
+    if (listed) {
+        const int at2 = at + __popcll(m & ((1ull << lane) - 1ull));
+        a.tile_list[at2] = t;
+        int4 *dst = reinterpret_cast<int4 *>(span_rec + at2);
+        dst[0] = make_int4(rec.tile, rec.p0, rec.p1, rec.region); dst[1] = rec.rng; dst[2] = make_int4(rec.reg_lo, rec.reg_hi, 0, 0);
+    }
 }
 
 // The tile kernels run over the compact tile list with a FIXED grid (LIST_GRID workgroups, each taking every LIST_GRID-th list
@@ -1753,12 +1770,13 @@ __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
 // round trip for sizes: outputs are bounds-checked against the buffers' capacity, and the host learns the totals (and whether
 // anything did not fit: then it grows the buffers and repeats the scan) from the single read-back at the end of the scan.
 constexpr int FUSE_IN = TILE - 2 * C3R_FLANK;     // 224
+constexpr int TICKET_Q = 16, TICKET_STRIDE = 64;     // ticket words 256 bytes apart: atomics on one cache line serialise like atomics on one word
 struct CandMeta { int32_t slot, depth, ncov, tpre, span; };      // per arrived candidate: slot (tile * TILE + offset), depth, covering reads,
                                                                  // tokens of the span's earlier candidates, list index of its span
 struct FusedArgs {
     ScanArgs a;                   // tile_list: spans with aligned bases, ascending; tile_rng: reads / segments of the span + flanks
-    const int2 *reg_bounds;       // [n_regions] {first position, end} (0-based): rows exist only inside their region
-    int32_t *ticket;              // next list entry to take
+    int32_t *ticket;              // [TICKET_Q * TICKET_STRIDE] tickets handed out per queue
+    const SpanRec *span_rec;      // [listed spans] where the span lies, its region's bounds (rows exist only inside their region), its read / segment ranges
     int32_t *arrived;             // rows handed out so far (= candidates, once the kernel is done)
     int32_t *overflow;            // bit 0: a span's candidates did not fit below cand_cap (nothing was written past it)
     int32_t cand_cap;
@@ -1776,17 +1794,35 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
     const ScanArgs &a = f.a;
     const int tid = (int)threadIdx.x;
     const int n = *a.n_tile_list;
-    for (;;) {
-        __syncthreads();                                  // (the previous span's LDS is free)
-        if (tid == 0) s_ticket = atomicAdd(f.ticket, 1);
-        __syncthreads();
-        const int b = s_ticket;
-        if (b >= n) break;
-        const int tile = a.tile_list[b];
-        const TileGeo tg = a.geo[tile];
-        const int2 rb = f.reg_bounds[tg.region];
+    // Spans are taken by ticket — dealing them out by stride is 15 % slower: heavy spans differ 10x and a static deal leaves the last
+    // workgroups alone with theirs.  ONE ticket word saturates at ~88 dequeues per microsecond (MI355X_MICROARCH.md, "dequeue"): 20 k
+    // spans = 0.23 ms of atomic throughput, 0.14 ms of it visible in the kernel's time.  So the list is dealt into TICKET_Q interleaved
+    // queues (queue q = list positions q, q + TICKET_Q, ...), a workgroup draws from its home queue and moves on to the next one when
+    // that is empty; the NEXT ticket is drawn before the current span is worked on, so its round trip is hidden; the span's record is
+    // one wave-uniform 48-byte load.
+    auto queue_len = [&](int q) { return n > q ? (n - q + TICKET_Q - 1) / TICKET_Q : 0; };
+    int home = (int)(blockIdx.x % TICKET_Q);
+    auto take = [&]() -> int {                            // (thread 0) next list position, or n when every queue is empty
+        for (int tries = 0; tries < TICKET_Q; ++tries) {
+            const int len = queue_len(home);
+            if (len > 0) { const int t = atomicAdd(&f.ticket[home * TICKET_STRIDE], 1); if (t < len) return home + t * TICKET_Q; }
+            home = (home + 1) % TICKET_Q;
+        }
+        return n;
+    };
+    if (tid == 0) s_ticket = take();
+    __syncthreads();
+    int b = s_ticket;
+    while (b < n) {
+        int t_next = 0;
+        const int q_next = home;
+        if (tid == 0) t_next = atomicAdd(&f.ticket[q_next * TICKET_STRIDE], 1);
+        const int4 *recp = reinterpret_cast<const int4 *>(f.span_rec + b);
+        const int4 r0 = recp[0], rng = recp[1], r2 = recp[2];
+        const int tile = r0.x;
+        TileGeo tg; tg.p0 = r0.y; tg.p1 = r0.z; tg.region = r0.w; tg.pad = 0;
+        const int2 rb = make_int2(r2.x, r2.y);
         const int x0 = tg.p0 - C3R_FLANK, x1 = min(tg.p1 + C3R_FLANK, rb.y);       // thread tid <-> position x0 + tid
-        const int4 rng = a.tile_rng[tile];
         const TileOut o = tile_columns<C>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1);
         const unsigned long long t_tail = a.dbg ? wall_clock64() : 0ull;
         if (C == C3R_CH_PHASED) {
@@ -1818,9 +1854,10 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
             f.span_info[b] = make_int4(s_row0, nc, nt, tile);
         }
         __syncthreads();
-        if (nc == 0) continue;
         const int row0 = s_row0;
-        if (row0 + nc > f.cand_cap) { if (tid == 0) atomicOr(f.overflow, 1); continue; }
+        const bool fits = row0 + nc <= f.cand_cap;
+        if (nc > 0 && !fits && tid == 0) atomicOr(f.overflow, 1);
+        if (nc > 0 && fits) {
         if (emit) {
             CandMeta m;
             m.slot = tile * TILE + (tid - C3R_FLANK); m.depth = o.depth; m.ncov = o.cov; m.tpre = tpre; m.span = b;
@@ -1851,7 +1888,12 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
         }
         const int gt = head + 4 * n4 + tid;
         if (gt < total) out[gt] = fetch(gt);
+        }
         if (a.dbg && tid == 0) atomicAdd(&a.dbg[7], wall_clock64() - t_tail);
+        // ---- hand over to the next span: its ticket has long arrived; the barrier also frees this span's LDS
+        if (tid == 0) s_ticket = t_next < queue_len(q_next) ? q_next + t_next * TICKET_Q : take();
+        __syncthreads();
+        b = s_ticket;
     }
 }
 
