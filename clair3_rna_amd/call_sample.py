@@ -186,7 +186,7 @@ class _Fetcher(object):
             from . import bamio
             bf = getattr(self.tls, "bf", None)
             if bf is None:
-                bf = self.tls.bf = bamio.BamFile(self.bam_fn)
+                bf = self.tls.bf = bamio.BamFile(self.bam_fn, threads=int(os.environ.get("C3R_FETCH_INFLATE", "8")))
                 self.handles.append(bf)
             rs = bf.fetch(ctg)
         ref = io.fetch_reference(self.ref_fn, ctg, 1, length, raw=True) if len(rs.reads) else b""
@@ -421,15 +421,36 @@ def Run(args, log=None):
                     warm_lock.release()
             t1 = time()
             mark(ctg, "device", t0)
-            rows = decode_stage(eng, ctg, todo)
-            mark(ctg, "decode", t1)
             with lock:
                 stats["fetch"] += dt
                 stats["dev"] += t1 - t0
                 stats["sites"] += todo if isinstance(todo, int) else 0
+            detach = isinstance(todo, int) and todo and hasattr(eng, "rows_begin") and getattr(args, "debug_dump", None) is None
+            if detach:
+                # the decode inputs leave the context as a host snapshot (c3r_rows_begin): this thread goes on to the next contig
+                # while a decode worker turns the snapshot into rows and — single process — merges them (c3r_vcf_merge)
+                snap = eng.rows_begin()
+                mark(ctg, "snapshot", t1)
+                return decode_pool.submit(decode_task, snap, ctg)      # (the look-ahead slot is free: the fetched arrays are done with)
+            rows = decode_stage(eng, ctg, todo)
+            mark(ctg, "decode", t1)
             return rows
         finally:
             slots.release()
+
+    def decode_task(snap, ctg):
+        try:
+            t0 = time()
+            rows = snap.decode(ctg, qual=qual_rows, show_ref=args.print_ref_calls)[0]
+            mark(ctg, "decode", t0)
+            if world == 1:
+                t1 = time()
+                res = ("merged", merger.merge_only(ctg, rows))
+                mark(ctg, "merge", t1)
+                return res
+            return rows
+        finally:
+            pass
 
     work_err = None
     t_merge = 0.0
@@ -437,6 +458,7 @@ def Run(args, log=None):
     n_sites = t_fetch = t_dev = 0
     called = []
     ctx_pools = [ThreadPoolExecutor(1) for _ in engines]
+    decode_pool = ThreadPoolExecutor(max(2, n_ctx + 1))                  # snapshots -> rows (-> merged records), beside the contexts
     stop = threading.Event()
 
     def stop_workers():
@@ -444,7 +466,7 @@ def Run(args, log=None):
         contigs are cancelled, the running ones finish, and the feeder — possibly parked on a look-ahead slot that a cancelled task
         will never release — is told to stop and woken."""
         stop.set()
-        for p_ in ctx_pools:
+        for p_ in ctx_pools + [decode_pool]:
             p_.shutdown(wait=True, cancel_futures=True)
         for _ in range(len(contigs) + n_ctx + args.fetch_threads + 2):
             try:
@@ -488,15 +510,20 @@ def Run(args, log=None):
                     if rows is None:
                         log("[WARNING] Contig name %s provided but no mapped reads found in BAM, skip!" % ctg)
                         continue
+                    if hasattr(rows, "result"):                        # decode (and merge) detached to a worker
+                        rows = rows.result()
                     t0 = time()
-                    merge_contig(ctg, rows)
+                    if isinstance(rows, tuple) and rows[0] == "merged":
+                        merger.write_merged(rows[1])                   # merged on the worker: only the ordered write is left
+                    else:
+                        merge_contig(ctg, rows)
                     t_merge += time() - t0
-                    mark(ctg, "merge", t0)
+                    mark(ctg, "write" if isinstance(rows, tuple) else "merge", t0)
                     results.append((ctg, None))
             except BaseException:
                 stop_workers()           # before the fetch pool's own shutdown waits for fetches nobody will consume
                 raise
-        for p_ in ctx_pools:
+        for p_ in ctx_pools + [decode_pool]:
             p_.shutdown()
         n_sites, t_fetch, t_dev = stats["sites"], stats["fetch"], stats["dev"]
         fetcher.close()

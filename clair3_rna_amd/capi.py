@@ -35,7 +35,7 @@ class C3RError(RuntimeError):
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_host_alloc", "c3r_host_free", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
            "c3r_pileup_scan", "c3r_pileup_scan_regions", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
-           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
+           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_rows_begin", "c3r_rows_decode", "c3r_rows_get", "c3r_rows_free", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
 _lib = None
@@ -90,6 +90,11 @@ def load_library():
     L.c3r_get_probs.argtypes = [vp, vp, i64]
     L.c3r_call_rows.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.c3r_get_rows.argtypes = [vp, vp, i64]
+    L.c3r_rows_begin.argtypes = [vp, C.POINTER(vp)]
+    L.c3r_rows_decode.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.c3r_rows_get.argtypes = [vp, vp, i64]
+    L.c3r_rows_free.argtypes = [vp]
+    L.c3r_rows_free.restype = None
     L.c3r_decode_text.argtypes = [C.c_char_p, i64, vp, vp, i32, C.POINTER(C.c_char_p), vp, i32, i32, vp, i64, C.POINTER(i64)]
     L.c3r_set_profiling.argtypes = [vp, i32]
     L.c3r_reset_kernel_stats.argtypes = [vp]
@@ -157,9 +162,13 @@ class Engine(object):
         self.params = default_params()
         self.n_candidates = 0
         self._keep = []
+        import weakref
+        self._snaps = weakref.WeakSet()          # row snapshots must be released before the context goes
 
     def close(self):
         if getattr(self, "h", None):
+            for sn in list(getattr(self, "_snaps", ())):
+                sn.free()
             self.L.c3r_destroy(self.h)
             self.h = None
 
@@ -312,6 +321,15 @@ class Engine(object):
         self._chk(self.L.c3r_get_rows(self.h, buf, n.value + 1))
         return buf.raw[:n.value], nr.value
 
+    def rows_begin(self):
+        """Detach the decode inputs of the resident batch (sites, tokens, probabilities, read bases; after infer()) into a host
+        snapshot: the engine is free for the next contig, RowSnapshot.decode() may run on any thread."""
+        h = C.c_void_p()
+        self._chk(self.L.c3r_rows_begin(self.h, C.byref(h)))
+        snap = RowSnapshot(self.L, h)
+        self._snaps.add(snap)
+        return snap
+
     def call_rows(self, ctg, qual=2, show_ref=True):
         """The same as a list of row strings (tests; 200 k Python strings cost more than producing the rows)."""
         text, _ = self.call_rows_text(ctg, qual, show_ref)
@@ -338,6 +356,39 @@ class Engine(object):
         n = C.c_int(0)
         self._chk(self.L.c3r_get_kernel_stats(self.h, names, ms, cnt, cap, C.byref(n)))
         return {names[i].decode(): dict(total_ms=ms[i], launches=cnt[i]) for i in range(min(n.value, cap))}
+
+
+class RowSnapshot(object):
+    """Host-side decode inputs of one batch (c3r_rows_begin); decode() needs no GPU and no engine."""
+
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    def decode(self, ctg, qual=2, show_ref=True):
+        """-> (bytes of newline-terminated VCF rows, number of rows); releases the snapshot."""
+        try:
+            n, nr = C.c_int64(0), C.c_int64(0)
+            rc = self.L.c3r_rows_decode(self.h, ctg.encode(), -1 if qual is None else int(qual), int(show_ref), C.byref(n), C.byref(nr))
+            if rc != 0:
+                raise C3RError(rc, "c3r_rows_decode failed")
+            buf = C.create_string_buffer(n.value + 1)
+            rc = self.L.c3r_rows_get(self.h, buf, n.value + 1)
+            if rc != 0:
+                raise C3RError(rc, "c3r_rows_get failed")
+            return buf.raw[:n.value], nr.value
+        finally:
+            self.free()
+
+    def free(self):
+        if self.h:
+            self.L.c3r_rows_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def decode_text(ctg, positions, ref33_list, alt_info_list, probs, qual=2, show_ref=True):

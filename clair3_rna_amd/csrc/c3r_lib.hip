@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -35,6 +37,7 @@ struct KStat { double ms = 0; int64_t n = 0; };
 
 }  // namespace
 
+struct c3r_rows;
 struct c3r_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -73,9 +76,16 @@ struct c3r_ctx {
     int32_t *h_scan = nullptr;             // pinned: what a fused scan reads back (totals, overflow flags)
     bool last_fused = false;
     std::vector<int64_t> last_starts, last_ends;
-    char *h_ref = nullptr; size_t h_ref_cap = 0, ref_len = 0;     // page-locked: upper-cased reference slice (upload source, decoder's view)
-    hipEvent_t ev_ref = nullptr;                                  // the upload of h_ref has been read
+    // page-locked buffers for the upper-cased reference slice (upload source, decoder's view).  Three of them: a row snapshot
+    // (c3r_rows_begin) keeps the buffer of ITS contig alive while the context already works on the next one
+    struct RefBuf { char *p = nullptr; size_t cap = 0; std::atomic<int> users{0}; hipEvent_t ev = nullptr; };
+    RefBuf refbuf[3];
+    int ref_cur = -1;                                             // the slot c3r_set_reference filled last
+    char *h_ref = nullptr; size_t ref_len = 0;                    // = refbuf[ref_cur].p
     int64_t ref_start1 = 1;
+    std::mutex pool_mu;                                           // guards stage_pool (snapshots are released from other threads)
+    std::vector<std::pair<void *, size_t>> stage_pool;            // page-locked staging blocks of released row snapshots
+    c3r_rows *rows_snap = nullptr;                                // c3r_call_rows keeps its snapshot here for c3r_get_rows
     DevBuf d_ref;
     std::vector<int32_t> h_bed[2];
     DevBuf d_bed[2];
@@ -106,9 +116,6 @@ struct c3r_ctx {
     double mx_calib_err = -1.0;            // max |dP| of precision 2 against precision 1 on the calibration windows (-1: not measured)
 
     // ---- host decode (A8)
-    void *h_stage = nullptr; size_t h_stage_cap = 0;     // pinned staging buffer for sites + tokens + probabilities
-    std::string rows_cache;
-    int64_t rows_count = 0;
 };
 
 namespace {
@@ -381,11 +388,11 @@ void c3r_destroy(c3r_ctx *ctx) {
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     net_free(ctx->net);
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->rows_snap) c3r_rows_free(ctx->rows_snap);
+    for (auto &sp : ctx->stage_pool) (void)hipHostFree(sp.first);
     if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
-    if (ctx->h_ref) (void)hipHostFree(ctx->h_ref);
-    if (ctx->ev_ref) (void)hipEventDestroy(ctx->ev_ref);
+    for (auto &rb : ctx->refbuf) { if (rb.p) (void)hipHostFree(rb.p); if (rb.ev) (void)hipEventDestroy(rb.ev); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -544,16 +551,25 @@ int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t 
     // The slice is upper-cased straight into a page-locked buffer the context keeps (one pass over the caller's bytes, on threads for a
     // whole chromosome), which is both the source of an asynchronous DMA upload — nothing here waits for the device — and the decoder's
     // view of the reference.  The previous upload must have left the buffer before it is overwritten.
-    if (!ctx->ev_ref) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_ref, hipEventDisableTiming));
-    else HIPCHK(ctx, hipEventSynchronize(ctx->ev_ref));
     ctx->ref_len = 0;
-    if ((size_t)len + 16 > ctx->h_ref_cap) {
-        if (ctx->h_ref) (void)hipHostFree(ctx->h_ref);
-        ctx->h_ref = nullptr; ctx->h_ref_cap = 0;
-        const size_t cap = (size_t)len + (size_t)len / 8 + 4096;
-        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_ref, cap, hipHostMallocDefault));
-        ctx->h_ref_cap = cap;
+    // a buffer no snapshot holds: the current one if it is free, else another (waiting for a decode to finish if all three are held)
+    int slot = -1;
+    while (slot < 0) {
+        if (ctx->ref_cur >= 0 && ctx->refbuf[ctx->ref_cur].users.load() == 0) slot = ctx->ref_cur;
+        for (int k = 0; k < 3 && slot < 0; ++k) if (k != ctx->ref_cur && ctx->refbuf[k].users.load() == 0) slot = k;
+        if (slot < 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
+    c3r_ctx::RefBuf &rb = ctx->refbuf[slot];
+    if (!rb.ev) HIPCHK(ctx, hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
+    else HIPCHK(ctx, hipEventSynchronize(rb.ev));                 // (its previous upload has left the buffer)
+    if ((size_t)len + 16 > rb.cap) {
+        if (rb.p) (void)hipHostFree(rb.p);
+        rb.p = nullptr; rb.cap = 0;
+        const size_t cap = (size_t)len + (size_t)len / 8 + 4096;
+        HIPCHK(ctx, hipHostMalloc((void **)&rb.p, cap, hipHostMallocDefault));
+        rb.cap = cap;
+    }
+    ctx->ref_cur = slot; ctx->h_ref = rb.p;
     {
         char *dst = ctx->h_ref;
         auto upper = [&](int64_t a, int64_t e) {
@@ -574,7 +590,7 @@ int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t 
     int rc = ensure(ctx, ctx->d_ref, std::max<size_t>((size_t)len, 16));
     if (rc) return rc;
     if (len) HIPCHK(ctx, hipMemcpyAsync(ctx->d_ref.p, ctx->h_ref, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_ref, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(rb.ev, ctx->stream));
     ctx->ref_len = (size_t)len;
     return C3R_OK;
 }
@@ -1406,46 +1422,78 @@ int c3r_decode_text(const char *ctg, int64_t n, const int32_t *pos, const char *
     return C3R_OK;
 }
 
-int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t *out_len, int64_t *n_rows) {
-    if (!ctx || !ctg || !out_len) return C3R_EINVAL;
-    ctx->rows_cache.clear(); ctx->rows_count = 0;
+// ---- row snapshots: everything the decoder needs of one batch, on the host, detached from the context
+}  // extern "C"
+struct c3r_rows {
+    c3r_ctx *ctx = nullptr;
+    void *stage = nullptr; size_t stage_cap = 0;          // page-locked: sites | tokens | probabilities
+    int64_t n = 0, n_tok = 0;
+    c3r_site_t *sites = nullptr; c3r_token_t *toks = nullptr; float *probs = nullptr;
+    std::vector<DevRead> reads; std::vector<uint8_t> seq;  // the contig's read headers and packed bases (inserted bases of the alt alleles)
+    int ref_slot = -1; const char *ref = nullptr; size_t ref_len = 0; int64_t ref_start1 = 1;
+    std::string rows; int64_t rows_count = 0;
+};
+extern "C" {
+
+int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
+    if (!ctx || !out) return C3R_EINVAL;
+    *out = nullptr;
     const int64_t n = ctx->n_cand;
-    *out_len = 0; if (n_rows) *n_rows = 0;
-    if (n == 0) return C3R_OK;
-    if (!ctx->net.d_probs || n > ctx->net.cap_probs) return fail(ctx, C3R_EINVAL, "c3r_infer must run before c3r_call_rows");
+    if (n > 0 && (!ctx->net.d_probs || n > ctx->net.cap_probs)) return fail(ctx, C3R_EINVAL, "c3r_infer must run before c3r_call_rows");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const bool timing = getenv("C3R_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    const auto t0 = now();
-    // one pinned staging buffer, grown geometrically and kept: 200 MB of pageable vectors cost 37 ms just to zero-fill
+    c3r_rows *r = new c3r_rows();
+    r->ctx = ctx; r->n = n; r->n_tok = ctx->n_tok;
+    if (n == 0) { *out = r; return C3R_OK; }
     const size_t b_sites = ((size_t)n * sizeof(c3r_site_t) + 255) & ~(size_t)255;
     const size_t b_toks = ((size_t)std::max<int64_t>(ctx->n_tok, 1) * sizeof(c3r_token_t) + 255) & ~(size_t)255;
     const size_t b_probs = (size_t)n * C3R_NPROB * sizeof(float);
-    if (b_sites + b_toks + b_probs > ctx->h_stage_cap) {
-        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-        ctx->h_stage = nullptr; ctx->h_stage_cap = 0;
-        const size_t cap = (b_sites + b_toks + b_probs) * 5 / 4 + 4096;
-        HIPCHK(ctx, hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
-        ctx->h_stage_cap = cap;
+    const size_t need = b_sites + b_toks + b_probs;
+    {   // a page-locked block from the pool of released snapshots (200 MB of pageable vectors cost 37 ms just to zero-fill)
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        for (size_t k = 0; k < ctx->stage_pool.size(); ++k)
+            if (ctx->stage_pool[k].second >= need) { r->stage = ctx->stage_pool[k].first; r->stage_cap = ctx->stage_pool[k].second; ctx->stage_pool.erase(ctx->stage_pool.begin() + (long)k); break; }
     }
-    c3r_site_t *sites = (c3r_site_t *)ctx->h_stage;
-    c3r_token_t *toks = (c3r_token_t *)((char *)ctx->h_stage + b_sites);
-    float *probs = (float *)((char *)ctx->h_stage + b_sites + b_toks);
-    const auto t1 = now();
-    HIPCHK(ctx, hipMemcpyAsync(sites, ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->n_tok) HIPCHK(ctx, hipMemcpyAsync(toks, ctx->d_tok.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (!r->stage) {
+        const size_t cap = need * 5 / 4 + 4096;
+        if (hipHostMalloc(&r->stage, cap, hipHostMallocDefault) != hipSuccess) { delete r; return fail(ctx, C3R_ENOMEM, "hipHostMalloc(%zu) failed", cap); }
+        r->stage_cap = cap;
+    }
+    r->sites = (c3r_site_t *)r->stage;
+    r->toks = (c3r_token_t *)((char *)r->stage + b_sites);
+    r->probs = (float *)((char *)r->stage + b_sites + b_toks);
+    auto bail = [&](int rc) { c3r_rows_free(r); return rc; };
+    if (hipMemcpyAsync(r->sites, ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        (ctx->n_tok && hipMemcpyAsync(r->toks, ctx->d_tok.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess))
+        return bail(fail(ctx, C3R_EHIP, "copying sites / tokens to the host failed"));
     int32_t *lstm_st = nullptr;
-    { int rc_ = queue_lstm_status(ctx, &lstm_st); if (rc_) return rc_; }
-    HIPCHK(ctx, hipMemcpyAsync(probs, ctx->net.d_probs, b_probs, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    { int rc_ = check_lstm_status(ctx, lstm_st); if (rc_) return rc_; }
-    const auto t2 = now();
-    { int rc_ = ensure_host_reads(ctx); if (!rc_) rc_ = ensure_host_seq(ctx); if (rc_) return rc_; }
-    const uint8_t *seq = ctx->h_seq.data();
-    const std::vector<DevRead> &reads = ctx->h_reads;
-    const RefView refv{ctx->h_ref, ctx->ref_len};
-    auto get_read = [&](uint32_t r) { return ReadView{seq, reads[r].seq_off, reads[r].l_seq}; };
+    int rc = queue_lstm_status(ctx, &lstm_st);
+    if (rc) return bail(rc);
+    if (hipMemcpyAsync(r->probs, ctx->net.d_probs, b_probs, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return bail(fail(ctx, C3R_EHIP, "copying probabilities to the host failed"));
+    if ((rc = check_lstm_status(ctx, lstm_st))) return bail(rc);
+    if ((rc = ensure_host_reads(ctx)) || (rc = ensure_host_seq(ctx))) return bail(rc);
+    // the host copies move into the snapshot (the next contig fetches its own); the reference buffer is shared and held by a user count
+    r->reads.swap(ctx->h_reads); r->seq.swap(ctx->h_seq);
+    ctx->host_reads_valid = false; ctx->host_seq_valid = false;
+    ctx->h_reads.clear(); ctx->h_seq.clear();
+    r->ref_slot = ctx->ref_cur; r->ref = ctx->h_ref; r->ref_len = ctx->ref_len; r->ref_start1 = ctx->ref_start1;
+    if (r->ref_slot >= 0) ctx->refbuf[r->ref_slot].users.fetch_add(1);
+    *out = r;
+    return C3R_OK;
+}
+
+int c3r_rows_decode(c3r_rows *r, const char *ctg, int qual, int show_ref, int64_t *out_len, int64_t *n_rows) {
+    if (!r || !ctg || !out_len) return C3R_EINVAL;
+    r->rows.clear(); r->rows_count = 0;
+    *out_len = 0; if (n_rows) *n_rows = 0;
+    const int64_t n = r->n;
+    if (n == 0) return C3R_OK;
+    const c3r_site_t *sites = r->sites; const c3r_token_t *toks = r->toks; const float *probs = r->probs;
+    const uint8_t *seq = r->seq.data();
+    const std::vector<DevRead> &reads = r->reads;
+    const RefView refv{r->ref, r->ref_len};
+    const int64_t ref_start1 = r->ref_start1;
+    auto get_read = [&](uint32_t k) { return ReadView{seq, reads[k].seq_off, reads[k].l_seq}; };
     // host threads: C3R_THREADS, else up to 32 (one process per GPU shares the node's cores with its peers)
     unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("C3R_THREADS")) nt = (unsigned)std::max(1, atoi(e));
@@ -1457,8 +1505,7 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
         AltDict alt;
         for (int64_t i = a; i < b; ++i) {
             int depth_tok;
-            alt_from_tokens(toks + sites[(size_t)i].tok_off, sites[(size_t)i].n_tok, get_read, refv, ctx->ref_start1, sites[(size_t)i].pos,
-                            alt, depth_tok);
+            alt_from_tokens(toks + sites[(size_t)i].tok_off, sites[(size_t)i].n_tok, get_read, refv, ref_start1, sites[(size_t)i].pos, alt, depth_tok);
             if (vcf_row(ctg, sites[(size_t)i].pos, sites[(size_t)i].ref33, sites[(size_t)i].depth, alt, probs + (size_t)i * C3R_NPROB, qual,
                         show_ref != 0, part[t]))
                 cnt[t]++;
@@ -1468,22 +1515,58 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
     for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
     work(0);
     for (auto &x : th) x.join();
-    const auto t3 = now();
     size_t total = 0;
     for (unsigned t = 0; t < nt; ++t) total += part[t].size();
-    ctx->rows_cache.reserve(total + 1);
-    for (unsigned t = 0; t < nt; ++t) { ctx->rows_cache += part[t]; ctx->rows_count += cnt[t]; }
-    if (timing) fprintf(stderr, "[c3r_call_rows] alloc %.1f ms, D2H %.1f ms (%.1f MB), decode %.1f ms on %u threads, concat %.1f ms\n", ms(t0, t1), ms(t1, t2),
-                        ((double)n * (sizeof(c3r_site_t) + 4 * C3R_NPROB) + (double)ctx->n_tok * sizeof(c3r_token_t)) / 1e6, ms(t2, t3), nt, ms(t3, now()));
-    *out_len = (int64_t)ctx->rows_cache.size();
-    if (n_rows) *n_rows = ctx->rows_count;
+    r->rows.reserve(total + 1);
+    for (unsigned t = 0; t < nt; ++t) { r->rows += part[t]; r->rows_count += cnt[t]; }
+    *out_len = (int64_t)r->rows.size();
+    if (n_rows) *n_rows = r->rows_count;
     return C3R_OK;
+}
+
+int c3r_rows_get(c3r_rows *r, char *out, int64_t cap) {
+    if (!r || !out) return C3R_EINVAL;
+    if (cap < (int64_t)r->rows.size() + 1) return C3R_EOVERFLOW;
+    memcpy(out, r->rows.c_str(), r->rows.size() + 1);
+    return C3R_OK;
+}
+
+void c3r_rows_free(c3r_rows *r) {
+    if (!r) return;
+    c3r_ctx *ctx = r->ctx;
+    if (r->ref_slot >= 0) ctx->refbuf[r->ref_slot].users.fetch_sub(1);
+    if (r->stage) {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        if (ctx->stage_pool.size() < 4) ctx->stage_pool.push_back({r->stage, r->stage_cap});
+        else (void)hipHostFree(r->stage);
+    }
+    delete r;
+}
+
+// the one-call form: snapshot + decode on this thread; the rows stay with the context until the next call
+int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t *out_len, int64_t *n_rows) {
+    if (!ctx || !ctg || !out_len) return C3R_EINVAL;
+    if (ctx->rows_snap) { c3r_rows_free(ctx->rows_snap); ctx->rows_snap = nullptr; }
+    *out_len = 0; if (n_rows) *n_rows = 0;
+    const bool timing = getenv("C3R_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = c3r_rows_begin(ctx, &ctx->rows_snap);
+    if (rc) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
+    rc = c3r_rows_decode(ctx->rows_snap, ctg, qual, show_ref, out_len, n_rows);
+    if (timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[c3r_call_rows] snapshot (D2H of sites, tokens, probabilities, read bases) %.1f ms, decode %.1f ms\n", ms(t0, t1), ms(t1, std::chrono::steady_clock::now()));
+    }
+    return rc;
 }
 
 int c3r_get_rows(c3r_ctx *ctx, char *out, int64_t cap) {
     if (!ctx || !out) return C3R_EINVAL;
-    if (cap < (int64_t)ctx->rows_cache.size() + 1) return fail(ctx, C3R_EOVERFLOW, "need %lld bytes", (long long)ctx->rows_cache.size() + 1);
-    memcpy(out, ctx->rows_cache.c_str(), ctx->rows_cache.size() + 1);
+    static const std::string empty;
+    const std::string &rows = ctx->rows_snap ? ctx->rows_snap->rows : empty;
+    if (cap < (int64_t)rows.size() + 1) return fail(ctx, C3R_EOVERFLOW, "need %lld bytes", (long long)rows.size() + 1);
+    memcpy(out, rows.c_str(), rows.size() + 1);
     return C3R_OK;
 }
 

@@ -146,6 +146,8 @@ class SampleMerger(object):
     def __init__(self, output_fn, header_text, qual=2, show_ref=False, rediportal=None, output_no_tagging_fn=None, native=True):
         self.output_fn, self.header = output_fn, header_text
         self.native, self._edits = native, None
+        import threading
+        self._edits_lock = threading.Lock()
         self.qual, self.show_ref, self.rediportal = qual, show_ref, rediportal
         self.out = open(output_fn, "w")
         self.out_nt_fn = output_no_tagging_fn if rediportal is not None else None
@@ -169,7 +171,31 @@ class SampleMerger(object):
                 for (c, pos), hit in self.rediportal.items():
                     self._edits.setdefault(c, []).append((pos, hit[0], hit[1]))
             edits = self._edits.get(contig)
-        merged, merged_nt, (n_read, n_kept, n_tag) = bamio.vcf_merge(blob, self.qual, self.show_ref, edits, self.out_nt is not None)
+        self.write_merged(bamio.vcf_merge(blob, self.qual, self.show_ref, edits, self.out_nt is not None))
+
+    def merge_only(self, contig, rows):
+        """The per-contig work of add_contig without touching the output (c3r_vcf_merge releases the GIL): callable from worker
+        threads, several contigs at a time; hand the result to write_merged in output order."""
+        if self.native is False:
+            raise RuntimeError("merge_only needs the native merge")
+        from . import bamio
+        blob = rows.encode() if isinstance(rows, str) else bytes(rows)
+        if not blob:
+            return None
+        edits = None
+        if self.rediportal:
+            with self._edits_lock:
+                if self._edits is None:
+                    self._edits = {}
+                    for (c, pos), hit in self.rediportal.items():
+                        self._edits.setdefault(c, []).append((pos, hit[0], hit[1]))
+            edits = self._edits.get(contig)
+        return bamio.vcf_merge(blob, self.qual, self.show_ref, edits, self.out_nt is not None)
+
+    def write_merged(self, res):
+        if res is None:
+            return
+        merged, merged_nt, (n_read, n_kept, n_tag) = res
         self._header()
         self.n_read += n_read
         self.n_kept += n_kept

@@ -35,6 +35,7 @@ extern "C" {
 #define C3R_EOVERFLOW (-6)    /* caller buffer too small */
 
 typedef struct c3r_ctx c3r_ctx;
+typedef struct c3r_rows c3r_rows;   /* a batch's decode inputs on the host, detached from the context (c3r_rows_begin) */
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 /* Library version string, e.g. "c3r 0.1 (gfx950)". */
@@ -151,6 +152,14 @@ int c3r_get_probs(c3r_ctx *ctx, float *probs, int64_t n);
  * qual < 0 means "no quality cut-off" (--qual None); show_ref != 0 keeps RefCall rows (--showRef). */
 int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t *out_len, int64_t *n_rows);
 int c3r_get_rows(c3r_ctx *ctx, char *out, int64_t cap);
+/* The same in two steps, so that the context can go on to the next contig while host threads decode this one: c3r_rows_begin (after
+ * c3r_infer) copies sites, tokens, probabilities and the read bases to the host and returns a snapshot; from then on the context may load
+ * new reads / a new reference (the snapshot keeps its contig's reference buffer alive).  c3r_rows_decode / c3r_rows_get work on the
+ * snapshot from ANY thread, no GPU involved.  c3r_rows_free must be called before c3r_destroy of the context that made the snapshot. */
+int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out);
+int c3r_rows_decode(c3r_rows *rows, const char *ctg, int qual, int show_ref, int64_t *out_len, int64_t *n_rows);
+int c3r_rows_get(c3r_rows *rows, char *out, int64_t cap);
+void c3r_rows_free(c3r_rows *rows);
 /* The same decoder on caller-supplied text (no GPU, no context): n sites, alt_info strings "<depth>-<k v ...>".
  * Returns C3R_EOVERFLOW (with *out_len = bytes needed, excluding the NUL) when `out` is too small. */
 int c3r_decode_text(const char *ctg, int64_t n, const int32_t *pos, const char *ref33s, int ref33_stride, const char *const *alt_infos,
