@@ -554,10 +554,12 @@ int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t 
     ctx->ref_len = 0;
     // a buffer no snapshot holds: the current one if it is free, else another (waiting for a decode to finish if all three are held)
     int slot = -1;
-    while (slot < 0) {
+    for (int waited = 0; slot < 0; ++waited) {
         if (ctx->ref_cur >= 0 && ctx->refbuf[ctx->ref_cur].users.load() == 0) slot = ctx->ref_cur;
         for (int k = 0; k < 3 && slot < 0; ++k) if (k != ctx->ref_cur && ctx->refbuf[k].users.load() == 0) slot = k;
-        if (slot < 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        if (slot >= 0) break;
+        if (waited > 600000) return fail(ctx, C3R_EINVAL, "all three reference buffers are held by row snapshots that were never released (c3r_rows_free)");
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
     c3r_ctx::RefBuf &rb = ctx->refbuf[slot];
     if (!rb.ev) HIPCHK(ctx, hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
