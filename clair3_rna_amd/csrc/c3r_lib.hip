@@ -1533,15 +1533,24 @@ int c3r_rows_get(c3r_rows *r, char *out, int64_t cap) {
     return C3R_OK;
 }
 
-void c3r_rows_free(c3r_rows *r) {
-    if (!r) return;
+// give back what only the decode needed (reference buffer, staging block, read copies); the rows text stays
+static void rows_release_inputs(c3r_rows *r) {
     c3r_ctx *ctx = r->ctx;
-    if (r->ref_slot >= 0) ctx->refbuf[r->ref_slot].users.fetch_sub(1);
+    if (r->ref_slot >= 0) { ctx->refbuf[r->ref_slot].users.fetch_sub(1); r->ref_slot = -1; r->ref = nullptr; r->ref_len = 0; }
     if (r->stage) {
         std::lock_guard<std::mutex> g(ctx->pool_mu);
         if (ctx->stage_pool.size() < 4) ctx->stage_pool.push_back({r->stage, r->stage_cap});
         else (void)hipHostFree(r->stage);
+        r->stage = nullptr; r->stage_cap = 0; r->sites = nullptr; r->toks = nullptr; r->probs = nullptr;
     }
+    r->n = 0;
+    std::vector<DevRead>().swap(r->reads);
+    std::vector<uint8_t>().swap(r->seq);
+}
+
+void c3r_rows_free(c3r_rows *r) {
+    if (!r) return;
+    rows_release_inputs(r);
     delete r;
 }
 
@@ -1556,6 +1565,7 @@ int c3r_call_rows(c3r_ctx *ctx, const char *ctg, int qual, int show_ref, int64_t
     if (rc) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     rc = c3r_rows_decode(ctx->rows_snap, ctg, qual, show_ref, out_len, n_rows);
+    rows_release_inputs(ctx->rows_snap);          // (only the text is kept for c3r_get_rows: no reference buffer stays pinned by it)
     if (timing) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[c3r_call_rows] snapshot (D2H of sites, tokens, probabilities, read bases) %.1f ms, decode %.1f ms\n", ms(t0, t1), ms(t1, std::chrono::steady_clock::now()));

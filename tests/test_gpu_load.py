@@ -113,3 +113,38 @@ def test_empty_and_filtered_out_inputs(eng):
     assert eng.scan(1, 1500) == 0
     cols = eng.columns()
     assert not cols["depth"].any()          # (the insertion after the ref-skip still lands on the intron's last column: channel i only)
+
+
+def test_row_snapshots_survive_the_next_contigs(eng):
+    """c3r_rows_begin detaches a batch's decode inputs from the context: the engine loads other reads and another reference (three
+    times over: the reference buffers rotate under the snapshots' user counts), and the snapshots — decoded afterwards, on other
+    threads — still give the rows c3r_call_rows gave for their contig."""
+    import threading
+    from clair3_rna_amd import capi, synth
+    w = synth.random_weights(18, seed=77)
+    cases = [synth.small_case(seed=300 + k, ref_len=30000 + 4000 * k, n_genes=5 + k, depth=18) for k in range(3)]      # (a context keeps three reference buffers: at most three undecoded snapshots)
+    eng.params = capi.default_params()
+    eng.set_params(); eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.load_weights(w, 18); eng.set_precision("f16x3")
+    want, snaps = [], []
+    for ref, rs, _ in cases:                                   # the one-call form, contig after contig
+        eng.load_reads(rs); eng.set_reference(1, ref)
+        assert eng.scan(1, len(ref)) > 20
+        eng.infer(fetch=False)
+        want.append(eng.call_rows_text("chr20", qual=2, show_ref=True))
+    for ref, rs, _ in cases:                                   # snapshots taken, engine moves on, nothing decoded yet
+        eng.load_reads(rs); eng.set_reference(1, ref)
+        eng.scan(1, len(ref))
+        eng.infer(fetch=False)
+        snaps.append(eng.rows_begin())
+    got = [None] * len(snaps)
+
+    def work(k):
+        got[k] = snaps[k].decode("chr20", qual=2, show_ref=True)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(snaps))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert got == want and all(n > 20 for _t, n in got)
+    # every snapshot released its reference buffer: the context takes new references without waiting
+    for ref, rs, _ in cases[:3]:
+        eng.set_reference(1, ref)
