@@ -10,7 +10,8 @@ import numpy as np
 from .reads import READ_DTYPE, ReadSet
 
 EXPORTS = ["c3r_bam_open", "c3r_bam_close", "c3r_bam_last_error", "c3r_bam_n_contigs", "c3r_bam_contig", "c3r_bam_has_index",
-           "c3r_bam_fetch", "c3r_bam_copy", "c3r_bam_index_build", "c3r_vcf_merge", "c3r_vcf_compress"]
+           "c3r_bam_fetch", "c3r_bam_copy", "c3r_bam_index_build", "c3r_vcf_merge", "c3r_vcf_compress", "c3r_vcfz_open", "c3r_vcfz_write",
+           "c3r_vcfz_close"]
 _LIB = None
 
 
@@ -132,3 +133,39 @@ def vcf_compress(path, threads=0):
     if rc != 0:
         raise IOError("c3r_vcf_compress(%s) failed with %d" % (path, rc))
     return path + ".gz"
+
+
+class VcfGzWriter(object):
+    """Streaming bgzip + tabix (c3r_vcfz_*): write() takes newline-terminated text in file order; close() leaves <path> (BGZF) and
+    <path>.tbi — the bytes vcf_compress makes of the concatenated text; discard() removes what was written."""
+
+    def __init__(self, gz_path, threads=0):
+        L = load_library()
+        L.c3r_vcfz_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.c3r_vcfz_write.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.c3r_vcfz_close.argtypes = [C.c_void_p, C.c_int]
+        self.L, self.path, self.h = L, gz_path, C.c_void_p()
+        rc = L.c3r_vcfz_open(os.fsencode(gz_path), threads, C.byref(self.h))
+        if rc != 0:
+            raise IOError("c3r_vcfz_open(%s) failed with %d" % (gz_path, rc))
+
+    def write(self, text):
+        b = text.encode() if isinstance(text, str) else bytes(text)
+        if not b:
+            return
+        rc = self.L.c3r_vcfz_write(self.h, b, len(b))
+        if rc != 0:
+            raise IOError("c3r_vcfz_write(%s) failed with %d (text must end in a newline)" % (self.path, rc))
+
+    def _end(self, keep):
+        if self.h:
+            h, self.h = self.h, None
+            rc = self.L.c3r_vcfz_close(h, int(keep))
+            if rc != 0:
+                raise IOError("c3r_vcfz_close(%s) failed with %d" % (self.path, rc))
+
+    def close(self):
+        self._end(True)
+
+    def discard(self):
+        self._end(False)

@@ -276,7 +276,9 @@ def Run(args, log=None):
     qual_rows = args.qual if args.qual is not None else 2              # call_variants.py:1827 (STEP 1 never passes --qual)
     qual_merge = args.qual if args.qual is not None else 2             # sort_vcf's own default
     header = vcf.header(args.ref_fn, cmd_fn, args.sample_name) + "\n"
-    merger = sort_vcf.SampleMerger(out_fn, header, qual_merge, args.print_ref_calls, table, out_nt_fn) if rank == 0 else None
+    # (compressed output is written as it is produced — bgzip blocks and the tabix index grow contig by contig — so that no
+    # compression pass is left after the last contig)
+    merger = sort_vcf.SampleMerger(out_fn, header, qual_merge, args.print_ref_calls, table, out_nt_fn, stream_gz=not args.no_compress) if rank == 0 else None
 
     def device_stage(eng, ctg, rs, ref):
         """-> number of candidates left resident in `eng` (rows are produced by decode_stage)."""
@@ -573,7 +575,7 @@ def Run(args, log=None):
                 for k in range(1, chunk_nums[c] + 1):
                     f.write("%s %d %d\n" % (c, k, chunk_nums[c]))
         t0 = time()
-        if not args.no_compress:
+        if not args.no_compress and not getattr(merger, "streamed", False):      # (streamed: <out>.vcf.gz + .tbi are complete already)
             sort_vcf.compress_vcf(out_fn)
             if table is not None and n_kept:
                 sort_vcf.compress_vcf(out_nt_fn)

@@ -221,67 +221,142 @@ template <typename T> void put(std::vector<uint8_t> &v, T x) { const uint8_t *p 
 
 extern "C" {
 
-int c3r_vcf_compress(const char *path, int threads) {
-    if (!path) return C3R_EINVAL;
-    FILE *f = fopen(path, "rb");
-    if (!f) return C3R_EINVAL;
-    std::vector<uint8_t> data;
-    {
-        uint8_t buf[1 << 16]; size_t k;
-        while ((k = fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + k);
-        fclose(f);
-    }
-    if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-    std::vector<uint8_t> gz; std::vector<uint64_t> coffs;
-    if (!bgzf_compress(data.data(), data.size(), threads, gz, coffs)) return C3R_EINVAL;
-    const uint64_t end_coff = gz.size();
-    const std::string gz_path = std::string(path) + ".gz";
-    if (!write_file(gz_path, gz.data(), gz.size(), BGZF_EOF, sizeof BGZF_EOF)) return C3R_EINVAL;
-    auto voff = [&](size_t u) -> uint64_t {         // a position at a block's end belongs to the next block
-        if (u >= data.size()) return end_coff << 16;
-        return (coffs[u / BLK] << 16) | (uint64_t)(u % BLK);
-    };
-    // TBI v1, VCF preset (format 2, col_seq 1, col_beg 2, col_end 0, meta '#', skip 0): UCSC bins + 16 kb linear index
+}  // extern "C"
+
+// Streaming form of the compressor: text arrives in newline-terminated pieces (the header, then each contig's merged records), every
+// full 0xff00-byte block is deflated on threads and written as soon as it is complete, index records are resolved once the blocks
+// they point into have their file offsets.  The bytes are those of compressing the concatenated text in one go (BGZF blocks are cut
+// at fixed offsets of the uncompressed stream), so c3r_vcf_compress is this object fed once.
+struct c3r_vcfz {
+    std::string gz_path;
+    FILE *f = nullptr;
+    int threads = 1;
+    std::vector<uint8_t> pend;                 // bytes not yet in a block (< BLK after every write)
+    uint64_t n_unc = 0;                        // uncompressed bytes already in blocks
+    uint64_t n_seen = 0;                       // uncompressed bytes received
+    uint64_t coff = 0;                         // compressed bytes written
+    std::vector<uint64_t> coffs;               // file offset of every finished block
+    struct Rec { uint64_t u; uint32_t step; uint32_t ctg; int64_t beg, end; };
+    std::vector<Rec> recs; size_t rec_head = 0; // index records waiting for their blocks
     struct Ctg { std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins; std::vector<uint64_t> lin; };
     std::vector<std::string> names; std::map<std::string, size_t> which; std::vector<Ctg> idx;
-    size_t u = 0;
-    const size_t n = data.size();
-    while (u <= n) {
-        const uint8_t *nl = u < n ? (const uint8_t *)memchr(data.data() + u, '\n', n - u) : nullptr;
-        const size_t le = nl ? (size_t)(nl - data.data()) : n;
-        const size_t ln = le - u, step = ln + 1;                  // Python: for line in data.split(b"\n"): n = len(line) + 1
-        if (ln > 0 && data[u] != '#') {
-            Field c[6];
-            const char *s = (const char *)data.data() + u;
-            // line.split(b"\t", 5)
-            int k = 0; size_t b = 0;
-            for (size_t i = 0; i <= ln && k < 5; ++i) if (i == ln || s[i] == '\t') { c[k++] = Field{s + b, i - b}; b = i + 1; }
-            if (k >= 4) {
-                const std::string ctg(c[0].p, c[0].n);
-                const int64_t beg = strtoll(std::string(c[1].p, c[1].n).c_str(), nullptr, 10) - 1;
-                const int64_t end = beg + (int64_t)std::max<size_t>(1, c[3].n);
-                auto it = which.find(ctg);
-                if (it == which.end()) { it = which.emplace(ctg, names.size()).first; names.push_back(ctg); idx.emplace_back(); }
-                Ctg &x = idx[it->second];
-                const uint64_t v0 = voff(u), v1 = voff(u + step);
-                auto &ch = x.bins[(uint32_t)reg2bin_vcf(beg, end)];
-                if (!ch.empty() && ch.back().second == v0) ch.back().second = v1;
-                else ch.emplace_back(v0, v1);
-                const size_t w1 = (size_t)((end - 1) >> 14);
-                if (x.lin.size() <= w1) x.lin.resize(w1 + 1, 0);
-                for (size_t w = (size_t)(beg >> 14); w <= w1; ++w) if (x.lin[w] == 0) x.lin[w] = v0;
-            }
-        }
-        u += step;
-        if (!nl) break;
+    bool bad = false;
+
+    bool flush_blocks(bool all) {
+        const size_t n = pend.size();
+        const size_t nb = all ? (n + BLK - 1) / BLK : n / BLK;
+        if (nb == 0) return true;
+        const size_t take = std::min(n, nb * BLK);
+        std::vector<uint8_t> gz; std::vector<uint64_t> co;
+        if (!bgzf_compress(pend.data(), take, threads, gz, co)) return false;
+        if (!gz.empty() && fwrite(gz.data(), 1, gz.size(), f) != gz.size()) return false;
+        for (uint64_t c : co) coffs.push_back(coff + c);
+        coff += gz.size();
+        n_unc += take;
+        pend.erase(pend.begin(), pend.begin() + (long)take);
+        return true;
     }
+    // a position at a block's end belongs to the next block; past the last byte: the EOF block
+    bool voff(uint64_t u, bool closing, uint64_t &v) const {
+        const size_t blk = (size_t)(u / BLK);
+        if (blk < coffs.size() && u < n_unc) { v = (coffs[blk] << 16) | (uint64_t)(u % BLK); return true; }
+        if (closing && u >= n_unc) { v = coff << 16; return true; }
+        return false;
+    }
+    void resolve(bool closing) {
+        for (; rec_head < recs.size(); ++rec_head) {
+            const Rec &r = recs[rec_head];
+            uint64_t v0, v1;
+            if (!voff(r.u, closing, v0) || !voff(r.u + r.step, closing, v1)) break;
+            Ctg &x = idx[r.ctg];
+            auto &ch = x.bins[(uint32_t)reg2bin_vcf(r.beg, r.end)];
+            if (!ch.empty() && ch.back().second == v0) ch.back().second = v1;
+            else ch.emplace_back(v0, v1);
+            const size_t w1 = (size_t)((r.end - 1) >> 14);
+            if (x.lin.size() <= w1) x.lin.resize(w1 + 1, 0);
+            for (size_t w = (size_t)(r.beg >> 14); w <= w1; ++w) if (x.lin[w] == 0) x.lin[w] = v0;
+        }
+        if (rec_head == recs.size()) { recs.clear(); rec_head = 0; }
+    }
+    // index records of the lines of text[0, n) (complete lines; the last one may lack its newline only in the final piece)
+    void scan_lines(const uint8_t *data, size_t n) {
+        size_t u = 0;
+        while (u <= n) {
+            const uint8_t *nl = u < n ? (const uint8_t *)memchr(data + u, '\n', n - u) : nullptr;
+            const size_t le = nl ? (size_t)(nl - data) : n;
+            const size_t ln = le - u, step = ln + 1;                  // Python: for line in data.split(b"\n"): n = len(line) + 1
+            if (ln > 0 && data[u] != '#') {
+                Field c[6];
+                const char *s = (const char *)data + u;
+                int k = 0; size_t b = 0;                              // line.split(b"\t", 5)
+                for (size_t i = 0; i <= ln && k < 5; ++i) if (i == ln || s[i] == '\t') { c[k++] = Field{s + b, i - b}; b = i + 1; }
+                if (k >= 4) {
+                    const std::string ctg(c[0].p, c[0].n);
+                    const int64_t beg = strtoll(std::string(c[1].p, c[1].n).c_str(), nullptr, 10) - 1;
+                    const int64_t end = beg + (int64_t)std::max<size_t>(1, c[3].n);
+                    auto it = which.find(ctg);
+                    if (it == which.end()) { it = which.emplace(ctg, names.size()).first; names.push_back(ctg); idx.emplace_back(); }
+                    recs.push_back(Rec{n_seen + u, (uint32_t)step, (uint32_t)it->second, beg, end});
+                }
+            }
+            u += step;
+            if (!nl) break;
+        }
+    }
+};
+
+extern "C" {
+
+int c3r_vcfz_open(const char *gz_path, int threads, c3r_vcfz **out) {
+    if (!gz_path || !out) return C3R_EINVAL;
+    *out = nullptr;
+    c3r_vcfz *z = new c3r_vcfz();
+    z->gz_path = gz_path;
+    z->threads = threads > 0 ? threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    z->f = fopen(gz_path, "wb");
+    if (!z->f) { delete z; return C3R_EINVAL; }
+    *out = z;
+    return C3R_OK;
+}
+
+// text: whole lines (n == 0 or text[n - 1] == '\n'), in file order
+int c3r_vcfz_write(c3r_vcfz *z, const char *text, int64_t n) {
+    if (!z || n < 0 || (n && !text) || z->bad) return C3R_EINVAL;
+    if (n == 0) return C3R_OK;
+    if (text[n - 1] != '\n') return C3R_EINVAL;
+    // (the trailing newline closes the last line: the split-based scan below would see one more, empty, line after it — nothing to index)
+    z->scan_lines((const uint8_t *)text, (size_t)n - 1);
+    z->n_seen += (uint64_t)n;
+    z->pend.insert(z->pend.end(), (const uint8_t *)text, (const uint8_t *)text + n);
+    if (!z->flush_blocks(false)) { z->bad = true; return C3R_EINVAL; }
+    z->resolve(false);
+    return C3R_OK;
+}
+
+// keep != 0: finish <gz_path> and write <gz_path>.tbi; keep == 0: drop what was written (the caller decided on an empty output)
+int c3r_vcfz_close(c3r_vcfz *z, int keep) {
+    if (!z) return C3R_EINVAL;
+    int rc = C3R_OK;
+    if (!keep || z->bad) {
+        if (z->f) fclose(z->f);
+        remove(z->gz_path.c_str());
+        rc = z->bad ? C3R_EINVAL : C3R_OK;
+        delete z;
+        return rc;
+    }
+    bool ok = z->flush_blocks(true);
+    z->resolve(true);
+    ok = ok && fwrite(BGZF_EOF, 1, sizeof BGZF_EOF, z->f) == sizeof BGZF_EOF;
+    ok = (fclose(z->f) == 0) && ok;
+    z->f = nullptr;
+    // TBI v1, VCF preset (format 2, col_seq 1, col_beg 2, col_end 0, meta '#', skip 0): UCSC bins + 16 kb linear index
     std::vector<uint8_t> tbi = {'T', 'B', 'I', 1};
     std::string nm;
-    for (auto &s : names) { nm += s; nm += '\0'; }
-    const int32_t hdr[8] = {(int32_t)names.size(), 2, 1, 2, 0, '#', 0, (int32_t)nm.size()};
+    for (auto &s : z->names) { nm += s; nm += '\0'; }
+    const int32_t hdr[8] = {(int32_t)z->names.size(), 2, 1, 2, 0, '#', 0, (int32_t)nm.size()};
     for (int32_t h : hdr) put(tbi, h);
     tbi.insert(tbi.end(), nm.begin(), nm.end());
-    for (Ctg &x : idx) {
+    for (c3r_vcfz::Ctg &x : z->idx) {
         for (size_t w = 1; w < x.lin.size(); ++w) if (x.lin[w] == 0) x.lin[w] = x.lin[w - 1];
         put(tbi, (int32_t)x.bins.size());
         for (auto &kv : x.bins) {
@@ -292,10 +367,38 @@ int c3r_vcf_compress(const char *path, int threads) {
         for (uint64_t v : x.lin) put(tbi, v);
     }
     std::vector<uint8_t> tgz; std::vector<uint64_t> tco;
-    if (!bgzf_compress(tbi.data(), tbi.size(), 1, tgz, tco)) return C3R_EINVAL;
-    if (!write_file(gz_path + ".tbi", tgz.data(), tgz.size(), BGZF_EOF, sizeof BGZF_EOF)) return C3R_EINVAL;
-    remove(path);
-    return C3R_OK;
+    ok = ok && bgzf_compress(tbi.data(), tbi.size(), 1, tgz, tco);
+    ok = ok && write_file(z->gz_path + ".tbi", tgz.data(), tgz.size(), BGZF_EOF, sizeof BGZF_EOF);
+    delete z;
+    return ok ? C3R_OK : C3R_EINVAL;
+}
+
+int c3r_vcf_compress(const char *path, int threads) {
+    if (!path) return C3R_EINVAL;
+    FILE *f = fopen(path, "rb");
+    if (!f) return C3R_EINVAL;
+    std::vector<uint8_t> data;
+    {
+        uint8_t buf[1 << 16]; size_t k;
+        while ((k = fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + k);
+        fclose(f);
+    }
+    c3r_vcfz *z = nullptr;
+    int rc = c3r_vcfz_open((std::string(path) + ".gz").c_str(), threads, &z);
+    if (rc) return rc;
+    // one piece; a file that does not end in a newline is indexed like Python's data.split(b"\n") would
+    if (!data.empty()) {
+        if (data.back() == '\n') rc = c3r_vcfz_write(z, (const char *)data.data(), (int64_t)data.size());
+        else {
+            z->scan_lines(data.data(), data.size());
+            z->n_seen += data.size();
+            z->pend.insert(z->pend.end(), data.begin(), data.end());
+        }
+    }
+    if (rc) { (void)c3r_vcfz_close(z, 0); return rc; }
+    rc = c3r_vcfz_close(z, 1);
+    if (rc == C3R_OK) remove(path);
+    return rc;
 }
 
 }  // extern "C"

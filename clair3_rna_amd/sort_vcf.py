@@ -143,15 +143,24 @@ class SampleMerger(object):
     each as the newline-terminated rows its chunks produced (any order, duplicates at chunk seams allowed); the files written
     are byte-identical to merge_chunk_vcfs over the per-chunk files."""
 
-    def __init__(self, output_fn, header_text, qual=2, show_ref=False, rediportal=None, output_no_tagging_fn=None, native=True):
+    def __init__(self, output_fn, header_text, qual=2, show_ref=False, rediportal=None, output_no_tagging_fn=None, native=True,
+                 stream_gz=False):
+        """stream_gz: write <output_fn>.gz + .tbi directly, block by block as the contigs arrive (bamio.VcfGzWriter: the bytes
+        compress_vcf would make of the finished file), instead of the plain file that compress_vcf turns into them afterwards."""
         self.output_fn, self.header = output_fn, header_text
         self.native, self._edits = native, None
         import threading
         self._edits_lock = threading.Lock()
         self.qual, self.show_ref, self.rediportal = qual, show_ref, rediportal
-        self.out = open(output_fn, "w")
+        self.stream_gz = bool(stream_gz) and native is not False
         self.out_nt_fn = output_no_tagging_fn if rediportal is not None else None
-        self.out_nt = open(self.out_nt_fn, "w") if self.out_nt_fn else None
+        if self.stream_gz:
+            from . import bamio
+            self.out = bamio.VcfGzWriter(output_fn + ".gz")
+            self.out_nt = bamio.VcfGzWriter(self.out_nt_fn + ".gz") if self.out_nt_fn else None
+        else:
+            self.out = open(output_fn, "w")
+            self.out_nt = open(self.out_nt_fn, "w") if self.out_nt_fn else None
         self.n_read = self.n_kept = self.n_tagged = 0
         self.header_done = False
 
@@ -200,9 +209,9 @@ class SampleMerger(object):
         self.n_read += n_read
         self.n_kept += n_kept
         self.n_tagged += n_tag
-        self.out.write(merged.decode())
+        self.out.write(merged if self.stream_gz else merged.decode())
         if self.out_nt:
-            self.out_nt.write(merged_nt.decode())
+            self.out_nt.write(merged_nt if self.stream_gz else merged_nt.decode())
 
     def _header(self):
         if not self.header_done:
@@ -231,10 +240,21 @@ class SampleMerger(object):
                 self.out_nt.write(by_pos[pos].replace("RNAEditing", "PASS"))
 
     def close(self, log=print):
-        self.out.close()
-        if self.out_nt:
-            self.out_nt.close()
-        if self.n_read == 0 or self.n_kept == 0:
+        empty = self.n_read == 0 or self.n_kept == 0
+        if self.stream_gz:
+            # (an empty result is an EMPTY file, header dropped: written the plain way and left to compress_vcf like before)
+            (self.out.discard if empty else self.out.close)()
+            if self.out_nt:
+                (self.out_nt.discard if (empty or not self.n_kept) else self.out_nt.close)()
+            self.streamed = not empty
+            if empty and self.out_nt_fn:
+                open(self.out_nt_fn, "w").close()
+        else:
+            self.out.close()
+            if self.out_nt:
+                self.out_nt.close()
+            self.streamed = False
+        if empty:
             open(self.output_fn, "w").close()
             log("[WARNING] No %s found, output empty vcf file" % ("vcf file" if self.n_read == 0 else "variant"))
         return self.n_read, self.n_kept, self.n_tagged

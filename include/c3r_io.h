@@ -68,6 +68,15 @@ int c3r_vcf_merge(const char *rows, int64_t n_bytes, int qual, int show_ref, con
  * <path>. */
 int c3r_vcf_compress(const char *path, int threads);
 
+/* The same compressor fed piece by piece (the whole-sample driver hands it the header and then every contig's merged records as they
+ * are written, so that no bgzip pass is left after the last contig): c3r_vcfz_write takes newline-terminated text in file order,
+ * deflates every complete 0xff00-byte block on `threads` threads and writes it; c3r_vcfz_close(keep = 1) writes the last block, the
+ * EOF block and <gz_path>.tbi — byte for byte what c3r_vcf_compress makes of the concatenated text; keep = 0 removes the file. */
+typedef struct c3r_vcfz c3r_vcfz;
+int c3r_vcfz_open(const char *gz_path, int threads, c3r_vcfz **out);
+int c3r_vcfz_write(c3r_vcfz *z, const char *text, int64_t n_bytes);
+int c3r_vcfz_close(c3r_vcfz *z, int keep);
+
 #ifdef __cplusplus
 }
 #endif

@@ -210,3 +210,58 @@ def test_native_merge_equals_python_merge_on_random_records(tmp_path):
                     outs.append((open(o).read(), open(o_nt).read() if tab is not None else None, counts))
                 assert outs[0] == outs[1], (qual, show_ref, tab is not None)
     assert outs[0][0].count("\n") > 1500
+
+
+def test_streaming_compressor_equals_whole_file_compressor(tmp_path):
+    """bamio.VcfGzWriter fed piece by piece (pieces of every size, block boundaries inside lines, inside pieces, on piece ends) writes the
+    .gz and .tbi bytes that compress_vcf makes of the concatenated file — and SampleMerger(stream_gz=True) the files of the plain
+    merger + compress_vcf."""
+    import random
+    from clair3_rna_amd import bamio
+    rng = random.Random(5)
+    header = "##fileformat=VCFv4.2\n##contig=<ID=chr1,length=900000>\n##contig=<ID=chr2,length=900000>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"
+    pieces = [header]
+    for ctg in ("chr1", "chr2", "chrUn_x"):
+        pos, rows = 0, []
+        for _ in range(rng.choice([1, 3000, 9000])):
+            pos += rng.randint(1, 120)
+            ref = rng.choice(["A", "C", "G", "T", "ACGTACGTAC" * rng.randint(1, 40)])
+            rows.append("%s\t%d\t.\t%s\t%s\t%.2f\tPASS\t.\tGT:GQ:DP:AD:AF\t0/1:%d:%d:%d,%d:%.4f\n"
+                        % (ctg, pos, ref, rng.choice("ACGT"), rng.random() * 40, rng.randint(0, 40), rng.randint(4, 90), rng.randint(0, 40), rng.randint(0, 40), rng.random()))
+        # one contig = several pieces of different sizes
+        k = 0
+        while k < len(rows):
+            step = rng.choice([1, 2, 50, 700, 5000])
+            pieces.append("".join(rows[k:k + step]))
+            k += step
+    text = "".join(pieces)
+    assert len(text) > 5 * 0xff00
+    plain = tmp_path / "whole.vcf"
+    plain.write_text(text)
+    sort_vcf.compress_vcf(str(plain))
+    z = bamio.VcfGzWriter(str(tmp_path / "stream.vcf.gz"), threads=3)
+    for p_ in pieces:
+        z.write(p_)
+    z.close()
+    assert (tmp_path / "stream.vcf.gz").read_bytes() == (tmp_path / "whole.vcf.gz").read_bytes()
+    assert (tmp_path / "stream.vcf.gz.tbi").read_bytes() == (tmp_path / "whole.vcf.gz.tbi").read_bytes()
+    # a piece without its newline is refused; discard() leaves nothing behind
+    z = bamio.VcfGzWriter(str(tmp_path / "bad.vcf.gz"))
+    with pytest.raises(IOError):
+        z.write("chr1\t5\t.\tA\tC")
+    z.discard()
+    assert not (tmp_path / "bad.vcf.gz").exists()
+    # SampleMerger in streaming mode == plain merger + compress_vcf (records and an empty result)
+    rows1 = "".join(r for r in pieces[1:] if r.startswith("chr1"))
+    for label, rows in (("full", rows1), ("empty", "")):
+        a, b = tmp_path / ("m_%s_a.vcf" % label), tmp_path / ("m_%s_b.vcf" % label)
+        m1 = sort_vcf.SampleMerger(str(a), header, 2, False, None, None)
+        m2 = sort_vcf.SampleMerger(str(b), header, 2, False, None, None, stream_gz=True)
+        for m in (m1, m2):
+            m.add_contig("chr1", rows)
+            m.close(log=lambda _m: None)
+        sort_vcf.compress_vcf(str(a))
+        if not m2.streamed:
+            sort_vcf.compress_vcf(str(b))
+        assert (tmp_path / ("m_%s_a.vcf.gz" % label)).read_bytes() == (tmp_path / ("m_%s_b.vcf.gz" % label)).read_bytes()
+        assert (tmp_path / ("m_%s_a.vcf.gz.tbi" % label)).read_bytes() == (tmp_path / ("m_%s_b.vcf.gz.tbi" % label)).read_bytes()
