@@ -11,7 +11,7 @@ from .reads import READ_DTYPE, ReadSet
 
 EXPORTS = ["c3r_bam_open", "c3r_bam_close", "c3r_bam_last_error", "c3r_bam_n_contigs", "c3r_bam_contig", "c3r_bam_has_index",
            "c3r_bam_fetch", "c3r_bam_copy", "c3r_bam_index_build", "c3r_vcf_merge", "c3r_vcf_compress", "c3r_vcfz_open", "c3r_vcfz_write",
-           "c3r_vcfz_close"]
+           "c3r_vcfz_close", "c3r_vcfz_piece_make", "c3r_vcfz_append", "c3r_vcfz_piece_free", "c3r_fasta_fetch"]
 _LIB = None
 
 
@@ -33,7 +33,7 @@ def load_library():
         L.c3r_bam_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64] + [C.POINTER(C.c_int64)] * 3
         L.c3r_bam_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.c3r_bam_index_build.argtypes = [C.c_char_p, C.c_char_p]
-        L.c3r_vcf_merge.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int64,
+        L.c3r_vcf_merge.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int64,
                                     C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.c3r_vcf_compress.argtypes = [C.c_char_p, C.c_int]
         _LIB = L
@@ -81,9 +81,9 @@ class BamFile:
         rc = self.L.c3r_bam_fetch(self.h, contig.encode(), int(beg0), int(end0) if end0 else 0, C.byref(n), C.byref(nc), C.byref(ns))
         if rc != 0:
             raise IOError("c3r_bam_fetch: %s" % self.L.c3r_bam_last_error(self.h).decode())
-        reads = np.zeros(n.value, READ_DTYPE)
-        cigar = np.zeros(nc.value, np.uint32)
-        seq = np.zeros(ns.value, np.uint8)
+        reads = np.empty(n.value, READ_DTYPE)
+        cigar = np.empty(nc.value, np.uint32)
+        seq = np.empty(ns.value, np.uint8)
         self.L.c3r_bam_copy(self.h, reads.ctypes.data, cigar.ctypes.data, seq.ctypes.data)
         return ReadSet(reads, cigar, seq)
 
@@ -97,8 +97,17 @@ def index_build(bam_path, bai_path=None):
     return bai_path
 
 
+def _text_ptr(x):
+    """(address, length, keep-alive) of bytes or a uint8 array."""
+    if isinstance(x, np.ndarray):
+        a = np.ascontiguousarray(x, dtype=np.uint8)
+        return a.ctypes.data, a.size, a
+    return C.cast(C.c_char_p(x), C.c_void_p).value, len(x), x
+
+
 def vcf_merge(rows, qual=2, show_ref=False, edits=None, want_no_tagging=False):
-    """c3r_vcf_merge on the records of one contig (bytes).  edits: [(pos, ref, alt), ...] REDIportal entries of the contig or
+    """c3r_vcf_merge on the records of one contig (bytes, or a uint8 array — then the results are arrays too: no copies are made
+    on this side).  edits: [(pos, ref, alt), ...] REDIportal entries of the contig or
     None.  -> (merged bytes, merged-without-tagging bytes or None, (n_read, n_kept, n_tagged))."""
     L = load_library()
     n_edit = len(edits) if edits else 0
@@ -113,18 +122,23 @@ def vcf_merge(rows, qual=2, show_ref=False, edits=None, want_no_tagging=False):
         epos_p = None
     n, n_nt, counts = C.c_int64(), C.c_int64(), (C.c_int64 * 3)()
     nt_len = C.byref(n_nt) if want_no_tagging else None
-    out = C.create_string_buffer(len(rows) + 16 * (n_edit + 1) + 64)       # a relabel adds at most 7 bytes to a record
-    out_nt = C.create_string_buffer(len(out)) if want_no_tagging else None
-    rc = L.c3r_vcf_merge(rows, len(rows), int(qual or 0), int(bool(show_ref)), epos_p, eref, ealt, n_edit, out, len(out), C.byref(n),
-                         out_nt, len(out) if want_no_tagging else 0, nt_len, counts)
+    as_array = isinstance(rows, np.ndarray)
+    rows_p, rows_n, _keep = _text_ptr(rows)
+    cap = rows_n + 16 * (n_edit + 1) + 64                                    # a relabel adds at most 7 bytes to a record
+    out = np.empty(cap, np.uint8)                                            # (not zero-filled: a large contig's records are ~100 MB)
+    out_nt = np.empty(cap, np.uint8) if want_no_tagging else None
+    rc = L.c3r_vcf_merge(rows_p, rows_n, int(qual or 0), int(bool(show_ref)), epos_p, eref, ealt, n_edit, out.ctypes.data, cap, C.byref(n),
+                         out_nt.ctypes.data if want_no_tagging else None, cap if want_no_tagging else 0, nt_len, counts)
     if rc == -6:                                                             # C3R_EOVERFLOW: sizes are known now
-        out = C.create_string_buffer(n.value + 1)
-        out_nt = C.create_string_buffer(n_nt.value + 1) if want_no_tagging else None
-        rc = L.c3r_vcf_merge(rows, len(rows), int(qual or 0), int(bool(show_ref)), epos_p, eref, ealt, n_edit, out, len(out), C.byref(n),
-                             out_nt, len(out_nt) if want_no_tagging else 0, nt_len, counts)
+        out = np.empty(n.value + 1, np.uint8)
+        out_nt = np.empty(n_nt.value + 1, np.uint8) if want_no_tagging else None
+        rc = L.c3r_vcf_merge(rows_p, rows_n, int(qual or 0), int(bool(show_ref)), epos_p, eref, ealt, n_edit, out.ctypes.data, out.size, C.byref(n),
+                             out_nt.ctypes.data if want_no_tagging else None, out_nt.size if want_no_tagging else 0, nt_len, counts)
     if rc != 0:
         raise IOError("c3r_vcf_merge failed with %d (malformed VCF record?)" % rc)
-    return out.raw[:n.value], (out_nt.raw[:n_nt.value] if want_no_tagging else None), tuple(counts)
+    if as_array:
+        return out[:n.value], (out_nt[:n_nt.value] if want_no_tagging else None), tuple(counts)
+    return out[:n.value].tobytes(), (out_nt[:n_nt.value].tobytes() if want_no_tagging else None), tuple(counts)
 
 
 def vcf_compress(path, threads=0):
@@ -135,6 +149,49 @@ def vcf_compress(path, threads=0):
     return path + ".gz"
 
 
+def fasta_fetch(ref_fn, fai_row, beg0=0, end0=None, upper=True, threads=0):
+    """Bases [beg0, end0) of one contig of an uncompressed faidx-indexed FASTA as a uint8 array (c3r_fasta_fetch: parallel pread,
+    line ends dropped, upper-cased) — `samtools faidx` without the subprocess or a pass in Python.  fai_row: (name, length, offset,
+    linebases, linewidth) as io.read_fai yields them."""
+    _name, length, offset, linebases, linewidth = fai_row
+    beg0 = max(0, int(beg0))
+    end0 = length if end0 is None else min(length, int(end0))
+    out = np.empty(max(0, end0 - beg0), np.uint8)
+    if out.size:
+        L = load_library()
+        L.c3r_fasta_fetch.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        rc = L.c3r_fasta_fetch(os.fsencode(ref_fn), offset, linebases, linewidth, beg0, end0, int(upper), threads, out.ctypes.data)
+        if rc != 0:
+            raise IOError("c3r_fasta_fetch(%s, %s): the file does not match its .fai" % (ref_fn, _name))
+    return out
+
+
+class VcfPiece(object):
+    """A run of whole lines compressed and indexed on its own (c3r_vcfz_piece_make; any thread) for VcfGzWriter.append."""
+
+    def __init__(self, text, threads=0):
+        L = load_library()
+        L.c3r_vcfz_piece_make.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        L.c3r_vcfz_piece_free.argtypes = [C.c_void_p]
+        L.c3r_vcfz_piece_free.restype = None
+        ptr, n, _keep = _text_ptr(text.encode() if isinstance(text, str) else text)
+        self.L, self.h, self.n = L, C.c_void_p(), n
+        rc = L.c3r_vcfz_piece_make(ptr, n, threads, C.byref(self.h))
+        if rc != 0:
+            raise IOError("c3r_vcfz_piece_make failed with %d (text must end in a newline)" % rc)
+
+    def free(self):
+        if self.h:
+            self.L.c3r_vcfz_piece_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class VcfGzWriter(object):
     """Streaming bgzip + tabix (c3r_vcfz_*): write() takes newline-terminated text in file order; close() leaves <path> (BGZF) and
     <path>.tbi — the bytes vcf_compress makes of the concatenated text; discard() removes what was written."""
@@ -142,7 +199,7 @@ class VcfGzWriter(object):
     def __init__(self, gz_path, threads=0):
         L = load_library()
         L.c3r_vcfz_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
-        L.c3r_vcfz_write.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.c3r_vcfz_write.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.c3r_vcfz_close.argtypes = [C.c_void_p, C.c_int]
         self.L, self.path, self.h = L, gz_path, C.c_void_p()
         rc = L.c3r_vcfz_open(os.fsencode(gz_path), threads, C.byref(self.h))
@@ -150,12 +207,22 @@ class VcfGzWriter(object):
             raise IOError("c3r_vcfz_open(%s) failed with %d" % (gz_path, rc))
 
     def write(self, text):
-        b = text.encode() if isinstance(text, str) else bytes(text)
-        if not b:
+        ptr, n, _keep = _text_ptr(text.encode() if isinstance(text, str) else text)
+        if not n:
             return
-        rc = self.L.c3r_vcfz_write(self.h, b, len(b))
+        rc = self.L.c3r_vcfz_write(self.h, ptr, n)
         if rc != 0:
             raise IOError("c3r_vcfz_write(%s) failed with %d (text must end in a newline)" % (self.path, rc))
+
+    def append(self, piece):
+        """A VcfPiece, in file order; the piece is consumed."""
+        self.L.c3r_vcfz_append.argtypes = [C.c_void_p, C.c_void_p]
+        try:
+            rc = self.L.c3r_vcfz_append(self.h, piece.h)
+        finally:
+            piece.free()
+        if rc != 0:
+            raise IOError("c3r_vcfz_append(%s) failed with %d" % (self.path, rc))
 
     def _end(self, keep):
         if self.h:

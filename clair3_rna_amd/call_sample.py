@@ -176,7 +176,7 @@ class _Fetcher(object):
 
     def __init__(self, bam_fn, ref_fn):
         self.bam_fn, self.ref_fn, self.tls = bam_fn, ref_fn, threading.local()
-        self.handles = []
+        self.handles, self.fai = [], None
 
     def __call__(self, ctg, length):
         t0 = time()
@@ -189,7 +189,14 @@ class _Fetcher(object):
                 bf = self.tls.bf = bamio.BamFile(self.bam_fn, threads=int(os.environ.get("C3R_FETCH_INFLATE", "8")))
                 self.handles.append(bf)
             rs = bf.fetch(ctg)
-        ref = io.fetch_reference(self.ref_fn, ctg, 1, length, raw=True) if len(rs.reads) else b""
+        ref = b""
+        if len(rs.reads):
+            # the whole contig, upper-cased, line ends dropped, by parallel pread (c3r_fasta_fetch) — a 250-Mb chromosome went
+            # through Python's bytes.replace in 0.4 s with the GIL held, which stalled every other thread of the process
+            from . import bamio
+            if self.fai is None:
+                self.fai = {r[0]: r for r in io.read_fai(self.ref_fn)}
+            ref = bamio.fasta_fetch(self.ref_fn, self.fai[ctg], 0, length)
         return rs, ref, time() - t0
 
     def close(self):
@@ -300,7 +307,7 @@ def Run(args, log=None):
                        splice_padding=int(args.enable_padding_in_splice_junction_regions), genotyping_mode=int(vcf_fn is not None))
         t = [time()]
         eng.load_reads(rs); t.append(time())
-        eng.set_reference(1, ref); t.append(time())
+        eng.set_reference(1, ref, upper_view=not isinstance(ref, (bytes, str))); t.append(time())      # (the fetcher's array: upper-cased, used in place)
         if vcf_fn is None:
             eng.begin_batch()
             n = eng.scan_regions(regions)
@@ -400,8 +407,9 @@ def Run(args, log=None):
         return r
 
     def context_task(eng, ctg, fut):
-        """One contig on one context, on that context's own thread: host preparation + uploads, tensor build, network, decode.
-        Contexts work side by side — while one waits for its kernels another normalises CIGARs or decodes."""
+        """One contig on the context whose thread took it from the queue (contigs are taken in calling order by whichever context
+        is free): host preparation + uploads, tensor build, network, snapshot.  Contexts work side by side — while one waits for
+        its kernels another queues its uploads and scans."""
         try:
             rs, ref, dt = fut.result()
             if not len(rs.reads):
@@ -433,7 +441,9 @@ def Run(args, log=None):
                 # while a decode worker turns the snapshot into rows and — single process — merges them (c3r_vcf_merge)
                 snap = eng.rows_begin()
                 mark(ctg, "snapshot", t1)
-                return decode_pool.submit(decode_task, snap, ctg)      # (the look-ahead slot is free: the fetched arrays are done with)
+                fut_d = decode_pool.submit(decode_task, snap, ctg)     # (the look-ahead slot is free: the fetched arrays are done with)
+                eng_decodes[engines.index(eng)].append(fut_d)
+                return fut_d
             rows = decode_stage(eng, ctg, todo)
             mark(ctg, "decode", t1)
             return rows
@@ -443,7 +453,8 @@ def Run(args, log=None):
     def decode_task(snap, ctg):
         try:
             t0 = time()
-            rows = snap.decode(ctg, qual=qual_rows, show_ref=args.print_ref_calls)[0]
+            # (rows stay a uint8 array from here to the compressed piece: no 100-MB bytes objects built under the GIL)
+            rows = snap.decode(ctg, qual=qual_rows, show_ref=args.print_ref_calls, as_array=world == 1)[0]
             mark(ctg, "decode", t0)
             if world == 1:
                 t1 = time()
@@ -454,13 +465,56 @@ def Run(args, log=None):
         finally:
             pass
 
+    def context_worker(k):
+        """Thread of context k: contigs from the shared queue until the end marker, then — once the decodes that still read this
+        context's snapshots are through — the context is released: device and page-locked memory go back while the last contigs
+        are still being decoded and written."""
+        eng = engines[k]
+        if reserve_sites and hasattr(eng, "reserve"):
+            # the network's buffers (8.9 GB for a full slice: 0.25-0.4 s of a first hipMalloc) while the first fetch is under way
+            t0 = time()
+            try:
+                eng.reserve(reserve_sites)
+            except Exception:
+                pass                      # (the first infer() sizes them, and reports whatever is wrong)
+            mark("ctx%d" % k, "reserve", t0)
+        while True:
+            item = ctx_queue.get()
+            if item is None:
+                break
+            ctg, fut, out = item
+            if not out.set_running_or_notify_cancel():          # (cancelled by the failure path, which released its slot)
+                continue
+            try:
+                out.set_result(context_task(eng, ctg, fut))
+            except BaseException as e:
+                out.set_exception(e)
+        t0 = time()
+        for f in list(eng_decodes[k]):
+            try:
+                f.result()
+            except BaseException:
+                pass                      # (reported by the main loop, which holds the same future)
+        if not stop.is_set():
+            eng.close()
+            mark("ctx%d" % k, "close", t0)
+
     work_err = None
     t_merge = 0.0
     results = []
     n_sites = t_fetch = t_dev = 0
     called = []
-    ctx_pools = [ThreadPoolExecutor(1) for _ in engines]
-    decode_pool = ThreadPoolExecutor(max(2, n_ctx + 1))                  # snapshots -> rows (-> merged records), beside the contexts
+    import queue
+    from concurrent.futures import Future
+    # candidates per kb of contig: ~3 on the synthetic GRCh38-sized samples, so a contig past ~50 Mb fills a whole network slice
+    reserve_sites = min(262144, int(max(fai[c] for c in contigs) * 0.005)) if contigs else 0
+    ctx_queue = queue.Queue()                                            # (contig, fetch future, result future) in calling order; None ends a worker
+    ctx_threads = [threading.Thread(target=context_worker, args=(k,), name="c3r-ctx%d" % k, daemon=True) for k in range(len(engines))]
+    # snapshots -> rows (-> merged records), beside the contexts.  A large contig's merge is 0.2-0.7 s on one thread when every
+    # candidate is a record: with n_ctx + 1 workers the snapshots queued up behind three merges (full-length GRCh38 timeline)
+    n_dec = int(os.environ.get("C3R_DECODE_WORKERS", "0")) or max(2, min(8, (n_thr if world > 1 else (os.cpu_count() or 8)) // 4))
+    decode_pool = ThreadPoolExecutor(n_dec)
+    eng_decodes = [[] for _ in engines]                                  # decode futures per context (its finish task waits for them)
     stop = threading.Event()
 
     def stop_workers():
@@ -468,8 +522,23 @@ def Run(args, log=None):
         contigs are cancelled, the running ones finish, and the feeder — possibly parked on a look-ahead slot that a cancelled task
         will never release — is told to stop and woken."""
         stop.set()
-        for p_ in ctx_pools + [decode_pool]:
-            p_.shutdown(wait=True, cancel_futures=True)
+        while True:                       # contigs no context has taken yet are cancelled; the running ones finish
+            try:
+                item = ctx_queue.get_nowait()
+            except queue.Empty:
+                break
+            if item is not None:
+                item[2].cancel()
+                try:
+                    slots.release()
+                except ValueError:
+                    pass
+        for _t in ctx_threads:
+            ctx_queue.put(None)
+        for t_ in ctx_threads:
+            if t_.is_alive():
+                t_.join()
+        decode_pool.shutdown(wait=True, cancel_futures=True)
         for _ in range(len(contigs) + n_ctx + args.fetch_threads + 2):
             try:
                 slots.release()
@@ -484,6 +553,8 @@ def Run(args, log=None):
             tasks = [None] * len(contigs)
             submitted = [threading.Event() for _ in contigs]
             feeder_err = []
+            for t_ in ctx_threads:
+                t_.start()
 
             def feeder():
                 try:
@@ -492,8 +563,11 @@ def Run(args, log=None):
                         if stop.is_set():
                             break
                         fut = fetch_pool.submit(fetch_task, c)
-                        tasks[i] = ctx_pools[i % n_ctx].submit(context_task, engines[i % n_ctx], c, fut)
+                        tasks[i] = Future()
+                        ctx_queue.put((c, fut, tasks[i]))
                         submitted[i].set()
+                    for _k in range(n_ctx):
+                        ctx_queue.put(None)
                 except BaseException as e:          # (e.g. the pools were shut down by a failure below)
                     feeder_err.append(e)
                 finally:
@@ -525,10 +599,13 @@ def Run(args, log=None):
             except BaseException:
                 stop_workers()           # before the fetch pool's own shutdown waits for fetches nobody will consume
                 raise
-        for p_ in ctx_pools + [decode_pool]:
-            p_.shutdown()
+        t0 = time()
+        for t_ in ctx_threads:
+            t_.join()
+        decode_pool.shutdown()
         n_sites, t_fetch, t_dev = stats["sites"], stats["fetch"], stats["dev"]
         fetcher.close()
+        mark("all", "shutdown", t0)
         called = [c for c, _f in results]
     except Exception as e:               # with several ranks: reach the rendezvous first, then every rank fails
         work_err = e
@@ -565,7 +642,9 @@ def Run(args, log=None):
                     merger.out.write(open(fn).read())
                     if merger.out_nt:
                         merger.out_nt.write(open(os.path.join(parts_dir, "%05d_nt.vcf" % k)).read())
+        t0 = time()
         n_read, n_kept, n_tag = merger.close(log)
+        mark("all", "close_out", t0)
         # tmp/CONTIGS and tmp/CHUNK_LIST as run_clair3_rna leaves them (:436-449): contigs without reads are dropped by its
         # `samtools idxstats` check (:184-210) before they are written; here that is known once the contig has been fetched
         with open(os.path.join(out_dir, "tmp", "CONTIGS"), "w") as f:

@@ -33,9 +33,9 @@ class C3RError(RuntimeError):
 
 
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
-           "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_host_alloc", "c3r_host_free", "c3r_set_reference", "c3r_set_bed", "c3r_set_sites",
+           "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_host_alloc", "c3r_host_free", "c3r_set_reference", "c3r_set_reference_view", "c3r_set_bed", "c3r_set_sites",
            "c3r_pileup_scan", "c3r_pileup_scan_regions", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
-           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_rows_begin", "c3r_rows_decode", "c3r_rows_get", "c3r_rows_free", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
+           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_reserve", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_rows_begin", "c3r_rows_decode", "c3r_rows_get", "c3r_rows_free", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
 _lib = None
@@ -68,7 +68,8 @@ def load_library():
     L.c3r_host_alloc.restype = vp
     L.c3r_host_free.argtypes = [vp]
     L.c3r_host_free.restype = None
-    L.c3r_set_reference.argtypes = [vp, i64, C.c_char_p, i64]
+    L.c3r_set_reference.argtypes = [vp, i64, vp, i64]
+    L.c3r_set_reference_view.argtypes = [vp, i64, vp, i64]
     L.c3r_set_bed.argtypes = [vp, i32, vp, i64]
     L.c3r_set_sites.argtypes = [vp, vp, i64]
     L.c3r_pileup_scan.argtypes = [vp, i64, i64, C.POINTER(i64)]
@@ -87,6 +88,7 @@ def load_library():
     L.c3r_set_precision.argtypes = [vp, i32]
     L.c3r_get_precision.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
     L.c3r_infer.argtypes = [vp, vp, i64, vp]
+    L.c3r_reserve.argtypes = [vp, i64]
     L.c3r_get_probs.argtypes = [vp, vp, i64]
     L.c3r_call_rows.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.c3r_get_rows.argtypes = [vp, vp, i64]
@@ -195,16 +197,24 @@ class Engine(object):
         self.readset = rs
         self._chk(self.L.c3r_load_reads(self.h, _ptr(rs.reads), len(rs.reads), _ptr(rs.cigar), len(rs.cigar), _ptr(rs.seq), len(rs.seq)))
 
-    def set_reference(self, ref_start, seq):
+    def set_reference(self, ref_start, seq, upper_view=False):
+        """seq: str, bytes, or a uint8 array (bamio.fasta_fetch) — an array is handed over by pointer, no copy on this side.
+        upper_view: the array is upper-cased already and is used in place (c3r_set_reference_view); this object and the row
+        snapshots taken from it keep the array alive for as long as the library reads it."""
+        if isinstance(seq, np.ndarray):
+            b = np.ascontiguousarray(seq, dtype=np.uint8)
+            self.ref_start, self._ref_bytes, self._ref_upper = ref_start, b, None
+            self._chk((self.L.c3r_set_reference_view if upper_view else self.L.c3r_set_reference)(self.h, ref_start, b.ctypes.data, b.size))
+            return
         b = seq.encode() if isinstance(seq, str) else (seq if isinstance(seq, bytes) else bytes(seq))
         self.ref_start, self._ref_bytes, self._ref_upper = ref_start, b, None
-        self._chk(self.L.c3r_set_reference(self.h, ref_start, b, len(b)))
+        self._chk(self.L.c3r_set_reference(self.h, ref_start, C.cast(C.c_char_p(b), C.c_void_p), len(b)))
 
     @property
     def ref_seq(self):
         """Upper-cased reference slice as str (debug dumps only: 40 ms per 64 MB contig, so built on demand)."""
         if self._ref_upper is None:
-            self._ref_upper = self._ref_bytes.decode().upper()
+            self._ref_upper = bytes(self._ref_bytes).decode().upper()
         return self._ref_upper
 
     def set_bed(self, which, intervals):
@@ -321,12 +331,17 @@ class Engine(object):
         self._chk(self.L.c3r_get_rows(self.h, buf, n.value + 1))
         return buf.raw[:n.value], nr.value
 
+    def reserve(self, n_sites):
+        """Size the network's device buffers for batches of up to n_sites candidates now rather than in the first infer()."""
+        self._chk(self.L.c3r_reserve(self.h, int(n_sites)))
+
     def rows_begin(self):
         """Detach the decode inputs of the resident batch (sites, tokens, probabilities, read bases; after infer()) into a host
         snapshot: the engine is free for the next contig, RowSnapshot.decode() may run on any thread."""
         h = C.c_void_p()
         self._chk(self.L.c3r_rows_begin(self.h, C.byref(h)))
         snap = RowSnapshot(self.L, h)
+        snap._ref_keep = getattr(self, "_ref_bytes", None)       # (c3r_set_reference_view: the decoder reads this array)
         self._snaps.add(snap)
         return snap
 
@@ -362,20 +377,22 @@ class RowSnapshot(object):
     """Host-side decode inputs of one batch (c3r_rows_begin); decode() needs no GPU and no engine."""
 
     def __init__(self, L, h):
-        self.L, self.h = L, h
+        self.L, self.h, self._ref_keep = L, h, None
 
-    def decode(self, ctg, qual=2, show_ref=True):
-        """-> (bytes of newline-terminated VCF rows, number of rows); releases the snapshot."""
+    def decode(self, ctg, qual=2, show_ref=True, as_array=False):
+        """-> (bytes of newline-terminated VCF rows, number of rows); releases the snapshot.  as_array: the rows as a uint8 array
+        instead (a large contig's rows are ~100 MB: turning them into a bytes object is a copy made with the GIL held, which
+        stalls every other thread of a whole-sample run)."""
         try:
             n, nr = C.c_int64(0), C.c_int64(0)
             rc = self.L.c3r_rows_decode(self.h, ctg.encode(), -1 if qual is None else int(qual), int(show_ref), C.byref(n), C.byref(nr))
             if rc != 0:
                 raise C3RError(rc, "c3r_rows_decode failed")
-            buf = C.create_string_buffer(n.value + 1)
-            rc = self.L.c3r_rows_get(self.h, buf, n.value + 1)
+            buf = np.empty(n.value + 1, np.uint8)
+            rc = self.L.c3r_rows_get(self.h, buf.ctypes.data, n.value + 1)
             if rc != 0:
                 raise C3RError(rc, "c3r_rows_get failed")
-            return buf.raw[:n.value], nr.value
+            return (buf[:n.value] if as_array else buf[:n.value].tobytes()), nr.value
         finally:
             self.free()
 
@@ -383,6 +400,7 @@ class RowSnapshot(object):
         if self.h:
             self.L.c3r_rows_free(self.h)
             self.h = None
+        self._ref_keep = None
 
     def __del__(self):
         try:

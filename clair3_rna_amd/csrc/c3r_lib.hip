@@ -382,20 +382,31 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    const bool timing = getenv("C3R_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_rcnt, &ctx->d_rend, &ctx->d_pass, &ctx->d_ekey, &ctx->d_ekey2, &ctx->d_skey, &ctx->d_skey2, &ctx->d_sval, &ctx->d_sval2,
                       &ctx->d_sorttmp, &ctx->d_s4tops, &ctx->d_pmtops, &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
-    for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    int n_dev = 0; size_t b_dev = 0, b_pin = 0;
+    for (DevBuf *b : bufs) if (b->p) { (void)hipFree(b->p); ++n_dev; b_dev += b->cap; }
+    const auto t1 = std::chrono::steady_clock::now();
     net_free(ctx->net);
+    const auto t2 = std::chrono::steady_clock::now();
     if (ctx->rows_snap) c3r_rows_free(ctx->rows_snap);
-    for (auto &sp : ctx->stage_pool) (void)hipHostFree(sp.first);
+    for (auto &sp : ctx->stage_pool) { (void)hipHostFree(sp.first); b_pin += sp.second; }
     if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
-    for (auto &rb : ctx->refbuf) { if (rb.p) (void)hipHostFree(rb.p); if (rb.ev) (void)hipEventDestroy(rb.ev); }
+    for (auto &rb : ctx->refbuf) { if (rb.p) { (void)hipHostFree(rb.p); b_pin += rb.cap; } if (rb.ev) (void)hipEventDestroy(rb.ev); }
+    const auto t3 = std::chrono::steady_clock::now();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    if (timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[c3r_destroy %p] %d device buffers (%.0f MB) %.1f ms, network buffers %.1f ms, page-locked (%.0f MB) %.1f ms, events + stream %.1f ms\n",
+                (void *)ctx, n_dev, b_dev / 1e6, ms(t0, t1), ms(t1, t2), b_pin / 1e6, ms(t2, t3), ms(t3, std::chrono::steady_clock::now()));
+    }
     delete ctx;
 }
 
@@ -593,6 +604,22 @@ int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t 
     if (rc) return rc;
     if (len) HIPCHK(ctx, hipMemcpyAsync(ctx->d_ref.p, ctx->h_ref, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipEventRecord(rb.ev, ctx->stream));
+    ctx->ref_len = (size_t)len;
+    return C3R_OK;
+}
+
+int c3r_set_reference_view(c3r_ctx *ctx, int64_t ref_start, const char *ref_upper, int64_t len) {
+    if (!ctx || !ref_upper || len < 0 || ref_start < 1) return C3R_EINVAL;
+    ctx->last_scan_pruned = false;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // Nothing is copied on the host: the decoder reads the caller's bytes (kept alive and unchanged by the caller, see c3r.h) and the
+    // upload takes them as they are — from pageable memory the runtime stages the copy itself and returns once the bytes have left.
+    ctx->ref_len = 0;
+    ctx->ref_cur = -1; ctx->h_ref = const_cast<char *>(ref_upper);
+    ctx->ref_start1 = ref_start;
+    int rc = ensure(ctx, ctx->d_ref, std::max<size_t>((size_t)len, 16));
+    if (rc) return rc;
+    if (len) HIPCHK(ctx, hipMemcpyAsync(ctx->d_ref.p, ref_upper, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
     ctx->ref_len = (size_t)len;
     return C3R_OK;
 }
@@ -1350,6 +1377,17 @@ int c3r_get_precision(c3r_ctx *ctx, int *mode_in_use, double *calibration_err) {
     if (!ctx) return C3R_EINVAL;
     if (mode_in_use) *mode_in_use = ctx->net.precision;
     if (calibration_err) *calibration_err = ctx->mx_calib_err;
+    return C3R_OK;
+}
+
+int c3r_reserve(c3r_ctx *ctx, int64_t n_sites) {
+    if (!ctx || n_sites < 0) return C3R_EINVAL;
+    if (!ctx->net.loaded) return fail(ctx, C3R_EINVAL, "c3r_load_weights must be called before c3r_reserve");
+    if (n_sites == 0) return C3R_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string e;
+    int rc = net_reserve(ctx->net, n_sites, ctx->stream, e);
+    if (rc) return fail(ctx, rc, "%s", e.c_str());
     return C3R_OK;
 }
 

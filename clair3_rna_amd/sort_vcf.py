@@ -188,8 +188,8 @@ class SampleMerger(object):
         if self.native is False:
             raise RuntimeError("merge_only needs the native merge")
         from . import bamio
-        blob = rows.encode() if isinstance(rows, str) else bytes(rows)
-        if not blob:
+        blob = rows.encode() if isinstance(rows, str) else (rows if hasattr(rows, "ctypes") else bytes(rows))     # (uint8 array: by pointer)
+        if not len(blob):
             return None
         edits = None
         if self.rediportal:
@@ -199,7 +199,12 @@ class SampleMerger(object):
                     for (c, pos), hit in self.rediportal.items():
                         self._edits.setdefault(c, []).append((pos, hit[0], hit[1]))
             edits = self._edits.get(contig)
-        return bamio.vcf_merge(blob, self.qual, self.show_ref, edits, self.out_nt is not None)
+        merged, merged_nt, counts = bamio.vcf_merge(blob, self.qual, self.show_ref, edits, self.out_nt is not None)
+        if self.stream_gz:
+            # compressed and indexed here, on the worker (bamio.VcfPiece): write_merged only appends the finished blocks
+            merged = bamio.VcfPiece(merged) if merged is not None and len(merged) else None
+            merged_nt = bamio.VcfPiece(merged_nt) if merged_nt is not None and len(merged_nt) else None
+        return merged, merged_nt, counts
 
     def write_merged(self, res):
         if res is None:
@@ -209,9 +214,13 @@ class SampleMerger(object):
         self.n_read += n_read
         self.n_kept += n_kept
         self.n_tagged += n_tag
-        self.out.write(merged if self.stream_gz else merged.decode())
-        if self.out_nt:
-            self.out_nt.write(merged_nt if self.stream_gz else merged_nt.decode())
+        for out, m in ((self.out, merged), (self.out_nt, merged_nt)):
+            if out is None or m is None:
+                continue
+            if hasattr(m, "free"):
+                out.append(m)
+            elif len(m):
+                out.write(m if self.stream_gz else (m.tobytes() if hasattr(m, "tobytes") else m).decode())
 
     def _header(self):
         if not self.header_done:

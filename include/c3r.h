@@ -78,6 +78,11 @@ void c3r_host_free(void *p);
  * replaces reference_sequence_from / `samtools faidx` (shared/utils.py:168-194,
  * src/create_tensor_pileup.py:424-428).  Upper-cased on upload like the reference does. */
 int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t len);
+/* The same for a slice the caller already holds UPPER-CASED (c3r_fasta_fetch, include/c3r_io.h) and keeps alive and unchanged until
+ * the context has been given another reference AND every row snapshot (c3r_rows_begin) taken meanwhile has been freed: no host copy
+ * is made — the upload reads the caller's bytes and so does the decoder.  (c3r_set_reference's pass over a 250-Mb chromosome is
+ * 40-250 ms of the calling thread.) */
+int c3r_set_reference_view(c3r_ctx *ctx, int64_t ref_start, const char *ref_upper, int64_t len);
 /* Optional interval filters, 0-based half-open, for the current contig.  which=0: `-l` column
  * filter (mpileup -l extend_bed, src/create_tensor_pileup.py:443); which=1: confident-bed candidate
  * filter (is_region_in, src/create_tensor_pileup.py:551-554).  n=0 clears. */
@@ -136,6 +141,10 @@ int64_t c3r_weight_count(int channels);
 int c3r_set_precision(c3r_ctx *ctx, int mode);
 /* The mode the network runs in (after "auto" has decided) and the calibration's max |dP| (-1: not measured). */
 int c3r_get_precision(c3r_ctx *ctx, int *mode_in_use, double *calibration_err);
+/* Optional: size the network's device buffers for batches of up to n_sites candidates now (after c3r_load_weights) instead of
+ * inside the first c3r_infer.  The layer-1 output of a full 2^18-site slice is 8.9 GB, and a first hipMalloc of that size takes
+ * 0.25-0.4 s: a caller that is still waiting for its input (a BAM fetch) spends them here for free. */
+int c3r_reserve(c3r_ctx *ctx, int64_t n_sites);
 /* Forward pass over tensors.  tensors==NULL: use the device-resident tensors of the last scan.
  * Otherwise `tensors` is a host int32 [n][33][C] array.  probs (host, [n][24]) may be NULL to keep
  * the result on the device only.  Replaces m.predict_on_batch (clair3_rna/call_variants.py:1505). */

@@ -76,6 +76,23 @@ typedef struct c3r_vcfz c3r_vcfz;
 int c3r_vcfz_open(const char *gz_path, int threads, c3r_vcfz **out);
 int c3r_vcfz_write(c3r_vcfz *z, const char *text, int64_t n_bytes);
 int c3r_vcfz_close(c3r_vcfz *z, int keep);
+/* Pieces: c3r_vcfz_piece_make compresses and indexes a run of whole lines (one contig's merged records) on its own — any thread, no
+ * writer involved — and c3r_vcfz_append puts it into the file in calling order: the bytes written so far are closed into a block of
+ * their own, the piece's blocks follow, its index entries are shifted to where it landed.  Same decompressed text and an equally
+ * valid index as feeding the lines through c3r_vcfz_write, different block boundaries; only the append stays on the ordering thread.
+ * A piece may be appended once and is freed by the caller. */
+typedef struct c3r_vcfz_piece c3r_vcfz_piece;
+int c3r_vcfz_piece_make(const char *text, int64_t n_bytes, int threads, c3r_vcfz_piece **out);
+int c3r_vcfz_append(c3r_vcfz *z, const c3r_vcfz_piece *piece);
+void c3r_vcfz_piece_free(c3r_vcfz_piece *piece);
+
+/* ---- reference side: `samtools faidx <fasta> ctg:beg-end` (shared/utils.py:168-193 reference_sequence_from) for an uncompressed,
+ * faidx-indexed FASTA.  The caller passes the contig's .fai geometry (file offset of its first base, bases per line, bytes per line
+ * including the line end); bases [beg0, end0) (0-based, half-open, inside the contig) are written to out[0, end0 - beg0) with the line
+ * ends dropped, upper-cased when `upper` (the reference upper-cases, :185), read with pread on `threads` threads (<= 0: up to 8).
+ * C3R_EINVAL when the file is shorter than the index says or a line does not end where the index says it does. */
+int c3r_fasta_fetch(const char *path, int64_t offset, int32_t linebases, int32_t linewidth, int64_t beg0, int64_t end0, int upper,
+                    int threads, uint8_t *out);
 
 #ifdef __cplusplus
 }

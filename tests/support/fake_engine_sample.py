@@ -28,8 +28,8 @@ class FakeEngine(object):
     def set_bed(self, which, iv): pass
     def set_params(self, **kw): self.kw = kw
     def set_sites(self, sites): self.sites = list(sites)
-    def set_reference(self, start, seq):
-        self.ref = seq if isinstance(seq, bytes) else seq.encode()
+    def set_reference(self, start, seq, upper_view=False):
+        self.ref = seq if isinstance(seq, bytes) else (seq.encode() if isinstance(seq, str) else bytes(seq))
         if os.environ.get("C3R_FAKE_FAIL_LEN") == str(len(self.ref)):       # test hook: this contig's device stage fails
             raise RuntimeError("stand-in engine: injected failure on the contig of length %d" % len(self.ref))
 

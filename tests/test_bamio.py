@@ -57,7 +57,7 @@ def bam_case(tmp_path_factory):
 
 def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "c3r_io.h")).read()
-    declared = sorted(set(re.findall(r"\b(c3r_(?:bam|vcfz?)_[a-z_0-9]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(c3r_(?:bam|vcfz?|fasta)_[a-z_0-9]+)\s*\(", hdr)))
     lib = bamio.load_library()
     assert declared and not [s for s in declared if not hasattr(lib, s)]
     assert sorted(bamio.EXPORTS) == declared

@@ -148,3 +148,38 @@ def test_row_snapshots_survive_the_next_contigs(eng):
     # every snapshot released its reference buffer: the context takes new references without waiting
     for ref, rs, _ in cases[:3]:
         eng.set_reference(1, ref)
+
+
+def test_reference_view_equals_the_copied_reference(eng):
+    """c3r_set_reference_view (the caller's upper-cased array used in place, no host copy) gives the sites, tensors and rows of
+    c3r_set_reference; more snapshots than a context has reference buffers may be outstanding, each keeping its own array alive
+    after the caller has dropped it."""
+    import gc
+    import numpy as np
+    from clair3_rna_amd import capi, synth
+    w = synth.random_weights(18, seed=78)
+    cases = [synth.small_case(seed=400 + k, ref_len=26000 + 3000 * k, n_genes=5 + k % 3, depth=16) for k in range(5)]
+    eng.params = capi.default_params()
+    eng.set_params(); eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.load_weights(w, 18); eng.set_precision("f16x3")
+    want, snaps = [], []
+    for ref, rs, _ in cases:
+        eng.load_reads(rs); eng.set_reference(1, ref.lower())          # (the copying entry point upper-cases)
+        assert eng.scan(1, len(ref)) > 20
+        tens = eng.tensors().copy()
+        eng.infer(fetch=False)
+        want.append((eng.sites().tobytes(), tens.tobytes(), eng.call_rows_text("chr20", qual=2, show_ref=True)))
+    for k, (ref, rs, _) in enumerate(cases):
+        arr = np.frombuffer(ref.upper().encode(), dtype=np.uint8).copy()
+        eng.load_reads(rs); eng.set_reference(1, arr, upper_view=True)
+        del arr
+        gc.collect()
+        assert eng.scan(1, len(ref)) > 20
+        assert (eng.sites().tobytes(), eng.tensors().tobytes()) == want[k][:2]
+        eng.infer(fetch=False)
+        snaps.append(eng.rows_begin())
+    eng.set_reference(1, cases[0][0])                                 # the engine's own hold on the last array is gone too
+    gc.collect()
+    junk = [np.full(40000, 78, np.uint8) for _ in range(64)]           # (freed arrays would be reused by these)
+    got = [sn.decode("chr20", qual=2, show_ref=True) for sn in snaps]
+    assert got == [x[2] for x in want] and junk

@@ -55,3 +55,46 @@ def test_vcf_header_contract(tmp_path):
     out = str(tmp_path / "o.vcf")
     assert vcf.write_chunk_vcf(out, "\n".join(h), []) is False and not os.path.exists(out)
     assert vcf.write_chunk_vcf(out, "\n".join(h), ["chr20\t5\t.\tA\tG\t9.00\tPASS\t.\tGT\t0/1"]) and os.path.exists(out)
+
+
+def test_native_fasta_fetch_equals_the_python_slice(tmp_path):
+    """c3r_fasta_fetch (parallel pread over the .fai geometry) against io.fetch_reference: random slices of a contig that spans
+    several pread pieces, lower-case input, CRLF line ends, a last line without its newline; a .fai that does not match the
+    file is an error, not a shifted sequence."""
+    import pytest
+    from clair3_rna_amd import bamio
+    rng = np.random.default_rng(8)
+    big = "".join(rng.choice(list("ACGTacgtNn"), size=9_000_001).tolist())
+    fa = str(tmp_path / "r.fa")
+    io.write_fasta(fa, [("c1", "acgtn" * 21), ("big", big), ("tail", "ACGTTGCA" * 9 + "AC")], width=70)
+    with open(fa, "rb+") as f:                                  # drop the file's last newline
+        f.seek(-1, 2)
+        assert f.read(1) == b"\n"
+        f.seek(-1, 2)
+        f.truncate()
+    fai = {r[0]: r for r in io.read_fai(fa)}
+    assert bamio.fasta_fetch(fa, fai["big"]).tobytes().decode() == big.upper()
+    assert bamio.fasta_fetch(fa, fai["big"], upper=False).tobytes().decode() == big
+    assert bamio.fasta_fetch(fa, fai["tail"]).tobytes() == b"ACGTTGCA" * 9 + b"AC"
+    assert bamio.fasta_fetch(fa, fai["c1"], 2, 12).tobytes().decode() == ("ACGTN" * 21)[2:12]
+    assert bamio.fasta_fetch(fa, fai["c1"], 50, 50).size == 0
+    for _ in range(40):
+        a = int(rng.integers(0, len(big)))
+        b = int(min(len(big), a + rng.integers(1, 300_000)))
+        for thr in (1, 3):
+            assert bamio.fasta_fetch(fa, fai["big"], a, b, threads=thr).tobytes().decode() == io.fetch_reference(fa, "big", a + 1, b)
+    # CRLF line ends
+    fa2 = str(tmp_path / "crlf.fa")
+    seq = "".join(rng.choice(list("ACGT"), size=1000).tolist())
+    with open(fa2, "wb") as f:
+        f.write(b">x\r\n")
+        off = f.tell()
+        for i in range(0, len(seq), 60):
+            f.write(seq[i:i + 60].encode() + b"\r\n")
+    row = ("x", len(seq), off, 60, 62)
+    assert bamio.fasta_fetch(fa2, row).tobytes().decode() == seq
+    assert bamio.fasta_fetch(fa2, row, 59, 121).tobytes().decode() == seq[59:121]
+    # an index that does not describe the file
+    for bad in (("x", len(seq), off, 61, 63), ("x", len(seq), off, 60, 61), ("x", len(seq) + 500, off, 60, 62), ("x", len(seq), off + 1, 60, 62)):
+        with pytest.raises(IOError):
+            bamio.fasta_fetch(fa2, bad)

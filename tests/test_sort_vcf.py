@@ -69,8 +69,6 @@ def test_cli_empty_inputs_and_bgzf_output(tmp_path):
 def test_bgzf_and_tabix_index_read_back(tmp_path):
     """compress_vcf: the .tbi (TBI v1, VCF preset) must lead a reader from a region to exactly the records overlapping it."""
     import random
-    import struct
-    import zlib
     rng = random.Random(5)
     hdr = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"
     recs = []
@@ -83,13 +81,20 @@ def test_bgzf_and_tabix_index_read_back(tmp_path):
     open(path, "w").write(hdr + "".join(r[3] for r in recs))
     gz = sort_vcf.compress_vcf(path)
     assert not os.path.exists(path) and gzip.open(gz, "rt").read() == hdr + "".join(r[3] for r in recs)
+    _check_tabix_read_back(gz, recs, ["chr1", "chr2", "chrM"], rng)
+
+
+def _check_tabix_read_back(gz, recs, names_want, rng, n_queries=40):
+    """Parse <gz>.tbi (TBI v1, VCF preset) and follow it, BGZF block by block, from random regions to exactly the records overlapping them."""
+    import struct
+    import zlib
     raw = open(gz, "rb").read()
     tbi = gzip.open(gz + ".tbi", "rb").read()
     assert tbi[:4] == b"TBI\x01"
     n_ref, fmt, cs, cb, ce, meta, skip, l_nm = struct.unpack_from("<8i", tbi, 4)
     assert (fmt, cs, cb, ce, meta, skip) == (2, 1, 2, 0, ord("#"), 0)
     names = tbi[36:36 + l_nm].split(b"\x00")[:-1]
-    assert [n.decode() for n in names] == ["chr1", "chr2", "chrM"]
+    assert [n.decode() for n in names] == names_want
     o = 36 + l_nm
     index = {}
     for nm in names:
@@ -124,8 +129,8 @@ def test_bgzf_and_tabix_index_read_back(tmp_path):
             out += list(range(off + (beg >> sh), off + (end >> sh) + 1))
         return out
 
-    for _ in range(40):
-        ctg = rng.choice(["chr1", "chr2", "chrM"])
+    for _ in range(n_queries):
+        ctg = rng.choice(names_want)
         beg = rng.randint(0, 3000000); end = beg + rng.choice([1, 100, 20000, 700000])
         bins, lin = index[ctg]
         lo = lin[min(beg >> 14, len(lin) - 1)] if lin else 0
@@ -265,3 +270,75 @@ def test_streaming_compressor_equals_whole_file_compressor(tmp_path):
             sort_vcf.compress_vcf(str(b))
         assert (tmp_path / ("m_%s_a.vcf.gz" % label)).read_bytes() == (tmp_path / ("m_%s_b.vcf.gz" % label)).read_bytes()
         assert (tmp_path / ("m_%s_a.vcf.gz.tbi" % label)).read_bytes() == (tmp_path / ("m_%s_b.vcf.gz.tbi" % label)).read_bytes()
+
+
+def test_pieces_compressed_on_their_own_give_the_same_text_and_a_valid_index(tmp_path):
+    """bamio.VcfPiece + VcfGzWriter.append (a contig's records compressed and indexed on a worker, appended in order): the file
+    inflates to the concatenated text, the .tbi leads from regions to exactly their records — across pieces mixed with plain
+    write() calls, a piece holding two contigs, an empty piece, pieces ending on a block boundary — and SampleMerger's
+    merge_only / write_merged (the whole-sample driver's path) writes the text of add_contig."""
+    import random
+    from clair3_rna_amd import bamio
+    rng = random.Random(11)
+    hdr = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"
+    recs, by_ctg = [], {}
+    for ctg, n in (("chr1", 6000), ("chr2", 2500), ("chr3", 1), ("chr4", 3000), ("chr5", 1800)):
+        for p in sorted(rng.sample(range(1, 3000000), n)):
+            ref = "ACGT"[p % 4] + "".join(rng.choice("ACGT") for _ in range(rng.choice([0, 0, 0, 1, 5, 40])))
+            recs.append((ctg, p, ref, "%s\t%d\t.\t%s\tG\t%.2f\tPASS\t.\tGT:GQ\t0/1:%d\n" % (ctg, p, ref, rng.uniform(3, 40), rng.randint(0, 40))))
+            by_ctg.setdefault(ctg, []).append(recs[-1][3])
+    # chr5: padded so that its text is a whole number of blocks (its last block is full, the next piece starts on the boundary)
+    t5 = "".join(by_ctg["chr5"])
+    gz = str(tmp_path / "p.vcf.gz")
+    z = bamio.VcfGzWriter(gz, threads=2)
+    z.write(hdr)
+    c1 = by_ctg["chr1"]
+    z.append(bamio.VcfPiece("".join(c1[:2500]), threads=3))           # one contig over two pieces and a plain write
+    z.write("".join(c1[2500:2600]))
+    z.append(bamio.VcfPiece("".join(c1[2600:])))
+    z.append(bamio.VcfPiece(""))
+    z.append(bamio.VcfPiece("".join(by_ctg["chr2"]) + "".join(by_ctg["chr3"])))     # two contigs in one piece
+    z.write("".join(by_ctg["chr4"][:7]))
+    z.write("".join(by_ctg["chr4"][7:]))
+    z.append(bamio.VcfPiece(t5))
+    z.close()
+    with pytest.raises(IOError):
+        bamio.VcfPiece("chr1\t5\t.\tA\tC")
+    assert gzip.open(gz, "rt").read() == hdr + "".join(r[3] for r in recs)
+    _check_tabix_read_back(gz, recs, ["chr1", "chr2", "chr3", "chr4", "chr5"], rng, n_queries=120)
+    # a piece whose length is a whole number of blocks, followed by another piece
+    line = "chr9\t%d\t.\tA\tG\t30.00\tPASS\t.\tGT\t0/1\n"
+    rows, tot, k = [], 0, 1
+    while tot + 3 * len(line % k) < 2 * 0xff00:
+        rows.append(("chr9", k, "A", line % k)); tot += len(line % k); k += 1
+    pre = "chr9\t%d\t.\tA\tG\t30.00\tPASS\t" % k
+    rows.append(("chr9", k, "A", pre + "x" * (2 * 0xff00 - tot - len(pre) - 1) + "\n")); tot += len(rows[-1][3]); k += 1
+    assert tot == 2 * 0xff00
+    more = [("chr9", k + j, "A", line % (k + j)) for j in range(50)]
+    gz2 = str(tmp_path / "q.vcf.gz")
+    z = bamio.VcfGzWriter(gz2)
+    z.append(bamio.VcfPiece("".join(r[3] for r in rows)))
+    z.append(bamio.VcfPiece("".join(r[3] for r in more)))
+    z.close()
+    assert gzip.open(gz2, "rt").read() == "".join(r[3] for r in rows + more)
+    _check_tabix_read_back(gz2, rows + more, ["chr9"], rng, n_queries=30)
+    # the driver's path: merge_only on workers, write_merged in order == add_contig
+    header = hdr
+    outs = []
+    kept = [r for r in recs if r[0] in ("chr1", "chr2", "chr4") and r[2] != "G"]       # (REF == ALT is a reference call: dropped by the merge)
+    for mode in ("pieces", "plain"):
+        fn = str(tmp_path / ("m_%s.vcf" % mode))
+        m = sort_vcf.SampleMerger(fn, header, 2, False, None, None, stream_gz=True)
+        for ctg in ("chr1", "chr2", "chr4"):
+            rows_ = "".join(by_ctg[ctg])
+            if mode == "pieces":
+                res = m.merge_only(ctg, rows_)
+                assert hasattr(res[0], "free")
+                m.write_merged(res)
+            else:
+                m.add_contig(ctg, rows_)
+        m.close(log=lambda _m: None)
+        assert m.streamed
+        outs.append(gzip.open(fn + ".gz", "rt").read())
+        _check_tabix_read_back(fn + ".gz", kept, ["chr1", "chr2", "chr4"], rng, n_queries=40)
+    assert outs[0] == outs[1] == header + "".join(r[3] for r in kept)
