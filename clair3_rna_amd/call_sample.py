@@ -576,6 +576,17 @@ def Run(args, log=None):
 
             feed = threading.Thread(target=feeder, name="c3r-feeder", daemon=True)
             feed.start()
+
+            def close_fetcher():
+                """The BAM handles (the mapped file, the record buffers of the largest contig each thread fetched) go as soon as
+                the last fetch is through, beside the contexts' last contigs."""
+                feed.join()
+                fetch_pool.shutdown(wait=True)          # (every fetch has been submitted; the with-block's own shutdown is then a no-op)
+                t0_ = time()
+                fetcher.close()
+                mark("all", "bam_close", t0_)
+            closer = threading.Thread(target=close_fetcher, name="c3r-closer", daemon=True)
+            closer.start()
             try:
                 for i, ctg in enumerate(contigs):                          # merge in calling order as the contigs come out
                     submitted[i].wait()
@@ -604,7 +615,7 @@ def Run(args, log=None):
             t_.join()
         decode_pool.shutdown()
         n_sites, t_fetch, t_dev = stats["sites"], stats["fetch"], stats["dev"]
-        fetcher.close()
+        closer.join()
         mark("all", "shutdown", t0)
         called = [c for c, _f in results]
     except Exception as e:               # with several ranks: reach the rendezvous first, then every rank fails

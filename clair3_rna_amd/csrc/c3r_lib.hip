@@ -1,6 +1,7 @@
 // c3r_lib.hip — host side of libc3r.so: the C-ABI of include/c3r.h over the gfx950 kernels.
 // No CPU fallback: every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <queue>
 #include <chrono>
 
@@ -84,7 +85,7 @@ struct c3r_ctx {
     char *h_ref = nullptr; size_t ref_len = 0;                    // = refbuf[ref_cur].p
     int64_t ref_start1 = 1;
     std::mutex pool_mu;                                           // guards stage_pool (snapshots are released from other threads)
-    std::vector<std::pair<void *, size_t>> stage_pool;            // page-locked staging blocks of released row snapshots
+    std::vector<std::pair<void *, size_t>> stage_pool;            // staging blocks of released row snapshots (stage_pinned())
     c3r_rows *rows_snap = nullptr;                                // c3r_call_rows keeps its snapshot here for c3r_get_rows
     DevBuf d_ref;
     std::vector<int32_t> h_bed[2];
@@ -163,6 +164,16 @@ inline int poison_byte() {
     static const int v = [] { const char *e = getenv("C3R_POISON"); return e && *e ? atoi(e) & 0xff : -1; }();
     return v;
 }
+
+// Staging blocks of row snapshots (sites | tokens | probabilities of one batch, ~0.3 GB for a large contig): ordinary memory by
+// default — the runtime stages the three copies (~30 ms for a large contig), but nothing has to be pinned on the first contigs and
+// unpinned when the context goes (0.1 ms per MB each way: 22 full-length contigs ran 3.4 s against 3.6-3.8 s with page-locked
+// blocks).  C3R_SNAPSHOT_PINNED=1 takes page-locked blocks.
+inline bool stage_pinned() {
+    static const bool v = [] { const char *e = getenv("C3R_SNAPSHOT_PINNED"); return e && *e == '1'; }();
+    return v;
+}
+inline void stage_free(void *p) { if (!p) return; if (stage_pinned()) (void)hipHostFree(p); else free(p); }
 
 int ensure(c3r_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return C3R_OK;
@@ -394,7 +405,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     net_free(ctx->net);
     const auto t2 = std::chrono::steady_clock::now();
     if (ctx->rows_snap) c3r_rows_free(ctx->rows_snap);
-    for (auto &sp : ctx->stage_pool) { (void)hipHostFree(sp.first); b_pin += sp.second; }
+    for (auto &sp : ctx->stage_pool) { stage_free(sp.first); b_pin += sp.second; }
     if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
     for (auto &rb : ctx->refbuf) { if (rb.p) { (void)hipHostFree(rb.p); b_pin += rb.cap; } if (rb.ev) (void)hipEventDestroy(rb.ev); }
@@ -404,7 +415,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     if (timing) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[c3r_destroy %p] %d device buffers (%.0f MB) %.1f ms, network buffers %.1f ms, page-locked (%.0f MB) %.1f ms, events + stream %.1f ms\n",
+        fprintf(stderr, "[c3r_destroy %p] %d device buffers (%.0f MB) %.1f ms, network buffers %.1f ms, host blocks (%.0f MB) %.1f ms, events + stream %.1f ms\n",
                 (void *)ctx, n_dev, b_dev / 1e6, ms(t0, t1), ms(t1, t2), b_pin / 1e6, ms(t2, t3), ms(t3, std::chrono::steady_clock::now()));
     }
     delete ctx;
@@ -1466,7 +1477,7 @@ int c3r_decode_text(const char *ctg, int64_t n, const int32_t *pos, const char *
 }  // extern "C"
 struct c3r_rows {
     c3r_ctx *ctx = nullptr;
-    void *stage = nullptr; size_t stage_cap = 0;          // page-locked: sites | tokens | probabilities
+    void *stage = nullptr; size_t stage_cap = 0;          // sites | tokens | probabilities
     int64_t n = 0, n_tok = 0;
     c3r_site_t *sites = nullptr; c3r_token_t *toks = nullptr; float *probs = nullptr;
     std::vector<DevRead> reads; std::vector<uint8_t> seq;  // the contig's read headers and packed bases (inserted bases of the alt alleles)
@@ -1495,13 +1506,27 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     }
     if (!r->stage) {
         const size_t cap = need * 5 / 4 + 4096;
-        if (hipHostMalloc(&r->stage, cap, hipHostMallocDefault) != hipSuccess) { delete r; return fail(ctx, C3R_ENOMEM, "hipHostMalloc(%zu) failed", cap); }
+        if (stage_pinned()) { if (hipHostMalloc(&r->stage, cap, hipHostMallocDefault) != hipSuccess) r->stage = nullptr; }
+        else {
+            // 2-MB aligned and advised huge: a fresh 0.5-GB block is touched for the first time by the copies below and handed back
+            // page by page when the context goes — 512 times fewer pages where transparent huge pages are available
+            const size_t cap2 = (cap + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            if (posix_memalign(&r->stage, (size_t)2 << 20, cap2) != 0) r->stage = nullptr;
+            else (void)madvise(r->stage, cap2, MADV_HUGEPAGE);
+        }
+        if (!r->stage) { delete r; return fail(ctx, C3R_ENOMEM, "staging block of %zu bytes: allocation failed", cap); }
         r->stage_cap = cap;
     }
     r->sites = (c3r_site_t *)r->stage;
     r->toks = (c3r_token_t *)((char *)r->stage + b_sites);
     r->probs = (float *)((char *)r->stage + b_sites + b_toks);
     auto bail = [&](int rc) { c3r_rows_free(r); return rc; };
+    const bool timing = getenv("C3R_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
+    if (timing) (void)hipStreamSynchronize(ctx->stream);              // (separates the wait for the network from the copies in the report)
+    const auto t1 = now();
     if (hipMemcpyAsync(r->sites, ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         (ctx->n_tok && hipMemcpyAsync(r->toks, ctx->d_tok.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess))
         return bail(fail(ctx, C3R_EHIP, "copying sites / tokens to the host failed"));
@@ -1511,7 +1536,11 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     if (hipMemcpyAsync(r->probs, ctx->net.d_probs, b_probs, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
         return bail(fail(ctx, C3R_EHIP, "copying probabilities to the host failed"));
     if ((rc = check_lstm_status(ctx, lstm_st))) return bail(rc);
+    const auto t2 = now();
     if ((rc = ensure_host_reads(ctx)) || (rc = ensure_host_seq(ctx))) return bail(rc);
+    if (timing)
+        fprintf(stderr, "[rows_begin %p] %lld sites, %lld tokens: wait %.1f ms, sites + tokens + probabilities (%.0f MB) %.1f ms, reads + bases (%.0f MB) %.1f ms\n", (void *)ctx,
+                (long long)n, (long long)ctx->n_tok, ms(t0, t1), need / 1e6, ms(t1, t2), (ctx->n_reads * sizeof(DevRead) + ctx->n_seq_bytes) / 1e6, ms(t2, now()));
     // the host copies move into the snapshot (the next contig fetches its own); the reference buffer is shared and held by a user count
     r->reads.swap(ctx->h_reads); r->seq.swap(ctx->h_seq);
     ctx->host_reads_valid = false; ctx->host_seq_valid = false;
@@ -1577,8 +1606,8 @@ static void rows_release_inputs(c3r_rows *r) {
     if (r->ref_slot >= 0) { ctx->refbuf[r->ref_slot].users.fetch_sub(1); r->ref_slot = -1; r->ref = nullptr; r->ref_len = 0; }
     if (r->stage) {
         std::lock_guard<std::mutex> g(ctx->pool_mu);
-        if (ctx->stage_pool.size() < 4) ctx->stage_pool.push_back({r->stage, r->stage_cap});
-        else (void)hipHostFree(r->stage);
+        if (ctx->stage_pool.size() < 3) ctx->stage_pool.push_back({r->stage, r->stage_cap});
+        else stage_free(r->stage);
         r->stage = nullptr; r->stage_cap = 0; r->sites = nullptr; r->toks = nullptr; r->probs = nullptr;
     }
     r->n = 0;

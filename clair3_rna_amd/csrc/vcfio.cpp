@@ -492,7 +492,7 @@ int c3r_vcfz_close(c3r_vcfz *z, int keep) {
         for (uint64_t v : x.lin) put(tbi, v);
     }
     std::vector<uint8_t> tgz; std::vector<uint64_t> tco;
-    ok = ok && bgzf_compress(tbi.data(), tbi.size(), 1, tgz, tco);
+    ok = ok && bgzf_compress(tbi.data(), tbi.size(), z->threads, tgz, tco);       // (a whole genome's index is a few MB: blocks on threads)
     ok = ok && write_file(z->gz_path + ".tbi", tgz.data(), tgz.size(), BGZF_EOF, sizeof BGZF_EOF);
     delete z;
     return ok ? C3R_OK : C3R_EINVAL;
