@@ -153,7 +153,7 @@ def build_parser():
     a("--gpu_precision", type=str, default=_env_precision(), choices=["f32", "f16x3", "f16+f8", "auto"],
       help="network arithmetic (c3r_set_precision): f16x3 = fp32-equivalent split-f16 (default); auto = the faster fp8-corrected path where a "
            "calibration run through the loaded weights agrees with f16x3 to 4e-5, else f16x3")
-    a("--fetch_threads", type=int, default=4)
+    a("--fetch_threads", type=int, default=8, help="contigs fetched ahead of the contexts, each on its own thread (BGZF inflate on C3R_FETCH_INFLATE threads per fetch); 8 measured best on a 256-thread host, capped by the rank's share of the cores under torch.distributed")
     a("--contexts", type=int, default=2, help="GPU contexts (each with its own host thread and HIP stream) working side by side: while one waits for its kernels the other normalises reads or decodes (every context sizes its own device buffers on its first contig; first uses take turns)")
     return p
 
@@ -274,12 +274,19 @@ def Run(args, log=None):
             table = sort_vcf.load_rediportal(src, contigs, tags)
 
     weights = io.load_weights(model, channels)
-    engines = [capi.Engine(args.gpu_id) for _ in range(max(1, args.contexts))]
-    for e in engines:
-        e.load_weights(weights, channels)
-        e.set_precision(args.gpu_precision)
-    if args.gpu_precision != "f16x3":
-        log("[INFO] network arithmetic: %s -> %s (calibration max |dP| %s)" % ((args.gpu_precision,) + tuple(engines[0].precision())))
+    n_ctx = max(1, args.contexts)
+    engines = []
+
+    def make_engines():
+        """The GPU contexts: created, given the weights and the arithmetic once the first fetches are under way (0.1-0.2 s that
+        used to come before the first BAM byte was read)."""
+        for _ in range(n_ctx):
+            engines.append(capi.Engine(args.gpu_id))
+        for e in engines:
+            e.load_weights(weights, channels)
+            e.set_precision(args.gpu_precision)
+        if args.gpu_precision != "f16x3":
+            log("[INFO] network arithmetic: %s -> %s (calibration max |dP| %s)" % ((args.gpu_precision,) + tuple(engines[0].precision())))
     qual_rows = args.qual if args.qual is not None else 2              # call_variants.py:1827 (STEP 1 never passes --qual)
     qual_merge = args.qual if args.qual is not None else 2             # sort_vcf's own default
     header = vcf.header(args.ref_fn, cmd_fn, args.sample_name) + "\n"
@@ -315,6 +322,8 @@ def Run(args, log=None):
             n = eng.n_candidates
             t.append(time())
             if n:
+                # (launched as soon as the tensors exist, side by side with the other context's pass: making the contexts take
+                # turns for the network — one copies while the other computes — measured 3.1-3.3 s against 2.7-2.8 s)
                 eng.infer(fetch=False)
             t.append(time())
             if os.environ.get("C3R_TIMING"):
@@ -386,7 +395,6 @@ def Run(args, log=None):
             bam_fn = link
     fetcher = _Fetcher(bam_fn, args.ref_fn)
     t_setup = time() - t_all
-    n_ctx = len(engines)
     # contigs fetched (or being fetched) but not yet through their context: every context busy + every fetch thread running ahead.
     # (n_ctx + 2 starved the contexts: a fetch takes ~100 ms, a context needs a new contig every ~35 ms)
     slots = threading.BoundedSemaphore(n_ctx + max(2, args.fetch_threads))
@@ -509,12 +517,12 @@ def Run(args, log=None):
     # candidates per kb of contig: ~3 on the synthetic GRCh38-sized samples, so a contig past ~50 Mb fills a whole network slice
     reserve_sites = min(262144, int(max(fai[c] for c in contigs) * 0.005)) if contigs else 0
     ctx_queue = queue.Queue()                                            # (contig, fetch future, result future) in calling order; None ends a worker
-    ctx_threads = [threading.Thread(target=context_worker, args=(k,), name="c3r-ctx%d" % k, daemon=True) for k in range(len(engines))]
+    ctx_threads = [threading.Thread(target=context_worker, args=(k,), name="c3r-ctx%d" % k, daemon=True) for k in range(n_ctx)]
     # snapshots -> rows (-> merged records), beside the contexts.  A large contig's merge is 0.2-0.7 s on one thread when every
     # candidate is a record: with n_ctx + 1 workers the snapshots queued up behind three merges (full-length GRCh38 timeline)
     n_dec = int(os.environ.get("C3R_DECODE_WORKERS", "0")) or max(2, min(8, (n_thr if world > 1 else (os.cpu_count() or 8)) // 4))
     decode_pool = ThreadPoolExecutor(n_dec)
-    eng_decodes = [[] for _ in engines]                                  # decode futures per context (its finish task waits for them)
+    eng_decodes = [[] for _ in range(n_ctx)]                                  # decode futures per context (its finish task waits for them)
     stop = threading.Event()
 
     def stop_workers():
@@ -553,8 +561,6 @@ def Run(args, log=None):
             tasks = [None] * len(contigs)
             submitted = [threading.Event() for _ in contigs]
             feeder_err = []
-            for t_ in ctx_threads:
-                t_.start()
 
             def feeder():
                 try:
@@ -588,6 +594,11 @@ def Run(args, log=None):
             closer = threading.Thread(target=close_fetcher, name="c3r-closer", daemon=True)
             closer.start()
             try:
+                t0 = time()
+                make_engines()                                             # (the first fetches are running)
+                mark("all", "engines", t0)
+                for t_ in ctx_threads:
+                    t_.start()
                 for i, ctg in enumerate(contigs):                          # merge in calling order as the contigs come out
                     submitted[i].wait()
                     if tasks[i] is None:
