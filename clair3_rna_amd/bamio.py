@@ -11,7 +11,7 @@ from .reads import READ_DTYPE, ReadSet
 
 EXPORTS = ["c3r_bam_open", "c3r_bam_close", "c3r_bam_last_error", "c3r_bam_n_contigs", "c3r_bam_contig", "c3r_bam_has_index",
            "c3r_bam_fetch", "c3r_bam_copy", "c3r_bam_index_build", "c3r_vcf_merge", "c3r_vcf_compress", "c3r_vcfz_open", "c3r_vcfz_write",
-           "c3r_vcfz_close", "c3r_vcfz_piece_make", "c3r_vcfz_append", "c3r_vcfz_piece_free", "c3r_fasta_fetch"]
+           "c3r_vcfz_close", "c3r_vcfz_piece_make", "c3r_vcfz_append", "c3r_vcfz_piece_free", "c3r_fasta_fetch", "c3r_io_alloc", "c3r_io_free"]
 _LIB = None
 
 
@@ -36,8 +36,29 @@ def load_library():
         L.c3r_vcf_merge.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int64,
                                     C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.c3r_vcf_compress.argtypes = [C.c_char_p, C.c_int]
+        L.c3r_io_alloc.argtypes = [C.c_size_t]
+        L.c3r_io_alloc.restype = C.c_void_p
+        L.c3r_io_free.argtypes = [C.c_void_p]
+        L.c3r_io_free.restype = None
         _LIB = L
     return _LIB
+
+
+def huge_empty(n, dtype=np.uint8):
+    """np.empty(n, dtype) in memory from c3r_io_alloc (2-MB aligned, advised huge) for arrays of 4 MB and more; freed with the
+    last array that views it."""
+    dtype = np.dtype(dtype)
+    nbytes = int(n) * dtype.itemsize
+    if nbytes < (4 << 20):
+        return np.empty(int(n), dtype)
+    import weakref
+    L = load_library()
+    p = L.c3r_io_alloc(nbytes)
+    if not p:
+        raise MemoryError("c3r_io_alloc(%d) failed" % nbytes)
+    flat = np.frombuffer((C.c_char * nbytes).from_address(p), dtype=np.uint8)      # every later view keeps `flat` alive as its base
+    weakref.finalize(flat, L.c3r_io_free, p)
+    return flat.view(dtype)
 
 
 class BamFile:
@@ -81,9 +102,9 @@ class BamFile:
         rc = self.L.c3r_bam_fetch(self.h, contig.encode(), int(beg0), int(end0) if end0 else 0, C.byref(n), C.byref(nc), C.byref(ns))
         if rc != 0:
             raise IOError("c3r_bam_fetch: %s" % self.L.c3r_bam_last_error(self.h).decode())
-        reads = np.empty(n.value, READ_DTYPE)
-        cigar = np.empty(nc.value, np.uint32)
-        seq = np.empty(ns.value, np.uint8)
+        reads = huge_empty(n.value, READ_DTYPE)
+        cigar = huge_empty(nc.value, np.uint32)
+        seq = huge_empty(ns.value, np.uint8)
         self.L.c3r_bam_copy(self.h, reads.ctypes.data, cigar.ctypes.data, seq.ctypes.data)
         return ReadSet(reads, cigar, seq)
 
@@ -125,8 +146,8 @@ def vcf_merge(rows, qual=2, show_ref=False, edits=None, want_no_tagging=False):
     as_array = isinstance(rows, np.ndarray)
     rows_p, rows_n, _keep = _text_ptr(rows)
     cap = rows_n + 16 * (n_edit + 1) + 64                                    # a relabel adds at most 7 bytes to a record
-    out = np.empty(cap, np.uint8)                                            # (not zero-filled: a large contig's records are ~100 MB)
-    out_nt = np.empty(cap, np.uint8) if want_no_tagging else None
+    out = huge_empty(cap, np.uint8)                                          # (not zero-filled: a large contig's records are ~100 MB)
+    out_nt = huge_empty(cap, np.uint8) if want_no_tagging else None
     rc = L.c3r_vcf_merge(rows_p, rows_n, int(qual or 0), int(bool(show_ref)), epos_p, eref, ealt, n_edit, out.ctypes.data, cap, C.byref(n),
                          out_nt.ctypes.data if want_no_tagging else None, cap if want_no_tagging else 0, nt_len, counts)
     if rc == -6:                                                             # C3R_EOVERFLOW: sizes are known now
@@ -156,7 +177,7 @@ def fasta_fetch(ref_fn, fai_row, beg0=0, end0=None, upper=True, threads=0):
     _name, length, offset, linebases, linewidth = fai_row
     beg0 = max(0, int(beg0))
     end0 = length if end0 is None else min(length, int(end0))
-    out = np.empty(max(0, end0 - beg0), np.uint8)
+    out = huge_empty(max(0, end0 - beg0), np.uint8)
     if out.size:
         L = load_library()
         L.c3r_fasta_fetch.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]

@@ -180,6 +180,7 @@ class _Fetcher(object):
 
     def __call__(self, ctg, length):
         t0 = time()
+        t_open = t_bam = 0.0
         if self.bam_fn.endswith(".npz"):
             rs = io.load_reads(self.bam_fn, ctg)
         else:
@@ -188,7 +189,9 @@ class _Fetcher(object):
             if bf is None:
                 bf = self.tls.bf = bamio.BamFile(self.bam_fn, threads=int(os.environ.get("C3R_FETCH_INFLATE", "8")))
                 self.handles.append(bf)
+                t_open = time() - t0
             rs = bf.fetch(ctg)
+            t_bam = time() - t0 - t_open
         ref = b""
         if len(rs.reads):
             # the whole contig, upper-cased, line ends dropped, by parallel pread (c3r_fasta_fetch) — a 250-Mb chromosome went
@@ -197,6 +200,7 @@ class _Fetcher(object):
             if self.fai is None:
                 self.fai = {r[0]: r for r in io.read_fai(self.ref_fn)}
             ref = bamio.fasta_fetch(self.ref_fn, self.fai[ctg], 0, length)
+        self.tls.detail = "open %.0f ms, alignments %.0f ms, reference %.0f ms" % (1e3 * t_open, 1e3 * t_bam, 1e3 * (time() - t0 - t_open - t_bam))
         return rs, ref, time() - t0
 
     def close(self):
@@ -412,6 +416,8 @@ def Run(args, log=None):
         t0 = time()
         r = fetcher(ctg, fai[ctg])
         mark(ctg, "fetch", t0)
+        if timeline:
+            log("[timeline-fetch %s] %d reads, %d CIGAR ops, %.0f MB of bases, %.0f Mb of reference: %s" % (ctg, len(r[0].reads), len(r[0].cigar), len(r[0].seq) / 1e6, len(r[1]) / 1e6, getattr(fetcher.tls, "detail", "")))
         return r
 
     def context_task(eng, ctg, fut):

@@ -388,7 +388,8 @@ class RowSnapshot(object):
             rc = self.L.c3r_rows_decode(self.h, ctg.encode(), -1 if qual is None else int(qual), int(show_ref), C.byref(n), C.byref(nr))
             if rc != 0:
                 raise C3RError(rc, "c3r_rows_decode failed")
-            buf = np.empty(n.value + 1, np.uint8)
+            from . import bamio
+            buf = bamio.huge_empty(n.value + 1, np.uint8)
             rc = self.L.c3r_rows_get(self.h, buf.ctypes.data, n.value + 1)
             if rc != 0:
                 raise C3RError(rc, "c3r_rows_get failed")

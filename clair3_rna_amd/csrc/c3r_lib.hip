@@ -1512,7 +1512,7 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
             // page by page when the context goes — 512 times fewer pages where transparent huge pages are available
             const size_t cap2 = (cap + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
             if (posix_memalign(&r->stage, (size_t)2 << 20, cap2) != 0) r->stage = nullptr;
-            else (void)madvise(r->stage, cap2, MADV_HUGEPAGE);
+            else if (!(getenv("C3R_IO_HUGE") && *getenv("C3R_IO_HUGE") == '0')) (void)madvise(r->stage, cap2, MADV_HUGEPAGE);
         }
         if (!r->stage) { delete r; return fail(ctx, C3R_ENOMEM, "staging block of %zu bytes: allocation failed", cap); }
         r->stage_cap = cap;

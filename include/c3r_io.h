@@ -86,6 +86,12 @@ int c3r_vcfz_piece_make(const char *text, int64_t n_bytes, int threads, c3r_vcfz
 int c3r_vcfz_append(c3r_vcfz *z, const c3r_vcfz_piece *piece);
 void c3r_vcfz_piece_free(c3r_vcfz_piece *piece);
 
+/* Host memory for the large arrays that cross this interface (a contig's records, its reference slice, its rows): 2-MB aligned and
+ * advised huge, so that a fresh 100-MB array is a few hundred page faults instead of tens of thousands where transparent huge pages
+ * are available.  Optional — every entry point takes any host pointer.  NULL when out of memory. */
+void *c3r_io_alloc(size_t bytes);
+void c3r_io_free(void *p);
+
 /* ---- reference side: `samtools faidx <fasta> ctg:beg-end` (shared/utils.py:168-193 reference_sequence_from) for an uncompressed,
  * faidx-indexed FASTA.  The caller passes the contig's .fai geometry (file offset of its first base, bases per line, bytes per line
  * including the line end); bases [beg0, end0) (0-based, half-open, inside the contig) are written to out[0, end0 - beg0) with the line

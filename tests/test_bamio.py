@@ -57,7 +57,7 @@ def bam_case(tmp_path_factory):
 
 def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "c3r_io.h")).read()
-    declared = sorted(set(re.findall(r"\b(c3r_(?:bam|vcfz?|fasta)_[a-z_0-9]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(c3r_(?:bam|vcfz?|fasta|io)_[a-z_0-9]+)\s*\(", hdr)))
     lib = bamio.load_library()
     assert declared and not [s for s in declared if not hasattr(lib, s)]
     assert sorted(bamio.EXPORTS) == declared
@@ -216,6 +216,25 @@ def test_malformed_records_are_errors_not_overreads(tmp_path):
             with pytest.raises(IOError, match="malformed alignment record"):
                 bf.fetch("c1")
             assert len(bf.fetch("c1", 0, 120).reads) == 1            # the record before it is still readable
+    # the same through the index, blocks inflated and records parsed on threads: the error of the FIRST bad record, nothing kept
+    p = str(tmp_path / "m_par.bam")
+    many = [(0, 100 + 3 * i, 60, 0, [op(10, M)], seq10, b"HPC\x01") for i in range(40)]
+    bad_mid = (0, 100 + 3 * 40, 60, 0, [op(10, M)], seq10, b"ZZBs" + struct.pack("<I", 5000) + b"\x00" * 4)
+    _raw_bam(p, many + [bad_mid] + [(0, 300 + 3 * i, 60, 0, [op(10, M)], seq10, b"") for i in range(40)])
+    bai = bamio.index_build(p)
+    try:
+        import pytest as _pt
+        mp = _pt.MonkeyPatch()
+        mp.setenv("C3R_IO_PAR_MIN", "0"); mp.setenv("C3R_IO_PARSE_MIN", "3")
+        try:
+            with bamio.BamFile(p, threads=4) as bf:
+                with pytest.raises(IOError, match="malformed alignment record at position %d" % (100 + 3 * 40 + 1)):
+                    bf.fetch("c1")
+                assert len(bf.fetch("c1", 0, 150).reads) == 17           # the records before it are still readable
+        finally:
+            mp.undo()
+    finally:
+        os.remove(bai)
     # l_seq far beyond the record
     p = str(tmp_path / "m2.bam")
     _raw_bam(p, [good, (0, 150, 60, 0, [op(10, M)], seq10, b"")])
@@ -236,11 +255,13 @@ def test_malformed_records_are_errors_not_overreads(tmp_path):
         bamio.BamFile(p)
 
 
-@pytest.mark.parametrize("margin,batch", [("1", "3"), ("70000", "512"), ("4194304", "1")])
-def test_long_index_chunks_inflate_in_parallel(bam_case, margin, batch, monkeypatch):
+@pytest.mark.parametrize("margin,batch,parse_min", [("1", "3", "1024"), ("70000", "512", "7"), ("4194304", "1", "1"), ("1", "3", "2")])
+def test_long_index_chunks_inflate_in_parallel(bam_case, margin, batch, parse_min, monkeypatch):
     """Indexed fetches whose chunk is long (a whole contig) inflate their blocks on threads (scan_blocks) instead of through the
-    one-block cursor.  Forced here on a small file: every chunk takes the parallel path, with a margin so short that records
-    run past the listed blocks (the fetch must start over with more), and with batches of 1-3 blocks (records across rounds)."""
+    one-block cursor, and parse the records of every batch on threads (take_records: per-thread arrays appended in file order).
+    Forced here on a small file: every chunk takes the parallel path, with a margin so short that records run past the listed
+    blocks (the fetch must start over with more), with batches of 1-3 blocks (records across rounds), and with threads started for
+    runs of 1, 2 or 7 records."""
     rs, rs2 = bam_case["rs"], bam_case["rs2"]
     end = _ref_end(rs)
     pos = rs.reads["pos"].astype(np.int64)
@@ -252,6 +273,7 @@ def test_long_index_chunks_inflate_in_parallel(bam_case, margin, batch, monkeypa
         monkeypatch.setenv("C3R_IO_PAR_MIN", "0")
         monkeypatch.setenv("C3R_IO_MARGIN", margin)
         monkeypatch.setenv("C3R_IO_BATCH", batch)
+        monkeypatch.setenv("C3R_IO_PARSE_MIN", parse_min)
         with bamio.BamFile(bam_case["path"], threads=4) as bf:
             got = [bf.fetch("chr20"), bf.fetch("chr21"), bf.fetch("chr20", 123456, 234567), bf.fetch("chr20", 590000, 600000)]
             assert len(bf.fetch("chrEmpty")) == 0

@@ -40,7 +40,7 @@ def main():
                                                                     "--fetch_threads", str(ft)] + a.extra.split()), log=msgs.append)
             print("fetch_threads %2d rep %d: %.2f s   %s" % (ft, rep, time.time() - t0, msgs[-1].strip()), flush=True)
             if os.environ.get("C3R_TIMING"):
-                print("\n".join(m for m in msgs if "[timeline]" in m or "[device_stage" in m), flush=True)
+                print("\n".join(m for m in msgs if "[timeline" in m or "[device_stage" in m), flush=True)
 
 
 if __name__ == "__main__":
