@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -205,6 +206,7 @@ struct c3r_bam {
     hvec<uint32_t> cigar;
     hvec<uint8_t> seq;
     std::vector<RecPart> parts;
+    double t_inflate = 0, t_visit = 0, t_parse = 0;      // seconds of the current fetch (reported under C3R_TIMING)
 };
 
 namespace {
@@ -469,17 +471,22 @@ int scan_blocks(c3r_bam *b, const std::vector<BlockRef> &blocks, size_t skip, F 
                 if (!inf.run(f + k.off + k.payload, k.bsize - k.payload - 8, buf.data() + uoff[i - b0], k.isize)) bad = true;
             }
         };
+        const auto ti0 = std::chrono::steady_clock::now();
         std::vector<std::thread> th;
         for (int t = 1; t < nt; ++t) th.emplace_back(work);
         work();
         for (auto &t : th) t.join();
+        const auto ti1 = std::chrono::steady_clock::now();
+        b->t_inflate += std::chrono::duration<double>(ti1 - ti0).count();
         if (bad) return failb(b, C3R_EINVAL, "%s: inflate failed", b->path.c_str());
         // virtual offset of byte u of this batch, in the canonical form a reader's tell() has after consuming byte u-1:
         // inside a block (coffset, u - block start); exactly at a block's end the address of the block that follows
         // (empty blocks hold no byte and are never chosen, so the value does not depend on how blocks are batched)
+        size_t jc = 0;                    // block of the most recent lookup: offsets are asked for in ascending order within a batch
         auto voff_of = [&](size_t u) -> uint64_t {
             if (u == 0) return (uint64_t)blocks[b0].off << 16;
-            const size_t j = (size_t)(std::upper_bound(uoff.begin(), uoff.end(), u - 1) - uoff.begin()) - 1;
+            while (jc + 2 < uoff.size() && uoff[jc + 1] <= u - 1) ++jc;          // the last block that starts at or before byte u - 1
+            const size_t j = jc;
             const BlockRef &k = blocks[b0 + j];
             if (u == uoff[j + 1]) return (uint64_t)(k.off + k.bsize) << 16;
             return ((uint64_t)k.off << 16) | (uint64_t)(u - uoff[j]);
@@ -505,10 +512,15 @@ int scan_blocks(c3r_bam *b, const std::vector<BlockRef> &blocks, size_t skip, F 
                 break;
             }
             const size_t bs = le32(buf.data() + u);
-            if (!visit(buf.data() + u + 4, bs, voff_of(u), voff_of(u + 4 + bs))) { stop = true; break; }
+            const uint64_t v0 = voff_of(u);                  // (in this order: the lookup keeps a cursor)
+            const uint64_t v1 = voff_of(u + 4 + bs);
+            if (!visit(buf.data() + u + 4, bs, v0, v1)) { stop = true; break; }
             u += 4 + bs;
         }
+        const auto tv1 = std::chrono::steady_clock::now();
+        b->t_visit += std::chrono::duration<double>(tv1 - ti1).count();
         batch_done();
+        b->t_parse += std::chrono::duration<double>(std::chrono::steady_clock::now() - tv1).count();
     }
     if (truncated) *truncated = !stop && !carry.empty();      // the listed blocks end inside a record
     return C3R_OK;
@@ -658,6 +670,8 @@ int c3r_bam_fetch(c3r_bam *b, const char *contig, int64_t beg0, int64_t end0, in
     if (!b || !contig) return C3R_EINVAL;
     b->reads.clear(); b->cigar.clear(); b->seq.clear();
     b->malformed = false;
+    b->t_inflate = b->t_visit = b->t_parse = 0;
+    const auto t_fetch0 = std::chrono::steady_clock::now();
     int tid = -1;
     for (size_t i = 0; i < b->names.size(); ++i) if (b->names[i] == contig) { tid = (int)i; break; }
     int rc = C3R_OK;
@@ -671,6 +685,9 @@ int c3r_bam_fetch(c3r_bam *b, const char *contig, int64_t beg0, int64_t end0, in
         }
     }
     if (rc == C3R_OK && b->malformed) { rc = C3R_EINVAL; b->reads.clear(); b->cigar.clear(); b->seq.clear(); }
+    if (getenv("C3R_TIMING") && b->reads.size() > 10000)
+        fprintf(stderr, "[c3r_bam_fetch %s] %zu reads in %.0f ms: inflate %.0f ms, record walk %.0f ms, parse %.0f ms\n", contig, b->reads.size(),
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fetch0).count(), 1e3 * b->t_inflate, 1e3 * b->t_visit, 1e3 * b->t_parse);
     if (n_reads) *n_reads = (int64_t)b->reads.size();
     if (n_cigar) *n_cigar = (int64_t)b->cigar.size();
     if (n_seq_bytes) *n_seq_bytes = (int64_t)b->seq.size();
