@@ -57,6 +57,8 @@ struct c3r_ctx {
     DevBuf d_rawreads, d_rawcig;           // the caller's records as they arrived (c3r_read_t, BAM-encoded ops)
     DevBuf d_rcnt, d_rend, d_pass, d_ekey, d_ekey2, d_skey, d_skey2, d_sval, d_sval2, d_sorttmp, d_s4tops, d_pmtops, d_stats;
     LoadStats *h_stats = nullptr;          // pinned
+    void *h_pack = nullptr;                // pinned: the indel-record count of k_pack_tokens
+    DevBuf d_tokb, d_tokrec, d_recoff;     // packed tokens of a row snapshot (c3r_rows_begin)
     std::vector<DevRead> h_reads;          // lazily: ensure_host_reads
     std::vector<int32_t> h_prefmax;        // lazily: host copy of the prefix max of read ends (passing reads)
     bool host_reads_valid = false;
@@ -174,6 +176,16 @@ inline bool stage_pinned() {
     return v;
 }
 inline void stage_free(void *p) { if (!p) return; if (stage_pinned()) (void)hipHostFree(p); else free(p); }
+// 2-MB aligned and advised huge (C3R_IO_HUGE=0: ordinary pages): a fresh 0.3-GB block is touched for the first time by the copies into it
+// and handed back page by page when the context goes — 512 times fewer pages where transparent huge pages are available.  free() releases it.
+inline void *huge_alloc(size_t bytes) {
+    void *p = nullptr;
+    const size_t cap = (std::max<size_t>(bytes, 1) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (posix_memalign(&p, (size_t)2 << 20, cap) != 0) return nullptr;
+    static const bool huge = [] { const char *e = getenv("C3R_IO_HUGE"); return !(e && *e == '0'); }();
+    if (huge) (void)madvise(p, cap, MADV_HUGEPAGE);
+    return p;
+}
 
 int ensure(c3r_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return C3R_OK;
@@ -398,7 +410,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_rcnt, &ctx->d_rend, &ctx->d_pass, &ctx->d_ekey, &ctx->d_ekey2, &ctx->d_skey, &ctx->d_skey2, &ctx->d_sval, &ctx->d_sval2,
                       &ctx->d_sorttmp, &ctx->d_s4tops, &ctx->d_pmtops, &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
-                      &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok};
+                      &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff};
     int n_dev = 0; size_t b_dev = 0, b_pin = 0;
     for (DevBuf *b : bufs) if (b->p) { (void)hipFree(b->p); ++n_dev; b_dev += b->cap; }
     const auto t1 = std::chrono::steady_clock::now();
@@ -407,6 +419,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (ctx->rows_snap) c3r_rows_free(ctx->rows_snap);
     for (auto &sp : ctx->stage_pool) { stage_free(sp.first); b_pin += sp.second; }
     if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
+    if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
     for (auto &rb : ctx->refbuf) { if (rb.p) { (void)hipHostFree(rb.p); b_pin += rb.cap; } if (rb.ev) (void)hipEventDestroy(rb.ev); }
     const auto t3 = std::chrono::steady_clock::now();
@@ -1477,10 +1490,12 @@ int c3r_decode_text(const char *ctg, int64_t n, const int32_t *pos, const char *
 }  // extern "C"
 struct c3r_rows {
     c3r_ctx *ctx = nullptr;
-    void *stage = nullptr; size_t stage_cap = 0;          // sites | tokens | probabilities
+    // one staging block: sites | token bytes | probabilities | indel-record offsets | read headers | packed bases
+    void *stage = nullptr; size_t stage_cap = 0;
     int64_t n = 0, n_tok = 0;
-    c3r_site_t *sites = nullptr; c3r_token_t *toks = nullptr; float *probs = nullptr;
-    std::vector<DevRead> reads; std::vector<uint8_t> seq;  // the contig's read headers and packed bases (inserted bases of the alt alleles)
+    c3r_site_t *sites = nullptr; uint8_t *tokb = nullptr; float *probs = nullptr; uint32_t *rec_off = nullptr;
+    DevRead *reads = nullptr; uint8_t *seq = nullptr;     // the contig's read headers and packed bases (inserted bases of the alt alleles)
+    TokRec *recs = nullptr; int64_t n_recs = 0;           // the tokens that carry an indel (k_pack_tokens), own allocation
     int ref_slot = -1; const char *ref = nullptr; size_t ref_len = 0; int64_t ref_start1 = 1;
     std::string rows; int64_t rows_count = 0;
 };
@@ -1495,11 +1510,12 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     c3r_rows *r = new c3r_rows();
     r->ctx = ctx; r->n = n; r->n_tok = ctx->n_tok;
     if (n == 0) { *out = r; return C3R_OK; }
-    const size_t b_sites = ((size_t)n * sizeof(c3r_site_t) + 255) & ~(size_t)255;
-    const size_t b_toks = ((size_t)std::max<int64_t>(ctx->n_tok, 1) * sizeof(c3r_token_t) + 255) & ~(size_t)255;
-    const size_t b_probs = (size_t)n * C3R_NPROB * sizeof(float);
-    const size_t need = b_sites + b_toks + b_probs;
-    {   // a page-locked block from the pool of released snapshots (200 MB of pageable vectors cost 37 ms just to zero-fill)
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int64_t n_tok = ctx->n_tok;
+    const size_t b_sites = up((size_t)n * sizeof(c3r_site_t)), b_tokb = up((size_t)std::max<int64_t>(n_tok, 1)), b_probs = up((size_t)n * C3R_NPROB * sizeof(float)),
+                 b_off = up((size_t)n * 4), b_reads = up((size_t)std::max(ctx->n_reads, 1) * sizeof(DevRead)), b_seq = up((size_t)ctx->n_seq_bytes + 16);
+    const size_t need = b_sites + b_tokb + b_probs + b_off + b_reads + b_seq;
+    {   // a block from the pool of released snapshots
         std::lock_guard<std::mutex> g(ctx->pool_mu);
         for (size_t k = 0; k < ctx->stage_pool.size(); ++k)
             if (ctx->stage_pool[k].second >= need) { r->stage = ctx->stage_pool[k].first; r->stage_cap = ctx->stage_pool[k].second; ctx->stage_pool.erase(ctx->stage_pool.begin() + (long)k); break; }
@@ -1507,19 +1523,17 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     if (!r->stage) {
         const size_t cap = need * 5 / 4 + 4096;
         if (stage_pinned()) { if (hipHostMalloc(&r->stage, cap, hipHostMallocDefault) != hipSuccess) r->stage = nullptr; }
-        else {
-            // 2-MB aligned and advised huge: a fresh 0.5-GB block is touched for the first time by the copies below and handed back
-            // page by page when the context goes — 512 times fewer pages where transparent huge pages are available
-            const size_t cap2 = (cap + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-            if (posix_memalign(&r->stage, (size_t)2 << 20, cap2) != 0) r->stage = nullptr;
-            else if (!(getenv("C3R_IO_HUGE") && *getenv("C3R_IO_HUGE") == '0')) (void)madvise(r->stage, cap2, MADV_HUGEPAGE);
-        }
+        else r->stage = huge_alloc(cap);
         if (!r->stage) { delete r; return fail(ctx, C3R_ENOMEM, "staging block of %zu bytes: allocation failed", cap); }
         r->stage_cap = cap;
     }
-    r->sites = (c3r_site_t *)r->stage;
-    r->toks = (c3r_token_t *)((char *)r->stage + b_sites);
-    r->probs = (float *)((char *)r->stage + b_sites + b_toks);
+    char *sp = (char *)r->stage;
+    r->sites = (c3r_site_t *)sp; sp += b_sites;
+    r->tokb = (uint8_t *)sp; sp += b_tokb;
+    r->probs = (float *)sp; sp += b_probs;
+    r->rec_off = (uint32_t *)sp; sp += b_off;
+    r->reads = (DevRead *)sp; sp += b_reads;
+    r->seq = (uint8_t *)sp;
     auto bail = [&](int rc) { c3r_rows_free(r); return rc; };
     const bool timing = getenv("C3R_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1527,24 +1541,41 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     const auto t0 = now();
     if (timing) (void)hipStreamSynchronize(ctx->stream);              // (separates the wait for the network from the copies in the report)
     const auto t1 = now();
-    if (hipMemcpyAsync(r->sites, ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        (ctx->n_tok && hipMemcpyAsync(r->toks, ctx->d_tok.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess))
-        return bail(fail(ctx, C3R_EHIP, "copying sites / tokens to the host failed"));
+    // tokens leave the device packed (k_pack_tokens: a byte per token, 12-byte records for the tokens with an indel)
+    int rc = C3R_OK;
+    if ((rc = ensure(ctx, ctx->d_tokb, (size_t)std::max<int64_t>(n_tok, 1))) || (rc = ensure(ctx, ctx->d_tokrec, (size_t)std::max<int64_t>(n_tok, 1) * sizeof(TokRec))) ||
+        (rc = ensure(ctx, ctx->d_recoff, (size_t)n * 4 + 8)))
+        return bail(rc);
+    if (!ctx->h_pack && hipHostMalloc((void **)&ctx->h_pack, 64, hipHostMallocDefault) != hipSuccess) return bail(fail(ctx, C3R_ENOMEM, "hipHostMalloc(64) failed"));
+    unsigned long long *d_counter = (unsigned long long *)((char *)ctx->d_recoff.p + (((size_t)n * 4 + 7) & ~(size_t)7));
+    if (hipMemsetAsync(d_counter, 0, 8, ctx->stream) != hipSuccess) return bail(fail(ctx, C3R_EHIP, "hipMemsetAsync failed"));
+    {
+        Launch L(ctx, "k_pack_tokens");
+        hipLaunchKernelGGL(k_pack_tokens, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const c3r_site_t *)ctx->d_sites_out.p, (const c3r_token_t *)ctx->d_tok.p, n,
+                           (uint8_t *)ctx->d_tokb.p, (TokRec *)ctx->d_tokrec.p, (uint32_t *)ctx->d_recoff.p, d_counter);
+    }
+    auto d2h = [&](void *dst, const void *src, size_t bytes) { return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess; };
+    if (!d2h(ctx->h_pack, d_counter, 8) || !d2h(r->sites, ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t)) || !d2h(r->tokb, ctx->d_tokb.p, (size_t)n_tok) ||
+        !d2h(r->rec_off, ctx->d_recoff.p, (size_t)n * 4) || !d2h(r->reads, ctx->d_reads.p, (size_t)ctx->n_reads * sizeof(DevRead)) ||
+        !d2h(r->seq, ctx->d_seq.p, (size_t)ctx->n_seq_bytes + 16))
+        return bail(fail(ctx, C3R_EHIP, "copying sites / tokens / reads to the host failed"));
     int32_t *lstm_st = nullptr;
-    int rc = queue_lstm_status(ctx, &lstm_st);
+    rc = queue_lstm_status(ctx, &lstm_st);
     if (rc) return bail(rc);
-    if (hipMemcpyAsync(r->probs, ctx->net.d_probs, b_probs, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+    if (!d2h(r->probs, ctx->net.d_probs, (size_t)n * C3R_NPROB * sizeof(float)) || hipStreamSynchronize(ctx->stream) != hipSuccess)
         return bail(fail(ctx, C3R_EHIP, "copying probabilities to the host failed"));
     if ((rc = check_lstm_status(ctx, lstm_st))) return bail(rc);
     const auto t2 = now();
-    if ((rc = ensure_host_reads(ctx)) || (rc = ensure_host_seq(ctx))) return bail(rc);
+    r->n_recs = (int64_t)*(unsigned long long *)ctx->h_pack;
+    if (r->n_recs > 0) {
+        r->recs = (TokRec *)huge_alloc((size_t)r->n_recs * sizeof(TokRec));
+        if (!r->recs) return bail(fail(ctx, C3R_ENOMEM, "indel records of %lld tokens: allocation failed", (long long)r->n_recs));
+        if (hipMemcpy(r->recs, ctx->d_tokrec.p, (size_t)r->n_recs * sizeof(TokRec), hipMemcpyDeviceToHost) != hipSuccess)
+            return bail(fail(ctx, C3R_EHIP, "copying indel records to the host failed"));
+    }
     if (timing)
-        fprintf(stderr, "[rows_begin %p] %lld sites, %lld tokens: wait %.1f ms, sites + tokens + probabilities (%.0f MB) %.1f ms, reads + bases (%.0f MB) %.1f ms\n", (void *)ctx,
-                (long long)n, (long long)ctx->n_tok, ms(t0, t1), need / 1e6, ms(t1, t2), (ctx->n_reads * sizeof(DevRead) + ctx->n_seq_bytes) / 1e6, ms(t2, now()));
-    // the host copies move into the snapshot (the next contig fetches its own); the reference buffer is shared and held by a user count
-    r->reads.swap(ctx->h_reads); r->seq.swap(ctx->h_seq);
-    ctx->host_reads_valid = false; ctx->host_seq_valid = false;
-    ctx->h_reads.clear(); ctx->h_seq.clear();
+        fprintf(stderr, "[rows_begin %p] %lld sites, %lld tokens (%lld with an indel): wait %.1f ms, pack + copies (%.0f MB) %.1f ms, indel records (%.0f MB) %.1f ms\n", (void *)ctx,
+                (long long)n, (long long)n_tok, (long long)r->n_recs, ms(t0, t1), need / 1e6, ms(t1, t2), r->n_recs * sizeof(TokRec) / 1e6, ms(t2, now()));
     r->ref_slot = ctx->ref_cur; r->ref = ctx->h_ref; r->ref_len = ctx->ref_len; r->ref_start1 = ctx->ref_start1;
     if (r->ref_slot >= 0) ctx->refbuf[r->ref_slot].users.fetch_add(1);
     *out = r;
@@ -1557,9 +1588,9 @@ int c3r_rows_decode(c3r_rows *r, const char *ctg, int qual, int show_ref, int64_
     *out_len = 0; if (n_rows) *n_rows = 0;
     const int64_t n = r->n;
     if (n == 0) return C3R_OK;
-    const c3r_site_t *sites = r->sites; const c3r_token_t *toks = r->toks; const float *probs = r->probs;
-    const uint8_t *seq = r->seq.data();
-    const std::vector<DevRead> &reads = r->reads;
+    const c3r_site_t *sites = r->sites; const uint8_t *tokb = r->tokb; const TokRec *recs = r->recs; const uint32_t *rec_off = r->rec_off; const float *probs = r->probs;
+    const uint8_t *seq = r->seq;
+    const DevRead *reads = r->reads;
     const RefView refv{r->ref, r->ref_len};
     const int64_t ref_start1 = r->ref_start1;
     auto get_read = [&](uint32_t k) { return ReadView{seq, reads[k].seq_off, reads[k].l_seq}; };
@@ -1574,7 +1605,13 @@ int c3r_rows_decode(c3r_rows *r, const char *ctg, int qual, int show_ref, int64_
         AltDict alt;
         for (int64_t i = a; i < b; ++i) {
             int depth_tok;
-            alt_from_tokens(toks + sites[(size_t)i].tok_off, sites[(size_t)i].n_tok, get_read, refv, ref_start1, sites[(size_t)i].pos, alt, depth_tok);
+            const uint8_t *tb = tokb + sites[(size_t)i].tok_off;
+            const TokRec *rc_ = recs ? recs + rec_off[(size_t)i] : nullptr;      // this site's indel records, in token order
+            alt_from_stream(sites[(size_t)i].n_tok, [tb, rc_](int k) mutable {
+                const uint8_t by = tb[k];
+                if (by & 0x80) { const TokRec &q = *rc_++; return TokView{by & 31, q.indel, q.read_idx, q.qpos}; }
+                return TokView{by & 31, 0, 0u, 0u};
+            }, get_read, refv, ref_start1, sites[(size_t)i].pos, alt, depth_tok);
             if (vcf_row(ctg, sites[(size_t)i].pos, sites[(size_t)i].ref33, sites[(size_t)i].depth, alt, probs + (size_t)i * C3R_NPROB, qual,
                         show_ref != 0, part[t]))
                 cnt[t]++;
@@ -1608,11 +1645,10 @@ static void rows_release_inputs(c3r_rows *r) {
         std::lock_guard<std::mutex> g(ctx->pool_mu);
         if (ctx->stage_pool.size() < 3) ctx->stage_pool.push_back({r->stage, r->stage_cap});
         else stage_free(r->stage);
-        r->stage = nullptr; r->stage_cap = 0; r->sites = nullptr; r->toks = nullptr; r->probs = nullptr;
+        r->stage = nullptr; r->stage_cap = 0; r->sites = nullptr; r->tokb = nullptr; r->probs = nullptr; r->rec_off = nullptr; r->reads = nullptr; r->seq = nullptr;
     }
+    if (r->recs) { free(r->recs); r->recs = nullptr; r->n_recs = 0; }
     r->n = 0;
-    std::vector<DevRead>().swap(r->reads);
-    std::vector<uint8_t>().swap(r->seq);
 }
 
 void c3r_rows_free(c3r_rows *r) {

@@ -73,8 +73,10 @@ struct RefView {
     char operator[](size_t i) const { return p[i]; }
     std::string substr(size_t a, size_t len) const { return std::string(p + a, len); }
 };
-template <typename GetRead>
-inline void alt_from_tokens(const c3r_token_t *tk, int n, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
+// what the dictionary needs of one token; `next(i)` is called for i = 0 .. n-1 in order (a packed token stream keeps a cursor)
+struct TokView { int base; int32_t indel; uint32_t read_idx, qpos; };
+template <typename NextTok, typename GetRead>
+inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
                             AltDict &alt, int &depth_out) {
     alt.clear();
     const int64_t ri = pos1 - ref_start1;
@@ -82,7 +84,7 @@ inline void alt_from_tokens(const c3r_token_t *tk, int n, GetRead get_read, cons
     if (rb != 'A' && rb != 'C' && rb != 'G' && rb != 'T') rb = 'A';
     int depth = 0, alt_count = 0, ins_count = 0, del_count = 0;
     for (int i = 0; i < n; ++i) {
-        const c3r_token_t &t = tk[i];
+        const TokView t = next(i);
         const int b = t.base;
         if (b == 1 || b == 2 || b == 4 || b == 8) {
             depth++;
@@ -109,6 +111,11 @@ inline void alt_from_tokens(const c3r_token_t *tk, int n, GetRead get_read, cons
     const int ref_count = std::max(0, depth - del_count - ins_count - alt_count);
     if (ref_count > 0) alt_add(alt, std::string("R") + rb, ref_count);
     depth_out = depth;
+}
+template <typename GetRead>
+inline void alt_from_tokens(const c3r_token_t *tk, int n, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
+                            AltDict &alt, int &depth_out) {
+    alt_from_stream(n, [tk](int i) { return TokView{tk[i].base, tk[i].indel, tk[i].read_idx, tk[i].qpos}; }, get_read, ref, ref_start1, pos1, alt, depth_out);
 }
 
 // ---------------------------------------------------------------------------------------------- call_site
