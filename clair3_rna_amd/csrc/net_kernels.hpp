@@ -20,6 +20,7 @@
 //   * 4 wavefronts split the 4H/32 row blocks evenly (H=128: 4 each, H=160: 5 each).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <chrono>
 #include <type_traits>
 #include <stdint.h>
@@ -1329,10 +1330,40 @@ inline int64_t net_weight_count(int C) {
     return n;
 }
 
+// The layer-1 output of a full slice is one 8.9-GB allocation.  A process that destroys a context and creates another (a second
+// sample, a test suite) would hand it back to the driver and ask for it again: the driver clears freed memory before it is
+// reused, and that hipMalloc then takes 0.8 s instead of 0.3 ms.  Up to two such blocks per process are kept for the next context
+// of the same device (C3R_NO_BLOCK_CACHE=1, or C3R_POISON — which wants fresh memory — turns this off).
+struct BigBlock { int dev; size_t bytes; void *p; };
+inline std::mutex &big_mu() { static std::mutex m; return m; }
+inline std::vector<BigBlock> &big_cache() { static std::vector<BigBlock> v; return v; }
+inline bool big_cache_on() {
+    static const bool on = [] { const char *a = getenv("C3R_NO_BLOCK_CACHE"), *b = getenv("C3R_POISON"); return !(a && *a == '1') && !(b && *b); }();
+    return on;
+}
+inline void *big_take(size_t bytes) {
+    if (!big_cache_on()) return nullptr;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(big_mu());
+    auto &c = big_cache();
+    for (size_t k = 0; k < c.size(); ++k) if (c[k].dev == dev && c[k].bytes == bytes) { void *p = c[k].p; c.erase(c.begin() + (long)k); return p; }
+    return nullptr;
+}
+inline void big_give(void *p, size_t bytes) {
+    if (!p) return;
+    if (big_cache_on() && bytes >= ((size_t)1 << 30)) {
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(big_mu());
+        if (big_cache().size() < 2) { big_cache().push_back(BigBlock{dev, bytes, p}); return; }
+    }
+    (void)hipFree(p);
+}
+
 inline void net_free(NetState &s) {
-    void *ptrs[] = {s.d_w1, s.d_b1, s.d_w2, s.d_b2, s.d_w4, s.d_b4, s.d_w5, s.d_b5, s.d_wo, s.d_bo, s.d_y1, s.d_y2, s.d_a4, s.d_probs,
+    void *ptrs[] = {s.d_w1, s.d_b1, s.d_w2, s.d_b2, s.d_w4, s.d_b4, s.d_w5, s.d_b5, s.d_wo, s.d_bo, s.d_y2, s.d_a4, s.d_probs,
                     s.d_w1h, s.d_w2h, s.d_w4h, s.d_w4f, s.d_w5p, s.d_wcp, s.d_w1q, s.d_w1s, s.d_w2q, s.d_w2s, s.d_w4q, s.d_w4s};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    big_give(s.d_y1, (size_t)s.cap_sites * NET_T * 2 * NET_H1 * sizeof(float));
     s = NetState();
 }
 
@@ -1664,8 +1695,9 @@ inline int net_reserve(NetState &s, int64_t n_total, hipStream_t st, std::string
     for (int i = 0; i < 3; ++i) {
         const bool is_y2 = i == 1;
         if (!grow && !is_y2) continue;                                   // only y2 is missing (precision switched to fp32)
-        if (*bufs[i]) { (void)hipFree(*bufs[i]); *bufs[i] = nullptr; }
+        if (*bufs[i]) { if (i == 0) big_give(*bufs[i], (size_t)s.cap_sites * NET_T * 2 * NET_H1 * sizeof(float)); else (void)hipFree(*bufs[i]); *bufs[i] = nullptr; }
         if (is_y2 && !want_y2) continue;
+        if (i == 0 && (*bufs[i] = (float *)big_take(sizes[i] * sizeof(float)))) continue;
         NET_HIP(hipMalloc((void **)bufs[i], sizes[i] * sizeof(float)));
         if (const char *e = getenv("C3R_POISON")) if (*e) { NET_HIP(hipMemsetAsync(*bufs[i], atoi(e) & 0xff, sizes[i] * sizeof(float), st)); NET_HIP(hipStreamSynchronize(st)); }
     }
