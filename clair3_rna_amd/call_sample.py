@@ -410,7 +410,6 @@ def Run(args, log=None):
         if timeline:
             log("[timeline] %-6s %-8s %7.3f -> %7.3f s" % (ctg, what, t0 - t_all, time() - t_all))
 
-    warm_lock, warmed = threading.Lock(), set()
 
     def fetch_task(ctg):
         t0 = time()
@@ -428,21 +427,11 @@ def Run(args, log=None):
             rs, ref, dt = fut.result()
             if not len(rs.reads):
                 return None
-            # A context sizes its device buffers on its first contig (the largest it will see: contigs are called largest
-            # first).  hipMalloc of several GB under another context's running kernels is slow (58 ms idle, ~300-500 ms busy)
-            # and holds up every other HIP call of the process meanwhile, so first uses take turns, each on a quiet GPU.
-            first = id(eng) not in warmed
-            if first:
-                warm_lock.acquire()
-            try:
-                t0 = time()
-                todo = device_stage(eng, ctg, rs, ref)
-                if first:
-                    eng.synchronize()
-            finally:
-                if first:
-                    warmed.add(id(eng))
-                    warm_lock.release()
+            # (A context sizes its device buffers on its first contig.  Round 2 made first uses take turns, each on a quiet GPU,
+            # because a multi-GB hipMalloc under another context's kernels took 0.3-0.5 s; with the network's buffers reserved
+            # ahead (c3r_reserve) what is left is cheaper than the wait: 1.38-1.47 s against 1.58-1.60 s on 22 half-length contigs.)
+            t0 = time()
+            todo = device_stage(eng, ctg, rs, ref)
             t1 = time()
             mark(ctg, "device", t0)
             with lock:
