@@ -286,9 +286,22 @@ def Run(args, log=None):
         used to come before the first BAM byte was read)."""
         for _ in range(n_ctx):
             engines.append(capi.Engine(args.gpu_id))
-        for e in engines:
-            e.load_weights(weights, channels)
-            e.set_precision(args.gpu_precision)
+        errs = []
+
+        def prepare(e):
+            try:
+                e.load_weights(weights, channels)             # (packing the weights into the kernels' layouts is host work: side by side)
+                e.set_precision(args.gpu_precision)
+            except BaseException as ex:
+                errs.append(ex)
+        th = [threading.Thread(target=prepare, args=(e,)) for e in engines[1:]]
+        for t_ in th:
+            t_.start()
+        prepare(engines[0])
+        for t_ in th:
+            t_.join()
+        if errs:
+            raise errs[0]
         if args.gpu_precision != "f16x3":
             log("[INFO] network arithmetic: %s -> %s (calibration max |dP| %s)" % ((args.gpu_precision,) + tuple(engines[0].precision())))
     qual_rows = args.qual if args.qual is not None else 2              # call_variants.py:1827 (STEP 1 never passes --qual)
