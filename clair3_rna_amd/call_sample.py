@@ -33,7 +33,10 @@ import threading
 from concurrent.futures import ThreadPoolExecutor
 from time import time
 
+import numpy as np
+
 from . import io, sort_vcf, vcf
+from .reads import READ_DTYPE, ReadSet
 from .call_var_bam import existing, resolve_region
 
 
@@ -172,40 +175,104 @@ def _all_ranks_ok(dist, world, err, what):
 
 
 class _Fetcher(object):
-    """Stage 1: whole-contig read fetch + reference slice, one BAM handle per worker thread."""
+    """Stage 1: a contig's alignments + reference slice, one BAM handle per worker thread.  A long contig is fetched as several
+    position ranges on several threads (`plan` / `part` / `join`): the first contig of a sample is then ready after a fraction of
+    the 0.4 s a cold handle needs for a whole chromosome, and the contexts start that much earlier."""
+
+    PART_BP = 24_000_000                 # shortest range worth a fetch of its own
 
     def __init__(self, bam_fn, ref_fn):
         self.bam_fn, self.ref_fn, self.tls = bam_fn, ref_fn, threading.local()
         self.handles, self.fai = [], None
+        self.lock = threading.Lock()
 
-    def __call__(self, ctg, length):
-        t0 = time()
-        t_open = t_bam = 0.0
-        if self.bam_fn.endswith(".npz"):
-            rs = io.load_reads(self.bam_fn, ctg)
-        else:
-            from . import bamio
-            bf = getattr(self.tls, "bf", None)
-            if bf is None:
-                bf = self.tls.bf = bamio.BamFile(self.bam_fn, threads=int(os.environ.get("C3R_FETCH_INFLATE", "8")))
+    def _handle(self):
+        from . import bamio
+        bf = getattr(self.tls, "bf", None)
+        if bf is None:
+            bf = self.tls.bf = bamio.BamFile(self.bam_fn, threads=int(os.environ.get("C3R_FETCH_INFLATE", "8")))
+            with self.lock:
                 self.handles.append(bf)
-                t_open = time() - t0
-            rs = bf.fetch(ctg)
-            t_bam = time() - t0 - t_open
-        ref = b""
-        if len(rs.reads):
-            # the whole contig, upper-cased, line ends dropped, by parallel pread (c3r_fasta_fetch) — a 250-Mb chromosome went
-            # through Python's bytes.replace in 0.4 s with the GIL held, which stalled every other thread of the process
-            from . import bamio
+        return bf
+
+    def plan(self, length, max_parts):
+        """-> [(beg0, end0), ...] position ranges of one contig, in order (one range: the whole contig)."""
+        if self.bam_fn.endswith(".npz") or max_parts <= 1:
+            return [(0, None)]
+        n = max(1, min(max_parts, length // int(os.environ.get("C3R_FETCH_PART_BP", self.PART_BP))))      # (the variable: tests split small contigs)
+        if n > 1 and not self._handle().has_index:
+            n = 1
+        edges = [length * k // n for k in range(n + 1)]
+        return [(edges[k], edges[k + 1] if k + 1 < n else None) for k in range(n)]
+
+    def part(self, ctg, beg0, end0):
+        """The alignments that START in [beg0, end0) (a fetch returns everything that overlaps the range: what started before it
+        belongs to the range before) -> ReadSet views, offsets relative to this part."""
+        if self.bam_fn.endswith(".npz"):
+            return io.load_reads(self.bam_fn, ctg)
+        rs = self._handle().fetch(ctg, beg0, end0)
+        if beg0 > 0 and len(rs.reads):
+            i0 = int(np.searchsorted(rs.reads["pos"], beg0, side="left"))
+            if i0:
+                if i0 >= len(rs.reads):
+                    return _empty_reads()
+                c0, s0 = int(rs.reads["cigar_off"][i0]), int(rs.reads["seq_off"][i0])
+                out = ReadSet.__new__(ReadSet)
+                out.reads, out.cigar, out.seq = rs.reads[i0:], rs.cigar[c0:], rs.seq[s0:]
+                out.base = (c0, s0)
+                return out
+        return rs
+
+    def reference(self, ctg, length):
+        from . import bamio
+        with self.lock:
             if self.fai is None:
                 self.fai = {r[0]: r for r in io.read_fai(self.ref_fn)}
-            ref = bamio.fasta_fetch(self.ref_fn, self.fai[ctg], 0, length)
-        self.tls.detail = "open %.0f ms, alignments %.0f ms, reference %.0f ms" % (1e3 * t_open, 1e3 * t_bam, 1e3 * (time() - t0 - t_open - t_bam))
+        # the whole contig, upper-cased, line ends dropped, by parallel pread (c3r_fasta_fetch) — a 250-Mb chromosome went
+        # through Python's bytes.replace in 0.4 s with the GIL held, which stalled every other thread of the process
+        return bamio.fasta_fetch(self.ref_fn, self.fai[ctg], 0, length)
+
+    @staticmethod
+    def join(parts):
+        """Parts in position order -> one ReadSet (arrays from c3r_io_alloc, offsets moved)."""
+        parts = [p_ for p_ in parts if len(p_.reads)]
+        if not parts:
+            return _empty_reads()
+        if len(parts) == 1 and getattr(parts[0], "base", (0, 0)) == (0, 0):
+            return parts[0]
+        from . import bamio
+        out = ReadSet.__new__(ReadSet)
+        out.reads = bamio.huge_empty(sum(len(p_.reads) for p_ in parts), READ_DTYPE)
+        out.cigar = bamio.huge_empty(sum(len(p_.cigar) for p_ in parts), np.uint32)
+        out.seq = bamio.huge_empty(sum(len(p_.seq) for p_ in parts), np.uint8)
+        r0 = c0 = s0 = 0
+        for p_ in parts:
+            nr, nc, ns = len(p_.reads), len(p_.cigar), len(p_.seq)
+            bc, bs = getattr(p_, "base", (0, 0))
+            out.reads[r0:r0 + nr] = p_.reads
+            out.reads["cigar_off"][r0:r0 + nr] += np.uint32((c0 - bc) & 0xffffffff)      # (modular: the sum is the new offset)
+            out.reads["seq_off"][r0:r0 + nr] += np.uint64((s0 - bs) & 0xffffffffffffffff)
+            out.cigar[c0:c0 + nc] = p_.cigar
+            out.seq[s0:s0 + ns] = p_.seq
+            r0 += nr; c0 += nc; s0 += ns
+        return out
+
+    def __call__(self, ctg, length):
+        """The whole contig on the calling thread -> (ReadSet, reference array or b"", seconds)."""
+        t0 = time()
+        rs = self.join([self.part(ctg, 0, None)])
+        ref = self.reference(ctg, length) if len(rs.reads) else b""
         return rs, ref, time() - t0
 
     def close(self):
         for bf in self.handles:
             bf.close()
+
+
+def _empty_reads():
+    out = ReadSet.__new__(ReadSet)
+    out.reads, out.cigar, out.seq = np.zeros(0, READ_DTYPE), np.zeros(0, np.uint32), np.zeros(0, np.uint8)
+    return out
 
 
 def Run(args, log=None):
@@ -424,13 +491,51 @@ def Run(args, log=None):
             log("[timeline] %-6s %-8s %7.3f -> %7.3f s" % (ctg, what, t0 - t_all, time() - t_all))
 
 
-    def fetch_task(ctg):
+    def submit_fetch(pool, ctg):
+        """A contig's fetch as tasks of the fetch pool — one per position range (_Fetcher.plan) and one for the reference — joined
+        by whichever finishes last.  -> Future of (ReadSet, reference, seconds)."""
+        from concurrent.futures import Future
         t0 = time()
-        r = fetcher(ctg, fai[ctg])
-        mark(ctg, "fetch", t0)
-        if timeline:
-            log("[timeline-fetch %s] %d reads, %d CIGAR ops, %.0f MB of bases, %.0f Mb of reference: %s" % (ctg, len(r[0].reads), len(r[0].cigar), len(r[0].seq) / 1e6, len(r[1]) / 1e6, getattr(fetcher.tls, "detail", "")))
-        return r
+        ranges = fetcher.plan(fai[ctg], max(1, args.fetch_threads))
+        out = Future()
+        state = dict(left=len(ranges) + 1, parts=[None] * len(ranges), ref=b"", err=None)
+        lk = threading.Lock()
+
+        def done_one():
+            with lk:
+                state["left"] -= 1
+                last = state["left"] == 0
+            if not last:
+                return
+            try:
+                if state["err"] is not None:
+                    raise state["err"]
+                rs = fetcher.join(state["parts"])
+                mark(ctg, "fetch", t0)
+                if timeline:
+                    log("[timeline-fetch %s] %d range(s): %d reads, %d CIGAR ops, %.0f MB of bases, %.0f Mb of reference" % (ctg, len(ranges), len(rs.reads), len(rs.cigar), len(rs.seq) / 1e6, len(state["ref"]) / 1e6))
+                out.set_result((rs, state["ref"] if len(rs.reads) else b"", time() - t0))
+            except BaseException as e:
+                out.set_exception(e)
+
+        def part_task(k, beg, end):
+            try:
+                state["parts"][k] = fetcher.part(ctg, beg, end)
+            except BaseException as e:
+                state["err"] = e
+            done_one()
+
+        def ref_task():
+            try:
+                state["ref"] = fetcher.reference(ctg, fai[ctg])
+            except BaseException as e:
+                state["err"] = e
+            done_one()
+
+        for k, (beg, end) in enumerate(ranges):
+            pool.submit(part_task, k, beg, end)
+        pool.submit(ref_task)
+        return out
 
     def context_task(eng, ctg, fut):
         """One contig on the context whose thread took it from the queue (contigs are taken in calling order by whichever context
@@ -576,7 +681,7 @@ def Run(args, log=None):
                         slots.acquire()
                         if stop.is_set():
                             break
-                        fut = fetch_pool.submit(fetch_task, c)
+                        fut = submit_fetch(fetch_pool, c)
                         tasks[i] = Future()
                         ctx_queue.put((c, fut, tasks[i]))
                         submitted[i].set()

@@ -207,3 +207,40 @@ def test_fetch_reference_slices_like_faidx(tmp_path):
     assert io.fetch_reference(fa, "c2", 1, 10 ** 9, raw=True) == seq2.encode()
     with pytest.raises(KeyError):
         io.fetch_reference(fa, "nope", 1, 2)
+
+
+def test_a_contig_fetched_as_position_ranges_equals_the_whole_fetch(tmp_path, monkeypatch):
+    """call_sample's fetcher splits a long contig into position ranges fetched on several threads and joins them (reads that start
+    before a range belong to the range before; offsets moved): the joined ReadSet must be the whole-contig fetch — with long
+    ref-skips crossing the range edges, ranges without a read, and every number of ranges."""
+    import numpy as np
+    from clair3_rna_amd import bam, bamio, call_sample, synth
+    L = 900000
+    ref, rs, _ = synth.generate_contig(contig_len=L, seed=21, depth=30.0, expressed_frac=0.05, intron_hi=120000.0)
+    bm = str(tmp_path / "x.bam")
+    bam.write_bam(bm, [("chr1", L), ("chr2", 1000)], {"chr1": rs})
+    bamio.index_build(bm)
+    fa = str(tmp_path / "r.fa")
+    io.write_fasta(fa, [("chr1", ref.decode()), ("chr2", "A" * 1000)])
+    f = call_sample._Fetcher(bm, fa)
+    whole = f.part("chr1", 0, None)
+    assert len(whole.reads) > 500 and np.array_equal(whole.reads["pos"], rs.reads["pos"])
+    end = whole.reads["pos"].astype(np.int64) + 1
+    for n_parts, part_bp in ((2, 400000), (5, 100000), (8, 30000), (64, 1000)):
+        monkeypatch.setenv("C3R_FETCH_PART_BP", str(part_bp))
+        ranges = f.plan(L, n_parts)
+        assert len(ranges) == min(n_parts, L // part_bp) and ranges[0][0] == 0 and ranges[-1][1] is None
+        assert all(ranges[k][1] == ranges[k + 1][0] for k in range(len(ranges) - 1))
+        parts = [f.part("chr1", b, e) for b, e in ranges]
+        assert sum(len(p_.reads) for p_ in parts) == len(whole.reads)           # every read in exactly one range
+        got = f.join(parts)
+        for name in ("pos", "n_cigar", "l_seq", "flag", "mapq", "hp", "cigar_off", "seq_off"):
+            assert np.array_equal(got.reads[name], whole.reads[name]), (n_parts, name)
+        assert np.array_equal(got.cigar, whole.cigar) and np.array_equal(got.seq, whole.seq)
+    assert any(len(p_.reads) == 0 for p_ in parts)                               # (5 % of the contig is expressed: empty ranges exist)
+    monkeypatch.setenv("C3R_FETCH_PART_BP", "100")
+    assert f.plan(1000, 8) == [(0, 125), (125, 250), (250, 375), (375, 500), (500, 625), (625, 750), (750, 875), (875, None)]
+    assert len(f.join([f.part("chr2", b, e) for b, e in f.plan(1000, 8)]).reads) == 0
+    rs2, ref2, _dt = f("chr1", L)
+    assert np.array_equal(rs2.cigar, whole.cigar) and ref2.tobytes().decode() == ref.decode().upper()
+    f.close()
