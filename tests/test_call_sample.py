@@ -244,3 +244,26 @@ def test_a_contig_fetched_as_position_ranges_equals_the_whole_fetch(tmp_path, mo
     rs2, ref2, _dt = f("chr1", L)
     assert np.array_equal(rs2.cigar, whole.cigar) and ref2.tobytes().decode() == ref.decode().upper()
     f.close()
+
+
+def test_a_failing_fetch_ends_the_run_with_an_error_not_a_hang(tmp_path):
+    """A BAM whose blocks are damaged inside the second contig: that contig's fetch raises on a fetch thread, the error reaches the
+    main loop through the joined future, the workers are stopped and the driver exits 1 with the message."""
+    import time
+    tmp = str(tmp_path)
+    fa, bm, wfn = _fake_sample(tmp)
+    raw = bytearray(open(bm, "rb").read())
+    # find the BGZF block that holds the middle of the file and damage its deflate stream
+    off, blocks = 0, []
+    while off + 18 <= len(raw):
+        bs = int.from_bytes(raw[off + 16:off + 18], "little") + 1
+        blocks.append((off, bs))
+        off += bs
+    o, bs = blocks[len(blocks) // 2]
+    for k in range(o + 30, o + min(bs - 10, 400)):
+        raw[k] ^= 0x5a
+    open(bm, "wb").write(bytes(raw))
+    t0 = time.time()
+    codes, outs = _launch(tmp, os.path.join(tmp, "bad"), fa, bm, wfn, ["--print_ref_calls"], expect_fail=True)
+    assert codes == [1] and "[ERROR] call_sample" in outs[0] and "c3r_bam_fetch" in outs[0], outs
+    assert time.time() - t0 < 60
