@@ -183,3 +183,28 @@ def test_reference_view_equals_the_copied_reference(eng):
     junk = [np.full(40000, 78, np.uint8) for _ in range(64)]           # (freed arrays would be reused by these)
     got = [sn.decode("chr20", qual=2, show_ref=True) for sn in snaps]
     assert got == [x[2] for x in want] and junk
+
+
+def test_reserve_sizes_the_network_before_the_first_infer():
+    """c3r_reserve needs the weights (the buffer shapes follow the precision in use), is idempotent, and leaves c3r_infer's results
+    untouched; a second context of the process takes over the first one's released layer-1 block."""
+    import numpy as np
+    from clair3_rna_amd import capi, synth
+    ref, rs, _ = synth.small_case(seed=515, ref_len=30000, n_genes=6, depth=18)
+    w = synth.random_weights(18, seed=79)
+    probs = []
+    for k in range(2):
+        e = capi.Engine(0)
+        try:
+            if k == 0:
+                with pytest.raises(capi.C3RError):
+                    e.reserve(1000)
+            e.load_weights(w, 18); e.set_precision("f16x3")
+            if k == 1:
+                e.reserve(300000); e.reserve(300000); e.reserve(0)
+            e.load_reads(rs); e.set_reference(1, ref)
+            assert e.scan(1, len(ref)) > 20
+            probs.append(np.array(e.infer(), copy=True))
+        finally:
+            e.close()
+    assert np.array_equal(probs[0], probs[1])
