@@ -156,7 +156,7 @@ def build_parser():
     a("--gpu_precision", type=str, default=_env_precision(), choices=["f32", "f16x3", "f16+f8", "auto"],
       help="network arithmetic (c3r_set_precision): f16x3 = fp32-equivalent split-f16 (default); auto = the faster fp8-corrected path where a "
            "calibration run through the loaded weights agrees with f16x3 to 4e-5, else f16x3")
-    a("--fetch_threads", type=int, default=8, help="contigs fetched ahead of the contexts, each on its own thread (BGZF inflate on C3R_FETCH_INFLATE threads per fetch); 8 measured best on a 256-thread host, capped by the rank's share of the cores under torch.distributed")
+    a("--fetch_threads", type=int, default=8, help="threads that fetch alignments (long contigs as several position ranges, BGZF inflate on C3R_FETCH_INFLATE threads each) and reference slices ahead of the contexts; capped by the rank's share of the cores under torch.distributed")
     a("--contexts", type=int, default=2, help="GPU contexts (each with its own host thread and HIP stream) working side by side: while one waits for its kernels the other normalises reads or decodes (every context sizes its own device buffers on its first contig; first uses take turns)")
     return p
 
