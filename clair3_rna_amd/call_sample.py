@@ -770,13 +770,36 @@ def Run(args, log=None):
                 for k, (a, b, c) in j["counts"].items():
                     merger.n_read += a; merger.n_kept += b; merger.n_tagged += c
             called = [c for c in all_contigs if c in called_set]
+            todo = []
             for k, c in enumerate(all_contigs):
                 fn = os.path.join(parts_dir, "%05d.vcf" % k)
                 if c in called_set and os.path.exists(fn) and os.path.getsize(fn):
+                    todo.append((fn, os.path.join(parts_dir, "%05d_nt.vcf" % k)))
+
+            def load_part(fns):
+                """One contig's merged records as the ranks left them -> what the writer takes: with compressed output a piece
+                compressed and indexed here, on a pool thread (the ordered step is then a file append), else the text."""
+                out = []
+                for fn_, want in ((fns[0], True), (fns[1], merger.out_nt is not None)):
+                    if not want or not os.path.exists(fn_):
+                        out.append(None)
+                    elif merger.stream_gz:
+                        from . import bamio as _b
+                        data = np.fromfile(fn_, dtype=np.uint8)
+                        out.append(_b.VcfPiece(data) if data.size else None)
+                    else:
+                        out.append(open(fn_).read())
+                return out
+            with ThreadPoolExecutor(max(1, min(8, n_thr // 4 or 1))) as part_pool:
+                for main_part, nt_part in part_pool.map(load_part, todo):
                     merger._header()
-                    merger.out.write(open(fn).read())
-                    if merger.out_nt:
-                        merger.out_nt.write(open(os.path.join(parts_dir, "%05d_nt.vcf" % k)).read())
+                    for out_, m_ in ((merger.out, main_part), (merger.out_nt, nt_part)):
+                        if out_ is None or m_ is None:
+                            continue
+                        if hasattr(m_, "free"):
+                            out_.append(m_)
+                        else:
+                            out_.write(m_)
         t0 = time()
         n_read, n_kept, n_tag = merger.close(log)
         mark("all", "close_out", t0)

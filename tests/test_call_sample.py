@@ -110,13 +110,13 @@ def _fake_sample(tmp):
     return fa, bm, wfn
 
 
-def _launch(tmp, out, fa, bm, wfn, extra, world=1, env_extra=None, expect_fail=False):
+def _launch(tmp, out, fa, bm, wfn, extra, world=1, env_extra=None, expect_fail=False, compress=False):
     import socket
     import subprocess
     import sys
     launcher = os.path.join(HERE, "support", "fake_engine_sample.py")
     argv = [sys.executable, launcher, "--bam_fn", bm, "--ref_fn", fa, "--output_dir", out, "--pileup_model_path", wfn, "--chunk_size", "9000",
-            "--no_compress", "--gpu_id", "0"] + extra
+            "--gpu_id", "0"] + ([] if compress else ["--no_compress"]) + extra
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -134,7 +134,12 @@ def _launch(tmp, out, fa, bm, wfn, extra, world=1, env_extra=None, expect_fail=F
     if expect_fail:
         return [p.returncode for p in procs], outs
     assert all(p.returncode == 0 for p in procs), outs
-    return [r for r in open(os.path.join(out, "output.vcf")).read().split("\n") if not r.startswith("##cmdline=")]
+    if compress:
+        assert os.path.exists(os.path.join(out, "output.vcf.gz.tbi")) and not os.path.exists(os.path.join(out, "output.vcf"))
+        text = gzip.open(os.path.join(out, "output.vcf.gz"), "rt").read()
+    else:
+        text = open(os.path.join(out, "output.vcf")).read()
+    return [r for r in text.split("\n") if not r.startswith("##cmdline=")]
 
 
 def test_driver_orchestration_single_and_two_ranks_gloo(tmp_path):
@@ -161,6 +166,9 @@ def test_driver_orchestration_single_and_two_ranks_gloo(tmp_path):
     assert sorted(called[0] + called[1]) == ["chr1", "chr2", "chr3", "chrX"]
     three_ctx = _launch(tmp, os.path.join(tmp, "ctx3"), fa, bm, wfn, ["--print_ref_calls", "--contexts", "3", "--fetch_threads", "1"])
     assert three_ctx == one
+    # compressed output: streamed pieces in one process; under two ranks the parts compressed on a pool at rank 0 and appended in order
+    assert _launch(tmp, os.path.join(tmp, "gz1"), fa, bm, wfn, ["--print_ref_calls"], compress=True) == one
+    assert _launch(tmp, os.path.join(tmp, "gz2"), fa, bm, wfn, ["--print_ref_calls"], world=2, compress=True) == one
     no_ref = _launch(tmp, os.path.join(tmp, "noref"), fa, bm, wfn, ["--qual", "10"], world=2)
     kept = [r.split("\t") for r in no_ref if r and r[0] != "#"]
     assert kept and all(r[4] != "." for r in kept) and all((r[6] == "LowQual") == (float(r[5]) <= 10) for r in kept)
