@@ -432,6 +432,17 @@ def Run(args, log=None):
         return rows
 
     part_counts = {}
+    edits_cache, edits_lock = [], threading.Lock()
+
+    def edits_by_contig():
+        """The REDIportal table as per-contig entry lists, built once for all the per-contig mergers of this rank."""
+        with edits_lock:
+            if not edits_cache:
+                d = {}
+                for (c, pos), hit in (table or {}).items():
+                    d.setdefault(c, []).append((pos, hit[0], hit[1]))
+                edits_cache.append(d)
+        return edits_cache[0]
 
     def merge_contig(ctg, rows):
         if world == 1:
@@ -440,6 +451,8 @@ def Run(args, log=None):
             k = all_contigs.index(ctg)
             m = sort_vcf.SampleMerger(os.path.join(parts_dir, "%05d.vcf" % k), "", qual_merge, args.print_ref_calls, table,
                                       os.path.join(parts_dir, "%05d_nt.vcf" % k))
+            if table:
+                m._edits = edits_by_contig()
             m.add_contig(ctg, rows)
             m.out.close()
             if m.out_nt:
@@ -575,14 +588,16 @@ def Run(args, log=None):
         try:
             t0 = time()
             # (rows stay a uint8 array from here to the compressed piece: no 100-MB bytes objects built under the GIL)
-            rows = snap.decode(ctg, qual=qual_rows, show_ref=args.print_ref_calls, as_array=world == 1)[0]
+            rows = snap.decode(ctg, qual=qual_rows, show_ref=args.print_ref_calls, as_array=True)[0]
             mark(ctg, "decode", t0)
+            t1 = time()
             if world == 1:
-                t1 = time()
                 res = ("merged", merger.merge_only(ctg, rows))
-                mark(ctg, "merge", t1)
-                return res
-            return rows
+            else:
+                merge_contig(ctg, rows)                    # this rank's part files of the contig, written here on the worker
+                res = ("merged", None)
+            mark(ctg, "merge", t1)
+            return res
         finally:
             pass
 

@@ -170,8 +170,8 @@ class SampleMerger(object):
         if self.native is False:
             return self.add_contig_py(contig, rows)
         from . import bamio
-        blob = rows.encode() if isinstance(rows, str) else bytes(rows)
-        if not blob:
+        blob = rows.encode() if isinstance(rows, str) else (rows if hasattr(rows, "ctypes") else bytes(rows))     # (uint8 array: by pointer)
+        if not len(blob):
             return
         edits = None
         if self.rediportal:
