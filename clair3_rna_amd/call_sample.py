@@ -740,7 +740,8 @@ def Run(args, log=None):
                         rows = rows.result()
                     t0 = time()
                     if isinstance(rows, tuple) and rows[0] == "merged":
-                        merger.write_merged(rows[1])                   # merged on the worker: only the ordered write is left
+                        if rows[1] is not None:
+                            merger.write_merged(rows[1])               # merged on the worker: only the ordered write is left
                     else:
                         merge_contig(ctg, rows)
                     t_merge += time() - t0
