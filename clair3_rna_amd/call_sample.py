@@ -856,6 +856,15 @@ def main(argv=None):
     except Exception as e:       # fail loudly: there is no CPU fallback
         print("[ERROR] call_sample (MI355X path) failed: %s" % e, file=sys.stderr)
         return 1
+    finally:
+        # (the command-line run owns the process group Run() created: taken down here rather than by the interpreter's exit)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            try:
+                import torch.distributed as dist
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
 
 
 if __name__ == "__main__":

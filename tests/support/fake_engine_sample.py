@@ -71,6 +71,24 @@ class FakeEngine(object):
         return "".join(rows).encode(), len(rows)
 
 
+class FakeSnapshot(object):
+    """Stand-in for capi.RowSnapshot: the rows of one contig, detached from the engine (decoded later, on a worker thread)."""
+
+    def __init__(self, rows):
+        self.rows = rows
+
+    def decode(self, ctg, qual=2, show_ref=True, as_array=False):
+        eng = FakeEngine()
+        eng._rows = self.rows
+        text, n = eng.call_rows_text(ctg, qual, show_ref)
+        return (np.frombuffer(text, dtype=np.uint8) if as_array else text), n
+
+    def free(self): pass
+
+
+if os.environ.get("C3R_FAKE_SNAPSHOTS") == "1":          # the driver's detached path: c3r_rows_begin -> decode pool -> worker-side merge
+    FakeEngine.rows_begin = lambda self: FakeSnapshot(list(self._rows))
+    FakeEngine.reserve = lambda self, n: None
 capi.Engine = FakeEngine
 if __name__ == "__main__":
     sys.exit(call_sample.main())

@@ -133,7 +133,7 @@ def _launch(tmp, out, fa, bm, wfn, extra, world=1, env_extra=None, expect_fail=F
     outs = [p.communicate(timeout=300)[0] for p in procs]
     if expect_fail:
         return [p.returncode for p in procs], outs
-    assert all(p.returncode == 0 for p in procs), outs
+    assert all(p.returncode == 0 for p in procs), ([p.returncode for p in procs], outs)
     if compress:
         assert os.path.exists(os.path.join(out, "output.vcf.gz.tbi")) and not os.path.exists(os.path.join(out, "output.vcf"))
         text = gzip.open(os.path.join(out, "output.vcf.gz"), "rt").read()
@@ -166,6 +166,12 @@ def test_driver_orchestration_single_and_two_ranks_gloo(tmp_path):
     assert sorted(called[0] + called[1]) == ["chr1", "chr2", "chr3", "chrX"]
     three_ctx = _launch(tmp, os.path.join(tmp, "ctx3"), fa, bm, wfn, ["--print_ref_calls", "--contexts", "3", "--fetch_threads", "1"])
     assert three_ctx == one
+    # the detached path of the real engine (row snapshots decoded, merged and — one process — compressed on the worker pool)
+    snap = {"C3R_FAKE_SNAPSHOTS": "1"}
+    assert _launch(tmp, os.path.join(tmp, "snap1"), fa, bm, wfn, ["--print_ref_calls"], env_extra=snap) == one
+    assert _launch(tmp, os.path.join(tmp, "snap2"), fa, bm, wfn, ["--print_ref_calls"], world=2, env_extra=snap) == one
+    assert _launch(tmp, os.path.join(tmp, "snap1z"), fa, bm, wfn, ["--print_ref_calls"], env_extra=snap, compress=True) == one
+    assert _launch(tmp, os.path.join(tmp, "snap2z"), fa, bm, wfn, ["--print_ref_calls"], world=2, env_extra=snap, compress=True) == one
     # compressed output: streamed pieces in one process; under two ranks the parts compressed on a pool at rank 0 and appended in order
     assert _launch(tmp, os.path.join(tmp, "gz1"), fa, bm, wfn, ["--print_ref_calls"], compress=True) == one
     assert _launch(tmp, os.path.join(tmp, "gz2"), fa, bm, wfn, ["--print_ref_calls"], world=2, compress=True) == one
