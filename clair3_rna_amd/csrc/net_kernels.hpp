@@ -1353,8 +1353,15 @@ inline void big_give(void *p, size_t bytes) {
     if (!p) return;
     if (big_cache_on() && bytes >= ((size_t)1 << 30)) {
         int dev = 0; (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> g(big_mu());
-        if (big_cache().size() < 2) { big_cache().push_back(BigBlock{dev, bytes, p}); return; }
+        void *evict = nullptr;
+        {
+            std::lock_guard<std::mutex> g(big_mu());
+            auto &c = big_cache();
+            if (c.size() >= 2) { evict = c.front().p; c.erase(c.begin()); }      // the older of the two goes: sizes nobody asks for again do not stay
+            c.push_back(BigBlock{dev, bytes, p});
+        }
+        if (evict) (void)hipFree(evict);
+        return;
     }
     (void)hipFree(p);
 }
