@@ -23,7 +23,6 @@
 #include "net_kernels.hpp"
 #include "pileup_kernels.hpp"
 #include "reads_kernels.hpp"
-#include <rocprim/device/device_radix_sort.hpp>
 
 using namespace c3r;
 
@@ -51,11 +50,20 @@ struct c3r_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // ---- inputs: the device holds the read tables; host copies are fetched on demand (depth cap, decode)
-    int32_t n_reads = 0, n_segs = 0;       // of the loaded contig
-    int64_t n_indel_ops = 0;               // I + D ops of the normalised CIGARs: bounds the indel-event scratch of a scan
-    int64_t n_seq_bytes = 0;
+    int32_t n_reads = 0;                   // of the loaded contig
+    int64_t n_indel_ops = 0;               // I + D ops of the passing reads: bounds the indel-event scratch of a scan
+    int64_t n_seq_bytes = 0, n_cigar_ops = 0;
     DevBuf d_rawreads, d_rawcig;           // the caller's records as they arrived (c3r_read_t, BAM-encoded ops)
-    DevBuf d_rcnt, d_rend, d_pass, d_ekey, d_ekey2, d_skey, d_skey2, d_sval, d_sval2, d_sorttmp, d_s4tops, d_pmtops, d_stats;
+    // the pile table (reads_kernels.hpp): bin counters {cnt | sc | ec | pc}, their prefix sums, the records, per-read notes of k_prep
+    DevBuf d_bincnt, d_tab, d_recs, d_serial, d_nind, d_lbk, d_stats;
+    BinGeo bins{0, 0};
+    int32_t first_pos = 0;                 // pos of the first read (the bins start there)
+    int64_t last_pos = 0;                  // pos of the last read (first guess of where the bins end)
+    bool bins_dirty = true;                // the counters are not all zero (failed load)
+    size_t bins_zeroed = 0;                // bytes of d_bincnt known to be zero when !bins_dirty
+    // legacy tables for token_at (30-channel mode only), built on demand: normalised CIGARs, aligned segments in read order
+    DevBuf d_lcnt;
+    bool legacy_valid = false;
     LoadStats *h_stats = nullptr;          // pinned
     void *h_pack = nullptr;                // pinned: the indel-record count of k_pack_tokens
     DevBuf d_tokb, d_tokrec, d_recoff;     // packed tokens of a row snapshot (c3r_rows_begin)
@@ -65,17 +73,16 @@ struct c3r_ctx {
     std::vector<uint8_t> h_seq;            // lazily: ensure_host_seq (decode reads inserted bases)
     bool host_seq_valid = false;
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
-    DevBuf d_bkt; int32_t n_bkt = 0;       // bucket index of the sorted read / segment arrays (k_bucket_index)
     DevBuf d_dbg;                          // C3R_SCAN_DBG: phase timers of k_scan_tiles
     DevBuf d_tile_cand;                    // [n_tiles] {first candidate, count} of the most recent scan (k_compact_write -> k_tile_tokens)
-    DevBuf d_ops, d_seg_op_off;            // expanded op records of the sorted segments (pileup_kernels.hpp, OpRec) and each segment's first record
-    DevBuf d_segs, d_seg_prefmax, d_tile_cols, d_tile_rng, d_tile_list, d_tile_list2, d_rsegs, d_rseg_first;
+    DevBuf d_tile_cols, d_tile_rng, d_tile_list, d_tile_list2, d_rsegs, d_rseg_first;
     ScanArgs last_scan;                    // arguments of the most recent scan (c3r_get_columns completes the pruned tiles with them)
     bool last_scan_pruned = false;
     // the fused path (k_fused_tiles): look-back words and counters, region bounds, what the last scan covered
     DevBuf d_lb, d_regb, d_span, d_spanbase, d_meta, d_spanrec;
     DevBuf d_winidx;                       // [resident candidates] row of the i-th site's window in d_tensors (the fused path writes windows as they arrive)
     DevBuf d_rawidx, d_export;             // c3r_get_tensors: index of a raw re-run, windows gathered into position order
+    DevBuf d_tokexp, d_tokoff;             // c3r_get_tokens: tokens gathered into site order, their offsets there
     int32_t *h_scan = nullptr;             // pinned: what a fused scan reads back (totals, overflow flags)
     bool last_fused = false;
     std::vector<int64_t> last_starts, last_ends;
@@ -252,77 +259,145 @@ struct Launch {
 static int device_excl_scan(c3r_ctx *ctx, int32_t *d, int n, int32_t *d_total);
 namespace {
 
-// ---- the filter-dependent tables, all on the device (reads_kernels.hpp)
-// Part A: pass flags -> rank among the passing reads, their ends sorted, deepest coverage (into the device-side LoadStats).
-int filter_cover(c3r_ctx *ctx) {
+// ---- the device tables of the loaded reads (reads_kernels.hpp): headers, prefix maxima, the pile table.  Everything depends on the
+// filters (records exist only for reads that pass them), so c3r_set_params with new --min-MQ / --excl-flags runs this again on the raw
+// records the device still holds.  Four kernels, one host wait (sizes and validation errors).
+int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
+    int rc;
+    ctx->host_reads_valid = false; ctx->legacy_valid = false;
+    if (!ctx->h_stats) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_stats, sizeof(LoadStats), hipHostMallocDefault));
+    if ((rc = ensure(ctx, ctx->d_stats, sizeof(LoadStats))) || (rc = ensure(ctx, ctx->d_reads, (size_t)n * sizeof(DevRead))) ||
+        (rc = ensure(ctx, ctx->d_serial, (size_t)n + 16)) || (rc = ensure(ctx, ctx->d_nind, (size_t)n * 4 + 16)) || (rc = ensure(ctx, ctx->d_prefmax, (size_t)n * 4 + 16)))
+        return rc;
+    const auto t_begin = std::chrono::steady_clock::now();
+    // bins from the first read's position (the records are sorted) to a guess of the largest end: the last read's position plus 2 Mb —
+    // when a read reaches further (the device knows after the first pass) the table grows and the pass runs again
+    int64_t want_end = std::max<int64_t>(last_pos, ctx->first_pos) + ((int64_t)1 << 21);
+    LoadStats hs;
+    for (int attempt = 0;; ++attempt) {
+        const int32_t base = ctx->first_pos >> BIN_SHIFT;
+        want_end = std::min<int64_t>(want_end, (int64_t)INT32_MAX);
+        const int32_t nb = (int32_t)((want_end >> BIN_SHIFT) - base + 2);
+        const size_t cnt_bytes = (size_t)nb * 4;
+        if (ctx->d_bincnt.cap < 4 * cnt_bytes || !ctx->d_bincnt.p) ctx->bins_zeroed = 0;                                // (a fresh block)
+        if ((rc = ensure(ctx, ctx->d_bincnt, 4 * cnt_bytes)) || (rc = ensure(ctx, ctx->d_tab, (size_t)(nb + 1) * sizeof(int4)))) return rc;
+        ctx->bins = BinGeo{base, nb};
+        // the four counter arrays lie back to back and every pass leaves them all zero (k_bin_scan, k_prep<true>): nothing to clear as
+        // long as they stay inside what has been cleared once
+        if (ctx->bins_dirty || 4 * cnt_bytes > ctx->bins_zeroed) {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_bincnt.p, 0, std::max(4 * cnt_bytes, ctx->bins_zeroed), ctx->stream));
+            ctx->bins_zeroed = std::max(4 * cnt_bytes, ctx->bins_zeroed);
+        }
+        ctx->bins_dirty = true;                               // until this pass has come through
+        const int nb_pm = (n + PM_BLK - 1) / PM_BLK, nb_bs = (nb + BS_BLK - 1) / BS_BLK;
+        const size_t lbk_bytes = 64 + (size_t)(nb_pm + 2 * nb_bs) * 8;
+        if ((rc = ensure(ctx, ctx->d_lbk, lbk_bytes))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_lbk.p, 0, lbk_bytes, ctx->stream));
+        LoadStats init;
+        memset(&init, 0, sizeof init);
+        init.err = ~0ull;
+        *ctx->h_stats = init;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_stats.p, ctx->h_stats, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+        PrepArgs a;
+        memset(&a, 0, sizeof a);
+        a.reads = (const c3r_read_t *)ctx->d_rawreads.p; a.n_reads = n; a.cigars = (const uint32_t *)ctx->d_rawcig.p;
+        a.n_cigar_ops = ctx->n_cigar_ops; a.n_seq_bytes = ctx->n_seq_bytes; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags;
+        a.geo = ctx->bins;
+        uint32_t *cnt = (uint32_t *)ctx->d_bincnt.p;
+        a.cnt = cnt; a.sc = cnt + nb; a.ec = cnt + 2 * (size_t)nb; uint32_t *pc = cnt + 3 * (size_t)nb;
+        a.tab = (const int4 *)ctx->d_tab.p; a.out = (DevRead *)ctx->d_reads.p; a.serial = (uint8_t *)ctx->d_serial.p; a.nind = (int32_t *)ctx->d_nind.p;
+        a.st = (LoadStats *)ctx->d_stats.p;
+        char *lbk = (char *)ctx->d_lbk.p;
+        const unsigned grid = (unsigned)((n + 256 / PREP_GRP - 1) / (256 / PREP_GRP));
+        {
+            Launch L(ctx, "k_prep_count");
+            hipLaunchKernelGGL(k_prep<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
+        }
+        {
+            Launch L(ctx, "k_prefmax_bins");
+            hipLaunchKernelGGL(k_prefmax_bins, dim3(nb_pm), dim3(1024), 0, ctx->stream, (const DevRead *)ctx->d_reads.p, n, ctx->prm.min_mq, ctx->prm.excl_flags, ctx->bins,
+                               (const int32_t *)ctx->d_nind.p, (int32_t *)ctx->d_prefmax.p, pc, a.st, (int32_t *)lbk, (unsigned long long *)(lbk + 64));
+        }
+        {
+            Launch L(ctx, "k_bin_scan");
+            hipLaunchKernelGGL(k_bin_scan, dim3(nb_bs), dim3(1024), 0, ctx->stream, (const uint32_t *)a.cnt, a.sc, pc, a.ec, (int)nb, (int4 *)ctx->d_tab.p, a.st, (int32_t *)(lbk + 4),
+                               (unsigned long long *)(lbk + 64 + (size_t)nb_pm * 8), (unsigned long long *)(lbk + 64 + (size_t)(nb_pm + nb_bs) * 8));
+        }
+        // ---- the one synchronisation: sizes, errors
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stats, ctx->d_stats.p, sizeof(LoadStats), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipGetLastError());
+        hs = *ctx->h_stats;
+        if (hs.err != ~0ull) {
+            const long long i = (long long)(hs.err >> 8);
+            switch ((int)(hs.err & 0xff)) {
+                case LD_UNSORTED: return fail(ctx, C3R_EINVAL, "reads must be sorted by pos (read %lld)", i);
+                case LD_CIGAR_RANGE: return fail(ctx, C3R_EINVAL, "cigar range of read %lld out of bounds", i);
+                case LD_SEQ_RANGE: return fail(ctx, C3R_EINVAL, "seq range of read %lld out of bounds", i);
+                case LD_BAD_OP: return fail(ctx, C3R_EINVAL, "bad cigar op in read %lld", i);
+                case LD_OP_LONG: return fail(ctx, C3R_EINVAL, "cigar op too long in read %lld", i);
+                case LD_END_2G: return fail(ctx, C3R_EINVAL, "read %lld ends beyond 2^31", i);
+                case LD_SEG_OPS: return fail(ctx, C3R_EINVAL, "read %lld: more than 65535 CIGAR ops between two N ops", i);
+                default: return fail(ctx, C3R_EINVAL, "invalid read %lld", i);
+            }
+        }
+        if ((int64_t)hs.max_end <= (((int64_t)base + nb) << BIN_SHIFT)) break;
+        if (attempt >= 1) return fail(ctx, C3R_EINVAL, "internal: the position bins did not grow to the reads' ends");
+        want_end = (int64_t)hs.max_end + 64;                  // a read reaches beyond the table: the counts of its far bins were clamped
+    }
+    if (hs.n_rec < 0) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
+    const auto t_sync = std::chrono::steady_clock::now();
+    // ---- second pass (nothing below waits for the device): every record into its bin
+    if ((rc = ensure(ctx, ctx->d_recs, (size_t)hs.n_rec * sizeof(PileRec) + 64))) return rc;
+    {
+        PrepArgs a;
+        memset(&a, 0, sizeof a);
+        a.n_reads = n; a.cigars = (const uint32_t *)ctx->d_rawcig.p; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.geo = ctx->bins;
+        a.cnt = (uint32_t *)ctx->d_bincnt.p; a.tab = (const int4 *)ctx->d_tab.p; a.out = (DevRead *)ctx->d_reads.p; a.serial = (uint8_t *)ctx->d_serial.p;
+        a.recs = (PileRec *)ctx->d_recs.p;
+        Launch L(ctx, "k_prep_write");
+        hipLaunchKernelGGL(k_prep<true>, dim3((unsigned)((n + 256 / PREP_GRP - 1) / (256 / PREP_GRP))), dim3(256), 0, ctx->stream, a);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    ctx->bins_dirty = false;                                  // (the record counters are back at zero once k_prep<true> is through)
+    ctx->n_reads = n; ctx->n_indel_ops = hs.n_indel; ctx->max_cover = hs.max_cover;
+    if (timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[c3r_load_reads] %d reads, %d records in %d bins: first pass until the sync %.2f ms, second pass queued in %.2f ms\n", n, hs.n_rec, ctx->bins.nb,
+                ms(t_begin, t_sync), ms(t_sync, std::chrono::steady_clock::now()));
+    }
+    return C3R_OK;
+}
+
+// New filters for the reads already loaded (c3r_set_params changed --min-MQ / --excl-flags): the tables are rebuilt from the raw records.
+int refilter(c3r_ctx *ctx) {
     const int n = ctx->n_reads;
     if (n == 0) return C3R_OK;
+    ctx->n_reads = 0;
+    return prepare_tables(ctx, n, ctx->last_pos, false);
+}
+
+// The legacy tables (reads_kernels.hpp): only token_at reads them — the ordered haplotype recompute of flagged columns, 30 channels.
+int ensure_legacy_tables(c3r_ctx *ctx) {
+    if (ctx->legacy_valid || ctx->n_reads == 0) return C3R_OK;
+    const int n = ctx->n_reads;
     int rc;
-    if ((rc = ensure(ctx, ctx->d_pass, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, ctx->d_ekey, (size_t)n * 4)) || (rc = ensure(ctx, ctx->d_ekey2, (size_t)n * 4))) return rc;
-    LoadStats *st = (LoadStats *)ctx->d_stats.p;
-    HIPCHK(ctx, hipMemsetAsync(&st->max_cover, 0, 4, ctx->stream));
-    {
-        Launch L(ctx, "k_reads_prep");
-        hipLaunchKernelGGL(k_reads_pass, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const c3r_read_t *)ctx->d_rawreads.p, (const int32_t *)ctx->d_rend.p, n,
-                           ctx->prm.min_mq, ctx->prm.excl_flags, (int32_t *)ctx->d_pass.p, (uint32_t *)ctx->d_ekey.p);
-    }
-    if ((rc = ensure(ctx, ctx->d_small, 64))) return rc;
-    if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_pass.p, n + 1, (int32_t *)((char *)ctx->d_small.p + 32)))) return rc;
-    {
-        Launch L(ctx, "k_sort");
-        size_t tmp = 0;
-        HIPCHK(ctx, rocprim::radix_sort_keys(nullptr, tmp, (const uint32_t *)ctx->d_ekey.p, (uint32_t *)ctx->d_ekey2.p, (size_t)n, 0, 32, ctx->stream));
-        if ((rc = ensure(ctx, ctx->d_sorttmp, tmp + 16))) return rc;
-        HIPCHK(ctx, rocprim::radix_sort_keys(ctx->d_sorttmp.p, tmp, (const uint32_t *)ctx->d_ekey.p, (uint32_t *)ctx->d_ekey2.p, (size_t)n, 0, 32, ctx->stream));
-    }
-    {
-        Launch L(ctx, "k_reads_prep");
-        hipLaunchKernelGGL(k_cover_max, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const c3r_read_t *)ctx->d_rawreads.p, n, (const int32_t *)ctx->d_pass.p,
-                           (const uint32_t *)ctx->d_ekey2.p, st);
-    }
-    return C3R_OK;
-}
-
-template <int WHAT>
-int device_prefmax(c3r_ctx *ctx, const void *items, int n, DevBuf &out) {
-    int rc = ensure(ctx, out, (size_t)std::max(n, 1) * 4 + 16);
-    if (rc || n == 0) return rc;
-    const int nb = (n + PM_BLK - 1) / PM_BLK;
-    if ((rc = ensure(ctx, ctx->d_pmtops, (size_t)nb * 4 + 16))) return rc;
-    Launch L(ctx, "k_prefmax");
-    hipLaunchKernelGGL(k_prefmax_local<WHAT>, dim3(nb), dim3(1024), 0, ctx->stream, items, n, ctx->prm.min_mq, ctx->prm.excl_flags, (int32_t *)out.p, (int32_t *)ctx->d_pmtops.p);
-    if (nb > 1) {
-        hipLaunchKernelGGL(k_prefmax_tops, dim3(1), dim3(1024), 0, ctx->stream, (int32_t *)ctx->d_pmtops.p, nb);
-        hipLaunchKernelGGL(k_prefmax_add, dim3(nb), dim3(1024), 0, ctx->stream, (int32_t *)out.p, n, (const int32_t *)ctx->d_pmtops.p);
-    }
-    return C3R_OK;
-}
-
-// Part B: prefix maxima of the passing reads' / segments' ends and the bucket index k_tile_ranges searches through.
-int filter_tables(c3r_ctx *ctx, int32_t max_end) {
-    ctx->host_reads_valid = false;
-    if (ctx->n_reads == 0) { ctx->n_bkt = 0; return C3R_OK; }
-    int rc;
-    if ((rc = device_prefmax<0>(ctx, ctx->d_reads.p, ctx->n_reads, ctx->d_prefmax))) return rc;
-    if ((rc = device_prefmax<1>(ctx, ctx->d_segs.p, ctx->n_segs, ctx->d_seg_prefmax))) return rc;
-    ctx->n_bkt = (int32_t)(((int64_t)std::max(max_end, 0) >> BKT_SHIFT) + 2);
-    if ((rc = ensure(ctx, ctx->d_bkt, (size_t)4 * ctx->n_bkt * 4 + 16))) return rc;
-    Launch L(ctx, "k_reads_prep");
-    hipLaunchKernelGGL(k_bucket_index, dim3((unsigned)((ctx->n_bkt + 255) / 256)), dim3(256), 0, ctx->stream, (const DevRead *)ctx->d_reads.p, ctx->n_reads,
-                       (const int32_t *)ctx->d_prefmax.p, (const DevSeg *)ctx->d_segs.p, ctx->n_segs, (const int32_t *)ctx->d_seg_prefmax.p,
-                       (int)ctx->n_bkt, (int32_t *)ctx->d_bkt.p);
-    return C3R_OK;
-}
-
-// New filters for the reads already loaded (c3r_set_params changed --min-MQ / --excl-flags).
-int refilter(c3r_ctx *ctx) {
-    if (ctx->n_reads == 0) return C3R_OK;
-    int rc = filter_cover(ctx);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stats, ctx->d_stats.p, sizeof(LoadStats), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = ensure(ctx, ctx->d_lcnt, (size_t)(n + 2) * sizeof(int2)))) return rc;
+    Launch L(ctx, "k_legacy_tables");
+    hipLaunchKernelGGL(k_legacy_count, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const DevRead *)ctx->d_reads.p, n, (const uint32_t *)ctx->d_rawcig.p, (int2 *)ctx->d_lcnt.p);
+    hipLaunchKernelGGL(k_legacy_scan, dim3(1), dim3(1024), 0, ctx->stream, (int2 *)ctx->d_lcnt.p, n + 1, (int2 *)ctx->d_lcnt.p + (n + 1));
+    int2 tot = make_int2(0, 0);
+    HIPCHK(ctx, hipMemcpyAsync(&tot, (int2 *)ctx->d_lcnt.p + (n + 1), sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->max_cover = ctx->h_stats->max_cover;
-    return filter_tables(ctx, ctx->h_stats->max_end);
+    if (tot.x < 0 || tot.y < 0) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
+    if ((rc = ensure(ctx, ctx->d_cigar, (size_t)tot.x * 4 + 16)) || (rc = ensure(ctx, ctx->d_rsegs, (size_t)tot.y * sizeof(DevSeg) + 16)) ||
+        (rc = ensure(ctx, ctx->d_rseg_first, (size_t)(n + 1) * 4)))
+        return rc;
+    hipLaunchKernelGGL(k_legacy_write, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const DevRead *)ctx->d_reads.p, n, (const uint32_t *)ctx->d_rawcig.p,
+                       (const int2 *)ctx->d_lcnt.p, (uint32_t *)ctx->d_cigar.p, (DevSeg *)ctx->d_rsegs.p, (uint32_t *)ctx->d_rseg_first.p);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->legacy_valid = true;
+    return C3R_OK;
 }
 
 // Host copies, fetched only by the paths that walk reads on the host: mpileup's depth cap (sequential by nature) and the decoder
@@ -407,8 +482,8 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     const bool timing = getenv("C3R_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_rcnt, &ctx->d_rend, &ctx->d_pass, &ctx->d_ekey, &ctx->d_ekey2, &ctx->d_skey, &ctx->d_skey2, &ctx->d_sval, &ctx->d_sval2,
-                      &ctx->d_sorttmp, &ctx->d_s4tops, &ctx->d_pmtops, &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_bkt, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_ops, &ctx->d_seg_op_off, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_segs, &ctx->d_seg_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+    DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_tab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
+                      &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff};
     int n_dev = 0; size_t b_dev = 0, b_pin = 0;
@@ -462,114 +537,24 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     if (n_cigar_ops >= INT32_MAX) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool timing = getenv("C3R_TIMING") != nullptr;
-    const auto t_begin = std::chrono::steady_clock::now();
     // whatever happens below, the previous contig's tables are gone
-    ctx->n_reads = 0; ctx->n_segs = 0; ctx->n_indel_ops = 0; ctx->n_seq_bytes = 0; ctx->max_cover = 0; ctx->n_bkt = 0;
-    ctx->host_reads_valid = false; ctx->host_seq_valid = false; ctx->last_scan_pruned = false;
+    ctx->n_reads = 0; ctx->n_indel_ops = 0; ctx->n_seq_bytes = 0; ctx->n_cigar_ops = 0; ctx->max_cover = 0;
+    ctx->host_reads_valid = false; ctx->host_seq_valid = false; ctx->last_scan_pruned = false; ctx->legacy_valid = false;
     const int n = (int)n_reads;
     int rc;
-    if (!ctx->h_stats) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_stats, sizeof(LoadStats), hipHostMallocDefault));
-    if ((rc = ensure(ctx, ctx->d_stats, sizeof(LoadStats))) || (rc = ensure(ctx, ctx->d_small, 64))) return rc;
     // ---- the caller's records go up as they are (three copies; truly asynchronous when the caller's arrays are pinned, see
     // c3r_host_alloc) and every table the tile kernels need is derived from them on the device
     if ((rc = upload(ctx, ctx->d_rawreads, reads, (size_t)n)) || (rc = upload(ctx, ctx->d_rawcig, cigars, (size_t)n_cigar_ops))) return rc;
     if ((rc = ensure(ctx, ctx->d_seq, (size_t)n_seq_bytes + 16))) return rc;
     if (n_seq_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq.p, seq4, (size_t)n_seq_bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync((char *)ctx->d_seq.p + n_seq_bytes, 0, 16, ctx->stream));        // (the walk reads the packed bases 16 bytes at a time)
-    ctx->n_seq_bytes = n_seq_bytes;
+    ctx->n_seq_bytes = n_seq_bytes; ctx->n_cigar_ops = n_cigar_ops;
     if (n == 0) return C3R_OK;
-    LoadStats init;
-    memset(&init, 0, sizeof init);
-    init.err = ~0ull;
-    *ctx->h_stats = init;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stats.p, ctx->h_stats, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    LoadStats *st = (LoadStats *)ctx->d_stats.p;
-    // ---- pass 1: validation and counts, their prefix sums, and the deepest coverage
-    if ((rc = ensure(ctx, ctx->d_rcnt, (size_t)(n + 1) * sizeof(int4))) || (rc = ensure(ctx, ctx->d_rend, (size_t)n * 4))) return rc;
-    const int nb4 = (n + 1 + S4_BLK - 1) / S4_BLK;
-    if ((rc = ensure(ctx, ctx->d_s4tops, (size_t)nb4 * sizeof(int4) + 16))) return rc;
-    {
-        Launch L(ctx, "k_reads_prep");
-        hipLaunchKernelGGL(k_reads_count, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const c3r_read_t *)ctx->d_rawreads.p, n, (const uint32_t *)ctx->d_rawcig.p,
-                           (long long)n_cigar_ops, (long long)n_seq_bytes, (int4 *)ctx->d_rcnt.p, (int32_t *)ctx->d_rend.p, st);
-            hipLaunchKernelGGL(k_scan4_local, dim3(nb4), dim3(1024), 0, ctx->stream, (int4 *)ctx->d_rcnt.p, n + 1, (int4 *)ctx->d_s4tops.p);
-            hipLaunchKernelGGL(k_scan4_tops, dim3(1), dim3(1024), 0, ctx->stream, (int4 *)ctx->d_s4tops.p, nb4, (int4 *)&st->n_norm);
-        if (nb4 > 1) hipLaunchKernelGGL(k_scan4_add, dim3(nb4), dim3(1024), 0, ctx->stream, (int4 *)ctx->d_rcnt.p, n + 1, (const int4 *)ctx->d_s4tops.p);
-    }
-    ctx->n_reads = n;
-    if ((rc = filter_cover(ctx))) { ctx->n_reads = 0; return rc; }
-    ctx->n_reads = 0;
-    // ---- the one synchronisation: sizes, errors
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stats, ctx->d_stats.p, sizeof(LoadStats), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipGetLastError());
-    const auto t_sync = std::chrono::steady_clock::now();
-    const LoadStats hs = *ctx->h_stats;
-    if (hs.err != ~0ull) {
-        const long long i = (long long)(hs.err >> 8);
-        switch ((int)(hs.err & 0xff)) {
-            case LD_UNSORTED: return fail(ctx, C3R_EINVAL, "reads must be sorted by pos (read %lld)", i);
-            case LD_CIGAR_RANGE: return fail(ctx, C3R_EINVAL, "cigar range of read %lld out of bounds", i);
-            case LD_SEQ_RANGE: return fail(ctx, C3R_EINVAL, "seq range of read %lld out of bounds", i);
-            case LD_BAD_OP: return fail(ctx, C3R_EINVAL, "bad cigar op in read %lld", i);
-            case LD_OP_LONG: return fail(ctx, C3R_EINVAL, "cigar op too long in read %lld", i);
-            case LD_END_2G: return fail(ctx, C3R_EINVAL, "read %lld ends beyond 2^31", i);
-            case LD_SEG_OPS: return fail(ctx, C3R_EINVAL, "read %lld: more than 65535 CIGAR ops between two N ops", i);
-            default: return fail(ctx, C3R_EINVAL, "invalid read %lld", i);
-        }
-    }
-    if (hs.n_norm < 0 || hs.n_segs < 0 || hs.n_oprec < 0) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
-    const int ns = hs.n_segs;
-    // ---- pass 2 (nothing below waits for the device): normalised CIGARs, headers, segments, their order, the op table
-    if ((rc = ensure(ctx, ctx->d_cigar, (size_t)hs.n_norm * 4 + 16)) || (rc = ensure(ctx, ctx->d_reads, (size_t)n * sizeof(DevRead))) ||
-        (rc = ensure(ctx, ctx->d_rsegs, (size_t)ns * sizeof(DevSeg) + 16)) || (rc = ensure(ctx, ctx->d_segs, (size_t)ns * sizeof(DevSeg) + 16)) ||
-        (rc = ensure(ctx, ctx->d_rseg_first, (size_t)(n + 1) * 4)) || (rc = ensure(ctx, ctx->d_skey, (size_t)ns * 4 + 16)) || (rc = ensure(ctx, ctx->d_skey2, (size_t)ns * 4 + 16)) ||
-        (rc = ensure(ctx, ctx->d_sval, (size_t)ns * 4 + 16)) || (rc = ensure(ctx, ctx->d_sval2, (size_t)ns * 4 + 16)) ||
-        (rc = ensure(ctx, ctx->d_seg_op_off, (size_t)(ns + 1) * 4 + 16)) || (rc = ensure(ctx, ctx->d_ops, (size_t)hs.n_oprec * sizeof(OpRec) + 64)))
-        return rc;
-    {
-        Launch L(ctx, "k_reads_prep");
-        hipLaunchKernelGGL(k_reads_write, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const c3r_read_t *)ctx->d_rawreads.p, n, (const uint32_t *)ctx->d_rawcig.p,
-                           (const int4 *)ctx->d_rcnt.p, (const int32_t *)ctx->d_rend.p, (uint32_t *)ctx->d_cigar.p, (DevRead *)ctx->d_reads.p, (DevSeg *)ctx->d_rsegs.p,
-                           (uint32_t *)ctx->d_rseg_first.p, (uint32_t *)ctx->d_skey.p, (uint32_t *)ctx->d_sval.p);
-    }
-    if (ns > 0) {
-        {   // segment order by ext_start; equal starts keep read order (a radix sort is stable)
-            Launch L(ctx, "k_sort");
-            size_t tmp = 0;
-            HIPCHK(ctx, rocprim::radix_sort_pairs(nullptr, tmp, (const uint32_t *)ctx->d_skey.p, (uint32_t *)ctx->d_skey2.p, (const uint32_t *)ctx->d_sval.p,
-                                                  (uint32_t *)ctx->d_sval2.p, (size_t)ns, 0, 32, ctx->stream));
-            if ((rc = ensure(ctx, ctx->d_sorttmp, tmp + 16))) return rc;
-            HIPCHK(ctx, rocprim::radix_sort_pairs(ctx->d_sorttmp.p, tmp, (const uint32_t *)ctx->d_skey.p, (uint32_t *)ctx->d_skey2.p, (const uint32_t *)ctx->d_sval.p,
-                                                  (uint32_t *)ctx->d_sval2.p, (size_t)ns, 0, 32, ctx->stream));
-        }
-        Launch L(ctx, "k_reads_prep");
-        hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, (const DevSeg *)ctx->d_rsegs.p, (const uint32_t *)ctx->d_sval2.p, ns,
-                           (DevSeg *)ctx->d_segs.p);
-    }
-    ctx->n_reads = n; ctx->n_segs = ns; ctx->n_indel_ops = hs.n_indel; ctx->max_cover = hs.max_cover;
-    if ((rc = filter_tables(ctx, hs.max_end))) { ctx->n_reads = 0; return rc; }
-    {   // expanded op table of the sorted segments: count -> exclusive scan -> write (its size is known from pass 1)
-        int32_t *off = (int32_t *)ctx->d_seg_op_off.p, *d_total = (int32_t *)((char *)ctx->d_small.p + 28);
-        {
-            Launch L(ctx, "k_ops_table");
-            hipLaunchKernelGGL(k_ops_count, dim3((unsigned)(ns / 256 + 1)), dim3(256), 0, ctx->stream, (const DevSeg *)ctx->d_segs.p, ns,
-                               (const uint32_t *)ctx->d_cigar.p, off);
-        }
-        if ((rc = device_excl_scan(ctx, off, ns + 1, d_total))) { ctx->n_reads = 0; return rc; }
-        if (ns > 0) {
-            Launch L(ctx, "k_ops_table");
-            hipLaunchKernelGGL(k_ops_write, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, (const DevSeg *)ctx->d_segs.p, ns,
-                               (const uint32_t *)ctx->d_cigar.p, (const int32_t *)off, (OpRec *)ctx->d_ops.p);
-        }
-    }
-    HIPCHK(ctx, hipGetLastError());
-    if (timing) {
-        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[c3r_load_reads] %d reads, %d segments, %d op records: uploads + pass 1 until the sync %.2f ms, pass 2 queued in %.2f ms\n", n, ns, hs.n_oprec,
-                ms(t_begin, t_sync), ms(t_sync, std::chrono::steady_clock::now()));
-    }
-    return C3R_OK;
+    ctx->first_pos = std::max(reads[0].pos, 0);
+    // the last read's position bounds the first guess of the bins (the records are sorted; an unsorted set fails in the first pass)
+    const int64_t last_pos = std::max(reads[n - 1].pos, reads[0].pos);
+    ctx->last_pos = last_pos;
+    return prepare_tables(ctx, n, last_pos, timing);
 }
 
 void *c3r_host_alloc(size_t bytes) {
@@ -785,11 +770,8 @@ static int depth_cap_mask(c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts
 static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int drop_words, int n_tiles) {
     memset(&a, 0, sizeof a);
     a.drop = d_drop; a.drop_words = drop_words;
-    a.reads = (const DevRead *)ctx->d_reads.p; a.cigar = (const uint32_t *)ctx->d_cigar.p; a.seq = (const uint8_t *)ctx->d_seq.p;
-    a.prefmax_end = (const int32_t *)ctx->d_prefmax.p; a.n_reads = ctx->n_reads;
-    a.segs = (const DevSeg *)ctx->d_segs.p; a.seg_prefmax = (const int32_t *)ctx->d_seg_prefmax.p; a.n_segs = ctx->n_segs;
-    a.ops = (const OpRec *)ctx->d_ops.p; a.seg_op_off = (const int32_t *)ctx->d_seg_op_off.p;
-    a.bkt = ctx->n_bkt > 0 && !getenv("C3R_NO_BUCKETS") ? (const int32_t *)ctx->d_bkt.p : nullptr; a.n_bkt = ctx->n_bkt;
+    a.reads = (const DevRead *)ctx->d_reads.p; a.seq = (const uint8_t *)ctx->d_seq.p; a.n_reads = ctx->n_reads;
+    a.recs = (const PileRec *)ctx->d_recs.p; a.tab = (const int4 *)ctx->d_tab.p; a.bins = ctx->bins;
     a.n_tiles = n_tiles;
     a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->ref_len;
     a.geo = (const TileGeo *)ctx->d_geo.p;
@@ -923,10 +905,11 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
         else hipLaunchKernelGGL(k_scan_tiles<C3R_CH_PHASED>, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, a);
     }
     if (a.n_reads > 0 && C == C3R_CH_PHASED) {
+        if ((rc = ensure_legacy_tables(ctx))) return rc;
         PhaseArgs f;
         f.tile_list = a.tile_list; f.n_tile_list = a.n_tile_list; f.tile_rng = a.tile_rng; f.geo = a.geo;
         f.reads = a.reads; f.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.rseg_first = (const uint32_t *)ctx->d_rseg_first.p;
-        f.cigar = a.cigar; f.seq = a.seq; f.flags = a.flags; f.cols = a.cols; f.min_mq = a.min_mq; f.excl_flags = a.excl_flags;
+        f.cigar = (const uint32_t *)ctx->d_cigar.p; f.seq = a.seq; f.flags = a.flags; f.cols = a.cols; f.min_mq = a.min_mq; f.excl_flags = a.excl_flags;
         f.drop = a.drop; f.drop_words = a.drop_words;
         Launch L(ctx, "k_phase_recompute");
         hipLaunchKernelGGL(k_phase_recompute, dim3(std::min(n_tiles, list_grid())), dim3(TILE), 0, ctx->stream, f);
@@ -991,24 +974,12 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = ensure_keep(ctx, ctx->d_tok, std::max<size_t>((size_t)(base_tok + n_tok) * sizeof(c3r_token_t), 16),
                           (size_t)base_tok * sizeof(c3r_token_t)))) return rc;
-    if (getenv("C3R_OLD_TOKENS")) {
-        TokArgs t;
-        t.reads = a.reads; t.cigar = a.cigar; t.seq = a.seq; t.prefmax_end = a.prefmax_end; t.n_reads = a.n_reads;
-        t.rsegs = (const DevSeg *)ctx->d_rsegs.p; t.rseg_first = (const uint32_t *)ctx->d_rseg_first.p;
-        t.cand_idx = (const int32_t *)ctx->d_cand.p; t.n_cand = n_cand; t.geo = (const TileGeo *)ctx->d_geo.p;
-        t.tile_rng = (const int4 *)ctx->d_tile_rng.p;
-        t.drop = a.drop; t.drop_words = a.drop_words;
-        t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
-        t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;
-        t.min_mq = a.min_mq; t.excl_flags = a.excl_flags;
-        Launch L(ctx, "k_tokens");
-        hipLaunchKernelGGL(k_tokens, dim3((unsigned)(((int64_t)n_cand * 64 + 255) / 256)), dim3(256), 0, ctx->stream, t);
-    } else {
+    {
         TileTokArgs t;
         t.a = a;
         t.cand_idx = (const int32_t *)ctx->d_cand.p; t.tile_cand = (const int2 *)ctx->d_tile_cand.p;
         t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
-        t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok; t.tok_cap = INT32_MAX; t.cand_cap = INT32_MAX; t.abort_flag = nullptr;     // (sized exactly above)
+        t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;     // (sized exactly above)
         Launch L(ctx, "k_tokens");
         hipLaunchKernelGGL(k_tile_tokens, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, t);
     }
@@ -1019,8 +990,8 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
     return C3R_OK;
 }
 
-// ---- the fused path (pileup_kernels.hpp, k_fused_tiles): memset of the look-back words, k_tile_ranges_fused, k_fused_tiles,
-// k_tile_tokens, and ONE read-back at the end (totals + overflow flags).  Output buffers are sized from what earlier passes needed;
+// ---- the fused path (pileup_kernels.hpp, k_fused_tiles): memset of the look-back words, k_tile_ranges_fused, k_fused_tiles (windows
+// AND tokens), k_order_spans, k_finalize_sites, and ONE read-back at the end (totals + overflow flags).  Output buffers are sized from what earlier passes needed;
 // kernels never write past them, and when the totals say something did not fit the buffers grow and the scan is repeated (the first
 // pass of a context; steady-state passes run once, without talking to the host in between).
 // raw_rerun: c3r_get_tensors(rescaled = 0) — the same scan again, un-rescaled windows only, into d_raw.
@@ -1062,13 +1033,13 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     const int nblk = (n_tiles + 255) / 256;
     // d_lb: [0] ticket of k_tile_ranges_fused, [4] ticket of k_fused_tiles, [8] candidates, [12] tokens (k_order_spans), [16] overflow
     // bits, [20] listed spans, [24..31] event-scratch cursor, [32] event-scratch overflow, [36] rows handed out, [40] ticket of
-    // k_order_spans, [64..] the TICKET_Q ticket words of k_fused_tiles, 256 bytes apart; then look-back words: one per block of 256 spans for
-    // k_tile_ranges_fused, then the same for k_order_spans
+    // k_order_spans, [44] token slots handed out, [64..] the TICKET_Q ticket words of k_fused_tiles, 256 bytes apart; then look-back words:
+    // one per block of 256 spans for k_tile_ranges_fused, then the same for k_order_spans
     const size_t lb_head = 64 + (size_t)TICKET_Q * TICKET_STRIDE * 4;
     const size_t lb_bytes = lb_head + (size_t)nblk * 16;
     if ((rc = ensure(ctx, ctx->d_ev, ev_cap * sizeof(EvRec))) || (rc = ensure(ctx, ctx->d_lb, lb_bytes)) || (rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16)) ||
-        (rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16)) || (rc = ensure(ctx, ctx->d_tile_cand, (size_t)n_tiles * 8 + 16)) ||
-        (rc = ensure(ctx, ctx->d_span, (size_t)n_tiles * sizeof(int4) + 16)) || (rc = ensure(ctx, ctx->d_spanbase, (size_t)n_tiles * sizeof(int2) + 16)) ||
+        (rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16)) ||
+        (rc = ensure(ctx, ctx->d_span, (size_t)n_tiles * sizeof(int4) + 16)) || (rc = ensure(ctx, ctx->d_spanbase, (size_t)n_tiles * 4 + 16)) ||
         (rc = ensure(ctx, ctx->d_spanrec, (size_t)n_tiles * sizeof(SpanRec) + 16)))
         return rc;
     if (!ctx->h_scan) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_scan, 64, hipHostMallocDefault));
@@ -1091,7 +1062,8 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     f.ticket = (int32_t *)(lb + 64); f.arrived = (int32_t *)(lb + 36); f.overflow = (int32_t *)(lb + 16);
     f.rescale = raw_rerun ? 0 : 1; f.max_depth = ctx->prm.max_depth_rescale;
     f.span_info = (int4 *)ctx->d_span.p;
-    f.ph.reads = a.reads; f.ph.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.ph.rseg_first = (const uint32_t *)ctx->d_rseg_first.p; f.ph.cigar = a.cigar; f.ph.seq = a.seq;
+    if (C == C3R_CH_PHASED && (rc = ensure_legacy_tables(ctx))) return rc;
+    f.ph.reads = a.reads; f.ph.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.ph.rseg_first = (const uint32_t *)ctx->d_rseg_first.p; f.ph.cigar = (const uint32_t *)ctx->d_cigar.p; f.ph.seq = a.seq;
     f.ph.min_mq = a.min_mq; f.ph.excl_flags = a.excl_flags; f.ph.drop = a.drop; f.ph.drop_words = a.drop_words;
     const size_t tbytes = (size_t)C3R_WINDOW * C * 4;
     // what this scan may write: candidates / tokens the buffers can take beyond what the batch already holds
@@ -1099,8 +1071,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     if (raw_rerun) { want_c = ctx->last_cand; want_t = 0; }
     else {
         want_c = std::min<int64_t>({(int64_t)(ctx->d_tensors.cap / tbytes) - base_cand, (int64_t)(ctx->d_sites_out.cap / sizeof(c3r_site_t)) - base_cand,
-                                    (int64_t)(ctx->d_winidx.cap / 4) - base_cand, (int64_t)(ctx->d_cand.cap / 4), (int64_t)(ctx->d_tokcnt.cap / 4),
-                                    (int64_t)(ctx->d_meta.cap / sizeof(CandMeta))});
+                                    (int64_t)(ctx->d_winidx.cap / 4) - base_cand, (int64_t)(ctx->d_cand.cap / 4), (int64_t)(ctx->d_meta.cap / sizeof(CandMeta))});
         want_t = (int64_t)(ctx->d_tok.cap / sizeof(c3r_token_t)) - base_tok;
         if (want_c < 1024) want_c = 65536;
         if (want_t < 1024) want_t = 32 * want_c;
@@ -1115,7 +1086,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             f.tensors = (int32_t *)ctx->d_raw.p;
             z.win_idx = (int32_t *)ctx->d_rawidx.p; z.row_base = 0;
         } else {
-            if ((rc = ensure(ctx, ctx->d_cand, (size_t)want_c * 4)) || (rc = ensure(ctx, ctx->d_tokcnt, (size_t)want_c * 4)) ||
+            if ((rc = ensure(ctx, ctx->d_cand, (size_t)want_c * 4)) ||
                 (rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_cand + want_c) * tbytes, (size_t)base_cand * tbytes)) ||
                 (rc = ensure_keep(ctx, ctx->d_sites_out, (size_t)(base_cand + want_c) * sizeof(c3r_site_t), (size_t)base_cand * sizeof(c3r_site_t))) ||
                 (rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + want_c) * 4, (size_t)base_cand * 4)) ||
@@ -1123,12 +1094,14 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
                 return rc;
             f.tensors = (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_cand * tbytes);
             z.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
-            z.cand_idx = (int32_t *)ctx->d_cand.p; z.tok_off = (int32_t *)ctx->d_tokcnt.p;
-            z.win_idx = (int32_t *)ctx->d_winidx.p + base_cand; z.row_base = (int32_t)base_cand;
+            z.cand_idx = (int32_t *)ctx->d_cand.p;
+            z.win_idx = (int32_t *)ctx->d_winidx.p + base_cand; z.row_base = (int32_t)base_cand; z.tok_base = (int32_t)base_tok;
+            f.tok = (c3r_token_t *)ctx->d_tok.p; f.tok_base = (int32_t)base_tok; f.tok_cap = (int32_t)std::min<int64_t>(want_t, INT32_MAX - base_tok);
+            f.tok_arrived = (int32_t *)(lb + 44);
         }
         f.meta = (CandMeta *)ctx->d_meta.p;
         f.cand_cap = (int32_t)std::min<int64_t>(want_c, INT32_MAX);
-        z.meta = f.meta; z.span_info = f.span_info; z.span_base = (const int2 *)ctx->d_spanbase.p; z.arrived = f.arrived; z.overflow = f.overflow; z.cand_cap = f.cand_cap;
+        z.meta = f.meta; z.span_info = f.span_info; z.span_base = (const int32_t *)ctx->d_spanbase.p; z.arrived = f.arrived; z.overflow = f.overflow; z.cand_cap = f.cand_cap;
         z.geo = a.geo; z.ref = a.ref; z.ref_beg0 = a.ref_beg0; z.ref_len = a.ref_len;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_lb.p, 0, lb_bytes, ctx->stream));
         {
@@ -1145,18 +1118,8 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         {
             Launch L(ctx, "k_order_sites");
             hipLaunchKernelGGL(k_order_spans, dim3(nblk), dim3(256), 0, ctx->stream, (const int4 *)ctx->d_span.p, (const int32_t *)(lb + 20), (int32_t *)(lb + 40),
-                               (unsigned long long *)(lb + lb_head + (size_t)nblk * 8), (int2 *)ctx->d_spanbase.p, (int2 *)ctx->d_tile_cand.p, (int32_t *)(lb + 8));
+                               (unsigned long long *)(lb + lb_head + (size_t)nblk * 8), (int32_t *)ctx->d_spanbase.p, (int32_t *)(lb + 8));
             hipLaunchKernelGGL(k_finalize_sites, dim3((unsigned)std::min<int64_t>((want_c + 3) / 4 + 1, 8192)), dim3(256), 0, ctx->stream, z);
-        }
-        if (!raw_rerun) {
-            TileTokArgs t;
-            t.a = a;
-            t.cand_idx = (const int32_t *)ctx->d_cand.p; t.tile_cand = (const int2 *)ctx->d_tile_cand.p;
-            t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
-            t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;
-            t.tok_cap = (int32_t)std::min<int64_t>(base_tok + want_t, INT32_MAX); t.cand_cap = f.cand_cap; t.abort_flag = f.overflow;
-            Launch L(ctx, "k_tokens");
-            hipLaunchKernelGGL(k_tile_tokens, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, t);
         }
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan, lb + 8, 32, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1253,6 +1216,9 @@ int c3r_get_sites(c3r_ctx *ctx, c3r_site_t *sites, int64_t cap_sites) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(sites, ctx->d_sites_out.p, (size_t)ctx->n_cand * sizeof(c3r_site_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // on the device a site's tokens lie where its span's token slots were handed out; c3r_get_tokens returns them site after site
+    uint32_t off = 0;
+    for (int64_t i = 0; i < ctx->n_cand; ++i) { sites[i].tok_off = off; off += (uint32_t)sites[i].n_tok; }
     return C3R_OK;
 }
 
@@ -1267,8 +1233,17 @@ int c3r_get_tokens(c3r_ctx *ctx, c3r_token_t *tokens, int64_t cap_tokens) {
     if (cap_tokens < ctx->n_tok) return fail(ctx, C3R_EOVERFLOW, "need room for %lld tokens", (long long)ctx->n_tok);
     if (ctx->n_tok == 0) return C3R_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpyAsync(tokens, ctx->d_tok.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream));
+    // site order (see c3r_get_sites): offsets = exclusive sums of the sites' token counts, then one wavefront per site copies its run
+    const int n = (int)ctx->n_cand;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_tokoff, (size_t)(n + 2) * 4)) || (rc = ensure(ctx, ctx->d_tokexp, (size_t)ctx->n_tok * sizeof(c3r_token_t))) || (rc = ensure(ctx, ctx->d_small, 64))) return rc;
+    hipLaunchKernelGGL(k_site_ntok, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const c3r_site_t *)ctx->d_sites_out.p, n, (int32_t *)ctx->d_tokoff.p);
+    if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_tokoff.p, n + 1, (int32_t *)((char *)ctx->d_small.p + 48)))) return rc;
+    hipLaunchKernelGGL(k_export_tokens, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 8192)), dim3(256), 0, ctx->stream, (const c3r_site_t *)ctx->d_sites_out.p,
+                       (const int32_t *)ctx->d_tokoff.p, n, (const c3r_token_t *)ctx->d_tok.p, (c3r_token_t *)ctx->d_tokexp.p);
+    HIPCHK(ctx, hipMemcpyAsync(tokens, ctx->d_tokexp.p, (size_t)ctx->n_tok * sizeof(c3r_token_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
     return C3R_OK;
 }
 

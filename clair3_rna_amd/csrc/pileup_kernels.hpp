@@ -8,14 +8,14 @@
 //   depth>216 rescale ......................... clair3_rna/utils.py:88-92,120
 //
 // Design.  A workgroup of 256 threads owns a run of at most TILE reference positions, one per thread: per-position
-// accumulators [TILE][C] int32 live in LDS, the aligned segments that touch the run are walked through the expanded op table (one lane
-// per CIGAR op, reads_kernels.hpp builds the tables on the device), base / deletion / indel events are LDS atomics, the gates run
-// per position (tile_columns).  Two drivers sit on top of it:
+// accumulators [TILE][C] int32 live in LDS, the ops that touch the run are ONE contiguous range of the pile table (PileRec: a
+// self-contained record per piece of an aligned op, binned by reference position when the reads are loaded — reads_kernels.hpp), one
+// lane per record; base / deletion / indel events are LDS atomics, the gates run per position (tile_columns).  Two drivers sit on top:
 //   k_fused_tiles (plain mode): the run = a span of 224 positions + 16 on either side, so every candidate's 33-column window is in
-//     LDS; windows are written from there, in arrival order, and k_order_spans / k_finalize_sites put the small records in position
-//     order (win_idx maps sites to window rows);
+//     LDS; windows are written from there, in arrival order, the candidates' read tokens right after them (tile_tokens), and
+//     k_order_spans / k_finalize_sites put the small records in position order (win_idx maps sites to window rows);
 //   k_scan_tiles (head/tail calling, splice padding, genotyping, c3r_get_columns): the finished tile is written to HBM once,
-//     coalesced, and selection, ordered compaction and the window gather (one wavefront per candidate) are separate kernels.
+//     coalesced, and selection, ordered compaction, the window gather (one wavefront per candidate) and the tokens are separate kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,8 +28,7 @@ constexpr int TILE = 256;      // reference positions per workgroup
 constexpr int SCAN_THREADS = 256;
 constexpr int WAVES = SCAN_THREADS / 64;
 
-// Read header as k_reads_write leaves it (normalised CIGAR: no P/H/zero-length ops, =/X folded into M, adjacent
-// equal ops merged; `end` = pos + reference length).
+// Read header as k_prep leaves it (`end` = pos + reference length; cig_off / n_cig: the caller's raw CIGAR).
 struct DevRead {
     int32_t pos;       // 0-based
     int32_t end;       // 0-based, exclusive
@@ -43,9 +42,8 @@ struct DevRead {
 };
 static_assert(sizeof(DevRead) == 32, "DevRead must be 32 bytes");
 
-// One aligned segment of a read = the CIGAR ops between two N (ref-skip) ops, prepared on the device at load time (reads_kernels.hpp) and
-// sorted by ext_start.  Tiles walk SEGMENTS, so a read spanning a 100-kb intron costs nothing in the intron's tiles;
-// only coverage (which positions have a pileup row) still comes from the whole-read spans, header-only.
+// LEGACY (token_at only: the ordered haplotype recompute of the 30-channel mode): one aligned segment of a read = the normalised CIGAR
+// ops between two N (ref-skip) ops, in read order (k_legacy_write, built on demand).
 struct DevSeg {
     int32_t ext_start;  // pos, or pos-1 when the segment starts with an I/D right after an N (indel attached to the
                         // last intron column)
@@ -65,26 +63,43 @@ struct DevSeg {
 };
 static_assert(sizeof(DevSeg) == 48, "DevSeg must be 48 bytes");
 
-// One CIGAR op of an aligned segment with everything a lane needs to process it on its own: absolute reference and query
-// offsets (no prefix sums over the segment's ops at scan time) and the read's filter / strand / haplotype fields.  Built on the
-// device when the reads are loaded (k_ops_count / k_ops_write), segment after segment in the sorted order of `segs`, so that
-// seg_op_off[s] .. seg_op_off[s + 1] are the records of segment s.  M ops are cut into pieces of at most OP_CHOP bases: one
-// 16-byte load of packed bases covers a piece, and a low-error read's few-hundred-base M ops spread over several lanes.
-// S ops leave no record (they only advance the query offset); `prev` still names them for the op that follows.
-struct OpRec {
-    int32_t rstart;     // 0-based reference position of the op's first base (I: of the base that follows the insertion)
-    uint32_t lenop;     // len << 4 | op   (op: C3R_CIG_M / _I / _D / _P)
-    uint64_t seq_off;   // the read's packed bases
-    uint32_t qstart;    // query offset of the op's first base
-    uint32_t l_seq;
-    uint32_t read_idx;
-    uint16_t flag;
-    uint8_t mapq;
-    uint8_t misc;       // bits 0-1: haplotype (1, 2, else 0); bits 2-5: the previous op of the read (15: none; N for the first op after a
-                        // ref-skip; M for the later pieces of a cut M op); bit 6: last record of its segment
+// One piece of an aligned CIGAR op of a read that passes the filters, with everything a lane needs to process it on its own: absolute
+// reference position, the address of its bases, strand and haplotype, the op before it, and the indel htslib attaches to its last
+// column.  M and D ops are cut into pieces of at most OP_CHOP reference positions (one 16-byte load of packed bases covers an M
+// piece; a low-error read's few-hundred-base M ops spread over several lanes); an I leaves a record only when samtools shows the
+// insertion (its predecessor consumes the reference: M, D, N); N / S / P ops leave none.  Records are binned by `rstart` (32-bp bins,
+// k_prep / k_bin_scan): every record that can touch the positions [e0, e1) — pieces starting up to OP_CHOP - 1 before e0, indels
+// anchored on e1 - 1 — lies in ONE contiguous range of the table.  The order inside a bin is arbitrary (whoever's atomic came first);
+// nothing downstream depends on it: counts are sums, alleles are compared as sets, first-seen order and tokens go by read_idx.
+struct PileRec {
+    int32_t rstart;     // 0-based reference position of the piece's first base (I: of the base that follows the insertion; the
+                        // insertion sits on the column rstart - 1)
+    uint32_t w;         // bits 0-1 op (C3R_CIG_M / _I / _D); 2-5 the op before it (15: none; M / D for the later pieces of a cut op);
+                        // 6 reverse strand; 7-8 haplotype (1, 2, else 0); 9-13 reference positions of the piece (M, D); 14-18 bases of
+                        // the piece that SEQ really holds (M; I: of its first 31)
+    uint64_t naddr;     // nibble index of the piece's first base in the packed bases (2 * seq_off + query offset; M, I)
+    uint32_t q;         // query offset of the piece's first base (D: of the base that follows the deletion)
+    uint32_t read_idx;  // BAM-order ordinal (first-seen order, token order, depth-cap mask)
+    int32_t nxt;        // the indel attached to the piece's LAST column: +length of the insertion, -length of the deletion, 0 none
+    uint32_t aux;       // I: inserted bases; D: length of the whole deletion
 };
-static_assert(sizeof(OpRec) == 32, "OpRec must be 32 bytes");
+static_assert(sizeof(PileRec) == 32, "PileRec must be 32 bytes");
 constexpr int OP_CHOP = 30;    // 30 bases + an odd start nibble fit the 32 nibbles of a 16-byte load
+
+// The bins of the pile table: 32 reference positions each, covering [base << 5, (base + nb) << 5); tab has nb + 1 entries,
+//   tab[b] = {first record of bin b, reads that start before bin b, reads whose prefix-max end lies before bin b, reads that end at or
+//             before the first position of bin b}
+// (k_bin_scan): two loads per span replace the four binary searches per tile of rounds 1-3.
+constexpr int BIN_SHIFT = 5;
+struct BinGeo { int32_t base, nb; };
+__host__ __device__ __forceinline__ int bin_of(const BinGeo g, int p) {          // the bin that holds position p, clamped into the table
+    const int b = (p >> BIN_SHIFT) - g.base;
+    return b < 0 ? 0 : b >= g.nb ? g.nb - 1 : b;
+}
+__host__ __device__ __forceinline__ int bin_edge(const BinGeo g, long long p) {  // tab index of the bin that holds p ("everything before it"), clamped to [0, nb]
+    const long long b = (p >> BIN_SHIFT) - g.base;
+    return b < 0 ? 0 : b > g.nb ? g.nb : (int)b;
+}
 
 struct EvRec {          // one indel event, bucketed by position inside a tile
     uint64_t key;       // insertion: first <=16 base codes, 4 bits each; deletion: 0
@@ -112,19 +127,13 @@ static_assert(sizeof(TileGeo) == 16, "TileGeo must be 16 bytes");
 
 struct ScanArgs {
     const DevRead *reads;
-    const uint32_t *cigar;
     const uint8_t *seq;
-    const int32_t *prefmax_end;   // inclusive prefix max of `end` over passing reads
     int32_t n_reads;
-    const DevSeg *segs;           // aligned segments sorted by ext_start
-    const int32_t *seg_prefmax;   // inclusive prefix max of segment `end` over passing segments
-    int32_t n_segs;
-    const int32_t *bkt;           // bucket index (k_bucket_index): [4][n_bkt] answers of the four searches of k_tile_ranges at every 256th position
-    int32_t n_bkt;
-    const OpRec *ops;             // expanded ops of the sorted segments
-    const int32_t *seg_op_off;    // [n_segs + 1] first record of each segment
+    const PileRec *recs;          // the pile table
+    const int4 *tab;              // [geo.nb + 1] per-bin prefix sums (BinGeo)
+    BinGeo bins;
     uint8_t *tile_cols;           // [n_tiles] 1 = this tile's columns were written (0: implicitly all-zero)
-    int4 *tile_rng;               // [n_tiles] {lo, hi, slo, shi} from k_tile_ranges
+    int4 *tile_rng;               // [n_tiles] {lo, hi, rlo, rhi} from k_tile_ranges: reads / records that can touch the tile
     int32_t *tile_list;           // compact list of tiles covered by at least one read span
     int32_t *n_tile_list;
     // prune: intron-only tiles with no aligned segment within 16 bp are not scanned at all (their rows cannot be in any candidate's
@@ -197,13 +206,16 @@ __host__ __device__ __forceinline__ bool flag_fails(unsigned flag, int excl) {
 __device__ __forceinline__ bool read_passes(const DevRead &r, int min_mq, int excl) {
     return !flag_fails(r.flag, excl) && r.mapq >= min_mq && r.end > r.pos;
 }
-__device__ __forceinline__ bool seg_passes(const DevSeg &g, int min_mq, int excl) {
-    return !flag_fails(g.flag, excl) && g.mapq >= min_mq;
-}
-__device__ __forceinline__ int lower_bound_seg(const DevSeg *g, int n, int v) {  // first i with g[i].ext_start >= v
-    int lo = 0, hi = n;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (g[mid].ext_start >= v) hi = mid; else lo = mid + 1; }
-    return lo;
+// The reads [lo, hi) and the records [rlo, rhi) that can touch the positions [e0, e1): supersets by less than a bin on either side.
+//   reads: everything up to the last read whose prefix-max end is <= e0 ends before e0; reads from the first one with pos >= e1 on
+//   start after it.  records: pieces that start up to OP_CHOP - 1 before e0; indels anchored on e1 - 1 have rstart = e1.
+__device__ __forceinline__ int4 span_ranges(const int4 *tab, const BinGeo g, int e0, int e1) {
+    int4 r;
+    r.x = tab[bin_edge(g, (long long)e0 + 1)].z;
+    r.y = tab[bin_edge(g, (long long)e1 + (1 << BIN_SHIFT) - 1)].y;
+    r.z = tab[bin_edge(g, (long long)e0 - (OP_CHOP - 1))].x;
+    r.w = tab[bin_edge(g, (long long)e1 + (1 << BIN_SHIFT))].x;
+    return r;
 }
 
 __device__ __forceinline__ int base_code(const uint8_t *seq, uint64_t off, uint32_t q, uint32_t l_seq) {
@@ -220,17 +232,6 @@ __device__ __forceinline__ int ref_index(uint8_t c) {   // evc_base_from: anythi
     return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0;
 }
 
-// first index i in [0,n) with a[i] > v  (a non-decreasing)
-__device__ __forceinline__ int upper_bound_gt(const int32_t *a, int n, int v) {
-    int lo = 0, hi = n;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] > v) hi = mid; else lo = mid + 1; }
-    return lo;
-}
-__device__ __forceinline__ int lower_bound_pos(const DevRead *r, int n, int v) {  // first i with r[i].pos >= v
-    int lo = 0, hi = n;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (r[mid].pos >= v) hi = mid; else lo = mid + 1; }
-    return lo;
-}
 // merged, sorted, disjoint half-open intervals: does [b,e) overlap any?
 __device__ __forceinline__ bool intervals_overlap(const int32_t *iv, int n, int b, int e) {
     int lo = 0, hi = n;   // first interval with end > b
@@ -255,6 +256,9 @@ struct TileLds {
     uint32_t *first;   // [FS_CAP][6] first-seen token index per class A,C,G,T,I,D of the positions with a tie at the top
     uint8_t *amb;      // [TILE] 0, or 1 + the position's row in `first` (current batch of the tie-break pass)
     uint8_t *odd;      // [TILE] phased mode: the column's haplotype channels need the ordered recompute (k_phase_recompute)
+    EvRec *evq;        // [evq_cap] the tile's indel events in arrival order, captured by the ACCUM pass (null / 0: not captured)
+    int32_t *evn;      // events met so far
+    int32_t evq_cap;
 };
 
 // Coverage of the tile from whole-read spans (incl. introns): header-only, one lane per read.
@@ -268,122 +272,36 @@ __device__ __forceinline__ void cover_reads(const ScanArgs &a, const TileLds &s,
     }
 }
 
-// ---- expanded op table (built once per c3r_load_reads, outside the scans)
-// What segment g expands to; out == nullptr: count only.
-__device__ __forceinline__ int seg_expand(const DevSeg &g, const uint32_t *cigar, OpRec *out) {
-    int n = 0, x = g.pos, prev = g.lead_n ? (int)C3R_CIG_N : 15;
-    uint32_t y = g.qstart;
-    OpRec o;
-    o.seq_off = g.seq_off; o.l_seq = g.l_seq; o.read_idx = g.read_idx; o.flag = g.flag; o.mapq = g.mapq;
-    const uint8_t hp2 = g.hp == 1 ? 1 : g.hp == 2 ? 2 : 0;
-    for (uint32_t k = 0; k < g.n_cig; ++k) {
-        const uint32_t c = cigar[g.cig_off + k];
-        const int op = (int)(c & 15u), len = (int)(c >> 4);
-        if (op == C3R_CIG_M) {
-            for (int d = 0; d < len; d += OP_CHOP) {
-                if (out) {
-                    o.rstart = x + d; o.lenop = ((uint32_t)min(OP_CHOP, len - d) << 4) | (uint32_t)C3R_CIG_M; o.qstart = y + (uint32_t)d;
-                    o.misc = (uint8_t)(hp2 | ((d ? (int)C3R_CIG_M : prev) << 2));
-                    out[n] = o;
-                }
-                ++n;
-            }
-            x += len; y += (uint32_t)len;
-        } else if (op == C3R_CIG_D || op == C3R_CIG_I) {
-            if (out) { o.rstart = x; o.lenop = c; o.qstart = y; o.misc = (uint8_t)(hp2 | (prev << 2)); out[n] = o; }
-            ++n;
-            if (op == C3R_CIG_D) x += len; else y += (uint32_t)len;
-        } else if (op == C3R_CIG_S) {
-            y += (uint32_t)len;
-        }
-        prev = op;
-    }
-    if (out && n > 0) out[n - 1].misc |= 64;
-    return n;
-}
-__global__ void k_ops_count(const DevSeg *segs, int n_segs, const uint32_t *cigar, int32_t *cnt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_segs) cnt[i] = seg_expand(segs[i], cigar, nullptr);
-    else if (i == n_segs) cnt[i] = 0;
-}
-__global__ void k_ops_write(const DevSeg *segs, int n_segs, const uint32_t *cigar, const int32_t *off, OpRec *ops) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_segs) seg_expand(segs[i], cigar, ops + off[i]);
-}
-
-// ---- the tile's walk, two levels.
-// Level 1 (list_segments): one lane per segment of the tile's range [slo, shi) — filters, overlap test — appends the op range
-// of every segment that touches the tile to a list in LDS; an exclusive scan over the list's op counts follows.
-// Level 2 (walk_list): one lane per op of the listed segments (entry by binary search in the scanned counts): an independent
-// 32-byte record, then for an M piece one 16-byte load of bases and the LDS atomics.  Three dependent cold misses per tile
-// (segment headers -> op records -> bases) whatever the tile holds, where the 16-lane-per-segment walk this replaces paid
-// three per round of 16 segments and again for every 16 ops of a segment.
-constexpr int LCAP = 256;                     // list entries per level-1 round (longer ranges take several rounds)
-struct SegList { uint32_t begin[LCAP]; int32_t cum[LCAP]; int n; int wtot[WAVES]; };   // lives in LDS
-
-__device__ __forceinline__ void list_segments(const ScanArgs &a, SegList &L, int sb, int se, int t0, int t1, int region) {
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    if (tid == 0) L.n = 0;
-    __syncthreads();
-    for (int base = sb; base < se; base += SCAN_THREADS) {
-        const int si = base + tid;
-        bool ok = false;
-        uint32_t ob = 0; int oc = 0;
-        if (si < se) {
-            const DevSeg *g = &a.segs[si];
-            const int es = g->ext_start, en = g->end;
-            const unsigned fl = g->flag; const int mq = g->mapq;
-            ob = (uint32_t)a.seg_op_off[si]; oc = a.seg_op_off[si + 1] - (int)ob;
-            ok = !flag_fails(fl, a.excl_flags) && mq >= a.min_mq && en > t0 && es < t1 && oc > 0;
-            if (ok && a.drop) ok = !read_dropped(a.drop, a.drop_words, region, (int)g->read_idx);
-        }
-        const unsigned long long m = __ballot(ok);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            int at = 0;
-            if (lane == leader) at = atomicAdd(&L.n, __popcll(m));
-            at = __shfl(at, leader, 64);
-            if (ok) { const int e = at + __popcll(m & ((1ull << lane) - 1ull)); L.begin[e] = ob; L.cum[e] = oc; }
-        }
-    }
-    __syncthreads();
-}
-
-// exclusive scan of the list's op counts in place (one entry per thread); returns the total
-__device__ __forceinline__ int scan_list(SegList &L) {
-    static_assert(LCAP == SCAN_THREADS, "one list entry per thread");
-    const int tid = (int)threadIdx.x, n = L.n;
-    const int c0 = tid < n ? L.cum[tid] : 0;
-    int tot;
-    const int ex = block_excl_scan(c0, L.wtot, &tot);
-    if (tid < n) L.cum[tid] = ex;
-    __syncthreads();
-    return tot;
+// ---- the tile's walk: one lane per record of the tile's range of the pile table.  A record is independent of every other one: two
+// 16-byte loads, for an M piece (an I) one 16-byte load of packed bases, then the LDS atomics — two dependent cold misses per tile
+// (records -> bases) whatever the tile holds.  (Round 2-3: segment headers -> scanned list in LDS -> binary search per lane -> op records
+// -> bases; round 1: a 16-lane group per segment with prefix sums over its ops.)
+//   M -> A/C/G/T or a/c/g/t (+ phased AP..TM), D -> '*' / '#', an I / a first D piece whose previous op is M, D, N (resp. M, N) ->
+//   insertion / deletion on the preceding column (htslib semantics).
+// the record's two 16-byte halves: ra = {rstart, w, naddr lo, naddr hi}, rb = {q, read_idx, nxt, aux}
+__device__ __forceinline__ int nibble_at(uint64_t w0, uint64_t w1, int ni) {     // nibble ni of the 16 loaded bytes (high nibble of a byte first)
+    const uint64_t w = ni < 16 ? w0 : w1;
+    return (int)((w >> (8 * ((ni & 15) >> 1) + ((ni & 1) ? 0 : 4))) & 15u);
 }
 
 template <int C, int MODE>
-__device__ __forceinline__ void walk_op(const ScanArgs &a, const TileLds &s, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int t0, int t1,
-                                        EvRec *ev) {
-    // the record's two 16-byte halves: {rstart, lenop, seq_off}, {qstart, l_seq, read_idx, flag | mapq << 16 | misc << 24}
-    const int op = (int)((uint32_t)ra.y & 15u), len = (int)((uint32_t)ra.y >> 4);
-    const int rstart = ra.x, qstart = rb.x, r = rb.z;
-    const uint64_t seq_off = (uint64_t)(uint32_t)ra.z | ((uint64_t)(uint32_t)ra.w << 32);
-    const uint32_t l_seq = (uint32_t)rb.y;
-    const bool rev = ((uint32_t)rb.w & 16u) != 0;
-    const int hp = (int)(((uint32_t)rb.w >> 24) & 3u), prev = (int)(((uint32_t)rb.w >> 26) & 15u);
+__device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int t0, int t1,
+                                         EvRec *ev) {
+    const uint32_t w = (uint32_t)ra.y;
+    const int op = (int)(w & 3u), prev = (int)((w >> 2) & 15u), hp = (int)((w >> 7) & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
+    const bool rev = (w & 64u) != 0;
+    const int rstart = ra.x, r = rb.y;
     if (op == C3R_CIG_M) {
         if (MODE == SCATTER) return;
         const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
         if (b0 >= b1) return;
-        const uint32_t q0 = (uint32_t)(qstart + (b0 - rstart));
-        const int odd = (int)(q0 & 1u), nb = b1 - b0;
+        const int off = b0 - rstart, nb = b1 - b0;
+        const int odd = (int)(((uint32_t)ra.z + (uint32_t)off) & 1u);          // the bases were loaded from nibble naddr + off on
 #pragma unroll
         for (int u = 0; u < OP_CHOP; ++u) {
             if (u >= nb) continue;
-            const int ni = odd + u;                                  // nibble index inside w0:w1 (high nibble of a byte first)
-            const uint64_t w = ni < 16 ? w0 : w1;
-            int code = (int)((w >> (8 * ((ni & 15) >> 1) + ((ni & 1) ? 0 : 4))) & 15u);
-            if (q0 + (uint32_t)u >= l_seq) code = 15;              // (a CIGAR may claim more bases than SEQ holds)
+            int code = nibble_at(w0, w1, odd + u);
+            if (off + u >= avail) code = 15;                           // (a CIGAR may claim more bases than SEQ holds)
             const int bi = acgt_index(code);
             const int pl = b0 + u - t0;
             if (bi < 0) {
@@ -410,107 +328,97 @@ __device__ __forceinline__ void walk_op(const ScanArgs &a, const TileLds &s, con
         for (int p = b0; p < b1; ++p) atomicAdd(&s.cnt[(p - t0) * C + (rev ? C3R_HASH : C3R_STAR)], 1);
     }
     // indel attached to the column BEFORE the op (htslib: peek the next op at the last position of the current one).
-    // After normalisation: I needs a ref-consuming predecessor, D needs an M or N predecessor.
-    const bool prev_ref = (prev == C3R_CIG_M || prev == C3R_CIG_D || prev == C3R_CIG_N);
-    const bool is_ins = (op == C3R_CIG_I) && prev_ref;
+    // I needs a ref-consuming predecessor (k_prep leaves no record otherwise), D needs an M or N predecessor (its first piece only: the
+    // later pieces of a cut deletion have D before them).
+    const bool is_ins = (op == C3R_CIG_I) && (prev == C3R_CIG_M || prev == C3R_CIG_D || prev == C3R_CIG_N);
     const bool is_del = (op == C3R_CIG_D) && (prev == C3R_CIG_M || prev == C3R_CIG_N);
     if (!(is_ins || is_del)) return;
     const int anchor = rstart - 1;
     if (anchor < t0 || anchor >= t1) return;
     const int pl = anchor - t0;
+    const int ilen = (int)(uint32_t)rb.w;                              // inserted bases / length of the whole deletion
+    const int odd = (int)((uint32_t)ra.z & 1u);
+    if (MODE == FIRSTSEEN) {
+        const int ai = s.amb[pl];
+        if (ai) atomicMin(&s.first[(ai - 1) * 6 + (is_ins ? 4 : 5)], 2u * (uint32_t)r + 1u);
+        return;
+    }
+    // the event record: allele key (the first <= 16 inserted base codes), channel of the max multiplicity
+    EvRec e;
+    e.key = 0;
+    int fc = 15;
+    if (is_ins) {
+        const int nk = ilen < 16 ? ilen : 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (j < nk) e.key |= (uint64_t)(j < avail ? nibble_at(w0, w1, odd + j) : 15) << (4 * j);
+        fc = (int)(e.key & 15u);
+    }
+    // 'I' iff the first inserted char is one of "ACGTN*" (upper case => forward strand), src/create_tensor_pileup.py:227-232
+    const bool up = !rev && (acgt_index(fc) >= 0 || fc == 15);
+    e.len = (uint32_t)ilen; e.read_idx = (uint32_t)r; e.qpos = (uint32_t)rb.x;
+    e.pl = (uint16_t)pl; e.kind = (uint8_t)((rev ? 1 : 0) | (is_ins ? 2 : 0));
+    e.ch = (uint8_t)(is_ins ? (up ? C3R_I1 : C3R_i1) : (rev ? C3R_d1 : C3R_D1));
     if (MODE == ACCUM) {
         // an indel on a ref-skip column takes the haplotype of the previous token-list ENTRY (:183,189)
         if (C == C3R_CH_PHASED && prev == C3R_CIG_N) s.odd[pl] = 1;
         int ch;
-        if (is_ins) {
-            const int fc = base_code(a.seq, seq_off, (uint32_t)qstart, l_seq);
-            // 'I' iff the first inserted char is one of "ACGTN*" (upper case => forward strand), src/create_tensor_pileup.py:227-232
-            ch = (!rev && (acgt_index(fc) >= 0 || fc == 15)) ? C3R_I : C3R_i;
-        } else {
-            ch = rev ? C3R_d : C3R_D;
-            atomicMax(&s.maxdel[pl], len);
-        }
+        if (is_ins) ch = up ? C3R_I : C3R_i;
+        else { ch = rev ? C3R_d : C3R_D; atomicMax(&s.maxdel[pl], ilen); }
         atomicAdd(&s.cnt[pl * C + ch], 1);
         if (C == C3R_CH_PHASED) {
             if (hp == 1) atomicAdd(&s.cnt[pl * C + (is_ins ? C3R_IP : C3R_DP)], 1);
             else if (hp == 2) atomicAdd(&s.cnt[pl * C + (is_ins ? C3R_IM : C3R_DM)], 1);
         }
-    } else if (MODE == SCATTER) {
-        EvRec e;
-        e.key = 0;
-        int ch;
-        if (is_ins) {
-            const int nk = len < 16 ? len : 16;
-            for (int j = 0; j < nk; ++j) e.key |= (uint64_t)base_code(a.seq, seq_off, (uint32_t)(qstart + j), l_seq) << (4 * j);
-            const int fc = (int)(e.key & 15u);
-            ch = (!rev && (acgt_index(fc) >= 0 || fc == 15)) ? C3R_I1 : C3R_i1;
-        } else {
-            ch = rev ? C3R_d1 : C3R_D1;
+        if (s.evq_cap > 0) {
+            const int at = atomicAdd(s.evn, 1);
+            if (at < s.evq_cap) s.evq[at] = e;
         }
-        e.len = (uint32_t)len; e.read_idx = (uint32_t)r; e.qpos = (uint32_t)qstart;
-        e.pl = (uint16_t)pl; e.kind = (uint8_t)((rev ? 1 : 0) | (is_ins ? 2 : 0)); e.ch = (uint8_t)ch;
+    } else {  // SCATTER
         const int slot = s.evoff[pl] + atomicAdd(&s.evfill[pl], 1);
         ev[slot] = e;
-    } else {  // FIRSTSEEN
-        const int ai = s.amb[pl];
-        if (ai) atomicMin(&s.first[(ai - 1) * 6 + (is_ins ? 4 : 5)], 2u * (uint32_t)r + 1u);
     }
 }
 
-// All ops of the listed segments, WALK_UNR records per lane and round: their loads (record, then bases) are issued together.
+// All records of [rlo, rhi), WALK_UNR per lane and round: their loads (record, then bases) are issued together.
 constexpr int WALK_UNR = 2;
 template <int C, int MODE>
-__device__ __forceinline__ void walk_list(const ScanArgs &a, const TileLds &s, const SegList &L, int total, int t0, int t1, EvRec *ev) {
-    const int tid = (int)threadIdx.x, n_list = L.n;
+__device__ __forceinline__ void walk_records(const ScanArgs &a, const TileLds &s, int rlo, int rhi, int t0, int t1, int region, EvRec *ev) {
+    const int tid = (int)threadIdx.x;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    for (int base = 0; base < total; base += SCAN_THREADS * WALK_UNR) {
+    for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
         int4 ra[WALK_UNR], rb[WALK_UNR];
         bool have[WALK_UNR];
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u) {
             const int iu = base + u * SCAN_THREADS + tid;
-            have[u] = iu < total;
-            const int i = have[u] ? iu : total - 1;          // (idle lanes re-read the last record)
-            int lo = 0, hi = n_list;                         // the entry that holds op i: last e with cum[e] <= i
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.cum[mid] <= i) lo = mid; else hi = mid; }
-            const int4 *rec = reinterpret_cast<const int4 *>(a.ops + (L.begin[lo] + (uint32_t)(i - L.cum[lo])));
+            have[u] = iu < rhi;
+            const int4 *rec = reinterpret_cast<const int4 *>(a.recs + (have[u] ? iu : rhi - 1));      // (idle lanes re-read the last record)
             ra[u] = rec[0]; rb[u] = rec[1];
         }
         uint64_t w0[WALK_UNR], w1[WALK_UNR];
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u) {
             w0[u] = 0; w1[u] = 0;
-            if (MODE != SCATTER && have[u] && ((uint32_t)ra[u].y & 15u) == C3R_CIG_M) {
-                const int b0 = max(ra[u].x, t0);
-                const uint32_t q0 = (uint32_t)rb[u].x + (uint32_t)(b0 - ra[u].x);
-                if (b0 < min(ra[u].x + (int)((uint32_t)ra[u].y >> 4), t1) && q0 < (uint32_t)rb[u].y) {
-                    const uint64_t so = (uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32);
-                    u64x2 w;                                 // (the packed-base buffer is padded: the load may run past a read's last byte)
-                    __builtin_memcpy(&w, a.seq + so + (q0 >> 1), 16);
-                    w0[u] = w[0]; w1[u] = w[1];
-                }
+            const uint32_t w = (uint32_t)ra[u].y;
+            const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
+            // does the record touch the tile at all?  (the range is a superset by up to a bin on either side)
+            const bool body = op != C3R_CIG_I && ra[u].x < t1 && ra[u].x + len > t0;
+            const bool anchored = op != C3R_CIG_M && ra[u].x - 1 >= t0 && ra[u].x - 1 < t1;
+            if (!(body || anchored)) have[u] = false;
+            if (have[u] && a.drop && read_dropped(a.drop, a.drop_words, region, rb[u].y)) have[u] = false;
+            int off = -1;                                    // first base to fetch, relative to the piece's first base
+            if (have[u] && op == C3R_CIG_M && MODE != SCATTER) off = max(ra[u].x, t0) - ra[u].x;
+            if (have[u] && op == C3R_CIG_I && MODE != FIRSTSEEN) off = 0;
+            if (off >= 0 && off < avail) {
+                const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)off;
+                u64x2 w;                                     // (the packed-base buffer is padded: the load may run past a read's last byte)
+                __builtin_memcpy(&w, a.seq + (na >> 1), 16);
+                w0[u] = w[0]; w1[u] = w[1];
             }
         }
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u)
-            if (have[u]) walk_op<C, MODE>(a, s, ra[u], rb[u], w0[u], w1[u], t0, t1, ev);
-    }
-}
-
-// One mode's pass over the tile's segments [slo, shi).  A range of at most LCAP segments is listed once (by the first pass)
-// and the list is re-used by the later passes; longer ranges are listed LCAP segments at a time in every pass.
-template <int C, int MODE>
-__device__ __forceinline__ void walk_tile(const ScanArgs &a, const TileLds &s, SegList &L, int slo, int shi, int t0, int t1, int region,
-                          EvRec *ev, bool &listed, int &total) {
-    const bool single = shi - slo <= LCAP;
-    for (int sb = slo; sb < shi; sb += LCAP) {
-        if (!(single && listed)) {
-            list_segments(a, L, sb, min(shi, sb + LCAP), t0, t1, region);
-            total = scan_list(L);
-            listed = true;
-        }
-        walk_list<C, MODE>(a, s, L, total, t0, t1, ev);
-        if (!single) __syncthreads();                        // the next round rewrites the list
+            if (have[u]) walk_rec<C, MODE>(a, s, ra[u], rb[u], w0[u], w1[u], t0, t1, ev);
     }
 }
 
@@ -531,32 +439,8 @@ __device__ __forceinline__ bool ev_equal(const ScanArgs &a, const EvRec &x, cons
     return !((x.kind ^ y.kind) & 1) || caseless;
 }
 
-// One thread per tile: the four binary searches that bound the tile's reads and segments.  Done here, thousands at a
-// time, instead of by one lane at the head of every tile workgroup (64 dependent global loads = tens of microseconds
-// of pure latency per tile).  Tiles that no read span covers are dropped from the work list.
-// Bucket index of the four sorted arrays k_tile_ranges searches (built when the reads are loaded / re-filtered): the answer at every
-// 256th position bounds the answer in between, so a tile's search runs over the reads (segments) that start inside one bucket — a few
-// steps instead of 16-18 dependent loads through the whole array.
-constexpr int BKT_SHIFT = 8;
-__global__ void k_bucket_index(const DevRead *reads, int n_reads, const int32_t *prefmax_end, const DevSeg *segs, int n_segs, const int32_t *seg_prefmax,
-                               int nb, int32_t *out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    const int v = b << BKT_SHIFT;
-    out[b] = lower_bound_pos(reads, n_reads, v);
-    out[nb + b] = upper_bound_gt(prefmax_end, n_reads, v);
-    out[2 * nb + b] = lower_bound_seg(segs, n_segs, v);
-    out[3 * nb + b] = upper_bound_gt(seg_prefmax, n_segs, v);
-}
-// [lo, hi] that holds the answer for query q, from table row `tab` (answers at b << BKT_SHIFT, non-decreasing)
-__device__ __forceinline__ void bucket_bounds(const int32_t *tab, int nb, int n, int q, int &lo, int &hi) {
-    if (tab == nullptr) { lo = 0; hi = n; return; }
-    if (q <= 0) { lo = 0; hi = tab[0]; return; }
-    const int b = q >> BKT_SHIFT;
-    if (b >= nb - 1) { lo = tab[nb - 1]; hi = n; return; }
-    lo = tab[b]; hi = tab[b + 1];
-}
-
+// One thread per tile: the reads and records that can touch it (span_ranges: four table entries), thousands at a time instead of by
+// one lane at the head of every tile workgroup.  Tiles that no read span covers are dropped from the work list.
 __global__ __launch_bounds__(256) void k_tile_ranges(const ScanArgs a) {     // (256 threads: the list append below counts four wavefronts)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     bool listed = false, pruned = false;
@@ -564,28 +448,16 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const ScanArgs a) {     // 
         const TileGeo tg = a.geo[t];
         const int t0 = tg.p0, t1 = tg.p1;
         if (t1 > t0) {                        // (not a guard tile)
-            const int32_t *T0 = a.bkt, *T1 = a.bkt ? a.bkt + a.n_bkt : nullptr, *T2 = a.bkt ? a.bkt + 2 * a.n_bkt : nullptr, *T3 = a.bkt ? a.bkt + 3 * a.n_bkt : nullptr;
-            auto ub_gt = [](const int32_t *arr, int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (arr[mid] > v) hi = mid; else lo = mid + 1; } return lo; };
-            auto lb_pos = [&](int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.reads[mid].pos >= v) hi = mid; else lo = mid + 1; } return lo; };
-            auto lb_seg = [&](int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.segs[mid].ext_start >= v) hi = mid; else lo = mid + 1; } return lo; };
-            int lo, hi;
-            int4 r;
-            bucket_bounds(T1, a.n_bkt, a.n_reads, t0, lo, hi); r.x = ub_gt(a.prefmax_end, lo, hi, t0);
-            bucket_bounds(T0, a.n_bkt, a.n_reads, t1, lo, hi); r.y = lb_pos(lo, hi, t1);
+            const int4 r = span_ranges(a.tab, a.bins, t0, t1);
             if (r.x < r.y) {
-                bucket_bounds(T3, a.n_bkt, a.n_segs, t0, lo, hi); r.z = ub_gt(a.seg_prefmax, lo, hi, t0);
-                bucket_bounds(T2, a.n_bkt, a.n_segs, t1, lo, hi); r.w = lb_seg(lo, hi, t1);
                 a.tile_rng[t] = r;
                 listed = true;
                 if (a.prune && r.z >= r.w) {
                     // intron-only tile.  A candidate is a position with aligned bases (depth > 0) and its window reaches 16
-                    // positions to either side: this tile's rows matter only if an aligned segment comes within 16 bp of it (a
-                    // superset test: the segments' ext_start / prefix-max ends, filters not applied)
-                    bucket_bounds(T3, a.n_bkt, a.n_segs, t0 - C3R_FLANK - 1, lo, hi);
-                    const int z = ub_gt(a.seg_prefmax, lo, hi, t0 - C3R_FLANK - 1);
-                    bucket_bounds(T2, a.n_bkt, a.n_segs, t1 + C3R_FLANK, lo, hi);
-                    const int w = lb_seg(lo, hi, t1 + C3R_FLANK);
-                    if (z >= w) { listed = false; pruned = true; }
+                    // positions to either side: this tile's rows matter only if an aligned base comes within 16 bp of it (a
+                    // superset test: whole bins, records of every passing read)
+                    const int4 q = span_ranges(a.tab, a.bins, t0 - C3R_FLANK - 1, t1 + C3R_FLANK);
+                    if (q.z >= q.w) { listed = false; pruned = true; }
                 }
             }
         }
@@ -645,7 +517,7 @@ __device__ __forceinline__ unsigned long long lb_lookback(unsigned long long *st
 }
 
 // The fused path's list of spans (k_fused_tiles): only spans that hold aligned bases, in ASCENDING order (= output order), with the
-// read / segment ranges of the span plus C3R_FLANK on either side.  Workgroups take blocks of 256 spans by ticket and place their
+// read / record ranges of the span plus C3R_FLANK on either side.  Workgroups take blocks of 256 spans by ticket and place their
 // listed spans behind those of the blocks before them (decoupled look-back over one word per block, as in k_fused_tiles).
 // Everything a workgroup of k_fused_tiles needs to know about its span, in one 48-byte record indexed by LIST position: the tile
 // kernel's per-span start-up was a chain of dependent loads (ticket -> tile_list -> geo -> region bounds, tile ranges) = several
@@ -668,21 +540,10 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
         const TileGeo tg = a.geo[t];
         const int t0 = tg.p0, t1 = tg.p1;
         if (t1 > t0) {
-            const int32_t *T0 = a.bkt, *T1 = a.bkt ? a.bkt + a.n_bkt : nullptr, *T2 = a.bkt ? a.bkt + 2 * a.n_bkt : nullptr, *T3 = a.bkt ? a.bkt + 3 * a.n_bkt : nullptr;
-            auto ub_gt = [](const int32_t *arr, int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (arr[mid] > v) hi = mid; else lo = mid + 1; } return lo; };
-            auto lb_pos = [&](int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.reads[mid].pos >= v) hi = mid; else lo = mid + 1; } return lo; };
-            auto lb_seg = [&](int lo, int hi, int v) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.segs[mid].ext_start >= v) hi = mid; else lo = mid + 1; } return lo; };
-            int lo, hi;
-            // a candidate needs aligned bases on its own position: spans whose own range meets no segment are not listed
-            bucket_bounds(T3, a.n_bkt, a.n_segs, t0, lo, hi); const int z = ub_gt(a.seg_prefmax, lo, hi, t0);
-            bucket_bounds(T2, a.n_bkt, a.n_segs, t1, lo, hi); const int w = lb_seg(lo, hi, t1);
-            if (z < w) {
-                const int e0 = t0 - C3R_FLANK, e1 = t1 + C3R_FLANK;
-                int4 r;
-                bucket_bounds(T1, a.n_bkt, a.n_reads, e0, lo, hi); r.x = ub_gt(a.prefmax_end, lo, hi, e0);
-                bucket_bounds(T0, a.n_bkt, a.n_reads, e1, lo, hi); r.y = lb_pos(lo, hi, e1);
-                bucket_bounds(T3, a.n_bkt, a.n_segs, e0, lo, hi); r.z = ub_gt(a.seg_prefmax, lo, hi, e0);
-                bucket_bounds(T2, a.n_bkt, a.n_segs, e1, lo, hi); r.w = lb_seg(lo, hi, e1);
+            // a candidate needs aligned bases on its own position: spans whose own range meets no record are not listed
+            const int4 own = span_ranges(a.tab, a.bins, t0, t1);
+            if (own.z < own.w) {
+                const int4 r = span_ranges(a.tab, a.bins, t0 - C3R_FLANK, t1 + C3R_FLANK);
                 a.tile_rng[t] = r;
                 listed = r.x < r.y;
                 rec.tile = t; rec.p0 = t0; rec.p1 = t1; rec.region = tg.region; rec.rng = r;
@@ -718,8 +579,9 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
 // 40 k are listed — spent ~0.09 ms per kernel dispatching workgroups that left at once.
 constexpr int LIST_GRID = 8192;
 
-// LDS of one tile workgroup.  Indel events of a tile stay in LDS when there are at most EV_LDS of them (a 20x ONT tile holds ~100);
-// deeper tiles bump-allocate global scratch.  (30 channels: the accumulators leave no room at four workgroups per CU.)
+// LDS of one tile workgroup.  Indel events of a tile stay in LDS when there are at most EV_LDS of them (a 20x ONT tile holds ~100): the
+// first walk captures them as it meets them, and they are bucketed by position without a second walk over the records; deeper tiles
+// walk again and bump-allocate global scratch.  (30 channels: the accumulators leave no room at four workgroups per CU.)
 template <int C>
 struct TileMem {
     static constexpr int EV_LDS = C == C3R_CH ? 192 : 0;
@@ -731,15 +593,15 @@ struct TileMem {
     uint32_t first[FS_CAP * 6];
     uint8_t amb[TILE];
     uint8_t odd[TILE];
-    int misc[8];
+    int misc[8];           // [0] events captured by the first walk, [2..5] block-scan scratch
     unsigned long long evbase;
-    SegList L;
     EvRec ev[EV_LDS > 0 ? EV_LDS : 1];
+    uint8_t evord[EV_LDS > 0 ? EV_LDS : 4];     // the captured events' indices, bucketed by position
 };
 struct TileOut { bool is_row, cand; int depth, cov; };
 
-// The columns of the positions [t0, t1) (at most TILE of them, thread tid <-> position t0 + tid) from the reads [lo, hi) and the aligned
-// segments [slo, shi): accumulators in LDS, indel alleles, the per-position gates (src/create_tensor_pileup.py:259-299, :536-556),
+// The columns of the positions [t0, t1) (at most TILE of them, thread tid <-> position t0 + tid) from the reads [lo, hi) and the
+// records [slo, shi) of the pile table: accumulators in LDS, indel alleles, the per-position gates (src/create_tensor_pileup.py:259-299, :536-556),
 // the reference-channel overwrite.  On return M.cnt holds the finished columns, M.odd the phased columns that need the ordered
 // recompute, and the thread its position's verdict.  Positions below pmin hold no rows (they lie before the region).
 // Used by the column-store kernel (k_scan_tiles) and by the fused kernel (k_fused_tiles), whose "tile" is a window-complete span.
@@ -748,20 +610,18 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
                                                 int cand_lo, int cand_hi) {
     constexpr int EV_LDS = TileMem<C>::EV_LDS;
     const int tid = threadIdx.x;
-    TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd};
-    SegList &L = M.L;
-    bool listed = false;
-    int n_ops = 0;
+    TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, M.ev, &M.misc[0], EV_LDS};
     unsigned long long tprev = a.dbg ? wall_clock64() : 0ull;
 #define C3R_PHASE(K) do { if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[K], now_ - tprev); tprev = now_; } } while (0)
     M.cov[tid] = 0; if (tid == 0) M.cov[TILE] = 0;
     for (int i = tid; i < TILE * C; i += SCAN_THREADS) M.cnt[i] = 0;
     M.evfill[tid] = 0; M.maxdel[tid] = 0; M.amb[tid] = 0; M.odd[tid] = 0;
+    if (tid == 0) M.misc[0] = 0;
     __syncthreads();
 
     C3R_PHASE(0);
     if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1, region);
-    if (!(a.abl & 1)) walk_tile<C, ACCUM>(a, s, L, slo, shi, t0, t1, region, nullptr, listed, n_ops);
+    if (!(a.abl & 1)) walk_records<C, ACCUM>(a, s, slo, shi, t0, t1, region, nullptr);
     __syncthreads();
     C3R_PHASE(1);
 
@@ -780,24 +640,39 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     if (ev_total > 0 && !(a.abl & 2)) {
         // the tile's indel events, bucketed by position (counting sort through evoff / evfill), then the max multiplicity of one
         // allele per (position, channel): I1 / i1 / D1 / d1
-        auto events = [&](EvRec *ev) __attribute__((always_inline)) {
-            walk_tile<C, SCATTER>(a, s, L, slo, shi, t0, t1, region, ev, listed, n_ops);
-            __threadfence_block();
+        if (ev_total <= EV_LDS) {
+            // the usual case: the first walk has captured every event (ev_total of them, in arrival order); bucket their indices
+            for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+                const int pl = M.ev[e].pl;
+                M.evord[M.evoff[pl] + atomicAdd(&M.evfill[pl], 1)] = (uint8_t)e;
+            }
             __syncthreads();
             for (int e = tid; e < ev_total; e += SCAN_THREADS) {
-                const EvRec me = ev[e];
+                const EvRec me = M.ev[e];
                 const int pl = me.pl;
                 const int b = M.evoff[pl];
                 const int32_t *rw = &M.cnt[pl * C];
                 const int n = rw[C3R_I] + rw[C3R_i] + rw[C3R_D] + rw[C3R_d];
                 int eq = 0;
-                for (int j = 0; j < n; ++j) eq += ev_equal(a, me, ev[b + j]) ? 1 : 0;
+                for (int j = 0; j < n; ++j) eq += ev_equal(a, me, M.ev[M.evord[b + j]]) ? 1 : 0;
                 atomicMax(&M.cnt[pl * C + me.ch], eq);
             }
-        };
-        if (ev_total <= EV_LDS) {
-            events(M.ev);                  // the usual case: the events never leave LDS
         } else {
+            auto events = [&](EvRec *ev) __attribute__((always_inline)) {
+                walk_records<C, SCATTER>(a, s, slo, shi, t0, t1, region, ev);
+                __threadfence_block();
+                __syncthreads();
+                for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+                    const EvRec me = ev[e];
+                    const int pl = me.pl;
+                    const int b = M.evoff[pl];
+                    const int32_t *rw = &M.cnt[pl * C];
+                    const int n = rw[C3R_I] + rw[C3R_i] + rw[C3R_D] + rw[C3R_d];
+                    int eq = 0;
+                    for (int j = 0; j < n; ++j) eq += ev_equal(a, me, ev[b + j]) ? 1 : 0;
+                    atomicMax(&M.cnt[pl * C + me.ch], eq);
+                }
+            };
             if (tid == 0) M.evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
             __syncthreads();
             const unsigned long long evb = M.evbase;
@@ -883,7 +758,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
             M.amb[tid] = mine ? (uint8_t)(1 + arank - base) : (uint8_t)0;
             for (int i = tid; i < FS_CAP * 6; i += SCAN_THREADS) M.first[i] = 0xffffffffu;
             __syncthreads();
-            walk_tile<C, FIRSTSEEN>(a, s, L, slo, shi, t0, t1, region, nullptr, listed, n_ops);
+            walk_records<C, FIRSTSEEN>(a, s, slo, shi, t0, t1, region, nullptr);
             __syncthreads();
             if (mine) {
                 int m = 0;
@@ -899,7 +774,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         }
     }
     C3R_PHASE(6);
-    if (a.dbg && tid == 0) { atomicAdd(&a.dbg[14], (unsigned long long)n_ops); atomicAdd(&a.dbg[15], 1ull); atomicAdd(&a.dbg[13], (unsigned long long)(shi - slo)); atomicAdd(&a.dbg[12], (unsigned long long)L.n); }
+    if (a.dbg && tid == 0) { atomicAdd(&a.dbg[14], (unsigned long long)(shi - slo)); atomicAdd(&a.dbg[15], 1ull); atomicAdd(&a.dbg[13], (unsigned long long)(hi - lo)); atomicAdd(&a.dbg[12], (unsigned long long)ev_total); }
 #undef C3R_PHASE
     TileOut o;
     o.is_row = is_row; o.cand = cand; o.depth = depth; o.cov = my_cov;
@@ -918,11 +793,11 @@ __device__ __forceinline__ void scan_tile(const ScanArgs &a, const int tile, Til
     if ((a.abl & 16) && rng.z >= rng.w) return;   // ablation: skip intron-only tiles
     if ((a.abl & 32) && rng.z < rng.w) return;    // ablation: skip tiles with aligned bases
     const int lo = rng.x, hi = rng.y;       // reads whose span can overlap [t0,t1)
-    const int slo = rng.z, shi = rng.w;     // aligned segments that can touch it
+    const int slo = rng.z, shi = rng.w;     // records of the pile table that can touch it
     if (slo >= shi) {
         // intron-only tile: rows exist (ref-skip columns) but every count is zero.  Only the flags are written; the
         // gather treats the columns of such a tile as zeros (tile_cols stays 0).
-        TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd};
+        TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, nullptr, nullptr, 0};
         M.cov[tid] = 0; if (tid == 0) M.cov[TILE] = 0;
         __syncthreads();
         cover_reads(a, s, lo, hi, t0, t1, tg.region);
@@ -997,9 +872,9 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
 // -------------------------------------------------------------------------------------------------
 // Splice-junction padding, part 1 (src/create_tensor_pileup.py:151-178, :532-534): per row
 //   max_skip_count = max(#'$', #'^', #'<', #'>')
-// i.e. reads ending here, reads starting here, reverse / forward reads showing a ref-skip here.  Header-only: starts,
-// ends and per-strand read coverage come from the read spans, per-strand ALIGNED coverage from the segment spans, and
-// ref-skips = covering - aligned.  Same tile list as k_scan_tiles; only launched in splice-padding mode.
+// i.e. reads ending here, reads starting here, reverse / forward reads showing a ref-skip here.  Starts, ends and per-strand read
+// coverage come from the read spans, per-strand ALIGNED coverage from the M / D pieces of the pile table (two loads per record, no
+// bases), and ref-skips = covering - aligned.  Same tile list as k_scan_tiles; only launched in splice-padding mode.
 __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) {
     __shared__ int32_t s_cov[2][TILE + 1];     // reads covering, by strand (difference arrays)
     __shared__ int32_t s_seg[2][TILE + 1];     // aligned segments covering, by strand
@@ -1028,12 +903,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_skip_counts(const ScanArgs a) 
         if (rd.end - 1 < t1) atomicAdd(&s_end[rd.end - 1 - t0], 1);
     }
     for (int g = rng.z + tid; g < rng.w; g += SCAN_THREADS) {
-        const DevSeg sg = a.segs[g];
-        if (!seg_passes(sg, a.min_mq, a.excl_flags) || sg.end <= t0 || sg.pos >= t1 || sg.end <= sg.pos) continue;
-        if (read_dropped(a.drop, a.drop_words, tg.region, (int)sg.read_idx)) continue;
-        const int st = (sg.flag & 16) ? 1 : 0;
-        atomicAdd(&s_seg[st][max(sg.pos, t0) - t0], 1);
-        if (sg.end < t1) atomicAdd(&s_seg[st][sg.end - t0], -1);
+        const int4 *rec = reinterpret_cast<const int4 *>(a.recs + g);
+        const int4 ra = rec[0];
+        const uint32_t w = (uint32_t)ra.y;
+        const int len = (int)((w >> 9) & 31u);
+        if ((w & 3u) == C3R_CIG_I || ra.x >= t1 || ra.x + len <= t0) continue;
+        if (a.drop && read_dropped(a.drop, a.drop_words, tg.region, rec[1].y)) continue;
+        const int st = (w & 64u) ? 1 : 0;
+        atomicAdd(&s_seg[st][max(ra.x, t0) - t0], 1);
+        if (ra.x + len < t1) atomicAdd(&s_seg[st][ra.x + len - t0], -1);
     }
     __syncthreads();
     int tot, v[4];
@@ -1428,73 +1306,22 @@ __device__ __forceinline__ TokenAt token_at(const DevRead &rd, int r, int p, con
 }
 
 // -------------------------------------------------------------------------------------------------
-// Alt tokens: for every emitted candidate list, in BAM order, what each covering read shows at the
-// centre column.  The host rebuilds the ordered alt_info dictionary from these
-// (src/create_tensor_pileup.py:179,221-261,595-596).
-struct TokArgs {
-    const DevRead *reads; const uint32_t *cigar; const uint8_t *seq; const int32_t *prefmax_end; int32_t n_reads;
-    const DevSeg *rsegs;           // aligned segments in READ order
-    const uint32_t *rseg_first;    // [n_reads+1] first segment of each read in rsegs
-    const int32_t *cand_idx; int32_t n_cand; const TileGeo *geo;
-    const int4 *tile_rng;          // from k_tile_ranges: the reads whose span can overlap the candidate's tile
-    const uint32_t *drop; int32_t drop_words;   // depth cap (see ScanArgs)
-    const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
-    int32_t tok_base;              // tokens already resident from earlier scans of the batch
-    int32_t min_mq, excl_flags;
-};
-
-__global__ __launch_bounds__(256) void k_tokens(const TokArgs t) {
-    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (w >= t.n_cand) return;
-    const int ci = t.cand_idx[w];
-    const int p = t.geo[ci / TILE].p0 + (ci % TILE);
-    // (two 16-step binary searches per candidate were most of this kernel's latency; the tile's range is a superset)
-    const int4 rng = t.tile_rng[ci / TILE];
-    const int lo = rng.x, hi = rng.y;
-    const int base_off = t.tok_base + t.tok_off[w];
-    if (lane == 0) t.sites[w].tok_off = (uint32_t)base_off;
-    int written = 0;
-    for (int rb = lo; rb < hi; rb += 64) {
-        const int r = rb + lane;
-        bool cov = false;
-        DevRead rd;
-        if (r < hi) {
-            rd = t.reads[r];
-            cov = read_passes(rd, t.min_mq, t.excl_flags) && rd.pos <= p && rd.end > p && !read_dropped(t.drop, t.drop_words, t.geo[ci / TILE].region, r);
-        }
-        const unsigned long long m = __ballot(cov);
-        if (cov) {
-            const int rank = __popcll(m & ((1ull << lane) - 1ull));
-            const TokenAt ta = token_at(rd, r, p, t.rsegs, t.rseg_first, t.cigar, t.seq);
-            c3r_token_t tk; tk.read_idx = (uint32_t)r; tk.indel = ta.indel; tk.qpos = ta.qpos; tk.base = ta.base; tk.rev = (rd.flag & 16) ? 1 : 0; tk.pad[0] = tk.pad[1] = 0;
-            t.tok[base_off + written + rank] = tk;
-        }
-        written += __popcll(m);
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Alt tokens, one workgroup per tile that holds candidates (replaces k_tokens' one wavefront per candidate, each of which
-// re-scanned its tile's reads and walked one read's CIGAR per lane, serially).  A token's slot is its read's rank among the
-// reads covering the candidate, in BAM order; per batch of TK_NB candidates and chunk of TK_RCH reads:
-//   1. cover pass  — one wavefront per candidate: ballots over the staged read spans give a 64-read cover mask and the running
-//                    rank per block, kept in LDS;
-//   2. op pass     — one lane per expanded op record of the tile's segments (the scan's two-level walk): every candidate the op
-//                    covers gets its token (base / deleted base, the indel the next record attaches to the op's last column)
-//                    written at  rank = prefix of its block + popcount of the mask below the read's bit, and the read's bit
-//                    is set in a "done" mask;
+// Alt tokens: for every emitted candidate, in BAM order, what each covering read shows at the centre column (base / '*' / ref-skip,
+// strand, indel length, query offset).  The host rebuilds the ordered alt_info dictionary from these
+// (src/create_tensor_pileup.py:179,221-261,595-596; decode.hpp / altinfo.py), because order drives tie-breaks in the decoder
+// (clair3_rna/call_variants.py:144,151,187,196).
+// tile_tokens: the candidates of ONE tile / span, by the workgroup that has just decided them (k_fused_tiles: the records are still
+// in the cache, the candidates in LDS) or by k_tile_tokens (column-store path).  A token's slot is its read's rank among the reads
+// covering the candidate, in BAM order; per batch of TK_NB candidates and chunk of TK_RCH reads:
+//   1. cover pass    — one wavefront per candidate: ballots over the staged read spans give a 64-read cover mask and the running
+//                      rank per block, kept in LDS;
+//   2. record pass   — one lane per record of the tile's range: every candidate an M / D piece covers gets its token (base / deleted
+//                      base, `nxt` when the candidate is the piece's last column) written at  rank = prefix of its block + popcount of
+//                      the mask below the read's bit, and the read's bit is set in a "done" mask; an I / D right after a ref-skip
+//                      writes the token of the last intron column;
 //   3. ref-skip pass — covering reads not done show a ref-skip ('>' / '<'): their default tokens fill the remaining slots.
-// Every slot is written exactly once.
-struct TileTokArgs {
-    ScanArgs a;                    // the scan's own arguments (reads, segments, op table, tile list and ranges, filters, depth cap)
-    const int32_t *cand_idx; const int2 *tile_cand; const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
-    int32_t tok_base;              // tokens already resident from earlier scans of the batch
-    const int32_t *abort_flag;     // null, or the fused scan's overflow word: set = the candidate tables are incomplete, nothing to do
-    int32_t cand_cap;              // candidates (scan-relative) that cand_idx / tok_off / sites can hold: spans beyond it are skipped
-    int32_t tok_cap;               // capacity of tok[] (the fused scan sizes it from the previous pass: nothing is written past it)
-};
-constexpr int TK_NB = 32, TK_RCH = 1024, TK_MAXB = TK_RCH / 64;
+// Every slot is written exactly once, by one lane.
+constexpr int TK_NB = 32, TK_RCH = 512, TK_MAXB = TK_RCH / 64;
 struct TokLds {
     int32_t pos[TK_RCH], end[TK_RCH];
     uint8_t rev[TK_RCH];
@@ -1503,141 +1330,75 @@ struct TokLds {
     int32_t lpos[TK_NB], toff[TK_NB], rank0[TK_NB], rank1[TK_NB];
 };
 
-__device__ __forceinline__ void tok_emit(const TileTokArgs &t, TokLds &K, int c, int ri, int r, int indel, uint32_t qpos, int base, bool rev) {
+__device__ __forceinline__ void tok_emit(TokLds &K, c3r_token_t *tok, long long tok_cap, int c, int ri, int r, int indel, uint32_t qpos, int base, bool rev) {
     const int b = ri >> 6, bit = ri & 63;
     const unsigned long long m = K.mask[c][b];
     if (!((m >> bit) & 1ull)) return;                         // (not a covering read by its header: nothing to place)
-    const int slot = K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << bit) - 1ull));
-    if (slot >= t.tok_cap) return;
+    const long long slot = (long long)K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << bit) - 1ull));
+    if (slot >= tok_cap) return;
     int4 v;
     v.x = r; v.y = indel; v.z = (int)qpos; v.w = base | ((rev ? 1 : 0) << 8);
-    *reinterpret_cast<int4 *>(&t.tok[slot]) = v;
+    *reinterpret_cast<int4 *>(&tok[slot]) = v;
     atomicOr(&K.done[c][b], 1ull << bit);
 }
 
-__device__ __forceinline__ void tok_op(const TileTokArgs &t, TokLds &K, uint32_t idx, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1,
-                                       int t0, int t1, int nb, int rc, int re) {
-    const int op = (int)((uint32_t)ra.y & 15u), len = (int)((uint32_t)ra.y >> 4);
-    const int rstart = ra.x, r = rb.z;
+__device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long tok_cap, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int boff,
+                                        int t0, int t1, int nb, int rc, int re) {
+    const uint32_t w = (uint32_t)ra.y;
+    const int op = (int)(w & 3u), prev = (int)((w >> 2) & 15u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
+    const bool rev = (w & 64u) != 0;
+    const int rstart = ra.x, r = rb.y;
     if (r < rc || r >= re) return;                            // (its read belongs to another chunk of the tile's reads)
-    const uint32_t qstart = (uint32_t)rb.x, l_seq = (uint32_t)rb.y;
-    const bool rev = ((uint32_t)rb.w & 16u) != 0, last = (((uint32_t)rb.w >> 30) & 1u) != 0;
-    const int prev = (int)(((uint32_t)rb.w >> 26) & 15u);
-    if (op == C3R_CIG_M || op == C3R_CIG_D) {
+    if (op != C3R_CIG_I) {
         const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
         if (b0 < b1) {
-            const uint32_t q0 = qstart + (uint32_t)(b0 - rstart);
-            const int odd = (int)(q0 & 1u);
+            const int odd = (int)(((uint32_t)ra.z + (uint32_t)boff) & 1u);      // the bases were loaded from nibble naddr + boff on
             for (int c = 0; c < nb; ++c) {
                 const int p = t0 + K.lpos[c];
                 if (p < b0) continue;
                 if (p >= b1) break;                           // (candidates ascend)
                 int base = 16;
-                if (op == C3R_CIG_M) {
-                    const int ni = odd + (p - b0);
-                    const uint64_t w = ni < 16 ? w0 : w1;
-                    base = (int)((w >> (8 * ((ni & 15) >> 1) + ((ni & 1) ? 0 : 4))) & 15u);
-                    if (q0 + (uint32_t)(p - b0) >= l_seq) base = 15;
-                }
+                if (op == C3R_CIG_M) base = (p - rstart) < avail ? nibble_at(w0, w1, odd + (p - rstart) - boff) : 15;
                 int indel = 0; uint32_t qpos = 0;
-                if (p == rstart + len - 1 && !last) {
-                    // htslib: the op after the one that ends on the column (same rules as the scan's walk_op)
-                    const int4 *nx = reinterpret_cast<const int4 *>(t.a.ops + (idx + 1));
-                    const int4 na = nx[0], nbv = nx[1];
-                    const int op2 = (int)((uint32_t)na.y & 15u), len2 = (int)((uint32_t)na.y >> 4), prev2 = (int)(((uint32_t)nbv.w >> 26) & 15u);
-                    if (op2 == C3R_CIG_I && (prev2 == C3R_CIG_M || prev2 == C3R_CIG_D || prev2 == C3R_CIG_N)) { indel = len2; qpos = (uint32_t)nbv.x; }
-                    else if (op2 == C3R_CIG_D && (prev2 == C3R_CIG_M || prev2 == C3R_CIG_N)) indel = -len2;
+                if (p == rstart + len - 1 && rb.z != 0) {
+                    // htslib: the op after the one that ends on the column (k_prep has looked ahead)
+                    indel = rb.z;
+                    if (indel > 0) qpos = (uint32_t)rb.x + (op == C3R_CIG_M ? (uint32_t)len : 0u);
                 }
-                tok_emit(t, K, c, r - rc, r, indel, qpos, base, rev);
+                tok_emit(K, tok, tok_cap, c, r - rc, r, indel, qpos, base, rev);
             }
         }
     }
-    if ((op == C3R_CIG_I || op == C3R_CIG_D) && prev == C3R_CIG_N) {
+    if (prev == C3R_CIG_N && (op == C3R_CIG_I || op == C3R_CIG_D)) {
         // I / D right after a ref-skip: attached to the last intron column, which shows the ref-skip itself
         const int anchor = rstart - 1;
         if (anchor >= t0 && anchor < t1)
             for (int c = 0; c < nb; ++c)
-                if (t0 + K.lpos[c] == anchor) tok_emit(t, K, c, r - rc, r, op == C3R_CIG_I ? len : -len, op == C3R_CIG_I ? qstart : 0u, 17, rev);
+                if (t0 + K.lpos[c] == anchor)
+                    tok_emit(K, tok, tok_cap, c, r - rc, r, op == C3R_CIG_I ? (int)(uint32_t)rb.w : -(int)(uint32_t)rb.w, op == C3R_CIG_I ? (uint32_t)rb.x : 0u, 17, rev);
     }
 }
 
-__device__ __forceinline__ void tok_walk_list(const TileTokArgs &t, TokLds &K, const SegList &L, int total, int t0, int t1, int nb, int rc, int re) {
-    const ScanArgs &a = t.a;
-    const int tid = (int)threadIdx.x, n_list = L.n;
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    for (int base = 0; base < total; base += SCAN_THREADS * WALK_UNR) {
-        int4 ra[WALK_UNR], rb[WALK_UNR];
-        uint32_t idx[WALK_UNR];
-        bool have[WALK_UNR];
-#pragma unroll
-        for (int u = 0; u < WALK_UNR; ++u) {
-            const int iu = base + u * SCAN_THREADS + tid;
-            have[u] = iu < total;
-            const int i = have[u] ? iu : total - 1;
-            int lo = 0, hi = n_list;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.cum[mid] <= i) lo = mid; else hi = mid; }
-            idx[u] = L.begin[lo] + (uint32_t)(i - L.cum[lo]);
-            const int4 *rec = reinterpret_cast<const int4 *>(a.ops + idx[u]);
-            ra[u] = rec[0]; rb[u] = rec[1];
-        }
-        uint64_t w0[WALK_UNR], w1[WALK_UNR];
-#pragma unroll
-        for (int u = 0; u < WALK_UNR; ++u) {
-            w0[u] = 0; w1[u] = 0;
-            if (have[u] && ((uint32_t)ra[u].y & 15u) == C3R_CIG_M) {
-                const int b0 = max(ra[u].x, t0);
-                const uint32_t q0 = (uint32_t)rb[u].x + (uint32_t)(b0 - ra[u].x);
-                if (b0 < min(ra[u].x + (int)((uint32_t)ra[u].y >> 4), t1) && q0 < (uint32_t)rb[u].y) {
-                    const uint64_t so = (uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32);
-                    u64x2 w;
-                    __builtin_memcpy(&w, a.seq + so + (q0 >> 1), 16);
-                    w0[u] = w[0]; w1[u] = w[1];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < WALK_UNR; ++u)
-            if (have[u]) tok_op(t, K, idx[u], ra[u], rb[u], w0[u], w1[u], t0, t1, nb, rc, re);
-    }
-}
-
-#ifndef C3R_TOK_OCC
-#define C3R_TOK_OCC 6
-#endif
-__global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const TileTokArgs t) {
-    __shared__ SegList L;
-    __shared__ TokLds K;
-    const ScanArgs &a = t.a;
+// cand(k, lpos, toff): position (relative to t0) and first token slot of the tile's k-th candidate, ascending.
+template <class CandFn>
+__device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0, int t1, int region, int lo, int hi, int rlo, int rhi, int nc, CandFn &&cand,
+                                            c3r_token_t *tok, long long tok_cap) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (t.abort_flag && *t.abort_flag) return;
-    const int n_list = *a.n_tile_list;
-    for (int lb = blockIdx.x; lb < n_list; lb += gridDim.x) {
-    const int tile = a.tile_list[lb];
-    const int2 tc = t.tile_cand[tile];
-    if (tc.y <= 0 || tc.x + tc.y > t.cand_cap) continue;
-    __syncthreads();
-    const TileGeo tg = a.geo[tile];
-    const int t0 = tg.p0, t1 = tg.p1, slot0 = tile * TILE;
-    const int4 rng = a.tile_rng[tile];
-    const int lo = rng.x, hi = rng.y, slo = rng.z, shi = rng.w;
-    const bool single = shi - slo <= LCAP;
-    bool listed = false;
-    int total = 0;
-    for (int cb = 0; cb < tc.y; cb += TK_NB) {
-        const int nb = min(TK_NB, tc.y - cb);
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    for (int cb = 0; cb < nc; cb += TK_NB) {
+        const int nb = min(TK_NB, nc - cb);
         __syncthreads();
         if (tid < nb) {
-            const int w = tc.x + cb + tid;
-            const int off = t.tok_base + t.tok_off[w];
-            K.lpos[tid] = t.cand_idx[w] - slot0; K.toff[tid] = off; K.rank0[tid] = 0;
-            if (t.sites) t.sites[w].tok_off = (uint32_t)off;
+            int lp, off;
+            cand(cb + tid, lp, off);
+            K.lpos[tid] = lp; K.toff[tid] = off; K.rank0[tid] = 0;
         }
         for (int rc = lo; rc < hi; rc += TK_RCH) {
             const int re = min(hi, rc + TK_RCH), nr = re - rc, nblk = (nr + 63) >> 6;
             __syncthreads();
             for (int i = tid; i < nr; i += SCAN_THREADS) {
                 const DevRead rd = a.reads[rc + i];
-                const bool pass = read_passes(rd, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, tg.region, rc + i);
+                const bool pass = read_passes(rd, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, rc + i);
                 K.pos[i] = rd.pos; K.end[i] = pass ? rd.end : INT32_MIN; K.rev[i] = (rd.flag & 16) ? 1 : 0;
             }
             for (int i = tid; i < TK_NB * TK_MAXB; i += SCAN_THREADS) (&K.done[0][0])[i] = 0ull;
@@ -1655,15 +1416,41 @@ __global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const
                 if (lane == 0) K.rank1[c] = run;
             }
             __syncthreads();
-            if (slo < shi)
-            for (int sb = slo; sb < shi; sb += LCAP) {
-                if (!(single && listed)) {
-                    list_segments(a, L, sb, min(shi, sb + LCAP), t0, t1, tg.region);
-                    total = scan_list(L);
-                    listed = true;
+            // the candidates' positions bound what a record must touch: [first candidate, last candidate]
+            const int c_lo = t0 + K.lpos[0], c_hi = t0 + K.lpos[nb - 1];
+            for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
+                int4 ra[WALK_UNR], rb[WALK_UNR];
+                bool have[WALK_UNR];
+#pragma unroll
+                for (int u = 0; u < WALK_UNR; ++u) {
+                    const int iu = base + u * SCAN_THREADS + tid;
+                    have[u] = iu < rhi;
+                    const int4 *rec = reinterpret_cast<const int4 *>(a.recs + (have[u] ? iu : rhi - 1));
+                    ra[u] = rec[0]; rb[u] = rec[1];
                 }
-                tok_walk_list(t, K, L, total, t0, t1, nb, rc, re);
-                if (!single) __syncthreads();
+                uint64_t w0[WALK_UNR], w1[WALK_UNR];
+                int boff[WALK_UNR];
+#pragma unroll
+                for (int u = 0; u < WALK_UNR; ++u) {
+                    w0[u] = 0; w1[u] = 0; boff[u] = 0;
+                    const uint32_t w = (uint32_t)ra[u].y;
+                    const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
+                    const bool body = op != C3R_CIG_I && ra[u].x <= c_hi && ra[u].x + len > c_lo;
+                    const bool anchored = op != C3R_CIG_M && ra[u].x - 1 >= c_lo && ra[u].x - 1 <= c_hi;
+                    if (!(body || anchored)) have[u] = false;
+                    if (have[u] && op == C3R_CIG_M) {
+                        boff[u] = max(ra[u].x, t0) - ra[u].x;
+                        if (boff[u] < avail) {
+                            const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)boff[u];
+                            u64x2 w;
+                            __builtin_memcpy(&w, a.seq + (na >> 1), 16);
+                            w0[u] = w[0]; w1[u] = w[1];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < WALK_UNR; ++u)
+                    if (have[u]) tok_rec(K, tok, tok_cap, ra[u], rb[u], w0[u], w1[u], boff[u], t0, t1, nb, rc, re);
             }
             __syncthreads();
             for (int c = wave; c < nb; c += WAVES) {
@@ -1671,17 +1458,45 @@ __global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const
                     const unsigned long long m = K.mask[c][b], rest = m & ~K.done[c][b];
                     if ((rest >> lane) & 1ull) {
                         const int i = 64 * b + lane;
-                        const int slot = K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << lane) - 1ull));
-                        if (slot >= t.tok_cap) continue;
+                        const long long slot = (long long)K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << lane) - 1ull));
+                        if (slot >= tok_cap) continue;
                         int4 v;
                         v.x = rc + i; v.y = 0; v.z = 0; v.w = 17 | ((int)K.rev[i] << 8);
-                        *reinterpret_cast<int4 *>(&t.tok[slot]) = v;
+                        *reinterpret_cast<int4 *>(&tok[slot]) = v;
                     }
                 }
                 if (lane == 0) K.rank0[c] = K.rank1[c];
             }
         }
     }
+}
+
+// the column-store path's token kernel: one workgroup per tile that holds candidates (tile_cand from the compaction)
+struct TileTokArgs {
+    ScanArgs a;                    // the scan's own arguments (reads, pile table, tile list and ranges, filters, depth cap)
+    const int32_t *cand_idx; const int2 *tile_cand; const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
+    int32_t tok_base;              // tokens already resident from earlier scans of the batch
+};
+#ifndef C3R_TOK_OCC
+#define C3R_TOK_OCC 6
+#endif
+__global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const TileTokArgs t) {
+    __shared__ TokLds K;
+    const ScanArgs &a = t.a;
+    const int n_list = *a.n_tile_list;
+    for (int lb = blockIdx.x; lb < n_list; lb += gridDim.x) {
+        const int tile = a.tile_list[lb];
+        const int2 tc = t.tile_cand[tile];
+        if (tc.y <= 0) continue;
+        const TileGeo tg = a.geo[tile];
+        const int slot0 = tile * TILE;
+        const int4 rng = a.tile_rng[tile];
+        tile_tokens(a, K, tg.p0, tg.p1, tg.region, rng.x, rng.y, rng.z, rng.w, tc.y, [&](int k, int &lp, int &off) {
+            const int w = tc.x + k;
+            lp = t.cand_idx[w] - slot0;
+            off = t.tok_base + t.tok_off[w];
+            if (t.sites) t.sites[w].tok_off = (uint32_t)off;
+        }, t.tok, (long long)INT32_MAX);
     }
 }
 
@@ -1762,11 +1577,13 @@ __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
 // Order.  Candidates must come out in position order, but a span's first output index is the sum of the counts of all spans before
 // it, and a span's run time varies 10x with depth: making each span wait for its predecessors (decoupled look-back inside this
 // kernel, the first version) let the chip's ~1300 resident workgroups retire only as fast as the slowest of them — 1.35 ms per
-// chr20 pass against 0.61 ms without the ordering.  So the WINDOWS are written where they arrive: a span takes its rows with one
-// atomic add and notes (first row, candidates, tokens) in span_info and a 20-byte record per candidate in `meta`.  k_order_spans
-// then sums the notes in span order (uniform work: look-back costs nothing there), and k_finalize_sites writes everything that is
-// small — site records, token offsets, slots — in position order, plus win_idx[i] = the row of the i-th site's window, through
-// which layer 1 of the network (and c3r_get_tensors) reads the tensors.  No count -> scan -> write over flag arrays, no host
+// chr20 pass against 0.61 ms without the ordering.  So the WINDOWS — and, since round 4, the candidates' TOKENS — are written where
+// they arrive: a span takes its rows and its token slots with one atomic add each and notes (first row, candidates, tokens, first
+// token) in span_info and a 20-byte record per candidate in `meta`.  k_order_spans then sums the candidate counts in span order
+// (uniform work: look-back costs nothing there), and k_finalize_sites writes everything that is small — site records with their
+// token offsets, slots — in position order, plus win_idx[i] = the row of the i-th site's window, through which layer 1 of the
+// network (and c3r_get_tensors) reads the tensors.  A site's tokens are found through its tok_off (contiguous, BAM order), so the
+// token array needs no global order either; c3r_get_tokens exports it in site order.  No count -> scan -> write over flag arrays, no host
 // round trip for sizes: outputs are bounds-checked against the buffers' capacity, and the host learns the totals (and whether
 // anything did not fit: then it grows the buffers and repeats the scan) from the single read-back at the end of the scan.
 constexpr int FUSE_IN = TILE - 2 * C3R_FLANK;     // 224
@@ -1782,15 +1599,20 @@ struct FusedArgs {
     int32_t cand_cap;
     int32_t rescale, max_depth;   // A5: windows with depth > 1.5 x max_depth are rescaled
     int32_t *tensors;             // [cand_cap][33][C], rows in arrival order
-    int4 *span_info;              // [listed spans] {first row, candidates, tokens, tile}
+    int4 *span_info;              // [listed spans] {first row, candidates, tokens, first token (scan-relative)}
     CandMeta *meta;               // [cand_cap]
+    c3r_token_t *tok;             // the batch's token array (null: no tokens wanted — the raw re-run of c3r_get_tensors)
+    int32_t tok_base;             // tokens already resident from earlier scans of the batch
+    int32_t tok_cap;              // token slots this scan may use (scan-relative); a span beyond it writes nothing and raises overflow bit 1
+    int32_t *tok_arrived;         // token slots handed out so far (= tokens, once the kernel is done)
     PhaseArgs ph;                 // 30 channels: the ordered recompute of flagged columns
 };
 
 template <int C>
 __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) void k_fused_tiles(const FusedArgs f) {
     __shared__ TileMem<C> M;
-    __shared__ int s_ticket, s_row0;
+    __shared__ int s_ticket, s_row0, s_tok0;
+    static_assert(sizeof(TokLds) <= sizeof(M.cnt), "the token pass re-uses the accumulators' LDS");
     const ScanArgs &a = f.a;
     const int tid = (int)threadIdx.x;
     const int n = *a.n_tile_list;
@@ -1847,15 +1669,17 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
         int nc, nt;
         const int rank = block_excl_scan(emit ? 1 : 0, wave_tot, &nc);
         const int tpre = block_excl_scan(emit ? o.cov : 0, wave_tot, &nt);
-        // per candidate (by rank): position in the span and depth for the window copy — the event arrays are free by now
-        if (emit) { M.amb[rank] = (uint8_t)tid; M.evfill[rank] = o.depth; }
+        // per candidate (by rank): position in the span, depth for the window copy, tokens of the span's earlier candidates — the event
+        // arrays are free by now
+        if (emit) { M.amb[rank] = (uint8_t)tid; M.evfill[rank] = o.depth; M.evoff[rank] = tpre; }
         if (tid == 0) {
             s_row0 = nc ? atomicAdd(f.arrived, nc) : 0;
-            f.span_info[b] = make_int4(s_row0, nc, nt, tile);
+            s_tok0 = (nc && f.tok) ? atomicAdd(f.tok_arrived, nt) : 0;
+            f.span_info[b] = make_int4(s_row0, nc, nt, s_tok0);
         }
         __syncthreads();
-        const int row0 = s_row0;
-        const bool fits = row0 + nc <= f.cand_cap;
+        const int row0 = s_row0, tok0 = s_tok0;
+        const bool fits = row0 + nc <= f.cand_cap && (!f.tok || (long long)tok0 + nt <= (long long)f.tok_cap);
         if (nc > 0 && !fits && tid == 0) atomicOr(f.overflow, 1);
         if (nc > 0 && fits) {
         if (emit) {
@@ -1888,6 +1712,15 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
         }
         const int gt = head + 4 * n4 + tid;
         if (gt < total) out[gt] = fetch(gt);
+        // ---- the candidates' tokens, while the span's records are still in the cache (k_tile_tokens walked the op table a second time:
+        // 0.29 ms and 291 MB per chr20 pass).  The accumulators are dead once the windows are out: their LDS holds the token pass's tables
+        if (f.tok) {
+            __syncthreads();
+            TokLds &K = *reinterpret_cast<TokLds *>(M.cnt);
+            tile_tokens(a, K, x0, x1, tg.region, rng.x, rng.y, rng.z, rng.w, nc, [&](int k, int &lp, int &off) {
+                lp = (int)M.amb[k]; off = f.tok_base + tok0 + M.evoff[k];
+            }, f.tok, (long long)f.tok_base + f.tok_cap);
+        }
         }
         if (a.dbg && tid == 0) atomicAdd(&a.dbg[7], wall_clock64() - t_tail);
         // ---- hand over to the next span: its ticket has long arrived; the barrier also frees this span's LDS
@@ -1899,9 +1732,9 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
 
 // Spans in list order -> where each span's candidates and tokens start in position order.  256 spans per workgroup, taken by ticket;
 // the workgroups' sums meet by decoupled look-back (uniform, tiny work per workgroup: nobody waits for long).
-//   span_base[i] = {first candidate, first token};  tile_cand[tile] = {first candidate, candidates};  totals = {candidates, tokens}
+//   span_base[i] = first candidate of span i;  totals = {candidates, tokens}
 __global__ __launch_bounds__(256) void k_order_spans(const int4 *span_info, const int32_t *n_list_p, int32_t *ticket, unsigned long long *ostate,
-                                                     int2 *span_base, int2 *tile_cand, int32_t *totals) {
+                                                     int32_t *span_base, int32_t *totals) {
     __shared__ int s_b, s_w[WAVES];
     __shared__ unsigned long long s_excl;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1915,7 +1748,7 @@ __global__ __launch_bounds__(256) void k_order_spans(const int4 *span_info, cons
     if (i < n) v = span_info[i];
     int tc, tt;
     const int ec = block_excl_scan(v.y, s_w, &tc);
-    const int et = block_excl_scan(v.z, s_w, &tt);
+    (void)block_excl_scan(v.z, s_w, &tt);
     if (wave == 0) {
         const unsigned long long mine = ((unsigned long long)(unsigned)tc << 32) | (unsigned)tt;
         const unsigned long long excl = lb_lookback(ostate, b, mine);
@@ -1925,20 +1758,16 @@ __global__ __launch_bounds__(256) void k_order_spans(const int4 *span_info, cons
         }
     }
     __syncthreads();
-    if (i < n) {
-        const int cb = (int)(s_excl >> 32) + ec, tb = (int)(unsigned)s_excl + et;
-        span_base[i] = make_int2(cb, tb);
-        tile_cand[v.w] = make_int2(cb, v.y);
-    }
+    if (i < n) span_base[i] = (int)(s_excl >> 32) + ec;
 }
 
 // Everything small about a candidate, in position order; one wavefront per arrived row.
-//   i = span_base[span].x + (row - first row of the span):  sites[i], cand_idx[i] = slot, tok_off[i] = first token (scan-relative),
-//   win_idx[i] = row_base + row
+//   i = span_base[span] + (row - first row of the span):  sites[i] (tok_off = the span's first token + the tokens of its earlier
+//   candidates), cand_idx[i] = slot, win_idx[i] = row_base + row
 struct FinalizeArgs {
-    const CandMeta *meta; const int4 *span_info; const int2 *span_base; const int32_t *arrived; const int32_t *overflow; int32_t cand_cap;
+    const CandMeta *meta; const int4 *span_info; const int32_t *span_base; const int32_t *arrived; const int32_t *overflow; int32_t cand_cap;
     const TileGeo *geo; const uint8_t *ref; int32_t ref_beg0, ref_len;
-    c3r_site_t *sites; int32_t *cand_idx; int32_t *tok_off; int32_t *win_idx; int32_t row_base;
+    c3r_site_t *sites; int32_t *cand_idx; int32_t *win_idx; int32_t row_base; int32_t tok_base;
 };
 __global__ __launch_bounds__(256) void k_finalize_sites(const FinalizeArgs g) {
     if (*g.overflow) return;                                  // (some rows were never written: the host repeats the scan with larger buffers)
@@ -1946,7 +1775,8 @@ __global__ __launch_bounds__(256) void k_finalize_sites(const FinalizeArgs g) {
     const int lane = (int)(threadIdx.x & 63), nw = (int)(gridDim.x * (blockDim.x >> 6));
     for (int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); row < n; row += nw) {
         const CandMeta m = g.meta[row];
-        const int i = g.span_base[m.span].x + (row - g.span_info[m.span].x);
+        const int4 si = g.span_info[m.span];
+        const int i = g.span_base[m.span] + (row - si.x);
         const int pc = g.geo[m.slot / TILE].p0 + (m.slot % TILE);
         if (g.sites) {
             c3r_site_t *st = &g.sites[i];
@@ -1956,11 +1786,10 @@ __global__ __launch_bounds__(256) void k_finalize_sites(const FinalizeArgs g) {
             } else if (lane < C3R_WINDOW + 3) {
                 st->ref33[lane] = 0;
             }
-            if (lane == 0) { st->pos = pc + 1; st->depth = m.depth; st->n_tok = m.ncov; st->tok_off = 0; }
+            if (lane == 0) { st->pos = pc + 1; st->depth = m.depth; st->n_tok = m.ncov; st->tok_off = (uint32_t)(g.tok_base + si.w + m.tpre); }
         }
         if (lane == 0) {
             if (g.cand_idx) g.cand_idx[i] = m.slot;
-            if (g.tok_off) g.tok_off[i] = g.span_base[m.span].y + m.tpre;
             g.win_idx[i] = g.row_base + row;
         }
     }
@@ -1979,6 +1808,21 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t *src, const i
 __global__ __launch_bounds__(256) void k_iota(int32_t *dst, int n, int base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = base + i;
+}
+// c3r_get_tokens: the tokens of site 0, then of site 1, ... (the fused path writes a span's tokens where they arrive); n_tok per site first
+__global__ __launch_bounds__(256) void k_site_ntok(const c3r_site_t *sites, int n, int32_t *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sites[i].n_tok;
+    else if (i == n) out[i] = 0;
+}
+__global__ __launch_bounds__(256) void k_export_tokens(const c3r_site_t *sites, const int32_t *dst_off, int n, const c3r_token_t *tok, c3r_token_t *out) {
+    const int lane = (int)(threadIdx.x & 63), nw = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); i < n; i += nw) {
+        const int4 *s_ = reinterpret_cast<const int4 *>(tok + sites[i].tok_off);
+        int4 *d_ = reinterpret_cast<int4 *>(out + dst_off[i]);
+        const int nt = sites[i].n_tok;
+        for (int k = lane; k < nt; k += 64) d_[k] = s_[k];
+    }
 }
 
 

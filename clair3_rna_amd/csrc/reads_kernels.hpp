@@ -3,16 +3,18 @@
 //
 // What it replaces: the BAM side of `samtools mpileup <bam> -r ...` (src/create_tensor_pileup.py:436-451) — htslib resolves
 // each read's CIGAR with a per-read cursor while it streams the file; here every read is prepared once, on the device, when
-// the contig's records arrive (c3r_load_reads).  Round 2 did this on host threads (normalise, segment, std::sort, pageable
-// uploads: 32 ms per chr20) outside the measured path.
+// the contig's records arrive (c3r_load_reads), and the result is a PILE TABLE: one self-contained 32-byte record (PileRec,
+// pileup_kernels.hpp) per piece of an aligned op, BINNED BY REFERENCE POSITION (32-bp bins, counting sort), so that the ops a span
+// of the genome needs are one contiguous range of the table — no segment lists, no sort, no per-span searches.
 //
-//   k_reads_count  one lane per read: validate, count normalised ops / aligned segments / indel ops / op records, reference end
-//   k_scan4_*      exclusive prefix sums of the four counts (int4 per read)
-//   k_reads_pass   filters (flag, MAPQ) -> pass flags and sort keys of the read ends
-//   k_cover_max    deepest coverage by passing reads (decides whether mpileup's -d cap can bite at all)
-//   k_reads_write  normalised CIGARs, DevRead headers, aligned segments in read order, sort keys of the segments
-//   k_seg_gather   segments into ext_start order (the permutation comes from rocPRIM's radix sort: a plain library sort)
-//   k_prefmax_*    inclusive prefix maxima of the passing reads' / segments' ends (binary-searched per tile)
+//   k_prep<false>     16 lanes per read: validate, reference end, DevRead header, count the records of every bin (atomics)
+//   k_prefmax_bins    inclusive prefix maximum of the passing reads' ends (one pass, decoupled look-back) + its histogram over the bins
+//   k_bin_scan        exclusive prefix sums over the bins (one pass, decoupled look-back): first record / reads started before /
+//                     reads whose prefix-max end lies before / reads ended before each bin; upper bound of the deepest coverage
+//   k_prep<true>      the same walk again: every record takes its slot in its bin (the bin counters count down to zero)
+// Round 3 prepared per-read normalised CIGARs, aligned segments, two rocPRIM radix sorts, prefix maxima, a bucket index and an op
+// table in ~45 launches and 0.85 ms per chr20; those tables survive only as the LEGACY tables below, built on demand for the one
+// consumer that still walks a single read's CIGAR (token_at: the ordered haplotype recompute of the 30-channel mode).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -26,15 +28,13 @@ namespace c3r {
 struct LoadStats {
     unsigned long long err;   // ~0: none; else (read index << 8) | code — the smallest failing read wins
     int32_t max_end;          // largest reference end of any read (exclusive, 0-based)
-    int32_t max_cover;        // most passing reads over one position
-    // the totals of the int4 scan, 16-byte aligned (k_scan4_tops stores them as one int4)
-    int32_t n_norm;           // normalised CIGAR ops
-    int32_t n_segs;           // aligned segments
-    int32_t n_indel;          // I + D ops after normalisation
-    int32_t n_oprec;          // expanded op records (pileup_kernels.hpp, OpRec)
+    int32_t max_cover;        // upper bound of the number of reads over one position (reads overlapping one 32-bp bin)
+    int32_t n_rec;            // records of the pile table
+    int32_t n_indel;          // I + D ops of the passing reads (bounds the indel-event scratch of a scan)
+    int32_t pad[2];
 };
-static_assert(sizeof(LoadStats) == 32 && offsetof(LoadStats, n_norm) == 16, "LoadStats layout");
-enum { LD_OK = 0, LD_UNSORTED = 1, LD_CIGAR_RANGE, LD_SEQ_RANGE, LD_BAD_OP, LD_OP_LONG, LD_END_2G, LD_SEG_OPS };
+static_assert(sizeof(LoadStats) == 32, "LoadStats layout");
+enum { LD_OK = 0, LD_UNSORTED = 1, LD_CIGAR_RANGE, LD_SEQ_RANGE, LD_BAD_OP, LD_OP_LONG, LD_END_2G, LD_SEG_OPS, LD_RECORDS };
 
 __device__ __forceinline__ void load_fail(LoadStats *st, int read, int code) {
     atomicMin(&st->err, ((unsigned long long)(unsigned)read << 8) | (unsigned)code);
@@ -43,14 +43,15 @@ __device__ __forceinline__ void load_fail(LoadStats *st, int read, int code) {
 // CIGAR normalisation as a stream: drop H, zero-length ops and pads (a pad is kept — as a 1-long op that consumes nothing —
 // exactly when the next real op is a D: htslib marks a deletion only when the D IMMEDIATELY follows the op that ends on the
 // column, while insertions are found through pads), fold = / X into M, merge equal neighbours.  emit(op, len) receives every
-// finalised op in order.  Returns LD_OK or the error code.
+// finalised op in order.  Returns LD_OK or the error code.  Serial: one lane walks one read.  The parallel walk of k_prep handles
+// the reads whose CIGAR needs none of this (every op kept as it is); the others come here.
 template <class Emit>
 __device__ __forceinline__ int walk_norm(const uint32_t *cig, uint32_t n, Emit &&emit) {
     bool have = false;
     uint32_t cop = 0;
     unsigned long long clen = 0;
     // ops are fetched eight at a time: the loads of a batch are independent of each other, so a read's walk pays one memory round trip
-    // per eight ops instead of one per op (the kernels end when the longest read — several hundred ops — is done)
+    // per eight ops instead of one per op
     constexpr uint32_t NB = 8;
     uint32_t buf[NB];
     for (uint32_t k = 0; k < n; ++k) {
@@ -84,8 +85,9 @@ __device__ __forceinline__ int walk_norm(const uint32_t *cig, uint32_t n, Emit &
 }
 
 // The aligned segments of a read = the runs of normalised ops between N ops, as a consumer of walk_norm's stream.
-// seg(first op index, op count, pos, qstart, end_x, lead_n, lead_indel, records) is called for every segment that is kept:
+// seg(first op index, op count, pos, qstart, end_x, lead_n, lead_indel) is called for every segment that is kept:
 // one that holds an M or D, or that starts with an I / D right after an N (that indel is attached to the last intron column).
+// (Legacy tables, and the "more than 65535 ops between two N ops" rule of the load-time validation.)
 struct SegWalk {
     long long x;          // reference cursor
     uint32_t y;           // query cursor
@@ -94,16 +96,15 @@ struct SegWalk {
     uint32_t k0, q0, first_op;
     long long x0;
     bool open, useful, after_n;
-    int nrec;             // op records of the open segment (M: one per OP_CHOP bases, I / D: one)
     int bad;              // LD_SEG_OPS when a segment holds more than 65535 ops
-    __device__ __forceinline__ void begin(int32_t pos) { x = pos; y = 0; k = 0; open = false; useful = false; after_n = false; nrec = 0; bad = 0; first_op = 15; k0 = 0; q0 = 0; x0 = pos; }
+    __device__ __forceinline__ void begin(int32_t pos) { x = pos; y = 0; k = 0; open = false; useful = false; after_n = false; bad = 0; first_op = 15; k0 = 0; q0 = 0; x0 = pos; }
     template <class Seg>
     __device__ __forceinline__ void close(Seg &&seg) {
         if (!open) return;
         const bool lead_indel = after_n && (first_op == C3R_CIG_I || first_op == C3R_CIG_D);
         if (useful || lead_indel) {
             if (k - k0 > 0xffffu) bad = LD_SEG_OPS;
-            seg(k0, k - k0, x0, q0, x, after_n, lead_indel, nrec);
+            seg(k0, k - k0, x0, q0, x, after_n, lead_indel);
         }
         open = false;
     }
@@ -114,164 +115,421 @@ struct SegWalk {
             x += len; after_n = true; ++k;
             return;
         }
-        if (!open) { open = true; useful = false; k0 = k; q0 = y; x0 = x; first_op = o; nrec = 0; }
-        if (o == C3R_CIG_M) { nrec += (int)((len + OP_CHOP - 1) / OP_CHOP); x += len; y += len; useful = true; }
-        else if (o == C3R_CIG_D) { nrec += 1; x += len; useful = true; }
-        else if (o == C3R_CIG_I) { nrec += 1; y += len; }
+        if (!open) { open = true; useful = false; k0 = k; q0 = y; x0 = x; first_op = o; }
+        if (o == C3R_CIG_M) { x += len; y += len; useful = true; }
+        else if (o == C3R_CIG_D) { x += len; useful = true; }
+        else if (o == C3R_CIG_I) { y += len; }
         else if (o == C3R_CIG_S) y += len;
         ++k;
     }
 };
 
-// counts: int4 {normalised ops, segments, indel ops, op records} per read (+ a zero entry at n_reads for the exclusive scan)
-__global__ __launch_bounds__(256) void k_reads_count(const c3r_read_t *reads, int n_reads, const uint32_t *cigars, long long n_cigar_ops,
-                                                     long long n_seq_bytes, int4 *cnt, int32_t *rend, LoadStats *st) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int my_end = 0;
-    if (i < n_reads) {
-        const c3r_read_t r = reads[i];
-        int4 c = make_int4(0, 0, 0, 0);
-        int err = LD_OK;
-        if (i > 0 && r.pos < reads[i - 1].pos) err = LD_UNSORTED;
-        else if ((long long)r.cigar_off + r.n_cigar > n_cigar_ops) err = LD_CIGAR_RANGE;
-        else if ((long long)r.seq_off + (r.l_seq + 1) / 2 > n_seq_bytes) err = LD_SEQ_RANGE;
-        long long rlen = 0;
-        if (!err) {
-            SegWalk w;
-            w.begin(r.pos);
-            auto seg = [&](uint32_t, uint32_t, long long, uint32_t, long long, bool, bool, int nrec) { c.y += 1; c.w += nrec; };
-            err = walk_norm(cigars + r.cigar_off, r.n_cigar, [&](uint32_t op, uint32_t len) {
-                c.x += 1;
-                if (op == C3R_CIG_I || op == C3R_CIG_D) c.z += 1;
-                if (op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N) rlen += len;
-                w.op(op, len, seg);
-            });
-            w.close(seg);
-            if (!err && w.bad) err = w.bad;
-            if (!err && (long long)r.pos + rlen > INT32_MAX) err = LD_END_2G;
+// ---- the pile table ---------------------------------------------------------------------------------------------------------
+constexpr int PREP_GRP = 16;                  // lanes per read in k_prep
+
+struct ReadInfo {
+    const uint32_t *cig;
+    int32_t pos;
+    uint32_t n_cig, l_seq, read_idx, wbits;   // wbits: strand and haplotype bits of PileRec::w
+    uint64_t seq_off;
+};
+
+// The records of ONE normalised op (code, length, reference / query offsets of its first base, the read's previous and next op).
+//   M, D: one record per OP_CHOP reference positions; the last piece carries the indel htslib attaches to the op's last column
+//         (an I after M / D, a D after M); I: one record, only when its predecessor consumes the reference (M, D, N) — otherwise
+//         samtools shows no insertion; N, S, P: none.
+// emit(rstart, w, naddr, q, nxt, aux).
+template <class Emit>
+__device__ __forceinline__ void op_records(const ReadInfo &R, uint32_t op, uint32_t len, long long x, uint32_t y, uint32_t prev, uint32_t nop, uint32_t nlen,
+                                           Emit &&emit) {
+    if (op == C3R_CIG_M) {
+        const int32_t nxt_last = nop == C3R_CIG_I ? (int32_t)nlen : nop == C3R_CIG_D ? -(int32_t)nlen : 0;
+        for (uint32_t d = 0; d < len; d += OP_CHOP) {
+            const uint32_t pl = min((uint32_t)OP_CHOP, len - d), q = y + d;
+            const uint32_t avail = q >= R.l_seq ? 0u : min(pl, R.l_seq - q);           // (a CIGAR may claim more bases than SEQ holds)
+            const uint32_t w = (uint32_t)C3R_CIG_M | ((d ? (uint32_t)C3R_CIG_M : prev) << 2) | R.wbits | (pl << 9) | (avail << 14);
+            emit((int32_t)(x + d), w, 2ull * R.seq_off + q, q, d + OP_CHOP >= len ? nxt_last : 0, 0u);
         }
-        if (err) { load_fail(st, i, err); c = make_int4(0, 0, 0, 0); rlen = 0; }
-        cnt[i] = c;
-        my_end = (int32_t)(r.pos + rlen);
-        rend[i] = my_end;
-    } else if (i == n_reads) cnt[i] = make_int4(0, 0, 0, 0);
-    int m = my_end;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&st->max_end, m);
+    } else if (op == C3R_CIG_D) {
+        const int32_t nxt_last = nop == C3R_CIG_I ? (int32_t)nlen : 0;
+        for (uint32_t d = 0; d < len; d += OP_CHOP) {
+            const uint32_t pl = min((uint32_t)OP_CHOP, len - d);
+            const uint32_t w = (uint32_t)C3R_CIG_D | ((d ? (uint32_t)C3R_CIG_D : prev) << 2) | R.wbits | (pl << 9);
+            emit((int32_t)(x + d), w, 0ull, y, d + OP_CHOP >= len ? nxt_last : 0, len);
+        }
+    } else if (op == C3R_CIG_I) {
+        if (prev == C3R_CIG_M || prev == C3R_CIG_D || prev == C3R_CIG_N) {
+            const uint32_t avail = y >= R.l_seq ? 0u : min(31u, R.l_seq - y);
+            emit((int32_t)x, (uint32_t)C3R_CIG_I | (prev << 2) | R.wbits | (avail << 14), 2ull * R.seq_off + y, y, 0, len);
+        }
+    }
 }
 
-// ---- exclusive scan of int4 items, three short launches (one when the input fits one block): local / tops / add
-constexpr int S4_IT = 4, S4_BLK = 1024 * S4_IT;
-__device__ __forceinline__ int4 add4(const int4 a, const int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ int4 wave_incl_scan4(int4 v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int4 t;
-        t.x = __shfl_up(v.x, off, 64); t.y = __shfl_up(v.y, off, 64); t.z = __shfl_up(v.z, off, 64); t.w = __shfl_up(v.w, off, 64);
-        if (lane >= off) v = add4(v, t);
+__device__ __forceinline__ uint32_t fold_op(uint32_t c) { const uint32_t op = c & 15u; return (op == C3R_CIG_EQ || op == C3R_CIG_X) ? (uint32_t)C3R_CIG_M : op; }
+__device__ __forceinline__ bool op_ref(uint32_t op) { return op == C3R_CIG_M || op == C3R_CIG_D || op == C3R_CIG_N; }
+__device__ __forceinline__ bool op_qry(uint32_t op) { return op == C3R_CIG_M || op == C3R_CIG_I || op == C3R_CIG_S; }
+
+// A first look at a read's CIGAR by its 16 lanes: total reference length (normalisation never changes it), the I / D ops, and whether
+// the parallel walk may take it as it is — every op kept (H only as the first or last op), no zero-length op, no pad, no equal
+// neighbours other than M-like ones (which pieces cut anyway), no unknown op code, at most 65535 ops and less than 2^28 reference
+// positions (the limits of the normalised form are then met without looking).  Aligners emit nothing else; the rest takes the
+// serial walk.  All lanes return the group's values.
+__device__ __forceinline__ bool cigar_is_plain(const ReadInfo &R, int gl, long long &ref_len, int &n_indel) {
+    unsigned long long rl = 0;
+    int ni = 0;
+    bool odd = R.n_cig > 0xffffu;
+    for (uint32_t k0 = 0; k0 < R.n_cig; k0 += PREP_GRP) {
+        const uint32_t k = k0 + (uint32_t)gl;
+        if (k < R.n_cig) {
+            const uint32_t c = R.cig[k], raw = c & 15u, op = fold_op(c), len = c >> 4;
+            if (raw > C3R_CIG_X || len == 0 || raw == C3R_CIG_P || (raw == C3R_CIG_H && k != 0 && k + 1 != R.n_cig)) odd = true;
+            if (k > 0 && op != C3R_CIG_M && op == fold_op(R.cig[k - 1])) odd = true;
+            if (op_ref(op)) rl += len;
+            if (op == C3R_CIG_I || op == C3R_CIG_D) ++ni;
+        }
     }
-    return v;
-}
-__global__ __launch_bounds__(1024) void k_scan4_local(int4 *data, int n, int4 *tops) {
-    __shared__ int4 wtot[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = blockIdx.x * S4_BLK + threadIdx.x * S4_IT;
-    int4 v[S4_IT], sum = make_int4(0, 0, 0, 0);
+    int o = odd ? 1 : 0;
 #pragma unroll
-    for (int k = 0; k < S4_IT; ++k) { v[k] = (i0 + k < n) ? data[i0 + k] : make_int4(0, 0, 0, 0); sum = add4(sum, v[k]); }
-    const int4 incl = wave_incl_scan4(sum);
+    for (int off = PREP_GRP / 2; off > 0; off >>= 1) {
+        rl += __shfl_xor(rl, off, PREP_GRP);
+        ni += __shfl_xor(ni, off, PREP_GRP);
+        o |= __shfl_xor(o, off, PREP_GRP);
+    }
+    ref_len = (long long)rl; n_indel = ni;
+    return !o && rl < (1ull << 28);
+}
+
+// The parallel walk: lane gl of the group takes ops gl, gl + 16, ...; reference / query offsets by 16-lane prefix sums.
+template <class Emit>
+__device__ __forceinline__ void walk_plain(const ReadInfo &R, int gl, Emit &&emit) {
+    uint32_t x = (uint32_t)R.pos, y = 0;                       // (less than 2^28 reference positions: 32 bits do)
+    for (uint32_t k0 = 0; k0 < R.n_cig; k0 += PREP_GRP) {
+        const uint32_t k = k0 + (uint32_t)gl;
+        const bool in = k < R.n_cig;
+        const uint32_t c = in ? R.cig[k] : 0u, op = in ? fold_op(c) : (uint32_t)C3R_CIG_H, len = c >> 4;
+        uint32_t prev = 15u, nop = 15u, nlen = 0;
+        if (in && k > 0) { prev = fold_op(R.cig[k - 1]); if (prev == C3R_CIG_H) prev = 15u; }
+        if (in && k + 1 < R.n_cig) { const uint32_t cn = R.cig[k + 1]; nop = fold_op(cn); nlen = cn >> 4; if (nop == C3R_CIG_H) nop = 15u; }
+        const uint32_t rl = op_ref(op) ? len : 0u, ql = op_qry(op) ? len : 0u;
+        uint32_t ri = rl, qi = ql;
+#pragma unroll
+        for (int off = 1; off < PREP_GRP; off <<= 1) {
+            const uint32_t tr = __shfl_up(ri, off, PREP_GRP), tq = __shfl_up(qi, off, PREP_GRP);
+            if (gl >= off) { ri += tr; qi += tq; }
+        }
+        if (in) op_records(R, op, len, (long long)(int32_t)(x + ri - rl), y + qi - ql, prev, nop, nlen, emit);
+        x += __shfl(ri, PREP_GRP - 1, PREP_GRP);
+        y += __shfl(qi, PREP_GRP - 1, PREP_GRP);
+    }
+}
+
+// The serial walk (one lane): walk_norm's stream, one op of look-ahead for the indel attached to an op's last column.  Returns the
+// error code of the normalised form (unknown op, a merged op of 2^28 or more, more than 65535 ops between two N ops).
+template <class Emit>
+__device__ __forceinline__ int walk_serial(const ReadInfo &R, Emit &&emit) {
+    SegWalk w;
+    w.begin(R.pos);
+    auto seg = [](uint32_t, uint32_t, long long, uint32_t, long long, bool, bool) {};
+    bool have = false;
+    uint32_t pop = 0, plen = 0, py = 0, pprev = 15u, prev = 15u, y = 0;
+    long long px = 0, x = R.pos;
+    const int err = walk_norm(R.cig, R.n_cig, [&](uint32_t op, uint32_t len) {
+        if (have) op_records(R, pop, plen, px, py, pprev, op, len, emit);
+        pop = op; plen = len; px = x; py = y; pprev = prev; have = true;
+        if (op_ref(op)) x += len;
+        if (op_qry(op)) y += len;
+        prev = op;
+        w.op(op, len, seg);
+    });
+    if (err) return err;
+    if (have) op_records(R, pop, plen, px, py, pprev, 15u, 0u, emit);
+    w.close(seg);
+    return w.bad;
+}
+
+struct PrepArgs {
+    const c3r_read_t *reads; int32_t n_reads;
+    const uint32_t *cigars; long long n_cigar_ops, n_seq_bytes;
+    int32_t min_mq, excl_flags;
+    BinGeo geo;
+    uint32_t *cnt;            // [nb] records per bin: counted up by k_prep<false>, counted down to zero by k_prep<true>
+    uint32_t *sc, *ec;        // [nb] reads that start in the bin / reads whose end falls into the 32 positions before the bin's last
+    const int4 *tab;          // [nb + 1] k_bin_scan's prefix sums (k_prep<true>)
+    DevRead *out;             // [n_reads] headers, written by k_prep<false>
+    uint8_t *serial;          // [n_reads] 1 = the read takes the serial walk
+    int32_t *nind;            // [n_reads] I + D ops of the read, 0 when the filters drop it (summed by k_prefmax_bins: 54 k atomics on one
+                              // word would take 0.6 ms)
+    PileRec *recs;
+    LoadStats *st;
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_prep(const PrepArgs a) {
+    const int gl = (int)(threadIdx.x & (PREP_GRP - 1));
+    const int i = (int)(blockIdx.x * (256 / PREP_GRP) + (threadIdx.x / PREP_GRP));
+    if (i >= a.n_reads) return;
+    ReadInfo R;
+    if (!WRITE) {
+        const c3r_read_t r = a.reads[i];
+        int err = LD_OK;
+        if (i > 0 && r.pos < a.reads[i - 1].pos) err = LD_UNSORTED;
+        else if ((long long)r.cigar_off + r.n_cigar > a.n_cigar_ops) err = LD_CIGAR_RANGE;
+        else if ((long long)r.seq_off + (r.l_seq + 1) / 2 > a.n_seq_bytes) err = LD_SEQ_RANGE;
+        R.cig = a.cigars + r.cigar_off; R.pos = r.pos; R.n_cig = err ? 0u : r.n_cigar; R.l_seq = r.l_seq; R.read_idx = (uint32_t)i; R.seq_off = r.seq_off;
+        R.wbits = ((r.flag & 16u) ? 64u : 0u) | ((r.hp == 1 ? 1u : r.hp == 2 ? 2u : 0u) << 7);
+        long long ref_len = 0;
+        int n_indel = 0;
+        const bool plain = cigar_is_plain(R, gl, ref_len, n_indel);
+        const bool pass = !err && !flag_fails(r.flag, a.excl_flags) && r.mapq >= a.min_mq;
+        auto count = [&](int32_t rstart, uint32_t, unsigned long long, uint32_t, int32_t, uint32_t) {
+            if (pass) __hip_atomic_fetch_add(&a.cnt[bin_of(a.geo, rstart)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (!err) {
+            if (plain) { if (pass) walk_plain(R, gl, count); }
+            else if (gl == 0) err = walk_serial(R, count);             // (also for a read the filters drop: its CIGAR is validated all the same)
+            if (!err && (long long)r.pos + ref_len > INT32_MAX) err = LD_END_2G;
+        }
+        if (gl == 0) {
+            if (err) { load_fail(a.st, i, err); ref_len = 0; n_indel = 0; }
+            DevRead d;
+            d.pos = r.pos; d.end = (int32_t)(r.pos + ref_len); d.cig_off = r.cigar_off; d.n_cig = r.n_cigar; d.seq_off = r.seq_off;
+            d.flag = r.flag; d.mapq = r.mapq; d.hp = r.hp; d.l_seq = r.l_seq;
+            a.out[i] = d;
+            a.serial[i] = plain ? 0 : 1;
+            __hip_atomic_fetch_add(&a.sc[bin_of(a.geo, d.pos)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // counted as "ended at or before the start of bin b" for every b >= ceil(end / 32) - base; k_bin_scan's exclusive sum over ec[j], j < b
+            int je = ((d.end + (1 << BIN_SHIFT) - 1) >> BIN_SHIFT) - a.geo.base - 1;
+            je = je < 0 ? 0 : je >= a.geo.nb ? a.geo.nb - 1 : je;
+            __hip_atomic_fetch_add(&a.ec[je], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.nind[i] = pass ? n_indel : 0;
+        }
+    } else {
+        const DevRead d = a.out[i];
+        if (flag_fails(d.flag, a.excl_flags) || d.mapq < a.min_mq) return;
+        R.cig = a.cigars + d.cig_off; R.pos = d.pos; R.n_cig = d.n_cig; R.l_seq = d.l_seq; R.read_idx = (uint32_t)i; R.seq_off = d.seq_off;
+        R.wbits = ((d.flag & 16u) ? 64u : 0u) | ((d.hp == 1 ? 1u : d.hp == 2 ? 2u : 0u) << 7);
+        auto put = [&](int32_t rstart, uint32_t w, unsigned long long naddr, uint32_t q, int32_t nxt, uint32_t aux) {
+            const int b = bin_of(a.geo, rstart);
+            const uint32_t left = __hip_atomic_fetch_add(&a.cnt[b], ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // counts down
+            int4 *dst = reinterpret_cast<int4 *>(a.recs + ((size_t)(uint32_t)a.tab[b].x + (left - 1u)));
+            dst[0] = make_int4(rstart, (int)w, (int)(uint32_t)naddr, (int)(uint32_t)(naddr >> 32));
+            dst[1] = make_int4((int)q, i, nxt, (int)aux);
+        };
+        if (!a.serial[i]) walk_plain(R, gl, put);
+        else if (gl == 0) (void)walk_serial(R, put);
+    }
+}
+
+// ---- decoupled look-back over 64-bit words (flag in the two top bits, 62 bits of payload), sums or maxima
+template <bool MAX>
+__device__ __forceinline__ unsigned long long lb_lookback_op(unsigned long long *state, int b, unsigned long long mine) {
+    const int lane = (int)(threadIdx.x & 63);
+    constexpr unsigned long long PAY = 0x3fffffffffffffffull;
+    unsigned long long excl = 0;
+    if (b > 0) {
+        if (lane == 0) lb_store(&state[b], (1ull << 62) | mine);
+        for (int top = b - 1; top >= 0; top -= 64) {
+            const int i = top - lane;
+            unsigned long long w = 0;
+            bool incl_found = false;
+            for (;;) {
+                w = i >= 0 ? lb_load(&state[i]) : (2ull << 62);
+                const unsigned long long not_ready = __ballot((w >> 62) == 0), incl = __ballot((w >> 62) == 2);
+                const int first_incl = incl ? __ffsll((long long)incl) - 1 : 64;
+                const unsigned long long need = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
+                if (!(not_ready & need)) { incl_found = incl != 0; w = (lane <= first_incl) ? (w & PAY) : 0ull; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long t = __shfl_xor(w, off, 64); w = MAX ? (t > w ? t : w) : w + t; }
+            excl = MAX ? (w > excl ? w : excl) : excl + w;
+            if (incl_found) break;
+        }
+    }
+    const unsigned long long incl_v = MAX ? (mine > excl ? mine : excl) : excl + mine;
+    if (lane == 0) lb_store(&state[b], (2ull << 62) | (incl_v & PAY));
+    return excl;
+}
+
+// ---- inclusive prefix maximum of the ends of the reads that pass the filters (INT_MIN before the first), one pass; pc[j] += 1 for
+// every read whose prefix maximum lies in bin j (reads before the first passing read: bin 0).  Also the two totals k_prep<false> left
+// per read: the largest end of a passing read (= the last prefix maximum) and the I + D ops.
+constexpr int PM_IT = 4, PM_BLK = 1024 * PM_IT;
+__global__ __launch_bounds__(1024) void k_prefmax_bins(const DevRead *reads, int n, int min_mq, int excl, BinGeo geo, const int32_t *nind, int32_t *out, uint32_t *pc,
+                                                       LoadStats *st, int32_t *ticket, unsigned long long *state) {
+    __shared__ int s_b, wtot[16], s_ni[16];
+    __shared__ unsigned long long s_excl;
+    if (threadIdx.x == 0) s_b = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int b = s_b, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = b * PM_BLK + (int)threadIdx.x * PM_IT;
+    int v[PM_IT], m = INT32_MIN, ni = 0;
+#pragma unroll
+    for (int k = 0; k < PM_IT; ++k) {
+        v[k] = INT32_MIN;
+        if (i0 + k < n) { const DevRead r = reads[i0 + k]; if (read_passes(r, min_mq, excl)) v[k] = r.end; ni += nind[i0 + k]; }
+        m = max(m, v[k]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ni += __shfl_xor(ni, off, 64);
+    if (lane == 0) s_ni[wave] = ni;
+    int incl = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl = max(incl, t); }
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    int4 wb = make_int4(0, 0, 0, 0), tot = wb;
-    for (int w = 0; w < 16; ++w) { const int4 t = wtot[w]; if (w < wave) wb = add4(wb, t); tot = add4(tot, t); }
-    int4 run = make_int4(wb.x + incl.x - sum.x, wb.y + incl.y - sum.y, wb.z + incl.z - sum.z, wb.w + incl.w - sum.w);
+    int before = INT32_MIN, tot = INT32_MIN;
+    for (int w = 0; w < 16; ++w) { const int t = wtot[w]; if (w < wave) before = max(before, t); tot = max(tot, t); }
+    if (wave == 0) {
+        // payload: end + 1 (ends are positive), 0 = none
+        const unsigned long long e = lb_lookback_op<true>(state, b, tot > 0 ? (unsigned long long)tot + 1ull : 0ull);
+        if (lane == 0) s_excl = e;
+    }
+    __syncthreads();
+    const int carry = s_excl ? (int)(s_excl - 1ull) : INT32_MIN;
+    int run = max(before, __shfl_up(incl, 1, 64));
+    if (lane == 0) run = before;
+    run = max(run, carry);
+    // a long read's end is the prefix maximum of all the reads that follow it until a longer one comes: a wavefront whose 256 reads
+    // share one value adds them with one atomic
+    const int first = max(run, v[0]);
+    int last = first;
 #pragma unroll
-    for (int k = 0; k < S4_IT; ++k) { if (i0 + k < n) data[i0 + k] = run; run = add4(run, v[k]); }
-    if (threadIdx.x == 0) tops[blockIdx.x] = tot;
+    for (int k = 1; k < PM_IT; ++k) last = max(last, v[k]);
+    const int wfirst = __shfl(first, 0, 64);
+    const bool flat = __all(first == wfirst && last == wfirst && i0 + PM_IT <= n);
+    if (flat) {
+        if (lane == 0) __hip_atomic_fetch_add(&pc[wfirst > 0 ? bin_of(geo, wfirst) : 0], 64u * PM_IT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < PM_IT; ++k) {
+        run = max(run, v[k]);
+        if (i0 + k < n) {
+            out[i0 + k] = run;
+            if (!flat) __hip_atomic_fetch_add(&pc[run > 0 ? bin_of(geo, run) : 0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i0 + k == n - 1) st->max_end = max(run, 0);
+        }
+    }
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s_ni[w]; if (t) atomicAdd(&st->n_indel, t); }
 }
-// the block sums (at most a few hundred), one block; the grand total goes to *total
-__global__ __launch_bounds__(1024) void k_scan4_tops(int4 *tops, int nb, int4 *total) {
-    __shared__ int4 wtot[16];
-    __shared__ int4 carry_s;
-    if (threadIdx.x == 0) carry_s = make_int4(0, 0, 0, 0);
+
+// ---- the bins' prefix sums, one pass.  Four counters per bin -> tab[b] (see BinGeo); sc / ec / pc are zeroed on the way (the next
+// load starts from clean counters; cnt counts down to zero in k_prep<true>), the totals go to tab[nb] and the LoadStats.
+constexpr int BS_IT = 4, BS_BLK = 1024 * BS_IT;
+__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t *cnt, uint32_t *sc, uint32_t *pc, uint32_t *ec, int nb, int4 *tab, LoadStats *st,
+                                                   int32_t *ticket, unsigned long long *state_a, unsigned long long *state_b) {
+    __shared__ int s_b;
+    __shared__ uint4 wtot[16];
+    __shared__ unsigned long long s_ea, s_eb;
+    __shared__ int s_cov[16];
+    if (threadIdx.x == 0) s_b = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int b = s_b, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = b * BS_BLK + (int)threadIdx.x * BS_IT;
+    uint4 v[BS_IT], sum = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < BS_IT; ++k) {
+        v[k] = make_uint4(0, 0, 0, 0);
+        if (i0 + k < nb) { v[k] = make_uint4(cnt[i0 + k], sc[i0 + k], pc[i0 + k], ec[i0 + k]); sc[i0 + k] = 0; pc[i0 + k] = 0; ec[i0 + k] = 0; }
+        sum.x += v[k].x; sum.y += v[k].y; sum.z += v[k].z; sum.w += v[k].w;
+    }
+    uint4 incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint4 t;
+        t.x = __shfl_up(incl.x, off, 64); t.y = __shfl_up(incl.y, off, 64); t.z = __shfl_up(incl.z, off, 64); t.w = __shfl_up(incl.w, off, 64);
+        if (lane >= off) { incl.x += t.x; incl.y += t.y; incl.z += t.z; incl.w += t.w; }
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint4 wb = make_uint4(0, 0, 0, 0), tot = wb;
+    for (int w = 0; w < 16; ++w) { const uint4 t = wtot[w]; if (w < wave) { wb.x += t.x; wb.y += t.y; wb.z += t.z; wb.w += t.w; } tot.x += t.x; tot.y += t.y; tot.z += t.z; tot.w += t.w; }
+    // two look-back chains of two 31-bit sums each (records | starts, prefix-max histogram | ends): waves 0 and 1
+    if (wave == 0) { const unsigned long long e = lb_lookback_op<false>(state_a, b, ((unsigned long long)tot.x << 31) | tot.y); if (lane == 0) s_ea = e; }
+    if (wave == 1) { const unsigned long long e = lb_lookback_op<false>(state_b, b, ((unsigned long long)tot.z << 31) | tot.w); if (lane == 0) s_eb = e; }
+    __syncthreads();
+    const unsigned long long ea = s_ea, eb = s_eb;
+    uint4 run;
+    run.x = (uint32_t)(ea >> 31) + wb.x + incl.x - sum.x; run.y = (uint32_t)(ea & 0x7fffffffu) + wb.y + incl.y - sum.y;
+    run.z = (uint32_t)(eb >> 31) + wb.z + incl.z - sum.z; run.w = (uint32_t)(eb & 0x7fffffffu) + wb.w + incl.w - sum.w;
+    int cov = 0;
+#pragma unroll
+    for (int k = 0; k < BS_IT; ++k) {
+        if (i0 + k < nb) {
+            tab[i0 + k] = make_int4((int)run.x, (int)run.y, (int)run.z, (int)run.w);
+            cov = max(cov, (int)(run.y + v[k].y) - (int)run.w);                // reads started up to the end of the bin - reads ended before its start
+        }
+        run.x += v[k].x; run.y += v[k].y; run.z += v[k].z; run.w += v[k].w;
+        if (i0 + k == nb - 1) {
+            tab[nb] = make_int4((int)run.x, (int)run.y, (int)run.z, (int)run.w);
+            st->n_rec = run.x >= 0x7fffffffu ? -1 : (int32_t)run.x;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cov = max(cov, __shfl_xor(cov, off, 64));
+    if (lane == 0) s_cov[wave] = cov;
+    __syncthreads();
+    if (threadIdx.x == 0) { int m = 0; for (int w = 0; w < 16; ++w) m = max(m, s_cov[w]); if (m > 0) atomicMax(&st->max_cover, m); }
+}
+
+// ---- LEGACY tables: per-read normalised CIGARs and aligned segments in read order, for token_at (pileup_kernels.hpp) — the ordered
+// haplotype recompute of flagged columns in the 30-channel mode.  Built on demand (c3r_lib.hip, ensure_legacy_tables), one lane per read.
+//   k_legacy_count: int2 {normalised ops, segments} per read (+ a zero entry at n_reads for the exclusive scan)
+__global__ __launch_bounds__(256) void k_legacy_count(const DevRead *reads, int n_reads, const uint32_t *cigars, int2 *cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_reads) return;
+    int2 c = make_int2(0, 0);
+    if (i < n_reads) {
+        const DevRead r = reads[i];
+        SegWalk w;
+        w.begin(r.pos);
+        auto seg = [&](uint32_t, uint32_t, long long, uint32_t, long long, bool, bool) { c.y += 1; };
+        (void)walk_norm(cigars + r.cig_off, r.n_cig, [&](uint32_t op, uint32_t len) { c.x += 1; w.op(op, len, seg); });
+        w.close(seg);
+    }
+    cnt[i] = c;
+}
+// single-block exclusive scan of the int2 counts in place (a few ten thousand reads; the legacy path is not on the hot path); totals to *total
+__global__ __launch_bounds__(1024) void k_legacy_scan(int2 *data, int n, int2 *total) {
+    __shared__ int2 wtot[16];
+    __shared__ int2 carry_s;
+    if (threadIdx.x == 0) carry_s = make_int2(0, 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < nb; base += 1024) {
+    for (int base = 0; base < n; base += 1024) {
         const int i = base + (int)threadIdx.x;
-        const int4 v = i < nb ? tops[i] : make_int4(0, 0, 0, 0);
-        const int4 incl = wave_incl_scan4(v);
+        const int2 v = i < n ? data[i] : make_int2(0, 0);
+        int2 incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int tx = __shfl_up(incl.x, off, 64), ty = __shfl_up(incl.y, off, 64);
+            if (lane >= off) { incl.x += tx; incl.y += ty; }
+        }
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
-        int4 wb = make_int4(0, 0, 0, 0), tot = wb;
-        for (int w = 0; w < 16; ++w) { const int4 t = wtot[w]; if (w < wave) wb = add4(wb, t); tot = add4(tot, t); }
-        const int4 c = carry_s;
-        if (i < nb) tops[i] = make_int4(c.x + wb.x + incl.x - v.x, c.y + wb.y + incl.y - v.y, c.z + wb.z + incl.z - v.z, c.w + wb.w + incl.w - v.w);
+        int2 wb = make_int2(0, 0), tot = wb;
+        for (int w = 0; w < 16; ++w) { const int2 t = wtot[w]; if (w < wave) { wb.x += t.x; wb.y += t.y; } tot.x += t.x; tot.y += t.y; }
+        const int2 c = carry_s;
+        if (i < n) data[i] = make_int2(c.x + wb.x + incl.x - v.x, c.y + wb.y + incl.y - v.y);
         __syncthreads();
-        if (threadIdx.x == 0) carry_s = add4(c, tot);
+        if (threadIdx.x == 0) carry_s = make_int2(c.x + tot.x, c.y + tot.y);
         __syncthreads();
     }
     if (threadIdx.x == 0) *total = carry_s;
 }
-__global__ __launch_bounds__(1024) void k_scan4_add(int4 *data, int n, const int4 *tops) {
-    const int4 off = tops[blockIdx.x];
-    const int i0 = blockIdx.x * S4_BLK + threadIdx.x * S4_IT;
-#pragma unroll
-    for (int k = 0; k < S4_IT; ++k) if (i0 + k < n) data[i0 + k] = add4(data[i0 + k], off);
-}
-
-// ---- filters: which reads does mpileup see (flag_fails, --min-MQ, non-empty reference span)
-// pass[i] = 1 / 0 (then scanned in place: rank among the passing reads); ekey[i] = the read's end, or ~0 for a read that fails
-__global__ __launch_bounds__(256) void k_reads_pass(const c3r_read_t *reads, const int32_t *rend, int n_reads, int min_mq, int excl_flags,
-                                                    int32_t *pass, uint32_t *ekey) {
+// off[i] = exclusive prefix {normalised ops, segments} of read i
+__global__ __launch_bounds__(256) void k_legacy_write(const DevRead *reads, int n_reads, const uint32_t *cigars, const int2 *off, uint32_t *ncig, DevSeg *rsegs,
+                                                      uint32_t *rseg_first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_reads) return;
-    if (i == n_reads) { pass[i] = 0; return; }
-    const c3r_read_t r = reads[i];
-    const bool ok = !flag_fails(r.flag, excl_flags) && r.mapq >= min_mq && rend[i] > r.pos;
-    pass[i] = ok ? 1 : 0;
-    ekey[i] = ok ? (uint32_t)rend[i] : 0xffffffffu;
-}
-// Coverage is deepest at some read's start p: (#passing reads with pos <= p) - (#passing reads with end <= p).  rank[] = exclusive
-// scan of the pass flags (rank[n_reads] = their number), ends_sorted = the keys above in ascending order.
-__global__ __launch_bounds__(256) void k_cover_max(const c3r_read_t *reads, int n_reads, const int32_t *rank, const uint32_t *ends_sorted,
-                                                   LoadStats *st) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int cover = 0;
-    if (i < n_reads && rank[i + 1] > rank[i]) {
-        const int p = reads[i].pos;
-        int lo = i + 1, hi = n_reads;                 // first read that starts after p
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (reads[mid].pos > p) hi = mid; else lo = mid + 1; }
-        const int started = rank[lo];
-        const int n_pass = rank[n_reads];
-        int a = 0, b = n_pass;                        // passing reads whose end is <= p
-        while (a < b) { const int mid = (a + b) >> 1; if (ends_sorted[mid] <= (uint32_t)p) a = mid + 1; else b = mid; }
-        cover = started - a;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cover = max(cover, __shfl_xor(cover, off, 64));
-    if ((threadIdx.x & 63) == 0 && cover > 0) atomicMax(&st->max_cover, cover);
-}
-
-// ---- second pass over the raw CIGARs: everything the counts were for
-// off[i] = exclusive prefix {normalised ops, segments, indel ops, op records} of read i.
-__global__ __launch_bounds__(256) void k_reads_write(const c3r_read_t *reads, int n_reads, const uint32_t *cigars, const int4 *off, const int32_t *rend,
-                                                     uint32_t *ncig, DevRead *out, DevSeg *rsegs, uint32_t *rseg_first, uint32_t *skey, uint32_t *sval) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n_reads) return;
-    const int4 o = off[i];
+    const int2 o = off[i];
     rseg_first[i] = (uint32_t)o.y;
     if (i == n_reads) return;
-    const c3r_read_t r = reads[i];
-    DevRead d;
-    d.pos = r.pos; d.end = rend[i]; d.cig_off = (uint32_t)o.x; d.n_cig = (uint32_t)(off[i + 1].x - o.x); d.seq_off = r.seq_off;
-    d.flag = r.flag; d.mapq = r.mapq; d.hp = r.hp; d.l_seq = r.l_seq;
-    out[i] = d;
+    const DevRead r = reads[i];
     uint32_t kout = (uint32_t)o.x, sout = (uint32_t)o.y;
     SegWalk w;
     w.begin(r.pos);
-    auto seg = [&](uint32_t k0, uint32_t nk, long long x0, uint32_t q0, long long x1, bool lead_n, bool lead_indel, int) {
+    auto seg = [&](uint32_t k0, uint32_t nk, long long x0, uint32_t q0, long long x1, bool lead_n, bool lead_indel) {
         DevSeg g;
         g.pos = (int32_t)x0;
         g.ext_start = g.pos - (lead_indel ? 1 : 0);
@@ -279,92 +537,13 @@ __global__ __launch_bounds__(256) void k_reads_write(const c3r_read_t *reads, in
         g.end = (int32_t)e;
         g.cig_off = (uint32_t)o.x + k0; g.qstart = q0; g.l_seq = r.l_seq; g.seq_off = r.seq_off; g.read_idx = (uint32_t)i;
         g.n_cig = (uint16_t)nk; g.flag = r.flag; g.mapq = r.mapq; g.hp = r.hp; g.lead_n = lead_n ? 1 : 0; g.pad = 0;
-        rsegs[sout] = g;
-        skey[sout] = (uint32_t)g.ext_start ^ 0x80000000u;
-        sval[sout] = sout;
-        ++sout;
+        rsegs[sout++] = g;
     };
-    (void)walk_norm(cigars + r.cigar_off, r.n_cigar, [&](uint32_t op, uint32_t len) {
+    (void)walk_norm(cigars + r.cig_off, r.n_cig, [&](uint32_t op, uint32_t len) {
         ncig[kout++] = (len << 4) | op;
         w.op(op, len, seg);
     });
     w.close(seg);
-}
-
-// segments into sorted order + the key of their prefix maximum
-__global__ __launch_bounds__(256) void k_seg_gather(const DevSeg *rsegs, const uint32_t *perm, int n_segs, DevSeg *segs) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_segs) return;
-    // 48-byte records as three 16-byte pieces
-    const int4 *s = reinterpret_cast<const int4 *>(rsegs + perm[k]);
-    int4 *d = reinterpret_cast<int4 *>(segs + k);
-    const int4 a = s[0], b = s[1], c = s[2];
-    d[0] = a; d[1] = b; d[2] = c;
-}
-
-// ---- inclusive prefix maximum of the ends of the items that pass the filters (INT_MIN before the first), three launches
-//   WHAT = 0: DevRead (flag, mapq, end > pos)    WHAT = 1: DevSeg (flag, mapq)
-constexpr int PM_IT = 8, PM_BLK = 1024 * PM_IT;
-template <int WHAT>
-__device__ __forceinline__ int pm_value(const void *items, int i, int min_mq, int excl) {
-    if (WHAT == 0) { const DevRead r = static_cast<const DevRead *>(items)[i]; return read_passes(r, min_mq, excl) ? r.end : INT32_MIN; }
-    const DevSeg *g = static_cast<const DevSeg *>(items) + i;
-    return (!flag_fails(g->flag, excl) && g->mapq >= min_mq) ? g->end : INT32_MIN;
-}
-__device__ __forceinline__ int wave_incl_max(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off, 64); if (lane >= off) v = max(v, t); }
-    return v;
-}
-template <int WHAT>
-__global__ __launch_bounds__(1024) void k_prefmax_local(const void *items, int n, int min_mq, int excl, int32_t *out, int32_t *tops) {
-    __shared__ int wtot[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = blockIdx.x * PM_BLK + threadIdx.x * PM_IT;
-    int v[PM_IT], m = INT32_MIN;
-#pragma unroll
-    for (int k = 0; k < PM_IT; ++k) { v[k] = (i0 + k < n) ? pm_value<WHAT>(items, i0 + k, min_mq, excl) : INT32_MIN; m = max(m, v[k]); }
-    const int incl = wave_incl_max(m);
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
-    int before = INT32_MIN, tot = INT32_MIN;
-    for (int w = 0; w < 16; ++w) { const int t = wtot[w]; if (w < wave) before = max(before, t); tot = max(tot, t); }
-    int run = max(before, __shfl_up(incl, 1, 64));
-    if (lane == 0) run = before;
-#pragma unroll
-    for (int k = 0; k < PM_IT; ++k) { run = max(run, v[k]); if (i0 + k < n) out[i0 + k] = run; }
-    if (threadIdx.x == 0) tops[blockIdx.x] = tot;
-}
-// tops[b] <- maximum of the blocks before b (one block; at most a few hundred entries)
-__global__ __launch_bounds__(1024) void k_prefmax_tops(int32_t *tops, int nb) {
-    __shared__ int wtot[16];
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = INT32_MIN;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < nb; base += 1024) {
-        const int i = base + (int)threadIdx.x;
-        const int v = i < nb ? tops[i] : INT32_MIN;
-        const int incl = wave_incl_max(v);
-        if (lane == 63) wtot[wave] = incl;
-        __syncthreads();
-        int before = INT32_MIN, tot = INT32_MIN;
-        for (int w = 0; w < 16; ++w) { const int t = wtot[w]; if (w < wave) before = max(before, t); tot = max(tot, t); }
-        int excl = max(before, __shfl_up(incl, 1, 64));
-        if (lane == 0) excl = before;
-        const int c = carry_s;
-        if (i < nb) tops[i] = max(c, excl);
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = max(c, tot);
-        __syncthreads();
-    }
-}
-__global__ __launch_bounds__(1024) void k_prefmax_add(int32_t *out, int n, const int32_t *tops) {
-    const int off = tops[blockIdx.x];
-    const int i0 = blockIdx.x * PM_BLK + threadIdx.x * PM_IT;
-#pragma unroll
-    for (int k = 0; k < PM_IT; ++k) if (i0 + k < n) out[i0 + k] = max(out[i0 + k], off);
 }
 
 }  // namespace c3r
