@@ -485,7 +485,7 @@ def main():
         # is everything that is not the network: read preparation (upload excluded: copies are not kernels), op table, scan, windows.
         net_ms = sum(v["total_ms"] for k, v in kernels.items() if k in NET_KERNELS)
         k1_ms = sum(v["total_ms"] for k, v in kernels.items()) - net_ms
-        prep = ("k_reads_prep", "k_sort", "k_prefmax", "k_ops_table")
+        prep = ("k_prep_count", "k_prefmax_bins", "k_bin_scan", "k_prep_write", "k_legacy_tables")
         prep_ms = sum(v["total_ms"] for k, v in kernels.items() if k in prep)
         k1_bytes = k1_algorithmic_bytes(rs, eng.sites()["pos"], 18) if n_prof else 0.0
         tb_gbps = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms else 0.0

@@ -55,7 +55,7 @@ struct c3r_ctx {
     int64_t n_seq_bytes = 0, n_cigar_ops = 0;
     DevBuf d_rawreads, d_rawcig;           // the caller's records as they arrived (c3r_read_t, BAM-encoded ops)
     // the pile table (reads_kernels.hpp): bin counters {cnt | sc | ec | pc}, their prefix sums, the records, per-read notes of k_prep
-    DevBuf d_bincnt, d_tab, d_recs, d_serial, d_nind, d_lbk, d_stats;
+    DevBuf d_bincnt, d_tab, d_recs, d_rbase, d_serial, d_nind, d_lbk, d_stats;
     BinGeo bins{0, 0};
     int32_t first_pos = 0;                 // pos of the first read (the bins start there)
     int64_t last_pos = 0;                  // pos of the last read (first guess of where the bins end)
@@ -115,6 +115,11 @@ struct c3r_ctx {
     int32_t n_regions = 0;
     DevBuf d_cols, d_depth, d_ncov, d_flags, d_skipmax, d_ev, d_small /* cursor,last_row,totals */, d_blockcnt, d_scan_tops;
     int64_t n_cand = 0, n_tok = 0;        // totals resident on the device (all scans of the current batch)
+    // rows of d_tensors / slots of d_tok taken by the batch so far: more than n_cand / n_tok when a large fused scan handed them out through
+    // several sub-allocators (pileup_kernels.hpp, ALLOC_SHARDS) — sites reach their window and tokens through win_idx / tok_off
+    int64_t n_rows = 0, n_tokspace = 0;
+    int32_t hint_rows = 4096, hint_toks = 131072;      // per-shard sizes the last sharded scan needed (+ 25 %)
+    int32_t last_shards = 1, last_shard_rows = 0;      // the most recent fused scan's row space (raw re-run of c3r_get_tensors)
     int64_t last_cand = 0, last_base = 0; // candidates of the most recent scan and their offset in the batch
     bool batching = false;
     DevBuf d_cand, d_tensors, d_raw, d_sites_out, d_tokcnt, d_tok;
@@ -348,13 +353,13 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
     if (hs.n_rec < 0) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
     const auto t_sync = std::chrono::steady_clock::now();
     // ---- second pass (nothing below waits for the device): every record into its bin
-    if ((rc = ensure(ctx, ctx->d_recs, (size_t)hs.n_rec * sizeof(PileRec) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_recs, (size_t)hs.n_rec * sizeof(PileRec) + 64)) || (rc = ensure(ctx, ctx->d_rbase, (size_t)hs.n_rec * sizeof(uint4) + 64))) return rc;
     {
         PrepArgs a;
         memset(&a, 0, sizeof a);
         a.n_reads = n; a.cigars = (const uint32_t *)ctx->d_rawcig.p; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.geo = ctx->bins;
         a.cnt = (uint32_t *)ctx->d_bincnt.p; a.tab = (const int4 *)ctx->d_tab.p; a.out = (DevRead *)ctx->d_reads.p; a.serial = (uint8_t *)ctx->d_serial.p;
-        a.recs = (PileRec *)ctx->d_recs.p;
+        a.recs = (PileRec *)ctx->d_recs.p; a.rbase = (uint4 *)ctx->d_rbase.p; a.seq = (const uint8_t *)ctx->d_seq.p;
         Launch L(ctx, "k_prep_write");
         hipLaunchKernelGGL(k_prep<true>, dim3((unsigned)((n + 256 / PREP_GRP - 1) / (256 / PREP_GRP))), dim3(256), 0, ctx->stream, a);
     }
@@ -482,7 +487,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     const bool timing = getenv("C3R_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_tab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
+    DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_tab, &ctx->d_recs, &ctx->d_rbase, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
                       &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff};
@@ -771,7 +776,7 @@ static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int d
     memset(&a, 0, sizeof a);
     a.drop = d_drop; a.drop_words = drop_words;
     a.reads = (const DevRead *)ctx->d_reads.p; a.seq = (const uint8_t *)ctx->d_seq.p; a.n_reads = ctx->n_reads;
-    a.recs = (const PileRec *)ctx->d_recs.p; a.tab = (const int4 *)ctx->d_tab.p; a.bins = ctx->bins;
+    a.recs = (const PileRec *)ctx->d_recs.p; a.rbase = (const uint4 *)ctx->d_rbase.p; a.tab = (const int4 *)ctx->d_tab.p; a.bins = ctx->bins;
     a.n_tiles = n_tiles;
     a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->ref_len;
     a.geo = (const TileGeo *)ctx->d_geo.p;
@@ -839,10 +844,10 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
     const int n_tiles = (int)ctx->h_geo.size();
     ctx->n_pos = (int64_t)n_tiles * TILE;
     if (!columns_only) {
-        if (!ctx->batching) { ctx->n_cand = 0; ctx->n_tok = 0; }
+        if (!ctx->batching) { ctx->n_cand = 0; ctx->n_tok = 0; ctx->n_rows = 0; ctx->n_tokspace = 0; }
         ctx->last_cand = 0; ctx->last_base = ctx->n_cand; ctx->tokens_ready = false;
     }
-    const int64_t base_cand = ctx->n_cand, base_tok = ctx->n_tok;
+    const int64_t base_cand = ctx->n_cand, base_row = ctx->n_rows, base_tok = ctx->n_tokspace;
     const int64_t n_pos = ctx->n_pos;
     const int n_cblocks = (int)((n_pos + CMP_BLOCK - 1) / CMP_BLOCK);
     int rc;
@@ -954,7 +959,7 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
     if (n_cand == 0) return C3R_OK;
     const size_t tbytes = (size_t)C3R_WINDOW * C * 4;
     if ((rc = ensure(ctx, ctx->d_cand, (size_t)n_cand * 4))) return rc;
-    if ((rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_cand + n_cand) * tbytes, (size_t)base_cand * tbytes))) return rc;
+    if ((rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_row + n_cand) * tbytes, (size_t)base_row * tbytes))) return rc;
     if ((rc = ensure_keep(ctx, ctx->d_sites_out, (size_t)(base_cand + n_cand) * sizeof(c3r_site_t), (size_t)base_cand * sizeof(c3r_site_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_tokcnt, (size_t)(n_cand + 1) * 4))) return rc;
     if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_raw, (size_t)n_cand * tbytes))) return rc;
@@ -963,9 +968,9 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
         hipLaunchKernelGGL(k_compact_write, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
                            (const int32_t *)ctx->d_blockcnt.p, (int32_t *)ctx->d_cand.p, heavy, (int2 *)ctx->d_tile_cand.p);
     }
-    if ((rc = run_gather(ctx, 1, (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_cand * tbytes), true))) return rc;
+    if ((rc = run_gather(ctx, 1, (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_row * tbytes), true))) return rc;
     if ((rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + n_cand) * 4, (size_t)base_cand * 4))) return rc;
-    hipLaunchKernelGGL(k_iota, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, ctx->stream, (int32_t *)ctx->d_winidx.p + base_cand, (int)n_cand, (int)base_cand);      // (windows in site order)
+    hipLaunchKernelGGL(k_iota, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, ctx->stream, (int32_t *)ctx->d_winidx.p + base_cand, (int)n_cand, (int)base_row);      // (windows in site order)
     {
         if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_tokcnt.p, (int)n_cand, (int32_t *)((char *)ctx->d_small.p + 16)))) return rc;
     }
@@ -985,7 +990,8 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
     }
     ctx->tokens_ready = true;
     ctx->n_cand = base_cand + n_cand;
-    ctx->n_tok = base_tok + n_tok;
+    ctx->n_tok += n_tok;
+    ctx->n_rows = base_row + n_cand; ctx->n_tokspace = base_tok + n_tok;
     HIPCHK(ctx, hipGetLastError());
     return C3R_OK;
 }
@@ -1024,25 +1030,26 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     const int n_tiles = (int)ctx->h_geo.size();
     ctx->n_pos = (int64_t)n_tiles * TILE;
     if (!raw_rerun) {
-        if (!ctx->batching) { ctx->n_cand = 0; ctx->n_tok = 0; }
+        if (!ctx->batching) { ctx->n_cand = 0; ctx->n_tok = 0; ctx->n_rows = 0; ctx->n_tokspace = 0; }
         ctx->last_cand = 0; ctx->last_base = ctx->n_cand; ctx->tokens_ready = false;
     }
-    const int64_t base_cand = raw_rerun ? 0 : ctx->n_cand, base_tok = raw_rerun ? 0 : ctx->n_tok;
+    const int64_t base_cand = raw_rerun ? 0 : ctx->n_cand, base_row = raw_rerun ? 0 : ctx->n_rows, base_tok = raw_rerun ? 0 : ctx->n_tokspace;
     if (ctx->n_reads == 0 || n_tiles == 0) return C3R_OK;
     const size_t ev_cap = event_capacity(ctx, n_regions, ctg_starts, ctg_ends, n_tiles, 2);
     const int nblk = (n_tiles + 255) / 256;
     // d_lb: [0] ticket of k_tile_ranges_fused, [4] ticket of k_fused_tiles, [8] candidates, [12] tokens (k_order_spans), [16] overflow
     // bits, [20] listed spans, [24..31] event-scratch cursor, [32] event-scratch overflow, [36] rows handed out, [40] ticket of
-    // k_order_spans, [44] token slots handed out, [64..] the TICKET_Q ticket words of k_fused_tiles, 256 bytes apart; then look-back words:
-    // one per block of 256 spans for k_tile_ranges_fused, then the same for k_order_spans
-    const size_t lb_head = 64 + (size_t)TICKET_Q * TICKET_STRIDE * 4;
+    // k_order_spans, [64..] the TICKET_Q ticket words of k_fused_tiles, 256 bytes apart, then the ALLOC_SHARDS allocator words (tokens << 32 |
+    // rows), 256 bytes apart; then look-back words: one per block of 256 spans for k_tile_ranges_fused, then the same for k_order_spans
+    const size_t lb_alloc = 64 + (size_t)TICKET_Q * TICKET_STRIDE * 4;
+    const size_t lb_head = lb_alloc + (size_t)ALLOC_SHARDS * ALLOC_STRIDE * 8;
     const size_t lb_bytes = lb_head + (size_t)nblk * 16;
     if ((rc = ensure(ctx, ctx->d_ev, ev_cap * sizeof(EvRec))) || (rc = ensure(ctx, ctx->d_lb, lb_bytes)) || (rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16)) ||
         (rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16)) ||
         (rc = ensure(ctx, ctx->d_span, (size_t)n_tiles * sizeof(int4) + 16)) || (rc = ensure(ctx, ctx->d_spanbase, (size_t)n_tiles * 4 + 16)) ||
         (rc = ensure(ctx, ctx->d_spanrec, (size_t)n_tiles * sizeof(SpanRec) + 16)))
         return rc;
-    if (!ctx->h_scan) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_scan, 64, hipHostMallocDefault));
+    if (!ctx->h_scan) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_scan, 64 + (size_t)ALLOC_SHARDS * ALLOC_STRIDE * 8, hipHostMallocDefault));
     const uint32_t *d_drop = nullptr;
     int drop_words = 0;
     if ((rc = depth_cap_mask(ctx, n_regions, ctg_starts, ctg_ends, &d_drop, &drop_words))) return rc;
@@ -1059,49 +1066,54 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         a.dbg = (unsigned long long *)ctx->d_dbg.p;
     }
     f.span_rec = (const SpanRec *)ctx->d_spanrec.p;
-    f.ticket = (int32_t *)(lb + 64); f.arrived = (int32_t *)(lb + 36); f.overflow = (int32_t *)(lb + 16);
+    f.ticket = (int32_t *)(lb + 64); f.alloc = (unsigned long long *)(lb + lb_alloc); f.overflow = (int32_t *)(lb + 16);
     f.rescale = raw_rerun ? 0 : 1; f.max_depth = ctx->prm.max_depth_rescale;
     f.span_info = (int4 *)ctx->d_span.p;
     if (C == C3R_CH_PHASED && (rc = ensure_legacy_tables(ctx))) return rc;
     f.ph.reads = a.reads; f.ph.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.ph.rseg_first = (const uint32_t *)ctx->d_rseg_first.p; f.ph.cigar = (const uint32_t *)ctx->d_cigar.p; f.ph.seq = a.seq;
     f.ph.min_mq = a.min_mq; f.ph.excl_flags = a.excl_flags; f.ph.drop = a.drop; f.ph.drop_words = a.drop_words;
     const size_t tbytes = (size_t)C3R_WINDOW * C * 4;
-    // what this scan may write: candidates / tokens the buffers can take beyond what the batch already holds
-    int64_t want_c, want_t;
-    if (raw_rerun) { want_c = ctx->last_cand; want_t = 0; }
-    else {
-        want_c = std::min<int64_t>({(int64_t)(ctx->d_tensors.cap / tbytes) - base_cand, (int64_t)(ctx->d_sites_out.cap / sizeof(c3r_site_t)) - base_cand,
+    // What this scan may write.  A small scan has one allocator and dense output: whatever the buffers can take beyond what the batch
+    // already holds.  A large one hands rows and token slots out through ALLOC_SHARDS sub-allocators of equal size, sized from what the
+    // previous large scan needed; when a shard runs over, the scan is repeated with what the counters say it needs.
+    const int nsh = raw_rerun ? ctx->last_shards : ((n_tiles >= 4096 && !getenv("C3R_ONE_SHARD")) ? ALLOC_SHARDS : 1);
+    int64_t want_c, want_t;            // per shard
+    if (raw_rerun) { want_c = ctx->last_shard_rows; want_t = 0; }
+    else if (nsh == 1) {
+        want_c = std::min<int64_t>({(int64_t)(ctx->d_tensors.cap / tbytes) - base_row, (int64_t)(ctx->d_sites_out.cap / sizeof(c3r_site_t)) - base_cand,
                                     (int64_t)(ctx->d_winidx.cap / 4) - base_cand, (int64_t)(ctx->d_cand.cap / 4), (int64_t)(ctx->d_meta.cap / sizeof(CandMeta))});
         want_t = (int64_t)(ctx->d_tok.cap / sizeof(c3r_token_t)) - base_tok;
         if (want_c < 1024) want_c = 65536;
         if (want_t < 1024) want_t = 32 * want_c;
-    }
+    } else { want_c = ctx->hint_rows; want_t = ctx->hint_toks; }
     int32_t n_cand = 0, n_tok = 0;
     for (int attempt = 0;; ++attempt) {
         FinalizeArgs z;
         memset(&z, 0, sizeof z);
-        if ((rc = ensure(ctx, ctx->d_meta, std::max<size_t>((size_t)want_c * sizeof(CandMeta), 16)))) return rc;
+        want_c = std::min<int64_t>(want_c, INT32_MAX / nsh); want_t = std::min<int64_t>(want_t, (INT32_MAX - base_tok) / nsh);
+        const int64_t rows = want_c * nsh, toks = want_t * nsh;
+        if ((rc = ensure(ctx, ctx->d_meta, std::max<size_t>((size_t)rows * sizeof(CandMeta), 16)))) return rc;
         if (raw_rerun) {
-            if ((rc = ensure(ctx, ctx->d_raw, std::max<size_t>((size_t)want_c * tbytes, 16))) || (rc = ensure(ctx, ctx->d_rawidx, std::max<size_t>((size_t)want_c * 4, 16)))) return rc;
+            if ((rc = ensure(ctx, ctx->d_raw, std::max<size_t>((size_t)rows * tbytes, 16))) || (rc = ensure(ctx, ctx->d_rawidx, std::max<size_t>((size_t)rows * 4, 16)))) return rc;
             f.tensors = (int32_t *)ctx->d_raw.p;
             z.win_idx = (int32_t *)ctx->d_rawidx.p; z.row_base = 0;
         } else {
-            if ((rc = ensure(ctx, ctx->d_cand, (size_t)want_c * 4)) ||
-                (rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_cand + want_c) * tbytes, (size_t)base_cand * tbytes)) ||
-                (rc = ensure_keep(ctx, ctx->d_sites_out, (size_t)(base_cand + want_c) * sizeof(c3r_site_t), (size_t)base_cand * sizeof(c3r_site_t))) ||
-                (rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + want_c) * 4, (size_t)base_cand * 4)) ||
-                (rc = ensure_keep(ctx, ctx->d_tok, (size_t)(base_tok + want_t) * sizeof(c3r_token_t), (size_t)base_tok * sizeof(c3r_token_t))))
+            if ((rc = ensure(ctx, ctx->d_cand, (size_t)rows * 4)) ||
+                (rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_row + rows) * tbytes, (size_t)base_row * tbytes)) ||
+                (rc = ensure_keep(ctx, ctx->d_sites_out, (size_t)(base_cand + rows) * sizeof(c3r_site_t), (size_t)base_cand * sizeof(c3r_site_t))) ||
+                (rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + rows) * 4, (size_t)base_cand * 4)) ||
+                (rc = ensure_keep(ctx, ctx->d_tok, (size_t)(base_tok + toks) * sizeof(c3r_token_t), (size_t)base_tok * sizeof(c3r_token_t))))
                 return rc;
-            f.tensors = (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_cand * tbytes);
+            f.tensors = (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_row * tbytes);
             z.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
             z.cand_idx = (int32_t *)ctx->d_cand.p;
-            z.win_idx = (int32_t *)ctx->d_winidx.p + base_cand; z.row_base = (int32_t)base_cand; z.tok_base = (int32_t)base_tok;
-            f.tok = (c3r_token_t *)ctx->d_tok.p; f.tok_base = (int32_t)base_tok; f.tok_cap = (int32_t)std::min<int64_t>(want_t, INT32_MAX - base_tok);
-            f.tok_arrived = (int32_t *)(lb + 44);
+            z.win_idx = (int32_t *)ctx->d_winidx.p + base_cand; z.row_base = (int32_t)base_row; z.tok_base = (int32_t)base_tok;
+            f.tok = (c3r_token_t *)ctx->d_tok.p; f.tok_base = (int32_t)base_tok; f.tok_cap = (int32_t)toks;
         }
         f.meta = (CandMeta *)ctx->d_meta.p;
-        f.cand_cap = (int32_t)std::min<int64_t>(want_c, INT32_MAX);
-        z.meta = f.meta; z.span_info = f.span_info; z.span_base = (const int32_t *)ctx->d_spanbase.p; z.arrived = f.arrived; z.overflow = f.overflow; z.cand_cap = f.cand_cap;
+        f.n_shards = nsh; f.shard_rows = (int32_t)want_c; f.shard_toks = (int32_t)want_t;
+        f.cand_cap = (int32_t)rows;
+        z.meta = f.meta; z.span_info = f.span_info; z.span_base = (const int32_t *)ctx->d_spanbase.p; z.alloc = f.alloc; z.n_shards = nsh; z.shard_rows = f.shard_rows; z.overflow = f.overflow;
         z.geo = a.geo; z.ref = a.ref; z.ref_beg0 = a.ref_beg0; z.ref_len = a.ref_len;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_lb.p, 0, lb_bytes, ctx->stream));
         {
@@ -1119,18 +1131,24 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             Launch L(ctx, "k_order_sites");
             hipLaunchKernelGGL(k_order_spans, dim3(nblk), dim3(256), 0, ctx->stream, (const int4 *)ctx->d_span.p, (const int32_t *)(lb + 20), (int32_t *)(lb + 40),
                                (unsigned long long *)(lb + lb_head + (size_t)nblk * 8), (int32_t *)ctx->d_spanbase.p, (int32_t *)(lb + 8));
-            hipLaunchKernelGGL(k_finalize_sites, dim3((unsigned)std::min<int64_t>((want_c + 3) / 4 + 1, 8192)), dim3(256), 0, ctx->stream, z);
+            hipLaunchKernelGGL(k_finalize_sites, dim3((unsigned)std::min<int64_t>((rows + 3) / 4 + 1, 8192)), dim3(256), 0, ctx->stream, z);
         }
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan, lb + 8, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan + 16, lb + lb_alloc, (size_t)ALLOC_SHARDS * ALLOC_STRIDE * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         n_cand = ctx->h_scan[0]; n_tok = ctx->h_scan[1];
+        int64_t need_c = 0, need_t = 0;          // the fullest shard
+        for (int sh = 0; sh < nsh; ++sh) {
+            const unsigned long long v = ((const unsigned long long *)(ctx->h_scan + 16))[(size_t)sh * ALLOC_STRIDE];
+            need_c = std::max<int64_t>(need_c, (int64_t)(uint32_t)v); need_t = std::max<int64_t>(need_t, (int64_t)(v >> 32));
+        }
         if (a.dbg) {
             unsigned long long d[16];
             HIPCHK(ctx, hipMemcpy(d, ctx->d_dbg.p, sizeof d, hipMemcpyDeviceToHost));
             const double nt = d[15] ? (double)d[15] : 1.0;
-            fprintf(stderr, "[k_fused_tiles] %llu spans; per span: segments in range %.1f, listed %.1f, ops %.1f; us per span: zero %.2f | cover+list+walk %.2f | scans %.2f | events %.2f | gates %.2f | first-seen %.2f | select+order+store %.2f\n",
-                    d[15], d[13] / nt, d[12] / nt, d[14] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[6] / nt / 100, d[7] / nt / 100);
+            fprintf(stderr, "[k_fused_tiles] %llu spans; per span: reads in range %.1f, records in range %.1f, indel events %.1f; us per span: zero %.2f | cover+walk %.2f | scans %.2f | events %.2f | gates %.2f | first-seen %.2f | select+store %.2f | tokens %.2f\n",
+                    d[15], d[13] / nt, d[14] / nt, d[12] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[6] / nt / 100, d[7] / nt / 100, d[8] / nt / 100);
         }
         if (ctx->h_scan[6]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
         if (n_cand < 0 || n_tok < 0) return fail(ctx, C3R_EOVERFLOW, "too many candidates or tokens for one scan");
@@ -1138,22 +1156,28 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             if (n_cand != ctx->last_cand || (ctx->h_scan[2] & 1)) return fail(ctx, C3R_EINVAL, "internal: the raw re-run found %d candidates, the scan %lld", n_cand, (long long)ctx->last_cand);
             return C3R_OK;
         }
-        if (n_cand <= want_c && n_tok <= want_t && !(ctx->h_scan[2] & 1)) break;
+        if (need_c <= want_c && need_t <= want_t && !(ctx->h_scan[2] & 1)) {
+            if (nsh > 1) { ctx->hint_rows = (int32_t)std::min<int64_t>(need_c + need_c / 4 + 64, INT32_MAX / nsh); ctx->hint_toks = (int32_t)std::min<int64_t>(need_t + need_t / 4 + 2048, INT32_MAX / nsh); }
+            break;
+        }
         if (attempt >= 2) return fail(ctx, C3R_EOVERFLOW, "internal: output buffers still too small after growing (%d candidates, %d tokens)", n_cand, n_tok);
-        want_c = std::max<int64_t>(want_c, (int64_t)n_cand + n_cand / 4 + 1024);
-        want_t = std::max<int64_t>(want_t, (int64_t)n_tok + n_tok / 4 + 1024);
+        want_c = std::max<int64_t>(want_c, need_c + need_c / 4 + 1024);
+        want_t = std::max<int64_t>(want_t, need_t + need_t / 4 + 1024);
     }
-    ctx->last_cand = n_cand;
+    ctx->last_cand = n_cand; ctx->last_shards = nsh; ctx->last_shard_rows = (int32_t)want_c;
     if (n_candidates) *n_candidates = n_cand;
     ctx->tokens_ready = true;
     ctx->n_cand = base_cand + n_cand;
-    ctx->n_tok = base_tok + n_tok;
+    ctx->n_tok += n_tok;
+    // (one allocator: dense output, the next scan of the batch appends; several: the scan's whole row / token space is taken)
+    ctx->n_rows = base_row + (nsh == 1 ? (int64_t)n_cand : want_c * nsh);
+    ctx->n_tokspace = base_tok + (nsh == 1 ? (int64_t)n_tok : want_t * nsh);
     return C3R_OK;
 }
 
 int c3r_batch_begin(c3r_ctx *ctx) {
     if (!ctx) return C3R_EINVAL;
-    ctx->batching = true; ctx->n_cand = 0; ctx->n_tok = 0; ctx->last_cand = 0; ctx->last_base = 0;
+    ctx->batching = true; ctx->n_cand = 0; ctx->n_tok = 0; ctx->n_rows = 0; ctx->n_tokspace = 0; ctx->last_cand = 0; ctx->last_base = 0;
     return C3R_OK;
 }
 
@@ -1486,7 +1510,7 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     r->ctx = ctx; r->n = n; r->n_tok = ctx->n_tok;
     if (n == 0) { *out = r; return C3R_OK; }
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const int64_t n_tok = ctx->n_tok;
+    const int64_t n_tok = ctx->n_tokspace;           // (token bytes are addressed through the sites' tok_off: the whole slot space)
     const size_t b_sites = up((size_t)n * sizeof(c3r_site_t)), b_tokb = up((size_t)std::max<int64_t>(n_tok, 1)), b_probs = up((size_t)n * C3R_NPROB * sizeof(float)),
                  b_off = up((size_t)n * 4), b_reads = up((size_t)std::max(ctx->n_reads, 1) * sizeof(DevRead)), b_seq = up((size_t)ctx->n_seq_bytes + 16);
     const size_t need = b_sites + b_tokb + b_probs + b_off + b_reads + b_seq;

@@ -90,7 +90,10 @@ constexpr int OP_CHOP = 30;    // 30 bases + an odd start nibble fit the 32 nibb
 //   tab[b] = {first record of bin b, reads that start before bin b, reads whose prefix-max end lies before bin b, reads that end at or
 //             before the first position of bin b}
 // (k_bin_scan): two loads per span replace the four binary searches per tile of rounds 1-3.
-constexpr int BIN_SHIFT = 5;
+#ifndef C3R_BIN_SHIFT
+#define C3R_BIN_SHIFT 5
+#endif
+constexpr int BIN_SHIFT = C3R_BIN_SHIFT;
 struct BinGeo { int32_t base, nb; };
 __host__ __device__ __forceinline__ int bin_of(const BinGeo g, int p) {          // the bin that holds position p, clamped into the table
     const int b = (p >> BIN_SHIFT) - g.base;
@@ -130,6 +133,9 @@ struct ScanArgs {
     const uint8_t *seq;
     int32_t n_reads;
     const PileRec *recs;          // the pile table
+    const uint4 *rbase;           // [records] the 16 bytes of packed bases that hold a record's bases (M: its <= 30, I: its first <= 31), from the
+                                  // byte of its first base on — a table of its own, parallel to the records, so that a lane's two loads (record,
+                                  // bases) leave together instead of one after the other
     const int4 *tab;              // [geo.nb + 1] per-bin prefix sums (BinGeo)
     BinGeo bins;
     uint8_t *tile_cols;           // [n_tiles] 1 = this tile's columns were written (0: implicitly all-zero)
@@ -192,6 +198,20 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wave_tot /* LDS [WAVE
     __syncthreads();
     *total = tot;
     return base + incl - v;
+}
+
+// two ints per thread, ONE barrier: `slot` (LDS, 2 * WAVES ints) must belong to this call site alone — the trailing barrier of
+// block_excl_scan only protects a shared scratch word against the next scan
+__device__ __forceinline__ int2 block_excl_scan2(int v0, int v1, int *slot, int *total0, int *total1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = wave_incl_scan(v0), i1 = wave_incl_scan(v1);
+    if (lane == 63) { slot[wave] = i0; slot[WAVES + wave] = i1; }
+    __syncthreads();
+    int b0 = 0, b1 = 0, t0 = 0, t1 = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { const int x = slot[w], y = slot[WAVES + w]; if (w < wave) { b0 += x; b1 += y; } t0 += x; t1 += y; }
+    *total0 = t0; *total1 = t1;
+    return make_int2(b0 + i0 - v0, b1 + i1 - v1);
 }
 
 __device__ __forceinline__ bool read_dropped(const uint32_t *drop, int words, int region, int r) {
@@ -262,14 +282,14 @@ struct TileLds {
 };
 
 // Coverage of the tile from whole-read spans (incl. introns): header-only, one lane per read.
+__device__ __forceinline__ void cover_one(const ScanArgs &a, const TileLds &s, const DevRead &rd, int r, int t0, int t1, int region) {
+    if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.pos >= t1) return;
+    if (read_dropped(a.drop, a.drop_words, region, r)) return;
+    atomicAdd(&s.cov[max(rd.pos, t0) - t0], 1);
+    if (rd.end < t1) atomicAdd(&s.cov[rd.end - t0], -1);
+}
 __device__ __forceinline__ void cover_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, int region) {
-    for (int r = lo + (int)threadIdx.x; r < hi; r += SCAN_THREADS) {
-        const DevRead rd = a.reads[r];
-        if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.pos >= t1) continue;
-        if (read_dropped(a.drop, a.drop_words, region, r)) continue;
-        atomicAdd(&s.cov[max(rd.pos, t0) - t0], 1);
-        if (rd.end < t1) atomicAdd(&s.cov[rd.end - t0], -1);
-    }
+    for (int r = lo + (int)threadIdx.x; r < hi; r += SCAN_THREADS) cover_one(a, s, a.reads[r], r, t0, t1, region);
 }
 
 // ---- the tile's walk: one lane per record of the tile's range of the pile table.  A record is independent of every other one: two
@@ -296,7 +316,7 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
         const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
         if (b0 >= b1) return;
         const int off = b0 - rstart, nb = b1 - b0;
-        const int odd = (int)(((uint32_t)ra.z + (uint32_t)off) & 1u);          // the bases were loaded from nibble naddr + off on
+        const int odd = (int)((uint32_t)ra.z & 1u) + off;                      // (w0:w1 = the 16 bytes from the piece's first base on)
 #pragma unroll
         for (int u = 0; u < OP_CHOP; ++u) {
             if (u >= nb) continue;
@@ -379,42 +399,34 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
     }
 }
 
-// All records of [rlo, rhi), WALK_UNR per lane and round: their loads (record, then bases) are issued together.
+// All records of [rlo, rhi), WALK_UNR per lane and round: all their loads (records and bases) are issued together.
 constexpr int WALK_UNR = 2;
 template <int C, int MODE>
 __device__ __forceinline__ void walk_records(const ScanArgs &a, const TileLds &s, int rlo, int rhi, int t0, int t1, int region, EvRec *ev) {
     const int tid = (int)threadIdx.x;
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
         int4 ra[WALK_UNR], rb[WALK_UNR];
         bool have[WALK_UNR];
+        uint64_t w0[WALK_UNR], w1[WALK_UNR];
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u) {
             const int iu = base + u * SCAN_THREADS + tid;
             have[u] = iu < rhi;
-            const int4 *rec = reinterpret_cast<const int4 *>(a.recs + (have[u] ? iu : rhi - 1));      // (idle lanes re-read the last record)
+            const int at = have[u] ? iu : rhi - 1;           // (idle lanes re-read the last record)
+            const int4 *rec = reinterpret_cast<const int4 *>(a.recs + at);
             ra[u] = rec[0]; rb[u] = rec[1];
+            const uint4 bs = a.rbase[at];
+            w0[u] = (uint64_t)bs.x | ((uint64_t)bs.y << 32); w1[u] = (uint64_t)bs.z | ((uint64_t)bs.w << 32);
         }
-        uint64_t w0[WALK_UNR], w1[WALK_UNR];
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u) {
-            w0[u] = 0; w1[u] = 0;
             const uint32_t w = (uint32_t)ra[u].y;
-            const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
+            const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u);
             // does the record touch the tile at all?  (the range is a superset by up to a bin on either side)
             const bool body = op != C3R_CIG_I && ra[u].x < t1 && ra[u].x + len > t0;
             const bool anchored = op != C3R_CIG_M && ra[u].x - 1 >= t0 && ra[u].x - 1 < t1;
             if (!(body || anchored)) have[u] = false;
             if (have[u] && a.drop && read_dropped(a.drop, a.drop_words, region, rb[u].y)) have[u] = false;
-            int off = -1;                                    // first base to fetch, relative to the piece's first base
-            if (have[u] && op == C3R_CIG_M && MODE != SCATTER) off = max(ra[u].x, t0) - ra[u].x;
-            if (have[u] && op == C3R_CIG_I && MODE != FIRSTSEEN) off = 0;
-            if (off >= 0 && off < avail) {
-                const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)off;
-                u64x2 w;                                     // (the packed-base buffer is padded: the load may run past a read's last byte)
-                __builtin_memcpy(&w, a.seq + (na >> 1), 16);
-                w0[u] = w[0]; w1[u] = w[1];
-            }
         }
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u)
@@ -594,6 +606,8 @@ struct TileMem {
     uint8_t amb[TILE];
     uint8_t odd[TILE];
     int misc[8];           // [0] events captured by the first walk, [2..5] block-scan scratch
+    int scan_slot[2][2 * WAVES];                // block_excl_scan2: one slot per call site
+    unsigned long long rowmask[WAVES];          // k_fused_tiles: which positions hold a pileup row, one bit each
     unsigned long long evbase;
     EvRec ev[EV_LDS > 0 ? EV_LDS : 1];
     uint8_t evord[EV_LDS > 0 ? EV_LDS : 4];     // the captured events' indices, bucketed by position
@@ -617,29 +631,40 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     for (int i = tid; i < TILE * C; i += SCAN_THREADS) M.cnt[i] = 0;
     M.evfill[tid] = 0; M.maxdel[tid] = 0; M.amb[tid] = 0; M.odd[tid] = 0;
     if (tid == 0) M.misc[0] = 0;
+    // loads that nothing before the gates depends on leave now: this position's reference base, and the first round of read headers
+    // (their round trip runs beside the walk's record and base loads instead of before them)
+    const int p = t0 + tid;
+    const int rp = p - a.ref_beg0;
+    const uint8_t rb = (rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
+    const int r0 = lo + tid;
+    DevRead rd0;
+    rd0.pos = 0; rd0.end = 0; rd0.flag = 4;
+    if (r0 < hi && !(a.abl & 4)) rd0 = a.reads[r0];
     __syncthreads();
 
     C3R_PHASE(0);
-    if (!(a.abl & 4)) cover_reads(a, s, lo, hi, t0, t1, region);
     if (!(a.abl & 1)) walk_records<C, ACCUM>(a, s, slo, shi, t0, t1, region, nullptr);
+    if (!(a.abl & 4)) {
+        if (r0 < hi) cover_one(a, s, rd0, r0, t0, t1, region);
+        cover_reads(a, s, lo + SCAN_THREADS, hi, t0, t1, region);
+    }
     __syncthreads();
     C3R_PHASE(1);
 
-    // coverage: inclusive scan of the difference array; indel events: exclusive scan of per-position counts
+    // coverage: inclusive scan of the difference array; indel events: exclusive scan of per-position counts (one scan, one barrier)
     int *wave_tot = &M.misc[2];
-    int tot;
     const int my_cov_d = M.cov[tid];
-    const int cov_ex = block_excl_scan(my_cov_d, wave_tot, &tot);
-    const int my_cov = cov_ex + my_cov_d;
     const int32_t *row = &M.cnt[tid * C];
     const int nev = row[C3R_I] + row[C3R_i] + row[C3R_D] + row[C3R_d];
-    int ev_total;
-    const int ev_ex = block_excl_scan(nev, wave_tot, &ev_total);
-    M.evoff[tid] = ev_ex;
+    int tot, ev_total;
+    const int2 ex = block_excl_scan2(my_cov_d, nev, M.scan_slot[0], &tot, &ev_total);
+    const int my_cov = (a.abl & 256) ? 1 : ex.x + my_cov_d;
+    M.evoff[tid] = ex.y;
     C3R_PHASE(2);
     if (ev_total > 0 && !(a.abl & 2)) {
         // the tile's indel events, bucketed by position (counting sort through evoff / evfill), then the max multiplicity of one
         // allele per (position, channel): I1 / i1 / D1 / d1
+        __syncthreads();                       // (evoff of every position is in place)
         if (ev_total <= EV_LDS) {
             // the usual case: the first walk has captured every event (ev_total of them, in arrival order); bucket their indices
             for (int e = tid; e < ev_total; e += SCAN_THREADS) {
@@ -689,7 +714,6 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
 
     C3R_PHASE(3);
     // ---- per-position gates (src/create_tensor_pileup.py:259-299, :536-556)
-    const int p = t0 + tid;
     bool is_row = false, cand = false, ambiguous = false;
     int depth = 0, refi = 0;
     int cls[6] = {0, 0, 0, 0, 0, 0};
@@ -702,19 +726,18 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         const int up = c[C3R_A] + c[C3R_C] + c[C3R_G] + c[C3R_T];
         const int lw = c[C3R_a] + c[C3R_c] + c[C3R_g] + c[C3R_t];
         depth = up + lw + c[C3R_STAR] + c[C3R_HASH];
-        const int rp = p - a.ref_beg0;
-        const uint8_t rb = (rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
         const bool ref_acgt = (rb == 'A' || rb == 'C' || rb == 'G' || rb == 'T');
         refi = ref_index(rb);
         cls[0] = c[C3R_A] + c[C3R_a]; cls[1] = c[C3R_C] + c[C3R_c]; cls[2] = c[C3R_G] + c[C3R_g]; cls[3] = c[C3R_T] + c[C3R_t];
         cls[4] = c[C3R_I] + c[C3R_i]; cls[5] = c[C3R_D] + c[C3R_d];
         const bool may_be_cand = p >= cand_lo && p < cand_hi;       // (the fused kernel decides candidates for its inner span only)
         const double denom = depth > 0 ? (double)depth : 1.0;
-        bool pass = false;
+        bool pass = (a.abl & 1024) != 0;
+        if (!pass)
         for (int x = 0; x < 4; ++x)
             if (x != refi && cls[x] > 0 && (double)cls[x] / denom >= a.snp_af) pass = true;
-        if (cls[4] > 0 && (double)cls[4] / denom >= a.indel_af) pass = true;
-        if (cls[5] > 0 && (double)cls[5] / denom >= a.indel_af) pass = true;
+        if (!pass && cls[4] > 0 && (double)cls[4] / denom >= a.indel_af) pass = true;
+        if (!pass && cls[5] > 0 && (double)cls[5] / denom >= a.indel_af) pass = true;
         if (depth > 0 && (a.snp_af == 0.0 || a.indel_af == 0.0)) pass = true;
         if (!pass) {
             // pileup_list[0][0] != reference_base: top class by count, ties broken by first occurrence
@@ -745,6 +768,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         c[ch_up] = -up;
         c[ch_lo] = -lw;
     }
+    if (a.abl & 512) ambiguous = false;
     const bool any_amb = __syncthreads_or(ambiguous ? 1 : 0) != 0;
     C3R_PHASE(4);
 
@@ -1342,7 +1366,7 @@ __device__ __forceinline__ void tok_emit(TokLds &K, c3r_token_t *tok, long long 
     atomicOr(&K.done[c][b], 1ull << bit);
 }
 
-__device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long tok_cap, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int boff,
+__device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long tok_cap, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1,
                                         int t0, int t1, int nb, int rc, int re) {
     const uint32_t w = (uint32_t)ra.y;
     const int op = (int)(w & 3u), prev = (int)((w >> 2) & 15u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
@@ -1352,13 +1376,13 @@ __device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long t
     if (op != C3R_CIG_I) {
         const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
         if (b0 < b1) {
-            const int odd = (int)(((uint32_t)ra.z + (uint32_t)boff) & 1u);      // the bases were loaded from nibble naddr + boff on
+            const int odd = (int)((uint32_t)ra.z & 1u);                          // (w0:w1 = the 16 bytes from the piece's first base on)
             for (int c = 0; c < nb; ++c) {
                 const int p = t0 + K.lpos[c];
                 if (p < b0) continue;
                 if (p >= b1) break;                           // (candidates ascend)
                 int base = 16;
-                if (op == C3R_CIG_M) base = (p - rstart) < avail ? nibble_at(w0, w1, odd + (p - rstart) - boff) : 15;
+                if (op == C3R_CIG_M) base = (p - rstart) < avail ? nibble_at(w0, w1, odd + (p - rstart)) : 15;
                 int indel = 0; uint32_t qpos = 0;
                 if (p == rstart + len - 1 && rb.z != 0) {
                     // htslib: the op after the one that ends on the column (k_prep has looked ahead)
@@ -1384,7 +1408,6 @@ template <class CandFn>
 __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0, int t1, int region, int lo, int hi, int rlo, int rhi, int nc, CandFn &&cand,
                                             c3r_token_t *tok, long long tok_cap) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     for (int cb = 0; cb < nc; cb += TK_NB) {
         const int nb = min(TK_NB, nc - cb);
         __syncthreads();
@@ -1421,36 +1444,28 @@ __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0
             for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
                 int4 ra[WALK_UNR], rb[WALK_UNR];
                 bool have[WALK_UNR];
+                uint64_t w0[WALK_UNR], w1[WALK_UNR];
 #pragma unroll
                 for (int u = 0; u < WALK_UNR; ++u) {
                     const int iu = base + u * SCAN_THREADS + tid;
                     have[u] = iu < rhi;
-                    const int4 *rec = reinterpret_cast<const int4 *>(a.recs + (have[u] ? iu : rhi - 1));
+                    const int at = have[u] ? iu : rhi - 1;
+                    const int4 *rec = reinterpret_cast<const int4 *>(a.recs + at);
                     ra[u] = rec[0]; rb[u] = rec[1];
+                    const uint4 bs = a.rbase[at];
+                    w0[u] = (uint64_t)bs.x | ((uint64_t)bs.y << 32); w1[u] = (uint64_t)bs.z | ((uint64_t)bs.w << 32);
                 }
-                uint64_t w0[WALK_UNR], w1[WALK_UNR];
-                int boff[WALK_UNR];
 #pragma unroll
                 for (int u = 0; u < WALK_UNR; ++u) {
-                    w0[u] = 0; w1[u] = 0; boff[u] = 0;
                     const uint32_t w = (uint32_t)ra[u].y;
-                    const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
+                    const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u);
                     const bool body = op != C3R_CIG_I && ra[u].x <= c_hi && ra[u].x + len > c_lo;
                     const bool anchored = op != C3R_CIG_M && ra[u].x - 1 >= c_lo && ra[u].x - 1 <= c_hi;
                     if (!(body || anchored)) have[u] = false;
-                    if (have[u] && op == C3R_CIG_M) {
-                        boff[u] = max(ra[u].x, t0) - ra[u].x;
-                        if (boff[u] < avail) {
-                            const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)boff[u];
-                            u64x2 w;
-                            __builtin_memcpy(&w, a.seq + (na >> 1), 16);
-                            w0[u] = w[0]; w1[u] = w[1];
-                        }
-                    }
                 }
 #pragma unroll
                 for (int u = 0; u < WALK_UNR; ++u)
-                    if (have[u]) tok_rec(K, tok, tok_cap, ra[u], rb[u], w0[u], w1[u], boff[u], t0, t1, nb, rc, re);
+                    if (have[u]) tok_rec(K, tok, tok_cap, ra[u], rb[u], w0[u], w1[u], t0, t1, nb, rc, re);
             }
             __syncthreads();
             for (int c = wave; c < nb; c += WAVES) {
@@ -1588,30 +1603,42 @@ __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
 // anything did not fit: then it grows the buffers and repeats the scan) from the single read-back at the end of the scan.
 constexpr int FUSE_IN = TILE - 2 * C3R_FLANK;     // 224
 constexpr int TICKET_Q = 16, TICKET_STRIDE = 64;     // ticket words 256 bytes apart: atomics on one cache line serialise like atomics on one word
+// Output rows and token slots are handed out by up to ALLOC_SHARDS sub-allocators, each owning an equal part of the scan's row / token
+// space and ONE 64-bit word (tokens << 32 | rows; the words 256 bytes apart): a span takes both with one returning atomic on its
+// workgroup's shard.  With one `arrived` and one `tok_arrived` word for the whole scan (in one cache line) the 2 x 23 k returning atomics
+// of a chr20 pass were the kernel's floor: a word takes ~88 of them per microsecond (MI355X_MICROARCH.md, "dequeue") = 0.52 ms, and the
+// kernel ran 0.65 ms with candidates against 0.33 ms without.  Rows and tokens are reached through win_idx / tok_off, so the holes
+// between the shards' runs cost address space only.
+constexpr int ALLOC_SHARDS = 16, ALLOC_STRIDE = 32;  // (u64 words)
 struct CandMeta { int32_t slot, depth, ncov, tpre, span; };      // per arrived candidate: slot (tile * TILE + offset), depth, covering reads,
                                                                  // tokens of the span's earlier candidates, list index of its span
 struct FusedArgs {
     ScanArgs a;                   // tile_list: spans with aligned bases, ascending; tile_rng: reads / segments of the span + flanks
     int32_t *ticket;              // [TICKET_Q * TICKET_STRIDE] tickets handed out per queue
     const SpanRec *span_rec;      // [listed spans] where the span lies, its region's bounds (rows exist only inside their region), its read / segment ranges
-    int32_t *arrived;             // rows handed out so far (= candidates, once the kernel is done)
-    int32_t *overflow;            // bit 0: a span's candidates did not fit below cand_cap (nothing was written past it)
-    int32_t cand_cap;
+    unsigned long long *alloc;    // [n_shards * ALLOC_STRIDE] per shard: tokens << 32 | rows handed out so far
+    int32_t n_shards;             // 1 for small scans (dense output), ALLOC_SHARDS for large ones
+    int32_t shard_rows, shard_toks;   // rows / token slots a shard owns: shard s hands out rows [s * shard_rows, (s + 1) * shard_rows)
+    int32_t *overflow;            // bit 0: a span's candidates or tokens did not fit into its shard (nothing was written past it)
+    int32_t cand_cap;             // = n_shards * shard_rows
     int32_t rescale, max_depth;   // A5: windows with depth > 1.5 x max_depth are rescaled
     int32_t *tensors;             // [cand_cap][33][C], rows in arrival order
     int4 *span_info;              // [listed spans] {first row, candidates, tokens, first token (scan-relative)}
     CandMeta *meta;               // [cand_cap]
     c3r_token_t *tok;             // the batch's token array (null: no tokens wanted — the raw re-run of c3r_get_tensors)
-    int32_t tok_base;             // tokens already resident from earlier scans of the batch
-    int32_t tok_cap;              // token slots this scan may use (scan-relative); a span beyond it writes nothing and raises overflow bit 1
-    int32_t *tok_arrived;         // token slots handed out so far (= tokens, once the kernel is done)
+    int32_t tok_base;             // token slots taken by earlier scans of the batch
+    int32_t tok_cap;              // = n_shards * shard_toks
     PhaseArgs ph;                 // 30 channels: the ordered recompute of flagged columns
 };
 
 template <int C>
-__global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) void k_fused_tiles(const FusedArgs f) {
+#ifndef C3R_FUSED_OCC
+#define C3R_FUSED_OCC 5
+#endif
+__global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SCAN_OCC30)) void k_fused_tiles(const FusedArgs f) {
     __shared__ TileMem<C> M;
-    __shared__ int s_ticket, s_row0, s_tok0;
+    __shared__ int s_ticket, s_row0, s_tok0, s_fits;
+    const int shard = (int)(blockIdx.x % (unsigned)f.n_shards);
     static_assert(sizeof(TokLds) <= sizeof(M.cnt), "the token pass re-uses the accumulators' LDS");
     const ScanArgs &a = f.a;
     const int tid = (int)threadIdx.x;
@@ -1646,7 +1673,8 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
         const int2 rb = make_int2(r2.x, r2.y);
         const int x0 = tg.p0 - C3R_FLANK, x1 = min(tg.p1 + C3R_FLANK, rb.y);       // thread tid <-> position x0 + tid
         const TileOut o = tile_columns<C>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1);
-        const unsigned long long t_tail = a.dbg ? wall_clock64() : 0ull;
+        unsigned long long t_tail = a.dbg ? wall_clock64() : 0ull;
+        int dbg_slot = 7;
         if (C == C3R_CH_PHASED) {
             // a column whose haplotype channels depend on the ORDER of the reads (see k_phase_recompute): redone in place, one thread
             // per flagged column
@@ -1657,29 +1685,41 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
                 for (int k = 0; k < 12; ++k) M.cnt[tid * C + C3R_AP + k] = cnt[k];
             }
         }
-        // ---- the window rule: 33 contiguous rows.  rowp[e] = rows among the positions before e (M.cov is free: coverage lives in o.cov)
-        int *wave_tot = &M.misc[2];
-        int n_rows;
-        const int rp = block_excl_scan(o.is_row ? 1 : 0, wave_tot, &n_rows);
-        M.cov[tid] = rp;
-        if (tid == 0) M.cov[TILE] = n_rows;
+        // ---- the window rule: 33 contiguous rows = 33 set bits in the span's row mask (one ballot per wavefront, one barrier)
+        {
+            const unsigned long long rm = __ballot(o.is_row);
+            if ((tid & 63) == 0) M.rowmask[tid >> 6] = rm;
+        }
         __syncthreads();
         bool emit = false;
-        if (o.cand && tid >= C3R_FLANK && tid + C3R_FLANK < TILE) emit = M.cov[tid + C3R_FLANK + 1] - M.cov[tid - C3R_FLANK] == C3R_WINDOW;
+        if (o.cand && tid >= C3R_FLANK && tid + C3R_FLANK < TILE) {
+            const int first = tid - C3R_FLANK, w = first >> 6, sh = first & 63;
+            unsigned long long bits = M.rowmask[w] >> sh;
+            if (sh > 64 - C3R_WINDOW) bits |= M.rowmask[w + 1] << (64 - sh);          // (first + 32 <= 255: w + 1 <= 3)
+            constexpr unsigned long long ALL = (1ull << C3R_WINDOW) - 1ull;
+            emit = (bits & ALL) == ALL;
+            if (a.abl & 2048) emit = false;
+        }
         int nc, nt;
-        const int rank = block_excl_scan(emit ? 1 : 0, wave_tot, &nc);
-        const int tpre = block_excl_scan(emit ? o.cov : 0, wave_tot, &nt);
+        const int2 ex = block_excl_scan2(emit ? 1 : 0, emit ? o.cov : 0, M.scan_slot[1], &nc, &nt);
+        const int rank = ex.x, tpre = ex.y;
         // per candidate (by rank): position in the span, depth for the window copy, tokens of the span's earlier candidates — the event
         // arrays are free by now
         if (emit) { M.amb[rank] = (uint8_t)tid; M.evfill[rank] = o.depth; M.evoff[rank] = tpre; }
         if (tid == 0) {
-            s_row0 = nc ? atomicAdd(f.arrived, nc) : 0;
-            s_tok0 = (nc && f.tok) ? atomicAdd(f.tok_arrived, nt) : 0;
+            int lrow = 0, ltok = 0;
+            if (nc) {
+                const unsigned long long got = atomicAdd(&f.alloc[shard * ALLOC_STRIDE], ((unsigned long long)(unsigned)(f.tok ? nt : 0) << 32) | (unsigned)nc);
+                lrow = (int)(unsigned)got; ltok = (int)(unsigned)(got >> 32);
+            }
+            s_fits = (long long)lrow + nc <= (long long)f.shard_rows && (!f.tok || (long long)ltok + nt <= (long long)f.shard_toks);
+            s_row0 = shard * f.shard_rows + lrow;
+            s_tok0 = shard * f.shard_toks + ltok;
             f.span_info[b] = make_int4(s_row0, nc, nt, s_tok0);
         }
         __syncthreads();
         const int row0 = s_row0, tok0 = s_tok0;
-        const bool fits = row0 + nc <= f.cand_cap && (!f.tok || (long long)tok0 + nt <= (long long)f.tok_cap);
+        const bool fits = s_fits != 0;
         if (nc > 0 && !fits && tid == 0) atomicOr(f.overflow, 1);
         if (nc > 0 && fits) {
         if (emit) {
@@ -1704,11 +1744,29 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
         };
         if (tid < head) out[tid] = fetch(tid);
         const int n4 = (total - head) >> 2;
-        for (int c4 = tid; c4 < n4; c4 += SCAN_THREADS) {
-            const int g = head + 4 * c4;
-            int4 v;
-            v.x = fetch(g); v.y = fetch(g + 1); v.z = fetch(g + 2); v.w = fetch(g + 3);
-            *reinterpret_cast<int4 *>(out + g) = v;
+        {
+            // a thread's groups of four lie 4 * SCAN_THREADS ints apart: window index and offset inside the window are carried along
+            // (one division per thread instead of one per int); a group that straddles two windows (1 in ~150) takes the general path
+            constexpr int STEP = 4 * SCAN_THREADS, KSTEP = STEP / WIN, OSTEP = STEP % WIN;
+            int g = head + 4 * tid;
+            int k = g / WIN, oo = g - k * WIN;
+            for (int c4 = tid; c4 < n4; c4 += SCAN_THREADS, g += STEP) {
+                int4 v;
+                if (oo + 3 < WIN) {
+                    const int32_t *src = &M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo];
+                    v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+                    const int dep = M.evfill[k];
+                    if (2 * (long long)dep > (long long)resc_thr) {
+                        const double sf = (double)dep / (double)f.max_depth;
+                        v.x = (int32_t)((double)v.x / sf); v.y = (int32_t)((double)v.y / sf); v.z = (int32_t)((double)v.z / sf); v.w = (int32_t)((double)v.w / sf);
+                    }
+                } else {
+                    v.x = fetch(g); v.y = fetch(g + 1); v.z = fetch(g + 2); v.w = fetch(g + 3);
+                }
+                *reinterpret_cast<int4 *>(out + g) = v;
+                oo += OSTEP; k += KSTEP;
+                if (oo >= WIN) { oo -= WIN; ++k; }
+            }
         }
         const int gt = head + 4 * n4 + tid;
         if (gt < total) out[gt] = fetch(gt);
@@ -1716,13 +1774,14 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? 5 : C3R_SCAN_OCC30)) v
         // 0.29 ms and 291 MB per chr20 pass).  The accumulators are dead once the windows are out: their LDS holds the token pass's tables
         if (f.tok) {
             __syncthreads();
+            if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[7], now_ - t_tail); t_tail = now_; dbg_slot = 8; }
             TokLds &K = *reinterpret_cast<TokLds *>(M.cnt);
             tile_tokens(a, K, x0, x1, tg.region, rng.x, rng.y, rng.z, rng.w, nc, [&](int k, int &lp, int &off) {
                 lp = (int)M.amb[k]; off = f.tok_base + tok0 + M.evoff[k];
-            }, f.tok, (long long)f.tok_base + f.tok_cap);
+            }, f.tok, (long long)f.tok_base + (long long)(shard + 1) * f.shard_toks);
         }
         }
-        if (a.dbg && tid == 0) atomicAdd(&a.dbg[7], wall_clock64() - t_tail);
+        if (a.dbg && tid == 0) atomicAdd(&a.dbg[dbg_slot], wall_clock64() - t_tail);
         // ---- hand over to the next span: its ticket has long arrived; the barrier also frees this span's LDS
         if (tid == 0) s_ticket = t_next < queue_len(q_next) ? q_next + t_next * TICKET_Q : take();
         __syncthreads();
@@ -1765,15 +1824,17 @@ __global__ __launch_bounds__(256) void k_order_spans(const int4 *span_info, cons
 //   i = span_base[span] + (row - first row of the span):  sites[i] (tok_off = the span's first token + the tokens of its earlier
 //   candidates), cand_idx[i] = slot, win_idx[i] = row_base + row
 struct FinalizeArgs {
-    const CandMeta *meta; const int4 *span_info; const int32_t *span_base; const int32_t *arrived; const int32_t *overflow; int32_t cand_cap;
+    const CandMeta *meta; const int4 *span_info; const int32_t *span_base; const unsigned long long *alloc; int32_t n_shards, shard_rows; const int32_t *overflow;
     const TileGeo *geo; const uint8_t *ref; int32_t ref_beg0, ref_len;
     c3r_site_t *sites; int32_t *cand_idx; int32_t *win_idx; int32_t row_base; int32_t tok_base;
 };
 __global__ __launch_bounds__(256) void k_finalize_sites(const FinalizeArgs g) {
     if (*g.overflow) return;                                  // (some rows were never written: the host repeats the scan with larger buffers)
-    const int n = min(*g.arrived, g.cand_cap);
+    const int n = g.n_shards * g.shard_rows;                  // the scan's row space; a shard's rows beyond what it handed out are holes
     const int lane = (int)(threadIdx.x & 63), nw = (int)(gridDim.x * (blockDim.x >> 6));
     for (int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); row < n; row += nw) {
+        const int sh = row / g.shard_rows;
+        if (row - sh * g.shard_rows >= (int)(unsigned)g.alloc[sh * ALLOC_STRIDE]) continue;
         const CandMeta m = g.meta[row];
         const int4 si = g.span_info[m.span];
         const int i = g.span_base[m.span] + (row - si.x);

@@ -125,7 +125,13 @@ struct SegWalk {
 };
 
 // ---- the pile table ---------------------------------------------------------------------------------------------------------
-constexpr int PREP_GRP = 16;                  // lanes per read in k_prep
+#ifndef C3R_PREP_ABL
+#define C3R_PREP_ABL 0
+#endif
+#ifndef C3R_PREP_GRP
+#define C3R_PREP_GRP 16
+#endif
+constexpr int PREP_GRP = C3R_PREP_GRP;        // lanes per read in k_prep
 
 struct ReadInfo {
     const uint32_t *cig;
@@ -260,6 +266,8 @@ struct PrepArgs {
     int32_t *nind;            // [n_reads] I + D ops of the read, 0 when the filters drop it (summed by k_prefmax_bins: 54 k atomics on one
                               // word would take 0.6 ms)
     PileRec *recs;
+    uint4 *rbase;             // [records] the packed bases of every record (ScanArgs::rbase)
+    const uint8_t *seq;
     LoadStats *st;
 };
 
@@ -282,10 +290,18 @@ __global__ __launch_bounds__(256) void k_prep(const PrepArgs a) {
         const bool plain = cigar_is_plain(R, gl, ref_len, n_indel);
         const bool pass = !err && !flag_fails(r.flag, a.excl_flags) && r.mapq >= a.min_mq;
         auto count = [&](int32_t rstart, uint32_t, unsigned long long, uint32_t, int32_t, uint32_t) {
+#if C3R_PREP_ABL & 1
+            if (pass && rstart == -12345) a.cnt[0] = 1;
+#else
             if (pass) __hip_atomic_fetch_add(&a.cnt[bin_of(a.geo, rstart)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         };
         if (!err) {
+#if C3R_PREP_ABL & 2
+            if (plain) { if (pass && r.pos == -12345) walk_plain(R, gl, count); }
+#else
             if (plain) { if (pass) walk_plain(R, gl, count); }
+#endif
             else if (gl == 0) err = walk_serial(R, count);             // (also for a read the filters drop: its CIGAR is validated all the same)
             if (!err && (long long)r.pos + ref_len > INT32_MAX) err = LD_END_2G;
         }
@@ -311,9 +327,15 @@ __global__ __launch_bounds__(256) void k_prep(const PrepArgs a) {
         auto put = [&](int32_t rstart, uint32_t w, unsigned long long naddr, uint32_t q, int32_t nxt, uint32_t aux) {
             const int b = bin_of(a.geo, rstart);
             const uint32_t left = __hip_atomic_fetch_add(&a.cnt[b], ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // counts down
-            int4 *dst = reinterpret_cast<int4 *>(a.recs + ((size_t)(uint32_t)a.tab[b].x + (left - 1u)));
+            const size_t at = (size_t)(uint32_t)a.tab[b].x + (left - 1u);
+            // the 16 bytes that hold the piece's bases (M, I): copied next to the record, so that the tile walk's two loads are independent
+            // (the packed-base buffer is padded: the load may run past a read's last byte)
+            uint4 bs = make_uint4(0, 0, 0, 0);
+            if ((w & 3u) != C3R_CIG_D && ((w >> 14) & 31u) != 0) __builtin_memcpy(&bs, a.seq + (naddr >> 1), 16);
+            int4 *dst = reinterpret_cast<int4 *>(a.recs + at);
             dst[0] = make_int4(rstart, (int)w, (int)(uint32_t)naddr, (int)(uint32_t)(naddr >> 32));
             dst[1] = make_int4((int)q, i, nxt, (int)aux);
+            a.rbase[at] = bs;
         };
         if (!a.serial[i]) walk_plain(R, gl, put);
         else if (gl == 0) (void)walk_serial(R, put);

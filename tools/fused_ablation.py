@@ -1,0 +1,18 @@
+# k_fused_tiles under timing-only ablations (env C3R_SCAN_ABL bits: 1 no record walk, 2 no indel events, 4 no coverage, 64 no window store,
+# 128 no tokens; results are wrong, times are what is measured):   python tools/fused_ablation.py
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from clair3_rna_amd import capi, synth
+import bench
+ref, rs, info = synth.generate_contig(contig_len=synth.CHR20_LEN, seed=synth.SEED, depth=20.0)
+chunks = bench.chunk_list(synth.CHR20_LEN)
+eng = capi.Engine(0); eng.set_params(); eng.load_reads(rs); eng.set_reference(1, ref)
+for abl in [int(x) for x in sys.argv[1:]] or (0, 128, 64, 192, 194, 198, 199, 7):
+    os.environ["C3R_SCAN_ABL"] = str(abl)
+    eng.begin_batch(); eng.scan_regions(chunks); eng.end_batch()
+    eng.set_profiling(True); eng.reset_kernel_stats()
+    for _ in range(3):
+        eng.begin_batch(); n = eng.scan_regions(chunks); eng.end_batch()
+    eng.set_profiling(False)
+    ks = eng.kernel_stats()
+    print("abl %3d  n=%6d  " % (abl, n) + "  ".join("%s %.3f" % (k.replace("k_", ""), v["total_ms"] / 3) for k, v in sorted(ks.items())))

@@ -22,6 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def short(name):
     if "rocprim" in name:
         return "rocprim_radix_sort"
+    if "k_prep<" in name or "k_prepIL" in name:
+        return "k_prep_write" if ("k_prep<true>" in name or "k_prepILb1" in name) else "k_prep_count"
     m = re.search(r"k_lstm2_mx|k_lstm2_w8|k_lstm1_rs|k_lstm|k_[a-z0-9_]+", name)
     if not m:
         return name[:40]
