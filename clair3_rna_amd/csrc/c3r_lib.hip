@@ -55,7 +55,7 @@ struct c3r_ctx {
     int64_t n_seq_bytes = 0, n_cigar_ops = 0;
     DevBuf d_rawreads, d_rawcig;           // the caller's records as they arrived (c3r_read_t, BAM-encoded ops)
     // the pile table (reads_kernels.hpp): bin counters {cnt | sc | ec | pc}, their prefix sums, the records, per-read notes of k_prep
-    DevBuf d_bincnt, d_tab, d_recs, d_rbase, d_serial, d_nind, d_lbk, d_stats;
+    DevBuf d_bincnt, d_binoff, d_rtab, d_recs, d_serial, d_nind, d_lbk, d_stats;
     BinGeo bins{0, 0};
     int32_t first_pos = 0;                 // pos of the first read (the bins start there)
     int64_t last_pos = 0;                  // pos of the last read (first guess of where the bins end)
@@ -282,20 +282,20 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
     for (int attempt = 0;; ++attempt) {
         const int32_t base = ctx->first_pos >> BIN_SHIFT;
         want_end = std::min<int64_t>(want_end, (int64_t)INT32_MAX);
-        const int32_t nb = (int32_t)((want_end >> BIN_SHIFT) - base + 2);
-        const size_t cnt_bytes = (size_t)nb * 4;
-        if (ctx->d_bincnt.cap < 4 * cnt_bytes || !ctx->d_bincnt.p) ctx->bins_zeroed = 0;                                // (a fresh block)
-        if ((rc = ensure(ctx, ctx->d_bincnt, 4 * cnt_bytes)) || (rc = ensure(ctx, ctx->d_tab, (size_t)(nb + 1) * sizeof(int4)))) return rc;
-        ctx->bins = BinGeo{base, nb};
-        // the four counter arrays lie back to back and every pass leaves them all zero (k_bin_scan, k_prep<true>): nothing to clear as
-        // long as they stay inside what has been cleared once
-        if (ctx->bins_dirty || 4 * cnt_bytes > ctx->bins_zeroed) {
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_bincnt.p, 0, std::max(4 * cnt_bytes, ctx->bins_zeroed), ctx->stream));
-            ctx->bins_zeroed = std::max(4 * cnt_bytes, ctx->bins_zeroed);
+        const int32_t nb = (int32_t)((want_end >> BIN_SHIFT) - base + 2), nbc = (nb >> CBIN_SHIFT) + 2;
+        const size_t cnt_bytes = ((size_t)nb + 3 * (size_t)nbc) * 4;          // records per bin | reads started | ended | prefix-max histogram per coarse bin
+        if (ctx->d_bincnt.cap < cnt_bytes || !ctx->d_bincnt.p) ctx->bins_zeroed = 0;                                    // (a fresh block)
+        if ((rc = ensure(ctx, ctx->d_bincnt, cnt_bytes)) || (rc = ensure(ctx, ctx->d_binoff, (size_t)(nb + 1) * 4 + 16)) || (rc = ensure(ctx, ctx->d_rtab, (size_t)(nbc + 1) * sizeof(int4)))) return rc;
+        ctx->bins = BinGeo{base, nb, nbc, 0};
+        // the counter arrays lie back to back and every pass leaves them all zero (k_bin_scan, k_prep<true>): nothing to clear as long as
+        // they stay inside what has been cleared once
+        if (ctx->bins_dirty || cnt_bytes > ctx->bins_zeroed) {
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_bincnt.p, 0, std::max(cnt_bytes, ctx->bins_zeroed), ctx->stream));
+            ctx->bins_zeroed = std::max(cnt_bytes, ctx->bins_zeroed);
         }
         ctx->bins_dirty = true;                               // until this pass has come through
-        const int nb_pm = (n + PM_BLK - 1) / PM_BLK, nb_bs = (nb + BS_BLK - 1) / BS_BLK;
-        const size_t lbk_bytes = 64 + (size_t)(nb_pm + 2 * nb_bs) * 8;
+        const int nb_pm = (n + PM_BLK - 1) / PM_BLK, nb_bs = (nb + BS_BLK - 1) / BS_BLK, nb_bc = (nbc + BS_BLK - 1) / BS_BLK;
+        const size_t lbk_bytes = 64 + (size_t)(nb_pm + nb_bs + 2 * nb_bc) * 8;
         if ((rc = ensure(ctx, ctx->d_lbk, lbk_bytes))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_lbk.p, 0, lbk_bytes, ctx->stream));
         LoadStats init;
@@ -309,14 +309,14 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
         a.n_cigar_ops = ctx->n_cigar_ops; a.n_seq_bytes = ctx->n_seq_bytes; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags;
         a.geo = ctx->bins;
         uint32_t *cnt = (uint32_t *)ctx->d_bincnt.p;
-        a.cnt = cnt; a.sc = cnt + nb; a.ec = cnt + 2 * (size_t)nb; uint32_t *pc = cnt + 3 * (size_t)nb;
-        a.tab = (const int4 *)ctx->d_tab.p; a.out = (DevRead *)ctx->d_reads.p; a.serial = (uint8_t *)ctx->d_serial.p; a.nind = (int32_t *)ctx->d_nind.p;
+        a.cnt = cnt; a.sc = cnt + nb; a.ec = a.sc + nbc; uint32_t *pc = a.ec + nbc;
+        a.rec_off = (const uint32_t *)ctx->d_binoff.p; a.out = (DevRead *)ctx->d_reads.p; a.serial = (uint8_t *)ctx->d_serial.p; a.nind = (int32_t *)ctx->d_nind.p;
         a.st = (LoadStats *)ctx->d_stats.p;
         char *lbk = (char *)ctx->d_lbk.p;
-        const unsigned grid = (unsigned)((n + 256 / PREP_GRP - 1) / (256 / PREP_GRP));
+        const unsigned grid = (unsigned)((n + PREP_READS - 1) / PREP_READS);
         {
             Launch L(ctx, "k_prep_count");
-            hipLaunchKernelGGL(k_prep<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(k_prep<false>, dim3(grid), dim3(PREP_THREADS), 0, ctx->stream, a);
         }
         {
             Launch L(ctx, "k_prefmax_bins");
@@ -325,8 +325,9 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
         }
         {
             Launch L(ctx, "k_bin_scan");
-            hipLaunchKernelGGL(k_bin_scan, dim3(nb_bs), dim3(1024), 0, ctx->stream, (const uint32_t *)a.cnt, a.sc, pc, a.ec, (int)nb, (int4 *)ctx->d_tab.p, a.st, (int32_t *)(lbk + 4),
-                               (unsigned long long *)(lbk + 64 + (size_t)nb_pm * 8), (unsigned long long *)(lbk + 64 + (size_t)(nb_pm + nb_bs) * 8));
+            hipLaunchKernelGGL(k_bin_scan, dim3(nb_bs + nb_bc), dim3(1024), 0, ctx->stream, (const uint32_t *)a.cnt, a.sc, pc, a.ec, ctx->bins, nb_bs, (uint32_t *)ctx->d_binoff.p,
+                               (int4 *)ctx->d_rtab.p, a.st, (int32_t *)(lbk + 4), (unsigned long long *)(lbk + 64 + (size_t)nb_pm * 8),
+                               (unsigned long long *)(lbk + 64 + (size_t)(nb_pm + nb_bs) * 8), (unsigned long long *)(lbk + 64 + (size_t)(nb_pm + nb_bs + nb_bc) * 8));
         }
         // ---- the one synchronisation: sizes, errors
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_stats, ctx->d_stats.p, sizeof(LoadStats), hipMemcpyDeviceToHost, ctx->stream));
@@ -353,15 +354,15 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
     if (hs.n_rec < 0) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
     const auto t_sync = std::chrono::steady_clock::now();
     // ---- second pass (nothing below waits for the device): every record into its bin
-    if ((rc = ensure(ctx, ctx->d_recs, (size_t)hs.n_rec * sizeof(PileRec) + 64)) || (rc = ensure(ctx, ctx->d_rbase, (size_t)hs.n_rec * sizeof(uint4) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_recs, (size_t)hs.n_rec * sizeof(PileRec) + 64))) return rc;
     {
         PrepArgs a;
         memset(&a, 0, sizeof a);
         a.n_reads = n; a.cigars = (const uint32_t *)ctx->d_rawcig.p; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.geo = ctx->bins;
-        a.cnt = (uint32_t *)ctx->d_bincnt.p; a.tab = (const int4 *)ctx->d_tab.p; a.out = (DevRead *)ctx->d_reads.p; a.serial = (uint8_t *)ctx->d_serial.p;
-        a.recs = (PileRec *)ctx->d_recs.p; a.rbase = (uint4 *)ctx->d_rbase.p; a.seq = (const uint8_t *)ctx->d_seq.p;
+        a.cnt = (uint32_t *)ctx->d_bincnt.p; a.rec_off = (const uint32_t *)ctx->d_binoff.p; a.out = (DevRead *)ctx->d_reads.p; a.serial = (uint8_t *)ctx->d_serial.p;
+        a.recs = (PileRec *)ctx->d_recs.p;
         Launch L(ctx, "k_prep_write");
-        hipLaunchKernelGGL(k_prep<true>, dim3((unsigned)((n + 256 / PREP_GRP - 1) / (256 / PREP_GRP))), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_prep<true>, dim3((unsigned)((n + PREP_READS - 1) / PREP_READS)), dim3(PREP_THREADS), 0, ctx->stream, a);
     }
     HIPCHK(ctx, hipGetLastError());
     ctx->bins_dirty = false;                                  // (the record counters are back at zero once k_prep<true> is through)
@@ -487,7 +488,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     const bool timing = getenv("C3R_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_tab, &ctx->d_recs, &ctx->d_rbase, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
+    DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_binoff, &ctx->d_rtab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
                       &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff};
@@ -776,7 +777,7 @@ static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int d
     memset(&a, 0, sizeof a);
     a.drop = d_drop; a.drop_words = drop_words;
     a.reads = (const DevRead *)ctx->d_reads.p; a.seq = (const uint8_t *)ctx->d_seq.p; a.n_reads = ctx->n_reads;
-    a.recs = (const PileRec *)ctx->d_recs.p; a.rbase = (const uint4 *)ctx->d_rbase.p; a.tab = (const int4 *)ctx->d_tab.p; a.bins = ctx->bins;
+    a.recs = (const PileRec *)ctx->d_recs.p; a.rec_off = (const uint32_t *)ctx->d_binoff.p; a.rtab = (const int4 *)ctx->d_rtab.p; a.bins = ctx->bins;
     a.n_tiles = n_tiles;
     a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->ref_len;
     a.geo = (const TileGeo *)ctx->d_geo.p;
@@ -1149,6 +1150,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             const double nt = d[15] ? (double)d[15] : 1.0;
             fprintf(stderr, "[k_fused_tiles] %llu spans; per span: reads in range %.1f, records in range %.1f, indel events %.1f; us per span: zero %.2f | cover+walk %.2f | scans %.2f | events %.2f | gates %.2f | first-seen %.2f | select+store %.2f | tokens %.2f\n",
                     d[15], d[13] / nt, d[14] / nt, d[12] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[6] / nt / 100, d[7] / nt / 100, d[8] / nt / 100);
+            fprintf(stderr, "   tail: row mask %.2f | scan %.2f | allocator atomic %.2f us\n", d[9] / nt / 100, d[10] / nt / 100, d[11] / nt / 100);
         }
         if (ctx->h_scan[6]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
         if (n_cand < 0 || n_tok < 0) return fail(ctx, C3R_EOVERFLOW, "too many candidates or tokens for one scan");

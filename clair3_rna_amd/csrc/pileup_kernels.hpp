@@ -86,15 +86,17 @@ struct PileRec {
 static_assert(sizeof(PileRec) == 32, "PileRec must be 32 bytes");
 constexpr int OP_CHOP = 30;    // 30 bases + an odd start nibble fit the 32 nibbles of a 16-byte load
 
-// The bins of the pile table: 32 reference positions each, covering [base << 5, (base + nb) << 5); tab has nb + 1 entries,
-//   tab[b] = {first record of bin b, reads that start before bin b, reads whose prefix-max end lies before bin b, reads that end at or
-//             before the first position of bin b}
-// (k_bin_scan): two loads per span replace the four binary searches per tile of rounds 1-3.
+// The bins of the pile table: 32 reference positions each, covering [base << 5, (base + nb) << 5).  Two tables of prefix sums (k_bin_scan):
+//   rec_off[b], b <= nb    first record of bin b
+//   rtab[c],  c <= nbc     per COARSE bin (8 bins = 256 positions): {reads that start before it, reads whose prefix-max end lies before it,
+//                          reads that end at or before its first position} — a span's reads are a superset anyway, the coarse grid adds a few
+// Four loads per span replace the four binary searches per tile of rounds 1-3.
 #ifndef C3R_BIN_SHIFT
 #define C3R_BIN_SHIFT 5
 #endif
 constexpr int BIN_SHIFT = C3R_BIN_SHIFT;
-struct BinGeo { int32_t base, nb; };
+constexpr int CBIN_SHIFT = 3;
+struct BinGeo { int32_t base, nb, nbc, pad; };          // nbc = coarse bins (>= ceil(nb / 8))
 __host__ __device__ __forceinline__ int bin_of(const BinGeo g, int p) {          // the bin that holds position p, clamped into the table
     const int b = (p >> BIN_SHIFT) - g.base;
     return b < 0 ? 0 : b >= g.nb ? g.nb - 1 : b;
@@ -133,10 +135,8 @@ struct ScanArgs {
     const uint8_t *seq;
     int32_t n_reads;
     const PileRec *recs;          // the pile table
-    const uint4 *rbase;           // [records] the 16 bytes of packed bases that hold a record's bases (M: its <= 30, I: its first <= 31), from the
-                                  // byte of its first base on — a table of its own, parallel to the records, so that a lane's two loads (record,
-                                  // bases) leave together instead of one after the other
-    const int4 *tab;              // [geo.nb + 1] per-bin prefix sums (BinGeo)
+    const uint32_t *rec_off;      // [bins.nb + 1] first record of every bin
+    const int4 *rtab;             // [bins.nbc + 1] read-range prefix sums per coarse bin (BinGeo)
     BinGeo bins;
     uint8_t *tile_cols;           // [n_tiles] 1 = this tile's columns were written (0: implicitly all-zero)
     int4 *tile_rng;               // [n_tiles] {lo, hi, rlo, rhi} from k_tile_ranges: reads / records that can touch the tile
@@ -229,12 +229,14 @@ __device__ __forceinline__ bool read_passes(const DevRead &r, int min_mq, int ex
 // The reads [lo, hi) and the records [rlo, rhi) that can touch the positions [e0, e1): supersets by less than a bin on either side.
 //   reads: everything up to the last read whose prefix-max end is <= e0 ends before e0; reads from the first one with pos >= e1 on
 //   start after it.  records: pieces that start up to OP_CHOP - 1 before e0; indels anchored on e1 - 1 have rstart = e1.
-__device__ __forceinline__ int4 span_ranges(const int4 *tab, const BinGeo g, int e0, int e1) {
+__device__ __forceinline__ int4 span_ranges(const uint32_t *rec_off, const int4 *rtab, const BinGeo g, int e0, int e1) {
     int4 r;
-    r.x = tab[bin_edge(g, (long long)e0 + 1)].z;
-    r.y = tab[bin_edge(g, (long long)e1 + (1 << BIN_SHIFT) - 1)].y;
-    r.z = tab[bin_edge(g, (long long)e0 - (OP_CHOP - 1))].x;
-    r.w = tab[bin_edge(g, (long long)e1 + (1 << BIN_SHIFT))].x;
+    const int c0 = bin_edge(g, (long long)e0 + 1) >> CBIN_SHIFT;                                                   // coarse bin that starts at or before e0 + 1
+    const int c1 = min(g.nbc, (bin_edge(g, (long long)e1 + (1 << BIN_SHIFT) - 1) + (1 << CBIN_SHIFT) - 1) >> CBIN_SHIFT);      // ... at or after e1
+    r.x = rtab[c0].y;
+    r.y = rtab[c1].x;
+    r.z = (int)rec_off[bin_edge(g, (long long)e0 - (OP_CHOP - 1))];
+    r.w = (int)rec_off[bin_edge(g, (long long)e1 + (1 << BIN_SHIFT))];
     return r;
 }
 
@@ -316,7 +318,7 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
         const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
         if (b0 >= b1) return;
         const int off = b0 - rstart, nb = b1 - b0;
-        const int odd = (int)((uint32_t)ra.z & 1u) + off;                      // (w0:w1 = the 16 bytes from the piece's first base on)
+        const int odd = (int)(((uint32_t)ra.z + (uint32_t)off) & 1u);          // the bases were loaded from nibble naddr + off on
 #pragma unroll
         for (int u = 0; u < OP_CHOP; ++u) {
             if (u >= nb) continue;
@@ -399,34 +401,42 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
     }
 }
 
-// All records of [rlo, rhi), WALK_UNR per lane and round: all their loads (records and bases) are issued together.
+// All records of [rlo, rhi), WALK_UNR per lane and round: their loads (record, then bases) are issued together.
 constexpr int WALK_UNR = 2;
 template <int C, int MODE>
 __device__ __forceinline__ void walk_records(const ScanArgs &a, const TileLds &s, int rlo, int rhi, int t0, int t1, int region, EvRec *ev) {
     const int tid = (int)threadIdx.x;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
         int4 ra[WALK_UNR], rb[WALK_UNR];
         bool have[WALK_UNR];
-        uint64_t w0[WALK_UNR], w1[WALK_UNR];
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u) {
             const int iu = base + u * SCAN_THREADS + tid;
             have[u] = iu < rhi;
-            const int at = have[u] ? iu : rhi - 1;           // (idle lanes re-read the last record)
-            const int4 *rec = reinterpret_cast<const int4 *>(a.recs + at);
+            const int4 *rec = reinterpret_cast<const int4 *>(a.recs + (have[u] ? iu : rhi - 1));      // (idle lanes re-read the last record)
             ra[u] = rec[0]; rb[u] = rec[1];
-            const uint4 bs = a.rbase[at];
-            w0[u] = (uint64_t)bs.x | ((uint64_t)bs.y << 32); w1[u] = (uint64_t)bs.z | ((uint64_t)bs.w << 32);
         }
+        uint64_t w0[WALK_UNR], w1[WALK_UNR];
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u) {
+            w0[u] = 0; w1[u] = 0;
             const uint32_t w = (uint32_t)ra[u].y;
-            const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u);
+            const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
             // does the record touch the tile at all?  (the range is a superset by up to a bin on either side)
             const bool body = op != C3R_CIG_I && ra[u].x < t1 && ra[u].x + len > t0;
             const bool anchored = op != C3R_CIG_M && ra[u].x - 1 >= t0 && ra[u].x - 1 < t1;
             if (!(body || anchored)) have[u] = false;
             if (have[u] && a.drop && read_dropped(a.drop, a.drop_words, region, rb[u].y)) have[u] = false;
+            int off = -1;                                    // first base to fetch, relative to the piece's first base
+            if (have[u] && op == C3R_CIG_M && MODE != SCATTER) off = max(ra[u].x, t0) - ra[u].x;
+            if (have[u] && op == C3R_CIG_I && MODE != FIRSTSEEN) off = 0;
+            if (off >= 0 && off < avail) {
+                const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)off;
+                u64x2 w;                                     // (the packed-base buffer is padded: the load may run past a read's last byte)
+                __builtin_memcpy(&w, a.seq + (na >> 1), 16);
+                w0[u] = w[0]; w1[u] = w[1];
+            }
         }
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u)
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const ScanArgs a) {     // 
         const TileGeo tg = a.geo[t];
         const int t0 = tg.p0, t1 = tg.p1;
         if (t1 > t0) {                        // (not a guard tile)
-            const int4 r = span_ranges(a.tab, a.bins, t0, t1);
+            const int4 r = span_ranges(a.rec_off, a.rtab, a.bins, t0, t1);
             if (r.x < r.y) {
                 a.tile_rng[t] = r;
                 listed = true;
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const ScanArgs a) {     // 
                     // intron-only tile.  A candidate is a position with aligned bases (depth > 0) and its window reaches 16
                     // positions to either side: this tile's rows matter only if an aligned base comes within 16 bp of it (a
                     // superset test: whole bins, records of every passing read)
-                    const int4 q = span_ranges(a.tab, a.bins, t0 - C3R_FLANK - 1, t1 + C3R_FLANK);
+                    const int4 q = span_ranges(a.rec_off, a.rtab, a.bins, t0 - C3R_FLANK - 1, t1 + C3R_FLANK);
                     if (q.z >= q.w) { listed = false; pruned = true; }
                 }
             }
@@ -553,9 +563,9 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
         const int t0 = tg.p0, t1 = tg.p1;
         if (t1 > t0) {
             // a candidate needs aligned bases on its own position: spans whose own range meets no record are not listed
-            const int4 own = span_ranges(a.tab, a.bins, t0, t1);
+            const int4 own = span_ranges(a.rec_off, a.rtab, a.bins, t0, t1);
             if (own.z < own.w) {
-                const int4 r = span_ranges(a.tab, a.bins, t0 - C3R_FLANK, t1 + C3R_FLANK);
+                const int4 r = span_ranges(a.rec_off, a.rtab, a.bins, t0 - C3R_FLANK, t1 + C3R_FLANK);
                 a.tile_rng[t] = r;
                 listed = r.x < r.y;
                 rec.tile = t; rec.p0 = t0; rec.p1 = t1; rec.region = tg.region; rec.rng = r;
@@ -1366,7 +1376,7 @@ __device__ __forceinline__ void tok_emit(TokLds &K, c3r_token_t *tok, long long 
     atomicOr(&K.done[c][b], 1ull << bit);
 }
 
-__device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long tok_cap, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1,
+__device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long tok_cap, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int boff,
                                         int t0, int t1, int nb, int rc, int re) {
     const uint32_t w = (uint32_t)ra.y;
     const int op = (int)(w & 3u), prev = (int)((w >> 2) & 15u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
@@ -1376,13 +1386,13 @@ __device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long t
     if (op != C3R_CIG_I) {
         const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
         if (b0 < b1) {
-            const int odd = (int)((uint32_t)ra.z & 1u);                          // (w0:w1 = the 16 bytes from the piece's first base on)
+            const int odd = (int)(((uint32_t)ra.z + (uint32_t)boff) & 1u);      // the bases were loaded from nibble naddr + boff on
             for (int c = 0; c < nb; ++c) {
                 const int p = t0 + K.lpos[c];
                 if (p < b0) continue;
                 if (p >= b1) break;                           // (candidates ascend)
                 int base = 16;
-                if (op == C3R_CIG_M) base = (p - rstart) < avail ? nibble_at(w0, w1, odd + (p - rstart)) : 15;
+                if (op == C3R_CIG_M) base = (p - rstart) < avail ? nibble_at(w0, w1, odd + (p - rstart) - boff) : 15;
                 int indel = 0; uint32_t qpos = 0;
                 if (p == rstart + len - 1 && rb.z != 0) {
                     // htslib: the op after the one that ends on the column (k_prep has looked ahead)
@@ -1408,6 +1418,7 @@ template <class CandFn>
 __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0, int t1, int region, int lo, int hi, int rlo, int rhi, int nc, CandFn &&cand,
                                             c3r_token_t *tok, long long tok_cap) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     for (int cb = 0; cb < nc; cb += TK_NB) {
         const int nb = min(TK_NB, nc - cb);
         __syncthreads();
@@ -1444,28 +1455,36 @@ __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0
             for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
                 int4 ra[WALK_UNR], rb[WALK_UNR];
                 bool have[WALK_UNR];
-                uint64_t w0[WALK_UNR], w1[WALK_UNR];
 #pragma unroll
                 for (int u = 0; u < WALK_UNR; ++u) {
                     const int iu = base + u * SCAN_THREADS + tid;
                     have[u] = iu < rhi;
-                    const int at = have[u] ? iu : rhi - 1;
-                    const int4 *rec = reinterpret_cast<const int4 *>(a.recs + at);
+                    const int4 *rec = reinterpret_cast<const int4 *>(a.recs + (have[u] ? iu : rhi - 1));
                     ra[u] = rec[0]; rb[u] = rec[1];
-                    const uint4 bs = a.rbase[at];
-                    w0[u] = (uint64_t)bs.x | ((uint64_t)bs.y << 32); w1[u] = (uint64_t)bs.z | ((uint64_t)bs.w << 32);
                 }
+                uint64_t w0[WALK_UNR], w1[WALK_UNR];
+                int boff[WALK_UNR];
 #pragma unroll
                 for (int u = 0; u < WALK_UNR; ++u) {
+                    w0[u] = 0; w1[u] = 0; boff[u] = 0;
                     const uint32_t w = (uint32_t)ra[u].y;
-                    const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u);
+                    const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
                     const bool body = op != C3R_CIG_I && ra[u].x <= c_hi && ra[u].x + len > c_lo;
                     const bool anchored = op != C3R_CIG_M && ra[u].x - 1 >= c_lo && ra[u].x - 1 <= c_hi;
                     if (!(body || anchored)) have[u] = false;
+                    if (have[u] && op == C3R_CIG_M) {
+                        boff[u] = max(ra[u].x, t0) - ra[u].x;
+                        if (boff[u] < avail) {
+                            const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)boff[u];
+                            u64x2 w;
+                            __builtin_memcpy(&w, a.seq + (na >> 1), 16);
+                            w0[u] = w[0]; w1[u] = w[1];
+                        }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < WALK_UNR; ++u)
-                    if (have[u]) tok_rec(K, tok, tok_cap, ra[u], rb[u], w0[u], w1[u], t0, t1, nb, rc, re);
+                    if (have[u]) tok_rec(K, tok, tok_cap, ra[u], rb[u], w0[u], w1[u], boff[u], t0, t1, nb, rc, re);
             }
             __syncthreads();
             for (int c = wave; c < nb; c += WAVES) {
@@ -1700,8 +1719,10 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             emit = (bits & ALL) == ALL;
             if (a.abl & 2048) emit = false;
         }
+        if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[9], now_ - t_tail); t_tail = now_; }
         int nc, nt;
         const int2 ex = block_excl_scan2(emit ? 1 : 0, emit ? o.cov : 0, M.scan_slot[1], &nc, &nt);
+        if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[10], now_ - t_tail); t_tail = now_; }
         const int rank = ex.x, tpre = ex.y;
         // per candidate (by rank): position in the span, depth for the window copy, tokens of the span's earlier candidates — the event
         // arrays are free by now
@@ -1716,6 +1737,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             s_row0 = shard * f.shard_rows + lrow;
             s_tok0 = shard * f.shard_toks + ltok;
             f.span_info[b] = make_int4(s_row0, nc, nt, s_tok0);
+            if (a.dbg) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[11], now_ - t_tail); t_tail = now_; }
         }
         __syncthreads();
         const int row0 = s_row0, tok0 = s_tok0;

@@ -125,9 +125,6 @@ struct SegWalk {
 };
 
 // ---- the pile table ---------------------------------------------------------------------------------------------------------
-#ifndef C3R_PREP_ABL
-#define C3R_PREP_ABL 0
-#endif
 #ifndef C3R_PREP_GRP
 #define C3R_PREP_GRP 16
 #endif
@@ -259,86 +256,140 @@ struct PrepArgs {
     int32_t min_mq, excl_flags;
     BinGeo geo;
     uint32_t *cnt;            // [nb] records per bin: counted up by k_prep<false>, counted down to zero by k_prep<true>
-    uint32_t *sc, *ec;        // [nb] reads that start in the bin / reads whose end falls into the 32 positions before the bin's last
-    const int4 *tab;          // [nb + 1] k_bin_scan's prefix sums (k_prep<true>)
+    uint32_t *sc, *ec;        // [nbc] per coarse bin: reads that start in it / reads that end in the 256 positions up to its first
+    const uint32_t *rec_off;  // [nb + 1] k_bin_scan's prefix sums (k_prep<true>)
     DevRead *out;             // [n_reads] headers, written by k_prep<false>
     uint8_t *serial;          // [n_reads] 1 = the read takes the serial walk
     int32_t *nind;            // [n_reads] I + D ops of the read, 0 when the filters drop it (summed by k_prefmax_bins: 54 k atomics on one
                               // word would take 0.6 ms)
     PileRec *recs;
-    uint4 *rbase;             // [records] the packed bases of every record (ScanArgs::rbase)
-    const uint8_t *seq;
     LoadStats *st;
 };
 
+// Bin counters are updated through a per-workgroup hash table in LDS: a workgroup's 64 reads are neighbours in the sorted input and
+// pile their records into the same few hundred bins, so it counts them in LDS and touches each global counter once.  One global
+// atomic per record (3.5 M per chr20 on ~60 k hot counters) ran at 35 G atomics/s and was 0.10 of the first pass's 0.145 ms
+// (tools/prep_probe.hip: 0.044 ms without them); coarser bins were slower still — it is contention on the counters, not their number.
+// (256 threads = 16 reads and 1024 slots measured best: 0.059 / 0.098 ms for the two passes against 0.085 / 0.128 with 1024 threads, where
+// a workgroup waits for the slowest of 64 reads)
+#ifndef C3R_PREP_THREADS
+#define C3R_PREP_THREADS 256
+#endif
+#ifndef C3R_HB_LOG
+#define C3R_HB_LOG 10
+#endif
+constexpr int PREP_THREADS = C3R_PREP_THREADS, PREP_READS = PREP_THREADS / PREP_GRP;
+constexpr int HB_LOG = C3R_HB_LOG, HB = 1 << HB_LOG, HB_PROBES = 16;
+struct BinHash { uint32_t key[HB], val[HB]; };              // key = bin + 1, 0 = empty
+// slot of `bin`, or -1: not there (insert: and no free slot among its HB_PROBES places — such a bin goes to the global counter directly,
+// in every walk alike, because an occupied slot never becomes free)
+__device__ __forceinline__ int hb_find(BinHash &T, uint32_t bin, bool insert) {
+    uint32_t h = (bin * 2654435761u) >> (32 - HB_LOG);
+    for (int p = 0; p < HB_PROBES; ++p, h = (h + 1) & (HB - 1)) {
+        uint32_t k = T.key[h];
+        if (k == bin + 1u) return (int)h;
+        if (k == 0u) {
+            if (!insert) return -1;
+            k = atomicCAS(&T.key[h], 0u, bin + 1u);
+            if (k == 0u || k == bin + 1u) return (int)h;
+        }
+    }
+    return -1;
+}
+
 template <bool WRITE>
-__global__ __launch_bounds__(256) void k_prep(const PrepArgs a) {
-    const int gl = (int)(threadIdx.x & (PREP_GRP - 1));
-    const int i = (int)(blockIdx.x * (256 / PREP_GRP) + (threadIdx.x / PREP_GRP));
-    if (i >= a.n_reads) return;
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
+    __shared__ BinHash T;
+    __shared__ uint32_t s_base[WRITE ? HB : 1];
+    const int tid = (int)threadIdx.x, gl = tid & (PREP_GRP - 1);
+    const int i = (int)(blockIdx.x * PREP_READS + (tid / PREP_GRP));
+    const bool valid = i < a.n_reads;
+    for (int h = tid; h < HB; h += PREP_THREADS) { T.key[h] = 0; T.val[h] = 0; }
+    __syncthreads();
     ReadInfo R;
+    R.cig = a.cigars; R.pos = 0; R.n_cig = 0; R.l_seq = 0; R.read_idx = (uint32_t)i; R.seq_off = 0; R.wbits = 0;
+    // every record of a passing read, counted in the workgroup's table (a bin that finds no place there: `spill`)
+    auto tally = [&](int32_t rstart, uint32_t, unsigned long long, uint32_t, int32_t, uint32_t) {
+        const int b = bin_of(a.geo, rstart);
+        const int s_ = hb_find(T, (uint32_t)b, true);
+        if (s_ >= 0) atomicAdd(&T.val[s_], 1u);
+        else if (!WRITE) __hip_atomic_fetch_add(&a.cnt[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     if (!WRITE) {
-        const c3r_read_t r = a.reads[i];
+        c3r_read_t r;
+        r.pos = 0; r.cigar_off = 0; r.n_cigar = 0; r.l_seq = 0; r.seq_off = 0; r.flag = 4; r.mapq = 0; r.hp = 0;
         int err = LD_OK;
-        if (i > 0 && r.pos < a.reads[i - 1].pos) err = LD_UNSORTED;
-        else if ((long long)r.cigar_off + r.n_cigar > a.n_cigar_ops) err = LD_CIGAR_RANGE;
-        else if ((long long)r.seq_off + (r.l_seq + 1) / 2 > a.n_seq_bytes) err = LD_SEQ_RANGE;
-        R.cig = a.cigars + r.cigar_off; R.pos = r.pos; R.n_cig = err ? 0u : r.n_cigar; R.l_seq = r.l_seq; R.read_idx = (uint32_t)i; R.seq_off = r.seq_off;
-        R.wbits = ((r.flag & 16u) ? 64u : 0u) | ((r.hp == 1 ? 1u : r.hp == 2 ? 2u : 0u) << 7);
         long long ref_len = 0;
         int n_indel = 0;
-        const bool plain = cigar_is_plain(R, gl, ref_len, n_indel);
-        const bool pass = !err && !flag_fails(r.flag, a.excl_flags) && r.mapq >= a.min_mq;
-        auto count = [&](int32_t rstart, uint32_t, unsigned long long, uint32_t, int32_t, uint32_t) {
-#if C3R_PREP_ABL & 1
-            if (pass && rstart == -12345) a.cnt[0] = 1;
-#else
-            if (pass) __hip_atomic_fetch_add(&a.cnt[bin_of(a.geo, rstart)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-        };
-        if (!err) {
-#if C3R_PREP_ABL & 2
-            if (plain) { if (pass && r.pos == -12345) walk_plain(R, gl, count); }
-#else
-            if (plain) { if (pass) walk_plain(R, gl, count); }
-#endif
-            else if (gl == 0) err = walk_serial(R, count);             // (also for a read the filters drop: its CIGAR is validated all the same)
-            if (!err && (long long)r.pos + ref_len > INT32_MAX) err = LD_END_2G;
+        bool plain = true, pass = false;
+        if (valid) {
+            r = a.reads[i];
+            if (i > 0 && r.pos < a.reads[i - 1].pos) err = LD_UNSORTED;
+            else if ((long long)r.cigar_off + r.n_cigar > a.n_cigar_ops) err = LD_CIGAR_RANGE;
+            else if ((long long)r.seq_off + (r.l_seq + 1) / 2 > a.n_seq_bytes) err = LD_SEQ_RANGE;
+            R.cig = a.cigars + r.cigar_off; R.pos = r.pos; R.n_cig = err ? 0u : r.n_cigar; R.l_seq = r.l_seq; R.seq_off = r.seq_off;
+            R.wbits = ((r.flag & 16u) ? 64u : 0u) | ((r.hp == 1 ? 1u : r.hp == 2 ? 2u : 0u) << 7);
+            plain = cigar_is_plain(R, gl, ref_len, n_indel);
+            pass = !err && !flag_fails(r.flag, a.excl_flags) && r.mapq >= a.min_mq;
+            if (!err) {
+                if (plain) { if (pass) walk_plain(R, gl, tally); }
+                else if (gl == 0) {                                        // (also for a read the filters drop: its CIGAR is validated all the same)
+                    if (pass) err = walk_serial(R, tally);
+                    else err = walk_serial(R, [](int32_t, uint32_t, unsigned long long, uint32_t, int32_t, uint32_t) {});
+                }
+                if (!err && (long long)r.pos + ref_len > INT32_MAX) err = LD_END_2G;
+            }
+            if (gl == 0) {
+                if (err) { load_fail(a.st, i, err); ref_len = 0; n_indel = 0; }
+                DevRead d;
+                d.pos = r.pos; d.end = (int32_t)(r.pos + ref_len); d.cig_off = r.cigar_off; d.n_cig = r.n_cigar; d.seq_off = r.seq_off;
+                d.flag = r.flag; d.mapq = r.mapq; d.hp = r.hp; d.l_seq = r.l_seq;
+                a.out[i] = d;
+                a.serial[i] = plain ? 0 : 1;
+                __hip_atomic_fetch_add(&a.sc[bin_of(a.geo, d.pos) >> CBIN_SHIFT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // counted as "ended at or before the start of coarse bin c" for every c > (ceil(end / 32) - base - 1) >> 3: k_bin_scan's exclusive
+                // sum over ec[j], j < c (later than true is safe: the sums bound the coverage from above)
+                int je = ((d.end + (1 << BIN_SHIFT) - 1) >> BIN_SHIFT) - a.geo.base - 1;
+                je = je < 0 ? 0 : je >= a.geo.nb ? a.geo.nb - 1 : je;
+                __hip_atomic_fetch_add(&a.ec[je >> CBIN_SHIFT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.nind[i] = pass ? n_indel : 0;
+            }
         }
-        if (gl == 0) {
-            if (err) { load_fail(a.st, i, err); ref_len = 0; n_indel = 0; }
-            DevRead d;
-            d.pos = r.pos; d.end = (int32_t)(r.pos + ref_len); d.cig_off = r.cigar_off; d.n_cig = r.n_cigar; d.seq_off = r.seq_off;
-            d.flag = r.flag; d.mapq = r.mapq; d.hp = r.hp; d.l_seq = r.l_seq;
-            a.out[i] = d;
-            a.serial[i] = plain ? 0 : 1;
-            __hip_atomic_fetch_add(&a.sc[bin_of(a.geo, d.pos)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // counted as "ended at or before the start of bin b" for every b >= ceil(end / 32) - base; k_bin_scan's exclusive sum over ec[j], j < b
-            int je = ((d.end + (1 << BIN_SHIFT) - 1) >> BIN_SHIFT) - a.geo.base - 1;
-            je = je < 0 ? 0 : je >= a.geo.nb ? a.geo.nb - 1 : je;
-            __hip_atomic_fetch_add(&a.ec[je], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.nind[i] = pass ? n_indel : 0;
-        }
+        __syncthreads();
+        for (int h = tid; h < HB; h += PREP_THREADS)
+            if (T.key[h]) __hip_atomic_fetch_add(&a.cnt[T.key[h] - 1u], T.val[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        const DevRead d = a.out[i];
-        if (flag_fails(d.flag, a.excl_flags) || d.mapq < a.min_mq) return;
-        R.cig = a.cigars + d.cig_off; R.pos = d.pos; R.n_cig = d.n_cig; R.l_seq = d.l_seq; R.read_idx = (uint32_t)i; R.seq_off = d.seq_off;
-        R.wbits = ((d.flag & 16u) ? 64u : 0u) | ((d.hp == 1 ? 1u : d.hp == 2 ? 2u : 0u) << 7);
+        bool pass = false, serial = false;
+        if (valid) {
+            const DevRead d = a.out[i];
+            pass = !(flag_fails(d.flag, a.excl_flags) || d.mapq < a.min_mq);
+            serial = a.serial[i] != 0;
+            R.cig = a.cigars + d.cig_off; R.pos = d.pos; R.n_cig = d.n_cig; R.l_seq = d.l_seq; R.seq_off = d.seq_off;
+            R.wbits = ((d.flag & 16u) ? 64u : 0u) | ((d.hp == 1 ? 1u : d.hp == 2 ? 2u : 0u) << 7);
+        }
+        // first walk: how many records this workgroup has for each of its bins; one atomic per bin takes that many slots (the counters
+        // count down: the workgroup's run in bin b is [rec_off[b] + left - n, rec_off[b] + left)); second walk: every record into its run
+        if (pass) { if (!serial) walk_plain(R, gl, tally); else if (gl == 0) (void)walk_serial(R, tally); }
+        __syncthreads();
+        for (int h = tid; h < HB; h += PREP_THREADS) {
+            if (!T.key[h]) continue;
+            const uint32_t b = T.key[h] - 1u, nrec = T.val[h];
+            const uint32_t left = __hip_atomic_fetch_add(&a.cnt[b], 0u - nrec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base[h] = a.rec_off[b] + (left - nrec);
+            T.val[h] = 0;
+        }
+        __syncthreads();
         auto put = [&](int32_t rstart, uint32_t w, unsigned long long naddr, uint32_t q, int32_t nxt, uint32_t aux) {
             const int b = bin_of(a.geo, rstart);
-            const uint32_t left = __hip_atomic_fetch_add(&a.cnt[b], ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // counts down
-            const size_t at = (size_t)(uint32_t)a.tab[b].x + (left - 1u);
-            // the 16 bytes that hold the piece's bases (M, I): copied next to the record, so that the tile walk's two loads are independent
-            // (the packed-base buffer is padded: the load may run past a read's last byte)
-            uint4 bs = make_uint4(0, 0, 0, 0);
-            if ((w & 3u) != C3R_CIG_D && ((w >> 14) & 31u) != 0) __builtin_memcpy(&bs, a.seq + (naddr >> 1), 16);
+            const int s_ = hb_find(T, (uint32_t)b, false);
+            size_t at;
+            if (s_ >= 0) at = (size_t)s_base[s_] + atomicAdd(&T.val[s_], 1u);
+            else at = (size_t)a.rec_off[b] + (__hip_atomic_fetch_add(&a.cnt[b], ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u);
             int4 *dst = reinterpret_cast<int4 *>(a.recs + at);
             dst[0] = make_int4(rstart, (int)w, (int)(uint32_t)naddr, (int)(uint32_t)(naddr >> 32));
             dst[1] = make_int4((int)q, i, nxt, (int)aux);
-            a.rbase[at] = bs;
         };
-        if (!a.serial[i]) walk_plain(R, gl, put);
-        else if (gl == 0) (void)walk_serial(R, put);
+        if (pass) { if (!serial) walk_plain(R, gl, put); else if (gl == 0) (void)walk_serial(R, put); }
     }
 }
 
@@ -373,10 +424,12 @@ __device__ __forceinline__ unsigned long long lb_lookback_op(unsigned long long 
     return excl;
 }
 
-// ---- inclusive prefix maximum of the ends of the reads that pass the filters (INT_MIN before the first), one pass; pc[j] += 1 for
-// every read whose prefix maximum lies in bin j (reads before the first passing read: bin 0).  Also the two totals k_prep<false> left
-// per read: the largest end of a passing read (= the last prefix maximum) and the I + D ops.
-constexpr int PM_IT = 4, PM_BLK = 1024 * PM_IT;
+// ---- inclusive prefix maximum of the ends of the reads that pass the filters (INT_MIN before the first), one pass, one read per
+// thread; pc[c] += 1 for every read whose prefix maximum lies in coarse bin c (reads before the first passing read: bin 0) — a long
+// read's end is the prefix maximum of all the reads that follow it until a longer one comes, so equal neighbours inside a wavefront
+// are added with one atomic.  Also the two totals k_prep<false> left per read: the largest end of a passing read (= the last prefix
+// maximum) and the I + D ops.
+constexpr int PM_BLK = 1024;
 __global__ __launch_bounds__(1024) void k_prefmax_bins(const DevRead *reads, int n, int min_mq, int excl, BinGeo geo, const int32_t *nind, int32_t *out, uint32_t *pc,
                                                        LoadStats *st, int32_t *ticket, unsigned long long *state) {
     __shared__ int s_b, wtot[16], s_ni[16];
@@ -384,18 +437,13 @@ __global__ __launch_bounds__(1024) void k_prefmax_bins(const DevRead *reads, int
     if (threadIdx.x == 0) s_b = atomicAdd(ticket, 1);
     __syncthreads();
     const int b = s_b, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = b * PM_BLK + (int)threadIdx.x * PM_IT;
-    int v[PM_IT], m = INT32_MIN, ni = 0;
-#pragma unroll
-    for (int k = 0; k < PM_IT; ++k) {
-        v[k] = INT32_MIN;
-        if (i0 + k < n) { const DevRead r = reads[i0 + k]; if (read_passes(r, min_mq, excl)) v[k] = r.end; ni += nind[i0 + k]; }
-        m = max(m, v[k]);
-    }
+    const int i = b * PM_BLK + (int)threadIdx.x;
+    int v = INT32_MIN, ni = 0;
+    if (i < n) { const DevRead r = reads[i]; if (read_passes(r, min_mq, excl)) v = r.end; ni = nind[i]; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ni += __shfl_xor(ni, off, 64);
     if (lane == 0) s_ni[wave] = ni;
-    int incl = m;
+    int incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl = max(incl, t); }
     if (lane == 63) wtot[wave] = incl;
@@ -409,89 +457,97 @@ __global__ __launch_bounds__(1024) void k_prefmax_bins(const DevRead *reads, int
     }
     __syncthreads();
     const int carry = s_excl ? (int)(s_excl - 1ull) : INT32_MIN;
-    int run = max(before, __shfl_up(incl, 1, 64));
-    if (lane == 0) run = before;
-    run = max(run, carry);
-    // a long read's end is the prefix maximum of all the reads that follow it until a longer one comes: a wavefront whose 256 reads
-    // share one value adds them with one atomic
-    const int first = max(run, v[0]);
-    int last = first;
-#pragma unroll
-    for (int k = 1; k < PM_IT; ++k) last = max(last, v[k]);
-    const int wfirst = __shfl(first, 0, 64);
-    const bool flat = __all(first == wfirst && last == wfirst && i0 + PM_IT <= n);
-    if (flat) {
-        if (lane == 0) __hip_atomic_fetch_add(&pc[wfirst > 0 ? bin_of(geo, wfirst) : 0], 64u * PM_IT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int run = max(max(before, carry), incl);
+    if (i < n) {
+        out[i] = run;
+        if (i == n - 1) st->max_end = max(run, 0);
     }
-#pragma unroll
-    for (int k = 0; k < PM_IT; ++k) {
-        run = max(run, v[k]);
-        if (i0 + k < n) {
-            out[i0 + k] = run;
-            if (!flat) __hip_atomic_fetch_add(&pc[run > 0 ? bin_of(geo, run) : 0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (i0 + k == n - 1) st->max_end = max(run, 0);
-        }
+    // one atomic per run of equal values inside the wavefront (the values never decrease)
+    const int key = i < n ? (run > 0 ? bin_of(geo, run) >> CBIN_SHIFT : 0) : -1;
+    const int prev = __shfl_up(key, 1, 64);
+    const unsigned long long heads = __ballot(key >= 0 && (lane == 0 || prev != key)), live = __ballot(key >= 0);
+    if (key >= 0 && (lane == 0 || prev != key)) {
+        const unsigned long long later = heads & ~((2ull << lane) - 1ull);        // the next head after this lane
+        const int end_lane = later ? __ffsll((long long)later) - 1 : 64;
+        const unsigned long long mine = live & (end_lane >= 64 ? ~0ull : ((1ull << end_lane) - 1ull)) & ~((1ull << lane) - 1ull);
+        __hip_atomic_fetch_add(&pc[key], (uint32_t)__popcll(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s_ni[w]; if (t) atomicAdd(&st->n_indel, t); }
 }
 
-// ---- the bins' prefix sums, one pass.  Four counters per bin -> tab[b] (see BinGeo); sc / ec / pc are zeroed on the way (the next
-// load starts from clean counters; cnt counts down to zero in k_prep<true>), the totals go to tab[nb] and the LoadStats.
+// ---- the bins' prefix sums, one launch, decoupled look-back.  Blocks [0, nfine): records per bin -> rec_off (cnt stays: k_prep<true> counts
+// it down to zero).  Blocks [nfine, ...): the three read counters per coarse bin -> rtab, zeroed on the way (the next load starts from
+// clean counters), and the upper bound of the deepest coverage.  Totals to rec_off[nb], rtab[nbc] and the LoadStats.
 constexpr int BS_IT = 4, BS_BLK = 1024 * BS_IT;
-__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t *cnt, uint32_t *sc, uint32_t *pc, uint32_t *ec, int nb, int4 *tab, LoadStats *st,
-                                                   int32_t *ticket, unsigned long long *state_a, unsigned long long *state_b) {
+__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t *cnt, uint32_t *sc, uint32_t *pc, uint32_t *ec, BinGeo geo, int nfine, uint32_t *rec_off, int4 *rtab, LoadStats *st,
+                                                   int32_t *tickets /* [2] */, unsigned long long *state_f, unsigned long long *state_a, unsigned long long *state_b) {
     __shared__ int s_b;
     __shared__ uint4 wtot[16];
     __shared__ unsigned long long s_ea, s_eb;
     __shared__ int s_cov[16];
-    if (threadIdx.x == 0) s_b = atomicAdd(ticket, 1);
+    const bool fine = (int)blockIdx.x < nfine;
+    if (threadIdx.x == 0) s_b = atomicAdd(&tickets[fine ? 0 : 1], 1);
     __syncthreads();
     const int b = s_b, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = b * BS_BLK + (int)threadIdx.x * BS_IT;
+    const int n = fine ? geo.nb : geo.nbc;
     uint4 v[BS_IT], sum = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < BS_IT; ++k) {
         v[k] = make_uint4(0, 0, 0, 0);
-        if (i0 + k < nb) { v[k] = make_uint4(cnt[i0 + k], sc[i0 + k], pc[i0 + k], ec[i0 + k]); sc[i0 + k] = 0; pc[i0 + k] = 0; ec[i0 + k] = 0; }
-        sum.x += v[k].x; sum.y += v[k].y; sum.z += v[k].z; sum.w += v[k].w;
+        if (i0 + k < n) {
+            if (fine) v[k].x = cnt[i0 + k];
+            else { v[k] = make_uint4(sc[i0 + k], pc[i0 + k], ec[i0 + k], 0); sc[i0 + k] = 0; pc[i0 + k] = 0; ec[i0 + k] = 0; }
+        }
+        sum.x += v[k].x; sum.y += v[k].y; sum.z += v[k].z;
     }
     uint4 incl = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         uint4 t;
-        t.x = __shfl_up(incl.x, off, 64); t.y = __shfl_up(incl.y, off, 64); t.z = __shfl_up(incl.z, off, 64); t.w = __shfl_up(incl.w, off, 64);
-        if (lane >= off) { incl.x += t.x; incl.y += t.y; incl.z += t.z; incl.w += t.w; }
+        t.x = __shfl_up(incl.x, off, 64); t.y = __shfl_up(incl.y, off, 64); t.z = __shfl_up(incl.z, off, 64);
+        if (lane >= off) { incl.x += t.x; incl.y += t.y; incl.z += t.z; }
     }
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
     uint4 wb = make_uint4(0, 0, 0, 0), tot = wb;
-    for (int w = 0; w < 16; ++w) { const uint4 t = wtot[w]; if (w < wave) { wb.x += t.x; wb.y += t.y; wb.z += t.z; wb.w += t.w; } tot.x += t.x; tot.y += t.y; tot.z += t.z; tot.w += t.w; }
-    // two look-back chains of two 31-bit sums each (records | starts, prefix-max histogram | ends): waves 0 and 1
-    if (wave == 0) { const unsigned long long e = lb_lookback_op<false>(state_a, b, ((unsigned long long)tot.x << 31) | tot.y); if (lane == 0) s_ea = e; }
-    if (wave == 1) { const unsigned long long e = lb_lookback_op<false>(state_b, b, ((unsigned long long)tot.z << 31) | tot.w); if (lane == 0) s_eb = e; }
+    for (int w = 0; w < 16; ++w) { const uint4 t = wtot[w]; if (w < wave) { wb.x += t.x; wb.y += t.y; wb.z += t.z; } tot.x += t.x; tot.y += t.y; tot.z += t.z; }
+    // look-back chains: fine blocks one sum; coarse blocks two 31-bit sums (starts | prefix-max histogram) on wave 0 and the ends on wave 1
+    if (wave == 0) {
+        const unsigned long long e = fine ? lb_lookback_op<false>(state_f, b, (unsigned long long)tot.x) : lb_lookback_op<false>(state_a, b, ((unsigned long long)tot.x << 31) | tot.y);
+        if (lane == 0) s_ea = e;
+    }
+    if (wave == 1 && !fine) { const unsigned long long e = lb_lookback_op<false>(state_b, b, (unsigned long long)tot.z); if (lane == 0) s_eb = e; }
     __syncthreads();
-    const unsigned long long ea = s_ea, eb = s_eb;
+    const unsigned long long ea = s_ea, eb = fine ? 0ull : s_eb;
     uint4 run;
-    run.x = (uint32_t)(ea >> 31) + wb.x + incl.x - sum.x; run.y = (uint32_t)(ea & 0x7fffffffu) + wb.y + incl.y - sum.y;
-    run.z = (uint32_t)(eb >> 31) + wb.z + incl.z - sum.z; run.w = (uint32_t)(eb & 0x7fffffffu) + wb.w + incl.w - sum.w;
+    run.x = (fine ? (uint32_t)ea : (uint32_t)(ea >> 31)) + wb.x + incl.x - sum.x;
+    run.y = (fine ? 0u : (uint32_t)(ea & 0x7fffffffu)) + wb.y + incl.y - sum.y;
+    run.z = (uint32_t)eb + wb.z + incl.z - sum.z;
+    run.w = 0;
     int cov = 0;
 #pragma unroll
     for (int k = 0; k < BS_IT; ++k) {
-        if (i0 + k < nb) {
-            tab[i0 + k] = make_int4((int)run.x, (int)run.y, (int)run.z, (int)run.w);
-            cov = max(cov, (int)(run.y + v[k].y) - (int)run.w);                // reads started up to the end of the bin - reads ended before its start
+        if (i0 + k < n) {
+            if (fine) rec_off[i0 + k] = run.x;
+            else {
+                rtab[i0 + k] = make_int4((int)run.x, (int)run.y, (int)run.z, 0);
+                cov = max(cov, (int)(run.x + v[k].x) - (int)run.z);                // reads started up to the end of the coarse bin - reads ended before its start
+            }
         }
-        run.x += v[k].x; run.y += v[k].y; run.z += v[k].z; run.w += v[k].w;
-        if (i0 + k == nb - 1) {
-            tab[nb] = make_int4((int)run.x, (int)run.y, (int)run.z, (int)run.w);
-            st->n_rec = run.x >= 0x7fffffffu ? -1 : (int32_t)run.x;
+        run.x += v[k].x; run.y += v[k].y; run.z += v[k].z;
+        if (i0 + k == n - 1) {
+            if (fine) { rec_off[n] = run.x; st->n_rec = run.x >= 0x7fffffffu ? -1 : (int32_t)run.x; }
+            else rtab[n] = make_int4((int)run.x, (int)run.y, (int)run.z, 0);
         }
     }
+    if (!fine) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cov = max(cov, __shfl_xor(cov, off, 64));
-    if (lane == 0) s_cov[wave] = cov;
-    __syncthreads();
-    if (threadIdx.x == 0) { int m = 0; for (int w = 0; w < 16; ++w) m = max(m, s_cov[w]); if (m > 0) atomicMax(&st->max_cover, m); }
+        for (int off = 32; off > 0; off >>= 1) cov = max(cov, __shfl_xor(cov, off, 64));
+        if (lane == 0) s_cov[wave] = cov;
+        __syncthreads();
+        if (threadIdx.x == 0) { int m = 0; for (int w = 0; w < 16; ++w) m = max(m, s_cov[w]); if (m > 0) atomicMax(&st->max_cover, m); }
+    }
 }
 
 // ---- LEGACY tables: per-read normalised CIGARs and aligned segments in read order, for token_at (pileup_kernels.hpp) — the ordered
