@@ -1132,7 +1132,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             Launch L(ctx, "k_order_sites");
             hipLaunchKernelGGL(k_order_spans, dim3(nblk), dim3(256), 0, ctx->stream, (const int4 *)ctx->d_span.p, (const int32_t *)(lb + 20), (int32_t *)(lb + 40),
                                (unsigned long long *)(lb + lb_head + (size_t)nblk * 8), (int32_t *)ctx->d_spanbase.p, (int32_t *)(lb + 8));
-            hipLaunchKernelGGL(k_finalize_sites, dim3((unsigned)std::min<int64_t>((rows + 3) / 4 + 1, 8192)), dim3(256), 0, ctx->stream, z);
+            hipLaunchKernelGGL(k_finalize_sites, dim3((unsigned)std::min<int64_t>((rows + 15) / 16 + 1, 8192)), dim3(256), 0, ctx->stream, z);
         }
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan, lb + 8, 32, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan + 16, lb + lb_alloc, (size_t)ALLOC_SHARDS * ALLOC_STRIDE * 8, hipMemcpyDeviceToHost, ctx->stream));

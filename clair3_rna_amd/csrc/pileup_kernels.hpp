@@ -18,6 +18,7 @@
 //     coalesced, and selection, ordered compaction, the window gather (one wavefront per candidate) and the tokens are separate kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/c3r_types.h"
@@ -622,7 +623,8 @@ struct TileMem {
     EvRec ev[EV_LDS > 0 ? EV_LDS : 1];
     uint8_t evord[EV_LDS > 0 ? EV_LDS : 4];     // the captured events' indices, bucketed by position
 };
-struct TileOut { bool is_row, cand; int depth, cov; };
+struct TileOut { bool is_row, cand; int depth, cov; int rd_pos, rd_end; bool rd_rev; };     // rd_*: the header of read lo + tid as the coverage pass saw it
+                                                                                             // (end = INT32_MIN: filtered out / dropped / beyond hi) — the token pass's first 256 reads
 
 // The columns of the positions [t0, t1) (at most TILE of them, thread tid <-> position t0 + tid) from the reads [lo, hi) and the
 // records [slo, shi) of the pile table: accumulators in LDS, indel alleles, the per-position gates (src/create_tensor_pileup.py:259-299, :536-556),
@@ -812,6 +814,8 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
 #undef C3R_PHASE
     TileOut o;
     o.is_row = is_row; o.cand = cand; o.depth = depth; o.cov = my_cov;
+    o.rd_pos = rd0.pos; o.rd_rev = (rd0.flag & 16) != 0;
+    o.rd_end = (r0 < hi && read_passes(rd0, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, r0)) ? rd0.end : INT32_MIN;
     return o;
 }
 
@@ -1414,9 +1418,10 @@ __device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long t
 }
 
 // cand(k, lpos, toff): position (relative to t0) and first token slot of the tile's k-th candidate, ascending.
+// pre: null, or the caller's copy of the header of read lo + tid (TileOut::rd_*): the first 256 reads are then staged from registers
 template <class CandFn>
 __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0, int t1, int region, int lo, int hi, int rlo, int rhi, int nc, CandFn &&cand,
-                                            c3r_token_t *tok, long long tok_cap) {
+                                            c3r_token_t *tok, long long tok_cap, const TileOut *pre = nullptr) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     for (int cb = 0; cb < nc; cb += TK_NB) {
@@ -1431,6 +1436,7 @@ __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0
             const int re = min(hi, rc + TK_RCH), nr = re - rc, nblk = (nr + 63) >> 6;
             __syncthreads();
             for (int i = tid; i < nr; i += SCAN_THREADS) {
+                if (pre && rc == lo && i == tid) { K.pos[i] = pre->rd_pos; K.end[i] = pre->rd_end; K.rev[i] = pre->rd_rev ? 1 : 0; continue; }
                 const DevRead rd = a.reads[rc + i];
                 const bool pass = read_passes(rd, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, rc + i);
                 K.pos[i] = rd.pos; K.end[i] = pass ? rd.end : INT32_MIN; K.rev[i] = (rd.flag & 16) ? 1 : 0;
@@ -1800,7 +1806,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             TokLds &K = *reinterpret_cast<TokLds *>(M.cnt);
             tile_tokens(a, K, x0, x1, tg.region, rng.x, rng.y, rng.z, rng.w, nc, [&](int k, int &lp, int &off) {
                 lp = (int)M.amb[k]; off = f.tok_base + tok0 + M.evoff[k];
-            }, f.tok, (long long)f.tok_base + (long long)(shard + 1) * f.shard_toks);
+            }, f.tok, (long long)f.tok_base + (long long)(shard + 1) * f.shard_toks, &o);
         }
         }
         if (a.dbg && tid == 0) atomicAdd(&a.dbg[dbg_slot], wall_clock64() - t_tail);
@@ -1853,25 +1859,35 @@ struct FinalizeArgs {
 __global__ __launch_bounds__(256) void k_finalize_sites(const FinalizeArgs g) {
     if (*g.overflow) return;                                  // (some rows were never written: the host repeats the scan with larger buffers)
     const int n = g.n_shards * g.shard_rows;                  // the scan's row space; a shard's rows beyond what it handed out are holes
-    const int lane = (int)(threadIdx.x & 63), nw = (int)(gridDim.x * (blockDim.x >> 6));
-    for (int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); row < n; row += nw) {
+    // sixteen lanes per arrived row: the 52-byte site record leaves as thirteen dwords of one store instruction
+    static_assert(sizeof(c3r_site_t) == 52 && offsetof(c3r_site_t, ref33) == 8 && offsetof(c3r_site_t, n_tok) == 44, "c3r_site_t layout");
+    const int gl = (int)(threadIdx.x & 15), ng = (int)(gridDim.x * (blockDim.x >> 4));
+    for (int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4); row < n; row += ng) {
         const int sh = row / g.shard_rows;
         if (row - sh * g.shard_rows >= (int)(unsigned)g.alloc[sh * ALLOC_STRIDE]) continue;
         const CandMeta m = g.meta[row];
         const int4 si = g.span_info[m.span];
         const int i = g.span_base[m.span] + (row - si.x);
         const int pc = g.geo[m.slot / TILE].p0 + (m.slot % TILE);
-        if (g.sites) {
-            c3r_site_t *st = &g.sites[i];
-            if (lane < C3R_WINDOW) {
-                const int rp = pc - C3R_FLANK + lane - g.ref_beg0;
-                st->ref33[lane] = (rp >= 0 && rp < g.ref_len) ? (char)g.ref[rp] : 'A';
-            } else if (lane < C3R_WINDOW + 3) {
-                st->ref33[lane] = 0;
+        if (g.sites && gl < 13) {
+            uint32_t v;
+            if (gl == 0) v = (uint32_t)(pc + 1);
+            else if (gl == 1) v = (uint32_t)m.depth;
+            else if (gl == 11) v = (uint32_t)m.ncov;
+            else if (gl == 12) v = (uint32_t)(g.tok_base + si.w + m.tpre);
+            else {
+                v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = 4 * (gl - 2) + k;           // character of ref33[36]: 33 reference bases ('A' beyond the contig), then NULs
+                    const int rp = pc - C3R_FLANK + c - g.ref_beg0;
+                    const uint32_t ch = c >= C3R_WINDOW ? 0u : (rp >= 0 && rp < g.ref_len) ? (uint32_t)g.ref[rp] : (uint32_t)'A';
+                    v |= ch << (8 * k);
+                }
             }
-            if (lane == 0) { st->pos = pc + 1; st->depth = m.depth; st->n_tok = m.ncov; st->tok_off = (uint32_t)(g.tok_base + si.w + m.tpre); }
+            reinterpret_cast<uint32_t *>(&g.sites[i])[gl] = v;
         }
-        if (lane == 0) {
+        if (gl == 0) {
             if (g.cand_idx) g.cand_idx[i] = m.slot;
             g.win_idx[i] = g.row_base + row;
         }

@@ -39,7 +39,9 @@ def short(name):
 
 def counters(d):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+    # (gpurun merges every call's files into gpurun_out/: only the newest collection of a sub-directory belongs to this round's build)
+    files = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return per
@@ -51,9 +53,9 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", "prof", prec)
     out = os.path.join(ROOT, "profiles")
     # 1. kernel stats
-    st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    st = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if st:
-        text = open(st[0]).read()
+        text = open(st[-1]).read()
         open(os.path.join(out, "%s_kernel_stats_%s.csv" % (tag, prec)), "w").write(
             "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
             "--no_fast --no_resident --no_overlap --precision %s   (MI355X; durations in ns; one context: 1 priming + 1 warm-up + 2 timed passes, "
