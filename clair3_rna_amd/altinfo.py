@@ -43,6 +43,12 @@ def alt_dict_from_tokens(tokens, readset, ref_seq, ref_start, pos):
             k = "I" + ref_base + seq
             alt[k] = alt.get(k, 0) + 1
             ins_count += 1
+            da = int(tk["del_after"])
+            if da:                 # mpileup_compat = 1: `+<ins>-<del>`, the deletion is the read's next token on this column
+                a = pos - ref_start + 1
+                k = "D" + ref_seq[a:a + da]
+                alt[k] = alt.get(k, 0) + 1
+                del_count += 1
         elif ind < 0:
             a = pos - ref_start + 1
             k = "D" + ref_seq[a:a + (-ind)]

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("C3R_LIB") or os.path.join(HERE, "libc3r.so")        # C3R_LIB: A/B builds of the kernels (development)
 
 SITE_DTYPE = np.dtype([("pos", "<i4"), ("depth", "<i4"), ("ref33", "S36"), ("n_tok", "<i4"), ("tok_off", "<u4")], align=True)
-TOKEN_DTYPE = np.dtype([("read_idx", "<u4"), ("indel", "<i4"), ("qpos", "<u4"), ("base", "u1"), ("rev", "u1"), ("pad", "u1", (2,))],
+TOKEN_DTYPE = np.dtype([("read_idx", "<u4"), ("indel", "<i4"), ("qpos", "<u4"), ("base", "u1"), ("rev", "u1"), ("del_after", "<u2")],
                        align=True)
 assert SITE_DTYPE.itemsize == 52 and TOKEN_DTYPE.itemsize == 16
 
@@ -23,7 +23,7 @@ class Params(C.Structure):
     _fields_ = [("channels", C.c_int32), ("min_mq", C.c_int32), ("excl_flags", C.c_int32), ("min_coverage", C.c_int32),
                 ("snp_min_af", C.c_double), ("indel_min_af", C.c_double), ("head_tail", C.c_int32),
                 ("splice_padding", C.c_int32), ("genotyping_mode", C.c_int32), ("max_depth_rescale", C.c_int32),
-                ("max_depth", C.c_int32), ("reserved", C.c_int32)]
+                ("max_depth", C.c_int32), ("mpileup_compat", C.c_int32)]
 
 
 class C3RError(RuntimeError):

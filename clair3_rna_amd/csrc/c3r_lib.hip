@@ -306,7 +306,7 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
         PrepArgs a;
         memset(&a, 0, sizeof a);
         a.reads = (const c3r_read_t *)ctx->d_rawreads.p; a.n_reads = n; a.cigars = (const uint32_t *)ctx->d_rawcig.p;
-        a.n_cigar_ops = ctx->n_cigar_ops; a.n_seq_bytes = ctx->n_seq_bytes; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags;
+        a.n_cigar_ops = ctx->n_cigar_ops; a.n_seq_bytes = ctx->n_seq_bytes; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.compat = ctx->prm.mpileup_compat;
         a.geo = ctx->bins;
         uint32_t *cnt = (uint32_t *)ctx->d_bincnt.p;
         a.cnt = cnt; a.sc = cnt + nb; a.ec = a.sc + nbc; uint32_t *pc = a.ec + nbc;
@@ -344,6 +344,7 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
                 case LD_OP_LONG: return fail(ctx, C3R_EINVAL, "cigar op too long in read %lld", i);
                 case LD_END_2G: return fail(ctx, C3R_EINVAL, "read %lld ends beyond 2^31", i);
                 case LD_SEG_OPS: return fail(ctx, C3R_EINVAL, "read %lld: more than 65535 CIGAR ops between two N ops", i);
+                case LD_PAD_INS: return fail(ctx, C3R_EINVAL, "read %lld: a pad (P) next to an insertion is not supported with mpileup_compat = 1", i);
                 default: return fail(ctx, C3R_EINVAL, "invalid read %lld", i);
             }
         }
@@ -358,7 +359,7 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
     {
         PrepArgs a;
         memset(&a, 0, sizeof a);
-        a.n_reads = n; a.cigars = (const uint32_t *)ctx->d_rawcig.p; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.geo = ctx->bins;
+        a.n_reads = n; a.cigars = (const uint32_t *)ctx->d_rawcig.p; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.compat = ctx->prm.mpileup_compat; a.geo = ctx->bins;
         a.cnt = (uint32_t *)ctx->d_bincnt.p; a.rec_off = (const uint32_t *)ctx->d_binoff.p; a.out = (DevRead *)ctx->d_reads.p; a.serial = (uint8_t *)ctx->d_serial.p;
         a.recs = (PileRec *)ctx->d_recs.p;
         Launch L(ctx, "k_prep_write");
@@ -528,7 +529,9 @@ void *c3r_stream(c3r_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int c3r_set_params(c3r_ctx *ctx, const c3r_params_t *p) {
     if (!ctx || !p) return C3R_EINVAL;
     if (p->channels != C3R_CH && p->channels != C3R_CH_PHASED) return fail(ctx, C3R_EINVAL, "channels must be 18 or 30");
-    const bool refilter = p->min_mq != ctx->prm.min_mq || p->excl_flags != ctx->prm.excl_flags;
+    if (p->mpileup_compat != 0 && p->mpileup_compat != 1) return fail(ctx, C3R_EINVAL, "mpileup_compat must be 0 (samtools <= 1.10) or 1 (samtools >= 1.11)");
+    // (the pile table holds the records of the reads that pass the filters, with the indel look-ahead of the chosen samtools)
+    const bool refilter = p->min_mq != ctx->prm.min_mq || p->excl_flags != ctx->prm.excl_flags || p->mpileup_compat != ctx->prm.mpileup_compat;
     ctx->prm = *p;
     if (ctx->prm.max_depth_rescale <= 0) ctx->prm.max_depth_rescale = 144;
     ctx->last_scan_pruned = false;
@@ -776,7 +779,7 @@ static int depth_cap_mask(c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts
 static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int drop_words, int n_tiles) {
     memset(&a, 0, sizeof a);
     a.drop = d_drop; a.drop_words = drop_words;
-    a.reads = (const DevRead *)ctx->d_reads.p; a.seq = (const uint8_t *)ctx->d_seq.p; a.n_reads = ctx->n_reads;
+    a.reads = (const DevRead *)ctx->d_reads.p; a.seq = (const uint8_t *)ctx->d_seq.p; a.n_reads = ctx->n_reads; a.compat = ctx->prm.mpileup_compat;
     a.recs = (const PileRec *)ctx->d_recs.p; a.rec_off = (const uint32_t *)ctx->d_binoff.p; a.rtab = (const int4 *)ctx->d_rtab.p; a.bins = ctx->bins;
     a.n_tiles = n_tiles;
     a.ref = (const uint8_t *)ctx->d_ref.p; a.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); a.ref_len = (int32_t)ctx->ref_len;
@@ -1610,7 +1613,7 @@ int c3r_rows_decode(c3r_rows *r, const char *ctg, int qual, int show_ref, int64_
             const TokRec *rc_ = recs ? recs + rec_off[(size_t)i] : nullptr;      // this site's indel records, in token order
             alt_from_stream(sites[(size_t)i].n_tok, [tb, rc_](int k) mutable {
                 const uint8_t by = tb[k];
-                if (by & 0x80) { const TokRec &q = *rc_++; return TokView{by & 31, q.indel, q.read_idx, q.qpos}; }
+                if (by & 0x80) { const TokRec &q = *rc_++; return TokView{by & 31, q.indel, q.read_idx, q.qpos, q.del_after}; }
                 return TokView{by & 31, 0, 0u, 0u};
             }, get_read, refv, ref_start1, sites[(size_t)i].pos, alt, depth_tok);
             if (vcf_row(ctg, sites[(size_t)i].pos, sites[(size_t)i].ref33, sites[(size_t)i].depth, alt, probs + (size_t)i * C3R_NPROB, qual,

@@ -74,7 +74,7 @@ struct RefView {
     std::string substr(size_t a, size_t len) const { return std::string(p + a, len); }
 };
 // what the dictionary needs of one token; `next(i)` is called for i = 0 .. n-1 in order (a packed token stream keeps a cursor)
-struct TokView { int base; int32_t indel; uint32_t read_idx, qpos; };
+struct TokView { int base; int32_t indel; uint32_t read_idx, qpos, del_after; };
 template <typename NextTok, typename GetRead>
 inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
                             AltDict &alt, int &depth_out) {
@@ -101,6 +101,12 @@ inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView
                 k += c;
             }
             alt_add(alt, k, 1); ins_count++;
+            if (t.del_after) {             // mpileup_compat = 1: `+<ins>-<del>`, the deletion is the read's next token on this column
+                int64_t a = pos1 - ref_start1 + 1, e = a + (int64_t)t.del_after;
+                a = std::max<int64_t>(0, std::min<int64_t>(a, (int64_t)ref.size()));
+                e = std::max<int64_t>(a, std::min<int64_t>(e, (int64_t)ref.size()));
+                alt_add(alt, "D" + ref.substr((size_t)a, (size_t)(e - a)), 1); del_count++;
+            }
         } else if (t.indel < 0) {
             int64_t a = pos1 - ref_start1 + 1, e = a + (-t.indel);
             a = std::max<int64_t>(0, std::min<int64_t>(a, (int64_t)ref.size()));
@@ -115,7 +121,7 @@ inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView
 template <typename GetRead>
 inline void alt_from_tokens(const c3r_token_t *tk, int n, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
                             AltDict &alt, int &depth_out) {
-    alt_from_stream(n, [tk](int i) { return TokView{tk[i].base, tk[i].indel, tk[i].read_idx, tk[i].qpos}; }, get_read, ref, ref_start1, pos1, alt, depth_out);
+    alt_from_stream(n, [tk](int i) { return TokView{tk[i].base, tk[i].indel, tk[i].read_idx, tk[i].qpos, tk[i].del_after}; }, get_read, ref, ref_start1, pos1, alt, depth_out);
 }
 
 // ---------------------------------------------------------------------------------------------- call_site

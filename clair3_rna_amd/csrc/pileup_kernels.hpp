@@ -85,6 +85,8 @@ struct PileRec {
     uint32_t aux;       // I: inserted bases; D: length of the whole deletion
 };
 static_assert(sizeof(PileRec) == 32, "PileRec must be 32 bytes");
+constexpr uint32_t PR_DEL_AFTER_INS = 1u << 19;    // w, first piece of a D that follows an insertion at once (mpileup_compat = 1): samtools >= 1.11 shows
+                                                    // the deletion on the insertion's column as well
 constexpr int OP_CHOP = 30;    // 30 bases + an odd start nibble fit the 32 nibbles of a 16-byte load
 
 // The bins of the pile table: 32 reference positions each, covering [base << 5, (base + nb) << 5).  Two tables of prefix sums (k_bin_scan):
@@ -135,6 +137,7 @@ struct ScanArgs {
     const DevRead *reads;
     const uint8_t *seq;
     int32_t n_reads;
+    int32_t compat;               // c3r_params_t::mpileup_compat (the records were built for it)
     const PileRec *recs;          // the pile table
     const uint32_t *rec_off;      // [bins.nb + 1] first record of every bin
     const int4 *rtab;             // [bins.nbc + 1] read-range prefix sums per coarse bin (BinGeo)
@@ -354,7 +357,7 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
     // I needs a ref-consuming predecessor (k_prep leaves no record otherwise), D needs an M or N predecessor (its first piece only: the
     // later pieces of a cut deletion have D before them).
     const bool is_ins = (op == C3R_CIG_I) && (prev == C3R_CIG_M || prev == C3R_CIG_D || prev == C3R_CIG_N);
-    const bool is_del = (op == C3R_CIG_D) && (prev == C3R_CIG_M || prev == C3R_CIG_N);
+    const bool is_del = (op == C3R_CIG_D) && (prev == C3R_CIG_M || prev == C3R_CIG_N || (w & PR_DEL_AFTER_INS));
     if (!(is_ins || is_del)) return;
     const int anchor = rstart - 1;
     if (anchor < t0 || anchor >= t1) return;
@@ -388,7 +391,9 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
         if (is_ins) ch = up ? C3R_I : C3R_i;
         else { ch = rev ? C3R_d : C3R_D; atomicMax(&s.maxdel[pl], ilen); }
         atomicAdd(&s.cnt[pl * C + ch], 1);
-        if (C == C3R_CH_PHASED) {
+        // (a deletion shown right behind an insertion takes the haplotype of the previous token-list ENTRY — the insertion's, '0':
+        // src/create_tensor_pileup.py:188-193)
+        if (C == C3R_CH_PHASED && !(w & PR_DEL_AFTER_INS)) {
             if (hp == 1) atomicAdd(&s.cnt[pl * C + (is_ins ? C3R_IP : C3R_DP)], 1);
             else if (hp == 2) atomicAdd(&s.cnt[pl * C + (is_ins ? C3R_IM : C3R_DM)], 1);
         }
@@ -1368,14 +1373,15 @@ struct TokLds {
     int32_t lpos[TK_NB], toff[TK_NB], rank0[TK_NB], rank1[TK_NB];
 };
 
-__device__ __forceinline__ void tok_emit(TokLds &K, c3r_token_t *tok, long long tok_cap, int c, int ri, int r, int indel, uint32_t qpos, int base, bool rev) {
+__device__ __forceinline__ void tok_emit(TokLds &K, c3r_token_t *tok, long long tok_cap, int c, int ri, int r, int indel, uint32_t qpos, int base, bool rev,
+                                         uint32_t del_after = 0) {
     const int b = ri >> 6, bit = ri & 63;
     const unsigned long long m = K.mask[c][b];
     if (!((m >> bit) & 1ull)) return;                         // (not a covering read by its header: nothing to place)
     const long long slot = (long long)K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << bit) - 1ull));
     if (slot >= tok_cap) return;
     int4 v;
-    v.x = r; v.y = indel; v.z = (int)qpos; v.w = base | ((rev ? 1 : 0) << 8);
+    v.x = r; v.y = indel; v.z = (int)qpos; v.w = base | ((rev ? 1 : 0) << 8) | (int)(min(del_after, 65535u) << 16);
     *reinterpret_cast<int4 *>(&tok[slot]) = v;
     atomicOr(&K.done[c][b], 1ull << bit);
 }
@@ -1397,13 +1403,13 @@ __device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long t
                 if (p >= b1) break;                           // (candidates ascend)
                 int base = 16;
                 if (op == C3R_CIG_M) base = (p - rstart) < avail ? nibble_at(w0, w1, odd + (p - rstart) - boff) : 15;
-                int indel = 0; uint32_t qpos = 0;
+                int indel = 0; uint32_t qpos = 0, dafter = 0;
                 if (p == rstart + len - 1 && rb.z != 0) {
                     // htslib: the op after the one that ends on the column (k_prep has looked ahead)
                     indel = rb.z;
-                    if (indel > 0) qpos = (uint32_t)rb.x + (op == C3R_CIG_M ? (uint32_t)len : 0u);
+                    if (indel > 0) { qpos = (uint32_t)rb.x + (op == C3R_CIG_M ? (uint32_t)len : 0u); dafter = op == C3R_CIG_M ? (uint32_t)rb.w : (uint32_t)ra.z; }
                 }
-                tok_emit(K, tok, tok_cap, c, r - rc, r, indel, qpos, base, rev);
+                tok_emit(K, tok, tok_cap, c, r - rc, r, indel, qpos, base, rev, dafter);
             }
         }
     }
@@ -1413,7 +1419,8 @@ __device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long t
         if (anchor >= t0 && anchor < t1)
             for (int c = 0; c < nb; ++c)
                 if (t0 + K.lpos[c] == anchor)
-                    tok_emit(K, tok, tok_cap, c, r - rc, r, op == C3R_CIG_I ? (int)(uint32_t)rb.w : -(int)(uint32_t)rb.w, op == C3R_CIG_I ? (uint32_t)rb.x : 0u, 17, rev);
+                    tok_emit(K, tok, tok_cap, c, r - rc, r, op == C3R_CIG_I ? (int)(uint32_t)rb.w : -(int)(uint32_t)rb.w, op == C3R_CIG_I ? (uint32_t)rb.x : 0u, 17, rev,
+                             (op == C3R_CIG_I && rb.z < 0) ? (uint32_t)(-rb.z) : 0u);
     }
 }
 
@@ -1930,8 +1937,8 @@ __global__ __launch_bounds__(256) void k_export_tokens(const c3r_site_t *sites, 
 // turns its tokens into one byte each (base code | 0x80 when an indel record follows) and appends the indel records (12 bytes,
 // token order kept by a ballot prefix) to a contiguous range it draws from one counter: a 250-Mb contig copies out ~60 MB instead
 // of 760 MB.
-struct TokRec { uint32_t read_idx; int32_t indel; uint32_t qpos; };
-static_assert(sizeof(TokRec) == 12, "TokRec must be 12 bytes");
+struct TokRec { uint32_t read_idx; int32_t indel; uint32_t qpos; uint32_t del_after; };
+static_assert(sizeof(TokRec) == 16, "TokRec must be 16 bytes");
 
 __global__ __launch_bounds__(256) void k_pack_tokens(const c3r_site_t *__restrict__ sites, const c3r_token_t *__restrict__ tok, int64_t n_sites,
                                                       uint8_t *__restrict__ bytes, TokRec *__restrict__ recs, uint32_t *__restrict__ rec_off,
@@ -1959,7 +1966,7 @@ __global__ __launch_bounds__(256) void k_pack_tokens(const c3r_site_t *__restric
         const bool f = valid && t.indel != 0;
         const unsigned long long m = __ballot(f);
         if (valid) bytes[off + i] = (uint8_t)((t.base & 31) | (f ? 0x80 : 0));
-        if (f) recs[base + run + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = TokRec{t.read_idx, t.indel, t.qpos};
+        if (f) recs[base + run + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = TokRec{t.read_idx, t.indel, t.qpos, t.del_after};
         run += (uint32_t)__popcll(m);
     }
 }

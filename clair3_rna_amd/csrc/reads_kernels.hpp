@@ -34,7 +34,7 @@ struct LoadStats {
     int32_t pad[2];
 };
 static_assert(sizeof(LoadStats) == 32, "LoadStats layout");
-enum { LD_OK = 0, LD_UNSORTED = 1, LD_CIGAR_RANGE, LD_SEQ_RANGE, LD_BAD_OP, LD_OP_LONG, LD_END_2G, LD_SEG_OPS, LD_RECORDS };
+enum { LD_OK = 0, LD_UNSORTED = 1, LD_CIGAR_RANGE, LD_SEQ_RANGE, LD_BAD_OP, LD_OP_LONG, LD_END_2G, LD_SEG_OPS, LD_RECORDS, LD_PAD_INS };
 
 __device__ __forceinline__ void load_fail(LoadStats *st, int read, int code) {
     atomicMin(&st->err, ((unsigned long long)(unsigned)read << 8) | (unsigned)code);
@@ -135,35 +135,46 @@ struct ReadInfo {
     int32_t pos;
     uint32_t n_cig, l_seq, read_idx, wbits;   // wbits: strand and haplotype bits of PileRec::w
     uint64_t seq_off;
+    int32_t compat;                           // c3r_params_t::mpileup_compat
 };
+// an op's neighbours in the normalised CIGAR (15 = none)
+struct OpCtx { uint32_t prev, prev2, nop, nlen, n2op, n2len; };
 
 // The records of ONE normalised op (code, length, reference / query offsets of its first base, the read's previous and next op).
 //   M, D: one record per OP_CHOP reference positions; the last piece carries the indel htslib attaches to the op's last column
 //         (an I after M / D, a D after M); I: one record, only when its predecessor consumes the reference (M, D, N) — otherwise
 //         samtools shows no insertion; N, S, P: none.
+// mpileup_compat = 1 (samtools >= 1.11, bam_plp_insertion): a D that follows an insertion AT ONCE is shown on the insertion's column too
+// (`C+2TT-1N`): the piece that carries the insertion also carries that deletion's length (M: aux, D: naddr; an I after a ref-skip: -nxt),
+// and the D's first piece is marked (PR_DEL_AFTER_INS) as a deletion event on the column before it.
 // emit(rstart, w, naddr, q, nxt, aux).
 template <class Emit>
-__device__ __forceinline__ void op_records(const ReadInfo &R, uint32_t op, uint32_t len, long long x, uint32_t y, uint32_t prev, uint32_t nop, uint32_t nlen,
-                                           Emit &&emit) {
+__device__ __forceinline__ void op_records(const ReadInfo &R, uint32_t op, uint32_t len, long long x, uint32_t y, const OpCtx c, Emit &&emit) {
+    const uint32_t prev = c.prev, nop = c.nop, nlen = c.nlen;
+    const uint32_t del_after = (R.compat && nop == C3R_CIG_I && c.n2op == C3R_CIG_D) ? c.n2len : 0u;     // (this op consumes the reference)
     if (op == C3R_CIG_M) {
         const int32_t nxt_last = nop == C3R_CIG_I ? (int32_t)nlen : nop == C3R_CIG_D ? -(int32_t)nlen : 0;
         for (uint32_t d = 0; d < len; d += OP_CHOP) {
             const uint32_t pl = min((uint32_t)OP_CHOP, len - d), q = y + d;
             const uint32_t avail = q >= R.l_seq ? 0u : min(pl, R.l_seq - q);           // (a CIGAR may claim more bases than SEQ holds)
             const uint32_t w = (uint32_t)C3R_CIG_M | ((d ? (uint32_t)C3R_CIG_M : prev) << 2) | R.wbits | (pl << 9) | (avail << 14);
-            emit((int32_t)(x + d), w, 2ull * R.seq_off + q, q, d + OP_CHOP >= len ? nxt_last : 0, 0u);
+            const bool last = d + OP_CHOP >= len;
+            emit((int32_t)(x + d), w, 2ull * R.seq_off + q, q, last ? nxt_last : 0, last ? del_after : 0u);
         }
     } else if (op == C3R_CIG_D) {
         const int32_t nxt_last = nop == C3R_CIG_I ? (int32_t)nlen : 0;
+        const bool ins_before = R.compat && prev == C3R_CIG_I && (c.prev2 == C3R_CIG_M || c.prev2 == C3R_CIG_D || c.prev2 == C3R_CIG_N);
         for (uint32_t d = 0; d < len; d += OP_CHOP) {
             const uint32_t pl = min((uint32_t)OP_CHOP, len - d);
-            const uint32_t w = (uint32_t)C3R_CIG_D | ((d ? (uint32_t)C3R_CIG_D : prev) << 2) | R.wbits | (pl << 9);
-            emit((int32_t)(x + d), w, 0ull, y, d + OP_CHOP >= len ? nxt_last : 0, len);
+            const uint32_t w = (uint32_t)C3R_CIG_D | ((d ? (uint32_t)C3R_CIG_D : prev) << 2) | R.wbits | (pl << 9) | ((!d && ins_before) ? PR_DEL_AFTER_INS : 0u);
+            const bool last = d + OP_CHOP >= len;
+            emit((int32_t)(x + d), w, last ? (unsigned long long)del_after : 0ull, y, last ? nxt_last : 0, len);
         }
     } else if (op == C3R_CIG_I) {
         if (prev == C3R_CIG_M || prev == C3R_CIG_D || prev == C3R_CIG_N) {
             const uint32_t avail = y >= R.l_seq ? 0u : min(31u, R.l_seq - y);
-            emit((int32_t)x, (uint32_t)C3R_CIG_I | (prev << 2) | R.wbits | (avail << 14), 2ull * R.seq_off + y, y, 0, len);
+            emit((int32_t)x, (uint32_t)C3R_CIG_I | (prev << 2) | R.wbits | (avail << 14), 2ull * R.seq_off + y, y,
+                 (R.compat && nop == C3R_CIG_D) ? -(int32_t)nlen : 0, len);
         }
     }
 }
@@ -210,9 +221,14 @@ __device__ __forceinline__ void walk_plain(const ReadInfo &R, int gl, Emit &&emi
         const uint32_t k = k0 + (uint32_t)gl;
         const bool in = k < R.n_cig;
         const uint32_t c = in ? R.cig[k] : 0u, op = in ? fold_op(c) : (uint32_t)C3R_CIG_H, len = c >> 4;
-        uint32_t prev = 15u, nop = 15u, nlen = 0;
-        if (in && k > 0) { prev = fold_op(R.cig[k - 1]); if (prev == C3R_CIG_H) prev = 15u; }
-        if (in && k + 1 < R.n_cig) { const uint32_t cn = R.cig[k + 1]; nop = fold_op(cn); nlen = cn >> 4; if (nop == C3R_CIG_H) nop = 15u; }
+        OpCtx cx;
+        cx.prev = 15u; cx.prev2 = 15u; cx.nop = 15u; cx.nlen = 0; cx.n2op = 15u; cx.n2len = 0;
+        if (in && k > 0) { cx.prev = fold_op(R.cig[k - 1]); if (cx.prev == C3R_CIG_H) cx.prev = 15u; }
+        if (in && k + 1 < R.n_cig) { const uint32_t cn = R.cig[k + 1]; cx.nop = fold_op(cn); cx.nlen = cn >> 4; if (cx.nop == C3R_CIG_H) cx.nop = 15u; }
+        if (R.compat && in) {          // the op after an insertion that follows / the op before an insertion that precedes
+            if (cx.nop == C3R_CIG_I && k + 2 < R.n_cig) { const uint32_t c2 = R.cig[k + 2]; cx.n2op = fold_op(c2); cx.n2len = c2 >> 4; if (cx.n2op == C3R_CIG_H) cx.n2op = 15u; }
+            if (cx.prev == C3R_CIG_I && k > 1) { cx.prev2 = fold_op(R.cig[k - 2]); if (cx.prev2 == C3R_CIG_H) cx.prev2 = 15u; }
+        }
         const uint32_t rl = op_ref(op) ? len : 0u, ql = op_qry(op) ? len : 0u;
         uint32_t ri = rl, qi = ql;
 #pragma unroll
@@ -220,32 +236,54 @@ __device__ __forceinline__ void walk_plain(const ReadInfo &R, int gl, Emit &&emi
             const uint32_t tr = __shfl_up(ri, off, PREP_GRP), tq = __shfl_up(qi, off, PREP_GRP);
             if (gl >= off) { ri += tr; qi += tq; }
         }
-        if (in) op_records(R, op, len, (long long)(int32_t)(x + ri - rl), y + qi - ql, prev, nop, nlen, emit);
+        if (in) op_records(R, op, len, (long long)(int32_t)(x + ri - rl), y + qi - ql, cx, emit);
         x += __shfl(ri, PREP_GRP - 1, PREP_GRP);
         y += __shfl(qi, PREP_GRP - 1, PREP_GRP);
     }
 }
 
-// The serial walk (one lane): walk_norm's stream, one op of look-ahead for the indel attached to an op's last column.  Returns the
-// error code of the normalised form (unknown op, a merged op of 2^28 or more, more than 65535 ops between two N ops).
+// The serial walk (one lane): walk_norm's stream, two ops of look-ahead (the indel attached to an op's last column, and with
+// mpileup_compat the deletion right behind that insertion).  Returns the error code of the normalised form (unknown op, a merged op of
+// 2^28 or more, more than 65535 ops between two N ops).
+// mpileup_compat = 1: samtools >= 1.11 prints the pads INSIDE an insertion as '*' (`+3T*T`); that text is not produced here, and a read
+// whose CIGAR has a pad next to an insertion is refused (LD_PAD_INS) rather than shown the <= 1.10 way (long-read RNA aligners emit no pads).
 template <class Emit>
 __device__ __forceinline__ int walk_serial(const ReadInfo &R, Emit &&emit) {
+    if (R.compat) {
+        bool has_i = false, has_p = false;
+        for (uint32_t k = 0; k < R.n_cig; ++k) {
+            const uint32_t c = R.cig[k], op = c & 15u;
+            if ((c >> 4) == 0 || op == C3R_CIG_H) continue;
+            if (op == C3R_CIG_I) has_i = true; else if (op == C3R_CIG_P) has_p = true; else { has_i = false; has_p = false; }
+            if (has_i && has_p) return LD_PAD_INS;
+        }
+    }
     SegWalk w;
     w.begin(R.pos);
     auto seg = [](uint32_t, uint32_t, long long, uint32_t, long long, bool, bool) {};
-    bool have = false;
-    uint32_t pop = 0, plen = 0, py = 0, pprev = 15u, prev = 15u, y = 0;
-    long long px = 0, x = R.pos;
+    struct NOp { uint32_t op, len, y, prev, prev2; long long x; };
+    NOp q[2];
+    int nq = 0;
+    uint32_t prev = 15u, prev2 = 15u, y = 0;
+    long long x = R.pos;
+    auto flush = [&](const NOp &o, uint32_t nop, uint32_t nlen, uint32_t n2op, uint32_t n2len) {
+        OpCtx cx;
+        cx.prev = o.prev; cx.prev2 = o.prev2; cx.nop = nop; cx.nlen = nlen; cx.n2op = n2op; cx.n2len = n2len;
+        op_records(R, o.op, o.len, o.x, o.y, cx, emit);
+    };
     const int err = walk_norm(R.cig, R.n_cig, [&](uint32_t op, uint32_t len) {
-        if (have) op_records(R, pop, plen, px, py, pprev, op, len, emit);
-        pop = op; plen = len; px = x; py = y; pprev = prev; have = true;
+        NOp c;
+        c.op = op; c.len = len; c.y = y; c.prev = prev; c.prev2 = prev2; c.x = x;
+        if (nq == 2) { flush(q[0], q[1].op, q[1].len, op, len); q[0] = q[1]; q[1] = c; }
+        else q[nq++] = c;
         if (op_ref(op)) x += len;
         if (op_qry(op)) y += len;
-        prev = op;
+        prev2 = prev; prev = op;
         w.op(op, len, seg);
     });
     if (err) return err;
-    if (have) op_records(R, pop, plen, px, py, pprev, 15u, 0u, emit);
+    if (nq == 2) { flush(q[0], q[1].op, q[1].len, 15u, 0u); flush(q[1], 15u, 0u, 15u, 0u); }
+    else if (nq == 1) flush(q[0], 15u, 0u, 15u, 0u);
     w.close(seg);
     return w.bad;
 }
@@ -253,7 +291,7 @@ __device__ __forceinline__ int walk_serial(const ReadInfo &R, Emit &&emit) {
 struct PrepArgs {
     const c3r_read_t *reads; int32_t n_reads;
     const uint32_t *cigars; long long n_cigar_ops, n_seq_bytes;
-    int32_t min_mq, excl_flags;
+    int32_t min_mq, excl_flags, compat;
     BinGeo geo;
     uint32_t *cnt;            // [nb] records per bin: counted up by k_prep<false>, counted down to zero by k_prep<true>
     uint32_t *sc, *ec;        // [nbc] per coarse bin: reads that start in it / reads that end in the 256 positions up to its first
@@ -307,7 +345,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
     for (int h = tid; h < HB; h += PREP_THREADS) { T.key[h] = 0; T.val[h] = 0; }
     __syncthreads();
     ReadInfo R;
-    R.cig = a.cigars; R.pos = 0; R.n_cig = 0; R.l_seq = 0; R.read_idx = (uint32_t)i; R.seq_off = 0; R.wbits = 0;
+    R.cig = a.cigars; R.pos = 0; R.n_cig = 0; R.l_seq = 0; R.read_idx = (uint32_t)i; R.seq_off = 0; R.wbits = 0; R.compat = a.compat;
     // every record of a passing read, counted in the workgroup's table (a bin that finds no place there: `spill`)
     auto tally = [&](int32_t rstart, uint32_t, unsigned long long, uint32_t, int32_t, uint32_t) {
         const int b = bin_of(a.geo, rstart);

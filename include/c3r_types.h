@@ -63,7 +63,10 @@ typedef struct c3r_params {
     int32_t  max_depth;       /* samtools mpileup -d: reads beyond this many live reads are discarded (htslib's
                                  rule, see c3r_pileup_scan); default 8000 = mpileup's own default, which the reference
                                  leaves in force (src/create_tensor_pileup.py:442); 0 = no cap                  */
-    int32_t  reserved;        /* must be 0                                                          */
+    int32_t  mpileup_compat;  /* which samtools the column text is restated from (run_clair3_rna:159,166 only sets a floor of 1.10):
+                                 0 = samtools <= 1.10 (default): an I immediately followed by a D shows the insertion only (`C+2TT`);
+                                 1 = samtools >= 1.11 (bam_plp_insertion): it shows both (`C+2TT-1N`), which the reference's parser
+                                     (src/create_tensor_pileup.py:151-163) reads as an insertion token AND a deletion token         */
 } c3r_params_t;
 
 /* One emitted candidate site (the non-tensor fields of a create_tensor output line,
@@ -84,7 +87,8 @@ typedef struct c3r_token {
     uint32_t qpos;        /* query offset of the first inserted base (valid when indel > 0) */
     uint8_t  base;        /* 4-bit BAM base code; 16 = '*'/'#' (inside deletion); 17 = ref-skip */
     uint8_t  rev;         /* 1 = reverse strand */
-    uint8_t  pad[2];
+    uint16_t del_after;   /* mpileup_compat = 1, indel > 0: length of the deletion that follows the insertion at once (0: none;
+                             saturates at 65535) — a second indel token of the read on this column, after the insertion */
 } c3r_token_t;
 
 #ifdef __cplusplus

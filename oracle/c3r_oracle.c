@@ -83,7 +83,7 @@ typedef struct {
     int64_t end;   /* last reference position covered (inclusive) */
 } cursor_t;
 
-typedef struct { int is_del, is_refskip, indel, is_head, is_tail; int64_t qpos; } plp_t;
+typedef struct { int is_del, is_refskip, indel, is_head, is_tail; int64_t qpos; int ins_k; /* first op behind the one on the column (indel > 0) */ } plp_t;
 
 /* Resolve what read r shows at reference position `pos` (0-based).  Restates the htslib column
  * resolution: locate the op covering pos; at the LAST position of that op peek the following op:
@@ -116,6 +116,7 @@ static void resolve(const c3r_read_t *r, const uint32_t *cg, cursor_t *s, int64_
     }
     int op = cig_op(cg[s->k]), l = cig_len(cg[s->k]);
     p->is_del = p->indel = p->is_refskip = 0;
+    p->ins_k = s->k + 1;
     if (s->x + l - 1 == pos && s->k + 1 < n) {
         int op2 = cig_op(cg[s->k + 1]), l2 = cig_len(cg[s->k + 1]);
         if (op2 == C3R_CIG_D && op != C3R_CIG_D) {
@@ -163,6 +164,14 @@ static int bed_contains(const int32_t *bed, int n_bed, int64_t pos0) {
 char *orc_mpileup_d(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *cigar_in, const uint8_t *seq,
                     const char *ctg, int64_t beg1, int64_t end1, int min_mq, int excl_flags,
                     const int32_t *bed, int n_bed, int with_hp, int max_depth, int64_t *out_len);
+/* compat: which samtools printer is restated (the reference only sets a floor of 1.10, run_clair3_rna:159,166):
+ *   0  samtools <= 1.10 pileup_seq: `+<n><n query bases>` for an insertion (pads skipped), nothing for a deletion behind it;
+ *   1  samtools >= 1.11 (htslib bam_plp_insertion): the run of I and P ops behind the column's op is printed as ONE insertion with the
+ *      pads as '*' (`+3T*T`), and when a D ends that run its length follows (`+2TT-1N`).  (Adjacent D ops count as one deletion, as
+ *      everywhere in this restatement.) */
+char *orc_mpileup_c(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *cigar_in, const uint8_t *seq,
+                    const char *ctg, int64_t beg1, int64_t end1, int min_mq, int excl_flags,
+                    const int32_t *bed, int n_bed, int with_hp, int max_depth, int compat, int64_t *out_len);
 
 /* samtools mpileup's default -d 8000 (the reference passes --max-depth only on request, src/create_tensor_pileup.py:442) */
 char *orc_mpileup(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *cigar_in, const uint8_t *seq,
@@ -212,6 +221,12 @@ static void depth_cap(const c3r_read_t *reads, int64_t n_reads, const uint32_t *
 char *orc_mpileup_d(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *cigar_in, const uint8_t *seq,
                     const char *ctg, int64_t beg1, int64_t end1, int min_mq, int excl_flags,
                     const int32_t *bed, int n_bed, int with_hp, int max_depth, int64_t *out_len) {
+    return orc_mpileup_c(reads_in, n_reads, cigar_in, seq, ctg, beg1, end1, min_mq, excl_flags, bed, n_bed, with_hp, max_depth, 0, out_len);
+}
+
+char *orc_mpileup_c(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *cigar_in, const uint8_t *seq,
+                    const char *ctg, int64_t beg1, int64_t end1, int min_mq, int excl_flags,
+                    const int32_t *bed, int n_bed, int with_hp, int max_depth, int compat, int64_t *out_len) {
     /* Zero-length CIGAR ops are dropped before the walk (conscious deviation): BAM writers do not emit
      * them, and what htslib's cursor does with them is an accident of its peek-next-op logic (e.g. `3M0I2D` loses the
      * deletion marker, `3M0D2I` the insertion).  The product path drops them at load, so the checker does too. */
@@ -282,7 +297,31 @@ char *orc_mpileup_d(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t 
             } else {
                 sb_putc(&bases, p.is_refskip ? (rev ? '<' : '>') : (rev ? '#' : '*'));
             }
-            if (p.indel > 0) {
+            if (p.indel > 0 && compat) {
+                /* bam_plp_insertion: the run of I / P ops behind the op on the column; a D that ends it is printed too */
+                int n_ops = (int)r->n_cigar, kk, total = 0, del_after = 0;
+                for (kk = p.ins_k; kk < n_ops; ++kk) {
+                    int o = cig_op(cg[kk]);
+                    if (o == C3R_CIG_I || o == C3R_CIG_P) total += cig_len(cg[kk]);
+                    else { if (o == C3R_CIG_D) { for (int k2 = kk; k2 < n_ops && cig_op(cg[k2]) == C3R_CIG_D; ++k2) del_after += cig_len(cg[k2]); } break; }
+                }
+                sb_putc(&bases, '+'); sb_putl(&bases, total);
+                int64_t q = p.qpos + 1 - p.is_del;
+                for (kk = p.ins_k; kk < n_ops; ++kk) {
+                    int o = cig_op(cg[kk]), ln = cig_len(cg[kk]);
+                    if (o == C3R_CIG_P) { for (int j = 0; j < ln; ++j) sb_putc(&bases, '*'); }
+                    else if (o == C3R_CIG_I) {
+                        for (int j = 0; j < ln; ++j, ++q) {
+                            int c = (q < (int64_t)r->l_seq) ? NT16[seq_code(seq, r->seq_off, (uint32_t)q)] : 'N';
+                            sb_putc(&bases, (char)(rev ? tolower(c) : toupper(c)));
+                        }
+                    } else break;
+                }
+                if (del_after > 0) {
+                    sb_putc(&bases, '-'); sb_putl(&bases, del_after);
+                    for (int j = 0; j < del_after; ++j) sb_putc(&bases, rev ? 'n' : 'N');
+                }
+            } else if (p.indel > 0) {
                 sb_putc(&bases, '+'); sb_putl(&bases, p.indel);
                 for (int j = 1; j <= p.indel; ++j) {
                     int64_t q = p.qpos + j - p.is_del;

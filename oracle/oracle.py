@@ -48,6 +48,9 @@ def lib():
         L.orc_mpileup_d.restype = C.c_void_p
         L.orc_mpileup_d.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_int64,
                                     C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+        L.orc_mpileup_c.restype = C.c_void_p
+        L.orc_mpileup_c.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_int64,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
         L.orc_generate_tensor.restype = C.c_void_p
         L.orc_generate_tensor.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_char,
                                           C.c_double, C.c_double, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -74,8 +77,8 @@ def _arr_ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def mpileup(reads, cigar, seq, ctg, beg1, end1, min_mq=5, excl_flags=2316, bed=None, with_hp=False, max_depth=8000):
-    """A1: reads -> mpileup text rows (list of str)."""
+def mpileup(reads, cigar, seq, ctg, beg1, end1, min_mq=5, excl_flags=2316, bed=None, with_hp=False, max_depth=8000, compat=0):
+    """A1: reads -> mpileup text rows (list of str).  compat: 0 = samtools <= 1.10 printer, 1 = samtools >= 1.11 (`+<ins>-<del>`)."""
     reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
     cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
@@ -83,8 +86,8 @@ def mpileup(reads, cigar, seq, ctg, beg1, end1, min_mq=5, excl_flags=2316, bed=N
     if bed is not None:
         bedarr = np.ascontiguousarray(np.asarray(sorted(bed), dtype=np.int32).reshape(-1, 2))
     n = C.c_int64(0)
-    p = lib().orc_mpileup_d(_arr_ptr(reads), len(reads), _arr_ptr(cigar), _arr_ptr(seq), ctg.encode(), beg1, end1,
-                            min_mq, excl_flags, _arr_ptr(bedarr), 0 if bedarr is None else len(bedarr), int(with_hp), int(max_depth), C.byref(n))
+    p = lib().orc_mpileup_c(_arr_ptr(reads), len(reads), _arr_ptr(cigar), _arr_ptr(seq), ctg.encode(), beg1, end1,
+                            min_mq, excl_flags, _arr_ptr(bedarr), 0 if bedarr is None else len(bedarr), int(with_hp), int(max_depth), int(compat), C.byref(n))
     text = _take_str(p)
     rows = text.split("\n")
     if rows and rows[-1] == "":

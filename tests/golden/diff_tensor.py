@@ -18,6 +18,8 @@ from tests.test_gpu_fuzz import _case  # noqa: E402
 
 OPTS = [
     ([], dict(), False),
+    (["--samtools_1_11_rows"], dict(), False),          # (not a reference flag: the rows are printed the samtools >= 1.11 way, `+<ins>-<del>`)
+    (["--samtools_1_11_rows", "--add_phasing_feature", "True"], dict(), True),
     (["--enable_variant_calling_at_sequence_head_and_tail", "True"], dict(head_tail=True), False),
     (["--enable_padding_in_splice_junction_regions", "True"], dict(splice_padding=True), False),
     (["--enable_padding_in_splice_junction_regions", "True", "--enable_variant_calling_at_sequence_head_and_tail", "True"],
@@ -37,7 +39,9 @@ def main():
             ref = ref.upper()
             rs = ReadSet.from_records(recs)
             L = len(ref)
-            rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, "chr20", 1, L, with_hp=phased)
+            compat = 1 if "--samtools_1_11_rows" in argv else 0
+            argv = [a for a in argv if a != "--samtools_1_11_rows"]
+            rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, "chr20", 1, L, with_hp=phased, compat=compat)
             try:
                 want, _ = rh.run_create_tensor(rows, ref, "chr20", ["--ctgStart", "1", "--ctgEnd", str(L - 33), "--minCoverage", "2"] + argv)
             except Exception as e:

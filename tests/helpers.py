@@ -10,7 +10,7 @@ def oracle_chunk(rs, ref, ref_start, ctg_start, ctg_end, channels=18, lbed=None,
     """Oracle A1..A5 for one chunk.  Returns dict(rows, lines, X, depth)."""
     es, ee = max(1, ctg_start - 33), ctg_end + 33
     rows = orc.mpileup(rs.reads, rs.cigar, rs.seq, CTG, es, ee, min_mq=pk.pop("min_mq", 5), excl_flags=pk.pop("excl_flags", 2316),
-                       bed=lbed, with_hp=(channels == 30), max_depth=pk.pop("max_depth", 8000))
+                       bed=lbed, with_hp=(channels == 30), max_depth=pk.pop("max_depth", 8000), compat=pk.pop("mpileup_compat", 0))
     P = orc.make_params(phased=(channels == 30), **pk)
     # the reference upper-cases the whole slice when it loads it ("uppercase for masked sequences", shared/utils.py:186-187)
     lines = orc.create_tensor(rows, CTG, ref.upper(), ref_start, P)

@@ -26,9 +26,9 @@ def _seeds(n):
     return range(base, base + n * scale)
 
 
-def _rand_cigar(rng, want_q):
+def _rand_cigar(rng, want_q, pads=True):
     """Random op sequence: M/=/X/I/D/N/S/H/P incl. zero-length ops, leading/trailing I or D, runs of D D, I I, N next to
-    I or D, pads between insertions.  Returns (cigar string, query length)."""
+    I or D, pads between insertions (pads = False: a short M in their place).  Returns (cigar string, query length)."""
     ops = []
     if rng.random() < 0.15:
         ops.append((rng.randint(1, 5), "H"))
@@ -46,7 +46,7 @@ def _rand_cigar(rng, want_q):
         elif r < 0.84:
             ops.append((rng.randint(1, 40), "N"))
         elif r < 0.90:
-            ops.append((rng.randint(1, 3), "P"))
+            ops.append((rng.randint(1, 3), "P" if pads else "M"))
         elif r < 0.95:
             ops.append((0, rng.choice("MID")))              # zero-length op
         else:
@@ -61,7 +61,7 @@ def _rand_cigar(rng, want_q):
     return "".join("%d%s" % lo for lo in ops), qlen
 
 
-def _case(seed, phased):
+def _case(seed, phased, pads=True):
     rng = random.Random(seed)
     L = rng.choice([300, 420, 777])
     ref = "".join(rng.choice("ACGT") for _ in range(L))
@@ -75,7 +75,7 @@ def _case(seed, phased):
     hot = rng.randint(30, L - 120)
     for _ in range(n_reads):
         pos = max(1, int(rng.gauss(hot, 40)))
-        cg, qlen = _rand_cigar(rng, 0)
+        cg, qlen = _rand_cigar(rng, 0, pads)
         if rng.random() < 0.1:
             qlen = max(1, qlen - rng.randint(1, 3))          # query shorter than the CIGAR claims
         seq = "".join(rng.choice("ACGTACGTACGTACGTN=RY") for _ in range(qlen))
@@ -134,6 +134,69 @@ def test_random_cigars_match_the_oracle(eng, kw):
     eng.set_params()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(channels=30), dict(head_tail=1), dict(splice_padding=1)])
+def test_random_cigars_with_the_samtools_1_11_printer(eng, kw):
+    """c3r_params_t.mpileup_compat = 1: an I immediately followed by a D shows both on the insertion's column (`C+2TT-1N`: one more D / d,
+    D1 / d1 count, a deletion token behind the insertion token).  The generator deals I next to D often (leading, after N, after D);
+    pads are left out: samtools >= 1.11 prints them inside insertions as '*', which the library refuses (second test below)."""
+    from clair3_rna_amd import capi
+    from clair3_rna_amd.reads import ReadSet
+    channels = kw.get("channels", 18)
+    okw = {k: bool(v) for k, v in kw.items() if k != "channels"}
+    n_lines, n_both = 0, 0
+    eng.load_reads(ReadSet.from_records([]))      # (switching the printer rebuilds the tables of the loaded reads: an earlier test's may hold pads)
+    for seed in _seeds(60):
+        ref, recs = _case(70000 + 100 * len(kw) + seed, phased=(channels == 30), pads=False)
+        rs = ReadSet.from_records(recs)
+        eng.params = capi.default_params()
+        eng.set_bed(0, None); eng.set_bed(1, None)
+        eng.set_params(min_coverage=2, mpileup_compat=1, **kw)
+        got = H.engine_chunk(eng, rs, ref, 1, 1, len(ref))
+        exp = H.oracle_chunk(rs, ref, 1, 1, len(ref), channels=channels, min_coverage=2, mpileup_compat=1, **okw)
+        assert got["lines"] == exp["lines"], (seed, recs, H.first_diff(got["lines"], exp["lines"]))
+        n_lines += len(exp["lines"])
+        n_both += sum(1 for r in exp["rows"] if re.search(r"[+][0-9]+[ACGTNacgtn=RYry]+-[0-9]+[Nn]", r.split("\t")[4]))
+        if seed % 20 == 0:                      # the same reads with the <= 1.10 text: the records are rebuilt when the parameter changes
+            eng.set_params(min_coverage=2, mpileup_compat=0, **kw)
+            n0 = eng.scan(1, len(ref))
+            old = H.oracle_chunk(rs, ref, 1, 1, len(ref), channels=channels, min_coverage=2, **okw)
+            assert n0 == len(old["lines"])
+    assert n_lines > 150 and n_both > 40, (n_lines, n_both)
+    eng.params = capi.default_params()
+    eng.set_params()
+
+
+def test_samtools_1_11_printer_known_answers_and_pads(eng):
+    from clair3_rna_amd import capi
+    from clair3_rna_amd.reads import ReadSet
+    ref = "ACGT" * 30
+    recs = [dict(pos=10, cigar="6M2I1D6M", seq="GTACGTTTTACGTA") for _ in range(4)] + [dict(pos=10, cigar="13M", seq="GTACGTACGTACG", flag=16) for _ in range(4)]
+    rs = ReadSet.from_records(recs)
+    out = {}
+    eng.load_reads(ReadSet.from_records([]))
+    for compat in (0, 1):
+        eng.params = capi.default_params()
+        eng.set_params(min_coverage=2, mpileup_compat=compat, head_tail=1)        # (head/tail calling: the reads are shorter than a window)
+        got = H.engine_chunk(eng, rs, ref, 1, 1, len(ref))
+        exp = H.oracle_chunk(rs, ref, 1, 1, len(ref), min_coverage=2, mpileup_compat=compat, head_tail=True)
+        assert got["lines"] == exp["lines"] and len(got["lines"]) > 0, H.first_diff(got["lines"], exp["lines"])
+        line = [l for l in got["lines"] if l.split("\t")[1] == "16"][0]                # the insertion sits on the sixth aligned base
+        out[compat] = line.split("\t")[4]
+        tk = got["tokens"][got["tokens"]["indel"] > 0]
+        assert (tk["del_after"] == (1 if compat else 0)).all() and len(tk) >= 4
+    assert out == {0: "8-ITTT 4 RT 4", 1: "8-ITTT 4 DA 4"}, out      # position 16 gains the deletion
+    # samtools >= 1.11 shows pads inside an insertion as '*': not restated on the device; refused, not silently shown the old way
+    bad = ReadSet.from_records([dict(pos=10, cigar="6M", seq="GTACGT"), dict(pos=12, cigar="4M1I1P1I4M", seq="ACGTTTACGT")])
+    eng.set_params(min_coverage=2, mpileup_compat=1)
+    with pytest.raises(capi.C3RError, match=r"read 1: a pad \(P\) next to an insertion is not supported with mpileup_compat = 1"):
+        eng.load_reads(bad)
+    eng.params = capi.default_params()
+    eng.set_params()
+    eng.load_reads(bad)                                                             # the default (<= 1.10) text takes it
+    eng.set_reference(1, ref)
+    eng.scan(1, len(ref))
+
+
 @pytest.mark.parametrize("mode", ["lbed", "cbed", "both_beds", "sites", "subregion", "deep"])
 def test_random_cigars_with_filters_and_regions(eng, mode):
     """The same random read sets through the -l BED, the confident BED, a genotyping site list, a sub-region with a shifted
@@ -184,10 +247,12 @@ def test_random_cigars_with_filters_and_regions(eng, mode):
     eng.set_params()
 
 
-def test_random_cigars_decode_rows_cpp_equals_python_and_regions(eng):
+@pytest.mark.parametrize("compat", [0, 1])
+def test_random_cigars_decode_rows_cpp_equals_python_and_regions(eng, compat):
     """On the random read sets: (1) c3r_call_rows (C++: tokens -> ordered alt_info -> decode -> row text) equals the Python
     path fed with the ORACLE's alt_info strings; (2) a multi-region scan over random chunk boundaries equals successive
-    scans.  Random weights make every genotype class and the decoder's retry loop show up."""
+    scans.  Random weights make every genotype class and the decoder's retry loop show up.  compat = 1: the samtools >= 1.11
+    text (a deletion token behind an insertion token travels in the packed token stream as del_after)."""
     from clair3_rna_amd import capi, decode, synth
     from clair3_rna_amd.reads import ReadSet
     from oracle import oracle as orc
@@ -198,14 +263,16 @@ def test_random_cigars_decode_rows_cpp_equals_python_and_regions(eng):
     n_rows, kinds = 0, set()
     for seed in _seeds(60):
         rng = random.Random(9000 + seed)
-        ref, recs = _case(80000 + seed, phased=False)
+        ref, recs = _case(80000 + seed, phased=False, pads=(compat == 0))
         rs = ReadSet.from_records(recs)
         L = len(ref)
         eng.params = capi.default_params()
         eng.set_bed(0, None); eng.set_bed(1, None)
-        eng.set_params(min_coverage=2)
+        if seed == _seeds(60)[0]:
+            eng.load_reads(ReadSet.from_records([]))
+        eng.set_params(min_coverage=2, mpileup_compat=compat)
         got = H.engine_chunk(eng, rs, ref, 1, 1, L)
-        exp = H.oracle_chunk(rs, ref, 1, 1, L, min_coverage=2)
+        exp = H.oracle_chunk(rs, ref, 1, 1, L, min_coverage=2, mpileup_compat=compat)
         assert got["lines"] == exp["lines"]
         if exp["lines"]:
             probs = eng.infer()
@@ -228,6 +295,7 @@ def test_random_cigars_decode_rows_cpp_equals_python_and_regions(eng):
         eng.begin_batch(); eng.scan_regions(chunks); eng.end_batch()
         assert np.array_equal(X1, eng.tensors()) and S1.tobytes() == eng.sites().tobytes() and T1.tobytes() == eng.tokens().tobytes(), (seed, chunks)
     assert n_rows > 1500 and {"0/0", "0/1", "1/1"} <= kinds, (n_rows, kinds)
+    eng.params = capi.default_params()
     eng.set_params()
 
 

@@ -81,7 +81,7 @@ def test_alt_info_from_tokens_matches_oracle_columns():
                             indel, q = ops[i + 1][0], y + (n if o == "M" else 0)
                         elif ops[i + 1][1] == "D" and o != "D":
                             indel = -ops[i + 1][0]
-                    tok = (ridx, indel, q, base, 1 if flag & 16 else 0, (0, 0))
+                    tok = (ridx, indel, q, base, 1 if flag & 16 else 0, 0)
                     break
                 x += n
                 if o == "M":

@@ -126,3 +126,37 @@ def test_query_shorter_than_cigar_prints_N():
 
 def test_read_without_reference_span_is_ignored():
     assert bases([R(9, "4S", "ACGT"), R(9, "2M", "GG")]) == {10: "^]G", 11: "G$"}
+
+
+def test_the_two_samtools_printers_differ_only_behind_an_insertion():
+    """compat = 0 restates samtools <= 1.10 (pileup_seq: `+<n>` and the next n query bases, pads skipped, nothing for a deletion behind
+    the insertion); compat = 1 restates samtools >= 1.11 (htslib bam_plp_insertion: the run of I / P ops as ONE insertion with the pads
+    as '*', and the length of a D that ends the run).  The reference's parser (src/create_tensor_pileup.py:151-163) reads `C+2TT-1N` as
+    three tokens: a base, an insertion, a deletion."""
+    # an I immediately followed by a D
+    assert bases([R(9, "2M2I1D2M", "ACTTGA")], compat=0) == {10: "^]A", 11: "C+2TT", 12: "*", 13: "G", 14: "A$"}
+    assert bases([R(9, "2M2I1D2M", "ACTTGA")], compat=1) == {10: "^]A", 11: "C+2TT-1N", 12: "*", 13: "G", 14: "A$"}
+    assert bases([R(9, "2M2I3D2M", "ACTTGA", flag=16)], compat=1) == {10: "^]a", 11: "c+2tt-3nnn", 12: "#", 13: "#", 14: "#", 15: "g", 16: "a$"}
+    # ... on a deleted column, and on the last column of a ref-skip
+    assert bases([R(9, "2M1D2I1D2M", "ACTTGA")], compat=1) == {10: "^]A", 11: "C-1N", 12: "*+2TT-1N", 13: "*", 14: "G", 15: "A$"}
+    assert bases([R(9, "2M2N1I2D2M", "ACTGA")], compat=1) == {10: "^]A", 11: "C", 12: ">", 13: ">+1T-2NN", 14: "*", 15: "*", 16: "G", 17: "A$"}
+    # pads inside an insertion
+    assert bases([R(9, "2M1I1P1I2M", "ACTTGA")], compat=0) == {10: "^]A", 11: "C+2TT", 12: "G", 13: "A$"}
+    assert bases([R(9, "2M1I1P1I2M", "ACTTGA")], compat=1) == {10: "^]A", 11: "C+3T*T", 12: "G", 13: "A$"}
+    assert bases([R(9, "2M1P2I2M", "ACTTGA")], compat=1) == {10: "^]A", 11: "C+3*TT", 12: "G", 13: "A$"}
+    assert bases([R(9, "2M2I1P1D2M", "ACTTGA")], compat=1) == {10: "^]A", 11: "C+3TT*-1N", 12: "*", 13: "G", 14: "A$"}
+    # everything else is printed alike
+    for cigar, seq in (("2M1D2M", "ACGT"), ("2M2I2M", "ACGTTA"), ("2M3N2M", "ACGT"), ("2M1D2I2M", "ACTTGA"), ("3M2I", "ACGTT"), ("2M1P1D2M", "ACGT")):
+        assert bases([R(9, cigar, seq)], compat=0) == bases([R(9, cigar, seq)], compat=1), cigar
+
+
+def test_new_printer_rows_through_the_oracle_parser():
+    """`C+2TT-1N` is a base, an insertion and a deletion for generate_tensor (src/create_tensor_pileup.py:151-163): the column counts a
+    D (and D1) that the <= 1.10 text does not have."""
+    recs = [R(9, "4M2I1D4M", "ACGTTTACGT") for _ in range(3)] + [R(9, "9M", "ACGTAACGT") for _ in range(3)]
+    old = orc.generate_tensor(bases(recs, compat=0)[13], "T", 13, "N" * 9 + "ACGTAACGT" + "N" * 20, 1)
+    new = orc.generate_tensor(bases(recs, compat=1)[13], "T", 13, "N" * 9 + "ACGTAACGT" + "N" * 20, 1)
+    I, I1, D, D1 = 4, 5, 6, 7
+    assert old["tensor"][I] == new["tensor"][I] == 3 and old["tensor"][I1] == new["tensor"][I1] == 3
+    assert old["tensor"][D] == 0 and new["tensor"][D] == 3 and new["tensor"][D1] == 3
+    assert [k for k, _n in new["alt"] if k.startswith("D")] == ["DA"] and not [k for k, _n in old["alt"] if k.startswith("D")]
