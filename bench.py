@@ -153,7 +153,7 @@ def cpu_baseline(rs, ref, weights, contig_len):
                        % (min(n_regions * size, contig_len), workers, n_cpu, t1 - t0, cores, n_net, t2 - t1))
 
 
-def run_strong(args, rank, local_rank, world, one_gpu):
+def run_strong(args, rank, local_rank, world, one_gpu, emit=True):
     """--scaling strong: BASELINE.json configs[2] — the 24 GRCh38 contigs, sharded by contig over the ranks (LPT by length, the
     reference's fan-out at run_clair3_rna:441-449,681-706), inputs host-resident.  One step = every rank takes ITS contigs from
     host records (reads AND reference: both change from contig to contig) to probabilities; total work is fixed, so the N-rank
@@ -222,10 +222,15 @@ def run_strong(args, rank, local_rank, world, one_gpu):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     loads = [sum(lens[i] for i in p) for p in plan]
+    my_reads = float(sum(info["n_reads"] for (_ci, _r, _rs, _ch, info) in data))
+    reads_max, reads_sum = my_reads, my_reads
     if dist is not None:
         dist.barrier()
         elapsed = shard.reduce_max(dist, elapsed, device=red_dev)
         sites = int(shard.reduce_sum(dist, sites, device=red_dev))
+        reads_max, reads_sum = shard.reduce_max(dist, my_reads, device=red_dev), shard.reduce_sum(dist, my_reads, device=red_dev)
+    for e in engs:
+        e.close()
     if rank == 0:
         out = {"metric": "candidate sites/sec (tensor build + inference)", "value": round(sites / elapsed, 1), "unit": "sites/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3), "higher_is_better": True,
@@ -234,12 +239,15 @@ def run_strong(args, rank, local_rank, world, one_gpu):
                "config": {"workload": "synthetic ONT dRNA004 whole genome ~%dx, 24 GRCh38 contigs x %.3g (BASELINE.json configs[2])" % (int(depth), args.genome_scale),
                           "inputs": "host-resident flat records and reference per contig", "contigs": len(names), "genome_bp": int(sum(lens)),
                           "parallelism": "contigs dealt largest-first to %d rank(s), no collective" % world, "lpt_imbalance": round(shard.imbalance(lens, plan), 4),
+                          "read_imbalance": round(reads_max / (reads_sum / world), 4) if reads_sum else None,      # max / mean READS per rank (the work), not lengths
                           "contigs_per_rank": [len(p) for p in plan], "bp_per_rank": loads, "sites_per_step": round(sites / max(1, args.steps), 1),
                           "precision": args.precision, "streams": len(engs)},
                "roofline": None, "cpu_baseline": None}
-        print(json.dumps(out), flush=True)
-    if dist is not None:
+        if emit:
+            print(json.dumps(out), flush=True)
+    if dist is not None and emit:
         dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 def main():
@@ -258,6 +266,8 @@ def main():
     ap.add_argument("--genome_scale", type=float, default=1.0, help="--scaling strong: shrink every contig by this factor (quick runs)")
     ap.add_argument("--no_resident", action="store_true", help="skip the additional measurement with the read tables already on the device")
     ap.add_argument("--no_fast", action="store_true", help="skip the additional measurement in precision 'auto' (reported as fast_precision)")
+    ap.add_argument("--no_strong", action="store_true", help="skip the additional N = 1 run of the strong-scaling configuration (BASELINE.json configs[2] at "
+                                                             "a quarter of every contig's length), reported as strong_1gpu")
     ap.add_argument("--no_overlap", action="store_true",
                     help="one context / one stream: tensor build and network strictly back to back")
     ap.add_argument("--precision", choices=["f16x3", "f32", "f16+f8", "auto"], default="f16x3",
@@ -277,7 +287,7 @@ def main():
     if one_gpu:
         local_rank = 0
     from clair3_rna_amd import capi, shard, synth
-    if world > 1:
+    if world > 1 or os.environ.get("C3R_HOST_SLICE"):
         shard.host_budget(apply=True)         # this rank's share of the node's cores (its GPU's NUMA node), host thread counts to match
     if args.scaling == "strong":
         return run_strong(args, rank, local_rank, world, one_gpu)
@@ -512,6 +522,20 @@ def main():
             except Exception:
                 pass
 
+    # ---- BASELINE.json configs[2] on ONE GPU: the 24 GRCh38 contigs (a quarter of each) from host-resident reads AND reference, so that the
+    # driver's record carries the configuration `--scaling strong` shards over N ranks — an ADDITIONAL figure, never `value`
+    strong = None
+    if world == 1 and not args.no_strong and args.steps > 0:
+        for e in engs:
+            e.close()
+        engs = []
+        sa = argparse.Namespace(**vars(args))
+        sa.genome_scale, sa.steps, sa.warmup = 0.25, 1, 0
+        so = run_strong(sa, rank, local_rank, world, one_gpu, emit=False)
+        strong = dict(value=so["value"], unit="sites/s", ms_per_step=so["ms_per_step"], workload=so["config"]["workload"], inputs=so["config"]["inputs"],
+                      genome_bp=so["config"]["genome_bp"], sites_per_step=so["config"]["sites_per_step"], streams=so["config"]["streams"],
+                      note="python bench.py --scaling strong --genome_scale 0.25 --steps 1 at N = 1; with --gpus N the same contigs are dealt to N ranks")
+
     if rank == 0:
         out = {
             "metric": "candidate sites/sec (tensor build + inference)",
@@ -528,7 +552,7 @@ def main():
                        "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world,
                        "streams": len(engs)},
             "roofline": roofline, "roofline_tensor_build": roofline_tb, "cpu_baseline": cpu, "stage_rates": stage_rates,
-            "resident_inputs": resident, "fast_precision": fast,
+            "resident_inputs": resident, "fast_precision": fast, "strong_1gpu": strong,
             "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
         }
         print(json.dumps(out), flush=True)

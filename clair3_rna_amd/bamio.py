@@ -9,7 +9,7 @@ import numpy as np
 
 from .reads import READ_DTYPE, ReadSet
 
-EXPORTS = ["c3r_bam_open", "c3r_bam_close", "c3r_bam_last_error", "c3r_bam_n_contigs", "c3r_bam_contig", "c3r_bam_has_index",
+EXPORTS = ["c3r_bam_open", "c3r_bam_close", "c3r_bam_last_error", "c3r_bam_n_contigs", "c3r_bam_contig", "c3r_bam_has_index", "c3r_bam_contig_weight",
            "c3r_bam_fetch", "c3r_bam_copy", "c3r_bam_index_build", "c3r_vcf_merge", "c3r_vcf_compress", "c3r_vcfz_open", "c3r_vcfz_write",
            "c3r_vcfz_close", "c3r_vcfz_piece_make", "c3r_vcfz_append", "c3r_vcfz_piece_free", "c3r_fasta_fetch", "c3r_io_alloc", "c3r_io_free"]
 _LIB = None
@@ -30,6 +30,7 @@ def load_library():
         L.c3r_bam_n_contigs.argtypes = [C.c_void_p]
         L.c3r_bam_contig.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]
         L.c3r_bam_has_index.argtypes = [C.c_void_p]
+        L.c3r_bam_contig_weight.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.c3r_bam_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64] + [C.POINTER(C.c_int64)] * 3
         L.c3r_bam_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.c3r_bam_index_build.argtypes = [C.c_char_p, C.c_char_p]
@@ -95,6 +96,15 @@ class BamFile:
             name, ln = C.c_char_p(), C.c_int64()
             self.L.c3r_bam_contig(self.h, i, C.byref(name), C.byref(ln))
             out.append((name.value.decode(), ln.value))
+        return out
+
+    def contig_weights(self):
+        """{contig: (mapped reads, compressed bytes)} from the index; -1 where it does not say (no index / no metadata pseudo-bin)."""
+        out = {}
+        for i, (name, _ln) in enumerate(self.contigs()):
+            nm, fb = C.c_int64(-1), C.c_int64(-1)
+            self.L.c3r_bam_contig_weight(self.h, i, C.byref(nm), C.byref(fb))
+            out[name] = (nm.value, fb.value)
         return out
 
     def fetch(self, contig, beg0=0, end0=None):

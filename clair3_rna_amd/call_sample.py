@@ -295,6 +295,13 @@ def Run(args, log=None):
         from . import shard
         n_thr, _cpus = shard.host_budget(apply=True)
         args.fetch_threads = max(1, min(args.fetch_threads, n_thr // 2 or 1))
+        os.environ.setdefault("C3R_FETCH_INFLATE", str(max(1, n_thr // args.fetch_threads)))    # inflate threads per fetch handle
+    elif os.environ.get("C3R_HOST_SLICE"):
+        # one process on the host slice a rank of an N-GPU run would get (tools/host_slice.py)
+        from . import shard
+        n_thr, _cpus = shard.host_budget(apply=True)
+        args.fetch_threads = max(1, min(args.fetch_threads, n_thr // 2 or 1))
+        os.environ.setdefault("C3R_FETCH_INFLATE", str(max(1, n_thr // args.fetch_threads)))
     if args.gpu_id is None:
         args.gpu_id = int(os.environ.get("C3R_DEVICE", "0"))
     for need in (args.bam_fn, args.ref_fn):
@@ -325,13 +332,51 @@ def Run(args, log=None):
     if rank == 0 and not os.path.exists(cmd_fn):
         with open(cmd_fn, "w") as f:
             f.write(" ".join(sys.argv) + "\n")
+    bam_fn = args.bam_fn
+    if bam_fn.endswith(".bam"):
+        from . import bamio
+        with bamio.BamFile(bam_fn) as probe:
+            indexed = probe.has_index
+        if not indexed:
+            # without an index every contig would cost a pass over the whole file: build one next to a link in tmp/
+            # (run_clair3_rna insists on an existing index, :469-477; samtools is not a dependency here).  Rank 0 alone builds it,
+            # under temporary names that are renamed into place, and the other ranks open the BAM only after the barrier: nobody
+            # ever sees a missing link or a half-written .bai
+            link = os.path.join(out_dir, "tmp", "input.bam")
+            build_err = None
+            if rank == 0:
+                try:
+                    tmp_link, tmp_bai = link + ".tmp%d" % os.getpid(), link + ".bai.tmp%d" % os.getpid()
+                    if os.path.lexists(tmp_link):
+                        os.remove(tmp_link)
+                    os.symlink(os.path.abspath(bam_fn), tmp_link)
+                    log("[INFO] %s has no .bai: building %s.bai" % (bam_fn, link))
+                    try:
+                        bamio.index_build(tmp_link, tmp_bai)
+                        os.replace(tmp_bai, link + ".bai")
+                        os.replace(tmp_link, link)
+                    finally:
+                        for t_ in (tmp_link, tmp_bai):
+                            if os.path.lexists(t_):
+                                os.remove(t_)
+                except Exception as e:           # the other ranks are waiting at the barrier: reach it, then fail together
+                    build_err = e
+            _all_ranks_ok(dist, world, build_err, "building the BAM index")
+            bam_fn = link
     all_contigs = contigs
     parts_dir = os.path.join(out_dir, "tmp", "parts")
     if world > 1:
         from . import shard
         os.makedirs(parts_dir, exist_ok=True)
         dist.barrier()                                                  # CMD is in place before anybody builds the header
-        mine = shard.lpt_assign([fai[c] for c in all_contigs], world)[rank]
+        # contigs are dealt by the WORK they hold ("by read count ... from the read index"): the mapped reads the BAM
+        # index reports per contig (pseudo-bin 37450), else the compressed bytes its records span, else its length.  RNA coverage is
+        # nowhere near proportional to length (chr19 against chr13), so a deal by length balances the wrong thing.
+        costs, basis = shard.contig_costs(bam_fn, all_contigs, fai)
+        plan = shard.lpt_assign(costs, world)
+        mine = plan[rank]
+        if rank == 0:
+            log("[INFO] %d contigs dealt to %d ranks by %s: load imbalance %.3f" % (len(all_contigs), world, basis, shard.imbalance(costs, plan)))
         contigs = [all_contigs[i] for i in mine]
 
     table = None
@@ -459,37 +504,6 @@ def Run(args, log=None):
                 m.out_nt.close()
             part_counts[k] = (m.n_read, m.n_kept, m.n_tagged)
 
-    bam_fn = args.bam_fn
-    if bam_fn.endswith(".bam"):
-        from . import bamio
-        with bamio.BamFile(bam_fn) as probe:
-            indexed = probe.has_index
-        if not indexed:
-            # without an index every contig would cost a pass over the whole file: build one next to a link in tmp/
-            # (run_clair3_rna insists on an existing index, :469-477; samtools is not a dependency here).  Rank 0 alone builds it,
-            # under temporary names that are renamed into place, and the other ranks open the BAM only after the barrier: nobody
-            # ever sees a missing link or a half-written .bai
-            link = os.path.join(out_dir, "tmp", "input.bam")
-            build_err = None
-            if rank == 0:
-                try:
-                    tmp_link, tmp_bai = link + ".tmp%d" % os.getpid(), link + ".bai.tmp%d" % os.getpid()
-                    if os.path.lexists(tmp_link):
-                        os.remove(tmp_link)
-                    os.symlink(os.path.abspath(bam_fn), tmp_link)
-                    log("[INFO] %s has no .bai: building %s.bai" % (bam_fn, link))
-                    try:
-                        bamio.index_build(tmp_link, tmp_bai)
-                        os.replace(tmp_bai, link + ".bai")
-                        os.replace(tmp_link, link)
-                    finally:
-                        for t_ in (tmp_link, tmp_bai):
-                            if os.path.lexists(t_):
-                                os.remove(t_)
-                except Exception as e:           # the other ranks are waiting at the barrier: reach it, then fail together
-                    build_err = e
-            _all_ranks_ok(dist, world, build_err, "building the BAM index")
-            bam_fn = link
     fetcher = _Fetcher(bam_fn, args.ref_fn)
     t_setup = time() - t_all
     # contigs fetched (or being fetched) but not yet through their context: every context busy + every fetch thread running ahead.

@@ -29,6 +29,16 @@
 
 #include "../../include/c3r.h"
 #include "../../include/c3r_io.h"
+#include <sched.h>
+
+// CPUs this process may run on (its affinity mask: one process per GPU is pinned to its share of the node, shard.host_budget), not the
+// machine's: what default thread counts are taken from
+static inline unsigned usable_cpus() {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) return (unsigned)n; }
+    return std::max(1u, std::thread::hardware_concurrency());
+}
 
 namespace {
 
@@ -156,6 +166,10 @@ inline void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t> &out) {
 struct RefIndex {
     std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
     std::vector<uint64_t> linear;
+    // the metadata pseudo-bin 37450 (SAM spec 5.2: two "chunks" — the file range of the contig's records, then the numbers of mapped and
+    // unmapped reads), when the index has it: the weight a contig gets when the sample's contigs are dealt to the GPUs
+    int64_t n_mapped = -1, n_unmapped = -1;
+    uint64_t off_beg = 0, off_end = 0;
 };
 
 }  // namespace
@@ -407,6 +421,9 @@ int load_bai(c3r_bam *b, const std::string &p) {
                 if (bin != 37450) {   // (37450 = metadata pseudo-bin)
                     auto &v = idx[r].bins[bin];
                     for (int c = 0; c < n_chunk; ++c) v.emplace_back(le64(m.p + o + 16 * c), le64(m.p + o + 16 * c + 8));
+                } else if (n_chunk >= 2) {
+                    idx[r].off_beg = le64(m.p + o); idx[r].off_end = le64(m.p + o + 8);
+                    idx[r].n_mapped = (int64_t)le64(m.p + o + 16); idx[r].n_unmapped = (int64_t)le64(m.p + o + 24);
                 }
                 o += 16 * (size_t)n_chunk;
             }
@@ -638,7 +655,7 @@ int c3r_bam_open(const char *path, int n_threads, c3r_bam **out) {
     if (!path || !out) return C3R_EINVAL;
     c3r_bam *b = new c3r_bam();
     b->path = path;
-    b->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    b->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, usable_cpus());
     *out = b;                      // handed back even on failure so that the caller can read the message
     if (!b->file.open(path)) return failb(b, C3R_EINVAL, "%s: cannot open", path);
     int rc = parse_header(b);
@@ -702,6 +719,24 @@ int c3r_bam_copy(c3r_bam *b, c3r_read_t *reads, uint32_t *cigar, uint8_t *seq) {
     return C3R_OK;
 }
 
+int c3r_bam_contig_weight(c3r_bam *b, int i, int64_t *n_mapped, int64_t *file_bytes) {
+    if (!b || i < 0 || (size_t)i >= b->names.size()) return C3R_EINVAL;
+    int64_t nm = -1, fb = -1;
+    if (b->has_bai && (size_t)i < b->bai.size()) {
+        const RefIndex &ri = b->bai[(size_t)i];
+        nm = ri.n_mapped;
+        uint64_t lo = ri.off_beg, hi = ri.off_end;
+        if (ri.n_mapped < 0) {             // no pseudo-bin: the span of the contig's chunks
+            lo = ~0ull; hi = 0;
+            for (auto &kv : ri.bins) for (auto &c : kv.second) { lo = std::min(lo, c.first); hi = std::max(hi, c.second); }
+        }
+        fb = hi > lo ? (int64_t)((hi >> 16) - (lo >> 16)) : 0;       // (virtual offsets: compressed file offset << 16 | offset in the block)
+    }
+    if (n_mapped) *n_mapped = nm;
+    if (file_bytes) *file_bytes = fb;
+    return C3R_OK;
+}
+
 int c3r_bam_index_build(const char *bam_path, const char *bai_path) {
     if (!bam_path || !bai_path) return C3R_EINVAL;
     c3r_bam *b = nullptr;
@@ -717,6 +752,12 @@ int c3r_bam_index_build(const char *bam_path, const char *bai_path) {
         if (tid < 0 || (size_t)tid >= n_ref || pos < 0) return true;        // unplaced reads are not indexed
         if (tid < last_tid || (tid == last_tid && pos < last_pos)) { unsorted = true; return false; }
         last_tid = tid; last_pos = pos;
+        {   // the pseudo-bin's numbers: file range of the contig's records, mapped / unmapped (FLAG 0x4) reads
+            RefIndex &ri0 = idx[(size_t)tid];
+            if (ri0.n_mapped < 0) { ri0.n_mapped = 0; ri0.n_unmapped = 0; ri0.off_beg = v0; }
+            ri0.off_end = v1;
+            if (le16(r + 14) & 4u) ri0.n_unmapped++; else ri0.n_mapped++;
+        }
         const uint32_t l_read_name = r[8], n_cig = le16(r + 12);
         int64_t rlen = 0;
         const uint8_t *cig = r + 32 + l_read_name;
@@ -742,10 +783,14 @@ int c3r_bam_index_build(const char *bam_path, const char *bai_path) {
             auto w64 = [&](uint64_t v) { fwrite(&v, 8, 1, fo); };
             fwrite("BAI\1", 1, 4, fo); w32((uint32_t)n_ref);
             for (auto &ri : idx) {
-                w32((uint32_t)ri.bins.size());
+                w32((uint32_t)(ri.bins.size() + (ri.n_mapped >= 0 ? 1 : 0)));
                 for (auto &kv : ri.bins) {
                     w32(kv.first); w32((uint32_t)kv.second.size());
                     for (auto &c : kv.second) { w64(c.first); w64(c.second); }
+                }
+                if (ri.n_mapped >= 0) {            // metadata pseudo-bin, as samtools index writes it
+                    w32(37450u); w32(2u);
+                    w64(ri.off_beg); w64(ri.off_end); w64((uint64_t)ri.n_mapped); w64((uint64_t)ri.n_unmapped);
                 }
                 w32((uint32_t)ri.linear.size());
                 for (uint64_t v : ri.linear) w64(v);

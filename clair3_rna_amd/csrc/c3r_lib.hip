@@ -23,6 +23,7 @@
 #include "net_kernels.hpp"
 #include "pileup_kernels.hpp"
 #include "reads_kernels.hpp"
+#include <sched.h>
 
 using namespace c3r;
 
@@ -134,6 +135,15 @@ struct c3r_ctx {
 };
 
 namespace {
+
+// CPUs this process may run on (its affinity mask: one process per GPU is pinned to its share of the node, shard.host_budget), not the
+// machine's: what default thread counts are taken from
+static inline unsigned usable_cpus() {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) return (unsigned)n; }
+    return std::max(1u, std::thread::hardware_concurrency());
+}
 
 int fail(c3r_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
@@ -610,7 +620,7 @@ int c3r_set_reference(c3r_ctx *ctx, int64_t ref_start, const char *ref, int64_t 
             }
         };
         // a 250 MB chromosome is memory-bound work for one core: split it
-        int64_t nt = std::max<int64_t>(1, std::min<int64_t>({8, (int64_t)std::thread::hardware_concurrency(), len >> 23}));
+        int64_t nt = std::max<int64_t>(1, std::min<int64_t>({8, (int64_t)usable_cpus(), len >> 23}));
         if (const char *e = getenv("C3R_THREADS")) nt = std::max<int64_t>(1, std::min<int64_t>(nt, atoi(e)));
         std::vector<std::thread> th;
         for (int64_t t = 1; t < nt; ++t) th.emplace_back(upper, len * t / nt, len * (t + 1) / nt);
@@ -1599,7 +1609,7 @@ int c3r_rows_decode(c3r_rows *r, const char *ctg, int qual, int show_ref, int64_
     const int64_t ref_start1 = r->ref_start1;
     auto get_read = [&](uint32_t k) { return ReadView{seq, reads[k].seq_off, reads[k].l_seq}; };
     // host threads: C3R_THREADS, else up to 32 (one process per GPU shares the node's cores with its peers)
-    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    unsigned nt = std::max(1u, std::min(32u, usable_cpus()));
     if (const char *e = getenv("C3R_THREADS")) nt = (unsigned)std::max(1, atoi(e));
     if ((int64_t)nt * 64 > n) nt = 1;
     std::vector<std::string> part(nt);

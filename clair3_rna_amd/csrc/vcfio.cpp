@@ -24,6 +24,16 @@
 #include <vector>
 
 #include "../../include/c3r_io.h"
+#include <sched.h>
+
+// CPUs this process may run on (its affinity mask: one process per GPU is pinned to its share of the node, shard.host_budget), not the
+// machine's: what default thread counts are taken from
+static inline unsigned usable_cpus() {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) return (unsigned)n; }
+    return std::max(1u, std::thread::hardware_concurrency());
+}
 
 #define C3R_OK 0
 #define C3R_EINVAL (-1)
@@ -363,7 +373,7 @@ int c3r_vcfz_open(const char *gz_path, int threads, c3r_vcfz **out) {
     *out = nullptr;
     c3r_vcfz *z = new c3r_vcfz();
     z->gz_path = gz_path;
-    z->threads = threads > 0 ? threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    z->threads = threads > 0 ? threads : (int)std::min(32u, std::max(1u, usable_cpus()));
     z->f = fopen(gz_path, "wb");
     if (!z->f) { delete z; return C3R_EINVAL; }
     *out = z;
@@ -402,7 +412,7 @@ int c3r_vcfz_piece_make(const char *text, int64_t n, int threads, c3r_vcfz_piece
     c3r_vcfz_piece *p = new c3r_vcfz_piece();
     p->n = (uint64_t)n;
     std::vector<uint64_t> co;
-    const int nt = threads > 0 ? threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    const int nt = threads > 0 ? threads : (int)std::min(32u, std::max(1u, usable_cpus()));
     if (n && !bgzf_compress((const uint8_t *)text, (size_t)n, nt, p->gz, co)) { delete p; return C3R_EINVAL; }
     const uint64_t gz_end = (uint64_t)p->gz.size() << 16;
     auto rel = [&](uint64_t u) { return u < (uint64_t)n ? (co[(size_t)(u / BLK)] << 16) | (u % BLK) : gz_end; };

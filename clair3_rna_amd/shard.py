@@ -26,6 +26,28 @@ def chunk_costs(read_pos, read_len, chunks):
     return [int(np.count_nonzero((read_pos < b + 33) & (ends > a - 33))) for a, b in chunks]
 
 
+def contig_costs(bam_fn, contigs, lengths):
+    """What each contig costs a rank, for the LPT deal of a whole sample: mapped reads per contig from the BAM index (its metadata
+    pseudo-bin), else the compressed bytes the contig's records span, else the contig's length — ONE basis for all contigs, so that the
+    costs are comparable.  -> (costs, name of the basis).  lengths: {contig: bp}."""
+    weights = {}
+    if str(bam_fn).endswith(".bam"):
+        try:
+            from . import bamio
+            with bamio.BamFile(bam_fn) as b:
+                if b.has_index:
+                    weights = b.contig_weights()
+        except Exception:
+            weights = {}
+    for k, basis in ((0, "mapped reads (BAM index)"), (1, "compressed bytes (BAM index)")):
+        vals = [weights.get(c, (-1, -1))[k] for c in contigs]
+        if vals and all(v >= 0 for v in vals) and sum(vals) > 0:
+            # (a contig without reads still costs its fetch and an empty scan: a small floor keeps them from piling up on one rank)
+            floor = max(1, sum(vals) // (200 * len(vals)))
+            return [max(int(v), floor) for v in vals], basis
+    return [int(lengths[c]) for c in contigs], "length"
+
+
 def reduce_max(dist, value, device="cpu"):
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
@@ -55,8 +77,14 @@ def imbalance(costs, plan):
 
 
 def local_world():
-    """(local_rank, local_world_size) of this process under torch.distributed.run (1 process per GPU); (0, 1) otherwise."""
+    """(local_rank, local_world_size) of this process under torch.distributed.run (1 process per GPU); (0, 1) otherwise.
+    C3R_HOST_SLICE=r/w overrides it: a single process then takes the host slice rank r of w would get on this node — how the
+    8-GPU host budget is tried out on a 1-GPU box (tools/host_slice.py)."""
     import os
+    ov = os.environ.get("C3R_HOST_SLICE")
+    if ov:
+        r, _, w = ov.partition("/")
+        return int(r), max(1, int(w))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
     lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     return lr, max(1, lw)
@@ -148,4 +176,6 @@ def host_budget(local_rank=None, local_world_size=None, apply=False):
                 pass
         os.environ.setdefault("C3R_THREADS", str(n_threads))
         os.environ.setdefault("OMP_NUM_THREADS", str(n_threads))
+        # (the native libraries take their default thread counts from the affinity mask set above: BGZF inflate, compression,
+        # FASTA slices, row decode — libc3r_io.so / libc3r.so, usable_cpus())
     return n_threads, cpus

@@ -34,6 +34,10 @@ int c3r_bam_n_contigs(c3r_bam *b);
 /* name points into the handle (valid until close) */
 int c3r_bam_contig(c3r_bam *b, int i, const char **name, int64_t *length);
 int c3r_bam_has_index(c3r_bam *b);
+/* How much work contig i holds, from the index (-1: not known — no index, or it has no metadata pseudo-bin): the number of mapped
+ * reads (BAI pseudo-bin 37450) and the compressed bytes its records span.  What the sample's contigs are dealt to the GPUs by
+ * (the reference fans out by chunk: run_clair3_rna:441-449,681-706; SURVEY.md 8e: "by read count ... from the read index"). */
+int c3r_bam_contig_weight(c3r_bam *b, int i, int64_t *n_mapped, int64_t *file_bytes);
 
 /* Collect the alignments of `contig` overlapping the 0-based half-open region [beg0, end0) in file
  * (coordinate) order; end0 <= 0 means the whole contig.  Uses the .bai when loaded, else inflates the

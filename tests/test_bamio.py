@@ -459,3 +459,59 @@ def test_independent_writer_bin_boundaries_long_cigar_and_index(tmp_path, seed):
         for w in range(pos_k >> 14, ((int(end[k]) - 1) >> 14) + 1):
             assert w < len(lin) and 0 < lin[w] <= v              # the linear index never points past an overlapping record
     assert len(lin) == len(mlin)
+
+
+def test_index_metadata_pseudo_bin_gives_the_contigs_work(bam_case, tmp_path):
+    """The index builder writes the metadata pseudo-bin (37450: file range, mapped / unmapped reads) as `samtools index` does; the reader
+    hands it out as the weight a contig gets when a sample's contigs are dealt to the GPUs (by read count, from the index).
+    An index without the pseudo-bin still yields the compressed bytes a contig's records span; no index: nothing (-1)."""
+    import shutil
+    from clair3_rna_amd import shard
+    p = str(tmp_path / "w.bam")
+    shutil.copy(bam_case["path"], p)
+    with bamio.BamFile(p) as bf:
+        assert not bf.has_index and bf.contig_weights()["chr20"] == (-1, -1)
+    bamio.index_build(p)
+    n20, n21 = len(bam_case["rs"]), len(bam_case["rs2"])
+    with bamio.BamFile(p) as bf:
+        w = bf.contig_weights()
+    assert w["chr20"][0] == n20 and w["chr21"][0] == n21 and w["chrEmpty"][0] == -1
+    assert w["chr20"][1] > w["chr21"][1] > 0                                        # compressed bytes follow the read counts here
+    # independent parse of the pseudo-bin: two 16-byte "chunks" — (first, last virtual offset), (mapped, unmapped)
+    raw = open(p + ".bai", "rb").read()
+    o = 8
+    n_bin = struct.unpack_from("<i", raw, o)[0]; o += 4
+    meta = None
+    for _ in range(n_bin):
+        b, nch = struct.unpack_from("<Ii", raw, o); o += 8
+        if b == 37450:
+            meta = struct.unpack_from("<QQQQ", raw, o)
+        o += 16 * nch
+    assert meta is not None and meta[2] == n20 and meta[3] == 0 and meta[1] > meta[0]
+    costs, basis = shard.contig_costs(p, ["chr20", "chr21"], {"chr20": 600000, "chr21": 150000})
+    assert basis.startswith("mapped reads") and costs == [n20, n21]
+    costs, basis = shard.contig_costs(p, ["chr20", "chr21", "chrEmpty"], {"chr20": 600000, "chr21": 150000, "chrEmpty": 5000})
+    assert basis.startswith("compressed bytes") and costs[0] > costs[1] >= costs[2] >= 1     # (one contig has no pseudo-bin: ONE basis for all)
+    # the same index with the pseudo-bins cut out (an index from a tool that writes none)
+    out = bytearray(raw[:8])
+    o = 8
+    for _ref in range(struct.unpack_from("<i", raw, 4)[0]):
+        n_bin = struct.unpack_from("<i", raw, o)[0]; o += 4
+        keep = bytearray()
+        kept = 0
+        for _ in range(n_bin):
+            b, nch = struct.unpack_from("<Ii", raw, o)
+            if b != 37450:
+                keep += raw[o:o + 8 + 16 * nch]; kept += 1
+            o += 8 + 16 * nch
+        n_intv = struct.unpack_from("<i", raw, o)[0]
+        out += struct.pack("<i", kept) + keep + raw[o:o + 4 + 8 * n_intv]
+        o += 4 + 8 * n_intv
+    open(p + ".bai", "wb").write(bytes(out))
+    with bamio.BamFile(p) as bf:
+        w2 = bf.contig_weights()
+    assert w2["chr20"][0] == -1 and w2["chr20"][1] > w2["chr21"][1] > 0
+    costs, basis = shard.contig_costs(p, ["chr20", "chr21"], {"chr20": 600000, "chr21": 150000})
+    assert basis.startswith("compressed bytes")
+    costs, basis = shard.contig_costs(str(tmp_path / "reads.cram"), ["chr20", "chr21"], {"chr20": 600000, "chr21": 150000})
+    assert basis == "length" and costs == [600000, 150000]

@@ -73,3 +73,27 @@ def test_eight_ranks_share_grch38_and_the_host(tmp_path):
         assert all(len(c) == n_cpu // 8 for c in cpu_sets)
         assert len(set().union(*cpu_sets)) == 8 * (n_cpu // 8)          # disjoint slices
     assert all(int(t) == n for _rk, _m, n, _c, t in r["ranks"]) and all(1 <= n <= max(1, n_cpu // 8) for _rk, _m, n, _c, _t in r["ranks"])
+
+
+def test_contigs_are_dealt_by_reads_not_by_length():
+    """SURVEY.md 8e shards "by read count ... from the read index".  RNA coverage is nowhere near proportional to contig length (gene-dense
+    chr19 / chr17 against chr13 / chr18 / chrY), so the bound is asserted on READ COUNTS: a GRCh38-like sample whose reads per megabase
+    vary 8-fold between contigs, dealt (1) by its read counts and (2) by length — the second is what call_sample did through round 3."""
+    import random
+    rng = random.Random(5)
+    names = [n for n, _l in shard.GRCH38]
+    dens = {"chr19": 3.2, "chr17": 2.3, "chr16": 1.7, "chr22": 1.9, "chr1": 1.4, "chr11": 1.5, "chr12": 1.3, "chr13": 0.45, "chr18": 0.5,
+            "chr4": 0.55, "chr5": 0.7, "chrX": 0.6, "chrY": 0.08, "chr21": 0.6}
+    reads = [int(l / 1e6 * 9000 * dens.get(n, 1.0) * rng.uniform(0.9, 1.1)) for n, l in shard.GRCH38]
+    lengths = [l for _n, l in shard.GRCH38]
+    for world in (2, 4, 8):
+        by_reads = shard.lpt_assign(reads, world)
+        by_len = shard.lpt_assign(lengths, world)
+        assert sorted(i for p in by_reads for i in p) == list(range(24))
+        bound = {2: 1.01, 4: 1.03, 8: 1.08}[world]
+        assert shard.imbalance(reads, by_reads) < bound, (world, shard.imbalance(reads, by_reads))
+        assert shard.imbalance(reads, by_len) > shard.imbalance(reads, by_reads)
+    assert shard.imbalance(reads, shard.lpt_assign(lengths, 8)) > 1.15            # the deal by length leaves one rank >15 % over the mean
+    # no contig is more than a rank's share at 8 ranks here; when one is (a mitochondrial contig in --include_all_ctgs runs), the bound is
+    # that contig's share and only a finer unit than the contig could do better
+    assert max(reads) / (sum(reads) / 8.0) < 1.0
