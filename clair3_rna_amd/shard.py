@@ -90,11 +90,19 @@ def local_world():
     return lr, max(1, lw)
 
 
+_BASE_AFFINITY = None
+
+
 def _cpu_lists():
     """[(numa node, [cpus])] from /sys; one pseudo-node with every allowed CPU when the topology is not exposed."""
     import glob
     import os
-    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    global _BASE_AFFINITY
+    if _BASE_AFFINITY is None:
+        # the CPUs the process started with: host_budget(apply=True) narrows the mask, and a second call in the same process (a driver
+        # that runs several samples) must slice what the process was given, not its own earlier slice (32 -> 4 -> 1 CPUs otherwise)
+        _BASE_AFFINITY = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    allowed = _BASE_AFFINITY
     nodes = []
     for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*"), key=lambda x: int(x.rsplit("node", 1)[1])):
         try:
@@ -153,7 +161,8 @@ def host_budget(local_rank=None, local_world_size=None, apply=False):
     every = [c for _n, cpus in nodes for c in cpus]
     cpus = None
     if local_world_size > 1:
-        node = _gpu_numa_node(local_rank)
+        # (C3R_HOST_SLICE pretends to be one of N ranks on a box with fewer GPUs: the plain equal slice)
+        node = None if os.environ.get("C3R_HOST_SLICE") else _gpu_numa_node(local_rank)
         by_node = dict(nodes)
         if node in by_node and len(nodes) > 1:
             # ranks whose GPUs hang off the same node share that node's CPUs evenly

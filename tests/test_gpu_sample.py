@@ -189,3 +189,34 @@ def test_two_ranks_share_the_contigs_and_rank0_assembles_the_same_file(tmp_path)
     import json
     c0, c1 = (json.load(open(os.path.join(out2, "tmp", "parts", n)))["called"] for n in sorted(parts))
     assert c0 and c1 and not set(c0) & set(c1)                      # both ranks worked, on different contigs
+
+
+def test_one_rank_on_its_eighth_of_the_host(tmp_path):
+    """What rank 0 of an 8-GPU run gets of the host, tried on one GPU: C3R_HOST_SLICE=0/8 pins the process to the slice shard.host_budget
+    computes, cuts the decode / fetch / inflate / compression threads to match, and the sample comes out byte-identical to the unconfined
+    run.  (Rates of the confined against the unconfined driver: tools/host_slice.py -> profiles/r4/host_slice.txt.)"""
+    import subprocess
+    import sys
+    tmp = str(tmp_path)
+    fa, bm, wfn, _ = _sample(tmp)
+    got = _run_sample(os.path.join(tmp, "out"), fa, bm, wfn)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from clair3_rna_amd import call_sample\n"
+            "n0 = len(os.sched_getaffinity(0))\n"
+            "argv = ['--bam_fn', %r, '--ref_fn', %r, '--output_dir', %r, '--pileup_model_path', %r, '--chunk_size', '12000', '--no_compress']\n"
+            "for k in range(2):\n"
+            "    assert call_sample.Run(call_sample.build_parser().parse_args(argv)) == 0\n"
+            "    print('SLICE', n0, len(os.sched_getaffinity(0)), os.environ.get('C3R_THREADS'), os.environ.get('C3R_FETCH_INFLATE'))\n"
+            % (root, bm, fa, os.path.join(tmp, "out8"), wfn))
+    env = dict(os.environ, C3R_HOST_SLICE="0/8")
+    for k in ("C3R_THREADS", "OMP_NUM_THREADS", "C3R_FETCH_INFLATE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l.split() for l in p.stdout.split("\n") if l.startswith("SLICE")]
+    assert len(lines) == 2
+    for _tag, n0, n1, thr, infl in lines:                     # the second run of the process keeps the same slice (it used to shrink: 32 -> 4 -> 1)
+        n0, n1 = int(n0), int(n1)
+        assert n1 == max(1, n0 // 8) and 1 <= int(thr) <= n1 and int(infl) >= 1
+    assert open(os.path.join(tmp, "out8", "output.vcf")).read() == open(got).read()
