@@ -587,7 +587,14 @@ def Run(args, log=None):
             if detach:
                 # the decode inputs leave the context as a host snapshot (c3r_rows_begin): this thread goes on to the next contig
                 # while a decode worker turns the snapshot into rows and — single process — merges them (c3r_vcf_merge)
-                snap = eng.rows_begin()
+                # (snapshots hold ~0.3 GB of staging and their contig's reference: the contexts may not run further ahead of the decode
+                # pool than it has workers + 2)
+                snap_slots.acquire()
+                try:
+                    snap = eng.rows_begin()
+                except BaseException:
+                    snap_slots.release()
+                    raise
                 mark(ctg, "snapshot", t1)
                 fut_d = decode_pool.submit(decode_task, snap, ctg)     # (the look-ahead slot is free: the fetched arrays are done with)
                 eng_decodes[engines.index(eng)].append(fut_d)
@@ -613,7 +620,7 @@ def Run(args, log=None):
             mark(ctg, "merge", t1)
             return res
         finally:
-            pass
+            snap_slots.release()
 
     def context_worker(k):
         """Thread of context k: contigs from the shared queue until the end marker, then — once the decodes that still read this
@@ -664,6 +671,7 @@ def Run(args, log=None):
     # candidate is a record: with n_ctx + 1 workers the snapshots queued up behind three merges (full-length GRCh38 timeline)
     n_dec = int(os.environ.get("C3R_DECODE_WORKERS", "0")) or max(2, min(8, (n_thr if world > 1 else (os.cpu_count() or 8)) // 4))
     decode_pool = ThreadPoolExecutor(n_dec)
+    snap_slots = threading.Semaphore(n_dec + 2)                                # snapshots taken but not decoded yet
     eng_decodes = [[] for _ in range(n_ctx)]                                  # decode futures per context (its finish task waits for them)
     stop = threading.Event()
 
@@ -683,6 +691,8 @@ def Run(args, log=None):
                     slots.release()
                 except ValueError:
                     pass
+        for _ in range(n_dec + n_ctx + 4):   # (a context parked on a snapshot slot whose decode will be cancelled below)
+            snap_slots.release()
         for _t in ctx_threads:
             ctx_queue.put(None)
         for t_ in ctx_threads:
@@ -775,6 +785,8 @@ def Run(args, log=None):
     except Exception as e:               # with several ranks: reach the rendezvous first, then every rank fails
         work_err = e
         stop_workers()                   # (idempotent) no thread is inside libc3r any more
+        if merger is not None:
+            merger.discard()             # no truncated output.vcf.gz (without EOF block) beside a stale .tbi
         if world == 1:
             for e_ in engines:
                 e_.close()
@@ -854,6 +866,8 @@ def Run(args, log=None):
             % (t_setup, t_fetch, t_dev, t_merge, t_gz, time() - t_all))
     except Exception as e:               # rank 0 still meets the others at the last rendezvous, and all of them fail
         fin_err = e
+        if merger is not None:
+            merger.discard()
         if world == 1:
             raise
     if world > 1:
@@ -864,7 +878,14 @@ def Run(args, log=None):
 def main(argv=None):
     args = build_parser().parse_args(argv)
     try:
-        return Run(args)
+        try:
+            return Run(args)
+        finally:
+            try:                          # the 8.9-GB blocks libc3r.so keeps for a process's next context: this process has none
+                from . import capi
+                capi.trim()
+            except Exception:
+                pass
     except SystemExit:
         raise
     except Exception as e:       # fail loudly: there is no CPU fallback

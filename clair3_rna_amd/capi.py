@@ -32,7 +32,7 @@ class C3RError(RuntimeError):
         self.code = code
 
 
-EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_last_error", "c3r_synchronize", "c3r_stream",
+EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_trim", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_host_alloc", "c3r_host_free", "c3r_set_reference", "c3r_set_reference_view", "c3r_set_bed", "c3r_set_sites",
            "c3r_pileup_scan", "c3r_pileup_scan_regions", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
            "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_reserve", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_rows_begin", "c3r_rows_decode", "c3r_rows_get", "c3r_rows_free", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
@@ -55,6 +55,8 @@ def load_library():
     L.c3r_create.argtypes = [i32, vp, C.POINTER(vp)]
     L.c3r_destroy.argtypes = [vp]
     L.c3r_destroy.restype = None
+    L.c3r_trim.argtypes = []
+    L.c3r_trim.restype = C.c_int64
     L.c3r_last_error.argtypes = [vp]
     L.c3r_last_error.restype = C.c_char_p
     L.c3r_synchronize.argtypes = [vp]
@@ -149,6 +151,11 @@ def pinned_readset(rs):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def trim():
+    """Give the device blocks libc3r.so keeps between contexts back to the driver (c3r_trim); returns the bytes released."""
+    return int(load_library().c3r_trim())
 
 
 class Engine(object):

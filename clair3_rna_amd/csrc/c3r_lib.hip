@@ -13,6 +13,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -39,6 +40,10 @@ struct KStat { double ms = 0; int64_t n = 0; };
 }  // namespace
 
 struct c3r_rows;
+// host copies of a loaded contig's read headers and packed bases (the decoder reads inserted bases from them): made by the first row
+// snapshot after c3r_load_reads and shared by every later one of the same contig — genotyping mode decodes a contig chunk by chunk
+// (c3r_call_rows ~50 times for chr1) and used to copy 100+ MB each time
+struct HostReads { std::vector<DevRead> reads; std::vector<uint8_t> seq; };
 struct c3r_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -66,6 +71,7 @@ struct c3r_ctx {
     DevBuf d_lcnt;
     bool legacy_valid = false;
     LoadStats *h_stats = nullptr;          // pinned
+    int32_t *h_lstm = nullptr;             // pinned: this context's copy of the layer-2 time-out word (queue_lstm_status)
     void *h_pack = nullptr;                // pinned: the indel-record count of k_pack_tokens
     DevBuf d_tokb, d_tokrec, d_recoff;     // packed tokens of a row snapshot (c3r_rows_begin)
     std::vector<DevRead> h_reads;          // lazily: ensure_host_reads
@@ -97,6 +103,7 @@ struct c3r_ctx {
     std::mutex pool_mu;                                           // guards stage_pool (snapshots are released from other threads)
     std::vector<std::pair<void *, size_t>> stage_pool;            // staging blocks of released row snapshots (stage_pinned())
     c3r_rows *rows_snap = nullptr;                                // c3r_call_rows keeps its snapshot here for c3r_get_rows
+    std::shared_ptr<HostReads> host_cache;                        // of the loaded contig (null until a snapshot needs it)
     DevBuf d_ref;
     std::vector<int32_t> h_bed[2];
     DevBuf d_bed[2];
@@ -164,21 +171,20 @@ int fail(c3r_ctx *ctx, int code, const char *fmt, ...) {
 // The layer-2 kernels meet their wavefronts through LDS counters with bounded waits (net_kernels.hpp, lds_wait): a wait that ever gives
 // up raises g_lstm_timeout instead of hanging the GPU.  Whoever hands probabilities to the host reads the word first — queued behind the
 // network on the same stream, so it costs no extra synchronisation — and fails the call rather than pass on numbers computed from a
-// half-written h_t.
+// half-written h_t.  The word is ONE per process and is never cleared: a time-out is a protocol error, not a load condition, and with
+// several contexts side by side (call_sample runs two) a reader that reset it could hide it from the context whose kernel raised it —
+// once set, every context of the process fails its probability fetches.  The pinned slot the word is copied into belongs to the context
+// (two outstanding queries of one thread used to share one slot).
 int queue_lstm_status(c3r_ctx *ctx, int32_t **slot) {
-    static thread_local int32_t *pinned = nullptr;
-    if (!pinned) HIPCHK(ctx, hipHostMalloc((void **)&pinned, 64, hipHostMallocDefault));
-    *pinned = 0;
-    HIPCHK(ctx, hipMemcpyFromSymbolAsync(pinned, HIP_SYMBOL(g_lstm_timeout), 4, 0, hipMemcpyDeviceToHost, ctx->stream));
-    *slot = pinned;
+    if (!ctx->h_lstm) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lstm, 64, hipHostMallocDefault));
+    *ctx->h_lstm = 0;
+    HIPCHK(ctx, hipMemcpyFromSymbolAsync(ctx->h_lstm, HIP_SYMBOL(g_lstm_timeout), 4, 0, hipMemcpyDeviceToHost, ctx->stream));
+    *slot = ctx->h_lstm;
     return C3R_OK;
 }
 int check_lstm_status(c3r_ctx *ctx, const int32_t *slot) {
-    if (slot && *slot) {
-        const int32_t zero = 0;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_timeout), &zero, 4);
-        return fail(ctx, C3R_EHIP, "internal: a layer-2 wavefront rendezvous timed out — the probabilities of this batch are not valid");
-    }
+    if (slot && *slot)
+        return fail(ctx, C3R_EHIP, "internal: a layer-2 wavefront rendezvous timed out in this process — probabilities are not valid (the flag stays set: restart the process)");
     return C3R_OK;
 }
 
@@ -512,6 +518,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     for (auto &sp : ctx->stage_pool) { stage_free(sp.first); b_pin += sp.second; }
     if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+    if (ctx->h_lstm) (void)hipHostFree(ctx->h_lstm);
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
     for (auto &rb : ctx->refbuf) { if (rb.p) { (void)hipHostFree(rb.p); b_pin += rb.cap; } if (rb.ev) (void)hipEventDestroy(rb.ev); }
     const auto t3 = std::chrono::steady_clock::now();
@@ -525,6 +532,8 @@ void c3r_destroy(c3r_ctx *ctx) {
     }
     delete ctx;
 }
+
+int64_t c3r_trim(void) { return (int64_t)big_trim(); }
 
 const char *c3r_last_error(const c3r_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -559,6 +568,7 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     // whatever happens below, the previous contig's tables are gone
     ctx->n_reads = 0; ctx->n_indel_ops = 0; ctx->n_seq_bytes = 0; ctx->n_cigar_ops = 0; ctx->max_cover = 0;
     ctx->host_reads_valid = false; ctx->host_seq_valid = false; ctx->last_scan_pruned = false; ctx->legacy_valid = false;
+    ctx->host_cache.reset();              // (snapshots of the previous contig keep their copy alive)
     const int n = (int)n_reads;
     int rc;
     // ---- the caller's records go up as they are (three copies; truly asynchronous when the caller's arrays are pinned, see
@@ -1508,7 +1518,8 @@ struct c3r_rows {
     void *stage = nullptr; size_t stage_cap = 0;
     int64_t n = 0, n_tok = 0;
     c3r_site_t *sites = nullptr; uint8_t *tokb = nullptr; float *probs = nullptr; uint32_t *rec_off = nullptr;
-    DevRead *reads = nullptr; uint8_t *seq = nullptr;     // the contig's read headers and packed bases (inserted bases of the alt alleles)
+    std::shared_ptr<HostReads> hr;                        // the contig's read headers and packed bases (inserted bases of the alt alleles)
+    const DevRead *reads = nullptr; const uint8_t *seq = nullptr;
     TokRec *recs = nullptr; int64_t n_recs = 0;           // the tokens that carry an indel (k_pack_tokens), own allocation
     int ref_slot = -1; const char *ref = nullptr; size_t ref_len = 0; int64_t ref_start1 = 1;
     std::string rows; int64_t rows_count = 0;
@@ -1527,8 +1538,8 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const int64_t n_tok = ctx->n_tokspace;           // (token bytes are addressed through the sites' tok_off: the whole slot space)
     const size_t b_sites = up((size_t)n * sizeof(c3r_site_t)), b_tokb = up((size_t)std::max<int64_t>(n_tok, 1)), b_probs = up((size_t)n * C3R_NPROB * sizeof(float)),
-                 b_off = up((size_t)n * 4), b_reads = up((size_t)std::max(ctx->n_reads, 1) * sizeof(DevRead)), b_seq = up((size_t)ctx->n_seq_bytes + 16);
-    const size_t need = b_sites + b_tokb + b_probs + b_off + b_reads + b_seq;
+                 b_off = up((size_t)n * 4);
+    const size_t need = b_sites + b_tokb + b_probs + b_off;
     {   // a block from the pool of released snapshots
         std::lock_guard<std::mutex> g(ctx->pool_mu);
         for (size_t k = 0; k < ctx->stage_pool.size(); ++k)
@@ -1546,9 +1557,15 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     r->tokb = (uint8_t *)sp; sp += b_tokb;
     r->probs = (float *)sp; sp += b_probs;
     r->rec_off = (uint32_t *)sp; sp += b_off;
-    r->reads = (DevRead *)sp; sp += b_reads;
-    r->seq = (uint8_t *)sp;
-    auto bail = [&](int rc) { c3r_rows_free(r); return rc; };
+    const bool fresh_reads = !ctx->host_cache;
+    if (fresh_reads) {
+        ctx->host_cache = std::make_shared<HostReads>();
+        ctx->host_cache->reads.resize((size_t)std::max(ctx->n_reads, 1));
+        ctx->host_cache->seq.resize((size_t)ctx->n_seq_bytes + 16);
+    }
+    r->hr = ctx->host_cache;
+    r->reads = r->hr->reads.data(); r->seq = r->hr->seq.data();
+    auto bail = [&](int rc) { if (fresh_reads) ctx->host_cache.reset(); c3r_rows_free(r); return rc; };      // (a half-copied cache is no cache)
     const bool timing = getenv("C3R_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -1570,8 +1587,8 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     }
     auto d2h = [&](void *dst, const void *src, size_t bytes) { return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess; };
     if (!d2h(ctx->h_pack, d_counter, 8) || !d2h(r->sites, ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t)) || !d2h(r->tokb, ctx->d_tokb.p, (size_t)n_tok) ||
-        !d2h(r->rec_off, ctx->d_recoff.p, (size_t)n * 4) || !d2h(r->reads, ctx->d_reads.p, (size_t)ctx->n_reads * sizeof(DevRead)) ||
-        !d2h(r->seq, ctx->d_seq.p, (size_t)ctx->n_seq_bytes + 16))
+        !d2h(r->rec_off, ctx->d_recoff.p, (size_t)n * 4) ||
+        (fresh_reads && (!d2h(r->hr->reads.data(), ctx->d_reads.p, (size_t)ctx->n_reads * sizeof(DevRead)) || !d2h(r->hr->seq.data(), ctx->d_seq.p, (size_t)ctx->n_seq_bytes + 16))))
         return bail(fail(ctx, C3R_EHIP, "copying sites / tokens / reads to the host failed"));
     int32_t *lstm_st = nullptr;
     rc = queue_lstm_status(ctx, &lstm_st);

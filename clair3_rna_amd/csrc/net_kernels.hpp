@@ -1366,6 +1366,20 @@ inline void big_give(void *p, size_t bytes) {
     (void)hipFree(p);
 }
 
+// every cached block back to the driver (c3r_trim): a host application that destroys its contexts to give HBM back gets all of it
+inline size_t big_trim() {
+    std::vector<BigBlock> all;
+    {
+        std::lock_guard<std::mutex> g(big_mu());
+        all.swap(big_cache());
+    }
+    size_t bytes = 0;
+    int cur = 0; (void)hipGetDevice(&cur);
+    for (auto &b : all) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); bytes += b.bytes; }
+    (void)hipSetDevice(cur);
+    return bytes;
+}
+
 inline void net_free(NetState &s) {
     void *ptrs[] = {s.d_w1, s.d_b1, s.d_w2, s.d_b2, s.d_w4, s.d_b4, s.d_w5, s.d_b5, s.d_wo, s.d_bo, s.d_y2, s.d_a4, s.d_probs,
                     s.d_w1h, s.d_w2h, s.d_w4h, s.d_w4f, s.d_w5p, s.d_wcp, s.d_w1q, s.d_w1s, s.d_w2q, s.d_w2s, s.d_w4q, s.d_w4s};

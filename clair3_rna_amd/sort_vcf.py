@@ -164,6 +164,26 @@ class SampleMerger(object):
         self.n_read = self.n_kept = self.n_tagged = 0
         self.header_done = False
 
+    def discard(self):
+        """Failure path: nothing half-written stays behind — the streamed .gz (no EOF block yet) and its writers go, and so does a
+        .tbi / plain file of an EARLIER run in the same directory, which would otherwise sit beside a truncated result."""
+        import os
+        for w, fn in ((self.out, self.output_fn), (self.out_nt, self.out_nt_fn)):
+            if w is None or fn is None:
+                continue
+            try:
+                if self.stream_gz:
+                    w.discard()
+                else:
+                    w.close()
+            except Exception:
+                pass
+            for stale in (fn, fn + ".gz", fn + ".gz.tbi"):
+                try:
+                    os.remove(stale)
+                except OSError:
+                    pass
+
     def add_contig(self, contig, rows):
         """rows: bytes (or str) of newline-terminated records of `contig`.  The work is done by c3r_vcf_merge
         (csrc/vcfio.cpp); add_contig_py below is the same in Python and is what the golden tests compare it with."""

@@ -44,6 +44,11 @@ const char *c3r_version(void);
  * non-blocking stream) or an existing hipStream_t the caller wants the work ordered on. */
 int c3r_create(int device_id, void *stream, c3r_ctx **out);
 void c3r_destroy(c3r_ctx *ctx);
+/* c3r_destroy keeps up to two of the largest device blocks (the 8.9-GB layer-1 output of a full network slice) for the process's next
+ * context: the driver clears freed memory before it hands it out again, 0.8 s for a block of that size.  c3r_trim() gives them back
+ * (for a host application that destroys its contexts to return HBM to other users of the GPU); returns the bytes released.
+ * C3R_NO_BLOCK_CACHE=1 turns the cache off. */
+int64_t c3r_trim(void);
 const char *c3r_last_error(const c3r_ctx *ctx);
 /* Block until all work queued on the context's stream is complete. */
 int c3r_synchronize(c3r_ctx *ctx);

@@ -16,7 +16,7 @@ int main(int argc, char **argv) {
     if (!a) { fprintf(stderr, "dlopen %s: %s\n", argv[1], dlerror()); return 3; }
     void *b = dlopen(argv[2], RTLD_NOW | RTLD_LOCAL);
     if (!b) { fprintf(stderr, "dlopen %s: %s\n", argv[2], dlerror()); return 3; }
-    NEED(a, c3r_version); NEED(a, c3r_create); NEED(a, c3r_destroy); NEED(a, c3r_last_error); NEED(a, c3r_default_params);
+    NEED(a, c3r_version); NEED(a, c3r_create); NEED(a, c3r_destroy); NEED(a, c3r_trim); NEED(a, c3r_last_error); NEED(a, c3r_default_params);
     NEED(a, c3r_set_params); NEED(a, c3r_load_reads); NEED(a, c3r_set_reference); NEED(a, c3r_pileup_scan); NEED(a, c3r_infer);
     NEED(a, c3r_get_tensors); NEED(a, c3r_get_sites); NEED(a, c3r_get_tokens); NEED(a, c3r_load_weights); NEED(a, c3r_call_rows); NEED(a, c3r_set_precision); NEED(a, c3r_get_precision);
     NEED(b, c3r_bam_open); NEED(b, c3r_bam_fetch); NEED(b, c3r_bam_copy); NEED(b, c3r_bam_close); NEED(b, c3r_bam_index_build); NEED(b, c3r_vcf_merge); NEED(b, c3r_vcf_compress);

@@ -281,3 +281,7 @@ def test_a_failing_fetch_ends_the_run_with_an_error_not_a_hang(tmp_path):
     codes, outs = _launch(tmp, os.path.join(tmp, "bad"), fa, bm, wfn, ["--print_ref_calls"], expect_fail=True)
     assert codes == [1] and "[ERROR] call_sample" in outs[0] and "c3r_bam_fetch" in outs[0], outs
     assert time.time() - t0 < 60
+    # nothing half-written stays behind: no output.vcf.gz without its EOF block, no index (a stale .tbi of an earlier run would sit
+    # beside it)
+    left = sorted(f for f in os.listdir(os.path.join(tmp, "bad")) if f.startswith("output"))
+    assert left == [], left
