@@ -48,6 +48,14 @@ struct c3r_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    // A context that owns its streams keeps TWO: `stream` (the device's highest priority) for everything but the network, and
+    // `net_stream` (default priority) for A6's kernels, chained by events inside c3r_infer.  A layer-2 workgroup owns its CU (8 waves x
+    // 256 VGPRs, 148 KB of LDS: nothing co-resides), and with one priority for all queues the dispatcher did not start another
+    // queue's kernel before the running LSTM kernel had handed out its last workgroup: the ~10 short kernels of another context's
+    // load_reads + scan each waited out most of a 7-14 ms kernel (profiles/r4/prep_beside_network.txt: 75-110 ms beside a network
+    // pass against 2 ms alone).  At high priority they take the CUs as LSTM workgroups retire (one lives ~1.2 ms).
+    hipStream_t net_stream = nullptr;
+    hipEvent_t ev_x = nullptr, ev_net = nullptr;
     std::string err;
     c3r_params_t prm;
     bool profiling = false;
@@ -491,7 +499,17 @@ int c3r_create(int device_id, void *stream, c3r_ctx **out) {
     c3r_default_params(&ctx->prm);
     if (stream) ctx->stream = (hipStream_t)stream;
     else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return C3R_EHIP; }
+        const char *two = getenv("C3R_TWO_STREAMS");
+        if (!(two && *two && *two != '0')) {
+            if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return C3R_EHIP; }
+        } else {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) != hipSuccess) { delete ctx; return C3R_EHIP; }
+            ctx->owns_stream = true;
+            if (hipStreamCreateWithPriority(&ctx->net_stream, hipStreamNonBlocking, least) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->ev_x, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_net, hipEventDisableTiming) != hipSuccess) { c3r_destroy(ctx); return C3R_EHIP; }
+        }
         ctx->owns_stream = true;
     }
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return C3R_EHIP; }
@@ -502,6 +520,7 @@ int c3r_create(int device_id, void *stream, c3r_ctx **out) {
 void c3r_destroy(c3r_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->net_stream) (void)hipStreamSynchronize(ctx->net_stream);
     (void)hipStreamSynchronize(ctx->stream);
     const bool timing = getenv("C3R_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -524,6 +543,9 @@ void c3r_destroy(c3r_ctx *ctx) {
     const auto t3 = std::chrono::steady_clock::now();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->net_stream) (void)hipStreamDestroy(ctx->net_stream);
+    if (ctx->ev_x) (void)hipEventDestroy(ctx->ev_x);
+    if (ctx->ev_net) (void)hipEventDestroy(ctx->ev_net);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     if (timing) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -1459,16 +1481,27 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
     }
     if (n == 0) return C3R_OK;
     std::string e;
+    // the network's kernels go to the context's default-priority stream, behind everything queued on `stream` so far (the tensors, an
+    // uploaded batch); whatever is queued on `stream` afterwards (probabilities, rows, the next batch's tensors) comes behind them
+    hipStream_t nst = ctx->net_stream ? ctx->net_stream : ctx->stream;
+    if (ctx->net_stream) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_x, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->net_stream, ctx->ev_x, 0));
+    }
     auto prof = [&](const char *name, int phase) {
         if (!ctx->profiling) return;
-        if (phase == 0) (void)hipEventRecord(ctx->ev0, ctx->stream);
+        if (phase == 0) (void)hipEventRecord(ctx->ev0, nst);
         else {
-            (void)hipEventRecord(ctx->ev1, ctx->stream); (void)hipEventSynchronize(ctx->ev1);
+            (void)hipEventRecord(ctx->ev1, nst); (void)hipEventSynchronize(ctx->ev1);
             float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
             KStat &k = ctx->kstats[name]; k.ms += ms; k.n += 1;
         }
     };
-    int rc = net_forward(ctx->net, d_x, d_rows, n, ctx->stream, prof, e);
+    int rc = net_forward(ctx->net, d_x, d_rows, n, nst, prof, e);
+    if (ctx->net_stream) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_net, ctx->net_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_net, 0));
+    }
     if (rc) return fail(ctx, rc, "%s", e.c_str());
     if (probs) {
         int32_t *st = nullptr;

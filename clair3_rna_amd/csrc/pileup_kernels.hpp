@@ -408,7 +408,10 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
 }
 
 // All records of [rlo, rhi), WALK_UNR per lane and round: their loads (record, then bases) are issued together.
-constexpr int WALK_UNR = 2;
+#ifndef C3R_WALK_UNR
+#define C3R_WALK_UNR 1
+#endif
+constexpr int WALK_UNR = C3R_WALK_UNR;
 template <int C, int MODE>
 __device__ __forceinline__ void walk_records(const ScanArgs &a, const TileLds &s, int rlo, int rhi, int t0, int t1, int region, EvRec *ev) {
     const int tid = (int)threadIdx.x;
@@ -654,15 +657,22 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     const int rp = p - a.ref_beg0;
     const uint8_t rb = (rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
     const int r0 = lo + tid;
-    DevRead rd0;
-    rd0.pos = 0; rd0.end = 0; rd0.flag = 4;
-    if (r0 < hi && !(a.abl & 4)) rd0 = a.reads[r0];
+    int rd_pos = 0, rd_end = INT32_MIN;                       // read lo + tid as the coverage sees it (end = INT32_MIN: not a covering read)
+    bool rd_rev = false;
+    if (r0 < hi && !(a.abl & 4)) {
+        const DevRead rd0 = a.reads[r0];
+        rd_pos = rd0.pos; rd_rev = (rd0.flag & 16) != 0;
+        if (read_passes(rd0, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, r0)) rd_end = rd0.end;
+    }
     __syncthreads();
 
     C3R_PHASE(0);
     if (!(a.abl & 1)) walk_records<C, ACCUM>(a, s, slo, shi, t0, t1, region, nullptr);
     if (!(a.abl & 4)) {
-        if (r0 < hi) cover_one(a, s, rd0, r0, t0, t1, region);
+        if (rd_end > t0 && rd_pos < t1) {
+            atomicAdd(&s.cov[max(rd_pos, t0) - t0], 1);
+            if (rd_end < t1) atomicAdd(&s.cov[rd_end - t0], -1);
+        }
         cover_reads(a, s, lo + SCAN_THREADS, hi, t0, t1, region);
     }
     __syncthreads();
@@ -819,8 +829,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
 #undef C3R_PHASE
     TileOut o;
     o.is_row = is_row; o.cand = cand; o.depth = depth; o.cov = my_cov;
-    o.rd_pos = rd0.pos; o.rd_rev = (rd0.flag & 16) != 0;
-    o.rd_end = (r0 < hi && read_passes(rd0, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, r0)) ? rd0.end : INT32_MIN;
+    o.rd_pos = rd_pos; o.rd_rev = rd_rev; o.rd_end = rd_end;
     return o;
 }
 
@@ -1778,7 +1787,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             return v;
         };
         if (tid < head) out[tid] = fetch(tid);
-        const int n4 = (total - head) >> 2;
+        const int n4 = (a.abl & 64) ? 0 : (total - head) >> 2;          // (ablation 64: no window store — byte attribution, tools/pmc_bytes.sh)
         {
             // a thread's groups of four lie 4 * SCAN_THREADS ints apart: window index and offset inside the window are carried along
             // (one division per thread instead of one per int); a group that straddles two windows (1 in ~150) takes the general path
@@ -1804,10 +1813,10 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             }
         }
         const int gt = head + 4 * n4 + tid;
-        if (gt < total) out[gt] = fetch(gt);
+        if (gt < total && !(a.abl & 64)) out[gt] = fetch(gt);
         // ---- the candidates' tokens, while the span's records are still in the cache (k_tile_tokens walked the op table a second time:
         // 0.29 ms and 291 MB per chr20 pass).  The accumulators are dead once the windows are out: their LDS holds the token pass's tables
-        if (f.tok) {
+        if (f.tok && !(a.abl & 128)) {                                   // (ablation 128: no token pass)
             __syncthreads();
             if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[7], now_ - t_tail); t_tail = now_; dbg_slot = 8; }
             TokLds &K = *reinterpret_cast<TokLds *>(M.cnt);

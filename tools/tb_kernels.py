@@ -2,6 +2,8 @@
 # or C3R_LIB=<variant>; C3R_SCAN_DBG=1 adds the per-phase clocks of the tile kernel:   python tools/tb_kernels.py [repeats]
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 2:
+    os.environ["C3R_SCAN_ABL"] = sys.argv[2]          # timing / traffic ablations of the tile kernel (results are wrong then)
 from clair3_rna_amd import capi, synth
 import bench
 ref, rs, info = synth.generate_contig(contig_len=synth.CHR20_LEN, seed=synth.SEED, depth=20.0)
