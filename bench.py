@@ -494,6 +494,7 @@ def main():
         # the two halves on their own (device time of each half's kernels in the profiled pass).  The tensor-build half
         # is everything that is not the network: read preparation (upload excluded: copies are not kernels), op table, scan, windows.
         net_ms = sum(v["total_ms"] for k, v in kernels.items() if k in NET_KERNELS)
+        h2d_ms = kernels.pop("h2d_reads", {"total_ms": 0.0})["total_ms"]          # (the upload of the pass's records: PCIe time, reported beside the kernels)
         k1_ms = sum(v["total_ms"] for k, v in kernels.items()) - net_ms
         prep = ("k_prep_count", "k_prefmax_bins", "k_bin_scan", "k_prep_write", "k_legacy_tables")
         prep_ms = sum(v["total_ms"] for k, v in kernels.items() if k in prep)
@@ -509,6 +510,11 @@ def main():
                            achieved=round(tb_gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(tb_gbps / PEAK_HBM_GBPS, 4),
                            bytes_per_site=round(k1_bytes / n_prof, 1) if n_prof else None, bytes_per_pass=int(k1_bytes), ms=round(k1_ms, 3),
                            note="bytes: SURVEY 8(d) formula evaluated on the pass's own candidates and reads (bench.k1_algorithmic_bytes)")
+        h2d_bytes = int(rs.reads.nbytes + rs.cigar.nbytes + rs.seq.nbytes)
+        roofline_tb["h2d"] = dict(bytes=h2d_bytes, ms=round(h2d_ms, 3), GBps=round(h2d_bytes / (h2d_ms * 1e-3) / 1e9, 1) if h2d_ms else None, included_in_ms=False,
+                                  frac_with_h2d=round(k1_bytes / ((k1_ms + h2d_ms) * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if k1_ms else None,
+                                  note="the pass's records go up from page-locked host memory inside c3r_load_reads (PCIe, not HBM): inside every timed step, "
+                                       "outside roofline_tensor_build.ms; frac_with_h2d counts it as if it were kernel time")
         traffic_fn = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
         if roofline and os.path.exists(traffic_fn):
             try:

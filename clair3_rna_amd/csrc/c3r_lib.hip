@@ -595,9 +595,13 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     int rc;
     // ---- the caller's records go up as they are (three copies; truly asynchronous when the caller's arrays are pinned, see
     // c3r_host_alloc) and every table the tile kernels need is derived from them on the device
-    if ((rc = upload(ctx, ctx->d_rawreads, reads, (size_t)n)) || (rc = upload(ctx, ctx->d_rawcig, cigars, (size_t)n_cigar_ops))) return rc;
-    if ((rc = ensure(ctx, ctx->d_seq, (size_t)n_seq_bytes + 16))) return rc;
-    if (n_seq_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq.p, seq4, (size_t)n_seq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ensure(ctx, ctx->d_rawreads, std::max<size_t>((size_t)n * sizeof(c3r_read_t), 16))) || (rc = ensure(ctx, ctx->d_rawcig, std::max<size_t>((size_t)n_cigar_ops * 4, 16))) ||
+        (rc = ensure(ctx, ctx->d_seq, (size_t)n_seq_bytes + 16))) return rc;
+    {
+        Launch l(ctx, "h2d_reads");           // (profiling: the three uploads as one entry of the kernel statistics — PCIe time, not a kernel)
+        if ((rc = upload(ctx, ctx->d_rawreads, reads, (size_t)n)) || (rc = upload(ctx, ctx->d_rawcig, cigars, (size_t)n_cigar_ops))) return rc;
+        if (n_seq_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq.p, seq4, (size_t)n_seq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     HIPCHK(ctx, hipMemsetAsync((char *)ctx->d_seq.p + n_seq_bytes, 0, 16, ctx->stream));        // (the walk reads the packed bases 16 bytes at a time)
     ctx->n_seq_bytes = n_seq_bytes; ctx->n_cigar_ops = n_cigar_ops;
     if (n == 0) return C3R_OK;

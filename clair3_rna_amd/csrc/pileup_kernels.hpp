@@ -1643,6 +1643,10 @@ __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
 // round trip for sizes: outputs are bounds-checked against the buffers' capacity, and the host learns the totals (and whether
 // anything did not fit: then it grows the buffers and repeats the scan) from the single read-back at the end of the scan.
 constexpr int FUSE_IN = TILE - 2 * C3R_FLANK;     // 224
+#ifndef C3R_TICKET_RUN
+#define C3R_TICKET_RUN 4
+#endif
+constexpr int TICKET_RUN = C3R_TICKET_RUN;
 constexpr int TICKET_Q = 16, TICKET_STRIDE = 64;     // ticket words 256 bytes apart: atomics on one cache line serialise like atomics on one word
 // Output rows and token slots are handed out by up to ALLOC_SHARDS sub-allocators, each owning an equal part of the scan's row / token
 // space and ONE 64-bit word (tokens << 32 | rows; the words 256 bytes apart): a span takes both with one returning atomic on its
@@ -1690,12 +1694,15 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
     // queues (queue q = list positions q, q + TICKET_Q, ...), a workgroup draws from its home queue and moves on to the next one when
     // that is empty; the NEXT ticket is drawn before the current span is worked on, so its round trip is hidden; the span's record is
     // one wave-uniform 48-byte load.
-    auto queue_len = [&](int q) { return n > q ? (n - q + TICKET_Q - 1) / TICKET_Q : 0; };
+    // Neighbouring spans share the records of their flanks (a third of what a span reads): runs of TICKET_RUN consecutive list positions
+    // belong to ONE queue, whose workgroups (blockIdx % TICKET_Q, TICKET_Q a multiple of the 8 XCDs) sit on one XCD = behind one L2.
+    auto queue_len = [&](int q) { return n / (TICKET_RUN * TICKET_Q) * TICKET_RUN + min(max(n % (TICKET_RUN * TICKET_Q) - q * TICKET_RUN, 0), TICKET_RUN); };
+    auto list_pos = [&](int q, int t) { return t / TICKET_RUN * (TICKET_RUN * TICKET_Q) + q * TICKET_RUN + t % TICKET_RUN; };
     int home = (int)(blockIdx.x % TICKET_Q);
     auto take = [&]() -> int {                            // (thread 0) next list position, or n when every queue is empty
         for (int tries = 0; tries < TICKET_Q; ++tries) {
             const int len = queue_len(home);
-            if (len > 0) { const int t = atomicAdd(&f.ticket[home * TICKET_STRIDE], 1); if (t < len) return home + t * TICKET_Q; }
+            if (len > 0) { const int t = atomicAdd(&f.ticket[home * TICKET_STRIDE], 1); if (t < len) return list_pos(home, t); }
             home = (home + 1) % TICKET_Q;
         }
         return n;
@@ -1827,7 +1834,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         }
         if (a.dbg && tid == 0) atomicAdd(&a.dbg[dbg_slot], wall_clock64() - t_tail);
         // ---- hand over to the next span: its ticket has long arrived; the barrier also frees this span's LDS
-        if (tid == 0) s_ticket = t_next < queue_len(q_next) ? q_next + t_next * TICKET_Q : take();
+        if (tid == 0) s_ticket = t_next < queue_len(q_next) ? list_pos(q_next, t_next) : take();
         __syncthreads();
         b = s_ticket;
     }

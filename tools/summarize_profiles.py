@@ -2,12 +2,13 @@
 """gpurun_out/prof/<prec>/ (tools/profile_bench.sh) -> profiles/<tag>_kernel_stats_<prec>.csv, <tag>_pmc_<prec>.csv,
 <tag>_bench_<prec>.json and profiles/pmc_traffic.json (per-launch HBM bytes read by bench.py).
 
-HBM bytes per launch = (fetch_factor * FETCH_SIZE + WRITE_SIZE) KB * 1024.  MI355X_MICROARCH.md (HBM section): on gfx950
-FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 B per lane, global_load and buffer_load..lds
-alike) and has to be doubled; other access patterns and WRITE_SIZE are uncalibrated.  The split-f16 layer-2 kernel streams the
-y1 planes exactly that way (LDS-DMA, 1 KiB contiguous per wave-instruction): fetch_factor = 2 there — 2 x 7.5 GB = 15.0 GB
-against 13.65 GB of algorithmic reads (the planes once per direction) plus the weight/L4 slices that miss L2.  Every other
-kernel is reported raw (fetch_factor = 1) and flagged uncalibrated."""
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, per-launch MEDIAN (the first pass of a run sizes the buffers: its
+tile kernel stops early and would pull a mean down).  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half of the
+bytes of a wide coalesced streaming read and "other access widths and WRITE_SIZE are uncalibrated: calibrate on a known byte count in
+your own access pattern".  tools/hbm_calib.hip does (profiles/r4/hbm_counter_calibration.txt): FETCH_SIZE is one half for 16-byte
+streaming loads, for 32-byte records read as two 16-byte loads per lane (the pile records) and for lone 8-byte gathers (64 B reported
+per 128-byte line touched); WRITE_SIZE is exact for streaming 16-byte stores and counts 32 B for a lone 16-byte record.  Both count
+traffic between the L2s and the fabric: Infinity-Cache hits are included, so they bound HBM traffic from above."""
 import collections
 import csv
 import glob
@@ -58,26 +59,47 @@ def main():
         text = open(st[-1]).read()
         open(os.path.join(out, "%s_kernel_stats_%s.csv" % (tag, prec)), "w").write(
             "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
-            "--no_fast --no_resident --no_overlap --precision %s   (MI355X; durations in ns; one context: 1 priming + 1 warm-up + 2 timed passes, "
+            "--no_fast --no_resident --no_overlap --no_strong --precision %s   (MI355X; durations in ns; one context: 1 priming + 1 warm-up + 2 timed passes, "
             "c3r_load_reads inside every pass)\n" % prec + text)
+    # 1b. the LAST pass of the same trace, kernel by kernel (the --stats averages above include the first pass, which sizes the buffers
+    # with a tile kernel that stops early and then repeats it): a pass starts at its k_prep<false> launch
+    tr = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    if tr:
+        ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(tr[-1])))
+        starts = [i for i, e in enumerate(ev) if e[2] == "k_prep_count"]
+        if starts:
+            last = ev[starts[-1]:]
+            per = collections.OrderedDict()
+            for a, b, k in last:
+                n, t = per.get(k, (0, 0))
+                per[k] = (n + 1, t + b - a)
+            net = ("k_lstm1", "k_lstm2", "k_heads_mfma", "k_heads", "k_fc4")
+            with open(os.path.join(out, "%s_last_pass_%s.csv" % (tag, prec)), "w") as f:
+                f.write("# the last timed pass of the trace behind %s_kernel_stats_%s.csv: every launch from its k_prep<false> on (ns)\n" % (tag, prec))
+                f.write("kernel,launches,total_ns\n")
+                for k, (n, t) in per.items():
+                    f.write("%s,%d,%d\n" % (k, n, t))
+                tb = [(n, t) for k, (n, t) in per.items() if k not in net and k.startswith("k_")]
+                f.write("# tensor build (all non-network kernels): %d launches, %.3f ms; network: %.3f ms\n"
+                        % (sum(n for n, _ in tb), sum(t for _, t in tb) / 1e6, sum(t for k, (n, t) in per.items() if k in net) / 1e6))
     # 2. PMC
     rows = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         for k, cs in counters(os.path.join(src, sub)).items():
             for c, v in cs.items():
-                rows.setdefault(k, {})[c] = (sum(v) / len(v), len(v))
+                rows.setdefault(k, {})[c] = (sorted(v)[len(v) // 2], len(v))
     hdr = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]
     traffic = {}
     with open(os.path.join(out, "%s_pmc_%s.csv" % (tag, prec)), "w") as f:
-        f.write("# rocprofv3 --pmc <set> --kernel-trace, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), same bench command; per-launch averages.\n"
-                "# hbm_bytes = (fetch_factor * FETCH_SIZE + WRITE_SIZE) KB * 1024; fetch_factor = 2 for the split-f16 k_lstm2 (wide coalesced streaming reads, MI355X_MICROARCH.md), 1 = raw/uncalibrated elsewhere (tools/summarize_profiles.py); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+        f.write("# rocprofv3 --pmc <set> --kernel-trace, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), same bench command; per-launch medians.\n"
+                "# hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024: FETCH_SIZE reports half of the bytes fetched on gfx950 (MI355X_MICROARCH.md; calibrated on this path's own access patterns by tools/hbm_calib.hip, profiles/r4/hbm_counter_calibration.txt); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                 "(1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); clock_GHz needs the kernel duration and is quoted in DESIGN.md.\n")
         f.write("kernel,launches," + ",".join(hdr) + ",hbm_bytes_per_launch,mfma_busy\n")
         for k in sorted(rows):
             r = rows[k]
             vals = [r.get(h, (0.0, 0))[0] for h in hdr]
             n = max(v[1] for v in r.values())
-            ff = 2.0 if (k == "k_lstm2" and prec in ("f16x3", "f16+f8")) else 1.0      # (precision 2 streams y1 the same way)
+            ff = 2.0
             hbm = (ff * vals[0] + vals[1]) * 1024
             busy = vals[2] / (1024 * vals[3] / 8) if vals[3] else 0.0
             traffic[k] = int(hbm)
