@@ -8,7 +8,7 @@
 One "step" = one full pass of the hot path over one synthetic chr20 (BASELINE.json configs[1]), as SURVEY.md 8(d) defines
 the metric: from the contig's aligned-read records RESIDENT IN HOST MEMORY (flat c3r_read_t records, BAM-encoded CIGARs, 4-bit
 bases — what a BAM reader hands over, where the reference starts `samtools mpileup`, src/create_tensor_pileup.py:436-451) to the
-[n, 24] probabilities on the host: upload + CIGAR normalisation / segmentation / op table on the device (c3r_load_reads), tensor
+[n, 24] probabilities on the host: upload + the position-binned pile table built on the device (c3r_load_reads), tensor
 build over the 13 five-megabase chunks (shared/param_p.py:91: CIGAR walk -> counts -> candidates -> windows), network forward,
 probabilities back.  Only the reference sequence and the weights are resident in HBM before the timed region (they do not change
 from pass to pass).  The rate with the read tables already prepared on the device is reported beside it as `resident_inputs`.  Multi-GPU: every rank owns its own chr20-sized contig (weak scaling, the
@@ -416,7 +416,7 @@ def main():
             rel = shard.reduce_max(dist, rel, device=red_dev)
             rsites = int(shard.reduce_sum(dist, rsites, device=red_dev))
         resident = dict(value=round(rsites / rel, 1), unit="sites/s", ms_per_step=round(1e3 * rel / args.steps, 3),
-                        note="read tables (normalised CIGARs, segments, op table) prepared once outside the timed region; not the headline")
+                        note="read tables (headers, position-binned pile table) prepared once outside the timed region; not the headline")
         host_inputs[0] = True
 
     # ---- the same K steps once more in precision "auto" (f16 main term + fp8 correction terms where the library's calibration through
@@ -492,7 +492,7 @@ def main():
             roofline = dict(kernel=dom, bound="hbm", achieved=None, peak=PEAK_HBM_GBPS, unit="GB/s", frac=None, traffic=None,
                             avg_launch_ms=round(avg_ms, 4), launches=st["launches"])
         # the two halves on their own (device time of each half's kernels in the profiled pass).  The tensor-build half
-        # is everything that is not the network: read preparation (upload excluded: copies are not kernels), op table, scan, windows.
+        # is everything that is not the network: read preparation (upload excluded: copies are not kernels; reported as h2d), scan, windows, tokens.
         net_ms = sum(v["total_ms"] for k, v in kernels.items() if k in NET_KERNELS)
         h2d_ms = kernels.pop("h2d_reads", {"total_ms": 0.0})["total_ms"]          # (the upload of the pass's records: PCIe time, reported beside the kernels)
         k1_ms = sum(v["total_ms"] for k, v in kernels.items()) - net_ms
@@ -505,7 +505,7 @@ def main():
                            tensor_build_algorithmic_GBps=round(tb_gbps, 1) if k1_ms else None,
                            tensor_build_ms=round(k1_ms, 3), read_preparation_ms=round(prep_ms, 3), inference_ms=round(net_ms, 3))
         # the tensor-build half against ITS roofline (HBM): SURVEY 8(d)'s algorithmic bytes, evaluated on this pass's candidates,
-        # over the summed device time of ALL tensor-build kernels of the profiled pass (read preparation and op table included)
+        # over the summed device time of ALL tensor-build kernels of the profiled pass (read preparation included)
         roofline_tb = dict(kernels=sorted(k for k in kernels if k not in NET_KERNELS), bound="hbm",
                            achieved=round(tb_gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(tb_gbps / PEAK_HBM_GBPS, 4),
                            bytes_per_site=round(k1_bytes / n_prof, 1) if n_prof else None, bytes_per_pass=int(k1_bytes), ms=round(k1_ms, 3),
