@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--two_streams", default="", help="e.g. 0,1: repeat every setting with C3R_TWO_STREAMS set that way")
+    ap.add_argument("--env", default="", help="NAME=v1,v2: repeat every setting with that environment variable set to each value")
     ap.add_argument("--extra", default="", help="further call_sample arguments, space-separated")
     a = ap.parse_args()
     tmp = tempfile.mkdtemp(dir="/tmp")
@@ -32,10 +33,13 @@ def main():
     io.write_fasta(fa, contigs); bam.write_bam(bm, [(n, len(r)) for n, r in contigs], reads); bamio.index_build(bm)
     np.save(wfn + ".c3rw.npy", synth.random_weights(18))
     del contigs, reads
-    for ft, ts in [(int(x), t) for x in a.ft.split(",") for t in (a.two_streams.split(",") if a.two_streams else [None])]:
+    ename, evals = ("C3R_TWO_STREAMS", a.two_streams.split(",")) if a.two_streams else (None, [None])
+    if a.env:
+        ename, evals = a.env.split("=")[0], a.env.split("=")[1].split(",")
+    for ft, ts in [(int(x), t) for x in a.ft.split(",") for t in evals]:
         if ts is not None:
-            os.environ["C3R_TWO_STREAMS"] = ts
-            print("C3R_TWO_STREAMS=%s" % ts)
+            os.environ[ename] = ts
+            print("%s=%s" % (ename, ts))
         for rep in range(a.reps):
             out = os.path.join(tmp, "out_%d_%d" % (ft, rep))
             msgs = []

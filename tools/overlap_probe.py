@@ -10,7 +10,7 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 prec = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
 ref, rs, info = synth.generate_contig(contig_len=synth.CHR20_LEN, seed=synth.SEED, depth=20.0)
 chunks = bench.chunk_list(synth.CHR20_LEN)
-rsh = capi.pinned_readset(rs)
+rsh = rs if os.environ.get("PAGEABLE") else capi.pinned_readset(rs)          # PAGEABLE=1: the records in ordinary host memory (the runtime stages the copies)
 weights = synth.random_weights(18)
 
 
