@@ -179,6 +179,15 @@ struct ScanArgs {
     int32_t splice;               // --enable_padding_in_splice_junction_regions: also produce skipmax[], materialise every tile
     int32_t *skipmax;             // [n_pos] max(#read starts, #read ends, #fwd ref-skips, #rev ref-skips) of the row
 };
+// Diagnostics of the tile kernels — per-phase clocks (C3R_SCAN_DBG) and timing / traffic ablations (C3R_SCAN_ABL) — are compiled in only
+// with -DC3R_SCAN_DIAG=1 (tools/build_variant.sh diag -DC3R_SCAN_DIAG=1): in the product build they fold away, which frees the scalar
+// registers their pointer and flags held in a kernel that parks scalars in vector lanes as it is.
+#ifndef C3R_SCAN_DIAG
+#define C3R_SCAN_DIAG 0
+#endif
+#define C3R_DBG(a_) (C3R_SCAN_DIAG ? (a_).dbg : (unsigned long long *)nullptr)
+#define C3R_ABL(a_) (C3R_SCAN_DIAG ? (a_).abl : 0)
+
 
 __device__ __forceinline__ int wave_incl_scan(int v) {
     const int lane = threadIdx.x & 63;
@@ -645,8 +654,8 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     constexpr int EV_LDS = TileMem<C>::EV_LDS;
     const int tid = threadIdx.x;
     TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, M.ev, &M.misc[0], EV_LDS};
-    unsigned long long tprev = a.dbg ? wall_clock64() : 0ull;
-#define C3R_PHASE(K) do { if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[K], now_ - tprev); tprev = now_; } } while (0)
+    unsigned long long tprev = C3R_DBG(a) ? wall_clock64() : 0ull;
+#define C3R_PHASE(K) do { if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[K], now_ - tprev); tprev = now_; } } while (0)
     M.cov[tid] = 0; if (tid == 0) M.cov[TILE] = 0;
     for (int i = tid; i < TILE * C; i += SCAN_THREADS) M.cnt[i] = 0;
     M.evfill[tid] = 0; M.maxdel[tid] = 0; M.amb[tid] = 0; M.odd[tid] = 0;
@@ -659,7 +668,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     const int r0 = lo + tid;
     int rd_pos = 0, rd_end = INT32_MIN;                       // read lo + tid as the coverage sees it (end = INT32_MIN: not a covering read)
     bool rd_rev = false;
-    if (r0 < hi && !(a.abl & 4)) {
+    if (r0 < hi && !(C3R_ABL(a) & 4)) {
         const DevRead rd0 = a.reads[r0];
         rd_pos = rd0.pos; rd_rev = (rd0.flag & 16) != 0;
         if (read_passes(rd0, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, r0)) rd_end = rd0.end;
@@ -667,8 +676,8 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     __syncthreads();
 
     C3R_PHASE(0);
-    if (!(a.abl & 1)) walk_records<C, ACCUM>(a, s, slo, shi, t0, t1, region, nullptr);
-    if (!(a.abl & 4)) {
+    if (!(C3R_ABL(a) & 1)) walk_records<C, ACCUM>(a, s, slo, shi, t0, t1, region, nullptr);
+    if (!(C3R_ABL(a) & 4)) {
         if (rd_end > t0 && rd_pos < t1) {
             atomicAdd(&s.cov[max(rd_pos, t0) - t0], 1);
             if (rd_end < t1) atomicAdd(&s.cov[rd_end - t0], -1);
@@ -685,10 +694,10 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     const int nev = row[C3R_I] + row[C3R_i] + row[C3R_D] + row[C3R_d];
     int tot, ev_total;
     const int2 ex = block_excl_scan2(my_cov_d, nev, M.scan_slot[0], &tot, &ev_total);
-    const int my_cov = (a.abl & 256) ? 1 : ex.x + my_cov_d;
+    const int my_cov = (C3R_ABL(a) & 256) ? 1 : ex.x + my_cov_d;
     M.evoff[tid] = ex.y;
     C3R_PHASE(2);
-    if (ev_total > 0 && !(a.abl & 2)) {
+    if (ev_total > 0 && !(C3R_ABL(a) & 2)) {
         // the tile's indel events, bucketed by position (counting sort through evoff / evfill), then the max multiplicity of one
         // allele per (position, channel): I1 / i1 / D1 / d1
         __syncthreads();                       // (evoff of every position is in place)
@@ -759,7 +768,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         cls[4] = c[C3R_I] + c[C3R_i]; cls[5] = c[C3R_D] + c[C3R_d];
         const bool may_be_cand = p >= cand_lo && p < cand_hi;       // (the fused kernel decides candidates for its inner span only)
         const double denom = depth > 0 ? (double)depth : 1.0;
-        bool pass = (a.abl & 1024) != 0;
+        bool pass = (C3R_ABL(a) & 1024) != 0;
         if (!pass)
         for (int x = 0; x < 4; ++x)
             if (x != refi && cls[x] > 0 && (double)cls[x] / denom >= a.snp_af) pass = true;
@@ -795,7 +804,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         c[ch_up] = -up;
         c[ch_lo] = -lw;
     }
-    if (a.abl & 512) ambiguous = false;
+    if (C3R_ABL(a) & 512) ambiguous = false;
     const bool any_amb = __syncthreads_or(ambiguous ? 1 : 0) != 0;
     C3R_PHASE(4);
 
@@ -825,7 +834,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         }
     }
     C3R_PHASE(6);
-    if (a.dbg && tid == 0) { atomicAdd(&a.dbg[14], (unsigned long long)(shi - slo)); atomicAdd(&a.dbg[15], 1ull); atomicAdd(&a.dbg[13], (unsigned long long)(hi - lo)); atomicAdd(&a.dbg[12], (unsigned long long)ev_total); }
+    if (C3R_DBG(a) && tid == 0) { atomicAdd(&C3R_DBG(a)[14], (unsigned long long)(shi - slo)); atomicAdd(&C3R_DBG(a)[15], 1ull); atomicAdd(&C3R_DBG(a)[13], (unsigned long long)(hi - lo)); atomicAdd(&C3R_DBG(a)[12], (unsigned long long)ev_total); }
 #undef C3R_PHASE
     TileOut o;
     o.is_row = is_row; o.cand = cand; o.depth = depth; o.cov = my_cov;
@@ -842,8 +851,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs &a, const int tile, Til
     const int t0 = tg.p0, t1 = tg.p1;
     const int slot0 = tile * TILE;        // index of the tile's first position in cols / depth / ncov / flags
     const int4 rng = a.tile_rng[tile];
-    if ((a.abl & 16) && rng.z >= rng.w) return;   // ablation: skip intron-only tiles
-    if ((a.abl & 32) && rng.z < rng.w) return;    // ablation: skip tiles with aligned bases
+    if ((C3R_ABL(a) & 16) && rng.z >= rng.w) return;   // ablation: skip intron-only tiles
+    if ((C3R_ABL(a) & 32) && rng.z < rng.w) return;    // ablation: skip tiles with aligned bases
     const int lo = rng.x, hi = rng.y;       // reads whose span can overlap [t0,t1)
     const int slo = rng.z, shi = rng.w;     // records of the pile table that can touch it
     if (slo >= shi) {
@@ -889,7 +898,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs &a, const int tile, Til
     // ---- write the tile's columns, coalesced
     const int npos = t1 - t0;
     int32_t *gcol = a.cols + (size_t)slot0 * C;
-    if (!(a.abl & 8))
+    if (!(C3R_ABL(a) & 8))
     for (int i = tid; i < npos * C; i += SCAN_THREADS) gcol[i] = M.cnt[i];
     if (tid == 0) a.tile_cols[tile] = 1;
     // ---- per-position metadata
@@ -1721,7 +1730,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         const int2 rb = make_int2(r2.x, r2.y);
         const int x0 = tg.p0 - C3R_FLANK, x1 = min(tg.p1 + C3R_FLANK, rb.y);       // thread tid <-> position x0 + tid
         const TileOut o = tile_columns<C>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1);
-        unsigned long long t_tail = a.dbg ? wall_clock64() : 0ull;
+        unsigned long long t_tail = C3R_DBG(a) ? wall_clock64() : 0ull;
         int dbg_slot = 7;
         if (C == C3R_CH_PHASED) {
             // a column whose haplotype channels depend on the ORDER of the reads (see k_phase_recompute): redone in place, one thread
@@ -1746,12 +1755,12 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             if (sh > 64 - C3R_WINDOW) bits |= M.rowmask[w + 1] << (64 - sh);          // (first + 32 <= 255: w + 1 <= 3)
             constexpr unsigned long long ALL = (1ull << C3R_WINDOW) - 1ull;
             emit = (bits & ALL) == ALL;
-            if (a.abl & 2048) emit = false;
+            if (C3R_ABL(a) & 2048) emit = false;
         }
-        if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[9], now_ - t_tail); t_tail = now_; }
+        if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[9], now_ - t_tail); t_tail = now_; }
         int nc, nt;
         const int2 ex = block_excl_scan2(emit ? 1 : 0, emit ? o.cov : 0, M.scan_slot[1], &nc, &nt);
-        if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[10], now_ - t_tail); t_tail = now_; }
+        if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[10], now_ - t_tail); t_tail = now_; }
         const int rank = ex.x, tpre = ex.y;
         // per candidate (by rank): position in the span, depth for the window copy, tokens of the span's earlier candidates — the event
         // arrays are free by now
@@ -1766,7 +1775,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             s_row0 = shard * f.shard_rows + lrow;
             s_tok0 = shard * f.shard_toks + ltok;
             f.span_info[b] = make_int4(s_row0, nc, nt, s_tok0);
-            if (a.dbg) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[11], now_ - t_tail); t_tail = now_; }
+            if (C3R_DBG(a)) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[11], now_ - t_tail); t_tail = now_; }
         }
         __syncthreads();
         const int row0 = s_row0, tok0 = s_tok0;
@@ -1794,7 +1803,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             return v;
         };
         if (tid < head) out[tid] = fetch(tid);
-        const int n4 = (a.abl & 64) ? 0 : (total - head) >> 2;          // (ablation 64: no window store — byte attribution, tools/pmc_bytes.sh)
+        const int n4 = (C3R_ABL(a) & 64) ? 0 : (total - head) >> 2;          // (ablation 64: no window store — byte attribution, tools/pmc_bytes.sh)
         {
             // a thread's groups of four lie 4 * SCAN_THREADS ints apart: window index and offset inside the window are carried along
             // (one division per thread instead of one per int); a group that straddles two windows (1 in ~150) takes the general path
@@ -1820,19 +1829,19 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             }
         }
         const int gt = head + 4 * n4 + tid;
-        if (gt < total && !(a.abl & 64)) out[gt] = fetch(gt);
+        if (gt < total && !(C3R_ABL(a) & 64)) out[gt] = fetch(gt);
         // ---- the candidates' tokens, while the span's records are still in the cache (k_tile_tokens walked the op table a second time:
         // 0.29 ms and 291 MB per chr20 pass).  The accumulators are dead once the windows are out: their LDS holds the token pass's tables
-        if (f.tok && !(a.abl & 128)) {                                   // (ablation 128: no token pass)
+        if (f.tok && !(C3R_ABL(a) & 128)) {                                   // (ablation 128: no token pass)
             __syncthreads();
-            if (a.dbg && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&a.dbg[7], now_ - t_tail); t_tail = now_; dbg_slot = 8; }
+            if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[7], now_ - t_tail); t_tail = now_; dbg_slot = 8; }
             TokLds &K = *reinterpret_cast<TokLds *>(M.cnt);
             tile_tokens(a, K, x0, x1, tg.region, rng.x, rng.y, rng.z, rng.w, nc, [&](int k, int &lp, int &off) {
                 lp = (int)M.amb[k]; off = f.tok_base + tok0 + M.evoff[k];
             }, f.tok, (long long)f.tok_base + (long long)(shard + 1) * f.shard_toks, &o);
         }
         }
-        if (a.dbg && tid == 0) atomicAdd(&a.dbg[dbg_slot], wall_clock64() - t_tail);
+        if (C3R_DBG(a) && tid == 0) atomicAdd(&C3R_DBG(a)[dbg_slot], wall_clock64() - t_tail);
         // ---- hand over to the next span: its ticket has long arrived; the barrier also frees this span's LDS
         if (tid == 0) s_ticket = t_next < queue_len(q_next) ? list_pos(q_next, t_next) : take();
         __syncthreads();

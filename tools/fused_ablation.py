@@ -1,6 +1,14 @@
 # k_fused_tiles under timing-only ablations (env C3R_SCAN_ABL bits: 1 no record walk, 2 no indel events, 4 no coverage, 64 no window store,
 # 128 no tokens; results are wrong, times are what is measured):   python tools/fused_ablation.py
+# (the ablation / phase-clock code is compiled in only with -DC3R_SCAN_DIAG=1:  bash tools/build_variant.sh diag -DC3R_SCAN_DIAG=1, then
+#  C3R_LIB=gpurun_variants/libc3r_diag.so; this script picks that library up by itself when it exists and C3R_LIB is not set)
 import os, sys
+if "C3R_LIB" not in os.environ:
+    _d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_variants", "libc3r_diag.so")
+    if os.path.exists(_d):
+        os.environ["C3R_LIB"] = _d
+    else:
+        sys.stderr.write("no gpurun_variants/libc3r_diag.so: C3R_SCAN_ABL / C3R_SCAN_DBG have no effect on the product build\n")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from clair3_rna_amd import capi, synth
 import bench

@@ -1,6 +1,7 @@
 #!/bin/bash
 # HBM counter bytes (FETCH_SIZE, WRITE_SIZE: separate --pmc passes with --kernel-trace only) of the tensor-build kernels of a chr20 pass,
-# optionally under a timing ablation of the tile kernel (C3R_SCAN_ABL):   gpurun -- bash tools/pmc_bytes.sh <tag> [abl]
+# optionally under a timing ablation of the tile kernel (C3R_SCAN_ABL; needs gpurun_variants/libc3r_diag.so = bash tools/build_variant.sh diag
+# -DC3R_SCAN_DIAG=1, which tools/tb_kernels.py then loads):   gpurun -- bash tools/pmc_bytes.sh <tag> [abl]
 TAG=${1:-x}; ABL=${2:-0}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

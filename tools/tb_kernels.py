@@ -2,8 +2,10 @@
 # or C3R_LIB=<variant>; C3R_SCAN_DBG=1 adds the per-phase clocks of the tile kernel:   python tools/tb_kernels.py [repeats]
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and sys.argv[2] != "0":
     os.environ["C3R_SCAN_ABL"] = sys.argv[2]          # timing / traffic ablations of the tile kernel (results are wrong then)
+    if "C3R_LIB" not in os.environ:                   # (compiled in only with -DC3R_SCAN_DIAG=1: bash tools/build_variant.sh diag -DC3R_SCAN_DIAG=1)
+        os.environ["C3R_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_variants", "libc3r_diag.so")
 from clair3_rna_amd import capi, synth
 import bench
 ref, rs, info = synth.generate_contig(contig_len=synth.CHR20_LEN, seed=synth.SEED, depth=20.0)
