@@ -81,6 +81,12 @@ struct c3r_ctx {
     LoadStats *h_stats = nullptr;          // pinned
     int32_t *h_lstm = nullptr;             // pinned: this context's copy of the layer-2 time-out word (queue_lstm_status)
     void *h_pack = nullptr;                // pinned: the indel-record count of k_pack_tokens
+    // large copies from / to ORDINARY host memory go through two page-locked 8-MB buffers the context owns (big_h2d / big_d2h): the
+    // runtime would pin the caller's pages for every copy and unpin them afterwards, which takes the process's memory-map lock — the
+    // lock the BAM fetchers' page faults take as well (call_sample: 8-120 ms for a contig's records where the transfer is 3 ms)
+    char *pin_buf[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};
     DevBuf d_tokb, d_tokrec, d_recoff;     // packed tokens of a row snapshot (c3r_rows_begin)
     std::vector<DevRead> h_reads;          // lazily: ensure_host_reads
     std::vector<int32_t> h_prefmax;        // lazily: host copy of the prefix max of read ends (passing reads)
@@ -257,13 +263,91 @@ int ensure_keep(c3r_ctx *ctx, DevBuf &b, size_t bytes, size_t used) {
     return C3R_OK;
 }
 
+int big_h2d_fwd(c3r_ctx *ctx, void *dst, const void *src, size_t bytes);
 template <typename T>
 int upload(c3r_ctx *ctx, DevBuf &b, const T *src, size_t n) {
     int rc = ensure(ctx, b, std::max<size_t>(n * sizeof(T), 16));
     if (rc) return rc;
-    if (n) HIPCHK(ctx, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    if (n) return big_h2d_fwd(ctx, b.p, src, n * sizeof(T));
     return C3R_OK;
 }
+
+// ---- large copies between ordinary (pageable) host memory and the device, staged through the context's two page-locked buffers
+constexpr size_t PIN_CHUNK = (size_t)8 << 20, PIN_MIN = (size_t)1 << 20;
+bool pin_ring_on() {
+    static const bool on = [] { const char *e = getenv("C3R_PIN_RING"); return !(e && *e == '0'); }();
+    return on;
+}
+bool host_is_page_locked(const void *p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+int pin_ring_init(c3r_ctx *ctx) {
+    for (int k = 0; k < 2; ++k) {
+        if (!ctx->pin_buf[k]) HIPCHK(ctx, hipHostMalloc((void **)&ctx->pin_buf[k], PIN_CHUNK, hipHostMallocDefault));
+        if (!ctx->pin_ev[k]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->pin_ev[k], hipEventDisableTiming));
+    }
+    return C3R_OK;
+}
+// host -> device; on return the caller's bytes have been read (the last chunks may still be on their way to the device, in stream order)
+int big_h2d(c3r_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return C3R_OK;
+    if (bytes < PIN_MIN || !pin_ring_on() || host_is_page_locked(src)) {
+        HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return C3R_OK;
+    }
+    int rc = pin_ring_init(ctx);
+    if (rc) return rc;
+    size_t off = 0;
+    for (int i = 0; off < bytes; ++i) {
+        const int k = i & 1;
+        const size_t n = std::min(PIN_CHUNK, bytes - off);
+        if (ctx->pin_busy[k]) HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[k]));          // the transfer out of this buffer is through
+        memcpy(ctx->pin_buf[k], (const char *)src + off, n);
+        HIPCHK(ctx, hipMemcpyAsync((char *)dst + off, ctx->pin_buf[k], n, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->pin_ev[k], ctx->stream));
+        ctx->pin_busy[k] = true;
+        off += n;
+    }
+    return C3R_OK;
+}
+// device -> host, complete on return (the transfer of chunk i runs beside the host copy of chunk i - 1)
+int big_d2h(c3r_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return C3R_OK;
+    if (bytes < PIN_MIN || !pin_ring_on() || host_is_page_locked(dst)) {
+        HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return C3R_OK;
+    }
+    int rc = pin_ring_init(ctx);
+    if (rc) return rc;
+    size_t off = 0, prev_off = 0, prev_n = 0;
+    int i = 0;
+    for (; off < bytes; ++i) {
+        const int k = i & 1;
+        const size_t n = std::min(PIN_CHUNK, bytes - off);
+        if (ctx->pin_busy[k]) HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[k]));          // (an upload that used the buffer before)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_buf[k], (const char *)src + off, n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->pin_ev[k], ctx->stream));
+        ctx->pin_busy[k] = true;
+        if (i > 0) {
+            const int pk = k ^ 1;
+            HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[pk]));
+            memcpy((char *)dst + prev_off, ctx->pin_buf[pk], prev_n);
+            ctx->pin_busy[pk] = false;
+        }
+        prev_off = off; prev_n = n; off += n;
+    }
+    const int lk = (i - 1) & 1;
+    HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[lk]));
+    memcpy((char *)dst + prev_off, ctx->pin_buf[lk], prev_n);
+    ctx->pin_busy[lk] = false;
+    return C3R_OK;
+}
+
+int big_h2d_fwd(c3r_ctx *ctx, void *dst, const void *src, size_t bytes) { return big_h2d(ctx, dst, src, bytes); }
 
 // Launch helper: optional per-kernel HIP-event timing on the context's stream.
 struct Launch {
@@ -537,6 +621,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     for (auto &sp : ctx->stage_pool) { stage_free(sp.first); b_pin += sp.second; }
     if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+    for (int k = 0; k < 2; ++k) { if (ctx->pin_buf[k]) (void)hipHostFree(ctx->pin_buf[k]); if (ctx->pin_ev[k]) (void)hipEventDestroy(ctx->pin_ev[k]); }
     if (ctx->h_lstm) (void)hipHostFree(ctx->h_lstm);
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
     for (auto &rb : ctx->refbuf) { if (rb.p) { (void)hipHostFree(rb.p); b_pin += rb.cap; } if (rb.ev) (void)hipEventDestroy(rb.ev); }
@@ -600,7 +685,7 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     {
         Launch l(ctx, "h2d_reads");           // (profiling: the three uploads as one entry of the kernel statistics — PCIe time, not a kernel)
         if ((rc = upload(ctx, ctx->d_rawreads, reads, (size_t)n)) || (rc = upload(ctx, ctx->d_rawcig, cigars, (size_t)n_cigar_ops))) return rc;
-        if (n_seq_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq.p, seq4, (size_t)n_seq_bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (n_seq_bytes && (rc = big_h2d(ctx, ctx->d_seq.p, seq4, (size_t)n_seq_bytes))) return rc;
     }
     HIPCHK(ctx, hipMemsetAsync((char *)ctx->d_seq.p + n_seq_bytes, 0, 16, ctx->stream));        // (the walk reads the packed bases 16 bytes at a time)
     ctx->n_seq_bytes = n_seq_bytes; ctx->n_cigar_ops = n_cigar_ops;
@@ -683,7 +768,7 @@ int c3r_set_reference_view(c3r_ctx *ctx, int64_t ref_start, const char *ref_uppe
     ctx->ref_start1 = ref_start;
     int rc = ensure(ctx, ctx->d_ref, std::max<size_t>((size_t)len, 16));
     if (rc) return rc;
-    if (len) HIPCHK(ctx, hipMemcpyAsync(ctx->d_ref.p, ref_upper, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
+    if (len && (rc = big_h2d(ctx, ctx->d_ref.p, ref_upper, (size_t)len))) return rc;
     ctx->ref_len = (size_t)len;
     return C3R_OK;
 }
@@ -1622,7 +1707,11 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
         hipLaunchKernelGGL(k_pack_tokens, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const c3r_site_t *)ctx->d_sites_out.p, (const c3r_token_t *)ctx->d_tok.p, n,
                            (uint8_t *)ctx->d_tokb.p, (TokRec *)ctx->d_tokrec.p, (uint32_t *)ctx->d_recoff.p, d_counter);
     }
-    auto d2h = [&](void *dst, const void *src, size_t bytes) { return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess; };
+    // (the snapshot's block is ordinary memory: the large arrays come down through the context's page-locked buffers, big_d2h)
+    auto d2h = [&](void *dst, const void *src, size_t bytes) {
+        if (bytes >= PIN_MIN && pin_ring_on()) return big_d2h(ctx, dst, src, bytes) == C3R_OK;
+        return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    };
     if (!d2h(ctx->h_pack, d_counter, 8) || !d2h(r->sites, ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t)) || !d2h(r->tokb, ctx->d_tokb.p, (size_t)n_tok) ||
         !d2h(r->rec_off, ctx->d_recoff.p, (size_t)n * 4) ||
         (fresh_reads && (!d2h(r->hr->reads.data(), ctx->d_reads.p, (size_t)ctx->n_reads * sizeof(DevRead)) || !d2h(r->hr->seq.data(), ctx->d_seq.p, (size_t)ctx->n_seq_bytes + 16))))
@@ -1638,7 +1727,7 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     if (r->n_recs > 0) {
         r->recs = (TokRec *)huge_alloc((size_t)r->n_recs * sizeof(TokRec));
         if (!r->recs) return bail(fail(ctx, C3R_ENOMEM, "indel records of %lld tokens: allocation failed", (long long)r->n_recs));
-        if (hipMemcpy(r->recs, ctx->d_tokrec.p, (size_t)r->n_recs * sizeof(TokRec), hipMemcpyDeviceToHost) != hipSuccess)
+        if (!d2h(r->recs, ctx->d_tokrec.p, (size_t)r->n_recs * sizeof(TokRec)) || hipStreamSynchronize(ctx->stream) != hipSuccess)
             return bail(fail(ctx, C3R_EHIP, "copying indel records to the host failed"));
     }
     if (timing)

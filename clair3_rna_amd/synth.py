@@ -195,9 +195,11 @@ def small_case(seed=1, ref_len=60000, n_genes=12, depth=20, platform="ont", phas
     return ref, rs, truth
 
 
-def random_weights(channels, seed=1234):
+def random_weights(channels, seed=1234, ref_bias=0.0):
     """Seeded random network weights in the blob layout of include/c3r.h (Keras order).
-    N(0,0.05) input kernels, N(0,0.02) recurrent kernels, unit forget-gate bias."""
+    N(0,0.05) input kernels, N(0,0.02) recurrent kernels, unit forget-gate bias.
+    ref_bias > 0 is added to the bias of the zygosity head's hom-ref class: random weights call every candidate a variant, a trained
+    model calls a few percent (tools/e2e_full.py --ref_bias: the host stages behind the network at a realistic record rate)."""
     rng = np.random.RandomState(seed)
     parts = []
     for (cin, H) in ((channels, 128), (256, 160)):
@@ -215,7 +217,9 @@ def random_weights(channels, seed=1234):
     parts.append(rng.normal(0, 0.3, size=(128, 21)))
     parts.append(rng.normal(0, 0.1, size=21))
     parts.append(rng.normal(0, 0.3, size=(128, 3)))
-    parts.append(rng.normal(0, 0.1, size=3))
+    zb = rng.normal(0, 0.1, size=3)
+    zb[0] += ref_bias
+    parts.append(zb)
     return np.concatenate([p.reshape(-1) for p in parts]).astype(np.float32)
 
 

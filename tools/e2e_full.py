@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--two_streams", default="", help="e.g. 0,1: repeat every setting with C3R_TWO_STREAMS set that way")
     ap.add_argument("--env", default="", help="NAME=v1,v2: repeat every setting with that environment variable set to each value")
+    ap.add_argument("--ref_bias", type=float, default=0.0, help="synth.random_weights(ref_bias=...): > 0 makes most candidates reference calls (no VCF record), as a trained model does")
     ap.add_argument("--extra", default="", help="further call_sample arguments, space-separated")
     a = ap.parse_args()
     tmp = tempfile.mkdtemp(dir="/tmp")
@@ -31,7 +32,7 @@ def main():
         contigs.append(("chr%d" % (i + 1), ref.decode())); reads["chr%d" % (i + 1)] = rs
     fa, bm, wfn = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "in.bam"), os.path.join(tmp, "model")
     io.write_fasta(fa, contigs); bam.write_bam(bm, [(n, len(r)) for n, r in contigs], reads); bamio.index_build(bm)
-    np.save(wfn + ".c3rw.npy", synth.random_weights(18))
+    np.save(wfn + ".c3rw.npy", synth.random_weights(18, ref_bias=a.ref_bias))
     del contigs, reads
     ename, evals = ("C3R_TWO_STREAMS", a.two_streams.split(",")) if a.two_streams else (None, [None])
     if a.env:
@@ -47,6 +48,8 @@ def main():
             call_sample.Run(call_sample.build_parser().parse_args(["--bam_fn", bm, "--ref_fn", fa, "--output_dir", out, "--pileup_model_path", wfn,
                                                                     "--fetch_threads", str(ft)] + a.extra.split()), log=msgs.append)
             print("fetch_threads %2d rep %d: %.2f s   %s" % (ft, rep, time.time() - t0, msgs[-1].strip()), flush=True)
+            if rep == 0:
+                print("   " + " ".join(m.strip() for m in msgs if "records written" in m), flush=True)
             if os.environ.get("C3R_TIMING"):
                 print("\n".join(m for m in msgs if "[timeline" in m or "[device_stage" in m), flush=True)
 

@@ -1,12 +1,12 @@
 #!/bin/bash
 # The whole-sample driver on 22 full-length GRCh38 contigs: wall time at several fetch-thread counts, then one kernel-traced repeat at
-# 8 fetch threads for the GPU-busy fraction and the launch count per contig.   gpurun -- bash tools/e2e_trace.sh > profiles/rN/sample_full_scale.txt
+# 8 fetch threads for the GPU-busy fraction and the launch count per contig.   gpurun -- bash tools/e2e_trace.sh [e2e_full.py arguments, e.g. --ref_bias 4] > profiles/rN/sample_full_scale.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/e2e
 rm -rf $OUT; mkdir -p $OUT
-python3 $R/tools/e2e_full.py --ft 6,8,12 --reps 3 2>&1 | grep -v "^\[" 
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/tools/e2e_full.py --ft 8 --reps 2 > $OUT/trace.log 2>&1
+python3 $R/tools/e2e_full.py --ft 6,8,12 --reps 3 "$@" 2>&1 | grep -v "^\[" 
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/tools/e2e_full.py --ft 8 --reps 2 "$@" > $OUT/trace.log 2>&1
 grep "fetch_threads" $OUT/trace.log
 python3 - <<PY
 import csv, glob, re, collections
