@@ -253,8 +253,8 @@ def run_strong(args, rank, local_rank, world, one_gpu, emit=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--depth", type=float, default=20.0)
     ap.add_argument("--contig_len", type=int, default=0, help="default: chr20 (64,444,167)")
     ap.add_argument("--contexts", type=int, default=2, help="engine contexts (HIP streams) whose passes are pipelined on the GPU")

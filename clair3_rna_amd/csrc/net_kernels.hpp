@@ -1079,6 +1079,9 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
     x_fetch(dir ? NET_T - 1 : 0);
     x_store(0);
     __syncthreads();
+#ifndef C3R_L1_K8
+#define C3R_L1_K8 1          // k_lstm1_rs, 18 channels: the 3 used slots of the second input group as a K = 8 product
+#endif
 #ifndef C3R_L1_RS_PRIO
 #define C3R_L1_RS_PRIO 0     // k_lstm1_rs: raise the priority of the wavefronts that arrive last on their SIMD (blk >= this value; 0: off)
 #endif
@@ -1104,9 +1107,19 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
             static_for<0, NG>([&](auto gc) {
                 constexpr int G = decltype(gc)::value;
                 if constexpr (G + 1 < NG) ldb(std::integral_constant<int, G + 1>{}, bh[(G + 1) & 1], bl[(G + 1) & 1]);
+                if constexpr (C3R_L1_K8 && G == NGX - 1 && CIN + 1 <= 16 + 4) {
+                    // the second input group holds channels 16 .. CIN - 1 and the bias slot CIN, zeros after them: a K = 8 product covers it
+                    // (lane half hh takes k = 4 hh .. 4 hh + 3 of the group: for hh = 0 the first half of the lane's K = 16 fragment, for
+                    // hh = 1 zeros — as is the first half of ITS fragment, k = 8 .. 11 of the group)
+                    const half4 a_h = __builtin_shufflevector(wh[G], wh[G], 0, 1, 2, 3), a_l = __builtin_shufflevector(wl[G], wl[G], 0, 1, 2, 3);
+                    const half4 b_h = __builtin_shufflevector(bh[G & 1], bh[G & 1], 0, 1, 2, 3);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x8f16(a_h, b_h, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x8f16(a_l, b_h, acc, 0, 0, 0);
+                } else {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[G], bh[G & 1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[G], bh[G & 1], acc, 0, 0, 0);
                 if constexpr (G >= NGX) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[G], bl[G & 1], acc, 0, 0, 0);      // (the int32 input has no lo half)
+                }
             });
             // ---- lane-local cell update of the block (four units per lane)
             constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
