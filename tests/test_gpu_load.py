@@ -208,3 +208,36 @@ def test_reserve_sizes_the_network_before_the_first_infer():
         finally:
             e.close()
     assert np.array_equal(probs[0], probs[1])
+
+
+def test_large_pageable_arrays_through_the_staging_buffers(eng):
+    """Copies of 1 MB and more from / to ordinary host memory go through the context's two page-locked 8-MB buffers (c3r_lib.hip, big_h2d /
+    big_d2h): the full synthetic chr20 — 14 MB of CIGARs and 19.7 MB of bases, three chunks each way round — loaded from ordinary numpy
+    arrays and from c3r_host_alloc memory (the direct path) gives the same sites, tokens and tensors, and the row snapshot (sites, packed
+    tokens, probabilities, read headers and bases copied DOWN through the same buffers) decodes to the same rows as the in-context decode."""
+    import bench
+    from clair3_rna_amd import capi, synth
+    ref, rs, _info = synth.generate_contig()
+    assert rs.seq.nbytes > 2 * (8 << 20) and rs.cigar.nbytes > (8 << 20)
+    chunks = bench.chunk_list(len(ref))[5:8]
+    out = []
+    for records in (rs, capi.pinned_readset(rs)):
+        eng.params = capi.default_params()
+        eng.set_bed(0, None); eng.set_bed(1, None)
+        eng.set_params()
+        eng.load_reads(records)
+        eng.set_reference(1, ref)
+        eng.begin_batch()
+        n = eng.scan_regions(chunks)
+        eng.end_batch()
+        out.append((n, eng.sites().tobytes(), eng.tokens().tobytes(), eng.tensors().tobytes()))
+    assert out[0][0] == out[1][0] > 30000
+    assert out[0] == out[1]
+    eng.load_weights(synth.random_weights(18), 18)
+    eng.set_precision("f16x3")
+    eng.infer(fetch=False)
+    rows_ctx = eng.call_rows_text("chr20")[0]
+    snap = eng.rows_begin()
+    rows_snap = snap.decode("chr20")[0]
+    snap.free()
+    assert bytes(rows_ctx) == bytes(rows_snap) and len(rows_ctx) > 1 << 20
