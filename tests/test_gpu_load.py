@@ -241,3 +241,33 @@ def test_large_pageable_arrays_through_the_staging_buffers(eng):
     rows_snap = snap.decode("chr20")[0]
     snap.free()
     assert bytes(rows_ctx) == bytes(rows_snap) and len(rows_ctx) > 1 << 20
+
+
+def test_a_two_stream_context_computes_the_same(eng, monkeypatch):
+    """C3R_TWO_STREAMS=1: the context's own stream at the device's highest priority, the network's kernels on a
+    second stream chained by events inside c3r_infer.  Same tensors, same probabilities, same rows as the one-stream context, also when
+    passes follow each other without a host wait in between (the next batch's tensors must not overtake the running network)."""
+    from clair3_rna_amd import capi, synth
+    ref, rs, _ = synth.small_case(seed=23, ref_len=80000, n_genes=12, depth=30)
+    w = synth.random_weights(18)
+    monkeypatch.setenv("C3R_TWO_STREAMS", "1")
+    two = capi.Engine(0)
+    monkeypatch.delenv("C3R_TWO_STREAMS")
+    try:
+        res = []
+        for e in (eng, two):
+            e.params = capi.default_params()
+            e.set_bed(0, None); e.set_bed(1, None)
+            e.set_params()
+            e.load_weights(w, 18); e.set_precision("f16x3")
+            got = []
+            for rep in range(3):
+                e.load_reads(rs); e.set_reference(1, ref)
+                n = e.scan(1, len(ref))
+                e.infer(fetch=False)
+                if rep == 2:
+                    got = [n, e.fetch_probs(n).tobytes(), e.tensors().tobytes(), bytes(e.call_rows_text("chr20")[0])]
+            res.append(got)
+        assert res[0][0] > 100 and res[0] == res[1]
+    finally:
+        two.close()
