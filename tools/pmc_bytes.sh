@@ -9,6 +9,7 @@ OUT=$R/gpurun_out/pmc_bytes/$TAG
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -- python3 $R/tools/tb_kernels.py 2 $ABL > $OUT/f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/w -- python3 $R/tools/tb_kernels.py 2 $ABL > $OUT/w.log 2>&1
+[ -x $R/tools/hbm_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/hbm_calib.hip -o $R/tools/hbm_calib          # (the binary is not kept in the tree)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cf -- $R/tools/hbm_calib > $OUT/cf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cw -- $R/tools/hbm_calib > $OUT/cw.log 2>&1
 python3 - <<PY
