@@ -20,7 +20,32 @@ def evc_base(b):
     return b if b in "ACGT" else "A"
 
 
-def alt_dict_from_tokens(tokens, readset, ref_seq, ref_start, pos):
+def pad_table(padins):
+    """{(read_idx, qpos): (total, pad_mask)} of a PADINS_DTYPE array (capi.Engine.pad_insertions), or None."""
+    if padins is None or len(padins) == 0:
+        return None
+    return {(int(e["read_idx"]), int(e["qpos"])): (int(e["total"]), int(e["pad_mask"])) for e in padins}
+
+
+def inserted_text(readset, read_idx, qpos, n_bases, rev, pads=None):
+    """The inserted string as the reference's alt_dict keys hold it (upper case).  mpileup_compat = 1: samtools >= 1.11 prints the pads of
+    the run of I ops between the bases, '*' on the forward and '#' on the reverse strand (--reverse-del); `pads` = pad_table()."""
+    seq = readset.read_bases(read_idx, qpos, n_bases)
+    e = pads.get((read_idx, qpos)) if pads else None
+    if e is None:
+        return seq
+    total, mask = e
+    out, j = [], 0
+    for ch in range(total):
+        if (mask >> ch) & 1:
+            out.append("#" if rev else "*")
+        else:
+            out.append(seq[j])
+            j += 1
+    return "".join(out)
+
+
+def alt_dict_from_tokens(tokens, readset, ref_seq, ref_start, pos, pads=None):
     """tokens: TOKEN_DTYPE slice for one site (BAM order). ref_seq[0] is 1-based ref_start.
     Returns (OrderedDict alt, depth)."""
     ref_base = evc_base(ref_seq[pos - ref_start])
@@ -39,7 +64,7 @@ def alt_dict_from_tokens(tokens, readset, ref_seq, ref_start, pos):
             del_count += 1
         ind = int(tk["indel"])
         if ind > 0:
-            seq = readset.read_bases(int(tk["read_idx"]), int(tk["qpos"]), ind)
+            seq = inserted_text(readset, int(tk["read_idx"]), int(tk["qpos"]), ind, bool(tk["rev"]), pads)
             k = "I" + ref_base + seq
             alt[k] = alt.get(k, 0) + 1
             ins_count += 1
@@ -64,13 +89,15 @@ def alt_info_string(depth, alt):
     return "%d-%s" % (depth, " ".join("%s %d" % kv for kv in alt.items()))
 
 
-def format_lines(ctg, sites, tensors_raw, tokens, readset, ref_seq, ref_start):
-    """Reproduce the reference's create_tensor stdout lines (debug / parity only)."""
+def format_lines(ctg, sites, tensors_raw, tokens, readset, ref_seq, ref_start, padins=None):
+    """Reproduce the reference's create_tensor stdout lines (debug / parity only).  padins: capi.Engine.pad_insertions() when the scan ran
+    with mpileup_compat = 1 on reads whose CIGARs hold pads."""
     out = []
+    pads = pad_table(padins)
     for i, s in enumerate(sites):
         pos = int(s["pos"])
         tk = tokens[int(s["tok_off"]):int(s["tok_off"]) + int(s["n_tok"])]
-        alt, _ = alt_dict_from_tokens(tk, readset, ref_seq, ref_start, pos)
+        alt, _ = alt_dict_from_tokens(tk, readset, ref_seq, ref_start, pos, pads)
         ints = " ".join(str(v) for v in tensors_raw[i].reshape(-1).tolist())
         out.append("%s\t%d\t%s\t%s\t%s" % (ctg, pos, s["ref33"].decode(), ints, alt_info_string(int(s["depth"]), alt)))
     return out

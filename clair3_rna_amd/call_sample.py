@@ -35,7 +35,7 @@ from time import time
 
 import numpy as np
 
-from . import io, sort_vcf, vcf
+from . import io, mpileup_compat, sort_vcf, vcf
 from .reads import READ_DTYPE, ReadSet
 from .call_var_bam import existing, resolve_region
 
@@ -152,6 +152,10 @@ def build_parser():
     a("--readiportal_source_fn", type=str, default=None)
     a("--readiportal_database_filter_tag", type=str, default=None)
     a("--no_compress", action="store_true", help="leave <prefix>.vcf uncompressed (tests)")
+    a("--samtools", type=str, default="samtools", help="as in run_clair3_rna; never piped, only asked for its version (--mpileup_compat auto)")
+    a("--mpileup_compat", type=str, default=mpileup_compat.env_default(), choices=list(mpileup_compat.CHOICES),
+      help="which samtools mpileup text the tensor build restates: auto = ask `--samtools --version` (>= 1.11 -> 1, <= 1.10 -> 0, not "
+           "runnable -> 1); 0 = samtools <= 1.10; 1 = samtools >= 1.11.  Default: $C3R_MPILEUP_COMPAT, else auto")
     a("--gpu_id", type=int, default=None, help="default: $C3R_DEVICE, else LOCAL_RANK under torch.distributed.run, else 0")
     a("--gpu_precision", type=str, default=_env_precision(), choices=["f32", "f16x3", "f16+f8", "auto"],
       help="network arithmetic (c3r_set_precision): f16x3 = fp32-equivalent split-f16 (default); auto = the faster fp8-corrected path where a "
@@ -279,6 +283,9 @@ def Run(args, log=None):
     from . import capi
     log = log or (lambda m: print(m, file=sys.stderr))
     t_all = time()
+    # which samtools the column text follows: asked in a child process before anything touches the GPU (rank 0's line is the one printed)
+    compat = mpileup_compat.resolve(getattr(args, "mpileup_compat", "auto"), getattr(args, "samtools", "samtools"),
+                                    log if int(os.environ.get("RANK", "0")) == 0 else (lambda m: None))
     # one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m clair3_rna_amd.call_sample ...`): contigs are
     # dealt to the ranks largest-first, every rank leaves the merged records of its contigs under tmp/parts/, rank 0 puts the
     # file together.  No data-path collective: torch.distributed (gloo) is the barrier, nothing else.
@@ -440,7 +447,8 @@ def Run(args, log=None):
         eng.set_bed(1, io.read_bed(bed_fn, ctg)[0] if bed_fn else None)
         eng.set_params(channels=channels, min_mq=args.min_mq, min_coverage=args.min_coverage, snp_min_af=args.snp_min_af,
                        indel_min_af=args.indel_min_af, head_tail=int(args.enable_variant_calling_at_sequence_head_and_tail),
-                       splice_padding=int(args.enable_padding_in_splice_junction_regions), genotyping_mode=int(vcf_fn is not None))
+                       splice_padding=int(args.enable_padding_in_splice_junction_regions), genotyping_mode=int(vcf_fn is not None),
+                       mpileup_compat=compat)
         t = [time()]
         eng.load_reads(rs); t.append(time())
         eng.set_reference(1, ref, upper_view=not isinstance(ref, (bytes, str))); t.append(time())      # (the fetcher's array: upper-cased, used in place)

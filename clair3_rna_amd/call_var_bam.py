@@ -16,7 +16,7 @@ from time import time
 
 import numpy as np
 
-from . import altinfo, decode, io, vcf
+from . import altinfo, decode, io, mpileup_compat, vcf
 
 
 def _env_precision():
@@ -24,14 +24,20 @@ def _env_precision():
     return capi.env_precision()
 
 
+_TRUE_WORDS = frozenset(["yes", "true", "t", "y", "1", "ture"])      # "ture" / "flase": misspellings the reference's own parser takes
+_FALSE_WORDS = frozenset(["no", "false", "f", "n", "0", "flase"])     # (shared/utils.py:143-153); run scripts in the wild may rely on them
+
+
 def str2bool(v):
+    """argparse type of the reference's boolean flags (`--flag True`)."""
     if isinstance(v, bool):
         return v
-    if v.lower() in ('yes', 'ture', 'true', 't', 'y', '1'):
+    word = str(v).strip().lower()
+    if word in _TRUE_WORDS:
         return True
-    if v.lower() in ('no', 'flase', 'false', 'f', 'n', '0'):
+    if word in _FALSE_WORDS:
         return False
-    raise argparse.ArgumentTypeError('Boolean value expected.')
+    raise argparse.ArgumentTypeError("Boolean value expected, got %r" % (v,))
 
 
 def str_none(v):
@@ -98,7 +104,10 @@ def build_parser():
     a('--snp_min_af', type=float, default=0.08)
     a('--indel_min_af', type=float, default=0.08)     # call_var_bam.py's own default; run_clair3_rna passes 0.15
     a('--qual', type=int, default=None)
-    a('--samtools', type=str, default="samtools")     # accepted, unused: the CIGAR walk runs on the GPU
+    a('--samtools', type=str, default="samtools")     # never piped (the CIGAR walk runs on the GPU); asked for its version: --mpileup_compat auto
+    a('--mpileup_compat', type=str, default=mpileup_compat.env_default(), choices=list(mpileup_compat.CHOICES),
+      help="which samtools mpileup text the tensor build restates: auto = ask `--samtools --version` (>= 1.11 -> 1, <= 1.10 -> 0, not "
+           "runnable -> 1); 0 = samtools <= 1.10; 1 = samtools >= 1.11 (`+<ins>-<del>`, pads inside insertions).  Default: $C3R_MPILEUP_COMPAT, else auto")
     a('--pypy', type=str, default="pypy3")
     a('--python', type=str, default="python3")
     a('--enable_phasing_model', type=str2bool, default=False)
@@ -166,6 +175,9 @@ def Run(args, engine=None):
     if not ref_seq:
         sys.exit("[ERROR] Failed to load reference sequence from file (%s)." % args.ref_fn)
 
+    # ---- which samtools the column text follows: asked in a child process before anything touches the GPU
+    compat = mpileup_compat.resolve(getattr(args, "mpileup_compat", "auto"), args.samtools)
+
     # ---- GPU: tensor build + network
     eng = engine or capi.Engine(args.gpu_id)
     eng.params = capi.default_params()
@@ -176,7 +188,8 @@ def Run(args, engine=None):
         eng.set_sites(sites)
     eng.set_params(channels=channels, min_mq=args.minMQ, min_coverage=args.minCoverage, snp_min_af=args.snp_min_af,
                    indel_min_af=args.indel_min_af, head_tail=int(args.enable_variant_calling_at_sequence_head_and_tail),
-                   splice_padding=int(args.enable_padding_in_splice_junction_regions), genotyping_mode=int(sites is not None))
+                   splice_padding=int(args.enable_padding_in_splice_junction_regions), genotyping_mode=int(sites is not None),
+                   mpileup_compat=compat)
     rs = io.load_reads(args.bam_fn, ctg, extend_start - 1, extend_end)      # mpileup -r ctg:extend_start-extend_end
     eng.load_reads(rs)
     eng.set_reference(ref_start, ref_seq)
@@ -193,7 +206,7 @@ def Run(args, engine=None):
             sites_out, toks = eng.sites(), eng.tokens()
             raw = eng.tensors(rescaled=False)
             with open(args.tensor_dump_fn, "w") as f:
-                for line in altinfo.format_lines(ctg, sites_out, raw, toks, rs, ref_seq, ref_start):
+                for line in altinfo.format_lines(ctg, sites_out, raw, toks, rs, ref_seq, ref_start, padins=eng.pad_insertions()):
                     f.write(line + "\n")
     if args.call_fn:
         vcf.write_chunk_vcf(args.call_fn, vcf.header(args.ref_fn, cmd_fn, args.sampleName), rows)

@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("C3R_LIB") or os.path.join(HERE, "libc3r.so")        #
 SITE_DTYPE = np.dtype([("pos", "<i4"), ("depth", "<i4"), ("ref33", "S36"), ("n_tok", "<i4"), ("tok_off", "<u4")], align=True)
 TOKEN_DTYPE = np.dtype([("read_idx", "<u4"), ("indel", "<i4"), ("qpos", "<u4"), ("base", "u1"), ("rev", "u1"), ("del_after", "<u2")],
                        align=True)
-assert SITE_DTYPE.itemsize == 52 and TOKEN_DTYPE.itemsize == 16
+PADINS_DTYPE = np.dtype([("read_idx", "<u4"), ("qpos", "<u4"), ("n_bases", "<u4"), ("total", "<u4"), ("pad_mask", "<u8")], align=True)
+assert SITE_DTYPE.itemsize == 52 and TOKEN_DTYPE.itemsize == 16 and PADINS_DTYPE.itemsize == 24
 
 C3R_ERRORS = {-1: "EINVAL", -2: "ENODEVICE", -3: "EHIP", -4: "ENOMEM", -5: "EUNSUPPORTED", -6: "EOVERFLOW"}
 
@@ -34,7 +35,7 @@ class C3RError(RuntimeError):
 
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_trim", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_host_alloc", "c3r_host_free", "c3r_set_reference", "c3r_set_reference_view", "c3r_set_bed", "c3r_set_sites",
-           "c3r_pileup_scan", "c3r_pileup_scan_regions", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_columns",
+           "c3r_pileup_scan", "c3r_pileup_scan_regions", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_pad_insertions", "c3r_get_columns",
            "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_reserve", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_rows_begin", "c3r_rows_decode", "c3r_rows_get", "c3r_rows_free", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
@@ -83,6 +84,7 @@ def load_library():
     L.c3r_get_sites.argtypes = [vp, vp, i64]
     L.c3r_token_count.argtypes = [vp, C.POINTER(i64)]
     L.c3r_get_tokens.argtypes = [vp, vp, i64]
+    L.c3r_get_pad_insertions.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.c3r_get_columns.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), vp, vp, vp, i64]
     L.c3r_weight_count.argtypes = [i32]
     L.c3r_weight_count.restype = i64
@@ -281,6 +283,16 @@ class Engine(object):
         out = np.zeros(n.value, dtype=TOKEN_DTYPE)
         if n.value:
             self._chk(self.L.c3r_get_tokens(self.h, _ptr(out), len(out)))
+        return out
+
+    def pad_insertions(self):
+        """mpileup_compat = 1: the loaded reads' insertions that hold pads (PADINS_DTYPE; empty for aligner-made CIGARs) —
+        altinfo.format_lines needs them beside the tokens to print `+3T*T` alleles."""
+        n = C.c_int64(0)
+        self._chk(self.L.c3r_get_pad_insertions(self.h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=PADINS_DTYPE)
+        if n.value:
+            self._chk(self.L.c3r_get_pad_insertions(self.h, _ptr(out), n.value, C.byref(n)))
         return out
 
     def columns(self):

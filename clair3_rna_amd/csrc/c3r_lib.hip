@@ -44,6 +44,7 @@ struct c3r_rows;
 // snapshot after c3r_load_reads and shared by every later one of the same contig — genotyping mode decodes a contig chunk by chunk
 // (c3r_call_rows ~50 times for chr1) and used to copy 100+ MB each time
 struct HostReads { std::vector<DevRead> reads; std::vector<uint8_t> seq; };
+typedef std::vector<c3r_padins_t> PadInsTab;
 struct c3r_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -94,6 +95,10 @@ struct c3r_ctx {
     std::vector<uint8_t> h_seq;            // lazily: ensure_host_seq (decode reads inserted bases)
     bool host_seq_valid = false;
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
+    // mpileup_compat = 1: the insertions of the loaded reads that hold pads (c3r_padins_t), on the device for ev_equal and on the host for
+    // the decoder (row snapshots share the vector); empty for every CIGAR an aligner emits
+    DevBuf d_padins;
+    std::shared_ptr<PadInsTab> padins;
     DevBuf d_dbg;                          // C3R_SCAN_DBG: phase timers of k_scan_tiles
     DevBuf d_tile_cand;                    // [n_tiles] {first candidate, count} of the most recent scan (k_compact_write -> k_tile_tokens)
     DevBuf d_tile_cols, d_tile_rng, d_tile_list, d_tile_list2, d_rsegs, d_rseg_first;
@@ -375,6 +380,46 @@ namespace {
 // ---- the device tables of the loaded reads (reads_kernels.hpp): headers, prefix maxima, the pile table.  Everything depends on the
 // filters (records exist only for reads that pass them), so c3r_set_params with new --min-MQ / --excl-flags runs this again on the raw
 // records the device still holds.  Four kernels, one host wait (sizes and validation errors).
+// mpileup_compat = 1, reads with pads inside a run of I ops (k_prep counted them): the table of those runs, from the raw records the device
+// holds (the caller's arrays may be gone when c3r_set_params switches the printer).  Same run rule as walk_serial's first look: I and P ops
+// in a row, zero-length ops and hard clips skipped; the entry's key is the query offset of the run's first inserted base.
+int build_padins(c3r_ctx *ctx, int n) {
+    std::vector<c3r_read_t> rd((size_t)n);
+    std::vector<uint32_t> cg((size_t)std::max<int64_t>(ctx->n_cigar_ops, 1));
+    HIPCHK(ctx, hipMemcpyAsync(rd.data(), ctx->d_rawreads.p, (size_t)n * sizeof(c3r_read_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(cg.data(), ctx->d_rawcig.p, (size_t)ctx->n_cigar_ops * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto tab = std::make_shared<PadInsTab>();
+    for (int i = 0; i < n; ++i) {
+        const c3r_read_t &r = rd[(size_t)i];
+        if ((int64_t)r.cigar_off + r.n_cigar > ctx->n_cigar_ops) continue;
+        uint32_t y = 0;
+        c3r_padins_t e;
+        memset(&e, 0, sizeof e);
+        bool open = false;
+        auto close = [&]() { if (open && e.n_bases && e.pad_mask && e.total <= 64) tab->push_back(e); open = false; };
+        for (uint32_t k = 0; k < r.n_cigar; ++k) {
+            const uint32_t c = cg[(size_t)r.cigar_off + k], op = c & 15u, len = c >> 4;
+            if (len == 0 || op == C3R_CIG_H) continue;
+            if (op == C3R_CIG_I || op == C3R_CIG_P) {
+                if (!open) { memset(&e, 0, sizeof e); e.read_idx = (uint32_t)i; e.qpos = y; open = true; }
+                for (uint32_t j = 0; j < len && e.total <= 64; ++j, ++e.total) if (op == C3R_CIG_P && e.total < 64) e.pad_mask |= 1ull << e.total;
+                if (op == C3R_CIG_I) { e.n_bases += len; y += len; }
+            } else {
+                close();
+                if (op == C3R_CIG_M || op == C3R_CIG_EQ || op == C3R_CIG_X || op == C3R_CIG_S) y += len;
+            }
+        }
+        close();
+    }
+    ctx->padins = tab;
+    if (tab->empty()) return C3R_OK;
+    int rc = upload(ctx, ctx->d_padins, tab->data(), tab->size());
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return C3R_OK;
+}
+
 int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
     int rc;
     ctx->host_reads_valid = false; ctx->legacy_valid = false;
@@ -452,7 +497,7 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
                 case LD_OP_LONG: return fail(ctx, C3R_EINVAL, "cigar op too long in read %lld", i);
                 case LD_END_2G: return fail(ctx, C3R_EINVAL, "read %lld ends beyond 2^31", i);
                 case LD_SEG_OPS: return fail(ctx, C3R_EINVAL, "read %lld: more than 65535 CIGAR ops between two N ops", i);
-                case LD_PAD_INS: return fail(ctx, C3R_EINVAL, "read %lld: a pad (P) next to an insertion is not supported with mpileup_compat = 1", i);
+                case LD_PAD_INS: return fail(ctx, C3R_EINVAL, "read %lld: an insertion with pads (P ops) of more than 64 characters is not supported with mpileup_compat = 1", i);
                 default: return fail(ctx, C3R_EINVAL, "invalid read %lld", i);
             }
         }
@@ -461,6 +506,8 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
         want_end = (int64_t)hs.max_end + 64;                  // a read reaches beyond the table: the counts of its far bins were clamped
     }
     if (hs.n_rec < 0) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
+    ctx->padins.reset();
+    if (hs.n_padreads > 0 && (rc = build_padins(ctx, n))) return rc;          // (hand-made CIGARs only: off the measured path)
     const auto t_sync = std::chrono::steady_clock::now();
     // ---- second pass (nothing below waits for the device): every record into its bin
     if ((rc = ensure(ctx, ctx->d_recs, (size_t)hs.n_rec * sizeof(PileRec) + 64))) return rc;
@@ -611,7 +658,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_binoff, &ctx->d_rtab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
                       &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
-                      &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff};
+                      &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff, &ctx->d_padins};
     int n_dev = 0; size_t b_dev = 0, b_pin = 0;
     for (DevBuf *b : bufs) if (b->p) { (void)hipFree(b->p); ++n_dev; b_dev += b->cap; }
     const auto t1 = std::chrono::steady_clock::now();
@@ -676,6 +723,7 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     ctx->n_reads = 0; ctx->n_indel_ops = 0; ctx->n_seq_bytes = 0; ctx->n_cigar_ops = 0; ctx->max_cover = 0;
     ctx->host_reads_valid = false; ctx->host_seq_valid = false; ctx->last_scan_pruned = false; ctx->legacy_valid = false;
     ctx->host_cache.reset();              // (snapshots of the previous contig keep their copy alive)
+    ctx->padins.reset();
     const int n = (int)n_reads;
     int rc;
     // ---- the caller's records go up as they are (three copies; truly asynchronous when the caller's arrays are pinned, see
@@ -921,6 +969,7 @@ static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int d
     a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.min_cov = ctx->prm.min_coverage;
     a.snp_af = ctx->prm.snp_min_af; a.indel_af = ctx->prm.indel_min_af;
     a.head_tail = ctx->prm.head_tail; a.splice = ctx->prm.splice_padding;
+    if (ctx->padins && !ctx->padins->empty()) { a.padins = (const c3r_padins_t *)ctx->d_padins.p; a.n_padins = (int32_t)ctx->padins->size(); }
     { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
 }
 
@@ -1407,6 +1456,16 @@ int c3r_get_tokens(c3r_ctx *ctx, c3r_token_t *tokens, int64_t cap_tokens) {
     return C3R_OK;
 }
 
+int c3r_get_pad_insertions(c3r_ctx *ctx, c3r_padins_t *out, int64_t cap, int64_t *n) {
+    if (!ctx || !n) return C3R_EINVAL;
+    const int64_t have = ctx->padins ? (int64_t)ctx->padins->size() : 0;
+    *n = have;
+    if (!out) return C3R_OK;
+    if (cap < have) return fail(ctx, C3R_EOVERFLOW, "need room for %lld entries", (long long)have);
+    if (have) memcpy(out, ctx->padins->data(), (size_t)have * sizeof(c3r_padins_t));
+    return C3R_OK;
+}
+
 int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t *cols, int32_t *depth, uint8_t *flags, int64_t cap_pos) {
     if (!ctx) return C3R_EINVAL;
     if (region_start) *region_start = (int64_t)ctx->reg_beg0 + 1;
@@ -1641,6 +1700,7 @@ struct c3r_rows {
     int64_t n = 0, n_tok = 0;
     c3r_site_t *sites = nullptr; uint8_t *tokb = nullptr; float *probs = nullptr; uint32_t *rec_off = nullptr;
     std::shared_ptr<HostReads> hr;                        // the contig's read headers and packed bases (inserted bases of the alt alleles)
+    std::shared_ptr<PadInsTab> padins;                    // mpileup_compat = 1: its insertions with pads (null / empty otherwise)
     const DevRead *reads = nullptr; const uint8_t *seq = nullptr;
     TokRec *recs = nullptr; int64_t n_recs = 0;           // the tokens that carry an indel (k_pack_tokens), own allocation
     int ref_slot = -1; const char *ref = nullptr; size_t ref_len = 0; int64_t ref_start1 = 1;
@@ -1686,6 +1746,7 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
         ctx->host_cache->seq.resize((size_t)ctx->n_seq_bytes + 16);
     }
     r->hr = ctx->host_cache;
+    r->padins = ctx->padins;
     r->reads = r->hr->reads.data(); r->seq = r->hr->seq.data();
     auto bail = [&](int rc) { if (fresh_reads) ctx->host_cache.reset(); c3r_rows_free(r); return rc; };      // (a half-copied cache is no cache)
     const bool timing = getenv("C3R_TIMING") != nullptr;
@@ -1751,6 +1812,7 @@ int c3r_rows_decode(c3r_rows *r, const char *ctg, int qual, int show_ref, int64_
     const RefView refv{r->ref, r->ref_len};
     const int64_t ref_start1 = r->ref_start1;
     auto get_read = [&](uint32_t k) { return ReadView{seq, reads[k].seq_off, reads[k].l_seq}; };
+    const PadView pads{r->padins && !r->padins->empty() ? r->padins->data() : nullptr, r->padins ? r->padins->size() : 0};
     // host threads: C3R_THREADS, else up to 32 (one process per GPU shares the node's cores with its peers)
     unsigned nt = std::max(1u, std::min(32u, usable_cpus()));
     if (const char *e = getenv("C3R_THREADS")) nt = (unsigned)std::max(1, atoi(e));
@@ -1766,9 +1828,9 @@ int c3r_rows_decode(c3r_rows *r, const char *ctg, int qual, int show_ref, int64_
             const TokRec *rc_ = recs ? recs + rec_off[(size_t)i] : nullptr;      // this site's indel records, in token order
             alt_from_stream(sites[(size_t)i].n_tok, [tb, rc_](int k) mutable {
                 const uint8_t by = tb[k];
-                if (by & 0x80) { const TokRec &q = *rc_++; return TokView{by & 31, q.indel, q.read_idx, q.qpos, q.del_after}; }
-                return TokView{by & 31, 0, 0u, 0u};
-            }, get_read, refv, ref_start1, sites[(size_t)i].pos, alt, depth_tok);
+                if (by & 0x80) { const TokRec &q = *rc_++; return TokView{by & 31, q.indel, q.read_idx, q.qpos, q.del_after, (by & 0x20) != 0}; }
+                return TokView{by & 31, 0, 0u, 0u, 0u, (by & 0x20) != 0};
+            }, get_read, refv, ref_start1, sites[(size_t)i].pos, alt, depth_tok, pads);
             if (vcf_row(ctg, sites[(size_t)i].pos, sites[(size_t)i].ref33, sites[(size_t)i].depth, alt, probs + (size_t)i * C3R_NPROB, qual,
                         show_ref != 0, part[t]))
                 cnt[t]++;

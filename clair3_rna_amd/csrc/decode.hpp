@@ -74,10 +74,19 @@ struct RefView {
     std::string substr(size_t a, size_t len) const { return std::string(p + a, len); }
 };
 // what the dictionary needs of one token; `next(i)` is called for i = 0 .. n-1 in order (a packed token stream keeps a cursor)
-struct TokView { int base; int32_t indel; uint32_t read_idx, qpos, del_after; };
+struct TokView { int base; int32_t indel; uint32_t read_idx, qpos, del_after; bool rev; };
+// mpileup_compat = 1: the loaded reads' insertions that hold pads (c3r_padins_t, sorted by read and query offset; usually none)
+struct PadView {
+    const c3r_padins_t *p; size_t n;
+    const c3r_padins_t *find(uint32_t r, uint32_t q) const {
+        size_t lo = 0, hi = n;
+        while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (p[mid].read_idx < r || (p[mid].read_idx == r && p[mid].qpos < q)) lo = mid + 1; else hi = mid; }
+        return (lo < n && p[lo].read_idx == r && p[lo].qpos == q) ? &p[lo] : nullptr;
+    }
+};
 template <typename NextTok, typename GetRead>
 inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
-                            AltDict &alt, int &depth_out) {
+                            AltDict &alt, int &depth_out, const PadView pads = PadView{nullptr, 0}) {
     alt.clear();
     const int64_t ri = pos1 - ref_start1;
     char rb = (ri >= 0 && ri < (int64_t)ref.size()) ? ref[(size_t)ri] : 'N';
@@ -94,8 +103,12 @@ inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView
         if (t.indel > 0) {
             const ReadView rv = get_read(t.read_idx);
             std::string k = "I"; k += rb;
-            for (int32_t j = 0; j < t.indel; ++j) {
-                const uint32_t q = t.qpos + (uint32_t)j;
+            // samtools >= 1.11 prints the pads of the run between the bases: '*', on the reverse strand '#' (--reverse-del); the key keeps them
+            const c3r_padins_t *pe = pads.n ? pads.find(t.read_idx, t.qpos) : nullptr;
+            const uint32_t total = pe ? pe->total : (uint32_t)t.indel;
+            for (uint32_t ch = 0, j = 0; ch < total; ++ch) {
+                if (pe && ((pe->pad_mask >> ch) & 1ull)) { k += t.rev ? '#' : '*'; continue; }
+                const uint32_t q = t.qpos + j++;
                 char c = 'N';
                 if (q < rv.l_seq) { const uint8_t by = rv.seq[rv.seq_off + (q >> 1)]; c = NT16_STR[(q & 1) ? (by & 15) : (by >> 4)]; }
                 k += c;
@@ -121,7 +134,7 @@ inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView
 template <typename GetRead>
 inline void alt_from_tokens(const c3r_token_t *tk, int n, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
                             AltDict &alt, int &depth_out) {
-    alt_from_stream(n, [tk](int i) { return TokView{tk[i].base, tk[i].indel, tk[i].read_idx, tk[i].qpos, tk[i].del_after}; }, get_read, ref, ref_start1, pos1, alt, depth_out);
+    alt_from_stream(n, [tk](int i) { return TokView{tk[i].base, tk[i].indel, tk[i].read_idx, tk[i].qpos, tk[i].del_after, tk[i].rev != 0}; }, get_read, ref, ref_start1, pos1, alt, depth_out);
 }
 
 // ---------------------------------------------------------------------------------------------- call_site

@@ -87,6 +87,8 @@ struct PileRec {
 static_assert(sizeof(PileRec) == 32, "PileRec must be 32 bytes");
 constexpr uint32_t PR_DEL_AFTER_INS = 1u << 19;    // w, first piece of a D that follows an insertion at once (mpileup_compat = 1): samtools >= 1.11 shows
                                                     // the deletion on the insertion's column as well
+constexpr uint32_t PR_INS_PADS = 1u << 20;         // w, I record of a read that has a run of I ops with pads in it (mpileup_compat = 1): the printed insertion may
+                                                    // hold '*' / '#' characters — look (read_idx, q) up in the c3r_padins_t table
 constexpr int OP_CHOP = 30;    // 30 bases + an odd start nibble fit the 32 nibbles of a 16-byte load
 
 // The bins of the pile table: 32 reference positions each, covering [base << 5, (base + nb) << 5).  Two tables of prefix sums (k_bin_scan):
@@ -115,7 +117,7 @@ struct EvRec {          // one indel event, bucketed by position inside a tile
     uint32_t read_idx;
     uint32_t qpos;      // query offset of the first inserted base
     uint16_t pl;        // position inside the tile
-    uint8_t kind;       // bit0 = reverse strand, bit1 = insertion
+    uint8_t kind;       // bit0 = reverse strand, bit1 = insertion, bit2 = the insertion holds pads (its c3r_padins_t entry exists)
     uint8_t ch;         // channel receiving the max-multiplicity (I1 / i1 / D1 / d1)
 };
 static_assert(sizeof(EvRec) == 24, "EvRec must be 24 bytes");
@@ -178,7 +180,19 @@ struct ScanArgs {
     int32_t drop_words;
     int32_t splice;               // --enable_padding_in_splice_junction_regions: also produce skipmax[], materialise every tile
     int32_t *skipmax;             // [n_pos] max(#read starts, #read ends, #fwd ref-skips, #rev ref-skips) of the row
+    const c3r_padins_t *padins;   // mpileup_compat = 1: insertions with pads, sorted by (read_idx, qpos); null / 0 for every CIGAR an aligner emits
+    int32_t n_padins;
 };
+// the table entry of the insertion of read r at query offset q, or null
+__device__ __forceinline__ const c3r_padins_t *padins_find(const c3r_padins_t *tab, int n, uint32_t r, uint32_t q) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const c3r_padins_t &e = tab[mid];
+        if (e.read_idx < r || (e.read_idx == r && e.qpos < q)) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && tab[lo].read_idx == r && tab[lo].qpos == q) ? &tab[lo] : nullptr;
+}
 // Diagnostics of the tile kernels — per-phase clocks (C3R_SCAN_DBG) and timing / traffic ablations (C3R_SCAN_ABL) — are compiled in only
 // with -DC3R_SCAN_DIAG=1 (tools/build_variant.sh diag -DC3R_SCAN_DIAG=1): in the product build they fold away, which frees the scalar
 // registers their pointer and flags held in a kernel that parks scalars in vector lanes as it is.
@@ -388,10 +402,12 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
         for (int j = 0; j < 16; ++j) if (j < nk) e.key |= (uint64_t)(j < avail ? nibble_at(w0, w1, odd + j) : 15) << (4 * j);
         fc = (int)(e.key & 15u);
     }
-    // 'I' iff the first inserted char is one of "ACGTN*" (upper case => forward strand), src/create_tensor_pileup.py:227-232
-    const bool up = !rev && (acgt_index(fc) >= 0 || fc == 15);
+    // 'I' iff the first inserted char is one of "ACGTN*" (upper case => forward strand), src/create_tensor_pileup.py:227-232; a leading pad
+    // prints as '*' on the forward strand (in the list) and as '#' on the reverse strand (not in it)
+    const c3r_padins_t *pe = (is_ins && (w & PR_INS_PADS)) ? padins_find(a.padins, a.n_padins, (uint32_t)r, (uint32_t)rb.x) : nullptr;
+    const bool up = !rev && (acgt_index(fc) >= 0 || fc == 15 || (pe && (pe->pad_mask & 1ull)));
     e.len = (uint32_t)ilen; e.read_idx = (uint32_t)r; e.qpos = (uint32_t)rb.x;
-    e.pl = (uint16_t)pl; e.kind = (uint8_t)((rev ? 1 : 0) | (is_ins ? 2 : 0));
+    e.pl = (uint16_t)pl; e.kind = (uint8_t)((rev ? 1 : 0) | (is_ins ? 2 : 0) | (pe ? 4 : 0));
     e.ch = (uint8_t)(is_ins ? (up ? C3R_I1 : C3R_i1) : (rev ? C3R_d1 : C3R_D1));
     if (MODE == ACCUM) {
         // an indel on a ref-skip column takes the haplotype of the previous token-list ENTRY (:183,189)
@@ -466,8 +482,13 @@ __device__ __forceinline__ void walk_records(const ScanArgs &a, const TileLds &s
 // kind and length, same bases, and the same letter case = strand — except that '=' (BAM base code 0) has no case, so an
 // insertion made of '=' only reads the same on both strands (and lands on channel i for both: '=' is not upper-case, :221-230).
 __device__ __forceinline__ bool ev_equal(const ScanArgs &a, const EvRec &x, const EvRec &y) {
-    if (((x.kind ^ y.kind) & 2) || x.len != y.len || x.key != y.key) return false;
+    if (((x.kind ^ y.kind) & 6) || x.len != y.len || x.key != y.key) return false;
     bool caseless = (x.kind & 2) && x.key == 0;
+    if (x.kind & 4) {                  // pads inside both insertions: the same number of them at the same places; '*' and '#' tell the strands apart
+        const c3r_padins_t *px = padins_find(a.padins, a.n_padins, x.read_idx, x.qpos), *py = padins_find(a.padins, a.n_padins, y.read_idx, y.qpos);
+        if (!px || !py || px->total != py->total || px->pad_mask != py->pad_mask) return false;
+        caseless = false;
+    }
     if ((x.kind & 2) && x.len > 16) {
         const DevRead rx = a.reads[x.read_idx], ry = a.reads[y.read_idx];
         for (uint32_t j = 16; j < x.len; ++j) {
@@ -1959,7 +1980,7 @@ __global__ __launch_bounds__(256) void k_export_tokens(const c3r_site_t *sites, 
 
 // ---- tokens for the row decoder, packed.  A token is 16 bytes (c3r_token_t) but the decoder reads the read index, the indel length
 // and the query offset only of the few tokens that carry an indel; of all others it needs the base code.  One wavefront per site
-// turns its tokens into one byte each (base code | 0x80 when an indel record follows) and appends the indel records (12 bytes,
+// turns its tokens into one byte each (base code | 0x20 on the reverse strand | 0x80 when an indel record follows) and appends the indel records (12 bytes,
 // token order kept by a ballot prefix) to a contiguous range it draws from one counter: a 250-Mb contig copies out ~60 MB instead
 // of 760 MB.
 struct TokRec { uint32_t read_idx; int32_t indel; uint32_t qpos; uint32_t del_after; };
@@ -1990,7 +2011,7 @@ __global__ __launch_bounds__(256) void k_pack_tokens(const c3r_site_t *__restric
         if (valid) t = tok[off + i];
         const bool f = valid && t.indel != 0;
         const unsigned long long m = __ballot(f);
-        if (valid) bytes[off + i] = (uint8_t)((t.base & 31) | (f ? 0x80 : 0));
+        if (valid) bytes[off + i] = (uint8_t)((t.base & 31) | (t.rev ? 0x20 : 0) | (f ? 0x80 : 0));
         if (f) recs[base + run + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = TokRec{t.read_idx, t.indel, t.qpos, t.del_after};
         run += (uint32_t)__popcll(m);
     }

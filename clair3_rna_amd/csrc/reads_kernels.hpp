@@ -31,7 +31,8 @@ struct LoadStats {
     int32_t max_cover;        // upper bound of the number of reads over one position (reads overlapping one 32-bp bin)
     int32_t n_rec;            // records of the pile table
     int32_t n_indel;          // I + D ops of the passing reads (bounds the indel-event scratch of a scan)
-    int32_t pad[2];
+    int32_t n_padreads;       // mpileup_compat = 1: reads with a pad inside a run of I ops (the host then builds the c3r_padins_t table)
+    int32_t pad;
 };
 static_assert(sizeof(LoadStats) == 32, "LoadStats layout");
 enum { LD_OK = 0, LD_UNSORTED = 1, LD_CIGAR_RANGE, LD_SEQ_RANGE, LD_BAD_OP, LD_OP_LONG, LD_END_2G, LD_SEG_OPS, LD_RECORDS, LD_PAD_INS };
@@ -41,8 +42,10 @@ __device__ __forceinline__ void load_fail(LoadStats *st, int read, int code) {
 }
 
 // CIGAR normalisation as a stream: drop H, zero-length ops and pads (a pad is kept — as a 1-long op that consumes nothing —
-// exactly when the next real op is a D: htslib marks a deletion only when the D IMMEDIATELY follows the op that ends on the
-// column, while insertions are found through pads), fold = / X into M, merge equal neighbours.  emit(op, len) receives every
+// exactly when the next real op is a D and the op before it is not an I: htslib marks a deletion only when the D IMMEDIATELY
+// follows the op that ends on the column, while insertions are found through pads; behind an insertion the column's indel IS the
+// insertion either way, and samtools >= 1.11 reaches the D through the pads of the run, bam_plp_insertion), fold = / X into M, merge
+// equal neighbours.  emit(op, len) receives every
 // finalised op in order.  Returns LD_OK or the error code.  Serial: one lane walks one read.  The parallel walk of k_prep handles
 // the reads whose CIGAR needs none of this (every op kept as it is); the others come here.
 template <class Emit>
@@ -69,6 +72,7 @@ __device__ __forceinline__ int walk_norm(const uint32_t *cig, uint32_t n, Emit &
             uint32_t k2 = k + 1;
             while (k2 < n && ((cig[k2] >> 4) == 0 || (cig[k2] & 15u) == C3R_CIG_P || (cig[k2] & 15u) == C3R_CIG_H)) ++k2;
             if (k2 >= n || (cig[k2] & 15u) != C3R_CIG_D) continue;
+            if (have && cop == C3R_CIG_I) continue;
             len = 1;
         }
         if (op > C3R_CIG_X) return LD_BAD_OP;
@@ -136,6 +140,7 @@ struct ReadInfo {
     uint32_t n_cig, l_seq, read_idx, wbits;   // wbits: strand and haplotype bits of PileRec::w
     uint64_t seq_off;
     int32_t compat;                           // c3r_params_t::mpileup_compat
+    uint32_t padbit;                          // PR_INS_PADS when a run of I ops of this read holds pads (mpileup_compat = 1), else 0
 };
 // an op's neighbours in the normalised CIGAR (15 = none)
 struct OpCtx { uint32_t prev, prev2, nop, nlen, n2op, n2len; };
@@ -173,7 +178,7 @@ __device__ __forceinline__ void op_records(const ReadInfo &R, uint32_t op, uint3
     } else if (op == C3R_CIG_I) {
         if (prev == C3R_CIG_M || prev == C3R_CIG_D || prev == C3R_CIG_N) {
             const uint32_t avail = y >= R.l_seq ? 0u : min(31u, R.l_seq - y);
-            emit((int32_t)x, (uint32_t)C3R_CIG_I | (prev << 2) | R.wbits | (avail << 14), 2ull * R.seq_off + y, y,
+            emit((int32_t)x, (uint32_t)C3R_CIG_I | (prev << 2) | R.wbits | (avail << 14) | R.padbit, 2ull * R.seq_off + y, y,
                  (R.compat && nop == C3R_CIG_D) ? -(int32_t)nlen : 0, len);
         }
     }
@@ -245,18 +250,25 @@ __device__ __forceinline__ void walk_plain(const ReadInfo &R, int gl, Emit &&emi
 // The serial walk (one lane): walk_norm's stream, two ops of look-ahead (the indel attached to an op's last column, and with
 // mpileup_compat the deletion right behind that insertion).  Returns the error code of the normalised form (unknown op, a merged op of
 // 2^28 or more, more than 65535 ops between two N ops).
-// mpileup_compat = 1: samtools >= 1.11 prints the pads INSIDE an insertion as '*' (`+3T*T`); that text is not produced here, and a read
-// whose CIGAR has a pad next to an insertion is refused (LD_PAD_INS) rather than shown the <= 1.10 way (long-read RNA aligners emit no pads).
+// mpileup_compat = 1: samtools >= 1.11 prints the pads INSIDE a run of I ops as '*' (`+3T*T`, bam_plp_insertion).  The walk itself
+// does not change (pads consume nothing; the record of the merged I op carries the bases); a read that has such a run is flagged
+// (*pads = true: its I records carry PR_INS_PADS) and the host builds the table of those runs (c3r_padins_t) that ev_equal and the
+// decoder look up.  A run of more than 64 characters is refused (LD_PAD_INS): the table describes the pads by a 64-bit mask.
 template <class Emit>
-__device__ __forceinline__ int walk_serial(const ReadInfo &R, Emit &&emit) {
+__device__ __forceinline__ int walk_serial(const ReadInfo &R, Emit &&emit, bool *pads = nullptr) {
     if (R.compat) {
-        bool has_i = false, has_p = false;
-        for (uint32_t k = 0; k < R.n_cig; ++k) {
-            const uint32_t c = R.cig[k], op = c & 15u;
-            if ((c >> 4) == 0 || op == C3R_CIG_H) continue;
-            if (op == C3R_CIG_I) has_i = true; else if (op == C3R_CIG_P) has_p = true; else { has_i = false; has_p = false; }
-            if (has_i && has_p) return LD_PAD_INS;
+        uint32_t run_i = 0, run_p = 0;
+        bool any = false;
+        for (uint32_t k = 0; k <= R.n_cig; ++k) {
+            const uint32_t c = k < R.n_cig ? R.cig[k] : (1u << 4) /* 1M: closes the last run */, op = c & 15u, len = c >> 4;
+            if (len == 0 || op == C3R_CIG_H) continue;
+            if (op == C3R_CIG_I) run_i += min(len, 1u << 20); else if (op == C3R_CIG_P) run_p += min(len, 1u << 20);
+            else {
+                if (run_i && run_p) { if (run_i + run_p > 64u) return LD_PAD_INS; any = true; }
+                run_i = 0; run_p = 0;
+            }
         }
+        if (pads) *pads = any;
     }
     SegWalk w;
     w.begin(R.pos);
@@ -297,7 +309,7 @@ struct PrepArgs {
     uint32_t *sc, *ec;        // [nbc] per coarse bin: reads that start in it / reads that end in the 256 positions up to its first
     const uint32_t *rec_off;  // [nb + 1] k_bin_scan's prefix sums (k_prep<true>)
     DevRead *out;             // [n_reads] headers, written by k_prep<false>
-    uint8_t *serial;          // [n_reads] 1 = the read takes the serial walk
+    uint8_t *serial;          // [n_reads] 1 = the read takes the serial walk (3: and holds a run of I ops with pads, mpileup_compat = 1)
     int32_t *nind;            // [n_reads] I + D ops of the read, 0 when the filters drop it (summed by k_prefmax_bins: 54 k atomics on one
                               // word would take 0.6 ms)
     PileRec *recs;
@@ -345,7 +357,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
     for (int h = tid; h < HB; h += PREP_THREADS) { T.key[h] = 0; T.val[h] = 0; }
     __syncthreads();
     ReadInfo R;
-    R.cig = a.cigars; R.pos = 0; R.n_cig = 0; R.l_seq = 0; R.read_idx = (uint32_t)i; R.seq_off = 0; R.wbits = 0; R.compat = a.compat;
+    R.cig = a.cigars; R.pos = 0; R.n_cig = 0; R.l_seq = 0; R.read_idx = (uint32_t)i; R.seq_off = 0; R.wbits = 0; R.compat = a.compat; R.padbit = 0;
     // every record of a passing read, counted in the workgroup's table (a bin that finds no place there: `spill`)
     auto tally = [&](int32_t rstart, uint32_t, unsigned long long, uint32_t, int32_t, uint32_t) {
         const int b = bin_of(a.geo, rstart);
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
         int err = LD_OK;
         long long ref_len = 0;
         int n_indel = 0;
-        bool plain = true, pass = false;
+        bool plain = true, pass = false, pads = false;
         if (valid) {
             r = a.reads[i];
             if (i > 0 && r.pos < a.reads[i - 1].pos) err = LD_UNSORTED;
@@ -372,8 +384,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
             if (!err) {
                 if (plain) { if (pass) walk_plain(R, gl, tally); }
                 else if (gl == 0) {                                        // (also for a read the filters drop: its CIGAR is validated all the same)
-                    if (pass) err = walk_serial(R, tally);
-                    else err = walk_serial(R, [](int32_t, uint32_t, unsigned long long, uint32_t, int32_t, uint32_t) {});
+                    if (pass) err = walk_serial(R, tally, &pads);
+                    else err = walk_serial(R, [](int32_t, uint32_t, unsigned long long, uint32_t, int32_t, uint32_t) {}, &pads);
                 }
                 if (!err && (long long)r.pos + ref_len > INT32_MAX) err = LD_END_2G;
             }
@@ -383,7 +395,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
                 d.pos = r.pos; d.end = (int32_t)(r.pos + ref_len); d.cig_off = r.cigar_off; d.n_cig = r.n_cigar; d.seq_off = r.seq_off;
                 d.flag = r.flag; d.mapq = r.mapq; d.hp = r.hp; d.l_seq = r.l_seq;
                 a.out[i] = d;
-                a.serial[i] = plain ? 0 : 1;
+                a.serial[i] = plain ? 0 : (pads && !err) ? 3 : 1;                       // (3: serial walk, and its I records carry PR_INS_PADS)
+                if (pads && !err) __hip_atomic_fetch_add(&a.st->n_padreads, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(&a.sc[bin_of(a.geo, d.pos) >> CBIN_SHIFT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // counted as "ended at or before the start of coarse bin c" for every c > (ceil(end / 32) - base - 1) >> 3: k_bin_scan's exclusive
                 // sum over ec[j], j < c (later than true is safe: the sums bound the coverage from above)
@@ -402,6 +415,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
             const DevRead d = a.out[i];
             pass = !(flag_fails(d.flag, a.excl_flags) || d.mapq < a.min_mq);
             serial = a.serial[i] != 0;
+            R.padbit = a.serial[i] == 3 ? PR_INS_PADS : 0u;
             R.cig = a.cigars + d.cig_off; R.pos = d.pos; R.n_cig = d.n_cig; R.l_seq = d.l_seq; R.seq_off = d.seq_off;
             R.wbits = ((d.flag & 16u) ? 64u : 0u) | ((d.hp == 1 ? 1u : d.hp == 2 ? 2u : 0u) << 7);
         }

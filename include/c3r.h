@@ -123,6 +123,10 @@ int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_si
 int c3r_get_sites(c3r_ctx *ctx, c3r_site_t *sites, int64_t cap_sites);
 int c3r_token_count(c3r_ctx *ctx, int64_t *n_tokens);
 int c3r_get_tokens(c3r_ctx *ctx, c3r_token_t *tokens, int64_t cap_tokens);
+/* mpileup_compat = 1: the insertions of the loaded reads that hold pads (c3r_padins_t, sorted by read and query offset) — what a caller that
+ * rebuilds alt_info from c3r_get_tokens needs beside the read bases (`+3T*T`, samtools >= 1.11).  out may be NULL to ask for the count; empty
+ * for every CIGAR an aligner emits.  Valid after c3r_load_reads / c3r_set_params. */
+int c3r_get_pad_insertions(c3r_ctx *ctx, c3r_padins_t *out, int64_t cap, int64_t *n);
 /* Debug / parity: per-position columns of the last scan.  cols: int32 [n_pos][C]; depth: int32
  * [n_pos]; flags: uint8 [n_pos] (bit0 = row exists, bit1 = candidate gate passed, bit2 = emitted).
  * Position i is 1-based ctg position region_start + i where region_start is returned. */

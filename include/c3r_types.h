@@ -66,7 +66,8 @@ typedef struct c3r_params {
     int32_t  mpileup_compat;  /* which samtools the column text is restated from (run_clair3_rna:159,166 only sets a floor of 1.10):
                                  0 = samtools <= 1.10 (default): an I immediately followed by a D shows the insertion only (`C+2TT`);
                                  1 = samtools >= 1.11 (bam_plp_insertion): it shows both (`C+2TT-1N`), which the reference's parser
-                                     (src/create_tensor_pileup.py:151-163) reads as an insertion token AND a deletion token         */
+                                     (src/create_tensor_pileup.py:151-163) reads as an insertion token AND a deletion token; pads (P ops) inside the
+                                     run of I ops are printed as '*' ('#' on the reverse strand: --reverse-del), `+3T*T` (c3r_padins_t)       */
 } c3r_params_t;
 
 /* One emitted candidate site (the non-tensor fields of a create_tensor output line,
@@ -90,6 +91,19 @@ typedef struct c3r_token {
     uint16_t del_after;   /* mpileup_compat = 1, indel > 0: length of the deletion that follows the insertion at once (0: none;
                              saturates at 65535) — a second indel token of the read on this column, after the insertion */
 } c3r_token_t;
+
+/* mpileup_compat = 1 only: an insertion whose run of I ops holds pads (CIGAR `2M1I1P1I2M`).  samtools >= 1.11 (bam_plp_insertion)
+ * prints the run as ONE insertion of `total` characters with the pads as '*' — '#' on the reverse strand, because the reference passes
+ * --reverse-del (src/create_tensor_pileup.py:436-451) — and the reference's parser keeps that text as the allele (:151-163, :221-232).  A token
+ * carries the inserted BASES only (indel = n_bases, qpos); whoever rebuilds the allele text looks the pair (read_idx, qpos) up here.  Sorted
+ * by (read_idx, qpos).  No aligner for long RNA reads emits pads: the table is empty except for hand-made CIGARs. */
+typedef struct c3r_padins {
+    uint32_t read_idx;    /* index into the loaded read array                                        */
+    uint32_t qpos;        /* query offset of the first inserted base                                 */
+    uint32_t n_bases;     /* inserted bases = sum of the run's I ops                                 */
+    uint32_t total;       /* printed length = bases + pads, at most 64                               */
+    uint64_t pad_mask;    /* bit j: character j of the printed insertion is a pad                    */
+} c3r_padins_t;
 
 #ifdef __cplusplus
 }

@@ -167,7 +167,8 @@ char *orc_mpileup_d(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t 
 /* compat: which samtools printer is restated (the reference only sets a floor of 1.10, run_clair3_rna:159,166):
  *   0  samtools <= 1.10 pileup_seq: `+<n><n query bases>` for an insertion (pads skipped), nothing for a deletion behind it;
  *   1  samtools >= 1.11 (htslib bam_plp_insertion): the run of I and P ops behind the column's op is printed as ONE insertion with the
- *      pads as '*' (`+3T*T`), and when a D ends that run its length follows (`+2TT-1N`).  (Adjacent D ops count as one deletion, as
+ *      pads as '*' — '#' for a reverse-strand read under --reverse-del, which the reference always passes (src/create_tensor_pileup.py:448) —
+ *      (`+3T*T`), and when a D ends that run its length follows (`+2TT-1N`).  (Adjacent D ops count as one deletion, as
  *      everywhere in this restatement.) */
 char *orc_mpileup_c(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t *cigar_in, const uint8_t *seq,
                     const char *ctg, int64_t beg1, int64_t end1, int min_mq, int excl_flags,
@@ -309,7 +310,7 @@ char *orc_mpileup_c(const c3r_read_t *reads_in, int64_t n_reads, const uint32_t 
                 int64_t q = p.qpos + 1 - p.is_del;
                 for (kk = p.ins_k; kk < n_ops; ++kk) {
                     int o = cig_op(cg[kk]), ln = cig_len(cg[kk]);
-                    if (o == C3R_CIG_P) { for (int j = 0; j < ln; ++j) sb_putc(&bases, '*'); }
+                    if (o == C3R_CIG_P) { for (int j = 0; j < ln; ++j) sb_putc(&bases, rev ? '#' : '*'); }      /* (pileup_seq: `pad = rev_del ? '#' : '*'` on the reverse strand; the reference passes --reverse-del) */
                     else if (o == C3R_CIG_I) {
                         for (int j = 0; j < ln; ++j, ++q) {
                             int c = (q < (int64_t)r->l_seq) ? NT16[seq_code(seq, r->seq_off, (uint32_t)q)] : 'N';

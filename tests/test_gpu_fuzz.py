@@ -137,16 +137,16 @@ def test_random_cigars_match_the_oracle(eng, kw):
 @pytest.mark.parametrize("kw", [dict(), dict(channels=30), dict(head_tail=1), dict(splice_padding=1)])
 def test_random_cigars_with_the_samtools_1_11_printer(eng, kw):
     """c3r_params_t.mpileup_compat = 1: an I immediately followed by a D shows both on the insertion's column (`C+2TT-1N`: one more D / d,
-    D1 / d1 count, a deletion token behind the insertion token).  The generator deals I next to D often (leading, after N, after D);
-    pads are left out: samtools >= 1.11 prints them inside insertions as '*', which the library refuses (second test below)."""
+    D1 / d1 count, a deletion token behind the insertion token).  The generator deals I next to D often (leading, after N, after D)
+    and pads next to insertions: samtools >= 1.11 prints those inside the insertion as '*' / '#' (`+3T*T`; c3r_padins_t)."""
     from clair3_rna_amd import capi
     from clair3_rna_amd.reads import ReadSet
     channels = kw.get("channels", 18)
     okw = {k: bool(v) for k, v in kw.items() if k != "channels"}
-    n_lines, n_both = 0, 0
-    eng.load_reads(ReadSet.from_records([]))      # (switching the printer rebuilds the tables of the loaded reads: an earlier test's may hold pads)
+    n_lines, n_both, n_padded = 0, 0, 0
+    eng.load_reads(ReadSet.from_records([]))
     for seed in _seeds(60):
-        ref, recs = _case(70000 + 100 * len(kw) + seed, phased=(channels == 30), pads=False)
+        ref, recs = _case(70000 + 100 * len(kw) + seed, phased=(channels == 30), pads=True)
         rs = ReadSet.from_records(recs)
         eng.params = capi.default_params()
         eng.set_bed(0, None); eng.set_bed(1, None)
@@ -155,13 +155,14 @@ def test_random_cigars_with_the_samtools_1_11_printer(eng, kw):
         exp = H.oracle_chunk(rs, ref, 1, 1, len(ref), channels=channels, min_coverage=2, mpileup_compat=1, **okw)
         assert got["lines"] == exp["lines"], (seed, recs, H.first_diff(got["lines"], exp["lines"]))
         n_lines += len(exp["lines"])
-        n_both += sum(1 for r in exp["rows"] if re.search(r"[+][0-9]+[ACGTNacgtn=RYry]+-[0-9]+[Nn]", r.split("\t")[4]))
+        n_both += sum(1 for r in exp["rows"] if re.search(r"[+][0-9]+[ACGTNacgtn=RYry*#]+-[0-9]+[Nn]", r.split("\t")[4]))
+        n_padded += sum(1 for l in exp["lines"] if re.search(r" I[ACGT][A-Z=]*[*#]", l.split("\t")[4]))
         if seed % 20 == 0:                      # the same reads with the <= 1.10 text: the records are rebuilt when the parameter changes
             eng.set_params(min_coverage=2, mpileup_compat=0, **kw)
             n0 = eng.scan(1, len(ref))
             old = H.oracle_chunk(rs, ref, 1, 1, len(ref), channels=channels, min_coverage=2, **okw)
             assert n0 == len(old["lines"])
-    assert n_lines > 150 and n_both > 40, (n_lines, n_both)
+    assert n_lines > 150 and n_both > 40 and n_padded > 3, (n_lines, n_both, n_padded)
     eng.params = capi.default_params()
     eng.set_params()
 
@@ -185,16 +186,51 @@ def test_samtools_1_11_printer_known_answers_and_pads(eng):
         tk = got["tokens"][got["tokens"]["indel"] > 0]
         assert (tk["del_after"] == (1 if compat else 0)).all() and len(tk) >= 4
     assert out == {0: "8-ITTT 4 RT 4", 1: "8-ITTT 4 DA 4"}, out      # position 16 gains the deletion
-    # samtools >= 1.11 shows pads inside an insertion as '*': not restated on the device; refused, not silently shown the old way
-    bad = ReadSet.from_records([dict(pos=10, cigar="6M", seq="GTACGT"), dict(pos=12, cigar="4M1I1P1I4M", seq="ACGTTTACGT")])
-    eng.set_params(min_coverage=2, mpileup_compat=1)
-    with pytest.raises(capi.C3RError, match=r"read 1: a pad \(P\) next to an insertion is not supported with mpileup_compat = 1"):
+    # samtools >= 1.11 shows the pads of a run of I ops inside the insertion: '*' for a forward read, '#' for a reverse one (--reverse-del).
+    # Four forward reads `4M1I1P1I4M` and three reverse ones make two alleles of the same bases; a leading pad decides the channel
+    # (key[1] in "ACGTN*": I for the forward reads, i for the reverse ones) and `I P D` shows the deletion behind the padded insertion
+    padded = ([dict(pos=10, cigar="6M", seq="GTACGT")] + [dict(pos=12, cigar="4M1I1P1I4M", seq="ACGTTTACGT") for _ in range(4)] +
+              [dict(pos=12, cigar="4M1I1P1I4M", seq="ACGTTTACGT", flag=16) for _ in range(3)] + [dict(pos=12, cigar="4M1P2I4M", seq="ACGTTTACGT") for _ in range(2)] +
+              [dict(pos=12, cigar="4M1P2I4M", seq="ACGTTTACGT", flag=16)] + [dict(pos=12, cigar="4M2I1P1D3M", seq="ACGTTTCGT") for _ in range(2)])
+    rs = ReadSet.from_records(padded)
+    eng.params = capi.default_params()
+    eng.set_params(min_coverage=2, mpileup_compat=1, head_tail=1)
+    got = H.engine_chunk(eng, rs, ref, 1, 1, len(ref))
+    exp = H.oracle_chunk(rs, ref, 1, 1, len(ref), min_coverage=2, mpileup_compat=1, head_tail=True)
+    assert got["lines"] == exp["lines"] and len(got["lines"]) > 0, H.first_diff(got["lines"], exp["lines"])
+    pi = eng.pad_insertions()
+    assert len(pi) == 12 and set(pi["total"].tolist()) == {3} and set(pi["pad_mask"].tolist()) == {1, 2, 4} and (pi["n_bases"] == 2).all()
+    alt16 = [l for l in got["lines"] if l.split("\t")[1] == "16"][0].split("\t")[4]
+    assert alt16 == "13-ITT*T 4 ITT#T 3 IT*TT 2 IT#TT 1 ITTT* 2 DA 2", alt16
+    row16 = [r for r in exp["rows"] if r.split("\t")[1] == "16"][0].split("\t")[4]
+    assert row16.count("+3T*T") == 4 and row16.count("+3t#t") == 3 and row16.count("+3*TT") == 2 and row16.count("+3#tt") == 1 and row16.count("+3TT*-1N") == 2
+    col = eng.columns()
+    c16 = col["cols"][16 - col["region_start"]]
+    assert (c16[4], c16[5], c16[13], c16[14]) == (8, 4, 4, 3), c16      # I = 4 + 2 + 2, I1 = 4; i = 3 + 1, i1 = 3
+    # the C++ decoder builds the same allele text from the packed tokens
+    w = synth_weights()
+    eng.load_weights(w, 18)
+    probs = eng.infer()
+    from clair3_rna_amd import decode
+    f = [l.split("\t") for l in exp["lines"]]
+    assert eng.call_rows("chr20") == decode.vcf_rows("chr20", [int(x[1]) for x in f], [x[2] for x in f], [x[4] for x in f], probs)
+    # a run of more than 64 characters is refused (the table describes the pads by a 64-bit mask); the <= 1.10 text takes it
+    bad = ReadSet.from_records([dict(pos=10, cigar="6M", seq="GTACGT"), dict(pos=12, cigar="4M40I1P30I4M", seq="ACGT" + "T" * 70 + "ACGT")])
+    with pytest.raises(capi.C3RError, match=r"read 1: an insertion with pads \(P ops\) of more than 64 characters"):
         eng.load_reads(bad)
     eng.params = capi.default_params()
     eng.set_params()
-    eng.load_reads(bad)                                                             # the default (<= 1.10) text takes it
+    eng.load_reads(bad)
     eng.set_reference(1, ref)
     eng.scan(1, len(ref))
+    assert len(eng.pad_insertions()) == 0
+
+
+def synth_weights():
+    from clair3_rna_amd import synth
+    w = synth.random_weights(18, seed=4242)
+    w[-24 * 129:] *= 6.0
+    return w
 
 
 @pytest.mark.parametrize("mode", ["lbed", "cbed", "both_beds", "sites", "subregion", "deep"])
@@ -263,7 +299,7 @@ def test_random_cigars_decode_rows_cpp_equals_python_and_regions(eng, compat):
     n_rows, kinds = 0, set()
     for seed in _seeds(60):
         rng = random.Random(9000 + seed)
-        ref, recs = _case(80000 + seed, phased=False, pads=(compat == 0))
+        ref, recs = _case(80000 + seed, phased=False, pads=True)
         rs = ReadSet.from_records(recs)
         L = len(ref)
         eng.params = capi.default_params()

@@ -301,12 +301,17 @@ def test_weird_cigars_against_oracle_columns(eng):
     assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
 
 
-def test_call_var_bam_driver_end_to_end(eng, tmp_path):
+@pytest.mark.parametrize("samtools_version, compat", [("1.10", 0), ("1.21", 1), (None, 1)])
+def test_call_var_bam_driver_end_to_end(eng, tmp_path, samtools_version, compat):
     """The drop-in CLI: BAM + FASTA + weights -> pileup_{ctg}_{chunk}.vcf, against oracle lines -> oracle network ->
-    decode.  Rows must agree exactly except QUAL/GQ, which may move by 0.01 because the probabilities differ at 1e-6."""
+    decode.  Rows must agree exactly except QUAL/GQ, which may move by 0.01 because the probabilities differ at 1e-6.
+    The column text follows the samtools the flag set names (--mpileup_compat auto: `--samtools --version`; 1.10 -> the <= 1.10 printer,
+    1.21 -> the >= 1.11 printer, no such binary -> the >= 1.11 printer): the reads hold insertions with a deletion or a pad right behind
+    them, on which the two printers — and therefore the reference's tensors and alt_info — differ."""
     from clair3_rna_amd import bam, call_var_bam, decode, io, synth, vcf
     from oracle import oracle as orc
     ref, rs, _ = synth.small_case(seed=43, ref_len=30000, n_genes=6, depth=20)
+    rs = H.merge_readsets(rs, H.indel_next_to_indel_reads(ref, int(rs.reads["pos"][len(rs.reads) // 3])))
     fa, bm, wfn = str(tmp_path / "ref.fa"), str(tmp_path / "in.bam"), str(tmp_path / "model")
     io.write_fasta(fa, [("chr20", ref), ("chrM", "ACGT" * 50)])
     bam.write_bam(bm, [("chr20", len(ref)), ("chrM", 200)], {"chr20": rs})
@@ -315,17 +320,19 @@ def test_call_var_bam_driver_end_to_end(eng, tmp_path):
     w = synth.random_weights(18, seed=5)
     np.save(wfn + ".c3rw.npy", w)
     open(str(tmp_path / "CMD"), "w").write("run_clair3_rna test\n")
-    total_rows = 0
+    samtools = H.fake_samtools(str(tmp_path / "samtools"), samtools_version) if samtools_version else str(tmp_path / "no_such_samtools")
+    total_rows, differ = 0, 0
     for chunk_id in (1, 2, 3):
         out = str(tmp_path / ("pileup_chr20_%d.vcf" % chunk_id))
         argv = ["--chkpnt_fn", wfn, "--bam_fn", bm, "--call_fn", out, "--sampleName", "S1", "--ref_fn", fa,
                 "--extend_bed", str(tmp_path / "split_beds" / "chr20"), "--ctgName", "chr20", "--chunk_id", str(chunk_id),
                 "--chunk_num", "3", "--platform", "ont", "--snp_min_af", "0.08", "--indel_min_af", "0.15", "--minMQ", "5",
-                "--minCoverage", "4", "--samtools", "samtools", "--pileup", "--cmd_fn", str(tmp_path / "CMD")]
+                "--minCoverage", "4", "--samtools", samtools, "--pileup", "--cmd_fn", str(tmp_path / "CMD")]
         assert call_var_bam.Run(call_var_bam.build_parser().parse_args(argv), engine=eng) == 0
         a, b = call_var_bam.chunk_region(len(ref), chunk_id, 3)
         rstart = max(1, a - 1000)
-        exp = H.oracle_chunk(rs, ref[rstart - 1:b + 1000], rstart, a, b)
+        exp = H.oracle_chunk(rs, ref[rstart - 1:b + 1000], rstart, a, b, mpileup_compat=compat)
+        differ += exp["lines"] != H.oracle_chunk(rs, ref[rstart - 1:b + 1000], rstart, a, b, mpileup_compat=1 - compat)["lines"]
         if not exp["lines"]:
             assert not os.path.exists(out)
             continue
@@ -344,7 +351,7 @@ def test_call_var_bam_driver_end_to_end(eng, tmp_path):
             gs, es = gf[9].split(":"), ef[9].split(":")
             assert gs[0] == es[0] and gs[2:] == es[2:] and abs(int(gs[1]) - int(es[1])) <= 1
         total_rows += len(got_rows)
-    assert total_rows > 100
+    assert total_rows > 100 and differ >= 1       # (the other printer would have given other lines: the choice was exercised)
 
 
 def test_dense_short_ops_cross_tile_and_batch_boundaries(eng):

@@ -17,6 +17,9 @@ def _sample(tmp, phased=False):
         ref, rs, _ = synth.small_case(seed=seed, ref_len=L, n_genes=max(3, L // 5000), depth=18, phased=phased)
         if name == "chr2":
             ref = ref[:5000] + ref[5000:9000].lower() + ref[9000:]       # soft-masked stretch: both flows must upper-case it
+        if name == "chr1":                       # reads on which the two samtools printers differ (an insertion with a deletion / a pad behind it)
+            from tests import helpers as H
+            rs = H.merge_readsets(rs, H.indel_next_to_indel_reads(ref, int(rs.reads["pos"][len(rs.reads) // 2])))
         contigs.append((name, ref))
         if name != "chr5":                       # a contig of the reference without any read in the BAM
             reads[name] = rs
@@ -81,6 +84,40 @@ def test_sample_equals_per_chunk_flow(tmp_path):
     again = _run_sample(os.path.join(tmp, "out_noindex"), fa, bm, wfn, ["--contexts", "3", "--fetch_threads", "2"])   # and three contexts side by side
     assert open(again).read() == a and os.path.exists(os.path.join(tmp, "out_noindex", "tmp", "input.bam.bai"))
     assert not os.path.exists(bm + ".bai")
+
+
+def test_sample_follows_the_samtools_it_is_given(tmp_path):
+    """--mpileup_compat: the whole-sample driver restates the printer of the samtools the user names (auto: `--samtools --version`), and
+    its records equal the per-chunk flow's under either printer; the two printers give different files on this sample (chr1 holds reads
+    with an insertion that has a deletion / a pad right behind it), and the >= 1.11 one is what a missing samtools resolves to."""
+    from tests import helpers as H
+    tmp = str(tmp_path)
+    fa, bm, wfn, _ = _sample(tmp)
+    old = H.fake_samtools(os.path.join(tmp, "samtools-1.10"), "1.10")
+    new = H.fake_samtools(os.path.join(tmp, "samtools-1.19"), "1.19.2")
+    a0 = open(_run_sample(os.path.join(tmp, "o0"), fa, bm, wfn, ["--samtools", old, "--print_ref_calls"])).read()
+    a1 = open(_run_sample(os.path.join(tmp, "o1"), fa, bm, wfn, ["--samtools", new, "--print_ref_calls"])).read()
+    assert a0 != a1
+    assert open(_run_sample(os.path.join(tmp, "f0"), fa, bm, wfn, ["--mpileup_compat", "0", "--print_ref_calls"])).read() == a0
+    assert open(_run_sample(os.path.join(tmp, "f1"), fa, bm, wfn, ["--samtools", os.path.join(tmp, "none"), "--print_ref_calls"])).read() == a1
+    for k, (text, st) in enumerate(((a0, old), (a1, new))):
+        os.makedirs(os.path.join(tmp, "flow%d" % k))
+        exp = _reference_flow(os.path.join(tmp, "flow%d" % k), fa, bm, wfn, os.path.join(tmp, "o%d" % k), extra_chunk=["--samtools", st], extra_merge=["--show_ref", "True"])
+        assert open(exp).read() == text
+    # against the oracle: the candidate lines of chr1 under the >= 1.11 text, position by position (RefCall rows are printed too)
+    from clair3_rna_amd import bamio
+    bf = bamio.BamFile(bm)
+    rs1 = bf.fetch("chr1")
+    bf.close()
+    ref1 = open(fa).read().split(">")[1].split("\n", 1)[1].replace("\n", "")
+    pos1 = sorted({int(r.split("\t")[1]) for r in a1.split("\n") if r.startswith("chr1\t")})
+    chunks = [r.split() for r in open(os.path.join(tmp, "o1", "tmp", "CHUNK_LIST")) if r.split()[0] == "chr1"]
+    from clair3_rna_amd import call_var_bam
+    exp_pos = set()
+    for _c, cid, cnum in chunks:
+        a, b = call_var_bam.chunk_region(len(ref1), int(cid), int(cnum))
+        exp_pos.update(int(l.split("\t")[1]) for l in H.oracle_chunk(rs1, ref1, 1, a, b, mpileup_compat=1)["lines"])
+    assert pos1 == sorted(exp_pos) and len(pos1) > 30
 
 
 def test_sample_options_bed_refcalls_all_contigs_tagging(tmp_path):

@@ -145,6 +145,9 @@ def test_the_two_samtools_printers_differ_only_behind_an_insertion():
     assert bases([R(9, "2M1I1P1I2M", "ACTTGA")], compat=1) == {10: "^]A", 11: "C+3T*T", 12: "G", 13: "A$"}
     assert bases([R(9, "2M1P2I2M", "ACTTGA")], compat=1) == {10: "^]A", 11: "C+3*TT", 12: "G", 13: "A$"}
     assert bases([R(9, "2M2I1P1D2M", "ACTTGA")], compat=1) == {10: "^]A", 11: "C+3TT*-1N", 12: "*", 13: "G", 14: "A$"}
+    # a reverse-strand read prints its pads as '#' (pileup_seq: `pad = rev_del ? '#' : '*'`; the reference always passes --reverse-del)
+    assert bases([R(9, "2M1I1P1I2M", "ACTTGA", flag=16)], compat=1) == {10: "^]a", 11: "c+3t#t", 12: "g", 13: "a$"}
+    assert bases([R(9, "2M1P2I2M", "ACTTGA", flag=16)], compat=1) == {10: "^]a", 11: "c+3#tt", 12: "g", 13: "a$"}
     # everything else is printed alike
     for cigar, seq in (("2M1D2M", "ACGT"), ("2M2I2M", "ACGTTA"), ("2M3N2M", "ACGT"), ("2M1D2I2M", "ACTTGA"), ("3M2I", "ACGTT"), ("2M1P1D2M", "ACGT")):
         assert bases([R(9, cigar, seq)], compat=0) == bases([R(9, cigar, seq)], compat=1), cigar
