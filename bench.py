@@ -28,8 +28,12 @@ import numpy as np  # noqa: E402
 
 CHUNK = 5000000            # shared/param_p.py:91 CHUNK_SIZE
 # algorithmic work per emitted candidate
-FLOP_PER_SITE = {"k_lstm1": 2.0 * (18 + 128) * 512 * 33 * 2, "k_lstm2": 2.0 * (256 + 160) * 640 * 33 * 2,
-                 "k_fc4": 2.0 * 10560 * 128, "k_heads": 2.0 * (128 * 256 + 128 * 24)}
+def flop_per_site(channels=18):
+    return {"k_lstm1": 2.0 * (channels + 128) * 512 * 33 * 2, "k_lstm2": 2.0 * (256 + 160) * 640 * 33 * 2,
+            "k_fc4": 2.0 * 10560 * 128, "k_heads": 2.0 * (128 * 256 + 128 * 24)}
+
+
+FLOP_PER_SITE = flop_per_site(18)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (never the 2:1-sparse figure)
 PEAK_HBM_GBPS = 8000.0
@@ -122,8 +126,8 @@ def cpu_baseline(rs, ref, weights, contig_len):
     import tempfile
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
-    size = 250000
-    n_regions = min((contig_len + size - 1) // size, 8 * cores)        # 8 cores: 16 Mb; 32 cores and up: the whole chr20
+    size = 125000
+    n_regions = min((contig_len + size - 1) // size, 2 * cores)        # bounded: two short regions per core (~4 s on the 256-thread box)
     workers = min(cores, n_regions)
     scratch = tempfile.mkdtemp(prefix="c3r_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     _CPU.update(orc=orc, rs=rs, ref=ref, size=size, contig_len=contig_len, dir=scratch)
@@ -134,7 +138,7 @@ def cpu_baseline(rs, ref, weights, contig_len):
         t1 = time.perf_counter()
         X = [np.load(os.path.join(scratch, f)) for f in sorted(os.listdir(scratch))]
         n_cpu = int(sum(counts))
-        n_net = min(n_cpu, 400 * cores)                                  # bounded: ~15 s of network on this box
+        n_net = min(n_cpu, 120 * cores)                                  # bounded: ~4 s of network on this box
         if n_net:
             orc.forward(weights, np.concatenate(X)[:n_net])
         t2 = time.perf_counter()
@@ -147,10 +151,122 @@ def cpu_baseline(rs, ref, weights, contig_len):
                 note="a port of the reference pipeline, not a tuned CPU code: the network leg is a scalar fp32 triple loop "
                      "(%.1f GFLOP/s per core here; TensorFlow/Eigen reach 10-100x that), so this is a baseline to read beside the "
                      "number, never a speed-up denominator" % (47.8e6 * n_net / max(t2 - t1, 1e-9) / cores / 1e9),
-                sample="chr20:1-%d of the same synthetic contig: text mpileup + parse + window driver in %d worker processes, one 250-kb "
+                sample="chr20:1-%d of the same synthetic contig: text mpileup + parse + window driver in %d worker processes, one 125-kb "
                        "region each (%d candidates, %.1f s), then the fp32 network on %d cores with OpenMP over the first %d of them (%.1f s); "
                        "value = 1 / (s per site of stage 1 + s per site of stage 2)"
                        % (min(n_regions * size, contig_len), workers, n_cpu, t1 - t0, cores, n_net, t2 - t1))
+
+
+def rooflines(kernels, n_prof, rs, site_pos, channels, precision):
+    """One profiled pass (HIP-event kernel statistics of c3r_set_profiling) -> (roofline of the dominant kernel, the tensor build against
+    ITS roofline, the two halves' rates).  `kernels` loses its "h2d_reads" entry (PCIe time, reported beside the kernels)."""
+    fps = flop_per_site(channels)
+    h2d_ms = kernels.pop("h2d_reads", {"total_ms": 0.0})["total_ms"]          # (the upload of the pass's records: PCIe time, reported beside the kernels)
+    dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+    st = kernels[dom]
+    avg_ms = st["total_ms"] / st["launches"]
+    if dom in fps:
+        per_site = fps[dom]
+        if dom == "k_lstm2" and precision != "f32":
+            per_site += fps["k_fc4"]          # the L4 dense layer is fused into the layer-2 kernel
+        flops_per_launch = per_site * n_prof / st["launches"]
+        ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        if precision in ("f16+f8", "auto"):
+            # algorithmic flops against the dense f16 peak; the kernel executes one f16 product plus two fp8 products (on the
+            # block-scaled pipe at twice the f16 rate) per algorithmic product = 2 f16-equivalents of matrix-pipe time
+            roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(ach / PEAK_F16_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
+                            launches=st["launches"], executed_f16_equiv_tflops=round(2 * ach, 1),
+                            executed_frac=round(2 * ach / PEAK_F16_MFMA_TFLOPS, 4),
+                            note="f16 main term + both correction terms as one block-scaled fp8 MFMA (K = 64), fp32 accumulation")
+        elif precision == "f16x3":
+            # ALGORITHMIC flops against the dense f16 MFMA peak.  The kernel executes 3 f16 products per algorithmic
+            # product (hi*hi + hi*lo + lo*hi), so matrix-pipe utilisation is 3x `frac`.
+            roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(ach / PEAK_F16_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
+                            launches=st["launches"], executed_tflops=round(3 * ach, 1),
+                            executed_frac=round(3 * ach / PEAK_F16_MFMA_TFLOPS, 4),
+                            vs_f32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 3),
+                            note="split-f16: fp32-equivalent GEMM as 3 f16 MFMAs with fp32 accumulation")
+        else:
+            roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
+                            launches=st["launches"])
+    else:
+        roofline = dict(kernel=dom, bound="hbm", achieved=None, peak=PEAK_HBM_GBPS, unit="GB/s", frac=None, traffic=None,
+                        avg_launch_ms=round(avg_ms, 4), launches=st["launches"])
+    # SURVEY 8(d): the two halves on their own (device time of each half's kernels in the profiled pass).  The tensor-build half
+    # is everything that is not the network: read preparation (upload excluded: copies are not kernels; reported as h2d), scan, windows, tokens.
+    net_ms = sum(v["total_ms"] for k, v in kernels.items() if k in NET_KERNELS)
+    k1_ms = sum(v["total_ms"] for k, v in kernels.items()) - net_ms
+    prep = ("k_prep_count", "k_prefmax_bins", "k_bin_scan", "k_prep_write", "k_legacy_tables")
+    prep_ms = sum(v["total_ms"] for k, v in kernels.items() if k in prep)
+    k1_bytes = k1_algorithmic_bytes(rs, site_pos, channels) if n_prof else 0.0
+    tb_gbps = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms else 0.0
+    stage_rates = dict(tensor_build_sites_per_s=round(n_prof / (k1_ms * 1e-3), 1) if k1_ms else None,
+                       inference_sites_per_s=round(n_prof / (net_ms * 1e-3), 1) if net_ms else None,
+                       tensor_build_algorithmic_GBps=round(tb_gbps, 1) if k1_ms else None,
+                       tensor_build_ms=round(k1_ms, 3), read_preparation_ms=round(prep_ms, 3), inference_ms=round(net_ms, 3))
+    if dom not in fps and roofline["bound"] == "hbm" and k1_ms:
+        # the dominant kernel is a tensor-build kernel (deep coverage, few candidates): the whole build's algorithmic bytes over ITS time
+        # would overstate it, so `achieved` stays with the build as a whole (roofline_tensor_build) and this entry names the kernel
+        roofline["note"] = "a tensor-build kernel dominates this workload: see roofline_tensor_build for the build as a whole"
+    # the tensor-build half against ITS roofline (HBM): SURVEY 8(d)'s algorithmic bytes, evaluated on this pass's candidates,
+    # over the summed device time of ALL tensor-build kernels of the profiled pass (read preparation included)
+    roofline_tb = dict(kernels=sorted(k for k in kernels if k not in NET_KERNELS), bound="hbm",
+                       achieved=round(tb_gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(tb_gbps / PEAK_HBM_GBPS, 4),
+                       bytes_per_site=round(k1_bytes / n_prof, 1) if n_prof else None, bytes_per_pass=int(k1_bytes), ms=round(k1_ms, 3),
+                       note="bytes: SURVEY 8(d) formula evaluated on the pass's own candidates and reads (bench.k1_algorithmic_bytes)")
+    h2d_bytes = int(rs.reads.nbytes + rs.cigar.nbytes + rs.seq.nbytes)
+    roofline_tb["h2d"] = dict(bytes=h2d_bytes, ms=round(h2d_ms, 3), GBps=round(h2d_bytes / (h2d_ms * 1e-3) / 1e9, 1) if h2d_ms else None, included_in_ms=False,
+                              frac_with_h2d=round(k1_bytes / ((k1_ms + h2d_ms) * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if k1_ms else None,
+                              note="the pass's records go up from page-locked host memory inside c3r_load_reads (PCIe, not HBM): inside every timed step, "
+                                   "outside roofline_tensor_build.ms; frac_with_h2d counts it as if it were kernel time")
+    return roofline, roofline_tb, stage_rates
+
+
+def extra_config(name, workload, gen, channels, precision, local_rank, steps=4, params=None):
+    """One more BASELINE.json configuration on one GPU, as an ADDITIONAL object of the bench line (never `value`): `steps` passes of the
+    whole hot path (host-resident records -> device tables -> tensor build -> network -> probabilities on the host) on one context, then
+    one profiled pass for the kernel table and the two rooflines."""
+    import torch
+    from clair3_rna_amd import capi, synth
+    ref, rs, info = synth.generate_contig(**gen)
+    contig_len = gen["contig_len"]
+    chunks = chunk_list(contig_len)
+    w = synth.random_weights(channels)
+    rsh = capi.pinned_readset(rs)
+    e = capi.Engine(local_rank)
+    try:
+        e.set_params(channels=channels, **(params or {}))
+        e.set_reference(1, ref); e.load_weights(w, channels); e.set_precision(precision)
+
+        def step():
+            e.load_reads(rsh)
+            e.begin_batch(); n = e.scan_regions(chunks); e.end_batch()
+            if n:
+                e.infer()
+            return n
+        step(); step()                                   # buffers sized, clocks up
+        e.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sites = sum(step() for _ in range(steps))
+        e.synchronize(); torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        e.set_profiling(True); e.reset_kernel_stats()
+        n_prof = step()
+        e.set_profiling(False)
+        kernels = e.kernel_stats()
+        roof, roof_tb, rates = rooflines(kernels, n_prof, rs, e.sites()["pos"] if n_prof else [], channels, precision)
+        mode = e.precision()[0]
+    finally:
+        e.close()
+    return dict(name=name, workload=workload, value=round(sites / el, 1), unit="sites/s", steps=steps, ms_per_step=round(1e3 * el / steps, 3),
+                sites_per_step=round(sites / steps, 1), reads=info["n_reads"], reads_per_s=round(info["n_reads"] * steps / el, 1),
+                exonic_bp=info["n_exonic"], channels=channels, precision=mode, contig_len=contig_len, streams=1,
+                host_and_copies_ms_per_step=round(1e3 * el / steps - sum(v["total_ms"] for v in kernels.values()), 3),
+                roofline=roof, roofline_tensor_build=roof_tb, stage_rates=rates,
+                kernels_ms_per_step={k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())})
 
 
 def run_strong(args, rank, local_rank, world, one_gpu, emit=True):
@@ -268,6 +384,8 @@ def main():
     ap.add_argument("--no_fast", action="store_true", help="skip the additional measurement in precision 'auto' (reported as fast_precision)")
     ap.add_argument("--no_strong", action="store_true", help="skip the additional N = 1 run of the strong-scaling configuration (BASELINE.json configs[2] at "
                                                              "a quarter of every contig's length), reported as strong_1gpu")
+    ap.add_argument("--no_extra", action="store_true", help="skip the additional N = 1 runs of BASELINE.json configs[3] (MAS-Seq, 30 channels: phased_1gpu), configs[4] "
+                                                            "(500x: stress_500x) and of the 20,000x locus that trips mpileup's depth cap (depth_cap_20000x)")
     ap.add_argument("--no_overlap", action="store_true",
                     help="one context / one stream: tensor build and network strictly back to back")
     ap.add_argument("--precision", choices=["f16x3", "f32", "f16+f8", "auto"], default="f16x3",
@@ -459,67 +577,13 @@ def main():
         eng.set_profiling(False)
         kernels = eng.kernel_stats()
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
-        st = kernels[dom]
-        avg_ms = st["total_ms"] / st["launches"]
-        if dom in FLOP_PER_SITE:
-            per_site = FLOP_PER_SITE[dom]
-            if dom == "k_lstm2" and args.precision != "f32":
-                per_site += FLOP_PER_SITE["k_fc4"]          # the L4 dense layer is fused into the layer-2 kernel
-            flops_per_launch = per_site * n_prof / st["launches"]
-            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            if args.precision in ("f16+f8", "auto"):
-                # algorithmic flops against the dense f16 peak; the kernel executes one f16 product plus two fp8 products (on the
-                # block-scaled pipe at twice the f16 rate) per algorithmic product = 2 f16-equivalents of matrix-pipe time
-                roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s",
-                                frac=round(ach / PEAK_F16_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
-                                launches=st["launches"], executed_f16_equiv_tflops=round(2 * ach, 1),
-                                executed_frac=round(2 * ach / PEAK_F16_MFMA_TFLOPS, 4),
-                                note="f16 main term + both correction terms as one block-scaled fp8 MFMA (K = 64), fp32 accumulation")
-            elif args.precision == "f16x3":
-                # ALGORITHMIC flops against the dense f16 MFMA peak.  The kernel executes 3 f16 products per algorithmic
-                # product (hi*hi + hi*lo + lo*hi), so matrix-pipe utilisation is 3x `frac`.
-                roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s",
-                                frac=round(ach / PEAK_F16_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
-                                launches=st["launches"], executed_tflops=round(3 * ach, 1),
-                                executed_frac=round(3 * ach / PEAK_F16_MFMA_TFLOPS, 4),
-                                vs_f32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 3),
-                                note="split-f16: fp32-equivalent GEMM as 3 f16 MFMAs with fp32 accumulation")
-            else:
-                roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                                frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_ms=round(avg_ms, 4),
-                                launches=st["launches"])
-        else:
-            roofline = dict(kernel=dom, bound="hbm", achieved=None, peak=PEAK_HBM_GBPS, unit="GB/s", frac=None, traffic=None,
-                            avg_launch_ms=round(avg_ms, 4), launches=st["launches"])
-        # the two halves on their own (device time of each half's kernels in the profiled pass).  The tensor-build half
-        # is everything that is not the network: read preparation (upload excluded: copies are not kernels; reported as h2d), scan, windows, tokens.
-        net_ms = sum(v["total_ms"] for k, v in kernels.items() if k in NET_KERNELS)
-        h2d_ms = kernels.pop("h2d_reads", {"total_ms": 0.0})["total_ms"]          # (the upload of the pass's records: PCIe time, reported beside the kernels)
-        k1_ms = sum(v["total_ms"] for k, v in kernels.items()) - net_ms
-        prep = ("k_prep_count", "k_prefmax_bins", "k_bin_scan", "k_prep_write", "k_legacy_tables")
-        prep_ms = sum(v["total_ms"] for k, v in kernels.items() if k in prep)
-        k1_bytes = k1_algorithmic_bytes(rs, eng.sites()["pos"], 18) if n_prof else 0.0
-        tb_gbps = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms else 0.0
-        stage_rates = dict(tensor_build_sites_per_s=round(n_prof / (k1_ms * 1e-3), 1) if k1_ms else None,
-                           inference_sites_per_s=round(n_prof / (net_ms * 1e-3), 1) if net_ms else None,
-                           tensor_build_algorithmic_GBps=round(tb_gbps, 1) if k1_ms else None,
-                           tensor_build_ms=round(k1_ms, 3), read_preparation_ms=round(prep_ms, 3), inference_ms=round(net_ms, 3))
-        # the tensor-build half against ITS roofline (HBM): SURVEY 8(d)'s algorithmic bytes, evaluated on this pass's candidates,
-        # over the summed device time of ALL tensor-build kernels of the profiled pass (read preparation included)
-        roofline_tb = dict(kernels=sorted(k for k in kernels if k not in NET_KERNELS), bound="hbm",
-                           achieved=round(tb_gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(tb_gbps / PEAK_HBM_GBPS, 4),
-                           bytes_per_site=round(k1_bytes / n_prof, 1) if n_prof else None, bytes_per_pass=int(k1_bytes), ms=round(k1_ms, 3),
-                           note="bytes: SURVEY 8(d) formula evaluated on the pass's own candidates and reads (bench.k1_algorithmic_bytes)")
-        h2d_bytes = int(rs.reads.nbytes + rs.cigar.nbytes + rs.seq.nbytes)
-        roofline_tb["h2d"] = dict(bytes=h2d_bytes, ms=round(h2d_ms, 3), GBps=round(h2d_bytes / (h2d_ms * 1e-3) / 1e9, 1) if h2d_ms else None, included_in_ms=False,
-                                  frac_with_h2d=round(k1_bytes / ((k1_ms + h2d_ms) * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if k1_ms else None,
-                                  note="the pass's records go up from page-locked host memory inside c3r_load_reads (PCIe, not HBM): inside every timed step, "
-                                       "outside roofline_tensor_build.ms; frac_with_h2d counts it as if it were kernel time")
+        roofline, roofline_tb, stage_rates = rooflines(kernels, n_prof, rs, eng.sites()["pos"] if n_prof else [], 18, args.precision)
         traffic_fn = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes
         if roofline and os.path.exists(traffic_fn):
             try:
                 per_kernel = json.load(open(traffic_fn)).get(args.precision, {})
                 roofline["traffic"] = per_kernel.get(dom)
+                roofline["traffic_source"] = "static: profiles/pmc_traffic.json, per-launch FETCH_SIZE / WRITE_SIZE of separate rocprofv3 --pmc passes over this command (tools/profile_bench.sh), not collected in this run"
                 # counter bytes of one pass through every tensor-build kernel (launches per pass: one each, the three-launch scans and the
                 # library sort a handful — their per-launch averages are small): raw FETCH_SIZE + WRITE_SIZE, see profiles/*_pmc_*.csv
                 tb = {k: v for k, v in per_kernel.items() if k.startswith("k_") and not k.startswith(("k_lstm", "k_heads", "k_fc4"))}
@@ -530,17 +594,43 @@ def main():
 
     # ---- BASELINE.json configs[2] on ONE GPU: the 24 GRCh38 contigs (a quarter of each) from host-resident reads AND reference, so that the
     # driver's record carries the configuration `--scaling strong` shards over N ranks — an ADDITIONAL figure, never `value`
-    strong = None
-    if world == 1 and not args.no_strong and args.steps > 0:
+    n_streams = len(engs)
+    strong, phased, stress, capped = None, None, None, None
+    if world == 1 and args.steps > 0 and not (args.no_strong and args.no_extra):
         for e in engs:
             e.close()
         engs = []
-        sa = argparse.Namespace(**vars(args))
-        sa.genome_scale, sa.steps, sa.warmup = 0.25, 1, 0
-        so = run_strong(sa, rank, local_rank, world, one_gpu, emit=False)
-        strong = dict(value=so["value"], unit="sites/s", ms_per_step=so["ms_per_step"], workload=so["config"]["workload"], inputs=so["config"]["inputs"],
-                      genome_bp=so["config"]["genome_bp"], sites_per_step=so["config"]["sites_per_step"], streams=so["config"]["streams"],
-                      note="python bench.py --scaling strong --genome_scale 0.25 --steps 1 at N = 1; with --gpus N the same contigs are dealt to N ranks")
+    if world == 1 and not args.no_strong and args.steps > 0:
+        try:
+            sa = argparse.Namespace(**vars(args))
+            sa.genome_scale, sa.steps, sa.warmup = 0.25, 1, 0
+            so = run_strong(sa, rank, local_rank, world, one_gpu, emit=False)
+            strong = dict(value=so["value"], unit="sites/s", ms_per_step=so["ms_per_step"], workload=so["config"]["workload"], inputs=so["config"]["inputs"],
+                          genome_bp=so["config"]["genome_bp"], sites_per_step=so["config"]["sites_per_step"], streams=so["config"]["streams"],
+                          note="python bench.py --scaling strong --genome_scale 0.25 --steps 1 at N = 1; with --gpus N the same contigs are dealt to N ranks")
+        except Exception as ex:                       # an additional measurement must never cost the headline
+            strong = dict(error="%s: %s" % (type(ex).__name__, ex))
+    # ---- BASELINE.json configs[3] and configs[4] on ONE GPU, and the depth-cap cliff: ADDITIONAL figures, never `value`
+    if world == 1 and not args.no_extra and args.steps > 0:
+        def guarded(fn):
+            try:
+                return fn()
+            except Exception as ex:
+                return dict(error="%s: %s" % (type(ex).__name__, ex))
+        phased = guarded(lambda: extra_config(
+            "phased_1gpu", "synthetic PacBio MAS-Seq chr20 ~30x with HP tags, 30 channels, phased-shape weights (BASELINE.json configs[3], one contig)",
+            dict(contig_len=synth.CHR20_LEN, seed=synth.SEED + 3, depth=30.0, platform="hifi", phased=True), 30, args.precision, local_rank))
+        stress = guarded(lambda: extra_config(
+            "stress_500x", "synthetic ONT dRNA004 windows at ~500x: 16 Mb contig, expressed loci at mean depth 500 (BASELINE.json configs[4])",
+            dict(contig_len=16000000, seed=synth.SEED + 4, depth=500.0), 18, args.precision, local_rank))
+        # one locus far beyond samtools mpileup's -d 8000: the depth-cap rule runs (csrc/c3r_lib.hip, depth_cap_mask), with the cap and without it
+        deep = dict(contig_len=400000, seed=synth.SEED + 5, depth=20000.0, expressed_frac=0.01, intron_lo=100.0, intron_hi=800.0)
+        capped = guarded(lambda: extra_config("depth_cap_20000x", "one 400-kb contig with loci at ~20,000x: mpileup's depth cap -d 8000 in force", deep, 18, args.precision, local_rank, steps=3))
+        nocap = guarded(lambda: extra_config("depth_cap_20000x_off", "the same reads with max_depth = 0 (no cap)", deep, 18, args.precision, local_rank, steps=3, params=dict(max_depth=0)))
+        if isinstance(capped, dict) and "error" not in capped and isinstance(nocap, dict) and "error" not in nocap:
+            capped["without_cap"] = dict(ms_per_step=nocap["ms_per_step"], sites_per_step=nocap["sites_per_step"], value=nocap["value"],
+                                         kernels_ms_per_step=nocap["kernels_ms_per_step"])
+            capped["cap_cost_ms_per_step"] = round(capped["ms_per_step"] - nocap["ms_per_step"], 3)
 
     if rank == 0:
         out = {
@@ -556,9 +646,10 @@ def main():
                        "contig_len": contig_len, "chunks": len(chunks), "channels": 18, "precision": args.precision, "reads_per_rank": info["n_reads"],
                        "exonic_bp_per_rank": info["n_exonic"], "sites_per_step_per_rank": round(sites_per_step_rank, 1),
                        "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world,
-                       "streams": len(engs)},
+                       "streams": n_streams},
             "roofline": roofline, "roofline_tensor_build": roofline_tb, "cpu_baseline": cpu, "stage_rates": stage_rates,
-            "resident_inputs": resident, "fast_precision": fast, "strong_1gpu": strong,
+            "resident_inputs": resident, "fast_precision": fast, "strong_1gpu": strong, "phased_1gpu": phased, "stress_500x": stress,
+            "depth_cap_20000x": capped,
             "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
         }
         print(json.dumps(out), flush=True)

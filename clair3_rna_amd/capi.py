@@ -36,7 +36,7 @@ class C3RError(RuntimeError):
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_trim", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_host_alloc", "c3r_host_free", "c3r_set_reference", "c3r_set_reference_view", "c3r_set_bed", "c3r_set_sites",
            "c3r_pileup_scan", "c3r_pileup_scan_regions", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_pad_insertions", "c3r_get_columns",
-           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_reserve", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_rows_begin", "c3r_rows_decode", "c3r_rows_get", "c3r_rows_free", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
+           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_get_precision_guard", "c3r_reserve", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_rows_begin", "c3r_rows_decode", "c3r_rows_get", "c3r_rows_free", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
 _lib = None
@@ -91,6 +91,7 @@ def load_library():
     L.c3r_load_weights.argtypes = [vp, vp, i64, i32]
     L.c3r_set_precision.argtypes = [vp, i32]
     L.c3r_get_precision.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
+    L.c3r_get_precision_guard.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(i32)]
     L.c3r_infer.argtypes = [vp, vp, i64, vp]
     L.c3r_reserve.argtypes = [vp, i64]
     L.c3r_get_probs.argtypes = [vp, vp, i64]
@@ -323,6 +324,13 @@ class Engine(object):
         m, e = C.c_int32(0), C.c_double(-1.0)
         self._chk(self.L.c3r_get_precision(self.h, C.byref(m), C.byref(e)))
         return {v: k for k, v in self.PRECISIONS.items()}[m.value], e.value
+
+    def precision_guard(self):
+        """dict(f16_err = max |dP| of split-f16 against the fp32 MFMA path on the calibration windows (-1 before weights are loaded),
+        scale_log2 = the power-of-two scales of LSTM 1 / LSTM 2 / L4, fell_back = the guard sent the request to the fp32 path)."""
+        e, sc, fb = C.c_double(-1.0), (C.c_int32 * 3)(), C.c_int32(0)
+        self._chk(self.L.c3r_get_precision_guard(self.h, C.byref(e), sc, C.byref(fb)))
+        return dict(f16_err=e.value, scale_log2=[int(v) for v in sc], fell_back=bool(fb.value))
 
     def infer(self, tensors=None, n=None, fetch=True):
         if tensors is None:

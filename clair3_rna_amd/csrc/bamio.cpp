@@ -729,6 +729,10 @@ int c3r_bam_contig_weight(c3r_bam *b, int i, int64_t *n_mapped, int64_t *file_by
         if (ri.n_mapped < 0) {             // no pseudo-bin: the span of the contig's chunks
             lo = ~0ull; hi = 0;
             for (auto &kv : ri.bins) for (auto &c : kv.second) { lo = std::min(lo, c.first); hi = std::max(hi, c.second); }
+            // `samtools index` writes the pseudo-bin only for references that HAVE records: a contig without a single bin (chrY, chrM or a
+            // decoy under --include_all_ctgs) holds no read — 0 mapped reads, 0 bytes, not "unknown" (which would push the whole deal of a
+            // sample from mapped reads down to compressed bytes)
+            if (ri.bins.empty()) nm = 0;
         }
         fb = hi > lo ? (int64_t)((hi >> 16) - (lo >> 16)) : 0;       // (virtual offsets: compressed file offset << 16 | offset in the block)
     }

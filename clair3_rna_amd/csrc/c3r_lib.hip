@@ -49,8 +49,9 @@ struct c3r_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    // A context that owns its streams keeps TWO: `stream` (the device's highest priority) for everything but the network, and
-    // `net_stream` (default priority) for A6's kernels, chained by events inside c3r_infer.  A layer-2 workgroup owns its CU (8 waves x
+    // With C3R_TWO_STREAMS=1 (opt-in; by default everything runs on ONE stream) a context that owns its streams keeps TWO: `stream` (the
+    // device's highest priority) for everything but the network, and `net_stream` (lowest priority) for A6's kernels, chained by events
+    // inside c3r_infer.  A layer-2 workgroup owns its CU (8 waves x
     // 256 VGPRs, 148 KB of LDS: nothing co-resides), and with one priority for all queues the dispatcher did not start another
     // queue's kernel before the running LSTM kernel had handed out its last workgroup: the ~10 short kernels of another context's
     // load_reads + scan each waited out most of a 7-14 ms kernel (profiles/r4/prep_beside_network.txt: 75-110 ms beside a network
@@ -133,7 +134,7 @@ struct c3r_ctx {
     // ---- scan state
     int32_t reg_beg0 = 0, reg_end0 = 0;   // first region of the most recent scan (c3r_get_columns)
     int64_t n_pos = 0;                    // position slots of the most recent scan (all regions, tile-padded)
-    int32_t max_cover = 0;                // most passing reads covering one position: below max_depth / 2 the cap cannot bite
+    int32_t max_cover = 0;                // upper bound of htslib's read list at any read's start (LoadStats): at or below max_depth the cap cannot bite
     std::vector<uint32_t> h_drop;         // depth cap of the most recent scan: [n_regions][drop_words] bit per read
     DevBuf d_drop;
     std::vector<TileGeo> h_geo;           // tile geometry of the most recent scan; re-uploaded only when it changes
@@ -156,6 +157,8 @@ struct c3r_ctx {
     NetState net;
     int precision_req = 1;                 // what c3r_set_precision asked for (3 = auto); net.precision is what runs
     double mx_calib_err = -1.0;            // max |dP| of precision 2 against precision 1 on the calibration windows (-1: not measured)
+    double f16_calib_err = -1.0;           // max |dP| of split-f16 against the fp32 MFMA path on the same windows, measured at c3r_load_weights
+    bool f16_fell_back = false;            // the guard sent a split-f16 request to the fp32 path
 
     // ---- host decode (A8)
 };
@@ -188,22 +191,21 @@ int fail(c3r_ctx *ctx, int code, const char *fmt, ...) {
     } while (0)
 
 // The layer-2 kernels meet their wavefronts through LDS counters with bounded waits (net_kernels.hpp, lds_wait): a wait that ever gives
-// up raises g_lstm_timeout instead of hanging the GPU.  Whoever hands probabilities to the host reads the word first — queued behind the
-// network on the same stream, so it costs no extra synchronisation — and fails the call rather than pass on numbers computed from a
-// half-written h_t.  The word is ONE per process and is never cleared: a time-out is a protocol error, not a load condition, and with
-// several contexts side by side (call_sample runs two) a reader that reset it could hide it from the context whose kernel raised it —
-// once set, every context of the process fails its probability fetches.  The pinned slot the word is copied into belongs to the context
-// (two outstanding queries of one thread used to share one slot).
+// up raises the context's time-out word (NetState::d_tmo) instead of hanging the GPU.  Whoever hands probabilities to the host reads the
+// word first — queued behind the network on the same stream, so it costs no extra synchronisation — and fails the call rather than pass
+// on numbers computed from a half-written h_t.  The word belongs to the CONTEXT and c3r_infer clears it before it queues a network pass:
+// the faulty batch fails (every fetch of its probabilities, until the next c3r_infer), a healthy context beside it does not, and a host
+// application that embeds the library goes on with the next batch or a fresh context (round 4 kept one word per process and never cleared it).
 int queue_lstm_status(c3r_ctx *ctx, int32_t **slot) {
     if (!ctx->h_lstm) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lstm, 64, hipHostMallocDefault));
     *ctx->h_lstm = 0;
-    HIPCHK(ctx, hipMemcpyFromSymbolAsync(ctx->h_lstm, HIP_SYMBOL(g_lstm_timeout), 4, 0, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->net.d_tmo) HIPCHK(ctx, hipMemcpyAsync(ctx->h_lstm, ctx->net.d_tmo, 4, hipMemcpyDeviceToHost, ctx->stream));
     *slot = ctx->h_lstm;
     return C3R_OK;
 }
 int check_lstm_status(c3r_ctx *ctx, const int32_t *slot) {
     if (slot && *slot)
-        return fail(ctx, C3R_EHIP, "internal: a layer-2 wavefront rendezvous timed out in this process — probabilities are not valid (the flag stays set: restart the process)");
+        return fail(ctx, C3R_EHIP, "internal: a layer-2 wavefront rendezvous timed out in this batch — its probabilities are not valid (the flag is cleared by the next c3r_infer of this context)");
     return C3R_OK;
 }
 
@@ -545,16 +547,15 @@ int ensure_legacy_tables(c3r_ctx *ctx) {
     const int n = ctx->n_reads;
     int rc;
     if ((rc = ensure(ctx, ctx->d_lcnt, (size_t)(n + 2) * sizeof(int2)))) return rc;
+    // sizes without asking the device: normalisation only drops or merges ops, and a read with k ref-skips has k + 1 segments out of at least
+    // 2 k + 1 ops — (ops + reads) / 2 segments at most.  (Round 4 read the two totals back: a host wait in every 30-channel pass.)
+    const size_t max_ops = (size_t)ctx->n_cigar_ops, max_segs = ((size_t)ctx->n_cigar_ops + (size_t)n) / 2 + 1;
+    if ((rc = ensure(ctx, ctx->d_cigar, max_ops * 4 + 16)) || (rc = ensure(ctx, ctx->d_rsegs, max_segs * sizeof(DevSeg) + 16)) ||
+        (rc = ensure(ctx, ctx->d_rseg_first, (size_t)(n + 1) * 4)))
+        return rc;
     Launch L(ctx, "k_legacy_tables");
     hipLaunchKernelGGL(k_legacy_count, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const DevRead *)ctx->d_reads.p, n, (const uint32_t *)ctx->d_rawcig.p, (int2 *)ctx->d_lcnt.p);
     hipLaunchKernelGGL(k_legacy_scan, dim3(1), dim3(1024), 0, ctx->stream, (int2 *)ctx->d_lcnt.p, n + 1, (int2 *)ctx->d_lcnt.p + (n + 1));
-    int2 tot = make_int2(0, 0);
-    HIPCHK(ctx, hipMemcpyAsync(&tot, (int2 *)ctx->d_lcnt.p + (n + 1), sizeof tot, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (tot.x < 0 || tot.y < 0) return fail(ctx, C3R_EINVAL, "too many CIGAR ops");
-    if ((rc = ensure(ctx, ctx->d_cigar, (size_t)tot.x * 4 + 16)) || (rc = ensure(ctx, ctx->d_rsegs, (size_t)tot.y * sizeof(DevSeg) + 16)) ||
-        (rc = ensure(ctx, ctx->d_rseg_first, (size_t)(n + 1) * 4)))
-        return rc;
     hipLaunchKernelGGL(k_legacy_write, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, ctx->stream, (const DevRead *)ctx->d_reads.p, n, (const uint32_t *)ctx->d_rawcig.p,
                        (const int2 *)ctx->d_lcnt.p, (uint32_t *)ctx->d_cigar.p, (DevSeg *)ctx->d_rsegs.p, (uint32_t *)ctx->d_rseg_first.p);
     HIPCHK(ctx, hipGetLastError());
@@ -918,7 +919,8 @@ static int depth_cap_mask(c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts
     *d_drop = nullptr;
     const int drop_words = (int)(((size_t)ctx->n_reads + 31) / 32);
     *drop_words_out = drop_words;
-    if (!(ctx->prm.max_depth > 0 && (int64_t)ctx->max_cover * 2 > ctx->prm.max_depth)) return C3R_OK;
+    // (max_cover bounds the engine's read list at every read's start, k_prep / k_bin_scan: at or below the cap no read can be discarded)
+    if (!(ctx->prm.max_depth > 0 && (int64_t)ctx->max_cover > ctx->prm.max_depth)) return C3R_OK;
     int rc;
     if ((rc = ensure_host_reads(ctx))) return rc;
     ctx->h_drop.assign((size_t)n_regions * drop_words, 0u);
@@ -1338,7 +1340,15 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         if (ctx->h_scan[6]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
         if (n_cand < 0 || n_tok < 0) return fail(ctx, C3R_EOVERFLOW, "too many candidates or tokens for one scan");
         if (raw_rerun) {
-            if (n_cand != ctx->last_cand || (ctx->h_scan[2] & 1)) return fail(ctx, C3R_EINVAL, "internal: the raw re-run found %d candidates, the scan %lld", n_cand, (long long)ctx->last_cand);
+            if (ctx->h_scan[2] & 1) {
+                // a shard ran over: which workgroup takes a span depends on dynamic tickets and stealing across queues, so the shards' loads
+                // differ from run to run and a shard that fitted in the scan itself may not fit now — grow and repeat like the scan does
+                // (d_raw / d_rawidx are private to the re-run)
+                if (attempt >= 2) return fail(ctx, C3R_EOVERFLOW, "internal: the raw re-run's buffers are still too small after growing (%d candidates)", n_cand);
+                want_c = std::max<int64_t>(want_c, need_c + need_c / 4 + 1024);
+                continue;
+            }
+            if (n_cand != ctx->last_cand) return fail(ctx, C3R_EINVAL, "internal: the raw re-run found %d candidates, the scan %lld", n_cand, (long long)ctx->last_cand);
             return C3R_OK;
         }
         if (need_c <= want_c && need_t <= want_t && !(ctx->h_scan[2] & 1)) {
@@ -1516,9 +1526,19 @@ int64_t c3r_weight_count(int channels) { return net_weight_count(channels); }
 // the weights' norm, so it is used only where it has been MEASURED: both paths run on 2048 pileup-shaped
 // windows drawn from a fixed seed and the probabilities must agree to C3R_MX_GUARD, a 2.5x margin under the 1e-4 tolerance.
 static constexpr double C3R_MX_GUARD = 4e-5;
-static int calibrate_mx(c3r_ctx *ctx, double *err_out) {
-    const int C = ctx->net.channels, n = 2048;
-    std::vector<int32_t> X((size_t)n * C3R_WINDOW * C, 0);
+// The split-f16 path itself (precision 1, the default) is fp32-equivalent only while its operands fit f16 with the layer's scale and the
+// products do not cancel pathologically; nothing in clair3_rna/model.py:126-172 bounds a trained model's weights.  So it is MEASURED too:
+// the same calibration windows through the fp32 MFMA path (precision 0) and through split-f16 must agree to C3R_F16_GUARD, else the context
+// runs the fp32 path and says so (stderr, c3r_get_precision, c3r_get_precision_guard).  The guard is the parity tolerance itself, 1e-4, and
+// not a fraction of it, because of what the two paths were measured to do as the weights' gain grows (profiles/r5/f16_guard_vs_weight_norm.txt:
+// N(0, 0.05) test weights times 1 / 2 / 3 / 4 / 6): they drift apart by 2.9e-6 / 2.3e-5 / 8.4e-5 / 1.4e-4 / 2.7e-4 — and each of them drifts
+// from the fp32 oracle by the SAME 2.4e-6 / 1.8e-5 / 7.9e-5 / 8.8e-5 / 3.3e-4: at high gain the network is ill-conditioned in fp32 itself
+// (summation order, hardware exp2 / rcp), and the fp32 MFMA path is no closer to the oracle than split-f16 is.  A tighter guard would send
+// such weights to a path three times slower for no gain in parity; what the guard is for — an operand that overflows f16, a scale that
+// flushes lo halves, a NaN — shows up as a disagreement of 1e-3 .. 1.
+static constexpr double C3R_F16_GUARD = 1e-4;
+static void calibration_windows(int C, int n, std::vector<int32_t> &X) {
+    X.assign((size_t)n * C3R_WINDOW * C, 0);
     uint64_t st = 0x9E3779B97F4A7C15ull;
     auto rnd = [&](uint32_t m) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)((st >> 11) % m); };
     static const int depths[6] = {6, 12, 20, 40, 90, 216};
@@ -1533,9 +1553,16 @@ static int calibrate_mx(c3r_ctx *ctx, double *err_out) {
             for (int r = (int)rnd(3); r > 0; --r) col[rnd((uint32_t)C)] += 1 + (int)rnd((uint32_t)std::max(1, depth / 3));
         }
     }
+}
+// max |dP| between two precisions on the calibration windows (a NaN on either side counts as 1.0)
+static int calibrate_pair(c3r_ctx *ctx, int mode_a, int mode_b, double *err_out) {
+    const int C = ctx->net.channels, n = 2048;
+    std::vector<int32_t> X;
+    calibration_windows(C, n, X);
     int32_t *d_x = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&d_x, X.size() * 4));
     std::vector<float> p1((size_t)n * C3R_NPROB), p2(p1.size());
+    const int keep = ctx->net.precision;
     auto run = [&](int mode, std::vector<float> &out) -> int {
         ctx->net.precision = mode;
         std::string e;
@@ -1547,9 +1574,10 @@ static int calibrate_mx(c3r_ctx *ctx, double *err_out) {
     };
     int rc = C3R_OK;
     if (hipMemcpyAsync(d_x, X.data(), X.size() * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = C3R_EHIP;
-    if (!rc) rc = run(1, p1);
-    if (!rc) rc = run(2, p2);
+    if (!rc) rc = run(mode_a, p1);
+    if (!rc) rc = run(mode_b, p2);
     (void)hipFree(d_x);
+    ctx->net.precision = keep;
     if (rc) return rc;
     double worst = 0.0;
     for (size_t i = 0; i < p1.size(); ++i) {
@@ -1560,12 +1588,33 @@ static int calibrate_mx(c3r_ctx *ctx, double *err_out) {
     return C3R_OK;
 }
 static int apply_precision(c3r_ctx *ctx) {
-    if (ctx->precision_req != 3) { ctx->net.precision = ctx->precision_req; return C3R_OK; }
-    ctx->net.precision = 1;
-    if (!ctx->net.loaded) return C3R_OK;                                      // decided when the weights arrive
+    const int req = ctx->precision_req;
+    ctx->net.precision = req == 3 ? 1 : req;
+    ctx->f16_fell_back = false;
+    if (!ctx->net.loaded || req == 0) return C3R_OK;                          // decided when the weights arrive
+    const bool rts = ctx->net.wlog2[0] != 12 || ctx->net.wlog2[1] != 12 || ctx->net.wlog2[2] != 12;
+    int rc;
+    // ---- the guard of the split-f16 arithmetic: once per set of weights
+    if (ctx->f16_calib_err < 0.0) {
+        double err = 1.0;
+        if ((rc = calibrate_pair(ctx, 0, 1, &err))) { ctx->net.precision = 0; return rc; }
+        ctx->f16_calib_err = err;
+    }
+    if (ctx->f16_calib_err > C3R_F16_GUARD) {
+        ctx->net.precision = 0; ctx->f16_fell_back = true;
+        fprintf(stderr, "[c3r] warning: with these weights the split-f16 network differs from the fp32 one by %.3g on the calibration windows (guard %.0e): "
+                        "running the fp32 MFMA path (c3r_set_precision 0), about a third of the speed\n", ctx->f16_calib_err, C3R_F16_GUARD);
+        return C3R_OK;
+    }
+    if (req == 1) return C3R_OK;
+    if (rts) {                                                                // (the fp8 fragments are built for the 2^12 scale)
+        if (req == 2) { ctx->net.precision = 1; return fail(ctx, C3R_EINVAL, "precision 2 (f16 + fp8 corrections) needs weights that fit the 2^12 split-f16 scale: max |w| < 8 per layer"); }
+        ctx->net.precision = 1;
+        return C3R_OK;
+    }
+    if (req == 2) return C3R_OK;
     double err = -1.0;
-    const int rc = calibrate_mx(ctx, &err);
-    if (rc) { ctx->net.precision = 1; return rc; }
+    if ((rc = calibrate_pair(ctx, 1, 2, &err))) { ctx->net.precision = 1; return rc; }
     ctx->mx_calib_err = err;
     ctx->net.precision = err <= C3R_MX_GUARD ? 2 : 1;
     return C3R_OK;
@@ -1580,7 +1629,7 @@ int c3r_load_weights(c3r_ctx *ctx, const float *blob, int64_t n_floats, int chan
     std::string e;
     int rc = net_load(ctx->net, blob, channels, ctx->stream, e);
     if (rc) return fail(ctx, rc, "%s", e.c_str());
-    ctx->mx_calib_err = -1.0;
+    ctx->mx_calib_err = -1.0; ctx->f16_calib_err = -1.0;
     return apply_precision(ctx);
 }
 
@@ -1595,6 +1644,14 @@ int c3r_get_precision(c3r_ctx *ctx, int *mode_in_use, double *calibration_err) {
     if (!ctx) return C3R_EINVAL;
     if (mode_in_use) *mode_in_use = ctx->net.precision;
     if (calibration_err) *calibration_err = ctx->mx_calib_err;
+    return C3R_OK;
+}
+
+int c3r_get_precision_guard(c3r_ctx *ctx, double *f16_err, int32_t *scale_log2, int *fell_back) {
+    if (!ctx) return C3R_EINVAL;
+    if (f16_err) *f16_err = ctx->f16_calib_err;
+    if (scale_log2) for (int l = 0; l < 3; ++l) scale_log2[l] = ctx->net.wlog2[l];
+    if (fell_back) *fell_back = ctx->f16_fell_back ? 1 : 0;
     return C3R_OK;
 }
 
@@ -1629,6 +1686,7 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
     }
     if (n == 0) return C3R_OK;
     std::string e;
+    if (ctx->net.d_tmo) HIPCHK(ctx, hipMemsetAsync(ctx->net.d_tmo, 0, 4, ctx->stream));     // (a time-out fails the batch it happened in, not the ones after it)
     // the network's kernels go to the context's default-priority stream, behind everything queued on `stream` so far (the tensors, an
     // uploaded batch); whatever is queued on `stream` afterwards (probabilities, rows, the next batch's tensors) comes behind them
     hipStream_t nst = ctx->net_stream ? ctx->net_stream : ctx->stream;

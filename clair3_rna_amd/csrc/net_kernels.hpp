@@ -335,22 +335,27 @@ __device__ __forceinline__ void lds_arrive(int *c) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63) == 0) atomicAdd(c, 1);
 }
-// A wait that gives up (2^24 polls, over a second, against real waits of microseconds) raises g_lstm_timeout instead of hanging the GPU:
-// the host checks the word whenever it fetches probabilities and fails the call (c3r_infer / c3r_get_probs) rather than hand out
-// numbers computed from a half-written h_t or x_t.
-__device__ int g_lstm_timeout = 0;
-__device__ __forceinline__ void lds_wait(int *c, int target) {
+// A wait that gives up (2^24 polls, over a second, against real waits of microseconds) raises the CONTEXT's time-out word (NetState::d_tmo,
+// a kernel argument) instead of hanging the GPU: the host checks the word whenever it fetches probabilities and fails the call (c3r_infer /
+// c3r_get_probs / c3r_rows_begin) rather than hand out numbers computed from a half-written h_t or x_t.  The word is cleared when the next
+// c3r_infer of that context starts: only the faulty batch fails, and no other context of the process is touched.
+__device__ __forceinline__ void lds_wait(int *c, int target, int *tmo) {
     for (int it = 0; __atomic_load_n(c, __ATOMIC_RELAXED) < target; ++it) {
-        if (it >= (1 << 24)) { if ((threadIdx.x & 63) == 0) atomicOr(&g_lstm_timeout, 1); break; }
+        if (it >= (1 << 24)) { if ((threadIdx.x & 63) == 0 && tmo) atomicOr(tmo, 1); break; }
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int ABL = 0>
+// RTS ("run-time scale"): the weights were packed with a power-of-two scale below 2^12 because some |w| would not fit f16 at 2^12
+// (net_load, NetState::wlog2); the scale (layer 2: wsc = 2^s, wun = 2^-s; fused L4: wun4) then comes in as kernel arguments.  With RTS
+// = false — every set of weights seen so far — the constants fold exactly as before.
+template <int ABL = 0, bool RTS = false>
 __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict__ xin, const half8 *__restrict__ Wp,
                                                       const float *__restrict__ bp, int n, const half8 *__restrict__ W4p,
-                                                      float *__restrict__ a4part, int nstride) {
+                                                      float *__restrict__ a4part, int nstride, float wsc_arg = WSCALE, float wun_arg = WUNSCALE, float wun4_arg = WUNSCALE,
+                                                      int *tmo = nullptr /* the context's time-out word (lds_wait) */) {
+    const float wsc = RTS ? wsc_arg : WSCALE, wun = RTS ? wun_arg : WUNSCALE, wun4 = RTS ? wun4_arg : WUNSCALE;
     constexpr int INP = 2 * NET_H1, H = NET_H2, NGX = INP / 16, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NBLK = 4 * H / 32, NTQ = NBLK / 4;
     constexpr int SB = 2, WG_SITES = 32 * SB, KC = INP / 8, PD = C3R_W8_PD;
     static_assert(NTQ == 5 && NG == 26, "3 + 2 tile split of a quarter, 26 k-groups");
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
         unsigned bias_hl[NT];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            const float bv = WSCALE * bp[((size_t)dir * NBLK + sq * NTQ + TOFF + tt) * 32 + j];
+            const float bv = wsc * bp[((size_t)dir * NBLK + sq * NTQ + TOFF + tt) * 32 + j];
             half2v hl;
             hl[0] = (_Float16)bv;
             hl[1] = (_Float16)(bv - (float)hl[0]);
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
                 }
             };
 
-            if (C3R_W8_ASYNC && step > 0) lds_wait(&s_ctr[1], 4 * step);      // x_t has landed (four DMA wavefronts per step)
+            if (C3R_W8_ASYNC && step > 0) lds_wait(&s_ctr[1], 4 * step, tmo);      // x_t has landed (four DMA wavefronts per step)
             floatx16 acc[NT][SB];
             {
                 floatx16 z;
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 #define C3R_STEP(G)                                                                                              \
     if constexpr ((G) < NG) {                                                                                     \
         C3R_FENCE();                                                                                              \
-        if constexpr (C3R_W8_ASYNC && (G) + PD == NGX) { lds_wait(&s_ctr[2], 8 * step); C3R_FENCE(); }   /* h_{t-1} is complete */ \
+        if constexpr (C3R_W8_ASYNC && (G) + PD == NGX) { lds_wait(&s_ctr[2], 8 * step, tmo); C3R_FENCE(); }   /* h_{t-1} is complete */ \
         if constexpr ((G) + PD < NG) { C3R_LOAD((G) + PD); }                                                      \
         mma(ah[(G) % (PD + 1)], al[(G) % (PD + 1)], bh[(G) % (PD + 1)], bl[(G) % (PD + 1)], (G) >= NGX, ((G) & 1) != 0);  \
         if constexpr ((G) + PD < NG) {                                                                            \
@@ -550,14 +555,14 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
             // x_{t+1} by LDS-DMA now, so that no weight load queues behind it (vmcnt retires in order): it lands during the
             // cell update
             if constexpr (C3R_W8_ASYNC) {
-                if (!L4T && step + 1 < NET_T) { lds_wait(&s_ctr[0], 8 * (step + 1)); dma_x16(dir ? NET_T - 2 - step : step + 1); }      // (everyone is done with x_t)
+                if (!L4T && step + 1 < NET_T) { lds_wait(&s_ctr[0], 8 * (step + 1), tmo); dma_x16(dir ? NET_T - 2 - step : step + 1); }      // (everyone is done with x_t)
             } else if (step + 1 < NET_T && !(ABL & 64)) dma_x(dir ? NET_T - 2 - step : step + 1);
             // ---- lane-local cell update, one tile at a time; cell state in registers
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 __builtin_amdgcn_sched_barrier(0);
                 constexpr int NU = 4 * SB;
-                constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
+                const float K1 = -1.4426950408889634f * wun, K2 = -2.8853900817779268f * wun;
                 float cq[NU], ei[NU], ef[NU], eg[NU], eo[NU], hval[NU];
 #pragma unroll
                 for (int u = 0; u < NU; ++u) cq[u] = cst[tt][u >> 2][u & 3];
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
             }
         }
         if constexpr (L4T) {
-            if constexpr (C3R_W8_ASYNC) lds_wait(&s_ctr[2], 8 * NET_T);
+            if constexpr (C3R_W8_ASYNC) lds_wait(&s_ctr[2], 8 * NET_T, tmo);
             // ---- the last step's h (buffer NET_T & 1) still owes its L4 contribution
             const int tl = dir ? 0 : NET_T - 1, hbuf = NET_T & 1;
             const half8 *w4 = W4p + (((size_t)(dir * NET_T + tl) * 4 + sq) * NGH) * 2 * 64 + lane;
@@ -636,8 +641,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
                 if (sidx < n) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float4 v = make_float4(facc[sb][4 * q] * WUNSCALE, facc[sb][4 * q + 1] * WUNSCALE, facc[sb][4 * q + 2] * WUNSCALE,
-                                               facc[sb][4 * q + 3] * WUNSCALE);
+                        float4 v = make_float4(facc[sb][4 * q] * wun4, facc[sb][4 * q + 1] * wun4, facc[sb][4 * q + 2] * wun4,
+                                               facc[sb][4 * q + 3] * wun4);
                         *(float4 *)(a4part + ((size_t)sidx * 2 + dir) * NET_L4 + 32 * sq + 8 * q + 4 * hh) = v;
                     }
                 }
@@ -670,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict__ xin, const half8 *__restrict__ Wp, const uint32_t *__restrict__ Wq,
                                                       const uint32_t *__restrict__ Wsc, const float *__restrict__ bp, int n,
                                                       const half8 *__restrict__ W4p, const uint32_t *__restrict__ W4q,
-                                                      const uint32_t *__restrict__ W4sc, float *__restrict__ a4part, int nstride) {
+                                                      const uint32_t *__restrict__ W4sc, float *__restrict__ a4part, int nstride, int *tmo = nullptr) {
     constexpr int INP = 2 * NET_H1, H = NET_H2, NGX = INP / 16, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NBLK = 4 * H / 32, NTQ = NBLK / 4;
     #ifndef C3R_MX_PD
 #define C3R_MX_PD 1
@@ -776,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             const int tprev = step ? (dir ? t + 1 : t - 1) : t;
             const int cur = step & 1, nxt = cur ^ 1;
 
-            if (C3R_W8_ASYNC && step > 0) lds_wait(&s_ctr[1], 4 * step);      // x_t has landed
+            if (C3R_W8_ASYNC && step > 0) lds_wait(&s_ctr[1], 4 * step, tmo);      // x_t has landed
             half8 ah[PD + 1][NTH], bh[PD + 1][SB];
             intx8 a8[NTH], b8[SB];
             int sc[NTH];
@@ -883,7 +888,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 #define C3R_STEP(G)                                                                                              \
     if constexpr ((G) < NG) {                                                                                     \
         C3R_FENCE();                                                                                              \
-        if constexpr (C3R_W8_ASYNC && (G) + PD == NGX) { lds_wait(&s_ctr[2], 8 * step); C3R_FENCE(); }   /* h_{t-1} is complete */ \
+        if constexpr (C3R_W8_ASYNC && (G) + PD == NGX) { lds_wait(&s_ctr[2], 8 * step, tmo); C3R_FENCE(); }   /* h_{t-1} is complete */ \
         if constexpr (PD == 0 || (G) + PD < NG) { load(std::integral_constant<int, (G) + PD>{}, ah[((G) + PD) % (PD + 1)], bh[((G) + PD) % (PD + 1)]); } \
         mma(std::integral_constant<int, (G)>{}, ah[(G) % (PD + 1)], bh[(G) % (PD + 1)]);                          \
         if constexpr (PD > 0 && (G) + PD < NG && (((G) & 1) || !C3R_MX_EVEN_BURST)) {                              \
@@ -904,7 +909,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 #undef C3R_STEP
 #undef C3R_FENCE
             if constexpr (C3R_W8_ASYNC) {
-                if (!L4T && step + 1 < NET_T) { lds_wait(&s_ctr[0], 8 * (step + 1)); dma_x16(dir ? NET_T - 2 - step : step + 1); }
+                if (!L4T && step + 1 < NET_T) { lds_wait(&s_ctr[0], 8 * (step + 1), tmo); dma_x16(dir ? NET_T - 2 - step : step + 1); }
             } else if (step + 1 < NET_T) dma_x(dir ? NET_T - 2 - step : step + 1);      // lands during the cell update
             // ---- lane-local cell update (k_lstm2_w8's), h_t to LDS as f16 plus the two fp8 bytes per unit
 #pragma unroll
@@ -969,7 +974,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
             }
         }
         if constexpr (L4T) {
-            if constexpr (C3R_W8_ASYNC) lds_wait(&s_ctr[2], 8 * NET_T);
+            if constexpr (C3R_W8_ASYNC) lds_wait(&s_ctr[2], 8 * NET_T, tmo);
             // ---- the last step's h (buffer NET_T & 1) still owes its L4 contribution
             const int tl = dir ? 0 : NET_T - 1, hbuf = NET_T & 1;
             const half8 *w4 = W4p + (((size_t)(dir * NET_T + tl) * 4 + sq) * NGH) * 2 * 64 + lane;
@@ -1022,9 +1027,11 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 // was "load, wait an L2 round trip, use": 13-16 k of a step's 21.7 k clocks.  The price: the workgroup's two 32-site blocks go through one
 // accumulator one after the other (no registers for two), and every B fragment is read from LDS by sixteen wavefronts.
 // Wp: [dir][quarter][g][tile(4)][hi|lo][lane] (tile blk = 4 quarter + tile); the bias rides on input slot CIN (x = 1 there).
-template <int CIN, bool YQ = false>
+template <int CIN, bool YQ = false, bool RTS = false>
 __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp, _Float16 *__restrict__ y, int n, int nstride,
-                                                   const int32_t *__restrict__ row_idx /* row of site i in xin (the tensor build writes windows as they arrive); null: i */) {
+                                                   const int32_t *__restrict__ row_idx /* row of site i in xin (the tensor build writes windows as they arrive); null: i */,
+                                                   float wun_arg = WUNSCALE /* RTS: 2^-s of the layer's weight scale (k_lstm2_w8) */) {
+    const float wun = RTS ? wun_arg : WUNSCALE;
     constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NTQ = 4, WG_SITES = 64, HV = H / 8, XP = 40;
     constexpr int NPC = (CIN + 1) / 2;
     static_assert(CIN % 2 == 0 && CIN < 32 && WG_SITES * NPC <= 1024, "even channel count, one free slot for the bias, one x piece per thread");
@@ -1122,7 +1129,7 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
                 }
             });
             // ---- lane-local cell update of the block (four units per lane)
-            constexpr float K1 = -1.4426950408889634f * WUNSCALE, K2 = -2.8853900817779268f * WUNSCALE;
+            const float K1 = -1.4426950408889634f * wun, K2 = -2.8853900817779268f * wun;
             float ei[4], ef[4], eg[4], eo[4], cq[4], hval[4];
             {
                 const float4 c4 = s_c[blk][sb][lane];
@@ -1327,8 +1334,12 @@ struct NetState {
     // precision 2 (MX corrections): fp8 (e4m3) fragments of w (lanes 0-31) and w - f16(w) (lanes 32-63) per block of 32 k, 32 bytes per
     // lane, and their E8M0 block scales, four blocks per dword: layer 1 (recurrent part only), layer 2, fused L4
     uint32_t *d_w1q = nullptr, *d_w1s = nullptr, *d_w2q = nullptr, *d_w2s = nullptr, *d_w4q = nullptr, *d_w4s = nullptr;
+    // log2 of the power-of-two scale the split-f16 weights of layer 1 / layer 2 / L4 were packed with: 12 unless some |w| (or a bias that
+    // travels with the weights) would overflow f16 at 2^12 (net_load); below 12 the run-time-scale variants of the kernels run
+    int wlog2[3] = {12, 12, 12};
     int precision = 1;            // 0 = fp32 MFMA, 1 = split-f16 (f16x3, fp32-equivalent), 2 = f16 main term + both corrections on the MX fp8 pipe
     float *d_y1 = nullptr, *d_y2 = nullptr, *d_a4 = nullptr, *d_probs = nullptr;
+    int32_t *d_tmo = nullptr;        // the context's time-out word of the layer-2 rendezvous (lds_wait); allocated with the weights
     int64_t cap_probs = 0;           // sites d_probs holds (the whole batch); cap_sites bounds one network slice
     int64_t cap_sites = 0;
 };
@@ -1395,7 +1406,7 @@ inline size_t big_trim() {
 
 inline void net_free(NetState &s) {
     void *ptrs[] = {s.d_w1, s.d_b1, s.d_w2, s.d_b2, s.d_w4, s.d_b4, s.d_w5, s.d_b5, s.d_wo, s.d_bo, s.d_y2, s.d_a4, s.d_probs,
-                    s.d_w1h, s.d_w2h, s.d_w4h, s.d_w4f, s.d_w5p, s.d_wcp, s.d_w1q, s.d_w1s, s.d_w2q, s.d_w2s, s.d_w4q, s.d_w4s};
+                    s.d_w1h, s.d_w2h, s.d_w4h, s.d_w4f, s.d_w5p, s.d_wcp, s.d_w1q, s.d_w1s, s.d_w2q, s.d_w2s, s.d_w4q, s.d_w4s, s.d_tmo};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     big_give(s.d_y1, (size_t)s.cap_sites * NET_T * 2 * NET_H1 * sizeof(float));
     s = NetState();
@@ -1437,7 +1448,7 @@ inline void split_h(float v, uint16_t &hi, uint16_t &lo) { hi = f2h(v); lo = f2h
 
 // Split-f16 packing of one LSTM direction: [wave][g16][tile][hi|lo][lane][8 halves], weights x 2^12.
 // bias_slot != nullptr (layer 1): the bias rides on the first padded input slot (k = cin).
-inline void pack_lstm_dir_h(const float *Kin, int cin, int inp, const float *R, int H, std::vector<uint16_t> &wp, const float *bias_slot = nullptr) {
+inline void pack_lstm_dir_h(const float *Kin, int cin, int inp, const float *R, int H, std::vector<uint16_t> &wp, const float *bias_slot = nullptr, float wscale = WSCALE) {
     const int K = inp + H, NG = K / 16, NBLK = 4 * H / 32, NT = NBLK / 4;
     wp.assign((size_t)NBLK * NG * 2 * 64 * 8, 0);
     auto wcat = [&](int k, int col) -> float {
@@ -1452,7 +1463,7 @@ inline void pack_lstm_dir_h(const float *Kin, int cin, int inp, const float *R, 
                 for (int kh = 0; kh < 2; ++kh)
                     for (int e = 0; e < 8; ++e) {
                         uint16_t hi, lo;
-                        split_h(WSCALE * wcat(16 * g + 8 * kh + e, col), hi, lo);
+                        split_h(wscale * wcat(16 * g + 8 * kh + e, col), hi, lo);
                         const int lane = kh * 32 + r;
                         const size_t base = ((((size_t)(blk / NT) * NG + g) * NT + (blk % NT)) * 2) * 64;
                         wp[((base + 0 * 64 + lane) * 8) + e] = hi;
@@ -1579,13 +1590,30 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
     std::vector<uint32_t> w1q, w1s, w2q, w2s, tq, ts;
     // gate row r of tile blk <-> Keras column (pack_lstm_dir_h): r = 8 q + 4 hh + m -> unit 8 blk + 4 hh + q, gate m
     auto gate_col = [](int blk, int r, int H) { const int qq = r >> 3, hh = (r >> 2) & 1, m = r & 3; return m * H + 8 * blk + 4 * hh + qq; };
+    // ---- the split-f16 scale of each layer.  2^12 keeps the lo halves of ordinary weights normal f16 numbers, but f16 ends at 65504: a
+    // weight (or a bias: layer 1's rides on an input slot, layer 2's is multiplied by the same scale) of 16 or more would become inf and
+    // the probabilities NaN.  So the scale is the largest power of two <= 2^12 that keeps 2^s max|w| <= 2^15 (a factor two of headroom);
+    // nothing in clair3_rna/model.py:126-172 bounds the weights.  Non-finite values are refused.
+    {
+        const int64_t nw = net_weight_count(C);
+        for (int64_t i = 0; i < nw; ++i) if (!std::isfinite(blob[i])) { err = "weight blob holds a non-finite value (index " + std::to_string(i) + ")"; return C3R_EINVAL; }
+        auto amax = [](const float *p, size_t n) { float m = 0.f; for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(p[i])); return m; };
+        const size_t n1 = (size_t)C * 4 * NET_H1 + (size_t)NET_H1 * 4 * NET_H1 + 4 * NET_H1, n2 = (size_t)2 * NET_H1 * 4 * NET_H2 + (size_t)NET_H2 * 4 * NET_H2 + 4 * NET_H2;
+        const float m[3] = {amax(blob, 2 * n1), amax(blob + 2 * n1, 2 * n2), amax(blob + 2 * n1 + 2 * n2, (size_t)NET_FLAT * NET_L4)};
+        for (int l = 0; l < 3; ++l) {
+            int sl = 12;
+            while (sl > -24 && std::ldexp(m[l], sl) > 32768.f) --sl;
+            s.wlog2[l] = sl;
+        }
+    }
+    const float wsc1 = std::ldexp(1.f, s.wlog2[0]), wsc2 = std::ldexp(1.f, s.wlog2[1]), wsc4 = std::ldexp(1.f, s.wlog2[2]);
     for (int d = 0; d < 2; ++d) {
         const float *Kin = q; q += (size_t)C * 4 * NET_H1;
         const float *R = q; q += (size_t)NET_H1 * 4 * NET_H1;
         const float *b = q; q += 4 * NET_H1;
         pack_lstm_dir(Kin, C, inp1, R, b, NET_H1, tw, tb);
         w1.insert(w1.end(), tw.begin(), tw.end()); b1.insert(b1.end(), tb.begin(), tb.end());
-        pack_lstm_dir_h(Kin, C, inp1, R, NET_H1, th, b);
+        pack_lstm_dir_h(Kin, C, inp1, R, NET_H1, th, b, wsc1);
         w1h.insert(w1h.end(), th.begin(), th.end());
         // (layer 1: the recurrent part only — the integer pileup counts are exact in f16 but not in fp8)
         pack_mx([&](int k, int blk, int r) { return R[(size_t)k * 4 * NET_H1 + gate_col(blk, r, NET_H1)]; }, 4 * NET_H1 / 32, NET_H1 / 32, 0, NET_H1 / 32, tq, ts);
@@ -1597,7 +1625,7 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
         const float *b = q; q += 4 * NET_H2;
         pack_lstm_dir(Kin, 2 * NET_H1, 2 * NET_H1, R, b, NET_H2, tw, tb);
         w2.insert(w2.end(), tw.begin(), tw.end()); b2.insert(b2.end(), tb.begin(), tb.end());
-        pack_lstm_dir_h(Kin, 2 * NET_H1, 2 * NET_H1, R, NET_H2, th);
+        pack_lstm_dir_h(Kin, 2 * NET_H1, 2 * NET_H1, R, NET_H2, th, nullptr, wsc2);
         w2h.insert(w2h.end(), th.begin(), th.end());
         pack_mx([&](int k, int blk, int r) {
                     const int col = gate_col(blk, r, NET_H2);
@@ -1630,7 +1658,7 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
                 for (int e = 0; e < 8; ++e) {
                     const int r = lane & 31, kh = lane >> 5;
                     uint16_t hi, lo;
-                    split_h(WSCALE * W4[(size_t)(16 * g + 8 * kh + e) * NET_L4 + 32 * blk + r], hi, lo);
+                    split_h(wsc4 * W4[(size_t)(16 * g + 8 * kh + e) * NET_L4 + 32 * blk + r], hi, lo);
                     const size_t base = (((size_t)blk * NG4h + g) * 2) * 64;
                     w4h[(base + lane) * 8 + e] = hi;
                     w4h[(base + 64 + lane) * 8 + e] = lo;
@@ -1647,7 +1675,7 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
                             const int r = lane & 31, kh = lane >> 5;
                             const size_t row = (size_t)t * 2 * NET_H2 + (size_t)d * NET_H2 + 16 * g + 8 * kh + e;
                             uint16_t hi, lo;
-                            split_h(WSCALE * W4[row * NET_L4 + 32 * blk + r], hi, lo);
+                            split_h(wsc4 * W4[row * NET_L4 + 32 * blk + r], hi, lo);
                             const size_t base = ((((size_t)(d * NET_T + t) * 4 + blk) * NGF + g) * 2) * 64;
                             w4f[(base + lane) * 8 + e] = hi;
                             w4f[(base + 64 + lane) * 8 + e] = lo;
@@ -1698,6 +1726,10 @@ inline int net_load(NetState &s, const float *blob, int C, hipStream_t st, std::
         (rc = net_upload_u(s.d_w1q, w1q, st, err)) || (rc = net_upload_u(s.d_w1s, w1s, st, err)) || (rc = net_upload_u(s.d_w2q, w2q, st, err)) ||
         (rc = net_upload_u(s.d_w2s, w2s, st, err)) || (rc = net_upload_u(s.d_w4q, w4q, st, err)) || (rc = net_upload_u(s.d_w4s, w4s, st, err)))
         return rc;
+    if (!s.d_tmo) {
+        if (hipMalloc((void **)&s.d_tmo, 64) != hipSuccess) { err = "hipMalloc(64) failed"; return C3R_ENOMEM; }
+        if (hipMemsetAsync(s.d_tmo, 0, 64, st) != hipSuccess) { err = "hipMemsetAsync failed"; return C3R_EHIP; }
+    }
     s.channels = C; s.inp1 = inp1; s.loaded = true;
     return C3R_OK;
 }
@@ -1772,22 +1804,31 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, const int32_t *row
         const int ns = (int)((n + 127) / 128 * 128);
         const dim3 g2(2, grid.x);
         const bool mx = s.precision == 2;
+        const bool rts = s.wlog2[0] != 12 || s.wlog2[1] != 12 || s.wlog2[2] != 12;      // (never with precision 2: c3r_lib refuses that pairing)
+        if (mx && rts) { err = "the fp8-corrected path (precision 2) needs weights that fit the 2^12 split-f16 scale"; return C3R_EINVAL; }
+        const float wun1 = std::ldexp(1.f, -s.wlog2[0]), wsc2 = std::ldexp(1.f, s.wlog2[1]), wun2 = std::ldexp(1.f, -s.wlog2[1]), wun4 = std::ldexp(1.f, -s.wlog2[2]);
         prof("k_lstm1", 0);
-        if (s.channels == C3R_CH) {
-            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx);
-            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx);
+        if (rts) {
+            if (s.channels == C3R_CH) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, false, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, wun1);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, false, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, wun1);
+        } else if (s.channels == C3R_CH) {
+            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE);
         } else {
-            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx);
-            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx);
+            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE);
         }
         prof("k_lstm1", 1);
         prof("k_lstm2", 0);
-        if (mx)
+        if (rts)
+            hipLaunchKernelGGL((k_lstm2_w8<0, true>), g2, dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const float *)s.d_b2, (int)n,
+                               (const half8 *)s.d_w4f, s.d_a4, ns, wsc2, wun2, wun4, s.d_tmo);
+        else if (mx)
             hipLaunchKernelGGL(k_lstm2_mx, g2, dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const uint32_t *)s.d_w2q, (const uint32_t *)s.d_w2s,
-                               (const float *)s.d_b2, (int)n, (const half8 *)s.d_w4f, (const uint32_t *)s.d_w4q, (const uint32_t *)s.d_w4s, s.d_a4, ns);
+                               (const float *)s.d_b2, (int)n, (const half8 *)s.d_w4f, (const uint32_t *)s.d_w4q, (const uint32_t *)s.d_w4s, s.d_a4, ns, s.d_tmo);
         else
-            hipLaunchKernelGGL((k_lstm2_w8<0>), g2, dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const float *)s.d_b2, (int)n,
-                               (const half8 *)s.d_w4f, s.d_a4, ns);
+            hipLaunchKernelGGL((k_lstm2_w8<0, false>), g2, dim3(512), 0, st, (const _Float16 *)y1h, (const half8 *)s.d_w2h, (const float *)s.d_b2, (int)n,
+                               (const half8 *)s.d_w4f, s.d_a4, ns, WSCALE, WUNSCALE, WUNSCALE, s.d_tmo);
         prof("k_lstm2", 1);
         heads_parts = 2;
     } else {

@@ -28,7 +28,7 @@ namespace c3r {
 struct LoadStats {
     unsigned long long err;   // ~0: none; else (read index << 8) | code — the smallest failing read wins
     int32_t max_end;          // largest reference end of any read (exclusive, 0-based)
-    int32_t max_cover;        // upper bound of the number of reads over one position (reads overlapping one 32-bp bin)
+    int32_t max_cover;        // upper bound of htslib's read list at any read's start: the most reads that overlap one 256-bp coarse bin or end on its edge
     int32_t n_rec;            // records of the pile table
     int32_t n_indel;          // I + D ops of the passing reads (bounds the indel-event scratch of a scan)
     int32_t n_padreads;       // mpileup_compat = 1: reads with a pad inside a run of I ops (the host then builds the c3r_padins_t table)
@@ -398,9 +398,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
                 a.serial[i] = plain ? 0 : (pads && !err) ? 3 : 1;                       // (3: serial walk, and its I records carry PR_INS_PADS)
                 if (pads && !err) __hip_atomic_fetch_add(&a.st->n_padreads, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(&a.sc[bin_of(a.geo, d.pos) >> CBIN_SHIFT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // counted as "ended at or before the start of coarse bin c" for every c > (ceil(end / 32) - base - 1) >> 3: k_bin_scan's exclusive
-                // sum over ec[j], j < c (later than true is safe: the sums bound the coverage from above)
-                int je = ((d.end + (1 << BIN_SHIFT) - 1) >> BIN_SHIFT) - a.geo.base - 1;
+                // ec: the coarse bin that holds the read's EXCLUSIVE end.  k_bin_scan's exclusive sum over ec[j], j < c, then counts the reads whose
+                // end position lies before coarse bin c, and  B(c) = reads started up to the end of c - that sum  bounds htslib's read list for every
+                // read that starts in c (the kept reads with end > start - 1: a read whose last base sits on start - 1 still has its end inside c,
+                // also when start is the bin's first position) — what decides whether mpileup's depth cap can bite at all (LoadStats::max_cover)
+                int je = (d.end >> BIN_SHIFT) - a.geo.base;
                 je = je < 0 ? 0 : je >= a.geo.nb ? a.geo.nb - 1 : je;
                 __hip_atomic_fetch_add(&a.ec[je >> CBIN_SHIFT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 a.nind[i] = pass ? n_indel : 0;

@@ -40,7 +40,8 @@ def contig_costs(bam_fn, contigs, lengths):
         except Exception:
             weights = {}
     for k, basis in ((0, "mapped reads (BAM index)"), (1, "compressed bytes (BAM index)")):
-        vals = [weights.get(c, (-1, -1))[k] for c in contigs]
+        # (a contig of the calling list that the BAM header does not have holds no read: 0, not "unknown")
+        vals = [weights.get(c, (0, 0))[k] for c in contigs] if weights else []
         if vals and all(v >= 0 for v in vals) and sum(vals) > 0:
             # (a contig without reads still costs its fetch and an empty scan: a small floor keeps them from piling up on one rank)
             floor = max(1, sum(vals) // (200 * len(vals)))

@@ -148,8 +148,15 @@ int64_t c3r_weight_count(int channels);
  * 3 = auto: mode 2 if it agrees with mode 1 to 4e-5 on 2048 calibration windows run through the loaded weights (measured at
  * c3r_load_weights / here), else mode 1.  Modes 2 and 3 need 18- or 30-channel weights like the others. */
 int c3r_set_precision(c3r_ctx *ctx, int mode);
-/* The mode the network runs in (after "auto" has decided) and the calibration's max |dP| (-1: not measured). */
+/* The mode the network runs in (after "auto" and the split-f16 guard have decided) and the fp8 calibration's max |dP| (-1: not measured). */
 int c3r_get_precision(c3r_ctx *ctx, int *mode_in_use, double *calibration_err);
+/* The guard of the split-f16 arithmetic itself.  Nothing in clair3_rna/model.py:126-172 bounds a trained model's weights, and f16 ends at
+ * 65504: c3r_load_weights refuses non-finite values, packs every layer (LSTM 1, LSTM 2, L4) with the largest power-of-two scale <= 2^12
+ * that keeps 2^s max|w| <= 2^15 (scale_log2[3]; 12 12 12 for ordinary weights), and runs 2048 pileup-shaped calibration windows through the
+ * fp32 MFMA path and the split-f16 path: f16_err = max |dP| between them.  Above 1e-4 (the parity tolerance: the two paths drift apart with
+ * the weights' gain exactly as each drifts from an fp32 CPU evaluation) a request for mode 1, 2 or 3 is served by mode 0
+ * (fp32 MFMA, about a third of the speed), *fell_back = 1, and a warning goes to stderr.  Any pointer may be NULL. */
+int c3r_get_precision_guard(c3r_ctx *ctx, double *f16_err, int32_t *scale_log2, int *fell_back);
 /* Optional: size the network's device buffers for batches of up to n_sites candidates now (after c3r_load_weights) instead of
  * inside the first c3r_infer.  The layer-1 output of a full 2^18-site slice is 8.9 GB, and a first hipMalloc of that size takes
  * 0.25-0.4 s: a caller that is still waiting for its input (a BAM fetch) spends them here for free. */

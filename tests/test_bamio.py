@@ -475,7 +475,7 @@ def test_index_metadata_pseudo_bin_gives_the_contigs_work(bam_case, tmp_path):
     n20, n21 = len(bam_case["rs"]), len(bam_case["rs2"])
     with bamio.BamFile(p) as bf:
         w = bf.contig_weights()
-    assert w["chr20"][0] == n20 and w["chr21"][0] == n21 and w["chrEmpty"][0] == -1
+    assert w["chr20"][0] == n20 and w["chr21"][0] == n21 and w["chrEmpty"] == (0, 0)      # (no bin at all: a contig without reads, not "unknown")
     assert w["chr20"][1] > w["chr21"][1] > 0                                        # compressed bytes follow the read counts here
     # independent parse of the pseudo-bin: two 16-byte "chunks" — (first, last virtual offset), (mapped, unmapped)
     raw = open(p + ".bai", "rb").read()
@@ -490,8 +490,9 @@ def test_index_metadata_pseudo_bin_gives_the_contigs_work(bam_case, tmp_path):
     assert meta is not None and meta[2] == n20 and meta[3] == 0 and meta[1] > meta[0]
     costs, basis = shard.contig_costs(p, ["chr20", "chr21"], {"chr20": 600000, "chr21": 150000})
     assert basis.startswith("mapped reads") and costs == [n20, n21]
-    costs, basis = shard.contig_costs(p, ["chr20", "chr21", "chrEmpty"], {"chr20": 600000, "chr21": 150000, "chrEmpty": 5000})
-    assert basis.startswith("compressed bytes") and costs[0] > costs[1] >= costs[2] >= 1     # (one contig has no pseudo-bin: ONE basis for all)
+    # a read-less contig (samtools index writes no pseudo-bin for it) and one the BAM header does not even have: the deal stays on read counts
+    costs, basis = shard.contig_costs(p, ["chr20", "chr21", "chrEmpty", "chrNotInBam"], {"chr20": 600000, "chr21": 150000, "chrEmpty": 5000, "chrNotInBam": 9000})
+    assert basis.startswith("mapped reads") and costs[:2] == [n20, n21] and costs[2] == costs[3] >= 1 and costs[2] < n21
     # the same index with the pseudo-bins cut out (an index from a tool that writes none)
     out = bytearray(raw[:8])
     o = 8

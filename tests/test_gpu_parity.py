@@ -244,6 +244,81 @@ def test_precision_f16_f8_opt_in_and_auto_guard(eng):
         eng.set_precision("f16x3")
 
 
+def _blob_offsets(C):
+    """start of (LSTM1 dir0 K, R, b | dir1 ... | LSTM2 ... | L4 W, b | heads) in the weight blob (include/c3r.h, c3r_load_weights)."""
+    H1, H2 = 128, 160
+    n1 = C * 4 * H1 + H1 * 4 * H1 + 4 * H1
+    n2 = 2 * H1 * 4 * H2 + H2 * 4 * H2 + 4 * H2
+    return dict(l1=0, l1_bias0=C * 4 * H1 + H1 * 4 * H1, l2=2 * n1, l2_bias0=2 * n1 + 2 * H1 * 4 * H2 + H2 * 4 * H2, l4=2 * n1 + 2 * n2, l4_bias=2 * n1 + 2 * n2 + 33 * 320 * 128)
+
+
+def test_split_f16_guard_against_weights_f16_cannot_hold(eng):
+    """Nothing in clair3_rna/model.py:126-172 bounds the weights, and the split-f16 operands are f16 numbers (65504 at most) times a scale:
+    c3r_load_weights picks a per-layer power-of-two scale from max |w| (2^12 for ordinary weights), refuses non-finite values, measures
+    split-f16 against the fp32 MFMA path on calibration windows and falls back to fp32 above 1e-4.  With single huge weights whatever runs
+    must meet the 1e-4 bar against the fp32 oracle; with heavy-tailed weights at ten times the norm the network is ill-conditioned in fp32
+    itself (the fp32 MFMA path is as far from the oracle as split-f16): there the guard's own promise is checked — what runs agrees with the
+    fp32 MFMA path to the tolerance, or IS the fp32 path."""
+    from clair3_rna_amd import capi, synth
+    from oracle import oracle as orc
+    rng = np.random.RandomState(21)
+    C = 18
+    o = _blob_offsets(C)
+    X = np.concatenate([_pileup_like(200, C, 31), rng.randint(-40, 41, size=(40, 33, C)).astype(np.int32)])
+    base = synth.random_weights(C, seed=1234)
+    try:
+        eng.set_precision("f16x3")
+        eng.load_weights(base, C)
+        g = eng.precision_guard()
+        assert g["scale_log2"] == [12, 12, 12] and 0 <= g["f16_err"] < 1e-5 and not g["fell_back"] and eng.precision()[0] == "f16x3", g
+        cases = {}
+        w = base.copy(); w[o["l1"] + 5] = 20.0; w[o["l1"] + 777] = -17.5                   # layer-1 kernel weights of 20: 2^12 x 20 is beyond f16
+        cases["l1 |w| = 20"] = (w, [10, 12, 12])
+        w = base.copy(); w[o["l2_bias0"] + 3] = 30.0; w[o["l2"] + 11] = 9.0                 # a layer-2 bias of 30
+        cases["l2 bias = 30"] = (w, [12, 10, 12])
+        w = base.copy(); w[o["l1_bias0"] + 130] = -30.0; w[o["l4"] + 99] = 100.0            # a layer-1 bias (rides on an input slot) and an L4 weight of 100
+        cases["l1 bias = -30, L4 |w| = 100"] = (w, [10, 12, 8])
+        t = rng.standard_t(3, size=base.size).astype(np.float32)                            # heavy-tailed weights at ten times the usual norm
+        w = base.copy(); n_lstm = o["l4_bias"]
+        w[:n_lstm] = (t[:n_lstm] * 0.3).astype(np.float32)
+        cases["Student-t x10"] = (w, None)
+        for name, (w, want_scale) in cases.items():
+            eng.load_weights(w, C)
+            g, (mode, _cal) = eng.precision_guard(), eng.precision()
+            if want_scale is not None:
+                assert g["scale_log2"] == want_scale, (name, g)
+            assert all(s_ <= 12 for s_ in g["scale_log2"]) and (mode == "f32") == g["fell_back"] and (g["fell_back"] == (g["f16_err"] > 1e-4)), (name, g, mode)
+            p = eng.infer(tensors=X)
+            err = float(np.abs(p - orc.forward(w, X)).max())
+            eng.set_precision("f32")
+            p32 = eng.infer(tensors=X)
+            eng.set_precision("f16x3")
+            d32, e32 = float(np.abs(p - p32).max()), float(np.abs(p32 - orc.forward(w, X)).max())
+            assert np.isfinite(p).all() and np.isfinite(p32).all(), name
+            if want_scale is not None:
+                assert err < 1e-4, (name, err, g, mode)
+            else:
+                assert g["fell_back"] or d32 < 2e-4, (name, d32, g)
+            print("%-28s scales %s  f16x3 vs f32 on the calibration windows %.2e  -> runs %s; max |dP| vs oracle %.2e (fp32 MFMA path: %.2e), vs fp32 MFMA %.2e" %
+                  (name, g["scale_log2"], g["f16_err"], mode, err, e32, d32))
+            # "auto" and the fp8-corrected path never run on a scale other than 2^12
+            eng.set_precision("auto")
+            assert eng.precision()[0] in (("f16x3", "f16+f8") if g["scale_log2"] == [12, 12, 12] and not g["fell_back"] else ("f16x3", "f32"))
+            if g["scale_log2"] != [12, 12, 12] and not g["fell_back"]:
+                with pytest.raises(capi.C3RError, match="precision 2"):
+                    eng.set_precision("f16+f8")
+            eng.set_precision("f16x3")
+        bad = base.copy(); bad[o["l2"] + 5] = np.nan
+        with pytest.raises(capi.C3RError, match="non-finite"):
+            eng.load_weights(bad, C)
+        bad[o["l2"] + 5] = np.inf
+        with pytest.raises(capi.C3RError, match="non-finite"):
+            eng.load_weights(bad, C)
+    finally:
+        eng.set_precision("f16x3")
+        eng.load_weights(base, C)
+
+
 def test_network_30ch_and_ragged_batch(eng):
     from clair3_rna_amd import synth
     from oracle import oracle as orc

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/busy
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 12 --warmup 3 --no_cpu_baseline --no_profile --no_fast > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 12 --warmup 3 --no_cpu_baseline --no_profile --no_fast --no_strong --no_extra > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv,glob
 rows=[]

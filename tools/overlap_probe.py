@@ -15,7 +15,7 @@ weights = synth.random_weights(18)
 
 
 def engine():
-    e = capi.Engine(0)              # (C3R_ONE_STREAM=1: the round-3 arrangement, one default-priority stream per context)
+    e = capi.Engine(0)              # (default: one default-priority stream per context; C3R_TWO_STREAMS=1: the build on a high-priority stream, the network on a low-priority one)
     e.set_params(); e.load_reads(rsh); e.set_reference(1, ref); e.load_weights(weights, 18); e.set_precision(prec)
     return e
 

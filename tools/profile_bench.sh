@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof/$PREC
 rm -rf $OUT; mkdir -p $OUT
 # --no_overlap: one context, so that a kernel's traced duration is its own run time (with two pipelined contexts a launch also
 # waits for CUs the other context's persistent workgroups hold) and agrees with the avg_launch_ms bench.py measures
-ARGS="$R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile --no_fast --no_resident --no_overlap --no_strong --precision $PREC"
+ARGS="$R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile --no_fast --no_resident --no_overlap --no_strong --no_extra --precision $PREC"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/quick/$TAG
 rm -rf $OUT; mkdir -p $OUT
-ARGS="$R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile --no_fast --no_resident --no_overlap"
+ARGS="$R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile --no_fast --no_resident --no_overlap --no_strong --no_extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/stats.log 2>&1
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/stats.csv 2>/dev/null
 python3 $R/bench.py --no_cpu_baseline --no_fast > $OUT/bench.json 2> $OUT/bench.err

@@ -1,7 +1,7 @@
 #!/bin/bash
 # socket power / clocks sampled while bench.py runs:  bash tools/smi_during_bench.sh
 R=${GRAFT_REPO_ROOT:-.}
-python3 $R/bench.py --no_cpu_baseline --no_profile --no_fast --steps 400 --warmup 3 > /tmp/bench_long.json 2>/dev/null &
+python3 $R/bench.py --no_cpu_baseline --no_profile --no_fast --no_strong --no_extra --steps 400 --warmup 3 > /tmp/bench_long.json 2>/dev/null &
 BP=$!
 for i in $(seq 1 300); do
   p=$(rocm-smi --showpower 2>/dev/null | grep -oE "Power \(W\): [0-9.]+" | grep -oE "[0-9.]+$")
