@@ -345,29 +345,38 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
         const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
         if (b0 >= b1) return;
         const int off = b0 - rstart, nb = b1 - b0;
-        const int odd = (int)(((uint32_t)ra.z + (uint32_t)off) & 1u);          // the bases were loaded from nibble naddr + off on
+        // The 16 loaded bytes hold the piece's bases from nibble naddr + off on, BAM order (the first base of a byte in its HIGH nibble).
+        // Swapping the nibbles of every byte and dropping the odd start nibble puts base u into bits 4u .. 4u + 3 of a 128-bit value:
+        // one v_bfe_u32 with constant operands per base instead of a variable 64-bit shift and a select.  A base is one of A C G T iff
+        // its code has exactly one bit set (1, 2, 4, 8), and then its channel is the bit's index: no chain of compares, and the only
+        // thing left under a condition is the LDS atomic itself (the chain compiled to ~36 instructions and four branches per base).
+        constexpr uint64_t LOWN = 0x0F0F0F0F0F0F0F0Full;
+        uint64_t s0 = ((w0 & LOWN) << 4) | ((w0 >> 4) & LOWN), s1 = ((w1 & LOWN) << 4) | ((w1 >> 4) & LOWN);
+        if (((uint32_t)ra.z + (uint32_t)off) & 1u) { s0 = (s0 >> 4) | (s1 << 60); s1 >>= 4; }
+        const uint32_t q4[4] = {(uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32)};
+        const int lim = min(nb, max(avail - off, 0));                  // (a CIGAR may claim more bases than SEQ holds: those show as N)
+        const int pl0 = b0 - t0;
+        int32_t *const c0 = &s.cnt[pl0 * C + (rev ? 9 : 0)];
+        int32_t *const ch = &s.cnt[pl0 * C + (hp == 2 ? (int)C3R_AM : (int)C3R_AP)];
 #pragma unroll
         for (int u = 0; u < OP_CHOP; ++u) {
-            if (u >= nb) continue;
-            int code = nibble_at(w0, w1, odd + u);
-            if (off + u >= avail) code = 15;                           // (a CIGAR may claim more bases than SEQ holds)
-            const int bi = acgt_index(code);
-            const int pl = b0 + u - t0;
-            if (bi < 0) {
-                // '=' / IUPAC letters are ignored by the reference's token scan WITHOUT consuming their HP entry: every
-                // later read of the column is then phased with its predecessor's tag (:116-145)
-                if (C == C3R_CH_PHASED && MODE == ACCUM && code != 15) s.odd[pl] = 1;
-                continue;
-            }
+            const uint32_t nib = (q4[u >> 3] >> (4 * (u & 7))) & 15u;
+            const bool in = u < lim;
+            const bool acgt = nib != 0u && (nib & (nib - 1u)) == 0u;
+            const int bi = __builtin_ctz(nib | 16u);                      // 0..3 for A C G T
             if (MODE == ACCUM) {
-                atomicAdd(&s.cnt[pl * C + (rev ? 9 + bi : bi)], 1);
+                if (in && acgt) atomicAdd(&c0[u * C + bi], 1);
                 if (C == C3R_CH_PHASED) {
-                    if (hp == 1) atomicAdd(&s.cnt[pl * C + C3R_AP + bi], 1);
-                    else if (hp == 2) atomicAdd(&s.cnt[pl * C + C3R_AM + bi], 1);
+                    if (in && acgt && hp != 0) atomicAdd(&ch[u * C + bi], 1);
+                    // '=' / IUPAC letters are ignored by the reference's token scan WITHOUT consuming their HP entry: every
+                    // later read of the column is then phased with its predecessor's tag (:116-145)
+                    if (in && !acgt && nib != 15u) s.odd[pl0 + u] = 1;
                 }
             } else if (MODE == FIRSTSEEN) {
-                const int ai = s.amb[pl];
-                if (ai) atomicMin(&s.first[(ai - 1) * 6 + bi], 2u * (uint32_t)r);
+                if (in && acgt) {
+                    const int ai = s.amb[pl0 + u];
+                    if (ai) atomicMin(&s.first[(ai - 1) * 6 + bi], 2u * (uint32_t)r);
+                }
             }
         }
         return;
