@@ -203,13 +203,17 @@ __device__ __forceinline__ const c3r_padins_t *padins_find(const c3r_padins_t *t
 #define C3R_ABL(a_) (C3R_SCAN_DIAG ? (a_).abl : 0)
 
 
+// Inclusive prefix sum over the 64 lanes of a wavefront on the DPP cross-lane path: row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (the sequence LLVM's atomic optimizer emits for gfx9) — six v_add with a
+// DPP operand.  The __shfl_up version was six ds_bpermute round trips through the LDS pipe (~100 cycles each, one after the other) per scan,
+// four scans per span and wavefront.
 __device__ __forceinline__ int wave_incl_scan(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
     return v;
 }
 
@@ -1419,7 +1423,18 @@ struct TokLds {
     unsigned long long mask[TK_NB][TK_MAXB], done[TK_NB][TK_MAXB];
     int32_t pre[TK_NB][TK_MAXB];
     int32_t lpos[TK_NB], toff[TK_NB], rank0[TK_NB], rank1[TK_NB];
+    unsigned long long cmask[TILE / 64];       // the batch's candidates as a bit per position of the tile
+    int32_t cpre[TILE / 64];                   // candidates (of the batch) before each 64-position word
 };
+// index of the batch's candidate at tile position x (its bit in cmask is set)
+__device__ __forceinline__ int tok_cand(const TokLds &K, int x) { return K.cpre[x >> 6] + __popcll(K.cmask[x >> 6] & ((1ull << (x & 63)) - 1ull)); }
+// the candidates among the tile positions [x0, x0 + n), n <= 64, as bits 0 .. n - 1
+__device__ __forceinline__ unsigned long long tok_cand_bits(const TokLds &K, int x0, int n) {
+    const int w = x0 >> 6, sh = x0 & 63;
+    unsigned long long bits = K.cmask[w] >> sh;
+    if (sh + n > 64) bits |= K.cmask[w + 1] << (64 - sh);          // (x0 + n <= TILE: w + 1 is a word of the mask)
+    return n >= 64 ? bits : bits & ((1ull << n) - 1ull);
+}
 
 __device__ __forceinline__ void tok_emit(TokLds &K, c3r_token_t *tok, long long tok_cap, int c, int ri, int r, int indel, uint32_t qpos, int base, bool rev,
                                          uint32_t del_after = 0) {
@@ -1434,41 +1449,39 @@ __device__ __forceinline__ void tok_emit(TokLds &K, c3r_token_t *tok, long long 
     atomicOr(&K.done[c][b], 1ull << bit);
 }
 
+// One record of the tile's range against the batch's candidates.  `bits`: the candidates the piece covers (tok_cand_bits over its positions
+// inside the tile, bit j = position b0 + j) — the caller has tested them before it fetched any bases: most records cover none.
 __device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long tok_cap, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int boff,
-                                        int t0, int t1, int nb, int rc, int re) {
+                                        int t0, int t1, unsigned long long bits, int rc, int re) {
     const uint32_t w = (uint32_t)ra.y;
     const int op = (int)(w & 3u), prev = (int)((w >> 2) & 15u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
     const bool rev = (w & 64u) != 0;
     const int rstart = ra.x, r = rb.y;
     if (r < rc || r >= re) return;                            // (its read belongs to another chunk of the tile's reads)
-    if (op != C3R_CIG_I) {
-        const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
-        if (b0 < b1) {
-            const int odd = (int)(((uint32_t)ra.z + (uint32_t)boff) & 1u);      // the bases were loaded from nibble naddr + boff on
-            for (int c = 0; c < nb; ++c) {
-                const int p = t0 + K.lpos[c];
-                if (p < b0) continue;
-                if (p >= b1) break;                           // (candidates ascend)
-                int base = 16;
-                if (op == C3R_CIG_M) base = (p - rstart) < avail ? nibble_at(w0, w1, odd + (p - rstart) - boff) : 15;
-                int indel = 0; uint32_t qpos = 0, dafter = 0;
-                if (p == rstart + len - 1 && rb.z != 0) {
-                    // htslib: the op after the one that ends on the column (k_prep has looked ahead)
-                    indel = rb.z;
-                    if (indel > 0) { qpos = (uint32_t)rb.x + (op == C3R_CIG_M ? (uint32_t)len : 0u); dafter = op == C3R_CIG_M ? (uint32_t)rb.w : (uint32_t)ra.z; }
-                }
-                tok_emit(K, tok, tok_cap, c, r - rc, r, indel, qpos, base, rev, dafter);
+    if (op != C3R_CIG_I && bits) {
+        const int b0 = max(rstart, t0);
+        const int odd = (int)(((uint32_t)ra.z + (uint32_t)boff) & 1u);      // the bases were loaded from nibble naddr + boff on
+        while (bits) {
+            const int j = __builtin_ctzll(bits);
+            bits &= bits - 1ull;
+            const int p = b0 + j, c = tok_cand(K, p - t0);
+            int base = 16;
+            if (op == C3R_CIG_M) base = (p - rstart) < avail ? nibble_at(w0, w1, odd + (p - rstart) - boff) : 15;
+            int indel = 0; uint32_t qpos = 0, dafter = 0;
+            if (p == rstart + len - 1 && rb.z != 0) {
+                // htslib: the op after the one that ends on the column (k_prep has looked ahead)
+                indel = rb.z;
+                if (indel > 0) { qpos = (uint32_t)rb.x + (op == C3R_CIG_M ? (uint32_t)len : 0u); dafter = op == C3R_CIG_M ? (uint32_t)rb.w : (uint32_t)ra.z; }
             }
+            tok_emit(K, tok, tok_cap, c, r - rc, r, indel, qpos, base, rev, dafter);
         }
     }
     if (prev == C3R_CIG_N && (op == C3R_CIG_I || op == C3R_CIG_D)) {
         // I / D right after a ref-skip: attached to the last intron column, which shows the ref-skip itself
-        const int anchor = rstart - 1;
-        if (anchor >= t0 && anchor < t1)
-            for (int c = 0; c < nb; ++c)
-                if (t0 + K.lpos[c] == anchor)
-                    tok_emit(K, tok, tok_cap, c, r - rc, r, op == C3R_CIG_I ? (int)(uint32_t)rb.w : -(int)(uint32_t)rb.w, op == C3R_CIG_I ? (uint32_t)rb.x : 0u, 17, rev,
-                             (op == C3R_CIG_I && rb.z < 0) ? (uint32_t)(-rb.z) : 0u);
+        const int ax = rstart - 1 - t0;
+        if (ax >= 0 && ax < t1 - t0 && ((K.cmask[ax >> 6] >> (ax & 63)) & 1ull))
+            tok_emit(K, tok, tok_cap, tok_cand(K, ax), r - rc, r, op == C3R_CIG_I ? (int)(uint32_t)rb.w : -(int)(uint32_t)rb.w, op == C3R_CIG_I ? (uint32_t)rb.x : 0u, 17, rev,
+                     (op == C3R_CIG_I && rb.z < 0) ? (uint32_t)(-rb.z) : 0u);
     }
 }
 
@@ -1482,11 +1495,16 @@ __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0
     for (int cb = 0; cb < nc; cb += TK_NB) {
         const int nb = min(TK_NB, nc - cb);
         __syncthreads();
+        if (tid < TILE / 64) K.cmask[tid] = 0ull;
+        __syncthreads();
         if (tid < nb) {
             int lp, off;
             cand(cb + tid, lp, off);
             K.lpos[tid] = lp; K.toff[tid] = off; K.rank0[tid] = 0;
+            atomicOr(&K.cmask[lp >> 6], 1ull << (lp & 63));
         }
+        __syncthreads();
+        if (tid < TILE / 64) { int pre = 0; for (int k = 0; k < tid; ++k) pre += __popcll(K.cmask[k]); K.cpre[tid] = pre; }
         for (int rc = lo; rc < hi; rc += TK_RCH) {
             const int re = min(hi, rc + TK_RCH), nr = re - rc, nblk = (nr + 63) >> 6;
             __syncthreads();
@@ -1511,11 +1529,12 @@ __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0
                 if (lane == 0) K.rank1[c] = run;
             }
             __syncthreads();
-            // the candidates' positions bound what a record must touch: [first candidate, last candidate]
-            const int c_lo = t0 + K.lpos[0], c_hi = t0 + K.lpos[nb - 1];
+            // a record matters only if its piece covers a candidate (or, an indel behind a ref-skip, sits on one): the candidates' bit mask says
+            // so from the record's first half alone, before its second half or any base is fetched
             for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
                 int4 ra[WALK_UNR], rb[WALK_UNR];
                 bool have[WALK_UNR];
+                unsigned long long bits[WALK_UNR];
 #pragma unroll
                 for (int u = 0; u < WALK_UNR; ++u) {
                     const int iu = base + u * SCAN_THREADS + tid;
@@ -1527,14 +1546,16 @@ __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0
                 int boff[WALK_UNR];
 #pragma unroll
                 for (int u = 0; u < WALK_UNR; ++u) {
-                    w0[u] = 0; w1[u] = 0; boff[u] = 0;
+                    w0[u] = 0; w1[u] = 0; boff[u] = 0; bits[u] = 0ull;
                     const uint32_t w = (uint32_t)ra[u].y;
                     const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
-                    const bool body = op != C3R_CIG_I && ra[u].x <= c_hi && ra[u].x + len > c_lo;
-                    const bool anchored = op != C3R_CIG_M && ra[u].x - 1 >= c_lo && ra[u].x - 1 <= c_hi;
-                    if (!(body || anchored)) have[u] = false;
-                    if (have[u] && op == C3R_CIG_M) {
-                        boff[u] = max(ra[u].x, t0) - ra[u].x;
+                    const int b0 = max(ra[u].x, t0), b1 = min(ra[u].x + len, t1);
+                    if (have[u] && op != C3R_CIG_I && b0 < b1) bits[u] = tok_cand_bits(K, b0 - t0, b1 - b0);
+                    const int ax = ra[u].x - 1 - t0;
+                    const bool anchored = op != C3R_CIG_M && ((w >> 2) & 15u) == (uint32_t)C3R_CIG_N && ax >= 0 && ax < t1 - t0 && ((K.cmask[ax >> 6] >> (ax & 63)) & 1ull);
+                    if (!(bits[u] || anchored)) have[u] = false;
+                    if (have[u] && op == C3R_CIG_M && bits[u]) {
+                        boff[u] = b0 - ra[u].x;
                         if (boff[u] < avail) {
                             const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)boff[u];
                             u64x2 w;
@@ -1545,7 +1566,7 @@ __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0
                 }
 #pragma unroll
                 for (int u = 0; u < WALK_UNR; ++u)
-                    if (have[u]) tok_rec(K, tok, tok_cap, ra[u], rb[u], w0[u], w1[u], boff[u], t0, t1, nb, rc, re);
+                    if (have[u]) tok_rec(K, tok, tok_cap, ra[u], rb[u], w0[u], w1[u], boff[u], t0, t1, bits[u], rc, re);
             }
             __syncthreads();
             for (int c = wave; c < nb; c += WAVES) {
