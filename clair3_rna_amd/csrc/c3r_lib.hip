@@ -1300,7 +1300,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         f.n_shards = nsh; f.shard_rows = (int32_t)want_c; f.shard_toks = (int32_t)want_t;
         f.cand_cap = (int32_t)rows;
         z.meta = f.meta; z.span_info = f.span_info; z.span_base = (const int32_t *)ctx->d_spanbase.p; z.alloc = f.alloc; z.n_shards = nsh; z.shard_rows = f.shard_rows; z.overflow = f.overflow;
-        z.geo = a.geo; z.ref = a.ref; z.ref_beg0 = a.ref_beg0; z.ref_len = a.ref_len;
+        z.ref = a.ref; z.ref_beg0 = a.ref_beg0; z.ref_len = a.ref_len;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_lb.p, 0, lb_bytes, ctx->stream));
         {
             Launch L(ctx, "k_tile_ranges");

@@ -670,6 +670,7 @@ struct TileMem {
     int misc[8];           // [0] events captured by the first walk, [2..5] block-scan scratch
     int scan_slot[2][2 * WAVES];                // block_excl_scan2: one slot per call site
     unsigned long long rowmask[WAVES];          // k_fused_tiles: which positions hold a pileup row, one bit each
+    unsigned long long ambmask[WAVES];          // k_fused_tiles: positions with a tie at the top of the allele counts (first-seen pass)
     unsigned long long evbase;
     EvRec ev[EV_LDS > 0 ? EV_LDS : 1];
     uint8_t evord[EV_LDS > 0 ? EV_LDS : 4];     // the captured events' indices, bucketed by position
@@ -682,7 +683,16 @@ struct TileOut { bool is_row, cand; int depth, cov; int rd_pos, rd_end; bool rd_
 // the reference-channel overwrite.  On return M.cnt holds the finished columns, M.odd the phased columns that need the ordered
 // recompute, and the thread its position's verdict.  Positions below pmin hold no rows (they lie before the region).
 // Used by the column-store kernel (k_scan_tiles) and by the fused kernel (k_fused_tiles), whose "tile" is a window-complete span.
+// FUSED (k_fused_tiles): the row mask of the window rule is published with the ambiguity votes (one barrier instead of two).
 template <int C>
+__device__ __forceinline__ void tile_zero(TileMem<C> &M) {
+    const int tid = threadIdx.x;
+    M.cov[tid] = 0; if (tid == 0) M.cov[TILE] = 0;
+    for (int i = tid; i < TILE * C; i += SCAN_THREADS) M.cnt[i] = 0;
+    M.evfill[tid] = 0; M.maxdel[tid] = 0; M.amb[tid] = 0; M.odd[tid] = 0;
+    if (tid == 0) M.misc[0] = 0;
+}
+template <int C, bool FUSED = false>
 __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M, int t0, int t1, int pmin, int region, int lo, int hi, int slo, int shi,
                                                 int cand_lo, int cand_hi) {
     constexpr int EV_LDS = TileMem<C>::EV_LDS;
@@ -690,10 +700,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, M.ev, &M.misc[0], EV_LDS};
     unsigned long long tprev = C3R_DBG(a) ? wall_clock64() : 0ull;
 #define C3R_PHASE(K) do { if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[K], now_ - tprev); tprev = now_; } } while (0)
-    M.cov[tid] = 0; if (tid == 0) M.cov[TILE] = 0;
-    for (int i = tid; i < TILE * C; i += SCAN_THREADS) M.cnt[i] = 0;
-    M.evfill[tid] = 0; M.maxdel[tid] = 0; M.amb[tid] = 0; M.odd[tid] = 0;
-    if (tid == 0) M.misc[0] = 0;
+    tile_zero<C>(M);
     // loads that nothing before the gates depends on leave now: this position's reference base, and the first round of read headers
     // (their round trip runs beside the walk's record and base loads instead of before them)
     const int p = t0 + tid;
@@ -839,7 +846,14 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         c[ch_lo] = -lw;
     }
     if (C3R_ABL(a) & 512) ambiguous = false;
-    const bool any_amb = __syncthreads_or(ambiguous ? 1 : 0) != 0;
+    bool any_amb;
+    if (FUSED) {
+        // the window rule's row mask travels with the votes: 33 contiguous rows = 33 set bits (k_fused_tiles)
+        const unsigned long long rm = __ballot(is_row), am = __ballot(ambiguous);
+        if ((tid & 63) == 0) { M.rowmask[tid >> 6] = rm; M.ambmask[tid >> 6] = am; }
+        __syncthreads();
+        any_amb = (M.ambmask[0] | M.ambmask[1] | M.ambmask[2] | M.ambmask[3]) != 0ull;
+    } else any_amb = __syncthreads_or(ambiguous ? 1 : 0) != 0;
     C3R_PHASE(4);
 
     if (any_amb) {
@@ -1715,8 +1729,8 @@ constexpr int TICKET_Q = 16, TICKET_STRIDE = 64;     // ticket words 256 bytes a
 // kernel ran 0.65 ms with candidates against 0.33 ms without.  Rows and tokens are reached through win_idx / tok_off, so the holes
 // between the shards' runs cost address space only.
 constexpr int ALLOC_SHARDS = 16, ALLOC_STRIDE = 32;  // (u64 words)
-struct CandMeta { int32_t slot, depth, ncov, tpre, span; };      // per arrived candidate: slot (tile * TILE + offset), depth, covering reads,
-                                                                 // tokens of the span's earlier candidates, list index of its span
+struct CandMeta { int32_t slot, depth, ncov, tpre, span, pos0; };      // per arrived candidate: slot (tile * TILE + offset), depth, covering reads, tokens of the
+                                                                       // span's earlier candidates, list index of its span, its 0-based position
 struct FusedArgs {
     ScanArgs a;                   // tile_list: spans with aligned bases, ascending; tile_rng: reads / segments of the span + flanks
     int32_t *ticket;              // [TICKET_Q * TICKET_STRIDE] tickets handed out per queue
@@ -1743,6 +1757,7 @@ template <int C>
 __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SCAN_OCC30)) void k_fused_tiles(const FusedArgs f) {
     __shared__ TileMem<C> M;
     __shared__ int s_ticket, s_row0, s_tok0, s_fits;
+    __shared__ int4 s_rec[3];
     const int shard = (int)(blockIdx.x % (unsigned)f.n_shards);
     static_assert(sizeof(TokLds) <= sizeof(M.cnt), "the token pass re-uses the accumulators' LDS");
     const ScanArgs &a = f.a;
@@ -1767,20 +1782,25 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         }
         return n;
     };
+    // The span's record (48 bytes: where it lies, its read / record ranges) is fetched one span AHEAD by three lanes — issued when the
+    // current span's windows are out, so that its round trip runs under the token pass, and parked in LDS (s_rec) across the hand-over:
+    // the next span starts without a dependent load.  (Round 4 tried the same with the fetch at the TOP of the span: the three registers
+    // it kept alive through the whole span cost more than the round trip.)
     if (tid == 0) s_ticket = take();
     __syncthreads();
     int b = s_ticket;
+    if (b < n && tid < 3) s_rec[tid] = reinterpret_cast<const int4 *>(f.span_rec + b)[tid];
+    __syncthreads();
     while (b < n) {
         int t_next = 0;
         const int q_next = home;
         if (tid == 0) t_next = atomicAdd(&f.ticket[q_next * TICKET_STRIDE], 1);
-        const int4 *recp = reinterpret_cast<const int4 *>(f.span_rec + b);
-        const int4 r0 = recp[0], rng = recp[1], r2 = recp[2];
+        const int4 r0 = s_rec[0], rng = s_rec[1], r2 = s_rec[2];
         const int tile = r0.x;
         TileGeo tg; tg.p0 = r0.y; tg.p1 = r0.z; tg.region = r0.w; tg.pad = 0;
         const int2 rb = make_int2(r2.x, r2.y);
         const int x0 = tg.p0 - C3R_FLANK, x1 = min(tg.p1 + C3R_FLANK, rb.y);       // thread tid <-> position x0 + tid
-        const TileOut o = tile_columns<C>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1);
+        const TileOut o = tile_columns<C, true>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1);
         unsigned long long t_tail = C3R_DBG(a) ? wall_clock64() : 0ull;
         int dbg_slot = 7;
         if (C == C3R_CH_PHASED) {
@@ -1793,12 +1813,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
                 for (int k = 0; k < 12; ++k) M.cnt[tid * C + C3R_AP + k] = cnt[k];
             }
         }
-        // ---- the window rule: 33 contiguous rows = 33 set bits in the span's row mask (one ballot per wavefront, one barrier)
-        {
-            const unsigned long long rm = __ballot(o.is_row);
-            if ((tid & 63) == 0) M.rowmask[tid >> 6] = rm;
-        }
-        __syncthreads();
+        // ---- the window rule: 33 contiguous rows = 33 set bits in the span's row mask (published by tile_columns with its last barrier)
         bool emit = false;
         if (o.cand && tid >= C3R_FLANK && tid + C3R_FLANK < TILE) {
             const int first = tid - C3R_FLANK, w = first >> 6, sh = first & 63;
@@ -1822,7 +1837,8 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
                 const unsigned long long got = atomicAdd(&f.alloc[shard * ALLOC_STRIDE], ((unsigned long long)(unsigned)(f.tok ? nt : 0) << 32) | (unsigned)nc);
                 lrow = (int)(unsigned)got; ltok = (int)(unsigned)(got >> 32);
             }
-            s_fits = (long long)lrow + nc <= (long long)f.shard_rows && (!f.tok || (long long)ltok + nt <= (long long)f.shard_toks);
+            const bool fits = (long long)lrow + nc <= (long long)f.shard_rows && (!f.tok || (long long)ltok + nt <= (long long)f.shard_toks);
+            s_fits = fits ? 1 : 0;
             s_row0 = shard * f.shard_rows + lrow;
             s_tok0 = shard * f.shard_toks + ltok;
             f.span_info[b] = make_int4(s_row0, nc, nt, s_tok0);
@@ -1835,7 +1851,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         if (nc > 0 && fits) {
         if (emit) {
             CandMeta m;
-            m.slot = tile * TILE + (tid - C3R_FLANK); m.depth = o.depth; m.ncov = o.cov; m.tpre = tpre; m.span = b;
+            m.slot = tile * TILE + (tid - C3R_FLANK); m.depth = o.depth; m.ncov = o.cov; m.tpre = tpre; m.span = b; m.pos0 = x0 + tid;
             f.meta[row0 + rank] = m;
         }
         // ---- the span's nc windows are ONE contiguous run of the output (rows [row0, row0 + nc) x 33 x C int32) and each window is
@@ -1881,10 +1897,20 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         }
         const int gt = head + 4 * n4 + tid;
         if (gt < total && !(C3R_ABL(a) & 64)) out[gt] = fetch(gt);
+        }
+        // ---- the next span: its ticket has long arrived; three lanes of the first wavefront fetch its record now (the round trip runs
+        // under the token pass; the list position travels from lane 0 by a cross-lane read, no barrier)
+        int b_next = 0;
+        int4 nrec = make_int4(0, 0, 0, 0);
+        if (tid < 64) {
+            if (tid == 0) b_next = t_next < queue_len(q_next) ? list_pos(q_next, t_next) : take();
+            b_next = __shfl(b_next, 0, 64);
+            if (b_next < n && tid < 3) nrec = reinterpret_cast<const int4 *>(f.span_rec + b_next)[tid];
+        }
+        if (nc > 0 && fits) {
         // ---- the candidates' tokens, while the span's records are still in the cache (k_tile_tokens walked the op table a second time:
         // 0.29 ms and 291 MB per chr20 pass).  The accumulators are dead once the windows are out: their LDS holds the token pass's tables
         if (f.tok && !(C3R_ABL(a) & 128)) {                                   // (ablation 128: no token pass)
-            __syncthreads();
             if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[7], now_ - t_tail); t_tail = now_; dbg_slot = 8; }
             TokLds &K = *reinterpret_cast<TokLds *>(M.cnt);
             tile_tokens(a, K, x0, x1, tg.region, rng.x, rng.y, rng.z, rng.w, nc, [&](int k, int &lp, int &off) {
@@ -1893,8 +1919,10 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         }
         }
         if (C3R_DBG(a) && tid == 0) atomicAdd(&C3R_DBG(a)[dbg_slot], wall_clock64() - t_tail);
-        // ---- hand over to the next span: its ticket has long arrived; the barrier also frees this span's LDS
-        if (tid == 0) s_ticket = t_next < queue_len(q_next) ? list_pos(q_next, t_next) : take();
+        // ---- hand over: the next span's record and list position into LDS (s_rec was last read at the top of this span, many barriers
+        // ago); the barrier also frees this span's LDS
+        if (tid < 3) s_rec[tid] = nrec;
+        if (tid == 0) s_ticket = b_next;
         __syncthreads();
         b = s_ticket;
     }
@@ -1936,7 +1964,7 @@ __global__ __launch_bounds__(256) void k_order_spans(const int4 *span_info, cons
 //   candidates), cand_idx[i] = slot, win_idx[i] = row_base + row
 struct FinalizeArgs {
     const CandMeta *meta; const int4 *span_info; const int32_t *span_base; const unsigned long long *alloc; int32_t n_shards, shard_rows; const int32_t *overflow;
-    const TileGeo *geo; const uint8_t *ref; int32_t ref_beg0, ref_len;
+    const uint8_t *ref; int32_t ref_beg0, ref_len;
     c3r_site_t *sites; int32_t *cand_idx; int32_t *win_idx; int32_t row_base; int32_t tok_base;
 };
 __global__ __launch_bounds__(256) void k_finalize_sites(const FinalizeArgs g) {
@@ -1951,7 +1979,7 @@ __global__ __launch_bounds__(256) void k_finalize_sites(const FinalizeArgs g) {
         const CandMeta m = g.meta[row];
         const int4 si = g.span_info[m.span];
         const int i = g.span_base[m.span] + (row - si.x);
-        const int pc = g.geo[m.slot / TILE].p0 + (m.slot % TILE);
+        const int pc = m.pos0;
         if (g.sites && gl < 13) {
             uint32_t v;
             if (gl == 0) v = (uint32_t)(pc + 1);
