@@ -657,7 +657,7 @@ constexpr int LIST_GRID = 8192;
 // first walk captures them as it meets them, and they are bucketed by position without a second walk over the records; deeper tiles
 // walk again and bump-allocate global scratch.  (30 channels: the accumulators leave no room at four workgroups per CU.)
 template <int C>
-struct TileMem {
+struct alignas(16) TileMem {
     static constexpr int EV_LDS = C == C3R_CH ? 192 : 0;
     int32_t cnt[TILE * C];
     int32_t cov[TILE + 1];
