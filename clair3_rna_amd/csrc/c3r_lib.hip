@@ -100,6 +100,8 @@ struct c3r_ctx {
     // the decoder (row snapshots share the vector); empty for every CIGAR an aligner emits
     DevBuf d_padins;
     std::shared_ptr<PadInsTab> padins;
+    DevBuf d_aftab;                        // the AF gates as integer thresholds per depth (ScanArgs::af_tab), rebuilt when the AFs change
+    double aftab_snp = -1.0, aftab_indel = -1.0;
     DevBuf d_dbg;                          // C3R_SCAN_DBG: phase timers of k_scan_tiles
     DevBuf d_tile_cand;                    // [n_tiles] {first candidate, count} of the most recent scan (k_compact_write -> k_tile_tokens)
     DevBuf d_tile_cols, d_tile_rng, d_tile_list, d_tile_list2, d_rsegs, d_rseg_first;
@@ -659,7 +661,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_binoff, &ctx->d_rtab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
                       &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
-                      &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff, &ctx->d_padins};
+                      &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff, &ctx->d_padins, &ctx->d_aftab};
     int n_dev = 0; size_t b_dev = 0, b_pin = 0;
     for (DevBuf *b : bufs) if (b->p) { (void)hipFree(b->p); ++n_dev; b_dev += b->cap; }
     const auto t1 = std::chrono::steady_clock::now();
@@ -956,6 +958,31 @@ static int depth_cap_mask(c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts
     return C3R_OK;
 }
 
+// The reference's AF gates divide in float64 (float(count) / denominator >= minimum_af, src/create_tensor_pileup.py:267-285).  For every
+// depth below AF_TAB the smallest count that passes is found HERE with that very division, so that the kernels compare integers: the
+// quotient grows with the count, hence "count >= threshold" is the same predicate, bit for bit.  65535: no count passes (af > 1).
+static int af_table(c3r_ctx *ctx) {
+    if (ctx->d_aftab.p && ctx->aftab_snp == ctx->prm.snp_min_af && ctx->aftab_indel == ctx->prm.indel_min_af) return C3R_OK;
+    std::vector<uint32_t> tab((size_t)AF_TAB);
+    auto thr = [](int d, double af) -> uint32_t {
+        const double denom = d > 0 ? (double)d : 1.0;
+        const int top = std::max(d, 1);
+        int c = (int)std::ceil(af * denom);                       // near the answer; settled by the division itself
+        c = std::max(1, std::min(c, top + 1));
+        while (c > 1 && (double)(c - 1) / denom >= af) --c;
+        while (c <= top && !((double)c / denom >= af)) ++c;
+        // (counts above the depth exist: insertions on ref-skip columns are not part of the depth)
+        while (c <= 65534 && !((double)c / denom >= af)) ++c;
+        return c > 65534 ? 65535u : (uint32_t)c;
+    };
+    for (int d = 0; d < AF_TAB; ++d) tab[(size_t)d] = thr(d, ctx->prm.snp_min_af) | (thr(d, ctx->prm.indel_min_af) << 16);
+    int rc = upload(ctx, ctx->d_aftab, tab.data(), tab.size());
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));               // (tab is a temporary)
+    ctx->aftab_snp = ctx->prm.snp_min_af; ctx->aftab_indel = ctx->prm.indel_min_af;
+    return C3R_OK;
+}
+
 // the inputs every tile kernel sees (the output side is filled in by the two scan paths)
 static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int drop_words, int n_tiles) {
     memset(&a, 0, sizeof a);
@@ -969,7 +996,7 @@ static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int d
     a.cbed = (const int32_t *)ctx->d_bed[1].p; a.n_cbed = (int32_t)(ctx->h_bed[1].size() / 2); a.has_cbed = ctx->has_bed[1];
     a.sites = (const int32_t *)ctx->d_sites.p; a.n_sites = (int32_t)ctx->h_sites.size(); a.genotyping = ctx->prm.genotyping_mode;
     a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.min_cov = ctx->prm.min_coverage;
-    a.snp_af = ctx->prm.snp_min_af; a.indel_af = ctx->prm.indel_min_af;
+    a.snp_af = ctx->prm.snp_min_af; a.indel_af = ctx->prm.indel_min_af; a.af_tab = (const uint32_t *)ctx->d_aftab.p;
     a.head_tail = ctx->prm.head_tail; a.splice = ctx->prm.splice_padding;
     if (ctx->padins && !ctx->padins->empty()) { a.padins = (const c3r_padins_t *)ctx->d_padins.p; a.n_padins = (int32_t)ctx->padins->size(); }
     { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
@@ -991,6 +1018,7 @@ int c3r_pileup_scan_regions(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (n_candidates) *n_candidates = 0;
+    { const int rc_af = af_table(ctx); if (rc_af) return rc_af; }
     ctx->last_starts.assign(ctg_starts, ctg_starts + n_regions); ctx->last_ends.assign(ctg_ends, ctg_ends + n_regions);
     ctx->last_scan_pruned = false;
     // The plain mode runs in one fused tile kernel (k_fused_tiles).  Head/tail calling (the end-of-stream rule needs the last row of the
@@ -1488,7 +1516,8 @@ int c3r_get_columns(c3r_ctx *ctx, int64_t *region_start, int64_t *n_pos, int32_t
     if (ctx->last_fused) {
         // the fused path never materialises columns: build those of the scan's first region now, through the column store
         if (ctx->last_starts.empty()) return fail(ctx, C3R_EINVAL, "no scan yet");
-        int rc = scan_column_store(ctx, 1, ctx->last_starts.data(), ctx->last_ends.data(), nullptr, true);
+        int rc = af_table(ctx);
+        if (!rc) rc = scan_column_store(ctx, 1, ctx->last_starts.data(), ctx->last_ends.data(), nullptr, true);
         ctx->geo_key.clear();                // (the device now holds the column store's geometry)
         if (rc) return rc;
     }

@@ -171,6 +171,9 @@ struct ScanArgs {
     int32_t has_lbed, has_cbed, genotyping;
     int32_t min_mq, excl_flags, min_cov;
     double snp_af, indel_af;
+    const uint32_t *af_tab;       // [AF_TAB] per depth d: the smallest count c >= 1 with (double)c / (double)max(d, 1) >= snp_af (low half) / indel_af (high
+                                  // half), 65535: none — the reference's float64 AF gates (src/create_tensor_pileup.py:267-285) as integer compares; built on the
+                                  // host with the very division (c3r_lib.hip, af_table); deeper positions divide
     EvRec *ev;                    // scratch: ev_cap records, bump-allocated per tile through ev_cursor
     unsigned long long *ev_cursor;
     unsigned long long ev_cap;    // a reservation past it is refused: the tile skips its events and raises *ev_overflow
@@ -297,6 +300,7 @@ __device__ __forceinline__ bool sorted_contains(const int32_t *a, int n, int v) 
     return lo < n && a[lo] == v;
 }
 
+constexpr int AF_TAB = 8192;
 enum WalkMode { ACCUM = 0, SCATTER = 1, FIRSTSEEN = 2 };
 constexpr int FS_CAP = 32;     // positions per batch of the first-seen (tie-break) pass
 
@@ -410,9 +414,14 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
     e.key = 0;
     int fc = 15;
     if (is_ins) {
+        // the first nk <= 16 inserted base codes, code j in bits 4j .. 4j + 3 — exactly the nibble-swapped, aligned form of the loaded bytes
+        // (see the base loop above); codes SEQ does not hold (beyond `avail`) read as N
         const int nk = ilen < 16 ? ilen : 16;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) if (j < nk) e.key |= (uint64_t)(j < avail ? nibble_at(w0, w1, odd + j) : 15) << (4 * j);
+        constexpr uint64_t LOWN = 0x0F0F0F0F0F0F0F0Full;
+        uint64_t s0 = ((w0 & LOWN) << 4) | ((w0 >> 4) & LOWN);
+        if (odd) s0 = (s0 >> 4) | ((((w1 & LOWN) << 4) | ((w1 >> 4) & LOWN)) << 60);
+        const uint64_t m_nk = nk >= 16 ? ~0ull : ((1ull << (4 * nk)) - 1ull), m_av = avail >= 16 ? ~0ull : ((1ull << (4 * avail)) - 1ull);
+        e.key = (s0 & m_nk & m_av) | (m_nk & ~m_av);
         fc = (int)(e.key & 15u);
     }
     // 'I' iff the first inserted char is one of "ACGTN*" (upper case => forward strand), src/create_tensor_pileup.py:227-232; a leading pad
@@ -810,11 +819,19 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         const bool may_be_cand = p >= cand_lo && p < cand_hi;       // (the fused kernel decides candidates for its inner span only)
         const double denom = depth > 0 ? (double)depth : 1.0;
         bool pass = (C3R_ABL(a) & 1024) != 0;
-        if (!pass)
-        for (int x = 0; x < 4; ++x)
-            if (x != refi && cls[x] > 0 && (double)cls[x] / denom >= a.snp_af) pass = true;
-        if (!pass && cls[4] > 0 && (double)cls[4] / denom >= a.indel_af) pass = true;
-        if (!pass && cls[5] > 0 && (double)cls[5] / denom >= a.indel_af) pass = true;
+        if (!pass && depth < AF_TAB) {
+            // (six float64 divisions per position otherwise: ~70 double-rate instructions in a kernel whose time follows its instruction count)
+            const uint32_t th = a.af_tab[depth];
+            const int ts = (int)(th & 0xffffu), ti = (int)(th >> 16);
+            for (int x = 0; x < 4; ++x)
+                if (x != refi && cls[x] >= ts) pass = true;
+            if (cls[4] >= ti || cls[5] >= ti) pass = true;
+        } else if (!pass) {
+            for (int x = 0; x < 4; ++x)
+                if (x != refi && cls[x] > 0 && (double)cls[x] / denom >= a.snp_af) pass = true;
+            if (!pass && cls[4] > 0 && (double)cls[4] / denom >= a.indel_af) pass = true;
+            if (!pass && cls[5] > 0 && (double)cls[5] / denom >= a.indel_af) pass = true;
+        }
         if (depth > 0 && (a.snp_af == 0.0 || a.indel_af == 0.0)) pass = true;
         if (!pass) {
             // pileup_list[0][0] != reference_base: top class by count, ties broken by first occurrence
