@@ -279,7 +279,7 @@ def run_strong(args, rank, local_rank, world, one_gpu, emit=True):
     names = [n for n, _l in shard.GRCH38]
     lens = [max(200000, int(l * args.genome_scale)) for _n, l in shard.GRCH38]
     plan = shard.lpt_assign(lens, world)
-    mine = plan[rank]
+    mine = sorted(plan[rank], key=lambda i: -lens[i])         # largest first: the pass ends on the shortest network launch (the one tail nothing hides)
     depth = args.depth if args.depth != 20.0 else 30.0                       # configs[2]: ~30x
     weights = synth.random_weights(18)
     torch.cuda.set_device(local_rank)
@@ -293,7 +293,9 @@ def run_strong(args, rank, local_rank, world, one_gpu, emit=True):
     data = []
     for ci in mine:
         ref, rs, info = synth.generate_contig(contig_len=lens[ci], seed=synth.SEED + 1000 + ci, depth=depth)
-        data.append((ci, ref, capi.pinned_readset(rs), chunk_list(lens[ci]), info))
+        # the reference as the fetcher of call_sample hands it over: an upper-cased uint8 array, used in place (c3r_set_reference_view) — the
+        # copying form spends 5-11 ms of the host thread per contig on upper-casing (profiles/r5/strong_1gpu_attribution.txt)
+        data.append((ci, capi.pinned_copy(np.frombuffer(ref, dtype=np.uint8)), capi.pinned_readset(rs), chunk_list(lens[ci]), info))
     engs = []
     for _ in range(1 if args.no_overlap else max(1, args.contexts)):
         e = capi.Engine(local_rank)
@@ -309,7 +311,7 @@ def run_strong(args, rank, local_rank, world, one_gpu, emit=True):
                 e = engs[j]
                 if pending[j]:
                     e.fetch_probs(pending[j])
-                e.set_reference(1, ref)
+                e.set_reference(1, ref, upper_view=True)
                 e.load_reads(rs)
                 e.begin_batch(); n = e.scan_regions(chunks); e.end_batch()
                 if n:
