@@ -599,7 +599,9 @@ def Run(args, log=None):
                 # pool than it has workers + 2)
                 snap_slots.acquire()
                 try:
-                    snap = eng.rows_begin()
+                    # (without --print_ref_calls the sites the decoder's early RefCall exit would drop anyway stay on the device; the decoder
+                    # reads inserted bases from the fetched arrays in place — the snapshot keeps them alive)
+                    snap = eng.rows_begin(drop_ref_calls=not args.print_ref_calls)
                 except BaseException:
                     snap_slots.release()
                     raise

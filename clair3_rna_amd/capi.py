@@ -36,7 +36,7 @@ class C3RError(RuntimeError):
 EXPORTS = ["c3r_version", "c3r_create", "c3r_destroy", "c3r_trim", "c3r_last_error", "c3r_synchronize", "c3r_stream",
            "c3r_default_params", "c3r_set_params", "c3r_load_reads", "c3r_host_alloc", "c3r_host_free", "c3r_set_reference", "c3r_set_reference_view", "c3r_set_bed", "c3r_set_sites",
            "c3r_pileup_scan", "c3r_pileup_scan_regions", "c3r_batch_begin", "c3r_batch_end", "c3r_batch_count", "c3r_get_tensors", "c3r_get_sites", "c3r_token_count", "c3r_get_tokens", "c3r_get_pad_insertions", "c3r_get_columns",
-           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_get_precision_guard", "c3r_reserve", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_rows_begin", "c3r_rows_decode", "c3r_rows_get", "c3r_rows_free", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
+           "c3r_weight_count", "c3r_load_weights", "c3r_set_precision", "c3r_get_precision", "c3r_get_precision_guard", "c3r_reserve", "c3r_infer", "c3r_get_probs", "c3r_call_rows", "c3r_get_rows", "c3r_rows_begin", "c3r_rows_begin_ex", "c3r_rows_decode", "c3r_rows_get", "c3r_rows_free", "c3r_decode_text", "c3r_set_profiling", "c3r_reset_kernel_stats",
            "c3r_get_kernel_stats"]
 
 _lib = None
@@ -98,6 +98,7 @@ def load_library():
     L.c3r_call_rows.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.c3r_get_rows.argtypes = [vp, vp, i64]
     L.c3r_rows_begin.argtypes = [vp, C.POINTER(vp)]
+    L.c3r_rows_begin_ex.argtypes = [vp, i32, vp, vp, C.POINTER(vp)]
     L.c3r_rows_decode.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.c3r_rows_get.argtypes = [vp, vp, i64]
     L.c3r_rows_free.argtypes = [vp]
@@ -362,13 +363,22 @@ class Engine(object):
         """Size the network's device buffers for batches of up to n_sites candidates now rather than in the first infer()."""
         self._chk(self.L.c3r_reserve(self.h, int(n_sites)))
 
-    def rows_begin(self):
+    def rows_begin(self, drop_ref_calls=False, host_reads=True):
         """Detach the decode inputs of the resident batch (sites, tokens, probabilities, read bases; after infer()) into a host
-        snapshot: the engine is free for the next contig, RowSnapshot.decode() may run on any thread."""
+        snapshot: the engine is free for the next contig, RowSnapshot.decode() may run on any thread.
+        drop_ref_calls: only the sites that can print a row WITHOUT show_ref leave the device (the decoder's early RefCall exit is applied
+        there; decode such a snapshot with show_ref=False only).  host_reads: the decoder reads inserted bases from the ReadSet handed to
+        load_reads (kept alive by the snapshot) instead of from a copy fetched back from the device."""
         h = C.c_void_p()
-        self._chk(self.L.c3r_rows_begin(self.h, C.byref(h)))
+        rs = getattr(self, "readset", None) if host_reads else None
+        if rs is not None and not (rs.reads.flags.c_contiguous and rs.seq.flags.c_contiguous and rs.reads.dtype == READ_DTYPE and len(rs.reads)):
+            rs = None
+        self._chk(self.L.c3r_rows_begin_ex(self.h, int(bool(drop_ref_calls)), _ptr(rs.reads) if rs is not None else None,
+                                           _ptr(rs.seq) if rs is not None else None, C.byref(h)))
         snap = RowSnapshot(self.L, h)
         snap._ref_keep = getattr(self, "_ref_bytes", None)       # (c3r_set_reference_view: the decoder reads this array)
+        snap._rs_keep = rs                                       # (c3r_rows_begin_ex: and these)
+        snap.dropped_ref_calls = bool(drop_ref_calls)
         self._snaps.add(snap)
         return snap
 
@@ -404,12 +414,14 @@ class RowSnapshot(object):
     """Host-side decode inputs of one batch (c3r_rows_begin); decode() needs no GPU and no engine."""
 
     def __init__(self, L, h):
-        self.L, self.h, self._ref_keep = L, h, None
+        self.L, self.h, self._ref_keep, self._rs_keep, self.dropped_ref_calls = L, h, None, None, False
 
     def decode(self, ctg, qual=2, show_ref=True, as_array=False):
         """-> (bytes of newline-terminated VCF rows, number of rows); releases the snapshot.  as_array: the rows as a uint8 array
         instead (a large contig's rows are ~100 MB: turning them into a bytes object is a copy made with the GIL held, which
         stalls every other thread of a whole-sample run)."""
+        if show_ref and self.dropped_ref_calls:
+            raise ValueError("this snapshot was taken without the RefCall sites (rows_begin(drop_ref_calls=True)): decode it with show_ref=False")
         try:
             n, nr = C.c_int64(0), C.c_int64(0)
             rc = self.L.c3r_rows_decode(self.h, ctg.encode(), -1 if qual is None else int(qual), int(show_ref), C.byref(n), C.byref(nr))
@@ -429,6 +441,7 @@ class RowSnapshot(object):
             self.L.c3r_rows_free(self.h)
             self.h = None
         self._ref_keep = None
+        self._rs_keep = None
 
     def __del__(self):
         try:

@@ -90,6 +90,7 @@ struct c3r_ctx {
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool pin_busy[2] = {false, false};
     DevBuf d_tokb, d_tokrec, d_recoff;     // packed tokens of a row snapshot (c3r_rows_begin)
+    DevBuf d_keep, d_sites_c, d_probs_c;   // c3r_rows_begin_ex(drop_ref_calls): keep flags / row numbers, the kept sites' records and probabilities
     std::vector<DevRead> h_reads;          // lazily: ensure_host_reads
     std::vector<int32_t> h_prefmax;        // lazily: host copy of the prefix max of read ends (passing reads)
     bool host_reads_valid = false;
@@ -661,7 +662,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_binoff, &ctx->d_rtab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
                       &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
-                      &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff, &ctx->d_padins, &ctx->d_aftab};
+                      &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff, &ctx->d_padins, &ctx->d_aftab, &ctx->d_keep, &ctx->d_sites_c, &ctx->d_probs_c};
     int n_dev = 0; size_t b_dev = 0, b_pin = 0;
     for (DevBuf *b : bufs) if (b->p) { (void)hipFree(b->p); ++n_dev; b_dev += b->cap; }
     const auto t1 = std::chrono::steady_clock::now();
@@ -1789,23 +1790,45 @@ struct c3r_rows {
     std::shared_ptr<HostReads> hr;                        // the contig's read headers and packed bases (inserted bases of the alt alleles)
     std::shared_ptr<PadInsTab> padins;                    // mpileup_compat = 1: its insertions with pads (null / empty otherwise)
     const DevRead *reads = nullptr; const uint8_t *seq = nullptr;
+    const c3r_read_t *creads = nullptr;                   // c3r_rows_begin_ex: the caller's own records and bases are read in place (no copy back)
     TokRec *recs = nullptr; int64_t n_recs = 0;           // the tokens that carry an indel (k_pack_tokens), own allocation
     int ref_slot = -1; const char *ref = nullptr; size_t ref_len = 0; int64_t ref_start1 = 1;
     std::string rows; int64_t rows_count = 0;
 };
 extern "C" {
 
-int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
-    if (!ctx || !out) return C3R_EINVAL;
+int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) { return c3r_rows_begin_ex(ctx, 0, nullptr, nullptr, out); }
+
+int c3r_rows_begin_ex(c3r_ctx *ctx, int drop_ref_calls, const c3r_read_t *host_reads, const uint8_t *host_seq, c3r_rows **out) {
+    if (!ctx || !out || ((host_reads == nullptr) != (host_seq == nullptr))) return C3R_EINVAL;
     *out = nullptr;
-    const int64_t n = ctx->n_cand;
+    int64_t n = ctx->n_cand;
     if (n > 0 && (!ctx->net.d_probs || n > ctx->net.cap_probs)) return fail(ctx, C3R_EINVAL, "c3r_infer must run before c3r_call_rows");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     c3r_rows *r = new c3r_rows();
     r->ctx = ctx; r->n = n; r->n_tok = ctx->n_tok;
     if (n == 0) { *out = r; return C3R_OK; }
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const int64_t n_tok = ctx->n_tokspace;           // (token bytes are addressed through the sites' tok_off: the whole slot space)
+    int64_t n_tok = ctx->n_tokspace;                 // (token bytes are addressed through the sites' tok_off: the whole slot space)
+    // ---- drop_ref_calls: only the sites that can print a row without --show_ref leave the device (k_row_keep / k_pack_rows)
+    const int64_t n_all = n;
+    const c3r_site_t *d_sites_src = (const c3r_site_t *)ctx->d_sites_out.p;
+    const float *d_probs_src = ctx->net.d_probs;
+    bool packed = false;
+    if (drop_ref_calls) {
+        int rc0;
+        if ((rc0 = ensure(ctx, ctx->d_keep, (size_t)(n_all + 2) * 4)) || (rc0 = ensure(ctx, ctx->d_small, 64))) { delete r; return rc0; }
+        hipLaunchKernelGGL(k_row_keep, dim3((unsigned)(n_all / 256 + 1)), dim3(256), 0, ctx->stream, d_sites_src, d_probs_src, (int)n_all, (int32_t *)ctx->d_keep.p);
+        if ((rc0 = device_excl_scan(ctx, (int32_t *)ctx->d_keep.p, (int)n_all + 1, (int32_t *)((char *)ctx->d_small.p + 52)))) { delete r; return rc0; }
+        int32_t n_keep = 0;
+        if (hipMemcpyAsync(&n_keep, (char *)ctx->d_small.p + 52, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            delete r; return fail(ctx, C3R_EHIP, "reading the number of kept sites failed");
+        }
+        n = n_keep; r->n = n;
+        if (n == 0) { r->n_tok = 0; *out = r; return C3R_OK; }
+        if ((rc0 = ensure(ctx, ctx->d_sites_c, (size_t)n * sizeof(c3r_site_t))) || (rc0 = ensure(ctx, ctx->d_probs_c, (size_t)n * C3R_NPROB * sizeof(float)))) { delete r; return rc0; }
+        packed = true;
+    }
     const size_t b_sites = up((size_t)n * sizeof(c3r_site_t)), b_tokb = up((size_t)std::max<int64_t>(n_tok, 1)), b_probs = up((size_t)n * C3R_NPROB * sizeof(float)),
                  b_off = up((size_t)n * 4);
     const size_t need = b_sites + b_tokb + b_probs + b_off;
@@ -1826,15 +1849,15 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     r->tokb = (uint8_t *)sp; sp += b_tokb;
     r->probs = (float *)sp; sp += b_probs;
     r->rec_off = (uint32_t *)sp; sp += b_off;
-    const bool fresh_reads = !ctx->host_cache;
-    if (fresh_reads) {
+    const bool fresh_reads = !host_reads && !ctx->host_cache;
+    if (host_reads) { r->creads = host_reads; r->seq = host_seq; }
+    else if (fresh_reads) {
         ctx->host_cache = std::make_shared<HostReads>();
         ctx->host_cache->reads.resize((size_t)std::max(ctx->n_reads, 1));
         ctx->host_cache->seq.resize((size_t)ctx->n_seq_bytes + 16);
     }
-    r->hr = ctx->host_cache;
+    if (!host_reads) { r->hr = ctx->host_cache; r->reads = r->hr->reads.data(); r->seq = r->hr->seq.data(); }
     r->padins = ctx->padins;
-    r->reads = r->hr->reads.data(); r->seq = r->hr->seq.data();
     auto bail = [&](int rc) { if (fresh_reads) ctx->host_cache.reset(); c3r_rows_free(r); return rc; };      // (a half-copied cache is no cache)
     const bool timing = getenv("C3R_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1845,12 +1868,18 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
     // tokens leave the device packed (k_pack_tokens: a byte per token, 12-byte records for the tokens with an indel)
     int rc = C3R_OK;
     if ((rc = ensure(ctx, ctx->d_tokb, (size_t)std::max<int64_t>(n_tok, 1))) || (rc = ensure(ctx, ctx->d_tokrec, (size_t)std::max<int64_t>(n_tok, 1) * sizeof(TokRec))) ||
-        (rc = ensure(ctx, ctx->d_recoff, (size_t)n * 4 + 8)))
+        (rc = ensure(ctx, ctx->d_recoff, (size_t)n * 4 + 32)))
         return bail(rc);
     if (!ctx->h_pack && hipHostMalloc((void **)&ctx->h_pack, 64, hipHostMallocDefault) != hipSuccess) return bail(fail(ctx, C3R_ENOMEM, "hipHostMalloc(64) failed"));
     unsigned long long *d_counter = (unsigned long long *)((char *)ctx->d_recoff.p + (((size_t)n * 4 + 7) & ~(size_t)7));
-    if (hipMemsetAsync(d_counter, 0, 8, ctx->stream) != hipSuccess) return bail(fail(ctx, C3R_EHIP, "hipMemsetAsync failed"));
-    {
+    if (hipMemsetAsync(d_counter, 0, 16, ctx->stream) != hipSuccess) return bail(fail(ctx, C3R_EHIP, "hipMemsetAsync failed"));
+    if (packed) {
+        Launch L(ctx, "k_pack_tokens");
+        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((n_all + 3) / 4)), dim3(256), 0, ctx->stream, d_sites_src, (const c3r_token_t *)ctx->d_tok.p, d_probs_src,
+                           (const int32_t *)ctx->d_keep.p, n_all, (c3r_site_t *)ctx->d_sites_c.p, (float *)ctx->d_probs_c.p, (uint8_t *)ctx->d_tokb.p, (TokRec *)ctx->d_tokrec.p,
+                           (uint32_t *)ctx->d_recoff.p, d_counter);
+        d_sites_src = (const c3r_site_t *)ctx->d_sites_c.p; d_probs_src = (const float *)ctx->d_probs_c.p;
+    } else {
         Launch L(ctx, "k_pack_tokens");
         hipLaunchKernelGGL(k_pack_tokens, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const c3r_site_t *)ctx->d_sites_out.p, (const c3r_token_t *)ctx->d_tok.p, n,
                            (uint8_t *)ctx->d_tokb.p, (TokRec *)ctx->d_tokrec.p, (uint32_t *)ctx->d_recoff.p, d_counter);
@@ -1860,14 +1889,16 @@ int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out) {
         if (bytes >= PIN_MIN && pin_ring_on()) return big_d2h(ctx, dst, src, bytes) == C3R_OK;
         return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
     };
-    if (!d2h(ctx->h_pack, d_counter, 8) || !d2h(r->sites, ctx->d_sites_out.p, (size_t)n * sizeof(c3r_site_t)) || !d2h(r->tokb, ctx->d_tokb.p, (size_t)n_tok) ||
+    if (!d2h(ctx->h_pack, d_counter, 16) || hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(fail(ctx, C3R_EHIP, "copying the token counters to the host failed"));
+    if (packed) n_tok = (int64_t)((unsigned long long *)ctx->h_pack)[1];          // (the kept sites' token bytes lie back to back)
+    if (!d2h(r->sites, d_sites_src, (size_t)n * sizeof(c3r_site_t)) || !d2h(r->tokb, ctx->d_tokb.p, (size_t)n_tok) ||
         !d2h(r->rec_off, ctx->d_recoff.p, (size_t)n * 4) ||
         (fresh_reads && (!d2h(r->hr->reads.data(), ctx->d_reads.p, (size_t)ctx->n_reads * sizeof(DevRead)) || !d2h(r->hr->seq.data(), ctx->d_seq.p, (size_t)ctx->n_seq_bytes + 16))))
         return bail(fail(ctx, C3R_EHIP, "copying sites / tokens / reads to the host failed"));
     int32_t *lstm_st = nullptr;
     rc = queue_lstm_status(ctx, &lstm_st);
     if (rc) return bail(rc);
-    if (!d2h(r->probs, ctx->net.d_probs, (size_t)n * C3R_NPROB * sizeof(float)) || hipStreamSynchronize(ctx->stream) != hipSuccess)
+    if (!d2h(r->probs, d_probs_src, (size_t)n * C3R_NPROB * sizeof(float)) || hipStreamSynchronize(ctx->stream) != hipSuccess)
         return bail(fail(ctx, C3R_EHIP, "copying probabilities to the host failed"));
     if ((rc = check_lstm_status(ctx, lstm_st))) return bail(rc);
     const auto t2 = now();
@@ -1898,7 +1929,8 @@ int c3r_rows_decode(c3r_rows *r, const char *ctg, int qual, int show_ref, int64_
     const DevRead *reads = r->reads;
     const RefView refv{r->ref, r->ref_len};
     const int64_t ref_start1 = r->ref_start1;
-    auto get_read = [&](uint32_t k) { return ReadView{seq, reads[k].seq_off, reads[k].l_seq}; };
+    const c3r_read_t *creads = r->creads;
+    auto get_read = [&](uint32_t k) { return creads ? ReadView{seq, creads[k].seq_off, creads[k].l_seq} : ReadView{seq, reads[k].seq_off, reads[k].l_seq}; };
     const PadView pads{r->padins && !r->padins->empty() ? r->padins->data() : nullptr, r->padins ? r->padins->size() : 0};
     // host threads: C3R_THREADS, else up to 32 (one process per GPU shares the node's cores with its peers)
     unsigned nt = std::max(1u, std::min(32u, usable_cpus()));
@@ -1951,7 +1983,7 @@ static void rows_release_inputs(c3r_rows *r) {
         std::lock_guard<std::mutex> g(ctx->pool_mu);
         if (ctx->stage_pool.size() < 3) ctx->stage_pool.push_back({r->stage, r->stage_cap});
         else stage_free(r->stage);
-        r->stage = nullptr; r->stage_cap = 0; r->sites = nullptr; r->tokb = nullptr; r->probs = nullptr; r->rec_off = nullptr; r->reads = nullptr; r->seq = nullptr;
+        r->stage = nullptr; r->stage_cap = 0; r->sites = nullptr; r->tokb = nullptr; r->probs = nullptr; r->rec_off = nullptr; r->reads = nullptr; r->seq = nullptr; r->creads = nullptr;
     }
     if (r->recs) { free(r->recs); r->recs = nullptr; r->n_recs = 0; }
     r->n = 0;

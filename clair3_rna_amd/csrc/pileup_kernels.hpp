@@ -2092,4 +2092,81 @@ __global__ __launch_bounds__(256) void k_pack_tokens(const c3r_site_t *__restric
     }
 }
 
+// ---- row snapshots without the sites the decoder prints nothing for.  Without --show_ref a site whose probabilities take the early
+// RefCall exit of the decoder (clair3_rna/call_variants.py:540-542: P(0/0) >= 0.5 and P(gt21 = ref ref) >= 0.5, decode.hpp call_site) leaves
+// no row, whatever its alt_info says, and so does a site whose reference class wins the first round of the decoder's arg-max — together 97 %
+// of the candidates of a trained model.  k_row_keep applies those very tests, an exclusive scan turns the flags into row numbers, and k_pack_rows moves only the kept sites: site record,
+// probabilities, packed tokens.  keep[n] is the scan's sentinel.
+__global__ __launch_bounds__(256) void k_row_keep(const c3r_site_t *__restrict__ sites, const float *__restrict__ probs, int n, int32_t *__restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { keep[i] = 0; return; }
+    const char c = sites[i].ref33[C3R_FLANK];
+    // iupac2acgt (decode.hpp): ACGTURYSWKMBDHVN -> ACGTTACCAGACAAAA, anything else A; then gt21 of the homozygous reference genotype
+    int rr = 0;                                                               // AA
+    if (c == 'C' || c == 'Y' || c == 'S' || c == 'B') rr = 4;                 // CC
+    else if (c == 'G' || c == 'K') rr = 7;                                    // GG
+    else if (c == 'T' || c == 'U') rr = 9;                                    // TT
+    const float *p = probs + (size_t)i * C3R_NPROB;
+    const float z0 = p[21], z1 = p[22], z2 = p[23];
+    bool ref_call = z0 >= 0.5f && p[rr] >= 0.5f;
+    // ... and the first round of the decoder's arg-max (call_site: `top == p_ref`): when no class product exceeds P(0/0) * P(gt21 = ref ref)
+    // the site is a RefCall before alt_info is looked at.  The same float32 products (one IEEE multiply each); p_ref must be a normal
+    // number so that a flushed denormal on either side cannot turn the comparison.
+    if (!ref_call) {
+        const float p_ref = z0 * p[rr];
+        float top = 0.f;
+        const int homo[4] = {0, 4, 7, 9}, het[6] = {1, 2, 3, 5, 6, 8};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) top = fmaxf(top, z1 * p[homo[k]]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) top = fmaxf(top, z2 * p[het[k]]);
+        top = fmaxf(top, fmaxf(z1 * p[15], z2 * p[15]));                      // InsIns
+        top = fmaxf(top, fmaxf(z1 * p[10], z2 * p[10]));                      // DelDel
+#pragma unroll
+        for (int k = 0; k < 4; ++k) top = fmaxf(top, fmaxf(p[16 + k] * z2, p[11 + k] * z2));      // base + Ins, base + Del
+        top = fmaxf(top, z2 * p[20]);                                         // InsDel
+        ref_call = p_ref >= 1e-30f && p_ref >= top;
+    }
+    keep[i] = ref_call ? 0 : 1;
+}
+// idx: the exclusive scan of the keep flags ([n + 1]); counters: [0] indel records, [1] token bytes handed out
+__global__ __launch_bounds__(256) void k_pack_rows(const c3r_site_t *__restrict__ sites, const c3r_token_t *__restrict__ tok, const float *__restrict__ probs,
+                                                    const int32_t *__restrict__ idx, int64_t n_sites, c3r_site_t *__restrict__ sites_c, float *__restrict__ probs_c,
+                                                    uint8_t *__restrict__ bytes, TokRec *__restrict__ recs, uint32_t *__restrict__ rec_off,
+                                                    unsigned long long *__restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int64_t site = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (site >= n_sites) return;
+    const int j = idx[site];
+    if (idx[site + 1] == j) return;                                           // not kept
+    const uint32_t off = sites[site].tok_off;
+    const int n_tok = sites[site].n_tok;
+    int cnt = 0;
+    for (int i = lane; i < n_tok; i += 64) cnt += tok[off + i].indel != 0;
+    for (int d = 32; d; d >>= 1) cnt += __shfl_xor(cnt, d);
+    uint32_t base = 0, bbase = 0;
+    if (lane == 0) {
+        base = cnt ? (uint32_t)atomicAdd(&counters[0], (unsigned long long)cnt) : 0u;
+        bbase = (uint32_t)atomicAdd(&counters[1], (unsigned long long)n_tok);
+        rec_off[j] = base;
+    }
+    base = __shfl(base, 0); bbase = __shfl(bbase, 0);
+    static_assert(sizeof(c3r_site_t) == 52 && offsetof(c3r_site_t, tok_off) == 48, "c3r_site_t layout");
+    if (lane < 13) reinterpret_cast<uint32_t *>(&sites_c[j])[lane] = lane == 12 ? bbase : reinterpret_cast<const uint32_t *>(&sites[site])[lane];
+    if (lane < C3R_NPROB) probs_c[(size_t)j * C3R_NPROB + lane] = probs[(size_t)site * C3R_NPROB + lane];
+    uint32_t run = 0;
+    for (int i0 = 0; i0 < n_tok; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < n_tok;
+        c3r_token_t t{};
+        if (valid) t = tok[off + i];
+        const bool f = valid && t.indel != 0;
+        const unsigned long long m = __ballot(f);
+        if (valid) bytes[bbase + i] = (uint8_t)((t.base & 31) | (t.rev ? 0x20 : 0) | (f ? 0x80 : 0));
+        if (f) recs[base + run + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = TokRec{t.read_idx, t.indel, t.qpos, t.del_after};
+        run += (uint32_t)__popcll(m);
+    }
+}
+
 }  // namespace c3r

@@ -182,6 +182,15 @@ int c3r_get_rows(c3r_ctx *ctx, char *out, int64_t cap);
  * new reads / a new reference (the snapshot keeps its contig's reference buffer alive).  c3r_rows_decode / c3r_rows_get work on the
  * snapshot from ANY thread, no GPU involved.  c3r_rows_free must be called before c3r_destroy of the context that made the snapshot. */
 int c3r_rows_begin(c3r_ctx *ctx, c3r_rows **out);
+/* The same with two ways of moving less.  drop_ref_calls != 0: the snapshot holds only the sites that can print a row when the decoder runs
+ * WITHOUT show_ref — a site whose probabilities take the decoder's early RefCall exit (P(0/0) >= 0.5 and P(gt21 = ref ref) >= 0.5,
+ * clair3_rna/call_variants.py:540-542) or whose reference class wins the first round of its arg-max (:730-760: no class product exceeds
+ * P(0/0) * P(ref ref)) prints nothing then, whatever its alt_info holds, so neither its record nor its tokens nor its
+ * probabilities leave the device (a trained model calls ~97 % of the candidates that way); decoding such a snapshot with show_ref != 0 is
+ * an error of the caller (those rows are gone).  host_reads / host_seq: the arrays that were handed to c3r_load_reads for the loaded contig,
+ * if the caller keeps them alive and unchanged until c3r_rows_free — the decoder then reads inserted bases from them in place instead of
+ * from a copy fetched back from the device (both NULL: fetched back, as c3r_rows_begin does). */
+int c3r_rows_begin_ex(c3r_ctx *ctx, int drop_ref_calls, const c3r_read_t *host_reads, const uint8_t *host_seq, c3r_rows **out);
 int c3r_rows_decode(c3r_rows *rows, const char *ctg, int qual, int show_ref, int64_t *out_len, int64_t *n_rows);
 int c3r_rows_get(c3r_rows *rows, char *out, int64_t cap);
 void c3r_rows_free(c3r_rows *rows);

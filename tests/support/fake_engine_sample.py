@@ -87,7 +87,7 @@ class FakeSnapshot(object):
 
 
 if os.environ.get("C3R_FAKE_SNAPSHOTS") == "1":          # the driver's detached path: c3r_rows_begin -> decode pool -> worker-side merge
-    FakeEngine.rows_begin = lambda self: FakeSnapshot(list(self._rows))
+    FakeEngine.rows_begin = lambda self, drop_ref_calls=False, host_reads=True: FakeSnapshot(list(self._rows))
     FakeEngine.reserve = lambda self, n: None
 capi.Engine = FakeEngine
 if __name__ == "__main__":

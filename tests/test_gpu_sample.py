@@ -258,3 +258,38 @@ def test_one_rank_on_its_eighth_of_the_host(tmp_path):
         assert n1 == max(1, n0 // 8) and 1 <= int(thr) <= n1 and int(infl) >= 1
     strip = lambda t: [l for l in t.split("\n") if not l.startswith("##cmdline=")]       # (the child's argv differs)
     assert strip(open(os.path.join(tmp, "out8", "output.vcf")).read()) == strip(open(got).read())
+
+
+@pytest.mark.parametrize("ref_bias", [0.0, 4.0])
+def test_snapshot_without_ref_calls_equals_the_full_snapshot(ref_bias):
+    """c3r_rows_begin_ex: with drop_ref_calls only the sites that survive the decoder's early RefCall exit (clair3_rna/call_variants.py:540-542,
+    applied on the device) are copied out, and the decoder reads inserted bases from the caller's own arrays.  Decoded without show_ref the
+    rows must be those of the full snapshot, byte for byte — with weights that call almost everything a variant and with a zygosity head
+    biased to 0/0 the way a trained model is (most sites dropped on the device)."""
+    from clair3_rna_amd import capi, synth
+    ref, rs, _ = synth.small_case(seed=77, ref_len=60000, n_genes=12, depth=25)
+    e = capi.Engine(0)
+    try:
+        e.set_params(min_coverage=2)
+        e.load_reads(rs); e.set_reference(1, ref)
+        e.load_weights(synth.random_weights(18, seed=9, ref_bias=ref_bias), 18)
+        n = e.scan(1, len(ref))
+        assert n > 500
+        e.infer(fetch=False)
+        full_all, n_all = e.rows_begin(host_reads=False).decode("chr20", qual=2, show_ref=True)
+        full, n_full = e.rows_begin(host_reads=False).decode("chr20", qual=2, show_ref=False)
+        inplace, n_inplace = e.rows_begin(host_reads=True).decode("chr20", qual=2, show_ref=False)
+        snap = e.rows_begin(drop_ref_calls=True)
+        with pytest.raises(ValueError):
+            snap.decode("chr20", qual=2, show_ref=True)
+        snap = e.rows_begin(drop_ref_calls=True)
+        filt, n_filt = snap.decode("chr20", qual=2, show_ref=False)
+        assert filt == full == inplace and n_filt == n_full == n_inplace
+        assert n_all == n and n_full < n_all
+        if ref_bias:
+            assert n_full < 0.5 * n_all, (n_full, n_all)        # (most candidates are reference calls, as with a trained model)
+        else:
+            assert n_full > 100
+        assert e.call_rows_text("chr20", qual=2, show_ref=False)[0] == full
+    finally:
+        e.close()
