@@ -216,26 +216,44 @@ def _block(entries, restart_interval=16):
     return bytes(body)
 
 
-def write_bundle(prefix, tensors, per_block=7):
-    """Write {key: float32 array} as a one-shard bundle in the same formats read_bundle parses."""
-    keys = sorted(tensors)
+def _string_tensor_bytes(strings):
+    """tensor_bundle's layout of a DT_STRING tensor in the data file: the elements' lengths as varint64s, the masked CRC32C of those length
+    bytes (4 bytes, little-endian), then the strings back to back."""
+    lens = b"".join(_put_varint(len(x)) for x in strings)
+    return lens + struct.pack("<I", _mask(crc32c(lens))) + b"".join(strings)
+
+
+def write_bundle(prefix, tensors, per_block=7, block_size=None, extra=()):
+    """Write {key: float32 array} as a one-shard bundle in the same formats read_bundle parses.
+    block_size: flush a data block once its entries reach that many bytes (LevelDB's TableBuilder rule; restart points every 16 keys) instead
+    of every `per_block` keys — 4096 is LevelDB's default block size, 262144 the one TensorFlow's table options carry.
+    extra: (key, dtype enum, shape, raw bytes) entries of other types, as a Keras object-based checkpoint holds them: the serialized object
+    graph under `_CHECKPOINTABLE_OBJECT_GRAPH` (DT_STRING = 7, scalar), `save_counter` and optimizer `iter` (DT_INT64 = 9)."""
+    items = [(k.encode(), _DT_FLOAT, tuple(np.shape(tensors[k])), np.ascontiguousarray(tensors[k], dtype="<f4").tobytes()) for k in tensors]
+    items += [(k.encode() if isinstance(k, str) else k, dt, tuple(shp), bytes(raw)) for k, dt, shp, raw in extra]
+    items.sort(key=lambda it: it[0])                       # the table's keys are sorted bytewise ('_' sorts behind the upper-case layer names)
     data, ents = bytearray(), []
-    for k in keys:
-        a = np.ascontiguousarray(tensors[k], dtype="<f4")
-        raw = a.tobytes()
-        shape = b"".join(b"\x12" + _put_varint(len(_put_varint(d)) + 1) + b"\x08" + _put_varint(d) for d in a.shape)
-        e = b"\x08" + _put_varint(_DT_FLOAT) + b"\x12" + _put_varint(len(shape)) + shape + b"\x20" + _put_varint(len(data)) + \
+    for k, dt, shp, raw in items:
+        shape = b"".join(b"\x12" + _put_varint(len(_put_varint(d)) + 1) + b"\x08" + _put_varint(d) for d in shp)
+        e = b"\x08" + _put_varint(dt) + b"\x12" + _put_varint(len(shape)) + shape + (b"\x20" + _put_varint(len(data)) if len(data) else b"") + \
             b"\x28" + _put_varint(len(raw)) + b"\x35" + struct.pack("<I", _mask(crc32c(raw)))
-        ents.append((k.encode(), e))
+        ents.append((k, e))
         data += raw
-    header = b"\x08\x01" + b"\x1a\x02\x08\x01"          # num_shards = 1, version { producer: 1 }
+    header = b"\x08\x01" + b"\x1a\x02\x08\x01"          # num_shards = 1, (endianness LITTLE = 0: the proto3 default is not written,) version { producer: 1 }
     ents = [(b"", header)] + ents
+    groups, cur, cur_bytes = [], [], 0
+    for k, v in ents:
+        cur.append((k, v)); cur_bytes += len(k) + len(v) + 3
+        if (block_size is None and len(cur) >= per_block) or (block_size is not None and cur_bytes >= block_size):
+            groups.append(cur); cur, cur_bytes = [], 0
+    if cur:
+        groups.append(cur)
     out, index = bytearray(), []
-    for i in range(0, len(ents), per_block):
-        blk = _block(ents[i:i + per_block])
+    for g in groups:
+        blk = _block(g)
         off = len(out)
         out += blk + b"\x00" + struct.pack("<I", _mask(crc32c(blk + b"\x00")))
-        index.append((ents[min(i + per_block, len(ents)) - 1][0], _put_varint(off) + _put_varint(len(blk))))
+        index.append((g[-1][0], _put_varint(off) + _put_varint(len(blk))))
     meta = _block([])
     mo = len(out)
     out += meta + b"\x00" + struct.pack("<I", _mask(crc32c(meta + b"\x00")))

@@ -172,3 +172,41 @@ def test_hand_built_prefix_compressed_multi_block_table(tmp_path):
         open(prefix + ".index", "wb").write(bytes(g))
         with pytest.raises(ValueError):
             tfckpt.read_bundle(prefix)
+
+
+@pytest.mark.parametrize("block_size", [1024, 4096, 262144])
+def test_bundle_laid_out_the_way_tensorflow_writes_it(tmp_path, block_size):
+    """A bundle as `model.save_weights(prefix)` of an object-based Keras model leaves it (clair3_rna/call_variants.py:1472 loads exactly that):
+    one shard, uncompressed table blocks flushed by size with restart points every 16 keys, keys sorted bytewise, the BundleHeaderProto under
+    the empty key, and — besides the float variables — the serialized object graph (DT_STRING), `save_counter` and the optimizer's `iter`
+    (DT_INT64), float optimizer slots.  The reader must skip what is not a model weight by dtype / name and still find every one of the
+    2,072,216 parameters of the 18-channel model exactly once."""
+    import struct
+    w = synth.random_weights(18, seed=23)
+    assert len(w) == 2072216
+    named = _keras_like(w, 18, 0)
+    named["optimizer/beta_1/.ATTRIBUTES/VARIABLE_VALUE"] = np.full((), 0.9, np.float32)
+    named["optimizer/learning_rate/.ATTRIBUTES/VARIABLE_VALUE"] = np.full((), 1e-3, np.float32)
+    named["L4/kernel/.OPTIMIZER_SLOT/optimizer/m/.ATTRIBUTES/VARIABLE_VALUE"] = np.zeros((10560, 128), np.float32)
+    named["L4/kernel/.OPTIMIZER_SLOT/optimizer/v/.ATTRIBUTES/VARIABLE_VALUE"] = np.ones((10560, 128), np.float32)
+    graph = b"\x0a\x2a\x0a\x05LSTM1" + bytes(range(64)) * 40               # (an opaque serialized TrackableObjectGraph: never parsed)
+    extra = [("_CHECKPOINTABLE_OBJECT_GRAPH", 7, (), tfckpt._string_tensor_bytes([graph])),
+             ("save_counter/.ATTRIBUTES/VARIABLE_VALUE", 9, (), struct.pack("<q", 3)),
+             ("optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE", 9, (), struct.pack("<q", 123456))]
+    prefix = str(tmp_path / "variables")
+    tfckpt.write_bundle(prefix, named, block_size=block_size, extra=extra)
+    idx = open(prefix + ".index", "rb").read()
+    assert idx[-8:] == struct.pack("<Q", 0xdb4775248b80fb57)
+    back = tfckpt.read_bundle(prefix)
+    assert "_CHECKPOINTABLE_OBJECT_GRAPH" not in back and "save_counter/.ATTRIBUTES/VARIABLE_VALUE" not in back      # skipped by dtype
+    assert set(back) == set(named) and all(np.array_equal(back[k], named[k]) for k in named)
+    blob = tfckpt.weights_from_bundle(prefix, 18)
+    assert blob.size == 2072216 and np.array_equal(blob, w)
+    assert np.array_equal(io.load_weights(prefix, 18), w)
+    # the 36 entries of this model fit one block at LevelDB's default 4 KB and at TensorFlow's 256 KB; at 1 KB the table is multi-block
+    from clair3_rna_amd.tfckpt import _varint
+    foot = idx[-48:]
+    _mo, p = _varint(foot, 0); _ms, p = _varint(foot, p); io_, p = _varint(foot, p); is_, p = _varint(foot, p)
+    n_blocks = len(tfckpt._read_block(idx, io_, is_))
+    assert (n_blocks > 1) == (block_size == 1024)
+    assert b"LSTM2/backward_layer/cell/recurrent_kernel" not in idx or idx.count(b"LSTM2/backward_layer/cell/") <= 2       # prefix compression at work
