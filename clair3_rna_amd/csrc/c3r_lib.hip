@@ -909,7 +909,8 @@ static size_t event_capacity(const c3r_ctx *ctx, int n_regions, const int64_t *c
     int cur = 0, maxov = 0;
     for (auto &e : edge) { cur += e.second; maxov = std::max(maxov, cur); }
     // (fused path: a position lies in its own span and in the flank of at most one neighbour)
-    return ev_cap + (size_t)maxov * (size_t)spans_per_position * (size_t)ctx->n_indel_ops;
+    // (a deep tile also takes 2 x 8-byte hash slots per event behind its events: 2/3 of a record each)
+    return ev_cap + 2 * ((size_t)maxov * (size_t)spans_per_position * (size_t)ctx->n_indel_ops);
 }
 
 // samtools mpileup -d (default 8000), restated from htslib's bam_plp_push / bam_plp_next (third-party, absent: parity

@@ -301,6 +301,7 @@ __device__ __forceinline__ bool sorted_contains(const int32_t *a, int n, int v) 
 }
 
 constexpr int AF_TAB = 8192;
+constexpr int EV_HASH_MIN = 1024;      // indel events of a tile from which their alleles are counted through a hash table (tile_columns)
 enum WalkMode { ACCUM = 0, SCATTER = 1, FIRSTSEEN = 2 };
 constexpr int FS_CAP = 32;     // positions per batch of the first-seen (tie-break) pass
 
@@ -769,25 +770,71 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
                 atomicMax(&M.cnt[pl * C + me.ch], eq);
             }
         } else {
+            // A deep tile (thousands of events: coverage in the thousands) counts its alleles through a hash table in the global scratch,
+            // one region of 2 n slots per position behind the tile's events: an allele's FIRST event claims a slot (CAS) and stands for it,
+            // every event of the same allele (ev_equal against the slot's representative — an equivalence: kind, length, bases, pads and, but
+            // for the '='-only insertions, strand) adds one.  The all-pairs count below is quadratic in the depth: at mpileup's cap of 8000
+            // reads a span spent 14 of its 22 ms there (profiles/r5/deep_locus_phases.txt); it stays for the shallow tiles, where it is cheaper.
+            const bool hashed = ev_total > EV_HASH_MIN;
+            const unsigned long long ev_units = (unsigned long long)((ev_total + 15) & ~15);
+            const unsigned long long tab_units = hashed ? ((unsigned long long)ev_total * 2ull * sizeof(uint2) + sizeof(EvRec) - 1) / sizeof(EvRec) : 0ull;
             auto events = [&](EvRec *ev) __attribute__((always_inline)) {
                 walk_records<C, SCATTER>(a, s, slo, shi, t0, t1, region, ev);
+                uint2 *tab = reinterpret_cast<uint2 *>(ev + ev_units);
+                if (hashed) for (int i = tid; i < 2 * ev_total; i += SCAN_THREADS) tab[i] = make_uint2(0xffffffffu, 0u);
                 __threadfence_block();
                 __syncthreads();
-                for (int e = tid; e < ev_total; e += SCAN_THREADS) {
-                    const EvRec me = ev[e];
-                    const int pl = me.pl;
-                    const int b = M.evoff[pl];
-                    const int32_t *rw = &M.cnt[pl * C];
-                    const int n = rw[C3R_I] + rw[C3R_i] + rw[C3R_D] + rw[C3R_d];
-                    int eq = 0;
-                    for (int j = 0; j < n; ++j) eq += ev_equal(a, me, ev[b + j]) ? 1 : 0;
-                    atomicMax(&M.cnt[pl * C + me.ch], eq);
+                if (!hashed) {
+                    for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+                        const EvRec me = ev[e];
+                        const int pl = me.pl;
+                        const int b = M.evoff[pl];
+                        const int32_t *rw = &M.cnt[pl * C];
+                        const int n = rw[C3R_I] + rw[C3R_i] + rw[C3R_D] + rw[C3R_d];
+                        int eq = 0;
+                        for (int j = 0; j < n; ++j) eq += ev_equal(a, me, ev[b + j]) ? 1 : 0;
+                        atomicMax(&M.cnt[pl * C + me.ch], eq);
+                    }
+                    return;
+                }
+                auto slot_of = [&](const EvRec &me, int n) -> uint32_t {
+                    // equal alleles hash alike: the strand counts unless the insertion may be the '='-only kind that has none
+                    const bool maybe_caseless = (me.kind & 2) && me.key == 0;
+                    uint64_t h = me.key * 0x9E3779B97F4A7C15ull + (uint64_t)me.len * 0xC2B2AE3D27D4EB4Full + (uint64_t)((me.kind & 6) | (maybe_caseless ? 0 : (me.kind & 1)));
+                    h ^= h >> 29;
+                    return (uint32_t)((h * 0xBF58476D1CE4E5B9ull) >> 33) % (uint32_t)(2 * n);
+                };
+                for (int pass = 0; pass < 2; ++pass) {
+                    // pass 0: claim or join the allele's slot; pass 1: every event reads its allele's count
+                    for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+                        const EvRec me = ev[e];
+                        const int pl = me.pl;
+                        const int b = M.evoff[pl];
+                        const int32_t *rw = &M.cnt[pl * C];
+                        const int n = rw[C3R_I] + rw[C3R_i] + rw[C3R_D] + rw[C3R_d];
+                        uint2 *reg = tab + 2 * b;
+                        uint32_t h = slot_of(me, n);
+                        for (int probe = 0; probe < 2 * n; ++probe) {
+                            uint32_t rep;
+                            if (pass == 0) rep = atomicCAS(&reg[h].x, 0xffffffffu, (uint32_t)e);
+                            else rep = __hip_atomic_load(&reg[h].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const bool mine = pass == 0 ? (rep == 0xffffffffu) : (rep == (uint32_t)e);
+                            if (mine || (rep != 0xffffffffu && ev_equal(a, me, ev[rep]))) {
+                                if (pass == 0) atomicAdd(&reg[h].y, 1u);
+                                else atomicMax(&M.cnt[pl * C + me.ch], (int)__hip_atomic_load(&reg[h].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                break;
+                            }
+                            h = h + 1u == (uint32_t)(2 * n) ? 0u : h + 1u;
+                        }
+                    }
+                    __threadfence_block();
+                    __syncthreads();
                 }
             };
-            if (tid == 0) M.evbase = atomicAdd(a.ev_cursor, (unsigned long long)((ev_total + 15) & ~15));
+            if (tid == 0) M.evbase = atomicAdd(a.ev_cursor, ev_units + tab_units);
             __syncthreads();
             const unsigned long long evb = M.evbase;
-            if (evb + (unsigned long long)((ev_total + 15) & ~15) > a.ev_cap) {
+            if (evb + ev_units + tab_units > a.ev_cap) {
                 // cannot happen with the host's sizing (c3r_pileup_scan_regions); if it ever does, no write leaves the buffer and the
                 // scan call fails instead of corrupting device memory
                 if (tid == 0) *a.ev_overflow = 1;
@@ -1447,12 +1494,18 @@ __device__ __forceinline__ TokenAt token_at(const DevRead &rd, int r, int p, con
 //                      writes the token of the last intron column;
 //   3. ref-skip pass — covering reads not done show a ref-skip ('>' / '<'): their default tokens fill the remaining slots.
 // Every slot is written exactly once, by one lane.
-constexpr int TK_NB = 32, TK_RCH = 512, TK_MAXB = TK_RCH / 64;
+constexpr int TK_NB = 32, TK_RCH = 512, TK_MAXB = TK_RCH / 64, TK_MASKS = TK_NB * TK_MAXB;
+// The cover masks are a table of TK_MASKS 64-read words shared by the batch's candidates: 32 candidates x 512 reads for the usual span,
+// and for a span that more reads reach (deep coverage) fewer candidates per batch and more reads per chunk — 16 x 1024 ... 1 x 16384 — so
+// that the records are walked once per BATCH and not once per 512 reads (at mpileup's depth cap a span with one candidate walked its
+// 267 k records 53 times: 110 ms; profiles/r5/deep_locus_phases.txt).  Chunks beyond TK_RCH reads take the headers from memory instead of
+// the staged copies.
 struct TokLds {
     int32_t pos[TK_RCH], end[TK_RCH];
     uint8_t rev[TK_RCH];
-    unsigned long long mask[TK_NB][TK_MAXB], done[TK_NB][TK_MAXB];
-    int32_t pre[TK_NB][TK_MAXB];
+    unsigned long long mask[TK_MASKS], done[TK_MASKS];        // [candidate][block of 64 reads], row stride maxb
+    int32_t pre[TK_MASKS];
+    int32_t maxb;                                             // 64-read blocks per chunk (row stride of the three tables)
     int32_t lpos[TK_NB], toff[TK_NB], rank0[TK_NB], rank1[TK_NB];
     unsigned long long cmask[TILE / 64];       // the batch's candidates as a bit per position of the tile
     int32_t cpre[TILE / 64];                   // candidates (of the batch) before each 64-position word
@@ -1469,15 +1522,15 @@ __device__ __forceinline__ unsigned long long tok_cand_bits(const TokLds &K, int
 
 __device__ __forceinline__ void tok_emit(TokLds &K, c3r_token_t *tok, long long tok_cap, int c, int ri, int r, int indel, uint32_t qpos, int base, bool rev,
                                          uint32_t del_after = 0) {
-    const int b = ri >> 6, bit = ri & 63;
-    const unsigned long long m = K.mask[c][b];
+    const int b = c * K.maxb + (ri >> 6), bit = ri & 63;
+    const unsigned long long m = K.mask[b];
     if (!((m >> bit) & 1ull)) return;                         // (not a covering read by its header: nothing to place)
-    const long long slot = (long long)K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << bit) - 1ull));
+    const long long slot = (long long)K.toff[c] + K.pre[b] + __popcll(m & ((1ull << bit) - 1ull));
     if (slot >= tok_cap) return;
     int4 v;
     v.x = r; v.y = indel; v.z = (int)qpos; v.w = base | ((rev ? 1 : 0) << 8) | (int)(min(del_after, 65535u) << 16);
     *reinterpret_cast<int4 *>(&tok[slot]) = v;
-    atomicOr(&K.done[c][b], 1ull << bit);
+    atomicOr(&K.done[b], 1ull << bit);
 }
 
 // One record of the tile's range against the batch's candidates.  `bits`: the candidates the piece covers (tok_cand_bits over its positions
@@ -1523,10 +1576,23 @@ __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0
                                             c3r_token_t *tok, long long tok_cap, const TileOut *pre = nullptr) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    for (int cb = 0; cb < nc; cb += TK_NB) {
-        const int nb = min(TK_NB, nc - cb);
+    // blocks of 64 reads per chunk (a power of two, all the tile's reads if the table takes them) and candidates per batch
+    int maxb = TK_MAXB;
+    while (maxb < TK_MASKS && maxb * 64 < hi - lo) maxb <<= 1;
+    const int nb_max = TK_MASKS / maxb, chunk = maxb * 64;
+    const bool staged = chunk <= TK_RCH;
+    // read rc + i of the chunk as the cover pass sees it: {pos, end (INT32_MIN: filtered out or dropped), reverse strand}
+    auto header = [&](int rc, int i, int &rpos, int &rend, bool &rrev) {
+        if (staged) { rpos = K.pos[i]; rend = K.end[i]; rrev = K.rev[i] != 0; return; }
+        const DevRead rd = a.reads[rc + i];
+        const bool pass = read_passes(rd, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, rc + i);
+        rpos = rd.pos; rend = pass ? rd.end : INT32_MIN; rrev = (rd.flag & 16) != 0;
+    };
+    for (int cb = 0; cb < nc; cb += nb_max) {
+        const int nb = min(nb_max, nc - cb);
         __syncthreads();
         if (tid < TILE / 64) K.cmask[tid] = 0ull;
+        if (tid == 0) K.maxb = maxb;
         __syncthreads();
         if (tid < nb) {
             int lp, off;
@@ -1536,25 +1602,28 @@ __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0
         }
         __syncthreads();
         if (tid < TILE / 64) { int pre = 0; for (int k = 0; k < tid; ++k) pre += __popcll(K.cmask[k]); K.cpre[tid] = pre; }
-        for (int rc = lo; rc < hi; rc += TK_RCH) {
-            const int re = min(hi, rc + TK_RCH), nr = re - rc, nblk = (nr + 63) >> 6;
+        for (int rc = lo; rc < hi; rc += chunk) {
+            const int re = min(hi, rc + chunk), nr = re - rc, nblk = (nr + 63) >> 6;
             __syncthreads();
+            if (staged)
             for (int i = tid; i < nr; i += SCAN_THREADS) {
                 if (pre && rc == lo && i == tid) { K.pos[i] = pre->rd_pos; K.end[i] = pre->rd_end; K.rev[i] = pre->rd_rev ? 1 : 0; continue; }
                 const DevRead rd = a.reads[rc + i];
                 const bool pass = read_passes(rd, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, rc + i);
                 K.pos[i] = rd.pos; K.end[i] = pass ? rd.end : INT32_MIN; K.rev[i] = (rd.flag & 16) ? 1 : 0;
             }
-            for (int i = tid; i < TK_NB * TK_MAXB; i += SCAN_THREADS) (&K.done[0][0])[i] = 0ull;
+            for (int i = tid; i < TK_MASKS; i += SCAN_THREADS) K.done[i] = 0ull;
             __syncthreads();
             for (int c = wave; c < nb; c += WAVES) {
                 const int p = t0 + K.lpos[c];
                 int run = K.rank0[c];
                 for (int b = 0; b < nblk; ++b) {
                     const int i = 64 * b + lane;
-                    const bool cov = i < nr && K.pos[i] <= p && K.end[i] > p;
+                    int rpos = 0, rend = INT32_MIN; bool rrev = false;
+                    if (i < nr) header(rc, i, rpos, rend, rrev);
+                    const bool cov = i < nr && rpos <= p && rend > p;
                     const unsigned long long m = __ballot(cov);
-                    if (lane == 0) { K.mask[c][b] = m; K.pre[c][b] = run; }
+                    if (lane == 0) { K.mask[c * maxb + b] = m; K.pre[c * maxb + b] = run; }
                     run += __popcll(m);
                 }
                 if (lane == 0) K.rank1[c] = run;
@@ -1602,13 +1671,15 @@ __device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0
             __syncthreads();
             for (int c = wave; c < nb; c += WAVES) {
                 for (int b = 0; b < nblk; ++b) {
-                    const unsigned long long m = K.mask[c][b], rest = m & ~K.done[c][b];
+                    const unsigned long long m = K.mask[c * maxb + b], rest = m & ~K.done[c * maxb + b];
                     if ((rest >> lane) & 1ull) {
                         const int i = 64 * b + lane;
-                        const long long slot = (long long)K.toff[c] + K.pre[c][b] + __popcll(m & ((1ull << lane) - 1ull));
+                        const long long slot = (long long)K.toff[c] + K.pre[c * maxb + b] + __popcll(m & ((1ull << lane) - 1ull));
                         if (slot >= tok_cap) continue;
+                        int rpos, rend; bool rrev;
+                        header(rc, i, rpos, rend, rrev);
                         int4 v;
-                        v.x = rc + i; v.y = 0; v.z = 0; v.w = 17 | ((int)K.rev[i] << 8);
+                        v.x = rc + i; v.y = 0; v.z = 0; v.w = 17 | ((rrev ? 1 : 0) << 8);
                         *reinterpret_cast<int4 *>(&tok[slot]) = v;
                     }
                 }
