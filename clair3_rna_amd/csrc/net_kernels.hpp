@@ -350,6 +350,12 @@ __device__ __forceinline__ void lds_wait(int *c, int target, int *tmo) {
 // RTS ("run-time scale"): the weights were packed with a power-of-two scale below 2^12 because some |w| would not fit f16 at 2^12
 // (net_load, NetState::wlog2); the scale (layer 2: wsc = 2^s, wun = 2^-s; fused L4: wun4) then comes in as kernel arguments.  With RTS
 // = false — every set of weights seen so far — the constants fold exactly as before.
+// C3R_PROBE_Y1 (timing only, results wrong): what a y1 format with a lo plane of half the bytes — an 8-bit block-scaled residual instead of
+// f16 — could gain at most: layer 2 skips every other lo-plane row of its LDS-DMA (a quarter of its y1 reads), layer 1 stores only half
+// of its lo plane (a quarter of its y1 writes).  profiles/r5/y1_traffic_probe.txt.
+#ifndef C3R_PROBE_Y1
+#define C3R_PROBE_Y1 0
+#endif
 template <int ABL = 0, bool RTS = false>
 __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict__ xin, const half8 *__restrict__ Wp,
                                                       const float *__restrict__ bp, int n, const half8 *__restrict__ W4p,
@@ -395,6 +401,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_w8(const _Float16 *__restrict_
 #pragma unroll
         for (int r = 0; r < 2 * KC / 4; ++r) {
             const int row = (wave & 3) * (2 * KC / 4) + r, pl = row / KC, kc = row % KC;
+            if (C3R_PROBE_Y1 && pl == 1 && (kc & 1)) continue;      // timing probe (results wrong): a quarter of the y1 read traffic gone
             const _Float16 *src = xin + (size_t)pl * plane_in + (((size_t)tt_ * KC + kc) * ns + xsite) * 8;
             __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)&xs[pl][kc][0][0], 16, 0, 0);
         }
@@ -1169,7 +1176,7 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
             _Float16 *yp = y + ((size_t)t * (2 * HV) + dir * HV + blk) * nstride * 8 + (uint32_t)(site0 + 32 * sb + j) * 8 + 4 * hh;
             *(half4 *)yp = vh;
             if constexpr (!YQ) {
-                *(half4 *)(yp + plane_out) = vl;
+                if (!(C3R_PROBE_Y1 && (blk & 1))) *(half4 *)(yp + plane_out) = vl;
             } else {                                     // the fp8 plane precision 2's layer 2 reads (k_lstm2_mx's x layout)
                 int w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], 0, false);
                 w_lo = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], w_lo, true);
