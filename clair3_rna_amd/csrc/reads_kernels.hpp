@@ -621,28 +621,31 @@ __global__ __launch_bounds__(256) void k_legacy_count(const DevRead *reads, int 
     }
     cnt[i] = c;
 }
-// single-block exclusive scan of the int2 counts in place (a few ten thousand reads; the legacy path is not on the hot path); totals to *total
+// single-block exclusive scan of the int2 counts in place; totals to *total.  Eight consecutive items per thread and round (8192 per round):
+// the carry between rounds is the serial part — one item per thread made the 68 k reads of a MAS-Seq chr20 67 rounds of two barriers each,
+// most of the 0.16 ms the legacy tables cost a 30-channel pass.
 __global__ __launch_bounds__(1024) void k_legacy_scan(int2 *data, int n, int2 *total) {
+    constexpr int IT = 8;
     __shared__ int2 wtot[16];
     __shared__ int2 carry_s;
     if (threadIdx.x == 0) carry_s = make_int2(0, 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + (int)threadIdx.x;
-        const int2 v = i < n ? data[i] : make_int2(0, 0);
-        int2 incl = v;
+    for (int base = 0; base < n; base += 1024 * IT) {
+        const int i0 = base + (int)threadIdx.x * IT;
+        int2 v[IT], sum = make_int2(0, 0);
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int tx = __shfl_up(incl.x, off, 64), ty = __shfl_up(incl.y, off, 64);
-            if (lane >= off) { incl.x += tx; incl.y += ty; }
-        }
+        for (int k = 0; k < IT; ++k) { v[k] = (i0 + k < n) ? data[i0 + k] : make_int2(0, 0); sum.x += v[k].x; sum.y += v[k].y; }
+        int2 incl;
+        incl.x = wave_incl_scan(sum.x); incl.y = wave_incl_scan(sum.y);
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
         int2 wb = make_int2(0, 0), tot = wb;
         for (int w = 0; w < 16; ++w) { const int2 t = wtot[w]; if (w < wave) { wb.x += t.x; wb.y += t.y; } tot.x += t.x; tot.y += t.y; }
         const int2 c = carry_s;
-        if (i < n) data[i] = make_int2(c.x + wb.x + incl.x - v.x, c.y + wb.y + incl.y - v.y);
+        int2 run = make_int2(c.x + wb.x + incl.x - sum.x, c.y + wb.y + incl.y - sum.y);
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { if (i0 + k < n) data[i0 + k] = run; run.x += v[k].x; run.y += v[k].y; }
         __syncthreads();
         if (threadIdx.x == 0) carry_s = make_int2(c.x + tot.x, c.y + tot.y);
         __syncthreads();
