@@ -15,5 +15,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $A
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
+# the additional configurations of the default line (configs[3] 30 channels, configs[4] 500x, the 20,000x locus): their kernels by full
+# template name (k_fused_tiles<30>, k_lstm1_rs<30, ...>) next to the 18-channel ones
+if [ "$PREC" = f16x3 ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_extra -- python3 $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile --no_fast --no_resident --no_overlap --no_strong --precision $PREC > $OUT/stats_extra.log 2>&1
+fi
 python3 $R/bench.py --precision $PREC > $OUT/bench.json 2> $OUT/bench.err
 ls -R $OUT | head -40

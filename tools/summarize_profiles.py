@@ -61,6 +61,12 @@ def main():
             "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
             "--no_fast --no_resident --no_overlap --no_strong --precision %s   (MI355X; durations in ns; one context: 1 priming + 1 warm-up + 2 timed passes, "
             "c3r_load_reads inside every pass)\n" % prec + text)
+    sx = sorted(glob.glob(os.path.join(src, "stats_extra", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    if sx:
+        open(os.path.join(out, "%s_kernel_stats_extra_%s.csv" % (tag, prec)), "w").write(
+            "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
+            "--no_fast --no_resident --no_overlap --no_strong --precision %s   (MI355X; ns): the chr20 passes AND the additional configurations "
+            "(phased_1gpu: the <30> instantiations; stress_500x; depth_cap_20000x), one context each\n" % prec + open(sx[-1]).read())
     # 1b. the LAST pass of the same trace, kernel by kernel (the --stats averages above include the first pass, which sizes the buffers
     # with a tile kernel that stops early and then repeats it): a pass starts at its k_prep<false> launch
     tr = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
