@@ -274,7 +274,8 @@ __device__ __forceinline__ int walk_serial(const ReadInfo &R, Emit &&emit, bool 
     w.begin(R.pos);
     auto seg = [](uint32_t, uint32_t, long long, uint32_t, long long, bool, bool) {};
     struct NOp { uint32_t op, len, y, prev, prev2; long long x; };
-    NOp q[2];
+    NOp q0, q1;                               // (two named slots, not an array indexed by nq: that array was the kernels' 80 B of scratch)
+    q0.op = q1.op = 15u; q0.len = q1.len = 0; q0.y = q1.y = 0; q0.prev = q1.prev = 15u; q0.prev2 = q1.prev2 = 15u; q0.x = q1.x = 0;
     int nq = 0;
     uint32_t prev = 15u, prev2 = 15u, y = 0;
     long long x = R.pos;
@@ -286,16 +287,17 @@ __device__ __forceinline__ int walk_serial(const ReadInfo &R, Emit &&emit, bool 
     const int err = walk_norm(R.cig, R.n_cig, [&](uint32_t op, uint32_t len) {
         NOp c;
         c.op = op; c.len = len; c.y = y; c.prev = prev; c.prev2 = prev2; c.x = x;
-        if (nq == 2) { flush(q[0], q[1].op, q[1].len, op, len); q[0] = q[1]; q[1] = c; }
-        else q[nq++] = c;
+        if (nq == 2) { flush(q0, q1.op, q1.len, op, len); q0 = q1; q1 = c; }
+        else if (nq == 1) { q1 = c; nq = 2; }
+        else { q0 = c; nq = 1; }
         if (op_ref(op)) x += len;
         if (op_qry(op)) y += len;
         prev2 = prev; prev = op;
         w.op(op, len, seg);
     });
     if (err) return err;
-    if (nq == 2) { flush(q[0], q[1].op, q[1].len, 15u, 0u); flush(q[1], 15u, 0u, 15u, 0u); }
-    else if (nq == 1) flush(q[0], 15u, 0u, 15u, 0u);
+    if (nq == 2) { flush(q0, q1.op, q1.len, 15u, 0u); flush(q1, 15u, 0u, 15u, 0u); }
+    else if (nq == 1) flush(q0, 15u, 0u, 15u, 0u);
     w.close(seg);
     return w.bad;
 }
