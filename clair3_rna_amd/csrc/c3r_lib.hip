@@ -93,6 +93,7 @@ struct c3r_ctx {
     DevBuf d_keep, d_sites_c, d_probs_c;   // c3r_rows_begin_ex(drop_ref_calls): keep flags / row numbers, the kept sites' records and probabilities
     std::vector<DevRead> h_reads;          // lazily: ensure_host_reads
     std::vector<int32_t> h_prefmax;        // lazily: host copy of the prefix max of read ends (passing reads)
+    std::vector<uint32_t> h_zone_sc, h_zone_ec;   // depth_cap_mask: reads per 256-position bin by start / by exclusive end
     bool host_reads_valid = false;
     std::vector<uint8_t> h_seq;            // lazily: ensure_host_seq (decode reads inserted bases)
     bool host_seq_valid = false;
@@ -919,6 +920,13 @@ static size_t event_capacity(const c3r_ctx *ctx, int n_regions, const int64_t *c
 // engine's list — the kept reads with exclusive end > start - 1 — holds more than max_depth reads.  Sequential by
 // nature, so it runs here on the host, per region, and only when the data can reach the cap at all (then the reads'
 // headers are fetched back from the device).  *d_drop: the per-region bit masks on the device, or null when no read is discarded.
+//
+// Only inside the contig's HOT ZONES: with the reads counted into 256-position bins by start and by exclusive end,
+//   B(c) = reads started before the end of bin c  -  reads whose end lies before bin c
+// bounds the list at the push of every read that starts in bin c (whatever was discarded earlier, whatever the region), so a read that
+// starts in a bin with B(c) <= max_depth is always kept.  The sequential rule runs over the maximal runs of bins above the cap, each
+// entered with the list it would hold there: the kept reads from before the zone that reach into it.  A contig with one 20,000x locus
+// costs a counting pass over its read headers and a heap over that locus' reads, not a heap over every read of every region.
 static int depth_cap_mask(c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, const uint32_t **d_drop, int *drop_words_out) {
     *d_drop = nullptr;
     const int drop_words = (int)(((size_t)ctx->n_reads + 31) / 32);
@@ -927,29 +935,85 @@ static int depth_cap_mask(c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts
     if (!(ctx->prm.max_depth > 0 && (int64_t)ctx->max_cover > ctx->prm.max_depth)) return C3R_OK;
     int rc;
     if ((rc = ensure_host_reads(ctx))) return rc;
+    const std::vector<DevRead> &R = ctx->h_reads;
+    const size_t n = R.size();
+    if (!n) return C3R_OK;
+    auto kept_by_filters = [&](const DevRead &rd) { return !(flag_fails(rd.flag, ctx->prm.excl_flags) || rd.mapq < ctx->prm.min_mq || rd.end <= rd.pos); };
+    // ---- hot zones [z0, z1) in positions, ascending
+    constexpr int ZSH = 8;
+    const int64_t zb0 = (int64_t)R.front().pos >> ZSH;
+    int64_t top = R.front().pos;
+    for (size_t i = 0; i < n; ++i) if (kept_by_filters(R[i])) top = std::max<int64_t>(top, R[i].end);
+    const size_t nz = (size_t)((top >> ZSH) - zb0) + 2;
+    std::vector<uint32_t> &sc = ctx->h_zone_sc, &ec = ctx->h_zone_ec;
+    sc.assign(nz, 0u); ec.assign(nz, 0u);
+    for (size_t i = 0; i < n; ++i) {
+        if (!kept_by_filters(R[i])) continue;
+        ++sc[(size_t)(((int64_t)R[i].pos >> ZSH) - zb0)];
+        ++ec[(size_t)(((int64_t)R[i].end >> ZSH) - zb0)];
+    }
+    std::vector<std::pair<int64_t, int64_t>> zones;
+    {
+        int64_t started = 0, ended_before = 0;
+        bool open = false;
+        for (size_t c = 0; c < nz; ++c) {
+            started += sc[c];
+            const bool hot = started - ended_before > (int64_t)ctx->prm.max_depth;
+            const int64_t p = ((int64_t)c + zb0) << ZSH;
+            if (hot && !open) { zones.push_back({p, p}); open = true; }
+            if (open) { if (hot) zones.back().second = p + (1 << ZSH); else open = false; }
+            ended_before += ec[c];
+        }
+    }
+    if (zones.empty()) return C3R_OK;
+    if (const char *e = getenv("C3R_CAP_ALL")) if (*e == '1') { zones.clear(); zones.push_back({(int64_t)R.front().pos, top + 1}); }     // (A/B aid: the rule over every read, as before round 5)
     ctx->h_drop.assign((size_t)n_regions * drop_words, 0u);
     bool any = false;
+    auto first_at_or_after = [&](int64_t p) {           // first read with pos >= p (reads are sorted by pos)
+        size_t lo = 0, hi = n;
+        while (lo < hi) { const size_t m = (lo + hi) / 2; if ((int64_t)R[m].pos < p) lo = m + 1; else hi = m; }
+        return lo;
+    };
     for (int r = 0; r < n_regions; ++r) {
         int64_t es = ctg_starts[r] - C3R_WINDOW, ee = ctg_ends[r] + C3R_WINDOW;
         if (es < 1) es = 1;
         const int32_t beg0 = (int32_t)(es - 1), end0 = (int32_t)ee;                // rows for [beg0, end0)
-        std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> live;
-        int32_t last_pos = INT_MIN;
-        size_t i = (size_t)(std::upper_bound(ctx->h_prefmax.begin(), ctx->h_prefmax.end(), beg0) - ctx->h_prefmax.begin());
-        for (; i < ctx->h_reads.size(); ++i) {
-            const DevRead &rd = ctx->h_reads[i];
-            if (rd.pos >= end0) break;
-            if (flag_fails(rd.flag, ctx->prm.excl_flags) || rd.mapq < ctx->prm.min_mq || rd.end <= rd.pos) continue;
-            if (rd.end <= beg0) continue;                                            // not fetched for this region
-            while (!live.empty() && live.top() <= rd.pos - 1) live.pop();
-            const bool first = rd.pos != last_pos;
-            last_pos = rd.pos;
-            if (!first && (int64_t)live.size() > ctx->prm.max_depth) {
-                ctx->h_drop[(size_t)r * drop_words + (i >> 5)] |= 1u << (i & 31);
-                any = true;
-                continue;
+        uint32_t *drop = ctx->h_drop.data() + (size_t)r * drop_words;
+        // the first read fetched for this region: the first one whose end (as a prefix maximum) passes beg0
+        const size_t i_region = (size_t)(std::upper_bound(ctx->h_prefmax.begin(), ctx->h_prefmax.end(), beg0) - ctx->h_prefmax.begin());
+        for (const auto &z : zones) {
+            if (z.first >= end0) break;
+            const size_t i0 = std::max(first_at_or_after(z.first), i_region);
+            if (i0 >= n || R[i0].pos >= end0 || (int64_t)R[i0].pos >= z.second) continue;
+            std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> live;
+            // the list on entry: kept reads of this region from before i0 that still reach R[i0].pos - 1 ... (popped lazily below, so "reach
+            // the zone" is enough)
+            const int32_t reach = (int32_t)std::max<int64_t>(std::max<int64_t>(z.first - 1, beg0), INT32_MIN);
+            size_t j = (size_t)(std::upper_bound(ctx->h_prefmax.begin(), ctx->h_prefmax.end(), reach) - ctx->h_prefmax.begin());
+            for (j = std::max(j, i_region); j < i0; ++j) {
+                const DevRead &rd = R[j];
+                if (!kept_by_filters(rd) || rd.end <= beg0 || rd.end <= reach) continue;
+                if (drop[j >> 5] >> (j & 31) & 1u) continue;                         // discarded in an earlier zone
+                live.push(rd.end);
             }
-            live.push(rd.end);
+            int32_t last_pos = INT_MIN;
+            // (the read before i0 starts before the zone or was not fetched: R[i0] is the first pushed for its position either way — unless
+            // i0 is the region's first read, where the rule starts afresh as well)
+            for (size_t i = i0; i < n; ++i) {
+                const DevRead &rd = R[i];
+                if (rd.pos >= end0 || (int64_t)rd.pos >= z.second) break;
+                if (!kept_by_filters(rd)) continue;
+                if (rd.end <= beg0) continue;                                            // not fetched for this region
+                while (!live.empty() && live.top() <= rd.pos - 1) live.pop();
+                const bool first = rd.pos != last_pos;
+                last_pos = rd.pos;
+                if (!first && (int64_t)live.size() > ctx->prm.max_depth) {
+                    drop[i >> 5] |= 1u << (i & 31);
+                    any = true;
+                    continue;
+                }
+                live.push(rd.end);
+            }
         }
     }
     if (any) {

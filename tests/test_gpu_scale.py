@@ -324,3 +324,30 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     per_rank = j["config"]["sites_per_step_per_rank"]
     assert abs(j["value"] - 2 * per_rank / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-3        # whole-job aggregate over both ranks
     assert j["roofline"]["kernel"] == "k_lstm2" and j.get("cpu_baseline") is None      # the CPU baseline is an N = 1 leg
+
+
+def test_depth_cap_between_separate_deep_loci(eng):
+    """mpileup's depth cap on a contig whose expressed loci lie far apart: the rule runs zone by zone (only where more reads than the
+    cap can be live at all), each zone entered with the reads that reach into it — the lines and tensors of every chunk, and of chunks
+    that cut through a locus, equal the oracle's, which walks every read of the region."""
+    from clair3_rna_amd import capi, synth
+    L = 400000
+    ref, rs, _ = synth.generate_contig(contig_len=L, seed=8117, depth=260.0, expressed_frac=0.03, intron_lo=100.0, intron_hi=4000.0)
+    ref = ref.decode()
+    n_changed = 0
+    for cap in (40, 150):
+        eng.params = capi.default_params()
+        eng.set_bed(0, None); eng.set_bed(1, None)
+        eng.set_params(min_coverage=2, max_depth=cap)
+        for a, b in [(1, L), (1, 130000), (130000, 131000), (131000, 270000), (270000, L)]:
+            got = H.engine_chunk(eng, rs, ref, 1, a, b)
+            exp = H.oracle_chunk(rs, ref, 1, a, b, min_coverage=2, max_depth=cap)
+            assert got["lines"] == exp["lines"], (cap, a, b, H.first_diff(got["lines"], exp["lines"]))
+            assert np.array_equal(got["X"], exp["X"])
+            if (a, b) == (1, L):
+                nocap = H.oracle_chunk(rs, ref, 1, a, b, min_coverage=2, max_depth=0)
+                n_changed += int(nocap["lines"] != exp["lines"])
+                assert len(exp["lines"]) > 50
+    assert n_changed == 2                                  # the cap bit at both settings
+    eng.params = capi.default_params()
+    eng.set_params()
