@@ -404,13 +404,19 @@ def Run(args, log=None):
         """The GPU contexts: created, given the weights and the arithmetic once the first fetches are under way (0.1-0.2 s that
         used to come before the first BAM byte was read)."""
         for _ in range(n_ctx):
+            t0_ = time()
             engines.append(capi.Engine(args.gpu_id))
+            mark("ctx%d" % (len(engines) - 1), "create", t0_)
         errs = []
 
         def prepare(e):
             try:
+                t0_ = time()
                 e.load_weights(weights, channels)             # (packing the weights into the kernels' layouts is host work: side by side)
+                mark("ctx%d" % engines.index(e), "weights", t0_)
+                t0_ = time()
                 e.set_precision(args.gpu_precision)
+                mark("ctx%d" % engines.index(e), "precision", t0_)
             except BaseException as ex:
                 errs.append(ex)
         th = [threading.Thread(target=prepare, args=(e,)) for e in engines[1:]]

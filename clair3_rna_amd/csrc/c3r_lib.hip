@@ -138,7 +138,7 @@ struct c3r_ctx {
     // ---- scan state
     int32_t reg_beg0 = 0, reg_end0 = 0;   // first region of the most recent scan (c3r_get_columns)
     int64_t n_pos = 0;                    // position slots of the most recent scan (all regions, tile-padded)
-    int32_t max_cover = 0;                // upper bound of htslib's read list at any read's start (LoadStats): at or below max_depth the cap cannot bite
+    int32_t max_cover = 0;                // upper bound of htslib's read list at any read's start (LoadStats): below max_depth the cap cannot bite
     std::vector<uint32_t> h_drop;         // depth cap of the most recent scan: [n_regions][drop_words] bit per read
     DevBuf d_drop;
     std::vector<TileGeo> h_geo;           // tile geometry of the most recent scan; re-uploaded only when it changes
@@ -917,7 +917,8 @@ static size_t event_capacity(const c3r_ctx *ctx, int n_regions, const int64_t *c
 // samtools mpileup -d (default 8000), restated from htslib's bam_plp_push / bam_plp_next (third-party, absent: parity
 // unpinned; the oracle restates the same rule independently): reads arrive in file order, filtered, and only those
 // overlapping the region; a read is discarded iff it is not the first read pushed for its start position and the
-// engine's list — the kept reads with exclusive end > start - 1 — holds more than max_depth reads.  Sequential by
+// engine's node pool — the kept reads with exclusive end > start - 1, plus the list's empty tail node — holds more than
+// max_depth nodes (`iter->mp->cnt > iter->maxcnt`): reads that all start on one position pile up to exactly max_depth.  Sequential by
 // nature, so it runs here on the host, per region, and only when the data can reach the cap at all (then the reads'
 // headers are fetched back from the device).  *d_drop: the per-region bit masks on the device, or null when no read is discarded.
 //
@@ -927,12 +928,13 @@ static size_t event_capacity(const c3r_ctx *ctx, int n_regions, const int64_t *c
 // starts in a bin with B(c) <= max_depth is always kept.  The sequential rule runs over the maximal runs of bins above the cap, each
 // entered with the list it would hold there: the kept reads from before the zone that reach into it.  A contig with one 20,000x locus
 // costs a counting pass over its read headers and a heap over that locus' reads, not a heap over every read of every region.
+constexpr int PLP_POOL_EXTRA = 1;      // nodes of htslib's pool that are not reads: the list's empty tail
 static int depth_cap_mask(c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, const uint32_t **d_drop, int *drop_words_out) {
     *d_drop = nullptr;
     const int drop_words = (int)(((size_t)ctx->n_reads + 31) / 32);
     *drop_words_out = drop_words;
-    // (max_cover bounds the engine's read list at every read's start, k_prep / k_bin_scan: at or below the cap no read can be discarded)
-    if (!(ctx->prm.max_depth > 0 && (int64_t)ctx->max_cover > ctx->prm.max_depth)) return C3R_OK;
+    // (max_cover bounds the engine's read list at every read's start, k_prep / k_bin_scan: below the cap no read can be discarded)
+    if (!(ctx->prm.max_depth > 0 && (int64_t)ctx->max_cover + PLP_POOL_EXTRA > ctx->prm.max_depth)) return C3R_OK;
     int rc;
     if ((rc = ensure_host_reads(ctx))) return rc;
     const std::vector<DevRead> &R = ctx->h_reads;
@@ -958,7 +960,7 @@ static int depth_cap_mask(c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts
         bool open = false;
         for (size_t c = 0; c < nz; ++c) {
             started += sc[c];
-            const bool hot = started - ended_before > (int64_t)ctx->prm.max_depth;
+            const bool hot = started - ended_before + PLP_POOL_EXTRA > (int64_t)ctx->prm.max_depth;
             const int64_t p = ((int64_t)c + zb0) << ZSH;
             if (hot && !open) { zones.push_back({p, p}); open = true; }
             if (open) { if (hot) zones.back().second = p + (1 << ZSH); else open = false; }
@@ -1007,7 +1009,7 @@ static int depth_cap_mask(c3r_ctx *ctx, int n_regions, const int64_t *ctg_starts
                 while (!live.empty() && live.top() <= rd.pos - 1) live.pop();
                 const bool first = rd.pos != last_pos;
                 last_pos = rd.pos;
-                if (!first && (int64_t)live.size() > ctx->prm.max_depth) {
+                if (!first && (int64_t)live.size() + PLP_POOL_EXTRA > ctx->prm.max_depth) {
                     drop[i >> 5] |= 1u << (i & 31);
                     any = true;
                     continue;

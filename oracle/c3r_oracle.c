@@ -192,10 +192,15 @@ static int flag_fails(unsigned flag, int excl_flags) {
 /* Depth cap, restated from htslib's pileup engine (bam_plp_push / bam_plp_next; third-party, absent here: parity unpinned).
  * Reads reach the engine in file order, already filtered by flag / MAPQ, and only those overlapping the region.  A read is
  * discarded iff it starts at the position the engine currently stands on — i.e. it is NOT the first read pushed for its start
- * position — and the engine's read list holds more than max_depth reads at that moment.  The list holds every kept read that
- * has not been retired yet; a read is retired while the column at or after its (exclusive) end is processed, and all columns
- * left of the new read's start have been processed by then: the list is the kept reads with exclusive end > start - 1.
+ * position — and the engine's node pool holds more than max_depth nodes at that moment (`iter->mp->cnt > iter->maxcnt`).  The pool
+ * holds the read list plus the list's empty tail node (allocated when the iterator is made and again after every kept read), so the
+ * test is  list + 1 > max_depth:  reads that all start on one position (an amplicon) pile up to exactly max_depth, the 8000 that
+ * samtools users see.  (Rounds 1-4 restated it as list > max_depth, one read more; htslib is absent here, so this stays unpinned —
+ * the constant below is the one place to change.)  The list holds every kept read that has not been retired yet; a read is retired
+ * while the column at or after its (exclusive) end is processed, and all columns left of the new read's start have been processed by
+ * then: the list is the kept reads with exclusive end > start - 1.
  * max_depth <= 0: no cap.  Marks dropped[i] = 1. */
+#define ORC_PLP_POOL_EXTRA 1      /* nodes of the pool that are not reads: the list's tail */
 static void depth_cap(const c3r_read_t *reads, int64_t n_reads, const uint32_t *cigar, int64_t beg0, int64_t end0_incl,
                       int min_mq, int excl_flags, int max_depth, uint8_t *dropped) {
     memset(dropped, 0, (size_t)(n_reads > 0 ? n_reads : 1));
@@ -213,7 +218,7 @@ static void depth_cap(const c3r_read_t *reads, int64_t n_reads, const uint32_t *
         n_live = w;
         const int first = (r->pos != last_pos);
         last_pos = r->pos;
-        if (!first && n_live > max_depth) { dropped[i] = 1; continue; }
+        if (!first && n_live + ORC_PLP_POOL_EXTRA > max_depth) { dropped[i] = 1; continue; }
         ends[n_live++] = r->pos + rl;
     }
     free(ends);

@@ -163,3 +163,29 @@ def test_new_printer_rows_through_the_oracle_parser():
     assert old["tensor"][I] == new["tensor"][I] == 3 and old["tensor"][I1] == new["tensor"][I1] == 3
     assert old["tensor"][D] == 0 and new["tensor"][D] == 3 and new["tensor"][D1] == 3
     assert [k for k, _n in new["alt"] if k.startswith("D")] == ["DA"] and not [k for k, _n in old["alt"] if k.startswith("D")]
+
+
+def test_depth_cap_follows_the_pileup_engines_node_pool():
+    """mpileup -d, hand-derived from htslib's bam_plp_push: a read is discarded iff the engine already stands on its start position (it
+    is not the first read pushed there) and the node pool — the read list plus the list's empty tail node — holds more than max_depth
+    nodes.  Reads that all start on one position therefore pile up to exactly max_depth (the 8000 samtools users see at amplicons)."""
+    cap = 3
+    recs = [R(9, "4M", "ACGT") for _ in range(6)]
+    p = pile(recs, max_depth=cap)
+    assert p[10][3] == "3" and p[13][3] == "3"                     # first read kept unseen, then list + 1 <= 3 twice more
+    # staggered starts: the first read of a position is always kept, whatever the list holds
+    recs = [R(9, "6M", "ACGTAC")] * 5 + [R(10, "4M", "CGTA")] * 2 + [R(12, "2M", "TA")]
+    p = pile(recs, max_depth=cap)
+    assert p[10][3] == "3"                                          # position 10: three of the five
+    assert p[11][3] == "4"                                          # + the first read of position 11; its twin meets a pool of 5 > 3
+    assert p[13][3] == "5" and p[13][4].count("^") == 1             # + the only read of position 13 (first pushed there)
+    # a read is retired while the column AT its exclusive end is processed — after the reads that start on that column were pushed: three
+    # reads whose last base sits right before the newcomers still fill the list (1 kept: the first), one position further they are gone
+    recs = [R(9, "2M", "AC")] * 3 + [R(11, "2M", "GT")] * 4
+    p = pile(recs, max_depth=cap)
+    assert p[10][3] == "3" and p[11][3] == "3" and p[12][3] == "1"
+    recs = [R(9, "2M", "AC")] * 3 + [R(12, "2M", "TA")] * 4
+    p = pile(recs, max_depth=cap)
+    assert p[11][3] == "3" and p[13][3] == "3"
+    # no cap
+    assert pile([R(9, "4M", "ACGT") for _ in range(6)], max_depth=0)[10][3] == "6"
