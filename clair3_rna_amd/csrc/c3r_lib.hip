@@ -80,6 +80,7 @@ struct c3r_ctx {
     // legacy tables for token_at (30-channel mode only), built on demand: normalised CIGARs, aligned segments in read order
     DevBuf d_lcnt;
     bool legacy_valid = false;
+    bool legacy_wanted = false;           // a fused 30-channel scan of this context has met a column whose haplotype channels depend on the reads' order
     LoadStats *h_stats = nullptr;          // pinned
     int32_t *h_lstm = nullptr;             // pinned: this context's copy of the layer-2 time-out word (queue_lstm_status)
     void *h_pack = nullptr;                // pinned: the indel-record count of k_pack_tokens
@@ -1351,8 +1352,14 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     f.ticket = (int32_t *)(lb + 64); f.alloc = (unsigned long long *)(lb + lb_alloc); f.overflow = (int32_t *)(lb + 16);
     f.rescale = raw_rerun ? 0 : 1; f.max_depth = ctx->prm.max_depth_rescale;
     f.span_info = (int4 *)ctx->d_span.p;
-    if (C == C3R_CH_PHASED && (rc = ensure_legacy_tables(ctx))) return rc;
-    f.ph.reads = a.reads; f.ph.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.ph.rseg_first = (const uint32_t *)ctx->d_rseg_first.p; f.ph.cigar = (const uint32_t *)ctx->d_cigar.p; f.ph.seq = a.seq;
+    // 30 channels: the per-read op / segment tables behind the ordered recompute of a flagged column (an IUPAC read base, an indel right
+    // behind a ref-skip) are built only for a context that has met such a column: aligners emit neither, and the tables cost 0.12 ms of
+    // a 0.7-ms MAS-Seq chr20 pass.  Without them a flagged column raises bit 2 of the scan's flags and the scan is repeated with them.
+    const bool env_eager = [] { const char *e = getenv("C3R_LEGACY_EAGER"); return e && *e == '1'; }();
+    if (C == C3R_CH_PHASED && (ctx->legacy_wanted || env_eager) && (rc = ensure_legacy_tables(ctx))) return rc;
+    const bool have_tables = C == C3R_CH_PHASED && ctx->legacy_valid;
+    f.ph.reads = a.reads; f.ph.rsegs = have_tables ? (const DevSeg *)ctx->d_rsegs.p : nullptr; f.ph.rseg_first = have_tables ? (const uint32_t *)ctx->d_rseg_first.p : nullptr;
+    f.ph.cigar = (const uint32_t *)ctx->d_cigar.p; f.ph.seq = a.seq;
     f.ph.min_mq = a.min_mq; f.ph.excl_flags = a.excl_flags; f.ph.drop = a.drop; f.ph.drop_words = a.drop_words;
     const size_t tbytes = (size_t)C3R_WINDOW * C * 4;
     // What this scan may write.  A small scan has one allocator and dense output: whatever the buffers can take beyond what the batch
@@ -1432,6 +1439,14 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             fprintf(stderr, "[k_fused_tiles] %llu spans; per span: reads in range %.1f, records in range %.1f, indel events %.1f; us per span: zero %.2f | cover+walk %.2f | scans %.2f | events %.2f | gates %.2f | first-seen %.2f | select+store %.2f | tokens %.2f\n",
                     d[15], d[13] / nt, d[14] / nt, d[12] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[6] / nt / 100, d[7] / nt / 100, d[8] / nt / 100);
             fprintf(stderr, "   tail: row mask %.2f | scan %.2f | allocator atomic %.2f us\n", d[9] / nt / 100, d[10] / nt / 100, d[11] / nt / 100);
+        }
+        if ((ctx->h_scan[2] & 4) && !f.ph.rsegs) {
+            // a flagged column and no tables yet: build them (this context keeps doing so from now on) and run the scan again
+            ctx->legacy_wanted = true;
+            if ((rc = ensure_legacy_tables(ctx))) return rc;
+            f.ph.rsegs = (const DevSeg *)ctx->d_rsegs.p; f.ph.rseg_first = (const uint32_t *)ctx->d_rseg_first.p; f.ph.cigar = (const uint32_t *)ctx->d_cigar.p;
+            --attempt;
+            continue;
         }
         if (ctx->h_scan[6]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
         if (n_cand < 0 || n_tok < 0) return fail(ctx, C3R_EOVERFLOW, "too many candidates or tokens for one scan");

@@ -1895,10 +1895,13 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             // a column whose haplotype channels depend on the ORDER of the reads (see k_phase_recompute): redone in place, one thread
             // per flagged column
             if (o.is_row && M.odd[tid]) {
-                int cnt[12];
-                phase_column(f.ph, x0 + tid, rng.x, rng.y, tg.region, cnt);
+                if (!f.ph.rsegs) atomicOr(f.overflow, 4);         // no op / segment tables yet: the host builds them and repeats the scan
+                else {
+                    int cnt[12];
+                    phase_column(f.ph, x0 + tid, rng.x, rng.y, tg.region, cnt);
 #pragma unroll
-                for (int k = 0; k < 12; ++k) M.cnt[tid * C + C3R_AP + k] = cnt[k];
+                    for (int k = 0; k < 12; ++k) M.cnt[tid * C + C3R_AP + k] = cnt[k];
+                }
             }
         }
         // ---- the window rule: 33 contiguous rows = 33 set bits in the span's row mask (published by tile_columns with its last barrier)

@@ -138,3 +138,50 @@ def test_splice_junction_padding_matches_reference_order_semantics(eng, channels
     assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
     assert np.array_equal(got["X"], exp["X"])
     _fresh(eng)
+
+
+def test_phased_scan_builds_the_ordered_recompute_tables_only_when_a_column_needs_them():
+    """30 channels, fused path: the per-read op / segment tables behind the ordered haplotype recompute are built only once a scan meets
+    a column that needs them (an IUPAC read base here); that scan is repeated with the tables and equals the oracle, and the context keeps
+    building them from then on."""
+    from clair3_rna_amd import capi, synth
+    from clair3_rna_amd.reads import ReadSet
+    L = 600000
+    ref, rs, _ = synth.generate_contig(contig_len=L, seed=424, depth=30.0, expressed_frac=0.05, intron_lo=100.0, intron_hi=4000.0, phased=True, platform="hifi")
+    ref = ref.decode()
+    e = capi.Engine(0)
+    try:
+        e.set_params(channels=30)
+        e.set_profiling(True)
+        got = H.engine_chunk(e, rs, ref, 1, 1, L)
+        exp = H.oracle_chunk(rs, ref, 1, 1, L, channels=30)
+        assert len(exp["lines"]) > 20 and got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
+        assert "k_legacy_tables" not in e.kernel_stats()
+        # the same reads, one of them with an IUPAC base on a covered column
+        seq = rs.seq.copy()
+        k = len(rs.reads) // 2
+        r = rs.reads[k]
+        q = 0                                                       # a query position well inside the read's first long match
+        for c in rs.cigar[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]:
+            op, ln = int(c) & 15, int(c) >> 4
+            if op in (0, 7, 8) and ln >= 12:
+                q += 6
+                break
+            if op in (0, 1, 4, 7, 8):
+                q += ln
+        byte, hi = int(r["seq_off"]) + q // 2, q % 2 == 0
+        seq[byte] = ((3 << 4) | (seq[byte] & 15)) if hi else ((seq[byte] & 0xf0) | 3)       # 'M' (A or C) there
+        rs2 = ReadSet(rs.reads, rs.cigar, seq)
+        e.reset_kernel_stats()
+        got = H.engine_chunk(e, rs2, ref, 1, 1, L)
+        exp = H.oracle_chunk(rs2, ref, 1, 1, L, channels=30)
+        assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
+        assert np.array_equal(got["X"], exp["X"])
+        st = e.kernel_stats()
+        assert st["k_legacy_tables"]["launches"] >= 1 and st["k_fused_tiles"]["launches"] >= 2      # found out, built, scanned again
+        # from now on the tables come with the reads
+        e.reset_kernel_stats()
+        got = H.engine_chunk(e, rs, ref, 1, 1, L)
+        assert "k_legacy_tables" in e.kernel_stats()
+    finally:
+        e.close()
