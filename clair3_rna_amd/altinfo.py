@@ -45,9 +45,12 @@ def inserted_text(readset, read_idx, qpos, n_bases, rev, pads=None):
     return "".join(out)
 
 
-def alt_dict_from_tokens(tokens, readset, ref_seq, ref_start, pos, pads=None):
+def alt_dict_from_tokens(tokens, readset, ref_seq, ref_start, pos, pads=None, depth=None):
     """tokens: TOKEN_DTYPE slice for one site (BAM order). ref_seq[0] is 1-based ref_start.
+    depth: the site record's depth — the engine writes tokens only for reads that show something other than the reference base or a
+    ref-skip (since round 5), so the column's depth cannot be counted from them; None: one token per covering read, counted here.
     Returns (OrderedDict alt, depth)."""
+    site_depth = depth
     ref_base = evc_base(ref_seq[pos - ref_start])
     alt = OrderedDict()
     depth = alt_count = ins_count = del_count = 0
@@ -79,6 +82,8 @@ def alt_dict_from_tokens(tokens, readset, ref_seq, ref_start, pos, pads=None):
             k = "D" + ref_seq[a:a + (-ind)]
             alt[k] = alt.get(k, 0) + 1
             del_count += 1
+    if site_depth is not None:
+        depth = int(site_depth)
     ref_count = max(0, depth - del_count - ins_count - alt_count)
     if ref_count > 0:
         alt["R" + ref_base] = alt.get("R" + ref_base, 0) + ref_count
@@ -97,7 +102,7 @@ def format_lines(ctg, sites, tensors_raw, tokens, readset, ref_seq, ref_start, p
     for i, s in enumerate(sites):
         pos = int(s["pos"])
         tk = tokens[int(s["tok_off"]):int(s["tok_off"]) + int(s["n_tok"])]
-        alt, _ = alt_dict_from_tokens(tk, readset, ref_seq, ref_start, pos, pads)
+        alt, _ = alt_dict_from_tokens(tk, readset, ref_seq, ref_start, pos, pads, depth=int(s["depth"]))
         ints = " ".join(str(v) for v in tensors_raw[i].reshape(-1).tolist())
         out.append("%s\t%d\t%s\t%s\t%s" % (ctg, pos, s["ref33"].decode(), ints, alt_info_string(int(s["depth"]), alt)))
     return out

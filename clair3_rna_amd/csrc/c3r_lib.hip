@@ -1151,8 +1151,8 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
     if ((rc = ensure(ctx, ctx->d_blockcnt, (size_t)(n_cblocks + 1) * 4))) return rc;
     if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_skipmax, (size_t)n_pos * 4))) return rc;
     // d_small: [0..7] ev_cursor (u64), [8..11] event-scratch overflow flag, [12..15] n_cand, [16..19] n_tok, [20..23] n_tile_list,
-    //          [24..27] n_tile_list2 (pruned intron-only tiles)
-    int32_t init[7] = {0, 0, 0, 0, 0, 0, 0};
+    //          [24..27] n_tile_list2 (pruned intron-only tiles), [28..31] tokens written, [32..35] tokens that found no slot (k_tile_tokens)
+    int32_t init[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_small.p, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_lastrow.p, 0xff, (size_t)n_regions * 4, ctx->stream));      // -1
     HIPCHK(ctx, hipMemsetAsync(ctx->d_flags.p, 0, (size_t)n_pos, ctx->stream));
@@ -1255,9 +1255,11 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
     if ((rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + n_cand) * 4, (size_t)base_cand * 4))) return rc;
     hipLaunchKernelGGL(k_iota, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, ctx->stream, (int32_t *)ctx->d_winidx.p + base_cand, (int)n_cand, (int)base_row);      // (windows in site order)
     {
-        if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_tokcnt.p, (int)n_cand, (int32_t *)((char *)ctx->d_small.p + 16)))) return rc;
+        // token SLOTS per candidate (the gates' bound of the reads with something to say, TileOut::cov) -> first slots; [n_cand] = their total
+        HIPCHK(ctx, hipMemsetAsync((int32_t *)ctx->d_tokcnt.p + n_cand, 0, 4, ctx->stream));
+        if ((rc = device_excl_scan(ctx, (int32_t *)ctx->d_tokcnt.p, (int)n_cand + 1, (int32_t *)((char *)ctx->d_small.p + 16)))) return rc;
     }
-    int32_t n_tok = 0;
+    int32_t n_tok = 0;                   // slots
     HIPCHK(ctx, hipMemcpyAsync(&n_tok, (char *)ctx->d_small.p + 16, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = ensure_keep(ctx, ctx->d_tok, std::max<size_t>((size_t)(base_tok + n_tok) * sizeof(c3r_token_t), 16),
@@ -1268,12 +1270,17 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
         t.cand_idx = (const int32_t *)ctx->d_cand.p; t.tile_cand = (const int2 *)ctx->d_tile_cand.p;
         t.tok_off = (const int32_t *)ctx->d_tokcnt.p; t.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
         t.tok = (c3r_token_t *)ctx->d_tok.p; t.tok_base = (int32_t)base_tok;     // (sized exactly above)
+        t.totals = (int32_t *)((char *)ctx->d_small.p + 28);
         Launch L(ctx, "k_tokens");
         hipLaunchKernelGGL(k_tile_tokens, dim3(std::min(n_tiles, list_grid())), dim3(SCAN_THREADS), 0, ctx->stream, t);
     }
+    int32_t tok_done[2] = {0, 0};        // tokens written, tokens that found no slot
+    HIPCHK(ctx, hipMemcpyAsync(tok_done, (char *)ctx->d_small.p + 28, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (tok_done[1]) return fail(ctx, C3R_EOVERFLOW, "internal: %d tokens found no slot (the gates' bound of a site's tokens was too small)", tok_done[1]);
     ctx->tokens_ready = true;
     ctx->n_cand = base_cand + n_cand;
-    ctx->n_tok += n_tok;
+    ctx->n_tok += tok_done[0];
     ctx->n_rows = base_row + n_cand; ctx->n_tokspace = base_tok + n_tok;
     HIPCHK(ctx, hipGetLastError());
     return C3R_OK;
@@ -1449,6 +1456,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             continue;
         }
         if (ctx->h_scan[6]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
+        if (ctx->h_scan[2] & 8) return fail(ctx, C3R_EOVERFLOW, "internal: tokens found no slot (the gates' bound of a site's tokens was too small)");
         if (n_cand < 0 || n_tok < 0) return fail(ctx, C3R_EOVERFLOW, "too many candidates or tokens for one scan");
         if (raw_rerun) {
             if (ctx->h_scan[2] & 1) {
@@ -1477,7 +1485,8 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     ctx->n_tok += n_tok;
     // (one allocator: dense output, the next scan of the batch appends; several: the scan's whole row / token space is taken)
     ctx->n_rows = base_row + (nsh == 1 ? (int64_t)n_cand : want_c * nsh);
-    ctx->n_tokspace = base_tok + (nsh == 1 ? (int64_t)n_tok : want_t * nsh);
+    // (token SLOTS: what the allocators handed out — a site reserves the gates' bound and n_tok counts what was written)
+    ctx->n_tokspace = base_tok + (nsh == 1 ? (int64_t)(((const unsigned long long *)(ctx->h_scan + 16))[0] >> 32) : want_t * nsh);
     return C3R_OK;
 }
 
@@ -2034,7 +2043,7 @@ int c3r_rows_decode(c3r_rows *r, const char *ctg, int qual, int show_ref, int64_
                 const uint8_t by = tb[k];
                 if (by & 0x80) { const TokRec &q = *rc_++; return TokView{by & 31, q.indel, q.read_idx, q.qpos, q.del_after, (by & 0x20) != 0}; }
                 return TokView{by & 31, 0, 0u, 0u, 0u, (by & 0x20) != 0};
-            }, get_read, refv, ref_start1, sites[(size_t)i].pos, alt, depth_tok, pads);
+            }, get_read, refv, ref_start1, sites[(size_t)i].pos, alt, depth_tok, pads, sites[(size_t)i].depth);
             if (vcf_row(ctg, sites[(size_t)i].pos, sites[(size_t)i].ref33, sites[(size_t)i].depth, alt, probs + (size_t)i * C3R_NPROB, qual,
                         show_ref != 0, part[t]))
                 cnt[t]++;

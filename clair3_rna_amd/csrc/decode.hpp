@@ -85,8 +85,10 @@ struct PadView {
     }
 };
 template <typename NextTok, typename GetRead>
+// site_depth >= 0: the tokens are only those of reads that show something other than the reference base or a ref-skip (what the kernels
+// write since round 5) and the column's depth comes from the site record; < 0: one token per covering read, the depth is counted here.
 inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
-                            AltDict &alt, int &depth_out, const PadView pads = PadView{nullptr, 0}) {
+                            AltDict &alt, int &depth_out, const PadView pads = PadView{nullptr, 0}, int site_depth = -1) {
     alt.clear();
     const int64_t ri = pos1 - ref_start1;
     char rb = (ri >= 0 && ri < (int64_t)ref.size()) ? ref[(size_t)ri] : 'N';
@@ -127,6 +129,7 @@ inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView
             alt_add(alt, "D" + ref.substr((size_t)a, (size_t)(e - a)), 1); del_count++;
         }
     }
+    if (site_depth >= 0) depth = site_depth;
     const int ref_count = std::max(0, depth - del_count - ins_count - alt_count);
     if (ref_count > 0) alt_add(alt, std::string("R") + rb, ref_count);
     depth_out = depth;

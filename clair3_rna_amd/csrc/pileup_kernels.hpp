@@ -685,8 +685,8 @@ struct alignas(16) TileMem {
     EvRec ev[EV_LDS > 0 ? EV_LDS : 1];
     uint8_t evord[EV_LDS > 0 ? EV_LDS : 4];     // the captured events' indices, bucketed by position
 };
-struct TileOut { bool is_row, cand; int depth, cov; int rd_pos, rd_end; bool rd_rev; };     // rd_*: the header of read lo + tid as the coverage pass saw it
-                                                                                             // (end = INT32_MIN: filtered out / dropped / beyond hi) — the token pass's first 256 reads
+struct TileOut { bool is_row, cand; int depth, cov; };     // cov: the token slots the position needs if it becomes a candidate — an upper bound of the reads that show
+                                                           // something other than the reference base or a ref-skip there (tile_tokens)
 
 // The columns of the positions [t0, t1) (at most TILE of them, thread tid <-> position t0 + tid) from the reads [lo, hi) and the
 // records [slo, shi) of the pile table: accumulators in LDS, indel alleles, the per-position gates (src/create_tensor_pileup.py:259-299, :536-556),
@@ -718,10 +718,9 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     const uint8_t rb = (rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
     const int r0 = lo + tid;
     int rd_pos = 0, rd_end = INT32_MIN;                       // read lo + tid as the coverage sees it (end = INT32_MIN: not a covering read)
-    bool rd_rev = false;
     if (r0 < hi && !(C3R_ABL(a) & 4)) {
         const DevRead rd0 = a.reads[r0];
-        rd_pos = rd0.pos; rd_rev = (rd0.flag & 16) != 0;
+        rd_pos = rd0.pos;
         if (read_passes(rd0, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, r0)) rd_end = rd0.end;
     }
     __syncthreads();
@@ -848,7 +847,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     C3R_PHASE(3);
     // ---- per-position gates (src/create_tensor_pileup.py:259-299, :536-556)
     bool is_row = false, cand = false, ambiguous = false;
-    int depth = 0, refi = 0;
+    int depth = 0, refi = 0, ntok_bound = 0;
     int cls[6] = {0, 0, 0, 0, 0, 0};
     bool gates_ok = false;
     if (p >= pmin && p < t1 && my_cov > 0) {
@@ -863,6 +862,9 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         refi = ref_index(rb);
         cls[0] = c[C3R_A] + c[C3R_a]; cls[1] = c[C3R_C] + c[C3R_c]; cls[2] = c[C3R_G] + c[C3R_g]; cls[3] = c[C3R_T] + c[C3R_t];
         cls[4] = c[C3R_I] + c[C3R_i]; cls[5] = c[C3R_D] + c[C3R_d];
+        // every read that gets a token (tile_tokens) is counted at least once here: a non-reference base, a '*' / '#', an indel
+        ntok_bound = cls[4] + cls[5] + c[C3R_STAR] + c[C3R_HASH];
+        for (int x = 0; x < 4; ++x) if (x != refi) ntok_bound += cls[x];
         const bool may_be_cand = p >= cand_lo && p < cand_hi;       // (the fused kernel decides candidates for its inner span only)
         const double denom = depth > 0 ? (double)depth : 1.0;
         bool pass = (C3R_ABL(a) & 1024) != 0;
@@ -949,8 +951,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     if (C3R_DBG(a) && tid == 0) { atomicAdd(&C3R_DBG(a)[14], (unsigned long long)(shi - slo)); atomicAdd(&C3R_DBG(a)[15], 1ull); atomicAdd(&C3R_DBG(a)[13], (unsigned long long)(hi - lo)); atomicAdd(&C3R_DBG(a)[12], (unsigned long long)ev_total); }
 #undef C3R_PHASE
     TileOut o;
-    o.is_row = is_row; o.cand = cand; o.depth = depth; o.cov = my_cov;
-    o.rd_pos = rd_pos; o.rd_rev = rd_rev; o.rd_end = rd_end;
+    o.is_row = is_row; o.cand = cand; o.depth = depth; o.cov = ntok_bound;
     return o;
 }
 
@@ -1484,33 +1485,25 @@ __device__ __forceinline__ TokenAt token_at(const DevRead &rd, int r, int p, con
 // (src/create_tensor_pileup.py:179,221-261,595-596; decode.hpp / altinfo.py), because order drives tie-breaks in the decoder
 // (clair3_rna/call_variants.py:144,151,187,196).
 // tile_tokens: the candidates of ONE tile / span, by the workgroup that has just decided them (k_fused_tiles: the records are still
-// in the cache, the candidates in LDS) or by k_tile_tokens (column-store path).  A token's slot is its read's rank among the reads
-// covering the candidate, in BAM order; per batch of TK_NB candidates and chunk of TK_RCH reads:
-//   1. cover pass    — one wavefront per candidate: ballots over the staged read spans give a 64-read cover mask and the running
-//                      rank per block, kept in LDS;
-//   2. record pass   — one lane per record of the tile's range: every candidate an M / D piece covers gets its token (base / deleted
-//                      base, `nxt` when the candidate is the piece's last column) written at  rank = prefix of its block + popcount of
-//                      the mask below the read's bit, and the read's bit is set in a "done" mask; an I / D right after a ref-skip
-//                      writes the token of the last intron column;
-//   3. ref-skip pass — covering reads not done show a ref-skip ('>' / '<'): their default tokens fill the remaining slots.
-// Every slot is written exactly once, by one lane.
-constexpr int TK_NB = 32, TK_RCH = 512, TK_MAXB = TK_RCH / 64, TK_MASKS = TK_NB * TK_MAXB;
-// The cover masks are a table of TK_MASKS 64-read words shared by the batch's candidates: 32 candidates x 512 reads for the usual span,
-// and for a span that more reads reach (deep coverage) fewer candidates per batch and more reads per chunk — 16 x 1024 ... 1 x 16384 — so
-// that the records are walked once per BATCH and not once per 512 reads (at mpileup's depth cap a span with one candidate walked its
-// 267 k records 53 times: 110 ms; profiles/r5/deep_locus_phases.txt).  Chunks beyond TK_RCH reads take the headers from memory instead of
-// the staged copies.
+// in the cache, the candidates in LDS) or by k_tile_tokens (column-store path).
+// A candidate's tokens are what the ordered alt_info is made of (src/create_tensor_pileup.py:221-258): one token per read that shows
+// something OTHER than the reference base or a ref-skip on the column — a non-reference A / C / G / T, a '*' / '#', an indel attached to
+// the column (also one sitting behind a ref-skip).  Reads that show the reference base, an N, an IUPAC letter or '>' / '<' add nothing to
+// alt_info beyond the depth, which the site record carries.  (Rounds 1-4 wrote a token for EVERY covering read: 5.6 M tokens per chr20
+// pass of which 0.5 M said anything, a cover pass over the span's read headers per batch of candidates, and records walked once per
+// batch x read chunk — at a deep locus with many candidates that product ran to 100 ms, profiles/r5/depth_cap_zones.txt.)
+// One pass: one lane per record of the tile's range; every candidate an M / D piece covers is looked at, and a read with something to
+// say takes the candidate's next slot (LDS counter).  Slots: the candidate owns `cap` of them from `toff` on — the gates' bound
+// (TileOut::cov) — so the order INSIDE a site is the order of arrival; c3r_get_tokens and the row snapshot sort a site's tokens by read
+// index, i.e. BAM order (k_export_tokens / k_pack_*).  done(k, n) reports the tokens written for candidate k.
 struct TokLds {
-    int32_t pos[TK_RCH], end[TK_RCH];
-    uint8_t rev[TK_RCH];
-    unsigned long long mask[TK_MASKS], done[TK_MASKS];        // [candidate][block of 64 reads], row stride maxb
-    int32_t pre[TK_MASKS];
-    int32_t maxb;                                             // 64-read blocks per chunk (row stride of the three tables)
-    int32_t lpos[TK_NB], toff[TK_NB], rank0[TK_NB], rank1[TK_NB];
-    unsigned long long cmask[TILE / 64];       // the batch's candidates as a bit per position of the tile
-    int32_t cpre[TILE / 64];                   // candidates (of the batch) before each 64-position word
+    unsigned long long cmask[TILE / 64];       // the candidates as a bit per position of the tile
+    int32_t cpre[TILE / 64];                   // candidates before each 64-position word
+    int32_t toff[TILE], cap[TILE], cnt[TILE];  // per candidate (rank by position): first slot, slots owned, tokens written
+    uint8_t refn[TILE];                        // its reference base as a 4-bit code (evc_base_from: anything but C / G / T counts as A)
+    int32_t lost;                              // tokens that found no slot (the bound was wrong: the scan fails)
 };
-// index of the batch's candidate at tile position x (its bit in cmask is set)
+// index of the candidate at tile position x (its bit in cmask is set)
 __device__ __forceinline__ int tok_cand(const TokLds &K, int x) { return K.cpre[x >> 6] + __popcll(K.cmask[x >> 6] & ((1ull << (x & 63)) - 1ull)); }
 // the candidates among the tile positions [x0, x0 + n), n <= 64, as bits 0 .. n - 1
 __device__ __forceinline__ unsigned long long tok_cand_bits(const TokLds &K, int x0, int n) {
@@ -1520,28 +1513,25 @@ __device__ __forceinline__ unsigned long long tok_cand_bits(const TokLds &K, int
     return n >= 64 ? bits : bits & ((1ull << n) - 1ull);
 }
 
-__device__ __forceinline__ void tok_emit(TokLds &K, c3r_token_t *tok, long long tok_cap, int c, int ri, int r, int indel, uint32_t qpos, int base, bool rev,
+__device__ __forceinline__ void tok_emit(TokLds &K, c3r_token_t *tok, long long tok_cap, int c, int r, int indel, uint32_t qpos, int base, bool rev,
                                          uint32_t del_after = 0) {
-    const int b = c * K.maxb + (ri >> 6), bit = ri & 63;
-    const unsigned long long m = K.mask[b];
-    if (!((m >> bit) & 1ull)) return;                         // (not a covering read by its header: nothing to place)
-    const long long slot = (long long)K.toff[c] + K.pre[b] + __popcll(m & ((1ull << bit) - 1ull));
-    if (slot >= tok_cap) return;
+    const int i = atomicAdd(&K.cnt[c], 1);
+    if (i >= K.cap[c]) { atomicAdd(&K.lost, 1); return; }
+    const long long slot = (long long)K.toff[c] + i;
+    if (slot >= tok_cap) { atomicAdd(&K.lost, 1); return; }
     int4 v;
     v.x = r; v.y = indel; v.z = (int)qpos; v.w = base | ((rev ? 1 : 0) << 8) | (int)(min(del_after, 65535u) << 16);
     *reinterpret_cast<int4 *>(&tok[slot]) = v;
-    atomicOr(&K.done[b], 1ull << bit);
 }
 
-// One record of the tile's range against the batch's candidates.  `bits`: the candidates the piece covers (tok_cand_bits over its positions
+// One record of the tile's range against the candidates.  `bits`: the candidates the piece covers (tok_cand_bits over its positions
 // inside the tile, bit j = position b0 + j) — the caller has tested them before it fetched any bases: most records cover none.
 __device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long tok_cap, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int boff,
-                                        int t0, int t1, unsigned long long bits, int rc, int re) {
+                                        int t0, int t1, unsigned long long bits) {
     const uint32_t w = (uint32_t)ra.y;
     const int op = (int)(w & 3u), prev = (int)((w >> 2) & 15u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
     const bool rev = (w & 64u) != 0;
     const int rstart = ra.x, r = rb.y;
-    if (r < rc || r >= re) return;                            // (its read belongs to another chunk of the tile's reads)
     if (op != C3R_CIG_I && bits) {
         const int b0 = max(rstart, t0);
         const int odd = (int)(((uint32_t)ra.z + (uint32_t)boff) & 1u);      // the bases were loaded from nibble naddr + boff on
@@ -1557,143 +1547,95 @@ __device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long t
                 indel = rb.z;
                 if (indel > 0) { qpos = (uint32_t)rb.x + (op == C3R_CIG_M ? (uint32_t)len : 0u); dafter = op == C3R_CIG_M ? (uint32_t)rb.w : (uint32_t)ra.z; }
             }
-            tok_emit(K, tok, tok_cap, c, r - rc, r, indel, qpos, base, rev, dafter);
+            // (base: one bit set = A / C / G / T; 16 = inside a deletion; 15 = N and the IUPAC codes say nothing)
+            const bool says = indel != 0 || base == 16 || ((base == 1 || base == 2 || base == 4 || base == 8) && base != (int)K.refn[c]);
+            if (says) tok_emit(K, tok, tok_cap, c, r, indel, qpos, base, rev, dafter);
         }
     }
     if (prev == C3R_CIG_N && (op == C3R_CIG_I || op == C3R_CIG_D)) {
         // I / D right after a ref-skip: attached to the last intron column, which shows the ref-skip itself
         const int ax = rstart - 1 - t0;
         if (ax >= 0 && ax < t1 - t0 && ((K.cmask[ax >> 6] >> (ax & 63)) & 1ull))
-            tok_emit(K, tok, tok_cap, tok_cand(K, ax), r - rc, r, op == C3R_CIG_I ? (int)(uint32_t)rb.w : -(int)(uint32_t)rb.w, op == C3R_CIG_I ? (uint32_t)rb.x : 0u, 17, rev,
+            tok_emit(K, tok, tok_cap, tok_cand(K, ax), r, op == C3R_CIG_I ? (int)(uint32_t)rb.w : -(int)(uint32_t)rb.w, op == C3R_CIG_I ? (uint32_t)rb.x : 0u, 17, rev,
                      (op == C3R_CIG_I && rb.z < 0) ? (uint32_t)(-rb.z) : 0u);
     }
 }
 
-// cand(k, lpos, toff): position (relative to t0) and first token slot of the tile's k-th candidate, ascending.
-// pre: null, or the caller's copy of the header of read lo + tid (TileOut::rd_*): the first 256 reads are then staged from registers
-template <class CandFn>
-__device__ __forceinline__ void tile_tokens(const ScanArgs &a, TokLds &K, int t0, int t1, int region, int lo, int hi, int rlo, int rhi, int nc, CandFn &&cand,
-                                            c3r_token_t *tok, long long tok_cap, const TileOut *pre = nullptr) {
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// cand(k, lpos, toff, cap): position (relative to t0), first token slot and slots owned of the tile's k-th candidate, ascending.
+// done(k, n): the tokens written for it.  Returns (to every thread) the tokens that found no slot — zero unless the bound is wrong.
+template <class CandFn, class DoneFn>
+__device__ __forceinline__ int tile_tokens(const ScanArgs &a, TokLds &K, int t0, int t1, int region, int rlo, int rhi, int nc, CandFn &&cand, DoneFn &&done,
+                                           c3r_token_t *tok, long long tok_cap) {
+    const int tid = (int)threadIdx.x;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    // blocks of 64 reads per chunk (a power of two, all the tile's reads if the table takes them) and candidates per batch
-    int maxb = TK_MAXB;
-    while (maxb < TK_MASKS && maxb * 64 < hi - lo) maxb <<= 1;
-    const int nb_max = TK_MASKS / maxb, chunk = maxb * 64;
-    const bool staged = chunk <= TK_RCH;
-    // read rc + i of the chunk as the cover pass sees it: {pos, end (INT32_MIN: filtered out or dropped), reverse strand}
-    auto header = [&](int rc, int i, int &rpos, int &rend, bool &rrev) {
-        if (staged) { rpos = K.pos[i]; rend = K.end[i]; rrev = K.rev[i] != 0; return; }
-        const DevRead rd = a.reads[rc + i];
-        const bool pass = read_passes(rd, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, rc + i);
-        rpos = rd.pos; rend = pass ? rd.end : INT32_MIN; rrev = (rd.flag & 16) != 0;
-    };
-    for (int cb = 0; cb < nc; cb += nb_max) {
-        const int nb = min(nb_max, nc - cb);
-        __syncthreads();
-        if (tid < TILE / 64) K.cmask[tid] = 0ull;
-        if (tid == 0) K.maxb = maxb;
-        __syncthreads();
-        if (tid < nb) {
-            int lp, off;
-            cand(cb + tid, lp, off);
-            K.lpos[tid] = lp; K.toff[tid] = off; K.rank0[tid] = 0;
-            atomicOr(&K.cmask[lp >> 6], 1ull << (lp & 63));
-        }
-        __syncthreads();
-        if (tid < TILE / 64) { int pre = 0; for (int k = 0; k < tid; ++k) pre += __popcll(K.cmask[k]); K.cpre[tid] = pre; }
-        for (int rc = lo; rc < hi; rc += chunk) {
-            const int re = min(hi, rc + chunk), nr = re - rc, nblk = (nr + 63) >> 6;
-            __syncthreads();
-            if (staged)
-            for (int i = tid; i < nr; i += SCAN_THREADS) {
-                if (pre && rc == lo && i == tid) { K.pos[i] = pre->rd_pos; K.end[i] = pre->rd_end; K.rev[i] = pre->rd_rev ? 1 : 0; continue; }
-                const DevRead rd = a.reads[rc + i];
-                const bool pass = read_passes(rd, a.min_mq, a.excl_flags) && !read_dropped(a.drop, a.drop_words, region, rc + i);
-                K.pos[i] = rd.pos; K.end[i] = pass ? rd.end : INT32_MIN; K.rev[i] = (rd.flag & 16) ? 1 : 0;
-            }
-            for (int i = tid; i < TK_MASKS; i += SCAN_THREADS) K.done[i] = 0ull;
-            __syncthreads();
-            for (int c = wave; c < nb; c += WAVES) {
-                const int p = t0 + K.lpos[c];
-                int run = K.rank0[c];
-                for (int b = 0; b < nblk; ++b) {
-                    const int i = 64 * b + lane;
-                    int rpos = 0, rend = INT32_MIN; bool rrev = false;
-                    if (i < nr) header(rc, i, rpos, rend, rrev);
-                    const bool cov = i < nr && rpos <= p && rend > p;
-                    const unsigned long long m = __ballot(cov);
-                    if (lane == 0) { K.mask[c * maxb + b] = m; K.pre[c * maxb + b] = run; }
-                    run += __popcll(m);
-                }
-                if (lane == 0) K.rank1[c] = run;
-            }
-            __syncthreads();
-            // a record matters only if its piece covers a candidate (or, an indel behind a ref-skip, sits on one): the candidates' bit mask says
-            // so from the record's first half alone, before its second half or any base is fetched
-            for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
-                int4 ra[WALK_UNR], rb[WALK_UNR];
-                bool have[WALK_UNR];
-                unsigned long long bits[WALK_UNR];
-#pragma unroll
-                for (int u = 0; u < WALK_UNR; ++u) {
-                    const int iu = base + u * SCAN_THREADS + tid;
-                    have[u] = iu < rhi;
-                    const int4 *rec = reinterpret_cast<const int4 *>(a.recs + (have[u] ? iu : rhi - 1));
-                    ra[u] = rec[0]; rb[u] = rec[1];
-                }
-                uint64_t w0[WALK_UNR], w1[WALK_UNR];
-                int boff[WALK_UNR];
-#pragma unroll
-                for (int u = 0; u < WALK_UNR; ++u) {
-                    w0[u] = 0; w1[u] = 0; boff[u] = 0; bits[u] = 0ull;
-                    const uint32_t w = (uint32_t)ra[u].y;
-                    const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
-                    const int b0 = max(ra[u].x, t0), b1 = min(ra[u].x + len, t1);
-                    if (have[u] && op != C3R_CIG_I && b0 < b1) bits[u] = tok_cand_bits(K, b0 - t0, b1 - b0);
-                    const int ax = ra[u].x - 1 - t0;
-                    const bool anchored = op != C3R_CIG_M && ((w >> 2) & 15u) == (uint32_t)C3R_CIG_N && ax >= 0 && ax < t1 - t0 && ((K.cmask[ax >> 6] >> (ax & 63)) & 1ull);
-                    if (!(bits[u] || anchored)) have[u] = false;
-                    if (have[u] && op == C3R_CIG_M && bits[u]) {
-                        boff[u] = b0 - ra[u].x;
-                        if (boff[u] < avail) {
-                            const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)boff[u];
-                            u64x2 w;
-                            __builtin_memcpy(&w, a.seq + (na >> 1), 16);
-                            w0[u] = w[0]; w1[u] = w[1];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < WALK_UNR; ++u)
-                    if (have[u]) tok_rec(K, tok, tok_cap, ra[u], rb[u], w0[u], w1[u], boff[u], t0, t1, bits[u], rc, re);
-            }
-            __syncthreads();
-            for (int c = wave; c < nb; c += WAVES) {
-                for (int b = 0; b < nblk; ++b) {
-                    const unsigned long long m = K.mask[c * maxb + b], rest = m & ~K.done[c * maxb + b];
-                    if ((rest >> lane) & 1ull) {
-                        const int i = 64 * b + lane;
-                        const long long slot = (long long)K.toff[c] + K.pre[c * maxb + b] + __popcll(m & ((1ull << lane) - 1ull));
-                        if (slot >= tok_cap) continue;
-                        int rpos, rend; bool rrev;
-                        header(rc, i, rpos, rend, rrev);
-                        int4 v;
-                        v.x = rc + i; v.y = 0; v.z = 0; v.w = 17 | ((rrev ? 1 : 0) << 8);
-                        *reinterpret_cast<int4 *>(&tok[slot]) = v;
-                    }
-                }
-                if (lane == 0) K.rank0[c] = K.rank1[c];
-            }
-        }
+    __syncthreads();
+    if (tid < TILE / 64) K.cmask[tid] = 0ull;
+    if (tid == 0) K.lost = 0;
+    __syncthreads();
+    if (tid < nc) {
+        int lp, off, cp;
+        cand(tid, lp, off, cp);
+        K.toff[tid] = off; K.cap[tid] = cp; K.cnt[tid] = 0;
+        const int rp = t0 + lp - a.ref_beg0;
+        const uint8_t rb = (rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
+        K.refn[tid] = (uint8_t)(1u << ref_index(rb));
+        atomicOr(&K.cmask[lp >> 6], 1ull << (lp & 63));
     }
+    __syncthreads();
+    if (tid < TILE / 64) { int pre = 0; for (int k = 0; k < tid; ++k) pre += __popcll(K.cmask[k]); K.cpre[tid] = pre; }
+    __syncthreads();
+    // a record matters only if its piece covers a candidate (or, an indel behind a ref-skip, sits on one): the candidates' bit mask says
+    // so from the record's first half alone, before its second half or any base is fetched
+    for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
+        int4 ra[WALK_UNR], rb[WALK_UNR];
+        bool have[WALK_UNR];
+        unsigned long long bits[WALK_UNR];
+#pragma unroll
+        for (int u = 0; u < WALK_UNR; ++u) {
+            const int iu = base + u * SCAN_THREADS + tid;
+            have[u] = iu < rhi;
+            const int4 *rec = reinterpret_cast<const int4 *>(a.recs + (have[u] ? iu : rhi - 1));
+            ra[u] = rec[0]; rb[u] = rec[1];
+        }
+        uint64_t w0[WALK_UNR], w1[WALK_UNR];
+        int boff[WALK_UNR];
+#pragma unroll
+        for (int u = 0; u < WALK_UNR; ++u) {
+            w0[u] = 0; w1[u] = 0; boff[u] = 0; bits[u] = 0ull;
+            const uint32_t w = (uint32_t)ra[u].y;
+            const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
+            const int b0 = max(ra[u].x, t0), b1 = min(ra[u].x + len, t1);
+            if (have[u] && op != C3R_CIG_I && b0 < b1) bits[u] = tok_cand_bits(K, b0 - t0, b1 - b0);
+            const int ax = ra[u].x - 1 - t0;
+            const bool anchored = op != C3R_CIG_M && ((w >> 2) & 15u) == (uint32_t)C3R_CIG_N && ax >= 0 && ax < t1 - t0 && ((K.cmask[ax >> 6] >> (ax & 63)) & 1ull);
+            if (!(bits[u] || anchored)) have[u] = false;
+            // (mpileup's depth cap: the records of a read this region's scan has discarded say nothing)
+            if (have[u] && a.drop && read_dropped(a.drop, a.drop_words, region, rb[u].y)) have[u] = false;
+            if (have[u] && op == C3R_CIG_M && bits[u]) {
+                boff[u] = b0 - ra[u].x;
+                if (boff[u] < avail) {
+                    const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)boff[u];
+                    u64x2 w;
+                    __builtin_memcpy(&w, a.seq + (na >> 1), 16);
+                    w0[u] = w[0]; w1[u] = w[1];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WALK_UNR; ++u)
+            if (have[u]) tok_rec(K, tok, tok_cap, ra[u], rb[u], w0[u], w1[u], boff[u], t0, t1, bits[u]);
+    }
+    __syncthreads();
+    if (tid < nc) done(tid, min(K.cnt[tid], K.cap[tid]));
+    return K.lost;
 }
 
 // the column-store path's token kernel: one workgroup per tile that holds candidates (tile_cand from the compaction)
 struct TileTokArgs {
     ScanArgs a;                    // the scan's own arguments (reads, pile table, tile list and ranges, filters, depth cap)
-    const int32_t *cand_idx; const int2 *tile_cand; const int32_t *tok_off; c3r_site_t *sites; c3r_token_t *tok;
-    int32_t tok_base;              // tokens already resident from earlier scans of the batch
+    const int32_t *cand_idx; const int2 *tile_cand; const int32_t *tok_off /* [n_cand + 1]: exclusive sums of the candidates' slot counts */; c3r_site_t *sites; c3r_token_t *tok;
+    int32_t tok_base;              // token slots already taken by earlier scans of the batch
+    int32_t *totals;               // [0] += tokens written, [1] += tokens that found no slot (the host fails the scan)
 };
 #ifndef C3R_TOK_OCC
 #define C3R_TOK_OCC 6
@@ -1709,12 +1651,17 @@ __global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const
         const TileGeo tg = a.geo[tile];
         const int slot0 = tile * TILE;
         const int4 rng = a.tile_rng[tile];
-        tile_tokens(a, K, tg.p0, tg.p1, tg.region, rng.x, rng.y, rng.z, rng.w, tc.y, [&](int k, int &lp, int &off) {
+        const int lost = tile_tokens(a, K, tg.p0, tg.p1, tg.region, rng.z, rng.w, tc.y, [&](int k, int &lp, int &off, int &cp) {
             const int w = tc.x + k;
             lp = t.cand_idx[w] - slot0;
             off = t.tok_base + t.tok_off[w];
+            cp = t.tok_off[w + 1] - t.tok_off[w];
             if (t.sites) t.sites[w].tok_off = (uint32_t)off;
+        }, [&](int k, int n) {
+            if (t.sites) t.sites[tc.x + k].n_tok = n;
+            if (n) atomicAdd(&t.totals[0], n);
         }, t.tok, (long long)INT32_MAX);
+        if (lost && threadIdx.x == 0) atomicAdd(&t.totals[1], lost);
     }
 }
 
@@ -1817,7 +1764,7 @@ constexpr int TICKET_Q = 16, TICKET_STRIDE = 64;     // ticket words 256 bytes a
 // kernel ran 0.65 ms with candidates against 0.33 ms without.  Rows and tokens are reached through win_idx / tok_off, so the holes
 // between the shards' runs cost address space only.
 constexpr int ALLOC_SHARDS = 16, ALLOC_STRIDE = 32;  // (u64 words)
-struct CandMeta { int32_t slot, depth, ncov, tpre, span, pos0; };      // per arrived candidate: slot (tile * TILE + offset), depth, covering reads, tokens of the
+struct CandMeta { int32_t slot, depth, ncov, tpre, span, pos0; };      // per arrived candidate: slot (tile * TILE + offset), depth, its tokens (the slots reserved until the token pass has counted), token slots of the
                                                                        // span's earlier candidates, list index of its span, its 0-based position
 struct FusedArgs {
     ScanArgs a;                   // tile_list: spans with aligned bases, ascending; tile_rng: reads / segments of the span + flanks
@@ -1932,7 +1879,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             s_fits = fits ? 1 : 0;
             s_row0 = shard * f.shard_rows + lrow;
             s_tok0 = shard * f.shard_toks + ltok;
-            f.span_info[b] = make_int4(s_row0, nc, nt, s_tok0);
+            f.span_info[b] = make_int4(s_row0, nc, 0, s_tok0);                // (.z: tokens actually written, added up by the token pass)
             if (C3R_DBG(a)) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[11], now_ - t_tail); t_tail = now_; }
         }
         __syncthreads();
@@ -2004,9 +1951,14 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         if (f.tok && !(C3R_ABL(a) & 128)) {                                   // (ablation 128: no token pass)
             if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[7], now_ - t_tail); t_tail = now_; dbg_slot = 8; }
             TokLds &K = *reinterpret_cast<TokLds *>(M.cnt);
-            tile_tokens(a, K, x0, x1, tg.region, rng.x, rng.y, rng.z, rng.w, nc, [&](int k, int &lp, int &off) {
+            const int lost = tile_tokens(a, K, x0, x1, tg.region, rng.z, rng.w, nc, [&](int k, int &lp, int &off, int &cp) {
                 lp = (int)M.amb[k]; off = f.tok_base + tok0 + M.evoff[k];
-            }, f.tok, (long long)f.tok_base + (long long)(shard + 1) * f.shard_toks, &o);
+                cp = (k + 1 < nc ? M.evoff[k + 1] : nt) - M.evoff[k];
+            }, [&](int k, int n) {
+                f.meta[row0 + k].ncov = n;                                  // (the site's n_tok: what was written, not what was reserved)
+                if (n) atomicAdd(&f.span_info[b].z, n);                     // the span's tokens: k_order_spans sums them into the scan's total
+            }, f.tok, (long long)f.tok_base + (long long)(shard + 1) * f.shard_toks);
+            if (lost && tid == 0) atomicOr(f.overflow, 8);
         }
         }
         if (C3R_DBG(a) && tid == 0) atomicAdd(&C3R_DBG(a)[dbg_slot], wall_clock64() - t_tail);
@@ -2116,13 +2068,37 @@ __global__ __launch_bounds__(256) void k_site_ntok(const c3r_site_t *sites, int 
     if (i < n) out[i] = sites[i].n_tok;
     else if (i == n) out[i] = 0;
 }
+// A site's tokens lie in the order they arrived (tile_tokens); whoever takes them out puts them into BAM order = by read index (a read has
+// at most one token per site).  One wavefront per site: rank of token k0 + lane among the site's n tokens, and among those that carry an
+// indel (the packed form keeps the indel records apart).  Sites hold two or three tokens; a deep site's thousands cost n^2 / 64 steps.
+__device__ __forceinline__ void site_tok_rank(const c3r_token_t *s_, int n, uint32_t my_read, int lane, int &rank, int &rank_ind) {
+    rank = 0; rank_ind = 0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        uint32_t oi = 0xffffffffu; int oind = 0;
+        if (j < n) { oi = s_[j].read_idx; oind = s_[j].indel != 0 ? 1 : 0; }
+        const int m = min(64, n - j0);
+        for (int l = 0; l < m; ++l) {
+            const uint32_t x = (uint32_t)__shfl((int)oi, l, 64);
+            const int xi = __shfl(oind, l, 64);
+            if (x < my_read) { ++rank; rank_ind += xi; }
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_export_tokens(const c3r_site_t *sites, const int32_t *dst_off, int n, const c3r_token_t *tok, c3r_token_t *out) {
     const int lane = (int)(threadIdx.x & 63), nw = (int)(gridDim.x * (blockDim.x >> 6));
     for (int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); i < n; i += nw) {
-        const int4 *s_ = reinterpret_cast<const int4 *>(tok + sites[i].tok_off);
+        const c3r_token_t *s_ = tok + sites[i].tok_off;
         int4 *d_ = reinterpret_cast<int4 *>(out + dst_off[i]);
         const int nt = sites[i].n_tok;
-        for (int k = lane; k < nt; k += 64) d_[k] = s_[k];
+        for (int k0 = 0; k0 < nt; k0 += 64) {
+            const int k = k0 + lane;
+            int4 v = make_int4(0, 0, 0, 0);
+            if (k < nt) v = reinterpret_cast<const int4 *>(s_)[k];
+            int rank, rind;
+            site_tok_rank(s_, nt, k < nt ? (uint32_t)v.x : 0xffffffffu, lane, rank, rind);
+            if (k < nt) d_[rank] = v;
+        }
     }
 }
 
@@ -2152,17 +2128,16 @@ __global__ __launch_bounds__(256) void k_pack_tokens(const c3r_site_t *__restric
         rec_off[site] = base;
     }
     base = __shfl(base, 0);
-    uint32_t run = 0;
     for (int i0 = 0; i0 < n_tok; i0 += 64) {
         const int i = i0 + lane;
         const bool valid = i < n_tok;
         c3r_token_t t{};
         if (valid) t = tok[off + i];
+        int rank, rind;
+        site_tok_rank(tok + off, n_tok, valid ? t.read_idx : 0xffffffffu, lane, rank, rind);        // BAM order
         const bool f = valid && t.indel != 0;
-        const unsigned long long m = __ballot(f);
-        if (valid) bytes[off + i] = (uint8_t)((t.base & 31) | (t.rev ? 0x20 : 0) | (f ? 0x80 : 0));
-        if (f) recs[base + run + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = TokRec{t.read_idx, t.indel, t.qpos, t.del_after};
-        run += (uint32_t)__popcll(m);
+        if (valid) bytes[off + rank] = (uint8_t)((t.base & 31) | (t.rev ? 0x20 : 0) | (f ? 0x80 : 0));
+        if (f) recs[base + (uint32_t)rind] = TokRec{t.read_idx, t.indel, t.qpos, t.del_after};
     }
 }
 
@@ -2229,17 +2204,16 @@ __global__ __launch_bounds__(256) void k_pack_rows(const c3r_site_t *__restrict_
     static_assert(sizeof(c3r_site_t) == 52 && offsetof(c3r_site_t, tok_off) == 48, "c3r_site_t layout");
     if (lane < 13) reinterpret_cast<uint32_t *>(&sites_c[j])[lane] = lane == 12 ? bbase : reinterpret_cast<const uint32_t *>(&sites[site])[lane];
     if (lane < C3R_NPROB) probs_c[(size_t)j * C3R_NPROB + lane] = probs[(size_t)site * C3R_NPROB + lane];
-    uint32_t run = 0;
     for (int i0 = 0; i0 < n_tok; i0 += 64) {
         const int i = i0 + lane;
         const bool valid = i < n_tok;
         c3r_token_t t{};
         if (valid) t = tok[off + i];
+        int rank, rind;
+        site_tok_rank(tok + off, n_tok, valid ? t.read_idx : 0xffffffffu, lane, rank, rind);        // BAM order
         const bool f = valid && t.indel != 0;
-        const unsigned long long m = __ballot(f);
-        if (valid) bytes[bbase + i] = (uint8_t)((t.base & 31) | (t.rev ? 0x20 : 0) | (f ? 0x80 : 0));
-        if (f) recs[base + run + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = TokRec{t.read_idx, t.indel, t.qpos, t.del_after};
-        run += (uint32_t)__popcll(m);
+        if (valid) bytes[bbase + rank] = (uint8_t)((t.base & 31) | (t.rev ? 0x20 : 0) | (f ? 0x80 : 0));
+        if (f) recs[base + (uint32_t)rind] = TokRec{t.read_idx, t.indel, t.qpos, t.del_after};
     }
 }
 

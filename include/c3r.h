@@ -118,7 +118,8 @@ int c3r_batch_end(c3r_ctx *ctx);
 int c3r_batch_count(c3r_ctx *ctx, int64_t *n_sites, int64_t *n_tokens);
 /* Copy out what the last scan (or the current batch) produced.  Any pointer may be NULL.  tensors: int32 [n][33][C]
  * row-major (the 594/990 integers of a create_tensor line, after the A5 rescale when
- * `rescaled` != 0, raw otherwise); sites: [n]; tokens: [n_tokens] (see c3r_token_count). */
+ * `rescaled` != 0, raw otherwise); sites: [n]; tokens: [n_tokens] (see c3r_token_count), site after site (tok_off / n_tok of
+ * c3r_get_sites), each site's in BAM order. */
 int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_sites);
 int c3r_get_sites(c3r_ctx *ctx, c3r_site_t *sites, int64_t cap_sites);
 int c3r_token_count(c3r_ctx *ctx, int64_t *n_tokens);

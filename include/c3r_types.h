@@ -76,17 +76,22 @@ typedef struct c3r_site {
     int32_t pos;          /* 1-based centre position */
     int32_t depth;        /* depth at the centre (first field of alt_info) */
     char    ref33[C3R_WINDOW + 3]; /* reference +-16, 'A'-padded at contig ends; NUL-terminated, padded to 36 */
-    int32_t n_tok;        /* number of per-read tokens recorded for the centre column */
+    int32_t n_tok;        /* number of per-read tokens recorded for the centre column (c3r_token_t: only the reads with something to say) */
     uint32_t tok_off;     /* offset of the first token in the token array */
 } c3r_site_t;
 
 /* One read's contribution to a candidate's centre column, in BAM order — what the host needs to
- * rebuild the ordered alt_info dictionary (src/create_tensor_pileup.py:179,221-261). */
+ * rebuild the ordered alt_info dictionary (src/create_tensor_pileup.py:179,221-261).  A site holds a token
+ * for every read that shows something OTHER than the reference base or a ref-skip on the column: a
+ * non-reference A / C / G / T, a '*' / '#', or an indel attached to the column (base 17 when that indel sits
+ * behind a ref-skip).  Reads that show the reference base, N or an IUPAC letter add nothing to alt_info but
+ * the depth, which c3r_site_t carries: R<ref> = max(0, depth - deletions - insertions - mismatches)
+ * (:259).  (Rounds 1-4 returned one token per covering read.) */
 typedef struct c3r_token {
     uint32_t read_idx;    /* index into the loaded read array */
     int32_t  indel;       /* >0 insertion length, <0 deletion length, 0 none */
     uint32_t qpos;        /* query offset of the first inserted base (valid when indel > 0) */
-    uint8_t  base;        /* 4-bit BAM base code; 16 = '*'/'#' (inside deletion); 17 = ref-skip */
+    uint8_t  base;        /* 4-bit BAM base code; 16 = '*'/'#' (inside deletion); 17 = ref-skip (with an indel behind it) */
     uint8_t  rev;         /* 1 = reverse strand */
     uint16_t del_after;   /* mpileup_compat = 1, indel > 0: length of the deletion that follows the insertion at once (0: none;
                              saturates at 65535) — a second indel token of the read on this column, after the insertion */

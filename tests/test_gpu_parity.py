@@ -496,7 +496,7 @@ def test_cpp_call_rows_equals_python_decode(eng):
     sites, toks = eng.sites(), eng.tokens()
     infos = []
     for s in sites:
-        alt, _ = altinfo.alt_dict_from_tokens(toks[int(s["tok_off"]):int(s["tok_off"]) + int(s["n_tok"])], rs, ref, 1, int(s["pos"]))
+        alt, _ = altinfo.alt_dict_from_tokens(toks[int(s["tok_off"]):int(s["tok_off"]) + int(s["n_tok"])], rs, ref, 1, int(s["pos"]), depth=int(s["depth"]))
         infos.append(altinfo.alt_info_string(int(s["depth"]), alt))
     py = decode.vcf_rows("chr20", sites["pos"], [s["ref33"].decode() for s in sites], infos, probs)
     assert eng.call_rows("chr20") == py
