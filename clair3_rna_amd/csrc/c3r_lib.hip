@@ -99,6 +99,7 @@ struct c3r_ctx {
     std::vector<uint8_t> h_seq;            // lazily: ensure_host_seq (decode reads inserted bases)
     bool host_seq_valid = false;
     DevBuf d_reads, d_cigar, d_seq, d_prefmax;
+    DevBuf d_wgtab;                        // k_prep's per-workgroup bin tables between its two passes
     // mpileup_compat = 1: the insertions of the loaded reads that hold pads (c3r_padins_t), on the device for ev_equal and on the host for
     // the decoder (row snapshots share the vector); empty for every CIGAR an aligner emits
     DevBuf d_padins;
@@ -474,6 +475,8 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
         a.st = (LoadStats *)ctx->d_stats.p;
         char *lbk = (char *)ctx->d_lbk.p;
         const unsigned grid = (unsigned)((n + PREP_READS - 1) / PREP_READS);
+        if ((rc = ensure(ctx, ctx->d_wgtab, (size_t)grid * 2 * HB * 4))) return rc;          // the workgroups' bin tables, kept for the second pass
+        a.wg_tab = (uint32_t *)ctx->d_wgtab.p;
         {
             Launch L(ctx, "k_prep_count");
             hipLaunchKernelGGL(k_prep<false>, dim3(grid), dim3(PREP_THREADS), 0, ctx->stream, a);
@@ -524,6 +527,7 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
         a.n_reads = n; a.cigars = (const uint32_t *)ctx->d_rawcig.p; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.compat = ctx->prm.mpileup_compat; a.geo = ctx->bins;
         a.cnt = (uint32_t *)ctx->d_bincnt.p; a.rec_off = (const uint32_t *)ctx->d_binoff.p; a.out = (DevRead *)ctx->d_reads.p; a.serial = (uint8_t *)ctx->d_serial.p;
         a.recs = (PileRec *)ctx->d_recs.p;
+        a.wg_tab = (uint32_t *)ctx->d_wgtab.p;
         Launch L(ctx, "k_prep_write");
         hipLaunchKernelGGL(k_prep<true>, dim3((unsigned)((n + PREP_READS - 1) / PREP_READS)), dim3(PREP_THREADS), 0, ctx->stream, a);
     }
@@ -661,7 +665,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     const bool timing = getenv("C3R_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    DevBuf *bufs[] = {&ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_binoff, &ctx->d_rtab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
+    DevBuf *bufs[] = {&ctx->d_wgtab, &ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_binoff, &ctx->d_rtab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
                       &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff, &ctx->d_padins, &ctx->d_aftab, &ctx->d_keep, &ctx->d_sites_c, &ctx->d_probs_c};

@@ -316,6 +316,8 @@ struct PrepArgs {
                               // word would take 0.6 ms)
     PileRec *recs;
     LoadStats *st;
+    uint32_t *wg_tab;         // [workgroups][2 HB] the workgroups' bin tables (keys, counts) as k_prep<false> leaves them: k_prep<true> starts from them
+                              // instead of walking its reads' CIGARs once more to count (null: it counts again)
 };
 
 // Bin counters are updated through a per-workgroup hash table in LDS: a workgroup's 64 reads are neighbours in the sorted input and
@@ -351,12 +353,15 @@ __device__ __forceinline__ int hb_find(BinHash &T, uint32_t bin, bool insert) {
 
 template <bool WRITE>
 __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
-    __shared__ BinHash T;
+    __shared__ __attribute__((aligned(16))) BinHash T;
     __shared__ uint32_t s_base[WRITE ? HB : 1];
     const int tid = (int)threadIdx.x, gl = tid & (PREP_GRP - 1);
     const int i = (int)(blockIdx.x * PREP_READS + (tid / PREP_GRP));
     const bool valid = i < a.n_reads;
-    for (int h = tid; h < HB; h += PREP_THREADS) { T.key[h] = 0; T.val[h] = 0; }
+    static_assert(sizeof(BinHash) == 2 * HB * 4 && (2 * HB) % 4 == 0, "the bin table travels as 16-byte words");
+    uint4 *const tab = a.wg_tab ? reinterpret_cast<uint4 *>(a.wg_tab + (size_t)blockIdx.x * 2 * HB) : nullptr;
+    if (WRITE && tab) { for (int h = tid; h < 2 * HB / 4; h += PREP_THREADS) reinterpret_cast<uint4 *>(&T)[h] = tab[h]; }
+    else for (int h = tid; h < HB; h += PREP_THREADS) { T.key[h] = 0; T.val[h] = 0; }
     __syncthreads();
     ReadInfo R;
     R.cig = a.cigars; R.pos = 0; R.n_cig = 0; R.l_seq = 0; R.read_idx = (uint32_t)i; R.seq_off = 0; R.wbits = 0; R.compat = a.compat; R.padbit = 0;
@@ -413,6 +418,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
         __syncthreads();
         for (int h = tid; h < HB; h += PREP_THREADS)
             if (T.key[h]) __hip_atomic_fetch_add(&a.cnt[T.key[h] - 1u], T.val[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tab) for (int h = tid; h < 2 * HB / 4; h += PREP_THREADS) tab[h] = reinterpret_cast<const uint4 *>(&T)[h];
     } else {
         bool pass = false, serial = false;
         if (valid) {
@@ -423,9 +429,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
             R.cig = a.cigars + d.cig_off; R.pos = d.pos; R.n_cig = d.n_cig; R.l_seq = d.l_seq; R.seq_off = d.seq_off;
             R.wbits = ((d.flag & 16u) ? 64u : 0u) | ((d.hp == 1 ? 1u : d.hp == 2 ? 2u : 0u) << 7);
         }
-        // first walk: how many records this workgroup has for each of its bins; one atomic per bin takes that many slots (the counters
-        // count down: the workgroup's run in bin b is [rec_off[b] + left - n, rec_off[b] + left)); second walk: every record into its run
-        if (pass) { if (!serial) walk_plain(R, gl, tally); else if (gl == 0) (void)walk_serial(R, tally); }
+        // how many records this workgroup has for each of its bins: the table k_prep<false> left (or, without it, a first walk); one atomic
+        // per bin takes that many slots (the counters count down: the workgroup's run in bin b is [rec_off[b] + left - n, rec_off[b] + left));
+        // then the walk: every record into its run
+        if (!tab) { if (pass) { if (!serial) walk_plain(R, gl, tally); else if (gl == 0) (void)walk_serial(R, tally); } }
         __syncthreads();
         for (int h = tid; h < HB; h += PREP_THREADS) {
             if (!T.key[h]) continue;
