@@ -475,7 +475,7 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
         a.st = (LoadStats *)ctx->d_stats.p;
         char *lbk = (char *)ctx->d_lbk.p;
         const unsigned grid = (unsigned)((n + PREP_READS - 1) / PREP_READS);
-        if ((rc = ensure(ctx, ctx->d_wgtab, (size_t)grid * 2 * HB * 4))) return rc;          // the workgroups' bin tables, kept for the second pass
+        if ((rc = ensure(ctx, ctx->d_wgtab, (size_t)grid * WG_TAB_WORDS * 4))) return rc;    // what the workgroups counted, kept for the second pass
         a.wg_tab = (uint32_t *)ctx->d_wgtab.p;
         {
             Launch L(ctx, "k_prep_count");

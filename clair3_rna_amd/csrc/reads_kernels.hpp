@@ -316,8 +316,9 @@ struct PrepArgs {
                               // word would take 0.6 ms)
     PileRec *recs;
     LoadStats *st;
-    uint32_t *wg_tab;         // [workgroups][2 HB] the workgroups' bin tables (keys, counts) as k_prep<false> leaves them: k_prep<true> starts from them
-                              // instead of walking its reads' CIGARs once more to count (null: it counts again)
+    uint32_t *wg_tab;         // [workgroups][2 HB + 4] what k_prep<false> counted per workgroup — [0] entries, then (bin + 1, records) pairs from word 4 on, only
+                              // the occupied slots of its table (a couple of hundred: ~2 KB of the slab's 8 KB are ever touched): k_prep<true> rebuilds its
+                              // table from them instead of walking its reads' CIGARs once more to count (null: it counts again)
 };
 
 // Bin counters are updated through a per-workgroup hash table in LDS: a workgroup's 64 reads are neighbours in the sorted input and
@@ -335,6 +336,7 @@ struct PrepArgs {
 constexpr int PREP_THREADS = C3R_PREP_THREADS, PREP_READS = PREP_THREADS / PREP_GRP;
 constexpr int HB_LOG = C3R_HB_LOG, HB = 1 << HB_LOG, HB_PROBES = 16;
 struct BinHash { uint32_t key[HB], val[HB]; };              // key = bin + 1, 0 = empty
+constexpr int WG_TAB_WORDS = 2 * HB + 4;                    // PrepArgs::wg_tab: words per workgroup
 // slot of `bin`, or -1: not there (insert: and no free slot among its HB_PROBES places — such a bin goes to the global counter directly,
 // in every walk alike, because an occupied slot never becomes free)
 __device__ __forceinline__ int hb_find(BinHash &T, uint32_t bin, bool insert) {
@@ -353,15 +355,15 @@ __device__ __forceinline__ int hb_find(BinHash &T, uint32_t bin, bool insert) {
 
 template <bool WRITE>
 __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
-    __shared__ __attribute__((aligned(16))) BinHash T;
+    __shared__ BinHash T;
     __shared__ uint32_t s_base[WRITE ? HB : 1];
+    __shared__ uint32_t s_ntab;
     const int tid = (int)threadIdx.x, gl = tid & (PREP_GRP - 1);
     const int i = (int)(blockIdx.x * PREP_READS + (tid / PREP_GRP));
     const bool valid = i < a.n_reads;
-    static_assert(sizeof(BinHash) == 2 * HB * 4 && (2 * HB) % 4 == 0, "the bin table travels as 16-byte words");
-    uint4 *const tab = a.wg_tab ? reinterpret_cast<uint4 *>(a.wg_tab + (size_t)blockIdx.x * 2 * HB) : nullptr;
-    if (WRITE && tab) { for (int h = tid; h < 2 * HB / 4; h += PREP_THREADS) reinterpret_cast<uint4 *>(&T)[h] = tab[h]; }
-    else for (int h = tid; h < HB; h += PREP_THREADS) { T.key[h] = 0; T.val[h] = 0; }
+    uint32_t *const tab = a.wg_tab ? a.wg_tab + (size_t)blockIdx.x * WG_TAB_WORDS : nullptr;
+    for (int h = tid; h < HB; h += PREP_THREADS) { T.key[h] = 0; T.val[h] = 0; }
+    if (tid == 0) s_ntab = 0;
     __syncthreads();
     ReadInfo R;
     R.cig = a.cigars; R.pos = 0; R.n_cig = 0; R.l_seq = 0; R.read_idx = (uint32_t)i; R.seq_off = 0; R.wbits = 0; R.compat = a.compat; R.padbit = 0;
@@ -418,7 +420,13 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
         __syncthreads();
         for (int h = tid; h < HB; h += PREP_THREADS)
             if (T.key[h]) __hip_atomic_fetch_add(&a.cnt[T.key[h] - 1u], T.val[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tab) for (int h = tid; h < 2 * HB / 4; h += PREP_THREADS) tab[h] = reinterpret_cast<const uint4 *>(&T)[h];
+        if (tab) {
+            // the occupied slots, densely (order does not matter): what the second pass needs to know instead of counting again
+            for (int h = tid; h < HB; h += PREP_THREADS)
+                if (T.key[h]) { const uint32_t k = atomicAdd(&s_ntab, 1u); reinterpret_cast<uint2 *>(tab + 4)[k] = make_uint2(T.key[h], T.val[h]); }
+            __syncthreads();
+            if (tid == 0) tab[0] = s_ntab;
+        }
     } else {
         bool pass = false, serial = false;
         if (valid) {
@@ -432,7 +440,16 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
         // how many records this workgroup has for each of its bins: the table k_prep<false> left (or, without it, a first walk); one atomic
         // per bin takes that many slots (the counters count down: the workgroup's run in bin b is [rec_off[b] + left - n, rec_off[b] + left));
         // then the walk: every record into its run
-        if (!tab) { if (pass) { if (!serial) walk_plain(R, gl, tally); else if (gl == 0) (void)walk_serial(R, tally); } }
+        if (tab) {
+            // (an entry that finds no place among its HB_PROBES slots now — the insertion order differs — is simply left out: its records take
+            // the direct path below, against the global counter that holds them since the first pass)
+            const uint32_t nt = tab[0];
+            for (uint32_t k = (uint32_t)tid; k < nt; k += PREP_THREADS) {
+                const uint2 e = reinterpret_cast<const uint2 *>(tab + 4)[k];
+                const int s_ = hb_find(T, e.x - 1u, true);
+                if (s_ >= 0) T.val[s_] = e.y;
+            }
+        } else if (pass) { if (!serial) walk_plain(R, gl, tally); else if (gl == 0) (void)walk_serial(R, tally); }
         __syncthreads();
         for (int h = tid; h < HB; h += PREP_THREADS) {
             if (!T.key[h]) continue;
