@@ -1498,13 +1498,18 @@ __device__ __forceinline__ TokenAt token_at(const DevRead &rd, int r, int p, con
 // index, i.e. BAM order (k_export_tokens / k_pack_*).  done(k, n) reports the tokens written for candidate k.
 struct TokLds {
     unsigned long long cmask[TILE / 64];       // the candidates as a bit per position of the tile
-    int32_t cpre[TILE / 64];                   // candidates before each 64-position word
     int32_t toff[TILE], cap[TILE], cnt[TILE];  // per candidate (rank by position): first slot, slots owned, tokens written
     uint8_t refn[TILE];                        // its reference base as a 4-bit code (evc_base_from: anything but C / G / T counts as A)
     int32_t lost;                              // tokens that found no slot (the bound was wrong: the scan fails)
 };
 // index of the candidate at tile position x (its bit in cmask is set)
-__device__ __forceinline__ int tok_cand(const TokLds &K, int x) { return K.cpre[x >> 6] + __popcll(K.cmask[x >> 6] & ((1ull << (x & 63)) - 1ull)); }
+__device__ __forceinline__ int tok_cand(const TokLds &K, int x) {
+    const int w = x >> 6;
+    int c = __popcll(K.cmask[w] & ((1ull << (x & 63)) - 1ull));
+#pragma unroll
+    for (int k = 0; k < TILE / 64 - 1; ++k) if (k < w) c += __popcll(K.cmask[k]);
+    return c;
+}
 // the candidates among the tile positions [x0, x0 + n), n <= 64, as bits 0 .. n - 1
 __device__ __forceinline__ unsigned long long tok_cand_bits(const TokLds &K, int x0, int n) {
     const int w = x0 >> 6, sh = x0 & 63;
@@ -1563,15 +1568,21 @@ __device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long t
 
 // cand(k, lpos, toff, cap): position (relative to t0), first token slot and slots owned of the tile's k-th candidate, ascending.
 // done(k, n): the tokens written for it.  Returns (to every thread) the tokens that found no slot — zero unless the bound is wrong.
-template <class CandFn, class DoneFn>
+// HAVE_MASK: thread tid stands for position t0 + tid and `mine` says whether it is a candidate (k_fused_tiles): the mask is four ballots,
+// no clearing, no atomics, one barrier less.
+template <bool HAVE_MASK, class CandFn, class DoneFn>
 __device__ __forceinline__ int tile_tokens(const ScanArgs &a, TokLds &K, int t0, int t1, int region, int rlo, int rhi, int nc, CandFn &&cand, DoneFn &&done,
-                                           c3r_token_t *tok, long long tok_cap) {
+                                           c3r_token_t *tok, long long tok_cap, bool mine = false) {
     const int tid = (int)threadIdx.x;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    __syncthreads();
-    if (tid < TILE / 64) K.cmask[tid] = 0ull;
+    const unsigned long long my_wave = HAVE_MASK ? __ballot(mine) : 0ull;
+    __syncthreads();                                        // (K lies where the accumulators lay: everyone is done with them)
+    if (HAVE_MASK) { if ((tid & 63) == 0) K.cmask[tid >> 6] = my_wave; }
+    else {
+        if (tid < TILE / 64) K.cmask[tid] = 0ull;
+        __syncthreads();
+    }
     if (tid == 0) K.lost = 0;
-    __syncthreads();
     if (tid < nc) {
         int lp, off, cp;
         cand(tid, lp, off, cp);
@@ -1579,10 +1590,8 @@ __device__ __forceinline__ int tile_tokens(const ScanArgs &a, TokLds &K, int t0,
         const int rp = t0 + lp - a.ref_beg0;
         const uint8_t rb = (rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
         K.refn[tid] = (uint8_t)(1u << ref_index(rb));
-        atomicOr(&K.cmask[lp >> 6], 1ull << (lp & 63));
+        if (!HAVE_MASK) atomicOr(&K.cmask[lp >> 6], 1ull << (lp & 63));
     }
-    __syncthreads();
-    if (tid < TILE / 64) { int pre = 0; for (int k = 0; k < tid; ++k) pre += __popcll(K.cmask[k]); K.cpre[tid] = pre; }
     __syncthreads();
     // a record matters only if its piece covers a candidate (or, an indel behind a ref-skip, sits on one): the candidates' bit mask says
     // so from the record's first half alone, before its second half or any base is fetched
@@ -1651,7 +1660,7 @@ __global__ __launch_bounds__(SCAN_THREADS, C3R_TOK_OCC) void k_tile_tokens(const
         const TileGeo tg = a.geo[tile];
         const int slot0 = tile * TILE;
         const int4 rng = a.tile_rng[tile];
-        const int lost = tile_tokens(a, K, tg.p0, tg.p1, tg.region, rng.z, rng.w, tc.y, [&](int k, int &lp, int &off, int &cp) {
+        const int lost = tile_tokens<false>(a, K, tg.p0, tg.p1, tg.region, rng.z, rng.w, tc.y, [&](int k, int &lp, int &off, int &cp) {
             const int w = tc.x + k;
             lp = t.cand_idx[w] - slot0;
             off = t.tok_base + t.tok_off[w];
@@ -1951,13 +1960,13 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         if (f.tok && !(C3R_ABL(a) & 128)) {                                   // (ablation 128: no token pass)
             if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[7], now_ - t_tail); t_tail = now_; dbg_slot = 8; }
             TokLds &K = *reinterpret_cast<TokLds *>(M.cnt);
-            const int lost = tile_tokens(a, K, x0, x1, tg.region, rng.z, rng.w, nc, [&](int k, int &lp, int &off, int &cp) {
+            const int lost = tile_tokens<true>(a, K, x0, x1, tg.region, rng.z, rng.w, nc, [&](int k, int &lp, int &off, int &cp) {
                 lp = (int)M.amb[k]; off = f.tok_base + tok0 + M.evoff[k];
                 cp = (k + 1 < nc ? M.evoff[k + 1] : nt) - M.evoff[k];
             }, [&](int k, int n) {
                 f.meta[row0 + k].ncov = n;                                  // (the site's n_tok: what was written, not what was reserved)
                 if (n) atomicAdd(&f.span_info[b].z, n);                     // the span's tokens: k_order_spans sums them into the scan's total
-            }, f.tok, (long long)f.tok_base + (long long)(shard + 1) * f.shard_toks);
+            }, f.tok, (long long)f.tok_base + (long long)(shard + 1) * f.shard_toks, emit);
             if (lost && tid == 0) atomicOr(f.overflow, 8);
         }
         }
