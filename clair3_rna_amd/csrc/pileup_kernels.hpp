@@ -2080,7 +2080,7 @@ __global__ __launch_bounds__(256) void k_site_ntok(const c3r_site_t *sites, int 
 // A site's tokens lie in the order they arrived (tile_tokens); whoever takes them out puts them into BAM order = by read index (a read has
 // at most one token per site).  One wavefront per site: rank of token k0 + lane among the site's n tokens, and among those that carry an
 // indel (the packed form keeps the indel records apart).  Sites hold two or three tokens; a deep site's thousands cost n^2 / 64 steps.
-__device__ __forceinline__ void site_tok_rank(const c3r_token_t *s_, int n, uint32_t my_read, int lane, int &rank, int &rank_ind) {
+__device__ __forceinline__ void site_tok_rank(const c3r_token_t *s_, int n, uint32_t my_read, int my_k, int lane, int &rank, int &rank_ind) {
     rank = 0; rank_ind = 0;
     for (int j0 = 0; j0 < n; j0 += 64) {
         const int j = j0 + lane;
@@ -2090,7 +2090,8 @@ __device__ __forceinline__ void site_tok_rank(const c3r_token_t *s_, int n, uint
         for (int l = 0; l < m; ++l) {
             const uint32_t x = (uint32_t)__shfl((int)oi, l, 64);
             const int xi = __shfl(oind, l, 64);
-            if (x < my_read) { ++rank; rank_ind += xi; }
+            // (equal read indices cannot occur — one token per read and site — but a rank must be a permutation whatever the input)
+            if (x < my_read || (x == my_read && j0 + l < my_k)) { ++rank; rank_ind += xi; }
         }
     }
 }
@@ -2105,7 +2106,7 @@ __global__ __launch_bounds__(256) void k_export_tokens(const c3r_site_t *sites, 
             int4 v = make_int4(0, 0, 0, 0);
             if (k < nt) v = reinterpret_cast<const int4 *>(s_)[k];
             int rank, rind;
-            site_tok_rank(s_, nt, k < nt ? (uint32_t)v.x : 0xffffffffu, lane, rank, rind);
+            site_tok_rank(s_, nt, k < nt ? (uint32_t)v.x : 0xffffffffu, k, lane, rank, rind);
             if (k < nt) d_[rank] = v;
         }
     }
@@ -2143,7 +2144,7 @@ __global__ __launch_bounds__(256) void k_pack_tokens(const c3r_site_t *__restric
         c3r_token_t t{};
         if (valid) t = tok[off + i];
         int rank, rind;
-        site_tok_rank(tok + off, n_tok, valid ? t.read_idx : 0xffffffffu, lane, rank, rind);        // BAM order
+        site_tok_rank(tok + off, n_tok, valid ? t.read_idx : 0xffffffffu, i, lane, rank, rind);     // BAM order
         const bool f = valid && t.indel != 0;
         if (valid) bytes[off + rank] = (uint8_t)((t.base & 31) | (t.rev ? 0x20 : 0) | (f ? 0x80 : 0));
         if (f) recs[base + (uint32_t)rind] = TokRec{t.read_idx, t.indel, t.qpos, t.del_after};
@@ -2219,7 +2220,7 @@ __global__ __launch_bounds__(256) void k_pack_rows(const c3r_site_t *__restrict_
         c3r_token_t t{};
         if (valid) t = tok[off + i];
         int rank, rind;
-        site_tok_rank(tok + off, n_tok, valid ? t.read_idx : 0xffffffffu, lane, rank, rind);        // BAM order
+        site_tok_rank(tok + off, n_tok, valid ? t.read_idx : 0xffffffffu, i, lane, rank, rind);     // BAM order
         const bool f = valid && t.indel != 0;
         if (valid) bytes[bbase + rank] = (uint8_t)((t.base & 31) | (t.rev ? 0x20 : 0) | (f ? 0x80 : 0));
         if (f) recs[base + (uint32_t)rind] = TokRec{t.read_idx, t.indel, t.qpos, t.del_after};
