@@ -13,6 +13,7 @@ for k in ("strong_1gpu", "phased_1gpu", "stress_500x", "depth_cap_20000x"):
     v = d.get(k)
     if not v: continue
     print(k, {x: v[x] for x in ("value", "ms_per_step", "sites_per_step", "reads", "reads_per_s", "error", "cap_cost_ms_per_step", "precision") if x in v})
+    if v.get("two_contexts"): print("   two contexts", v["two_contexts"])
     if "kernels_ms_per_step" in v: print("   kernels", v["kernels_ms_per_step"])
     if v.get("roofline"): print("   roofline", {x: v["roofline"][x] for x in ("kernel", "bound", "achieved", "frac", "avg_launch_ms") if x in v["roofline"]})
     if v.get("roofline_tensor_build"): print("   tensor build", {x: v["roofline_tensor_build"][x] for x in ("achieved", "frac", "ms", "bytes_per_site")})
