@@ -858,7 +858,8 @@ int c3r_set_sites(c3r_ctx *ctx, const int32_t *sites, int64_t n) {
 }
 
 // ------------------------------------------------------------------------------------------------
-static int run_gather(c3r_ctx *ctx, int rescale, int32_t *dst, bool with_sites) {
+// dst16: the windows go out as int16 (the resident, rescaled tensors), else int32 (c3r_get_tensors' raw export)
+static int run_gather(c3r_ctx *ctx, int rescale, void *dst, bool with_sites, bool dst16) {
     // operates on the candidates of the most recent scan; `dst` already points at their slot
     GatherArgs g;
     g.cols = (const int32_t *)ctx->d_cols.p; g.depth = (const int32_t *)ctx->d_depth.p; g.ncov = (const int32_t *)ctx->d_ncov.p;
@@ -867,7 +868,7 @@ static int run_gather(c3r_ctx *ctx, int rescale, int32_t *dst, bool with_sites) 
     g.ref = (const uint8_t *)ctx->d_ref.p; g.ref_beg0 = (int32_t)(ctx->ref_start1 - 1); g.ref_len = (int32_t)ctx->ref_len;
     g.head_tail = ctx->prm.head_tail; g.last_row = (const int32_t *)ctx->d_lastrow.p;
     g.rescale = rescale; g.max_depth = ctx->prm.max_depth_rescale;
-    g.tensors = dst;
+    g.tensors = dst; g.x16 = dst16 ? 1 : 0;
     g.raw = nullptr; g.skipmax = nullptr;
     g.sites = with_sites ? (c3r_site_t *)ctx->d_sites_out.p + ctx->last_base : nullptr;
     g.tok_cnt = with_sites ? (int32_t *)ctx->d_tokcnt.p : nullptr;
@@ -1239,23 +1240,24 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
         fprintf(stderr, "[k_scan_tiles] %llu heavy tiles; per tile: segments in range %.1f, listed %.1f, ops %.1f; us per tile: zero %.2f | cover+list+walk %.2f | scans %.2f | events %.2f | gates %.2f | store %.2f | first-seen %.2f\n",
                 d[15], d[13] / nt, d[12] / nt, d[14] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[5] / nt / 100, d[6] / nt / 100);
     }
-    if (flag_cand[0]) { ctx->last_scan_pruned = false; return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap); }
+    if (flag_cand[0] & 2) { ctx->last_scan_pruned = false; return fail(ctx, C3R_EOVERFLOW, "a position is covered by more than 32,767 reads (after mpileup's depth cap): lower max_depth"); }
+    if (flag_cand[0] & 1) { ctx->last_scan_pruned = false; return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap); }
     const int32_t n_cand = flag_cand[1];
     ctx->last_cand = n_cand;
     if (n_candidates) *n_candidates = n_cand;
     if (n_cand == 0) return C3R_OK;
-    const size_t tbytes = (size_t)C3R_WINDOW * C * 4;
+    const size_t tbytes = (size_t)C3R_WINDOW * C * sizeof(int16_t);          // the resident windows are int16 (a caller sees int32: c3r_get_tensors)
     if ((rc = ensure(ctx, ctx->d_cand, (size_t)n_cand * 4))) return rc;
     if ((rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_row + n_cand) * tbytes, (size_t)base_row * tbytes))) return rc;
     if ((rc = ensure_keep(ctx, ctx->d_sites_out, (size_t)(base_cand + n_cand) * sizeof(c3r_site_t), (size_t)base_cand * sizeof(c3r_site_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_tokcnt, (size_t)(n_cand + 1) * 4))) return rc;
-    if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_raw, (size_t)n_cand * tbytes))) return rc;
+    if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_raw, (size_t)n_cand * 2 * tbytes))) return rc;      // (raw windows: int32)
     {
         Launch L(ctx, "k_compact_write");
         hipLaunchKernelGGL(k_compact_write, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
                            (const int32_t *)ctx->d_blockcnt.p, (int32_t *)ctx->d_cand.p, heavy, (int2 *)ctx->d_tile_cand.p);
     }
-    if ((rc = run_gather(ctx, 1, (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_row * tbytes), true))) return rc;
+    if ((rc = run_gather(ctx, 1, (char *)ctx->d_tensors.p + (size_t)base_row * tbytes, true, true))) return rc;
     if ((rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + n_cand) * 4, (size_t)base_cand * 4))) return rc;
     hipLaunchKernelGGL(k_iota, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, ctx->stream, (int32_t *)ctx->d_winidx.p + base_cand, (int)n_cand, (int)base_row);      // (windows in site order)
     {
@@ -1372,7 +1374,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     f.ph.reads = a.reads; f.ph.rsegs = have_tables ? (const DevSeg *)ctx->d_rsegs.p : nullptr; f.ph.rseg_first = have_tables ? (const uint32_t *)ctx->d_rseg_first.p : nullptr;
     f.ph.cigar = (const uint32_t *)ctx->d_cigar.p; f.ph.seq = a.seq;
     f.ph.min_mq = a.min_mq; f.ph.excl_flags = a.excl_flags; f.ph.drop = a.drop; f.ph.drop_words = a.drop_words;
-    const size_t tbytes = (size_t)C3R_WINDOW * C * 4;
+    const size_t tbytes = (size_t)C3R_WINDOW * C * sizeof(int16_t);          // the resident windows are int16 (a caller sees int32: c3r_get_tensors)
     // What this scan may write.  A small scan has one allocator and dense output: whatever the buffers can take beyond what the batch
     // already holds.  A large one hands rows and token slots out through ALLOC_SHARDS sub-allocators of equal size, sized from what the
     // previous large scan needed; when a shard runs over, the scan is repeated with what the counters say it needs.
@@ -1394,8 +1396,8 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         const int64_t rows = want_c * nsh, toks = want_t * nsh;
         if ((rc = ensure(ctx, ctx->d_meta, std::max<size_t>((size_t)rows * sizeof(CandMeta), 16)))) return rc;
         if (raw_rerun) {
-            if ((rc = ensure(ctx, ctx->d_raw, std::max<size_t>((size_t)rows * tbytes, 16))) || (rc = ensure(ctx, ctx->d_rawidx, std::max<size_t>((size_t)rows * 4, 16)))) return rc;
-            f.tensors = (int32_t *)ctx->d_raw.p;
+            if ((rc = ensure(ctx, ctx->d_raw, std::max<size_t>((size_t)rows * 2 * tbytes, 16))) || (rc = ensure(ctx, ctx->d_rawidx, std::max<size_t>((size_t)rows * 4, 16)))) return rc;
+            f.tensors = ctx->d_raw.p; f.x16 = 0;
             z.win_idx = (int32_t *)ctx->d_rawidx.p; z.row_base = 0;
         } else {
             if ((rc = ensure(ctx, ctx->d_cand, (size_t)rows * 4)) ||
@@ -1404,7 +1406,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
                 (rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + rows) * 4, (size_t)base_cand * 4)) ||
                 (rc = ensure_keep(ctx, ctx->d_tok, (size_t)(base_tok + toks) * sizeof(c3r_token_t), (size_t)base_tok * sizeof(c3r_token_t))))
                 return rc;
-            f.tensors = (int32_t *)((char *)ctx->d_tensors.p + (size_t)base_row * tbytes);
+            f.tensors = (char *)ctx->d_tensors.p + (size_t)base_row * tbytes; f.x16 = 1;
             z.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
             z.cand_idx = (int32_t *)ctx->d_cand.p;
             z.win_idx = (int32_t *)ctx->d_winidx.p + base_cand; z.row_base = (int32_t)base_row; z.tok_base = (int32_t)base_tok;
@@ -1459,7 +1461,8 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             --attempt;
             continue;
         }
-        if (ctx->h_scan[6]) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
+        if (ctx->h_scan[6] & 2) return fail(ctx, C3R_EOVERFLOW, "a position is covered by more than 32,767 reads (after mpileup's depth cap): lower max_depth");
+        if (ctx->h_scan[6] & 1) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
         if (ctx->h_scan[2] & 8) return fail(ctx, C3R_EOVERFLOW, "internal: tokens found no slot (the gates' bound of a site's tokens was too small)");
         if (n_cand < 0 || n_tok < 0) return fail(ctx, C3R_EOVERFLOW, "too many candidates or tokens for one scan");
         if (raw_rerun) {
@@ -1534,7 +1537,7 @@ int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_si
             if (!ctx->prm.splice_padding) {     // (splice padding: the scan already kept the raw windows, the columns have moved on)
                 int rc = ensure(ctx, ctx->d_raw, bytes);
                 if (rc) return rc;
-                if ((rc = run_gather(ctx, 0, (int32_t *)ctx->d_raw.p, false))) return rc;
+                if ((rc = run_gather(ctx, 0, ctx->d_raw.p, false, false))) return rc;
             }
             idx = nullptr;
         }
@@ -1543,8 +1546,9 @@ int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_si
     if (idx) {
         int rc = ensure(ctx, ctx->d_export, bytes);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)std::min<int64_t>((ctx->n_cand + 3) / 4, 8192)), dim3(256), 0, ctx->stream, (const int32_t *)src, idx, (int)ctx->n_cand, row_ints,
-                           (int32_t *)ctx->d_export.p);
+        // (the resident windows are int16 rows in arrival order: gathered into position order and widened; a raw re-run's are int32)
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)std::min<int64_t>((ctx->n_cand + 3) / 4, 8192)), dim3(256), 0, ctx->stream, src, idx, (int)ctx->n_cand, row_ints,
+                           (int32_t *)ctx->d_export.p, rescaled ? 1 : 0);
         src = ctx->d_export.p;
     }
     HIPCHK(ctx, hipMemcpyAsync(tensors, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1799,18 +1803,20 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
     if (!ctx->net.loaded) return fail(ctx, C3R_EINVAL, "c3r_load_weights must be called before c3r_infer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int C = ctx->net.channels;
-    const int32_t *d_x = nullptr, *d_rows = nullptr;
+    const void *d_x = nullptr;
+    const int32_t *d_rows = nullptr;
+    const bool x16 = tensors == nullptr;                 // the resident windows are int16, a caller's batch int32
     if (tensors == nullptr) {
         if (C != ctx->prm.channels) return fail(ctx, C3R_EINVAL, "weights are for %d channels, scan produced %d", C, ctx->prm.channels);
         if (n != ctx->n_cand) return fail(ctx, C3R_EINVAL, "n=%lld but %lld candidates are resident", (long long)n, (long long)ctx->n_cand);
-        d_x = (const int32_t *)ctx->d_tensors.p;
+        d_x = ctx->d_tensors.p;
         d_rows = (const int32_t *)ctx->d_winidx.p;       // windows lie in arrival order (k_fused_tiles)
     } else if (n > 0) {
         int rc = ensure(ctx, ctx->d_raw, (size_t)n * C3R_WINDOW * C * 4);
         if (rc) return rc;
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_raw.p, tensors, (size_t)n * C3R_WINDOW * C * 4, hipMemcpyHostToDevice, ctx->stream));
         if (!probs) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the caller's buffer must be free to go when we return
-        d_x = (const int32_t *)ctx->d_raw.p;
+        d_x = ctx->d_raw.p;
     }
     if (n == 0) return C3R_OK;
     std::string e;
@@ -1831,7 +1837,7 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
             KStat &k = ctx->kstats[name]; k.ms += ms; k.n += 1;
         }
     };
-    int rc = net_forward(ctx->net, d_x, d_rows, n, nst, prof, e);
+    int rc = net_forward(ctx->net, d_x, d_rows, n, nst, prof, e, x16);
     if (ctx->net_stream) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_net, ctx->net_stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_net, 0));

@@ -92,7 +92,8 @@ __device__ __forceinline__ float selu(float x) {
 template <int INP, int CIN, int H, bool INT_IN, int SB = 2, int ABL = 0>
 __global__ __launch_bounds__(256, (SB == 1 ? 2 : 1)) void k_lstm(const void *__restrict__ xin, const float4 *__restrict__ Wp,
                                                                   const float *__restrict__ bp, float *__restrict__ y, int n,
-                                                                  const int32_t *__restrict__ row_idx = nullptr /* INT_IN: row of site i in xin (null: i) */) {
+                                                                  const int32_t *__restrict__ row_idx = nullptr /* INT_IN: row of site i in xin (null: i) */,
+                                                                  int x16 = 0 /* INT_IN: the rows are int16 (the tensor build's windows), not int32 */) {
     constexpr int NGX = INP / 8;           // k-groups fed from the layer input (global memory)
     constexpr int NGH = H / 8;             // k-groups fed from h_{t-1} (LDS)
     constexpr int NG = NGX + NGH;
@@ -147,12 +148,20 @@ __global__ __launch_bounds__(256, (SB == 1 ? 2 : 1)) void k_lstm(const void *__r
             for (int sb = 0; sb < SB; ++sb) {
                 if (ABL & 16) { b[sb] = make_float4(1.f, 0.5f, 0.25f, (float)g); continue; }
                 if (INT_IN) {
-                    const int32_t *xp = (const int32_t *)xin + xoff[sb] + (size_t)t * CIN;
                     const int k0 = 8 * g + 4 * hh;
-                    b[sb].x = (k0 + 0 < CIN) ? (float)xp[k0 + 0] : 0.f;
-                    b[sb].y = (k0 + 1 < CIN) ? (float)xp[k0 + 1] : 0.f;
-                    b[sb].z = (k0 + 2 < CIN) ? (float)xp[k0 + 2] : 0.f;
-                    b[sb].w = (k0 + 3 < CIN) ? (float)xp[k0 + 3] : 0.f;
+                    if (x16) {
+                        const int16_t *xp = (const int16_t *)xin + xoff[sb] + (size_t)t * CIN;
+                        b[sb].x = (k0 + 0 < CIN) ? (float)xp[k0 + 0] : 0.f;
+                        b[sb].y = (k0 + 1 < CIN) ? (float)xp[k0 + 1] : 0.f;
+                        b[sb].z = (k0 + 2 < CIN) ? (float)xp[k0 + 2] : 0.f;
+                        b[sb].w = (k0 + 3 < CIN) ? (float)xp[k0 + 3] : 0.f;
+                    } else {
+                        const int32_t *xp = (const int32_t *)xin + xoff[sb] + (size_t)t * CIN;
+                        b[sb].x = (k0 + 0 < CIN) ? (float)xp[k0 + 0] : 0.f;
+                        b[sb].y = (k0 + 1 < CIN) ? (float)xp[k0 + 1] : 0.f;
+                        b[sb].z = (k0 + 2 < CIN) ? (float)xp[k0 + 2] : 0.f;
+                        b[sb].w = (k0 + 3 < CIN) ? (float)xp[k0 + 3] : 0.f;
+                    }
                 } else {
                     b[sb] = *(const float4 *)((const float *)xin + xoff[sb] + (size_t)t * CIN + 8 * g + 4 * hh);
                 }
@@ -1035,9 +1044,12 @@ __global__ __launch_bounds__(512, 2) void k_lstm2_mx(const _Float16 *__restrict_
 // accumulator one after the other (no registers for two), and every B fragment is read from LDS by sixteen wavefronts.
 // Wp: [dir][quarter][g][tile(4)][hi|lo][lane] (tile blk = 4 quarter + tile); the bias rides on input slot CIN (x = 1 there).
 template <int CIN, bool YQ = false, bool RTS = false>
-__global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ xin, const half8 *__restrict__ Wp, _Float16 *__restrict__ y, int n, int nstride,
+__global__ __launch_bounds__(1024) void k_lstm1_rs(const void *__restrict__ xin_v, const half8 *__restrict__ Wp, _Float16 *__restrict__ y, int n, int nstride,
                                                    const int32_t *__restrict__ row_idx /* row of site i in xin (the tensor build writes windows as they arrive); null: i */,
-                                                   float wun_arg = WUNSCALE /* RTS: 2^-s of the layer's weight scale (k_lstm2_w8) */) {
+                                                   float wun_arg = WUNSCALE /* RTS: 2^-s of the layer's weight scale (k_lstm2_w8) */,
+                                                   int x16 = 0 /* the rows are int16 (the tensor build's windows), not int32 (a caller's batch) */) {
+    const int32_t *__restrict__ xin = (const int32_t *)xin_v;
+    const int16_t *__restrict__ xin16 = (const int16_t *)xin_v;
     const float wun = RTS ? wun_arg : WUNSCALE;
     constexpr int H = NET_H1, NGX = 2, NGH = H / 16, NG = NGX + NGH, HP = H + 8, NTQ = 4, WG_SITES = 64, HV = H / 8, XP = 40;
     constexpr int NPC = (CIN + 1) / 2;
@@ -1079,7 +1091,10 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const int32_t *__restrict__ x
         xrow = (size_t)sj * NET_T * CIN + 2 * (tid % NPC);
     }
     auto x_fetch = [&](int tt_) {
-        if (xmine) xr = *(const int2v *)(xin + xrow + (size_t)tt_ * CIN);
+        if (xmine) {
+            if (x16) { const int pr = *(const int *)(xin16 + xrow + (size_t)tt_ * CIN); xr[0] = (int)(int16_t)(pr & 0xffff); xr[1] = pr >> 16; }
+            else xr = *(const int2v *)(xin + xrow + (size_t)tt_ * CIN);
+        }
     };
     auto x_store = [&](int buf) {
         if (xmine) {
@@ -1780,25 +1795,27 @@ inline int net_reserve(NetState &s, int64_t n_total, hipStream_t st, std::string
 }
 
 // d_x: device int32 [n][33][C].  prof(name, 0|1) brackets each kernel for optional event timing.
-inline int net_forward_slice(NetState &s, const int32_t *d_x, const int32_t *row_idx, int64_t n, float *d_probs, hipStream_t st,
-                             const std::function<void(const char *, int)> &prof, std::string &err);
+inline int net_forward_slice(NetState &s, const void *d_x, const int32_t *row_idx, int64_t n, float *d_probs, hipStream_t st,
+                             const std::function<void(const char *, int)> &prof, std::string &err, bool x16);
 
 // d_x: device int32 [rows][33][C]; site i of the batch reads row row_idx[i] (row_idx == nullptr: row i)
-inline int net_forward(NetState &s, const int32_t *d_x, const int32_t *row_idx, int64_t n, hipStream_t st,
-                       const std::function<void(const char *, int)> &prof, std::string &err) {
+// x16: the rows are int16 (the tensor build's windows) instead of int32 (a caller's batch, the calibration windows)
+inline int net_forward(NetState &s, const void *d_x, const int32_t *row_idx, int64_t n, hipStream_t st,
+                       const std::function<void(const char *, int)> &prof, std::string &err, bool x16 = false) {
     int rc = net_reserve(s, n, st, err);
     if (rc) return rc;
     const int64_t step = std::min(n, NET_SLICE);
     for (int64_t off = 0; off < n; off += step) {
         const int64_t m = std::min(step, n - off);
-        const int32_t *x = row_idx ? d_x : d_x + (size_t)off * NET_T * s.channels;
-        if ((rc = net_forward_slice(s, x, row_idx ? row_idx + off : nullptr, m, s.d_probs + (size_t)off * C3R_NPROB, st, prof, err))) return rc;
+        const void *x = row_idx ? d_x : (const void *)((const char *)d_x + (size_t)off * NET_T * s.channels * (x16 ? 2 : 4));
+        if ((rc = net_forward_slice(s, x, row_idx ? row_idx + off : nullptr, m, s.d_probs + (size_t)off * C3R_NPROB, st, prof, err, x16))) return rc;
     }
     return C3R_OK;
 }
 
-inline int net_forward_slice(NetState &s, const int32_t *d_x, const int32_t *row_idx, int64_t n, float *d_probs, hipStream_t st,
-                             const std::function<void(const char *, int)> &prof, std::string &err) {
+inline int net_forward_slice(NetState &s, const void *d_x, const int32_t *row_idx, int64_t n, float *d_probs, hipStream_t st,
+                             const std::function<void(const char *, int)> &prof, std::string &err, bool x16) {
+    const int xi = x16 ? 1 : 0;
     const int nb = (int)((n + NET_SITES - 1) / NET_SITES);
     const dim3 grid((unsigned)((n + LSTM_SITES - 1) / LSTM_SITES), 2), block(256);
     int heads_parts = 1;
@@ -1816,14 +1833,14 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, const int32_t *row
         const float wun1 = std::ldexp(1.f, -s.wlog2[0]), wsc2 = std::ldexp(1.f, s.wlog2[1]), wun2 = std::ldexp(1.f, -s.wlog2[1]), wun4 = std::ldexp(1.f, -s.wlog2[2]);
         prof("k_lstm1", 0);
         if (rts) {
-            if (s.channels == C3R_CH) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, false, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, wun1);
-            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, false, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, wun1);
+            if (s.channels == C3R_CH) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, false, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, wun1, xi);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, false, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, wun1, xi);
         } else if (s.channels == C3R_CH) {
-            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE);
-            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE);
+            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE, xi);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE, xi);
         } else {
-            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE);
-            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE);
+            if (mx) hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, true>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE, xi);
+            else hipLaunchKernelGGL((k_lstm1_rs<C3R_CH_PHASED, false>), g2, dim3(1024), 0, st, d_x, (const half8 *)s.d_w1h, y1h, (int)n, ns, row_idx, WUNSCALE, xi);
         }
         prof("k_lstm1", 1);
         prof("k_lstm2", 0);
@@ -1843,11 +1860,11 @@ inline int net_forward_slice(NetState &s, const int32_t *d_x, const int32_t *row
     if (s.channels == C3R_CH) {
         constexpr int INP = 32;
         hipLaunchKernelGGL((k_lstm<INP, C3R_CH, NET_H1, true, LSTM_SB>), grid, block, 0, st, (const void *)d_x,
-                           (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n, row_idx);
+                           (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n, row_idx, xi);
     } else {
         constexpr int INP = 32;
         hipLaunchKernelGGL((k_lstm<INP, C3R_CH_PHASED, NET_H1, true, LSTM_SB>), grid, block, 0, st, (const void *)d_x,
-                           (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n, row_idx);
+                           (const float4 *)s.d_w1, (const float *)s.d_b1, s.d_y1, (int)n, row_idx, xi);
     }
     prof("k_lstm1", 1);
     prof("k_lstm2", 0);

@@ -177,7 +177,7 @@ struct ScanArgs {
     EvRec *ev;                    // scratch: ev_cap records, bump-allocated per tile through ev_cursor
     unsigned long long *ev_cursor;
     unsigned long long ev_cap;    // a reservation past it is refused: the tile skips its events and raises *ev_overflow
-    int32_t *ev_overflow;
+    int32_t *ev_overflow;         // bit 0: the event scratch; bit 1: a position covered by 32768 reads or more — its counts may not fit the 16-bit windows
     int32_t *last_row;            // [n_regions] atomicMax of the last SLOT (index into the position arrays) with a row
     const uint32_t *drop;         // mpileup depth cap: [n_regions][drop_words] bit per read = discarded in that region; null: none
     int32_t drop_words;
@@ -745,6 +745,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     int tot, ev_total;
     const int2 ex = block_excl_scan2(my_cov_d, nev, M.scan_slot[0], &tot, &ev_total);
     const int my_cov = (C3R_ABL(a) & 256) ? 1 : ex.x + my_cov_d;
+    if (my_cov >= 32768) atomicOr(a.ev_overflow, 2);          // (every count of a column is a count of reads that cover it: below this, the windows fit int16)
     M.evoff[tid] = ex.y;
     C3R_PHASE(2);
     if (ev_total > 0 && !(C3R_ABL(a) & 2)) {
@@ -836,7 +837,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
             if (evb + ev_units + tab_units > a.ev_cap) {
                 // cannot happen with the host's sizing (c3r_pileup_scan_regions); if it ever does, no write leaves the buffer and the
                 // scan call fails instead of corrupting device memory
-                if (tid == 0) *a.ev_overflow = 1;
+                if (tid == 0) atomicOr(a.ev_overflow, 1);
             } else {
                 events(a.ev + evb);
             }
@@ -1259,7 +1260,8 @@ struct GatherArgs {
     const uint8_t *ref; int32_t ref_beg0; int32_t ref_len;
     int32_t head_tail; const int32_t *last_row;
     int32_t rescale; int32_t max_depth;   // 144
-    int32_t *tensors;      // [n][33][C]
+    void *tensors;         // [n][33][C]: int16 when x16 (the resident, rescaled windows), else int32 (c3r_get_tensors' raw export)
+    int32_t x16;
     int32_t *raw;          // [n][33][C] un-rescaled copy (may be null)
     const int32_t *skipmax; // splice-padding mode only
     c3r_site_t *sites;     // [n] (may be null)
@@ -1279,7 +1281,8 @@ __device__ __forceinline__ void gather_window(const GatherArgs &g, int w, int ci
     const int dep = g.depth[ci];
     const bool scale = g.rescale && dep > 0 && (double)dep > (double)g.max_depth * 1.5;
     const double sf = (double)dep / (double)g.max_depth;
-    int32_t *out = g.tensors + (size_t)w * C3R_WINDOW * C;
+    int32_t *out = (int32_t *)g.tensors + (size_t)w * C3R_WINDOW * C;
+    int16_t *out16 = (int16_t *)g.tensors + (size_t)w * C3R_WINDOW * C;
     int32_t *raw = g.raw ? g.raw + (size_t)w * C3R_WINDOW * C : nullptr;
     const int first = ci - C3R_FLANK;
     // two channels (8 bytes) per lane and round: C is even, so a pair never straddles two columns, and every window, column and
@@ -1307,7 +1310,8 @@ __device__ __forceinline__ void gather_window(const GatherArgs &g, int w, int ci
         if (i < 2 * NP) {
             if (raw) *(int2v *)(raw + i) = v[it];
             if (scale) { v[it][0] = (int32_t)((double)v[it][0] / sf); v[it][1] = (int32_t)((double)v[it][1] / sf); }
-            *(int2v *)(out + i) = v[it];
+            if (g.x16) *(int *)(out16 + i) = (v[it][0] & 0xffff) | (v[it][1] << 16);
+            else *(int2v *)(out + i) = v[it];
         }
     }
     if (g.sites) {
@@ -1785,7 +1789,9 @@ struct FusedArgs {
     int32_t *overflow;            // bit 0: a span's candidates or tokens did not fit into its shard (nothing was written past it)
     int32_t cand_cap;             // = n_shards * shard_rows
     int32_t rescale, max_depth;   // A5: windows with depth > 1.5 x max_depth are rescaled
-    int32_t *tensors;             // [cand_cap][33][C], rows in arrival order
+    void *tensors;                // [cand_cap][33][C], rows in arrival order: int16 (x16: the resident, rescaled windows — a count never exceeds the reads that
+                                  // cover its position, and a position that 32768 reads cover fails the scan) or int32 (the raw re-run of c3r_get_tensors)
+    int32_t x16;
     int4 *span_info;              // [listed spans] {first row, candidates, tokens, first token (scan-relative)}
     CandMeta *meta;               // [cand_cap]
     c3r_token_t *tok;             // the batch's token array (null: no tokens wanted — the raw re-run of c3r_get_tensors)
@@ -1905,9 +1911,6 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         // one contiguous run of LDS: all threads copy the run, 16 bytes per lane and store (a window is 8 bytes short of a multiple
         // of 16, so whole-window copies could only use 8-byte stores)
         constexpr int WIN = C3R_WINDOW * C;
-        int32_t *out = f.tensors + (size_t)row0 * WIN;
-        const int total = nc * WIN;
-        const int head = min(total, (int)((16u - ((unsigned)(uintptr_t)out & 15u)) & 15u) >> 2);      // ints before the first 16-byte boundary
         const int resc_thr = f.rescale ? 3 * f.max_depth : INT32_MAX;                                // depth > 1.5 x max_depth  <=>  2 depth > 3 max_depth
         auto fetch = [&](int g) -> int {
             const int k = g / WIN, oo = g - k * WIN;
@@ -1916,6 +1919,46 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             if (2 * (long long)dep > (long long)resc_thr) v = (int32_t)((double)v / ((double)dep / (double)f.max_depth));
             return v;
         };
+        const int total = nc * WIN;
+        if (f.x16) {
+            // eight 16-bit values per lane and store: the run starts on a 4-byte boundary (a window is 1188 / 1980 bytes), so the values before
+            // the first 16-byte boundary are an even number, every group of eight starts on an even offset of its window (8-byte LDS reads),
+            // and a group straddles two windows once in ~70
+            int16_t *out = (int16_t *)f.tensors + (size_t)row0 * WIN;
+            const int head = min(total, (int)((16u - ((unsigned)(uintptr_t)out & 15u)) & 15u) >> 1);
+            if (tid < head && !(C3R_ABL(a) & 64)) out[tid] = (int16_t)fetch(tid);
+            const int n8 = (C3R_ABL(a) & 64) ? 0 : (total - head) >> 3;
+            constexpr int STEP = 8 * SCAN_THREADS, KSTEP = STEP / WIN, OSTEP = STEP % WIN;
+            int g = head + 8 * tid;
+            int k = g / WIN, oo = g - k * WIN;
+            for (int c8 = tid; c8 < n8; c8 += SCAN_THREADS, g += STEP) {
+                int v[8];
+                if (oo + 7 < WIN) {
+                    const int32_t *src = &M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = src[e];
+                    const int dep = M.evfill[k];
+                    if (2 * (long long)dep > (long long)resc_thr) {
+                        const double sf = (double)dep / (double)f.max_depth;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (int32_t)((double)v[e] / sf);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fetch(g + e);
+                }
+                int4 pk;
+                pk.x = (v[0] & 0xffff) | (v[1] << 16); pk.y = (v[2] & 0xffff) | (v[3] << 16);
+                pk.z = (v[4] & 0xffff) | (v[5] << 16); pk.w = (v[6] & 0xffff) | (v[7] << 16);
+                *reinterpret_cast<int4 *>(out + g) = pk;
+                oo += OSTEP; k += KSTEP;
+                if (oo >= WIN) { oo -= WIN; ++k; }
+            }
+            const int gt = head + 8 * n8 + tid;
+            if (gt < total && !(C3R_ABL(a) & 64)) out[gt] = (int16_t)fetch(gt);
+        } else {
+        int32_t *out = (int32_t *)f.tensors + (size_t)row0 * WIN;
+        const int head = min(total, (int)((16u - ((unsigned)(uintptr_t)out & 15u)) & 15u) >> 2);      // ints before the first 16-byte boundary
         if (tid < head) out[tid] = fetch(tid);
         const int n4 = (C3R_ABL(a) & 64) ? 0 : (total - head) >> 2;          // (ablation 64: no window store — byte attribution, tools/pmc_bytes.sh)
         {
@@ -1944,6 +1987,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         }
         const int gt = head + 4 * n4 + tid;
         if (gt < total && !(C3R_ABL(a) & 64)) out[gt] = fetch(gt);
+        }
         }
         // ---- the next span: its ticket has long arrived; three lanes of the first wavefront fetch its record now (the round trip runs
         // under the token pass; the list position travels from lane 0 by a cross-lane read, no barrier)
@@ -2059,12 +2103,19 @@ __global__ __launch_bounds__(256) void k_finalize_sites(const FinalizeArgs g) {
 
 // rows of a [n][row_ints] int32 table through an index (c3r_get_tensors: windows in position order), and the identity index the
 // column-store path leaves for its candidates
-__global__ __launch_bounds__(256) void k_gather_rows(const int32_t *src, const int32_t *idx, int n, int row_ints, int32_t *dst) {
+// (x16: the source rows are int16 — the resident windows; idx null: row i)
+__global__ __launch_bounds__(256) void k_gather_rows(const void *src, const int32_t *idx, int n, int row_ints, int32_t *dst, int x16) {
     const int lane = (int)(threadIdx.x & 63), nw = (int)(gridDim.x * (blockDim.x >> 6));
     for (int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); i < n; i += nw) {
-        const int32_t *s_ = src + (size_t)idx[i] * row_ints;
+        const size_t row = idx ? (size_t)idx[i] : (size_t)i;
         int32_t *d_ = dst + (size_t)i * row_ints;
-        for (int k = lane; k < row_ints; k += 64) d_[k] = s_[k];
+        if (x16) {
+            const int16_t *s_ = (const int16_t *)src + row * row_ints;
+            for (int k = lane; k < row_ints; k += 64) d_[k] = (int32_t)s_[k];
+        } else {
+            const int32_t *s_ = (const int32_t *)src + row * row_ints;
+            for (int k = lane; k < row_ints; k += 64) d_[k] = s_[k];
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_iota(int32_t *dst, int n, int base) {

@@ -62,7 +62,9 @@ typedef struct c3r_params {
     int32_t  max_depth_rescale; /* 144 (param_p.py:14); windows with depth > 1.5x are rescaled     */
     int32_t  max_depth;       /* samtools mpileup -d: reads beyond this many live reads are discarded (htslib's
                                  rule, see c3r_pileup_scan); default 8000 = mpileup's own default, which the reference
-                                 leaves in force (src/create_tensor_pileup.py:442); 0 = no cap                  */
+                                 leaves in force (src/create_tensor_pileup.py:442); 0 = no cap.  The resident windows are
+                                 16-bit: a scan in which more than 32,767 kept reads cover one position fails with
+                                 C3R_EOVERFLOW (cannot happen at the default cap)                                 */
     int32_t  mpileup_compat;  /* which samtools the column text is restated from (run_clair3_rna:159,166 only sets a floor of 1.10):
                                  0 = samtools <= 1.10 (default): an I immediately followed by a D shows the insertion only (`C+2TT`);
                                  1 = samtools >= 1.11 (bam_plp_insertion): it shows both (`C+2TT-1N`), which the reference's parser

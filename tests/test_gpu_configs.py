@@ -185,3 +185,33 @@ def test_phased_scan_builds_the_ordered_recompute_tables_only_when_a_column_need
         assert "k_legacy_tables" in e.kernel_stats()
     finally:
         e.close()
+
+
+def test_a_position_covered_by_more_than_32767_reads_is_refused_not_wrapped(eng):
+    """The resident windows are int16 (a count never exceeds the reads that cover its position).  Without mpileup's depth cap a locus can be
+    covered by more reads than that: the scan fails with a message instead of wrapping a count; with the cap in force (the reference's own
+    configuration, 8000) the same reads go through."""
+    from clair3_rna_amd import capi
+    from clair3_rna_amd.reads import ReadSet
+    import random
+    rng = random.Random(5)
+    ref = "".join(rng.choice("ACGT") for _ in range(400))
+    seq = ref[100:160]
+    recs = [dict(pos=100, cigar="60M", seq=seq[:30] + ("T" if seq[30] != "T" else "G") + seq[31:] if i % 3 == 0 else seq, flag=16 * (i % 2)) for i in range(33000)]
+    rs = ReadSet.from_records(recs)
+    eng.params = capi.default_params()
+    eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.set_params(max_depth=0)
+    eng.load_reads(rs)
+    eng.set_reference(1, ref)
+    with pytest.raises(capi.C3RError, match="32,767 reads"):
+        eng.scan(1, len(ref))
+    eng.set_params(max_depth=8000)
+    eng.load_reads(rs)
+    n = eng.scan(1, len(ref))
+    s = eng.sites()
+    assert n >= 1 and 131 in s["pos"].tolist()
+    X = eng.tensors()
+    assert X.dtype == np.int32 and np.abs(X).max() <= 216 and int(s["depth"][s["pos"].tolist().index(131)]) == 8000
+    eng.params = capi.default_params()
+    eng.set_params()
