@@ -1934,9 +1934,11 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             for (int c8 = tid; c8 < n8; c8 += SCAN_THREADS, g += STEP) {
                 int v[8];
                 if (oo + 7 < WIN) {
-                    const int32_t *src = &M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo];
+                    // (an even offset into an even-strided row of a 16-byte-aligned array: 8-byte LDS reads)
+                    typedef int int2v __attribute__((ext_vector_type(2)));
+                    const int2v *src = reinterpret_cast<const int2v *>(&M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = src[e];
+                    for (int e = 0; e < 4; ++e) { const int2v t = src[e]; v[2 * e] = t[0]; v[2 * e + 1] = t[1]; }
                     const int dep = M.evfill[k];
                     if (2 * (long long)dep > (long long)resc_thr) {
                         const double sf = (double)dep / (double)f.max_depth;
@@ -1947,9 +1949,9 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fetch(g + e);
                 }
-                int4 pk;
-                pk.x = (v[0] & 0xffff) | (v[1] << 16); pk.y = (v[2] & 0xffff) | (v[3] << 16);
-                pk.z = (v[4] & 0xffff) | (v[5] << 16); pk.w = (v[6] & 0xffff) | (v[7] << 16);
+                int4 pk;                                       // low halves of two values side by side: one v_perm_b32 per pair
+                pk.x = (int)__builtin_amdgcn_perm((unsigned)v[1], (unsigned)v[0], 0x05040100u); pk.y = (int)__builtin_amdgcn_perm((unsigned)v[3], (unsigned)v[2], 0x05040100u);
+                pk.z = (int)__builtin_amdgcn_perm((unsigned)v[5], (unsigned)v[4], 0x05040100u); pk.w = (int)__builtin_amdgcn_perm((unsigned)v[7], (unsigned)v[6], 0x05040100u);
                 *reinterpret_cast<int4 *>(out + g) = pk;
                 oo += OSTEP; k += KSTEP;
                 if (oo >= WIN) { oo -= WIN; ++k; }
