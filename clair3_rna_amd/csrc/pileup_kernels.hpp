@@ -624,9 +624,11 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
         const TileGeo tg = a.geo[t];
         const int t0 = tg.p0, t1 = tg.p1;
         if (t1 > t0) {
-            // a candidate needs aligned bases on its own position: spans whose own range meets no record are not listed
+            // a candidate needs aligned bases on its own position, min_cov of them: spans whose own range meets no record — or fewer records than
+            // the coverage gate asks reads for (a read shows at most one piece on a position) — are not listed.  Real RNA-seq is full of
+            // them: the one-to-three-read islands between the expressed loci
             const int4 own = span_ranges(a.rec_off, a.rtab, a.bins, t0, t1);
-            if (own.z < own.w) {
+            if (own.z < own.w && own.w - own.z >= a.min_cov) {
                 const int4 r = span_ranges(a.rec_off, a.rtab, a.bins, t0 - C3R_FLANK, t1 + C3R_FLANK);
                 a.tile_rng[t] = r;
                 listed = r.x < r.y;
