@@ -336,7 +336,11 @@ struct PrepArgs {
 constexpr int PREP_THREADS = C3R_PREP_THREADS, PREP_READS = PREP_THREADS / PREP_GRP;
 constexpr int HB_LOG = C3R_HB_LOG, HB = 1 << HB_LOG, HB_PROBES = 16;
 struct BinHash { uint32_t key[HB], val[HB]; };              // key = bin + 1, 0 = empty
-constexpr int WG_TAB_WORDS = 2 * HB + 4;                    // PrepArgs::wg_tab: words per workgroup
+#ifndef C3R_WG_TAB_PAIRS
+#define C3R_WG_TAB_PAIRS 510
+#endif
+constexpr int WG_TAB_PAIRS = C3R_WG_TAB_PAIRS, WG_TAB_WORDS = 2 * WG_TAB_PAIRS + 4;      // PrepArgs::wg_tab: a 4-KB slab per workgroup; a workgroup with more occupied slots
+                                                                             // (long reads far apart) says so ([0] = ~0) and the second pass counts again
 // slot of `bin`, or -1: not there (insert: and no free slot among its HB_PROBES places — such a bin goes to the global counter directly,
 // in every walk alike, because an occupied slot never becomes free)
 __device__ __forceinline__ int hb_find(BinHash &T, uint32_t bin, bool insert) {
@@ -423,9 +427,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
         if (tab) {
             // the occupied slots, densely (order does not matter): what the second pass needs to know instead of counting again
             for (int h = tid; h < HB; h += PREP_THREADS)
-                if (T.key[h]) { const uint32_t k = atomicAdd(&s_ntab, 1u); reinterpret_cast<uint2 *>(tab + 4)[k] = make_uint2(T.key[h], T.val[h]); }
+                if (T.key[h]) { const uint32_t k = atomicAdd(&s_ntab, 1u); if (k < (uint32_t)WG_TAB_PAIRS) reinterpret_cast<uint2 *>(tab + 4)[k] = make_uint2(T.key[h], T.val[h]); }
             __syncthreads();
-            if (tid == 0) tab[0] = s_ntab;
+            if (tid == 0) tab[0] = s_ntab <= (uint32_t)WG_TAB_PAIRS ? s_ntab : ~0u;
         }
     } else {
         bool pass = false, serial = false;
@@ -440,10 +444,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
         // how many records this workgroup has for each of its bins: the table k_prep<false> left (or, without it, a first walk); one atomic
         // per bin takes that many slots (the counters count down: the workgroup's run in bin b is [rec_off[b] + left - n, rec_off[b] + left));
         // then the walk: every record into its run
-        if (tab) {
+        const uint32_t nt = tab ? tab[0] : ~0u;
+        if (nt != ~0u) {
             // (an entry that finds no place among its HB_PROBES slots now — the insertion order differs — is simply left out: its records take
             // the direct path below, against the global counter that holds them since the first pass)
-            const uint32_t nt = tab[0];
             for (uint32_t k = (uint32_t)tid; k < nt; k += PREP_THREADS) {
                 const uint2 e = reinterpret_cast<const uint2 *>(tab + 4)[k];
                 const int s_ = hb_find(T, e.x - 1u, true);
