@@ -112,7 +112,8 @@ struct c3r_ctx {
     ScanArgs last_scan;                    // arguments of the most recent scan (c3r_get_columns completes the pruned tiles with them)
     bool last_scan_pruned = false;
     // the fused path (k_fused_tiles): look-back words and counters, region bounds, what the last scan covered
-    DevBuf d_lb, d_regb, d_span, d_spanbase, d_meta, d_spanrec;
+    DevBuf d_lb, d_regb, d_span, d_spanbase, d_meta, d_spanrec, d_deep;       // (d_deep: list positions of the deep spans, k_fused_deep)
+    int n_cu = 0;                          // compute units of the device (k_fused_deep: one workgroup each)
     DevBuf d_winidx;                       // [resident candidates] row of the i-th site's window in d_tensors (the fused path writes windows as they arrive)
     DevBuf d_rawidx, d_export;             // c3r_get_tensors: index of a raw re-run, windows gathered into position order
     DevBuf d_tokexp, d_tokoff;             // c3r_get_tokens: tokens gathered into site order, their offsets there
@@ -637,6 +638,7 @@ int c3r_create(int device_id, void *stream, c3r_ctx **out) {
     if (hipSetDevice(device_id) != hipSuccess) return C3R_ENODEVICE;
     c3r_ctx *ctx = new c3r_ctx();
     ctx->device = device_id;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess) ctx->n_cu = cu; }
     c3r_default_params(&ctx->prm);
     if (stream) ctx->stream = (hipStream_t)stream;
     else {
@@ -666,7 +668,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     const bool timing = getenv("C3R_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     DevBuf *bufs[] = {&ctx->d_wgtab, &ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_binoff, &ctx->d_rtab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
-                      &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+                      &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_deep, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff, &ctx->d_padins, &ctx->d_aftab, &ctx->d_keep, &ctx->d_sites_c, &ctx->d_probs_c};
     int n_dev = 0; size_t b_dev = 0, b_pin = 0;
@@ -1074,6 +1076,7 @@ static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int d
     a.head_tail = ctx->prm.head_tail; a.splice = ctx->prm.splice_padding;
     if (ctx->padins && !ctx->padins->empty()) { a.padins = (const c3r_padins_t *)ctx->d_padins.p; a.n_padins = (int32_t)ctx->padins->size(); }
     { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
+    { const char *e = getenv("C3R_DEEP_MIN"); a.deep_min = e ? std::max(1, atoi(e)) : DEEP_MIN_RECORDS; }
 }
 
 static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int64_t *n_candidates, bool columns_only);
@@ -1335,7 +1338,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     const int nblk = (n_tiles + 255) / 256;
     // d_lb: [0] ticket of k_tile_ranges_fused, [4] ticket of k_fused_tiles, [8] candidates, [12] tokens (k_order_spans), [16] overflow
     // bits, [20] listed spans, [24..31] event-scratch cursor, [32] event-scratch overflow, [36] rows handed out, [40] ticket of
-    // k_order_spans, [64..] the TICKET_Q ticket words of k_fused_tiles, 256 bytes apart, then the ALLOC_SHARDS allocator words (tokens << 32 |
+    // k_order_spans, [44] deep spans listed, [48] ticket of k_fused_deep, [64..] the TICKET_Q ticket words of k_fused_tiles, 256 bytes apart, then the ALLOC_SHARDS allocator words (tokens << 32 |
     // rows), 256 bytes apart; then look-back words: one per block of 256 spans for k_tile_ranges_fused, then the same for k_order_spans
     const size_t lb_alloc = 64 + (size_t)TICKET_Q * TICKET_STRIDE * 4;
     const size_t lb_head = lb_alloc + (size_t)ALLOC_SHARDS * ALLOC_STRIDE * 8;
@@ -1343,7 +1346,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     if ((rc = ensure(ctx, ctx->d_ev, ev_cap * sizeof(EvRec))) || (rc = ensure(ctx, ctx->d_lb, lb_bytes)) || (rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16)) ||
         (rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16)) ||
         (rc = ensure(ctx, ctx->d_span, (size_t)n_tiles * sizeof(int4) + 16)) || (rc = ensure(ctx, ctx->d_spanbase, (size_t)n_tiles * 4 + 16)) ||
-        (rc = ensure(ctx, ctx->d_spanrec, (size_t)n_tiles * sizeof(SpanRec) + 16)))
+        (rc = ensure(ctx, ctx->d_spanrec, (size_t)n_tiles * sizeof(SpanRec) + 16)) || (rc = ensure(ctx, ctx->d_deep, (size_t)n_tiles * 4 + 16)))
         return rc;
     if (!ctx->h_scan) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_scan, 64 + (size_t)ALLOC_SHARDS * ALLOC_STRIDE * 8, hipHostMallocDefault));
     const uint32_t *d_drop = nullptr;
@@ -1421,13 +1424,21 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         {
             Launch L(ctx, "k_tile_ranges");
             hipLaunchKernelGGL(k_tile_ranges_fused, dim3(nblk), dim3(256), 0, ctx->stream, a, (int32_t *)lb, (unsigned long long *)(lb + lb_head), nblk, (const int2 *)ctx->d_regb.p,
-                               (SpanRec *)ctx->d_spanrec.p);
+                               (SpanRec *)ctx->d_spanrec.p, (int32_t *)ctx->d_deep.p, (int32_t *)(lb + 44));
         }
         {
             Launch L(ctx, "k_fused_tiles");
             const int grid = std::min(n_tiles, 2048);
             if (C == C3R_CH) hipLaunchKernelGGL(k_fused_tiles<C3R_CH>, dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, f);
             else hipLaunchKernelGGL(k_fused_tiles<C3R_CH_PHASED>, dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, f);
+        }
+        {
+            // the deep spans k_fused_tiles has left out: one workgroup of sixteen wavefronts per CU, spans by ticket (no deep span: the workgroups leave at once)
+            Launch L(ctx, "k_fused_deep");
+            DeepArgs d{(const int32_t *)ctx->d_deep.p, (const int32_t *)(lb + 44), (int32_t *)(lb + 48)};
+            const int grid = std::min(n_tiles, ctx->n_cu > 0 ? ctx->n_cu : 256);
+            if (C == C3R_CH) hipLaunchKernelGGL(k_fused_deep<C3R_CH>, dim3(grid), dim3(DEEP_THREADS), 0, ctx->stream, f, d);
+            else hipLaunchKernelGGL(k_fused_deep<C3R_CH_PHASED>, dim3(grid), dim3(DEEP_THREADS), 0, ctx->stream, f, d);
         }
         {
             Launch L(ctx, "k_order_sites");

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/c3r_types.h"
 
@@ -156,6 +157,7 @@ struct ScanArgs {
     int32_t n_tiles;
     int32_t head_tail;            // last_row (end of the row stream) is only needed for the head/tail flush rule
     int32_t abl;                  // timing-only ablation bits (env C3R_SCAN_ABL, 0 in production)
+    int32_t deep_min;             // a tile whose record range holds at least this many records takes the position-major walk (walk_columns); env C3R_DEEP_MIN
     unsigned long long *dbg;      // null in production; env C3R_SCAN_DBG: per-phase wall-clock sums of k_scan_tiles' heavy tiles (100 MHz ticks)
     const uint8_t *ref;           // upper-cased reference slice
     int32_t ref_beg0;             // 0-based position of ref[0]
@@ -221,10 +223,12 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 }
 
 // block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, *total = sum
+// (NT > SCAN_THREADS — the deep-span workgroup of k_fused_deep: every thread takes part in the barriers, the first SCAN_THREADS threads hold the values)
+template <int NT = SCAN_THREADS>
 __device__ __forceinline__ int block_excl_scan(int v, int *wave_tot /* LDS [WAVES] */, int *total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int incl = wave_incl_scan(v);
-    if (lane == 63) wave_tot[wave] = incl;
+    if (lane == 63 && (NT == SCAN_THREADS || wave < WAVES)) wave_tot[wave] = incl;
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
@@ -236,10 +240,11 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wave_tot /* LDS [WAVE
 
 // two ints per thread, ONE barrier: `slot` (LDS, 2 * WAVES ints) must belong to this call site alone — the trailing barrier of
 // block_excl_scan only protects a shared scratch word against the next scan
+template <int NT = SCAN_THREADS>
 __device__ __forceinline__ int2 block_excl_scan2(int v0, int v1, int *slot, int *total0, int *total1) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = wave_incl_scan(v0), i1 = wave_incl_scan(v1);
-    if (lane == 63) { slot[wave] = i0; slot[WAVES + wave] = i1; }
+    if (lane == 63 && (NT == SCAN_THREADS || wave < WAVES)) { slot[wave] = i0; slot[WAVES + wave] = i1; }
     __syncthreads();
     int b0 = 0, b1 = 0, t0 = 0, t1 = 0;
 #pragma unroll
@@ -302,6 +307,7 @@ __device__ __forceinline__ bool sorted_contains(const int32_t *a, int n, int v) 
 
 constexpr int AF_TAB = 8192;
 constexpr int EV_HASH_MIN = 1024;      // indel events of a tile from which their alleles are counted through a hash table (tile_columns)
+constexpr int DEEP_MIN_RECORDS = 1536; // records in a tile's range from which it takes the position-major walk (walk_columns); ScanArgs::deep_min
 enum WalkMode { ACCUM = 0, SCATTER = 1, FIRSTSEEN = 2 };
 constexpr int FS_CAP = 32;     // positions per batch of the first-seen (tie-break) pass
 
@@ -319,15 +325,29 @@ struct TileLds {
     int32_t evq_cap;
 };
 
-// Coverage of the tile from whole-read spans (incl. introns): header-only, one lane per read.
-__device__ __forceinline__ void cover_one(const ScanArgs &a, const TileLds &s, const DevRead &rd, int r, int t0, int t1, int region) {
-    if (!read_passes(rd, a.min_mq, a.excl_flags) || rd.end <= t0 || rd.pos >= t1) return;
-    if (read_dropped(a.drop, a.drop_words, region, r)) return;
-    atomicAdd(&s.cov[max(rd.pos, t0) - t0], 1);
-    if (rd.end < t1) atomicAdd(&s.cov[rd.end - t0], -1);
+// Coverage of the tile from whole-read spans (incl. introns): header-only, one lane per read.  A read that starts at or before the tile's
+// first position adds to cov[0]: at a deep locus that is most of a wavefront's reads on ONE LDS word (a 64-way serialised atomic), so those
+// are counted by ballot and added once per wavefront.
+__device__ __forceinline__ void cover_span(const TileLds &s, bool covers, int pos, int end, int t0, int t1) {
+    const bool early = covers && pos <= t0;
+    const unsigned long long m = __ballot(early);
+    if (m && (int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&s.cov[0], __popcll(m));
+    if (covers && !early) atomicAdd(&s.cov[pos - t0], 1);
+    if (covers && end < t1) atomicAdd(&s.cov[end - t0], -1);
 }
+template <int NT = SCAN_THREADS>
 __device__ __forceinline__ void cover_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, int region) {
-    for (int r = lo + (int)threadIdx.x; r < hi; r += SCAN_THREADS) cover_one(a, s, a.reads[r], r, t0, t1, region);
+    for (int base = lo; base < hi; base += NT) {              // (uniform trip count: the ballot sees whole wavefronts)
+        const int r = base + (int)threadIdx.x;
+        bool covers = false;
+        int pos = 0, end = 0;
+        if (r < hi) {
+            const DevRead rd = a.reads[r];
+            pos = rd.pos; end = rd.end;
+            covers = read_passes(rd, a.min_mq, a.excl_flags) && rd.end > t0 && rd.pos < t1 && !read_dropped(a.drop, a.drop_words, region, r);
+        }
+        cover_span(s, covers, pos, end, t0, t1);
+    }
 }
 
 // ---- the tile's walk: one lane per record of the tile's range of the pile table.  A record is independent of every other one: two
@@ -342,58 +362,15 @@ __device__ __forceinline__ int nibble_at(uint64_t w0, uint64_t w1, int ni) {    
     return (int)((w >> (8 * ((ni & 15) >> 1) + ((ni & 1) ? 0 : 4))) & 15u);
 }
 
+// The indel a record attaches to the column BEFORE its op (htslib: the next op is peeked at on the last position of the current one): the second
+// half of a record's walk, shared by the record-major walk (walk_rec) and the position-major one (walk_columns).
 template <int C, int MODE>
-__device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int t0, int t1,
-                                         EvRec *ev) {
+__device__ __forceinline__ void walk_event(const ScanArgs &a, const TileLds &s, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int t0, int t1,
+                                           EvRec *ev) {
     const uint32_t w = (uint32_t)ra.y;
-    const int op = (int)(w & 3u), prev = (int)((w >> 2) & 15u), hp = (int)((w >> 7) & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
+    const int op = (int)(w & 3u), prev = (int)((w >> 2) & 15u), hp = (int)((w >> 7) & 3u), avail = (int)((w >> 14) & 31u);
     const bool rev = (w & 64u) != 0;
     const int rstart = ra.x, r = rb.y;
-    if (op == C3R_CIG_M) {
-        if (MODE == SCATTER) return;
-        const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
-        if (b0 >= b1) return;
-        const int off = b0 - rstart, nb = b1 - b0;
-        // The 16 loaded bytes hold the piece's bases from nibble naddr + off on, BAM order (the first base of a byte in its HIGH nibble).
-        // Swapping the nibbles of every byte and dropping the odd start nibble puts base u into bits 4u .. 4u + 3 of a 128-bit value:
-        // one v_bfe_u32 with constant operands per base instead of a variable 64-bit shift and a select.  A base is one of A C G T iff
-        // its code has exactly one bit set (1, 2, 4, 8), and then its channel is the bit's index: no chain of compares, and the only
-        // thing left under a condition is the LDS atomic itself (the chain compiled to ~36 instructions and four branches per base).
-        constexpr uint64_t LOWN = 0x0F0F0F0F0F0F0F0Full;
-        uint64_t s0 = ((w0 & LOWN) << 4) | ((w0 >> 4) & LOWN), s1 = ((w1 & LOWN) << 4) | ((w1 >> 4) & LOWN);
-        if (((uint32_t)ra.z + (uint32_t)off) & 1u) { s0 = (s0 >> 4) | (s1 << 60); s1 >>= 4; }
-        const uint32_t q4[4] = {(uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32)};
-        const int lim = min(nb, max(avail - off, 0));                  // (a CIGAR may claim more bases than SEQ holds: those show as N)
-        const int pl0 = b0 - t0;
-        int32_t *const c0 = &s.cnt[pl0 * C + (rev ? 9 : 0)];
-        int32_t *const ch = &s.cnt[pl0 * C + (hp == 2 ? (int)C3R_AM : (int)C3R_AP)];
-#pragma unroll
-        for (int u = 0; u < OP_CHOP; ++u) {
-            const uint32_t nib = (q4[u >> 3] >> (4 * (u & 7))) & 15u;
-            const bool in = u < lim;
-            const bool acgt = nib != 0u && (nib & (nib - 1u)) == 0u;
-            const int bi = __builtin_ctz(nib | 16u);                      // 0..3 for A C G T
-            if (MODE == ACCUM) {
-                if (in && acgt) atomicAdd(&c0[u * C + bi], 1);
-                if (C == C3R_CH_PHASED) {
-                    if (in && acgt && hp != 0) atomicAdd(&ch[u * C + bi], 1);
-                    // '=' / IUPAC letters are ignored by the reference's token scan WITHOUT consuming their HP entry: every
-                    // later read of the column is then phased with its predecessor's tag (:116-145)
-                    if (in && !acgt && nib != 15u) s.odd[pl0 + u] = 1;
-                }
-            } else if (MODE == FIRSTSEEN) {
-                if (in && acgt) {
-                    const int ai = s.amb[pl0 + u];
-                    if (ai) atomicMin(&s.first[(ai - 1) * 6 + bi], 2u * (uint32_t)r);
-                }
-            }
-        }
-        return;
-    }
-    if (op == C3R_CIG_D && MODE == ACCUM) {
-        const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
-        for (int p = b0; p < b1; ++p) atomicAdd(&s.cnt[(p - t0) * C + (rev ? C3R_HASH : C3R_STAR)], 1);
-    }
     // indel attached to the column BEFORE the op (htslib: peek the next op at the last position of the current one).
     // I needs a ref-consuming predecessor (k_prep leaves no record otherwise), D needs an M or N predecessor (its first piece only: the
     // later pieces of a cut deletion have D before them).
@@ -455,21 +432,76 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
     }
 }
 
+template <int C, int MODE>
+__device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int t0, int t1,
+                                         EvRec *ev) {
+    const uint32_t w = (uint32_t)ra.y;
+    const int op = (int)(w & 3u), hp = (int)((w >> 7) & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
+    const bool rev = (w & 64u) != 0;
+    const int rstart = ra.x, r = rb.y;
+    if (op == C3R_CIG_M) {
+        if (MODE == SCATTER) return;
+        const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
+        if (b0 >= b1) return;
+        const int off = b0 - rstart, nb = b1 - b0;
+        // The 16 loaded bytes hold the piece's bases from nibble naddr + off on, BAM order (the first base of a byte in its HIGH nibble).
+        // Swapping the nibbles of every byte and dropping the odd start nibble puts base u into bits 4u .. 4u + 3 of a 128-bit value:
+        // one v_bfe_u32 with constant operands per base instead of a variable 64-bit shift and a select.  A base is one of A C G T iff
+        // its code has exactly one bit set (1, 2, 4, 8), and then its channel is the bit's index: no chain of compares, and the only
+        // thing left under a condition is the LDS atomic itself (the chain compiled to ~36 instructions and four branches per base).
+        constexpr uint64_t LOWN = 0x0F0F0F0F0F0F0F0Full;
+        uint64_t s0 = ((w0 & LOWN) << 4) | ((w0 >> 4) & LOWN), s1 = ((w1 & LOWN) << 4) | ((w1 >> 4) & LOWN);
+        if (((uint32_t)ra.z + (uint32_t)off) & 1u) { s0 = (s0 >> 4) | (s1 << 60); s1 >>= 4; }
+        const uint32_t q4[4] = {(uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32)};
+        const int lim = min(nb, max(avail - off, 0));                  // (a CIGAR may claim more bases than SEQ holds: those show as N)
+        const int pl0 = b0 - t0;
+        int32_t *const c0 = &s.cnt[pl0 * C + (rev ? 9 : 0)];
+        int32_t *const ch = &s.cnt[pl0 * C + (hp == 2 ? (int)C3R_AM : (int)C3R_AP)];
+#pragma unroll
+        for (int u = 0; u < OP_CHOP; ++u) {
+            const uint32_t nib = (q4[u >> 3] >> (4 * (u & 7))) & 15u;
+            const bool in = u < lim;
+            const bool acgt = nib != 0u && (nib & (nib - 1u)) == 0u;
+            const int bi = __builtin_ctz(nib | 16u);                      // 0..3 for A C G T
+            if (MODE == ACCUM) {
+                if (in && acgt && !(C3R_ABL(a) & 4096)) atomicAdd(&c0[u * C + bi], 1);
+                if (C == C3R_CH_PHASED) {
+                    if (in && acgt && hp != 0) atomicAdd(&ch[u * C + bi], 1);
+                    // '=' / IUPAC letters are ignored by the reference's token scan WITHOUT consuming their HP entry: every
+                    // later read of the column is then phased with its predecessor's tag (:116-145)
+                    if (in && !acgt && nib != 15u) s.odd[pl0 + u] = 1;
+                }
+            } else if (MODE == FIRSTSEEN) {
+                if (in && acgt) {
+                    const int ai = s.amb[pl0 + u];
+                    if (ai) atomicMin(&s.first[(ai - 1) * 6 + bi], 2u * (uint32_t)r);
+                }
+            }
+        }
+        return;
+    }
+    if (op == C3R_CIG_D && MODE == ACCUM) {
+        const int b0 = max(rstart, t0), b1 = min(rstart + len, t1);
+        for (int p = b0; p < b1; ++p) atomicAdd(&s.cnt[(p - t0) * C + (rev ? C3R_HASH : C3R_STAR)], 1);
+    }
+    walk_event<C, MODE>(a, s, ra, rb, w0, w1, t0, t1, ev);
+}
+
 // All records of [rlo, rhi), WALK_UNR per lane and round: their loads (record, then bases) are issued together.
 #ifndef C3R_WALK_UNR
 #define C3R_WALK_UNR 1
 #endif
 constexpr int WALK_UNR = C3R_WALK_UNR;
-template <int C, int MODE>
+template <int C, int MODE, int NT = SCAN_THREADS, int WALK_UNR = c3r::WALK_UNR>
 __device__ __forceinline__ void walk_records(const ScanArgs &a, const TileLds &s, int rlo, int rhi, int t0, int t1, int region, EvRec *ev) {
     const int tid = (int)threadIdx.x;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
+    for (int base = rlo; base < rhi; base += NT * WALK_UNR) {
         int4 ra[WALK_UNR], rb[WALK_UNR];
         bool have[WALK_UNR];
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u) {
-            const int iu = base + u * SCAN_THREADS + tid;
+            const int iu = base + u * NT + tid;
             have[u] = iu < rhi;
             const int4 *rec = reinterpret_cast<const int4 *>(a.recs + (have[u] ? iu : rhi - 1));      // (idle lanes re-read the last record)
             ra[u] = rec[0]; rb[u] = rec[1];
@@ -488,7 +520,7 @@ __device__ __forceinline__ void walk_records(const ScanArgs &a, const TileLds &s
             int off = -1;                                    // first base to fetch, relative to the piece's first base
             if (have[u] && op == C3R_CIG_M && MODE != SCATTER) off = max(ra[u].x, t0) - ra[u].x;
             if (have[u] && op == C3R_CIG_I && MODE != FIRSTSEEN) off = 0;
-            if (off >= 0 && off < avail) {
+            if (off >= 0 && off < avail && !(C3R_ABL(a) & 8192)) {
                 const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)off;
                 u64x2 w;                                     // (the packed-base buffer is padded: the load may run past a read's last byte)
                 __builtin_memcpy(&w, a.seq + (na >> 1), 16);
@@ -610,7 +642,7 @@ struct SpanRec { int32_t tile, p0, p1, region; int4 rng; int32_t reg_lo, reg_hi,
 static_assert(sizeof(SpanRec) == 48, "SpanRec must be 48 bytes");
 
 __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int32_t *ticket, unsigned long long *rstate, int nblk, const int2 *reg_bounds,
-                                                           SpanRec *span_rec) {
+                                                           SpanRec *span_rec, int32_t *deep_list, int32_t *n_deep) {
     __shared__ int s_b, s_base, s_cnt[4];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_b = atomicAdd(ticket, 1);
@@ -658,6 +690,15 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
         int4 *dst = reinterpret_cast<int4 *>(span_rec + at2);
         dst[0] = make_int4(rec.tile, rec.p0, rec.p1, rec.region); dst[1] = rec.rng; dst[2] = make_int4(rec.reg_lo, rec.reg_hi, 0, 0);
     }
+    // the deep spans' list positions, in any order, for k_fused_deep (one atomic per wavefront that holds any)
+    const bool deep = listed && rec.rng.w - rec.rng.z >= a.deep_min;
+    const unsigned long long md = __ballot(deep);
+    if (md) {
+        int base = 0;
+        if (lane == __builtin_ctzll(md)) base = atomicAdd(n_deep, __popcll(md));
+        base = __shfl(base, __builtin_ctzll(md), 64);
+        if (deep) deep_list[base + __popcll(md & ((1ull << lane) - 1ull))] = at + __popcll(m & ((1ull << lane) - 1ull));
+    }
 }
 
 // The tile kernels run over the compact tile list with a FIXED grid (LIST_GRID workgroups, each taking every LIST_GRID-th list
@@ -668,9 +709,10 @@ constexpr int LIST_GRID = 8192;
 // LDS of one tile workgroup.  Indel events of a tile stay in LDS when there are at most EV_LDS of them (a 20x ONT tile holds ~100): the
 // first walk captures them as it meets them, and they are bucketed by position without a second walk over the records; deeper tiles
 // walk again and bump-allocate global scratch.  (30 channels: the accumulators leave no room at four workgroups per CU.)
-template <int C>
+template <int C, int EVL = (C == C3R_CH ? 192 : 0)>
 struct alignas(16) TileMem {
-    static constexpr int EV_LDS = C == C3R_CH ? 192 : 0;
+    static constexpr int EV_LDS = EVL;
+    typedef typename std::conditional<(EVL > 256), uint16_t, uint8_t>::type evord_t;
     int32_t cnt[TILE * C];
     int32_t cov[TILE + 1];
     int32_t evoff[TILE];
@@ -685,7 +727,7 @@ struct alignas(16) TileMem {
     unsigned long long ambmask[WAVES];          // k_fused_tiles: positions with a tie at the top of the allele counts (first-seen pass)
     unsigned long long evbase;
     EvRec ev[EV_LDS > 0 ? EV_LDS : 1];
-    uint8_t evord[EV_LDS > 0 ? EV_LDS : 4];     // the captured events' indices, bucketed by position
+    evord_t evord[EV_LDS > 0 ? EV_LDS : 4];     // the captured events' indices, bucketed by position
 };
 struct TileOut { bool is_row, cand; int depth, cov; };     // cov: the token slots the position needs if it becomes a candidate — an upper bound of the reads that show
                                                            // something other than the reference base or a ref-skip there (tile_tokens)
@@ -696,28 +738,33 @@ struct TileOut { bool is_row, cand; int depth, cov; };     // cov: the token slo
 // recompute, and the thread its position's verdict.  Positions below pmin hold no rows (they lie before the region).
 // Used by the column-store kernel (k_scan_tiles) and by the fused kernel (k_fused_tiles), whose "tile" is a window-complete span.
 // FUSED (k_fused_tiles): the row mask of the window rule is published with the ambiguity votes (one barrier instead of two).
-template <int C>
-__device__ __forceinline__ void tile_zero(TileMem<C> &M) {
+template <int C, int NT, int EVL>
+__device__ __forceinline__ void tile_zero(TileMem<C, EVL> &M) {
     const int tid = threadIdx.x;
-    M.cov[tid] = 0; if (tid == 0) M.cov[TILE] = 0;
-    for (int i = tid; i < TILE * C; i += SCAN_THREADS) M.cnt[i] = 0;
-    M.evfill[tid] = 0; M.maxdel[tid] = 0; M.amb[tid] = 0; M.odd[tid] = 0;
-    if (tid == 0) M.misc[0] = 0;
+    for (int i = tid; i < TILE * C; i += NT) M.cnt[i] = 0;
+    if (NT == SCAN_THREADS || tid < TILE) {
+        M.cov[tid] = 0; if (tid == 0) M.cov[TILE] = 0;
+        M.evfill[tid] = 0; M.maxdel[tid] = 0; M.amb[tid] = 0; M.odd[tid] = 0;
+        if (tid == 0) M.misc[0] = 0;
+    }
 }
-template <int C, bool FUSED = false>
-__device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M, int t0, int t1, int pmin, int region, int lo, int hi, int slo, int shi,
+// NT: threads of the workgroup.  SCAN_THREADS everywhere but in k_fused_deep, whose workgroups of 1024 keep thread tid <-> position t0 + tid for the
+// first TILE threads (`pos_thread`) and put all sixteen wavefronts on everything that goes record by record, read by read or event by event.
+template <int C, bool FUSED = false, int NT = SCAN_THREADS, int EVL = TileMem<C>::EV_LDS>
+__device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EVL> &M, int t0, int t1, int pmin, int region, int lo, int hi, int slo, int shi,
                                                 int cand_lo, int cand_hi) {
-    constexpr int EV_LDS = TileMem<C>::EV_LDS;
+    constexpr int EV_LDS = EVL;
     const int tid = threadIdx.x;
+    const bool pos_thread = NT == SCAN_THREADS || tid < TILE;
     TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, M.ev, &M.misc[0], EV_LDS};
     unsigned long long tprev = C3R_DBG(a) ? wall_clock64() : 0ull;
 #define C3R_PHASE(K) do { if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[K], now_ - tprev); tprev = now_; } } while (0)
-    tile_zero<C>(M);
+    tile_zero<C, NT, EVL>(M);
     // loads that nothing before the gates depends on leave now: this position's reference base, and the first round of read headers
     // (their round trip runs beside the walk's record and base loads instead of before them)
     const int p = t0 + tid;
     const int rp = p - a.ref_beg0;
-    const uint8_t rb = (rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
+    const uint8_t rb = (pos_thread && rp >= 0 && rp < a.ref_len) ? a.ref[rp] : (uint8_t)'N';
     const int r0 = lo + tid;
     int rd_pos = 0, rd_end = INT32_MIN;                       // read lo + tid as the coverage sees it (end = INT32_MIN: not a covering read)
     if (r0 < hi && !(C3R_ABL(a) & 4)) {
@@ -728,27 +775,24 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     __syncthreads();
 
     C3R_PHASE(0);
-    if (!(C3R_ABL(a) & 1)) walk_records<C, ACCUM>(a, s, slo, shi, t0, t1, region, nullptr);
+    if (!(C3R_ABL(a) & 1)) walk_records<C, ACCUM, NT>(a, s, slo, shi, t0, t1, region, nullptr);
     if (!(C3R_ABL(a) & 4)) {
-        if (rd_end > t0 && rd_pos < t1) {
-            atomicAdd(&s.cov[max(rd_pos, t0) - t0], 1);
-            if (rd_end < t1) atomicAdd(&s.cov[rd_end - t0], -1);
-        }
-        cover_reads(a, s, lo + SCAN_THREADS, hi, t0, t1, region);
+        cover_span(s, rd_end > t0 && rd_pos < t1, rd_pos, rd_end, t0, t1);
+        cover_reads<NT>(a, s, lo + NT, hi, t0, t1, region);
     }
     __syncthreads();
     C3R_PHASE(1);
 
     // coverage: inclusive scan of the difference array; indel events: exclusive scan of per-position counts (one scan, one barrier)
     int *wave_tot = &M.misc[2];
-    const int my_cov_d = M.cov[tid];
-    const int32_t *row = &M.cnt[tid * C];
-    const int nev = row[C3R_I] + row[C3R_i] + row[C3R_D] + row[C3R_d];
+    const int my_cov_d = pos_thread ? M.cov[tid] : 0;
+    const int32_t *row = &M.cnt[(pos_thread ? tid : 0) * C];
+    const int nev = pos_thread ? row[C3R_I] + row[C3R_i] + row[C3R_D] + row[C3R_d] : 0;
     int tot, ev_total;
-    const int2 ex = block_excl_scan2(my_cov_d, nev, M.scan_slot[0], &tot, &ev_total);
+    const int2 ex = block_excl_scan2<NT>(my_cov_d, nev, M.scan_slot[0], &tot, &ev_total);
     const int my_cov = (C3R_ABL(a) & 256) ? 1 : ex.x + my_cov_d;
-    if (my_cov >= 32768) atomicOr(a.ev_overflow, 2);          // (every count of a column is a count of reads that cover it: below this, the windows fit int16)
-    M.evoff[tid] = ex.y;
+    if (pos_thread && my_cov >= 32768) atomicOr(a.ev_overflow, 2);          // (every count of a column is a count of reads that cover it: below this, the windows fit int16)
+    if (pos_thread) M.evoff[tid] = ex.y;
     C3R_PHASE(2);
     if (ev_total > 0 && !(C3R_ABL(a) & 2)) {
         // the tile's indel events, bucketed by position (counting sort through evoff / evfill), then the max multiplicity of one
@@ -756,12 +800,12 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         __syncthreads();                       // (evoff of every position is in place)
         if (ev_total <= EV_LDS) {
             // the usual case: the first walk has captured every event (ev_total of them, in arrival order); bucket their indices
-            for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+            for (int e = tid; e < ev_total; e += NT) {
                 const int pl = M.ev[e].pl;
-                M.evord[M.evoff[pl] + atomicAdd(&M.evfill[pl], 1)] = (uint8_t)e;
+                M.evord[M.evoff[pl] + atomicAdd(&M.evfill[pl], 1)] = (typename TileMem<C, EVL>::evord_t)e;
             }
             __syncthreads();
-            for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+            for (int e = tid; e < ev_total; e += NT) {
                 const EvRec me = M.ev[e];
                 const int pl = me.pl;
                 const int b = M.evoff[pl];
@@ -781,13 +825,13 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
             const unsigned long long ev_units = (unsigned long long)((ev_total + 15) & ~15);
             const unsigned long long tab_units = hashed ? ((unsigned long long)ev_total * 2ull * sizeof(uint2) + sizeof(EvRec) - 1) / sizeof(EvRec) : 0ull;
             auto events = [&](EvRec *ev) __attribute__((always_inline)) {
-                walk_records<C, SCATTER>(a, s, slo, shi, t0, t1, region, ev);
+                walk_records<C, SCATTER, NT>(a, s, slo, shi, t0, t1, region, ev);
                 uint2 *tab = reinterpret_cast<uint2 *>(ev + ev_units);
-                if (hashed) for (int i = tid; i < 2 * ev_total; i += SCAN_THREADS) tab[i] = make_uint2(0xffffffffu, 0u);
+                if (hashed) for (int i = tid; i < 2 * ev_total; i += NT) tab[i] = make_uint2(0xffffffffu, 0u);
                 __threadfence_block();
                 __syncthreads();
                 if (!hashed) {
-                    for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+                    for (int e = tid; e < ev_total; e += NT) {
                         const EvRec me = ev[e];
                         const int pl = me.pl;
                         const int b = M.evoff[pl];
@@ -808,7 +852,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
                 };
                 for (int pass = 0; pass < 2; ++pass) {
                     // pass 0: claim or join the allele's slot; pass 1: every event reads its allele's count
-                    for (int e = tid; e < ev_total; e += SCAN_THREADS) {
+                    for (int e = tid; e < ev_total; e += NT) {
                         const EvRec me = ev[e];
                         const int pl = me.pl;
                         const int b = M.evoff[pl];
@@ -853,11 +897,11 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     int depth = 0, refi = 0, ntok_bound = 0;
     int cls[6] = {0, 0, 0, 0, 0, 0};
     bool gates_ok = false;
-    if (p >= pmin && p < t1 && my_cov > 0) {
+    if (pos_thread && p >= pmin && p < t1 && my_cov > 0) {
         is_row = !a.has_lbed || intervals_overlap(a.lbed, a.n_lbed, p, p + 1);
     }
     if (is_row) {
-        int32_t *c = &M.cnt[tid * C];
+        int32_t *c = &M.cnt[tid * C];                    // (is_row: a position thread)
         const int up = c[C3R_A] + c[C3R_C] + c[C3R_G] + c[C3R_T];
         const int lw = c[C3R_a] + c[C3R_c] + c[C3R_g] + c[C3R_t];
         depth = up + lw + c[C3R_STAR] + c[C3R_HASH];
@@ -919,7 +963,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
     if (FUSED) {
         // the window rule's row mask travels with the votes: 33 contiguous rows = 33 set bits (k_fused_tiles)
         const unsigned long long rm = __ballot(is_row), am = __ballot(ambiguous);
-        if ((tid & 63) == 0) { M.rowmask[tid >> 6] = rm; M.ambmask[tid >> 6] = am; }
+        if ((tid & 63) == 0 && pos_thread) { M.rowmask[tid >> 6] = rm; M.ambmask[tid >> 6] = am; }
         __syncthreads();
         any_amb = (M.ambmask[0] | M.ambmask[1] | M.ambmask[2] | M.ambmask[3]) != 0ull;
     } else any_amb = __syncthreads_or(ambiguous ? 1 : 0) != 0;
@@ -929,13 +973,13 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C> &M
         // "top allele != reference" with a tie at the top: the reference's stable sort keeps the class seen first in the column.  A
         // third walk records, for the tied positions only (FS_CAP at a time), the first read that shows each class
         int n_amb;
-        const int arank = block_excl_scan(ambiguous ? 1 : 0, wave_tot, &n_amb);
+        const int arank = block_excl_scan<NT>(ambiguous ? 1 : 0, wave_tot, &n_amb);
         for (int base = 0; base < n_amb; base += FS_CAP) {
             const bool mine = ambiguous && arank >= base && arank < base + FS_CAP;
-            M.amb[tid] = mine ? (uint8_t)(1 + arank - base) : (uint8_t)0;
-            for (int i = tid; i < FS_CAP * 6; i += SCAN_THREADS) M.first[i] = 0xffffffffu;
+            if (pos_thread) M.amb[tid] = mine ? (uint8_t)(1 + arank - base) : (uint8_t)0;
+            for (int i = tid; i < FS_CAP * 6; i += NT) M.first[i] = 0xffffffffu;
             __syncthreads();
-            walk_records<C, FIRSTSEEN>(a, s, slo, shi, t0, t1, region, nullptr);
+            walk_records<C, FIRSTSEEN, NT>(a, s, slo, shi, t0, t1, region, nullptr);
             __syncthreads();
             if (mine) {
                 int m = 0;
@@ -1576,14 +1620,14 @@ __device__ __forceinline__ void tok_rec(TokLds &K, c3r_token_t *tok, long long t
 // done(k, n): the tokens written for it.  Returns (to every thread) the tokens that found no slot — zero unless the bound is wrong.
 // HAVE_MASK: thread tid stands for position t0 + tid and `mine` says whether it is a candidate (k_fused_tiles): the mask is four ballots,
 // no clearing, no atomics, one barrier less.
-template <bool HAVE_MASK, class CandFn, class DoneFn>
+template <bool HAVE_MASK, int NT = SCAN_THREADS, class CandFn, class DoneFn>
 __device__ __forceinline__ int tile_tokens(const ScanArgs &a, TokLds &K, int t0, int t1, int region, int rlo, int rhi, int nc, CandFn &&cand, DoneFn &&done,
                                            c3r_token_t *tok, long long tok_cap, bool mine = false) {
     const int tid = (int)threadIdx.x;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     const unsigned long long my_wave = HAVE_MASK ? __ballot(mine) : 0ull;
     __syncthreads();                                        // (K lies where the accumulators lay: everyone is done with them)
-    if (HAVE_MASK) { if ((tid & 63) == 0) K.cmask[tid >> 6] = my_wave; }
+    if (HAVE_MASK) { if ((tid & 63) == 0 && (NT == SCAN_THREADS || tid < TILE)) K.cmask[tid >> 6] = my_wave; }
     else {
         if (tid < TILE / 64) K.cmask[tid] = 0ull;
         __syncthreads();
@@ -1601,13 +1645,13 @@ __device__ __forceinline__ int tile_tokens(const ScanArgs &a, TokLds &K, int t0,
     __syncthreads();
     // a record matters only if its piece covers a candidate (or, an indel behind a ref-skip, sits on one): the candidates' bit mask says
     // so from the record's first half alone, before its second half or any base is fetched
-    for (int base = rlo; base < rhi; base += SCAN_THREADS * WALK_UNR) {
+    for (int base = rlo; base < rhi; base += NT * WALK_UNR) {
         int4 ra[WALK_UNR], rb[WALK_UNR];
         bool have[WALK_UNR];
         unsigned long long bits[WALK_UNR];
 #pragma unroll
         for (int u = 0; u < WALK_UNR; ++u) {
-            const int iu = base + u * SCAN_THREADS + tid;
+            const int iu = base + u * NT + tid;
             have[u] = iu < rhi;
             const int4 *rec = reinterpret_cast<const int4 *>(a.recs + (have[u] ? iu : rhi - 1));
             ra[u] = rec[0]; rb[u] = rec[1];
@@ -1802,13 +1846,189 @@ struct FusedArgs {
     PhaseArgs ph;                 // 30 channels: the ordered recompute of flagged columns
 };
 
+// One span, by the whole workgroup: columns (tile_columns), the window rule, rows and token slots, the windows, `between()` (k_fused_tiles
+// fetches the next span's record there), the candidates' tokens.  b: the span's list position.
+struct SpanShared { int row0, tok0, fits; };
+template <int C, int NT, int EVL, class Between>
+__device__ __forceinline__ void fused_span(const FusedArgs &f, TileMem<C, EVL> &M, SpanShared &S, const int b, const int shard, const int4 r0, const int4 rng, const int4 r2,
+                                           Between &&between) {
+    const ScanArgs &a = f.a;
+    const int tid = (int)threadIdx.x;
+    {
+        const int tile = r0.x;
+        TileGeo tg; tg.p0 = r0.y; tg.p1 = r0.z; tg.region = r0.w; tg.pad = 0;
+        const int2 rb = make_int2(r2.x, r2.y);
+        const int x0 = tg.p0 - C3R_FLANK, x1 = min(tg.p1 + C3R_FLANK, rb.y);       // thread tid <-> position x0 + tid
+        const TileOut o = tile_columns<C, true, NT, EVL>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1);
+        unsigned long long t_tail = C3R_DBG(a) ? wall_clock64() : 0ull;
+        int dbg_slot = 7;
+        if (C == C3R_CH_PHASED) {
+            // a column whose haplotype channels depend on the ORDER of the reads (see k_phase_recompute): redone in place, one thread
+            // per flagged column
+            if (o.is_row && M.odd[tid]) {
+                if (!f.ph.rsegs) atomicOr(f.overflow, 4);         // no op / segment tables yet: the host builds them and repeats the scan
+                else {
+                    int cnt[12];
+                    phase_column(f.ph, x0 + tid, rng.x, rng.y, tg.region, cnt);
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) M.cnt[tid * C + C3R_AP + k] = cnt[k];
+                }
+            }
+        }
+        // ---- the window rule: 33 contiguous rows = 33 set bits in the span's row mask (published by tile_columns with its last barrier)
+        bool emit = false;
+        if (o.cand && tid >= C3R_FLANK && tid + C3R_FLANK < TILE) {
+            const int first = tid - C3R_FLANK, w = first >> 6, sh = first & 63;
+            unsigned long long bits = M.rowmask[w] >> sh;
+            if (sh > 64 - C3R_WINDOW) bits |= M.rowmask[w + 1] << (64 - sh);          // (first + 32 <= 255: w + 1 <= 3)
+            constexpr unsigned long long ALL = (1ull << C3R_WINDOW) - 1ull;
+            emit = (bits & ALL) == ALL;
+            if (C3R_ABL(a) & 2048) emit = false;
+        }
+        if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[9], now_ - t_tail); t_tail = now_; }
+        int nc, nt;
+        const int2 ex = block_excl_scan2<NT>(emit ? 1 : 0, emit ? o.cov : 0, M.scan_slot[1], &nc, &nt);
+        if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[10], now_ - t_tail); t_tail = now_; }
+        const int rank = ex.x, tpre = ex.y;
+        // per candidate (by rank): position in the span, depth for the window copy, tokens of the span's earlier candidates — the event
+        // arrays are free by now
+        if (emit) { M.amb[rank] = (uint8_t)tid; M.evfill[rank] = o.depth; M.evoff[rank] = tpre; }
+        if (tid == 0) {
+            int lrow = 0, ltok = 0;
+            if (nc) {
+                const unsigned long long got = atomicAdd(&f.alloc[shard * ALLOC_STRIDE], ((unsigned long long)(unsigned)(f.tok ? nt : 0) << 32) | (unsigned)nc);
+                lrow = (int)(unsigned)got; ltok = (int)(unsigned)(got >> 32);
+            }
+            const bool fits = (long long)lrow + nc <= (long long)f.shard_rows && (!f.tok || (long long)ltok + nt <= (long long)f.shard_toks);
+            S.fits = fits ? 1 : 0;
+            S.row0 = shard * f.shard_rows + lrow;
+            S.tok0 = shard * f.shard_toks + ltok;
+            f.span_info[b] = make_int4(S.row0, nc, 0, S.tok0);                // (.z: tokens actually written, added up by the token pass)
+            if (C3R_DBG(a)) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[11], now_ - t_tail); t_tail = now_; }
+        }
+        __syncthreads();
+        const int row0 = S.row0, tok0 = S.tok0;
+        const bool fits = S.fits != 0;
+        if (nc > 0 && !fits && tid == 0) atomicOr(f.overflow, 1);
+        if (nc > 0 && fits) {
+        if (emit) {
+            CandMeta m;
+            m.slot = tile * TILE + (tid - C3R_FLANK); m.depth = o.depth; m.ncov = o.cov; m.tpre = tpre; m.span = b; m.pos0 = x0 + tid;
+            f.meta[row0 + rank] = m;
+        }
+        // ---- the span's nc windows are ONE contiguous run of the output (rows [row0, row0 + nc) x 33 x C int32) and each window is
+        // one contiguous run of LDS: all threads copy the run, 16 bytes per lane and store (a window is 8 bytes short of a multiple
+        // of 16, so whole-window copies could only use 8-byte stores)
+        constexpr int WIN = C3R_WINDOW * C;
+        const int resc_thr = f.rescale ? 3 * f.max_depth : INT32_MAX;                                // depth > 1.5 x max_depth  <=>  2 depth > 3 max_depth
+        auto fetch = [&](int g) -> int {
+            const int k = g / WIN, oo = g - k * WIN;
+            int v = M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo];
+            const int dep = M.evfill[k];
+            if (2 * (long long)dep > (long long)resc_thr) v = (int32_t)((double)v / ((double)dep / (double)f.max_depth));
+            return v;
+        };
+        const int total = nc * WIN;
+        if (f.x16) {
+            // eight 16-bit values per lane and store: the run starts on a 4-byte boundary (a window is 1188 / 1980 bytes), so the values before
+            // the first 16-byte boundary are an even number, every group of eight starts on an even offset of its window (8-byte LDS reads),
+            // and a group straddles two windows once in ~70
+            int16_t *out = (int16_t *)f.tensors + (size_t)row0 * WIN;
+            const int head = min(total, (int)((16u - ((unsigned)(uintptr_t)out & 15u)) & 15u) >> 1);
+            if (tid < head && !(C3R_ABL(a) & 64)) out[tid] = (int16_t)fetch(tid);
+            const int n8 = (C3R_ABL(a) & 64) ? 0 : (total - head) >> 3;
+            constexpr int STEP = 8 * NT, KSTEP = STEP / WIN, OSTEP = STEP % WIN;
+            int g = head + 8 * tid;
+            int k = g / WIN, oo = g - k * WIN;
+            for (int c8 = tid; c8 < n8; c8 += NT, g += STEP) {
+                int v[8];
+                if (oo + 7 < WIN) {
+                    // (an even offset into an even-strided row of a 16-byte-aligned array: 8-byte LDS reads)
+                    typedef int int2v __attribute__((ext_vector_type(2)));
+                    const int2v *src = reinterpret_cast<const int2v *>(&M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const int2v t = src[e]; v[2 * e] = t[0]; v[2 * e + 1] = t[1]; }
+                    const int dep = M.evfill[k];
+                    if (2 * (long long)dep > (long long)resc_thr) {
+                        const double sf = (double)dep / (double)f.max_depth;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (int32_t)((double)v[e] / sf);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fetch(g + e);
+                }
+                int4 pk;                                       // low halves of two values side by side: one v_perm_b32 per pair
+                pk.x = (int)__builtin_amdgcn_perm((unsigned)v[1], (unsigned)v[0], 0x05040100u); pk.y = (int)__builtin_amdgcn_perm((unsigned)v[3], (unsigned)v[2], 0x05040100u);
+                pk.z = (int)__builtin_amdgcn_perm((unsigned)v[5], (unsigned)v[4], 0x05040100u); pk.w = (int)__builtin_amdgcn_perm((unsigned)v[7], (unsigned)v[6], 0x05040100u);
+                *reinterpret_cast<int4 *>(out + g) = pk;
+                oo += OSTEP; k += KSTEP;
+                if (oo >= WIN) { oo -= WIN; ++k; }
+            }
+            const int gt = head + 8 * n8 + tid;
+            if (gt < total && !(C3R_ABL(a) & 64)) out[gt] = (int16_t)fetch(gt);
+        } else {
+        int32_t *out = (int32_t *)f.tensors + (size_t)row0 * WIN;
+        const int head = min(total, (int)((16u - ((unsigned)(uintptr_t)out & 15u)) & 15u) >> 2);      // ints before the first 16-byte boundary
+        if (tid < head) out[tid] = fetch(tid);
+        const int n4 = (C3R_ABL(a) & 64) ? 0 : (total - head) >> 2;          // (ablation 64: no window store — byte attribution, tools/pmc_bytes.sh)
+        {
+            // a thread's groups of four lie 4 * SCAN_THREADS ints apart: window index and offset inside the window are carried along
+            // (one division per thread instead of one per int); a group that straddles two windows (1 in ~150) takes the general path
+            constexpr int STEP = 4 * NT, KSTEP = STEP / WIN, OSTEP = STEP % WIN;
+            int g = head + 4 * tid;
+            int k = g / WIN, oo = g - k * WIN;
+            for (int c4 = tid; c4 < n4; c4 += NT, g += STEP) {
+                int4 v;
+                if (oo + 3 < WIN) {
+                    const int32_t *src = &M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo];
+                    v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+                    const int dep = M.evfill[k];
+                    if (2 * (long long)dep > (long long)resc_thr) {
+                        const double sf = (double)dep / (double)f.max_depth;
+                        v.x = (int32_t)((double)v.x / sf); v.y = (int32_t)((double)v.y / sf); v.z = (int32_t)((double)v.z / sf); v.w = (int32_t)((double)v.w / sf);
+                    }
+                } else {
+                    v.x = fetch(g); v.y = fetch(g + 1); v.z = fetch(g + 2); v.w = fetch(g + 3);
+                }
+                *reinterpret_cast<int4 *>(out + g) = v;
+                oo += OSTEP; k += KSTEP;
+                if (oo >= WIN) { oo -= WIN; ++k; }
+            }
+        }
+        const int gt = head + 4 * n4 + tid;
+        if (gt < total && !(C3R_ABL(a) & 64)) out[gt] = fetch(gt);
+        }
+        }
+        between();
+        if (nc > 0 && fits) {
+        // ---- the candidates' tokens, while the span's records are still in the cache (k_tile_tokens walked the op table a second time:
+        // 0.29 ms and 291 MB per chr20 pass).  The accumulators are dead once the windows are out: their LDS holds the token pass's tables
+        if (f.tok && !(C3R_ABL(a) & 128)) {                                   // (ablation 128: no token pass)
+            if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[7], now_ - t_tail); t_tail = now_; dbg_slot = 8; }
+            TokLds &K = *reinterpret_cast<TokLds *>(M.cnt);
+            const int lost = tile_tokens<true, NT>(a, K, x0, x1, tg.region, rng.z, rng.w, nc, [&](int k, int &lp, int &off, int &cp) {
+                lp = (int)M.amb[k]; off = f.tok_base + tok0 + M.evoff[k];
+                cp = (k + 1 < nc ? M.evoff[k + 1] : nt) - M.evoff[k];
+            }, [&](int k, int n) {
+                f.meta[row0 + k].ncov = n;                                  // (the site's n_tok: what was written, not what was reserved)
+                if (n) atomicAdd(&f.span_info[b].z, n);                     // the span's tokens: k_order_spans sums them into the scan's total
+            }, f.tok, (long long)f.tok_base + (long long)(shard + 1) * f.shard_toks, emit);
+            if (lost && tid == 0) atomicOr(f.overflow, 8);
+        }
+        }
+        if (C3R_DBG(a) && tid == 0) atomicAdd(&C3R_DBG(a)[dbg_slot], wall_clock64() - t_tail);
+    }
+}
+
 template <int C>
 #ifndef C3R_FUSED_OCC
 #define C3R_FUSED_OCC 5
 #endif
 __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SCAN_OCC30)) void k_fused_tiles(const FusedArgs f) {
     __shared__ TileMem<C> M;
-    __shared__ int s_ticket, s_row0, s_tok0, s_fits;
+    __shared__ int s_ticket;
+    __shared__ SpanShared S;
     __shared__ int4 s_rec[3];
     const int shard = (int)(blockIdx.x % (unsigned)f.n_shards);
     static_assert(sizeof(TokLds) <= sizeof(M.cnt), "the token pass re-uses the accumulators' LDS");
@@ -1846,185 +2066,63 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
     while (b < n) {
         int t_next = 0;
         const int q_next = home;
-        if (tid == 0) t_next = atomicAdd(&f.ticket[q_next * TICKET_STRIDE], 1);
         const int4 r0 = s_rec[0], rng = s_rec[1], r2 = s_rec[2];
-        const int tile = r0.x;
-        TileGeo tg; tg.p0 = r0.y; tg.p1 = r0.z; tg.region = r0.w; tg.pad = 0;
-        const int2 rb = make_int2(r2.x, r2.y);
-        const int x0 = tg.p0 - C3R_FLANK, x1 = min(tg.p1 + C3R_FLANK, rb.y);       // thread tid <-> position x0 + tid
-        const TileOut o = tile_columns<C, true>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1);
-        unsigned long long t_tail = C3R_DBG(a) ? wall_clock64() : 0ull;
-        int dbg_slot = 7;
-        if (C == C3R_CH_PHASED) {
-            // a column whose haplotype channels depend on the ORDER of the reads (see k_phase_recompute): redone in place, one thread
-            // per flagged column
-            if (o.is_row && M.odd[tid]) {
-                if (!f.ph.rsegs) atomicOr(f.overflow, 4);         // no op / segment tables yet: the host builds them and repeats the scan
-                else {
-                    int cnt[12];
-                    phase_column(f.ph, x0 + tid, rng.x, rng.y, tg.region, cnt);
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) M.cnt[tid * C + C3R_AP + k] = cnt[k];
-                }
-            }
-        }
-        // ---- the window rule: 33 contiguous rows = 33 set bits in the span's row mask (published by tile_columns with its last barrier)
-        bool emit = false;
-        if (o.cand && tid >= C3R_FLANK && tid + C3R_FLANK < TILE) {
-            const int first = tid - C3R_FLANK, w = first >> 6, sh = first & 63;
-            unsigned long long bits = M.rowmask[w] >> sh;
-            if (sh > 64 - C3R_WINDOW) bits |= M.rowmask[w + 1] << (64 - sh);          // (first + 32 <= 255: w + 1 <= 3)
-            constexpr unsigned long long ALL = (1ull << C3R_WINDOW) - 1ull;
-            emit = (bits & ALL) == ALL;
-            if (C3R_ABL(a) & 2048) emit = false;
-        }
-        if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[9], now_ - t_tail); t_tail = now_; }
-        int nc, nt;
-        const int2 ex = block_excl_scan2(emit ? 1 : 0, emit ? o.cov : 0, M.scan_slot[1], &nc, &nt);
-        if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[10], now_ - t_tail); t_tail = now_; }
-        const int rank = ex.x, tpre = ex.y;
-        // per candidate (by rank): position in the span, depth for the window copy, tokens of the span's earlier candidates — the event
-        // arrays are free by now
-        if (emit) { M.amb[rank] = (uint8_t)tid; M.evfill[rank] = o.depth; M.evoff[rank] = tpre; }
-        if (tid == 0) {
-            int lrow = 0, ltok = 0;
-            if (nc) {
-                const unsigned long long got = atomicAdd(&f.alloc[shard * ALLOC_STRIDE], ((unsigned long long)(unsigned)(f.tok ? nt : 0) << 32) | (unsigned)nc);
-                lrow = (int)(unsigned)got; ltok = (int)(unsigned)(got >> 32);
-            }
-            const bool fits = (long long)lrow + nc <= (long long)f.shard_rows && (!f.tok || (long long)ltok + nt <= (long long)f.shard_toks);
-            s_fits = fits ? 1 : 0;
-            s_row0 = shard * f.shard_rows + lrow;
-            s_tok0 = shard * f.shard_toks + ltok;
-            f.span_info[b] = make_int4(s_row0, nc, 0, s_tok0);                // (.z: tokens actually written, added up by the token pass)
-            if (C3R_DBG(a)) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[11], now_ - t_tail); t_tail = now_; }
-        }
-        __syncthreads();
-        const int row0 = s_row0, tok0 = s_tok0;
-        const bool fits = s_fits != 0;
-        if (nc > 0 && !fits && tid == 0) atomicOr(f.overflow, 1);
-        if (nc > 0 && fits) {
-        if (emit) {
-            CandMeta m;
-            m.slot = tile * TILE + (tid - C3R_FLANK); m.depth = o.depth; m.ncov = o.cov; m.tpre = tpre; m.span = b; m.pos0 = x0 + tid;
-            f.meta[row0 + rank] = m;
-        }
-        // ---- the span's nc windows are ONE contiguous run of the output (rows [row0, row0 + nc) x 33 x C int32) and each window is
-        // one contiguous run of LDS: all threads copy the run, 16 bytes per lane and store (a window is 8 bytes short of a multiple
-        // of 16, so whole-window copies could only use 8-byte stores)
-        constexpr int WIN = C3R_WINDOW * C;
-        const int resc_thr = f.rescale ? 3 * f.max_depth : INT32_MAX;                                // depth > 1.5 x max_depth  <=>  2 depth > 3 max_depth
-        auto fetch = [&](int g) -> int {
-            const int k = g / WIN, oo = g - k * WIN;
-            int v = M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo];
-            const int dep = M.evfill[k];
-            if (2 * (long long)dep > (long long)resc_thr) v = (int32_t)((double)v / ((double)dep / (double)f.max_depth));
-            return v;
-        };
-        const int total = nc * WIN;
-        if (f.x16) {
-            // eight 16-bit values per lane and store: the run starts on a 4-byte boundary (a window is 1188 / 1980 bytes), so the values before
-            // the first 16-byte boundary are an even number, every group of eight starts on an even offset of its window (8-byte LDS reads),
-            // and a group straddles two windows once in ~70
-            int16_t *out = (int16_t *)f.tensors + (size_t)row0 * WIN;
-            const int head = min(total, (int)((16u - ((unsigned)(uintptr_t)out & 15u)) & 15u) >> 1);
-            if (tid < head && !(C3R_ABL(a) & 64)) out[tid] = (int16_t)fetch(tid);
-            const int n8 = (C3R_ABL(a) & 64) ? 0 : (total - head) >> 3;
-            constexpr int STEP = 8 * SCAN_THREADS, KSTEP = STEP / WIN, OSTEP = STEP % WIN;
-            int g = head + 8 * tid;
-            int k = g / WIN, oo = g - k * WIN;
-            for (int c8 = tid; c8 < n8; c8 += SCAN_THREADS, g += STEP) {
-                int v[8];
-                if (oo + 7 < WIN) {
-                    // (an even offset into an even-strided row of a 16-byte-aligned array: 8-byte LDS reads)
-                    typedef int int2v __attribute__((ext_vector_type(2)));
-                    const int2v *src = reinterpret_cast<const int2v *>(&M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const int2v t = src[e]; v[2 * e] = t[0]; v[2 * e + 1] = t[1]; }
-                    const int dep = M.evfill[k];
-                    if (2 * (long long)dep > (long long)resc_thr) {
-                        const double sf = (double)dep / (double)f.max_depth;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (int32_t)((double)v[e] / sf);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fetch(g + e);
-                }
-                int4 pk;                                       // low halves of two values side by side: one v_perm_b32 per pair
-                pk.x = (int)__builtin_amdgcn_perm((unsigned)v[1], (unsigned)v[0], 0x05040100u); pk.y = (int)__builtin_amdgcn_perm((unsigned)v[3], (unsigned)v[2], 0x05040100u);
-                pk.z = (int)__builtin_amdgcn_perm((unsigned)v[5], (unsigned)v[4], 0x05040100u); pk.w = (int)__builtin_amdgcn_perm((unsigned)v[7], (unsigned)v[6], 0x05040100u);
-                *reinterpret_cast<int4 *>(out + g) = pk;
-                oo += OSTEP; k += KSTEP;
-                if (oo >= WIN) { oo -= WIN; ++k; }
-            }
-            const int gt = head + 8 * n8 + tid;
-            if (gt < total && !(C3R_ABL(a) & 64)) out[gt] = (int16_t)fetch(gt);
-        } else {
-        int32_t *out = (int32_t *)f.tensors + (size_t)row0 * WIN;
-        const int head = min(total, (int)((16u - ((unsigned)(uintptr_t)out & 15u)) & 15u) >> 2);      // ints before the first 16-byte boundary
-        if (tid < head) out[tid] = fetch(tid);
-        const int n4 = (C3R_ABL(a) & 64) ? 0 : (total - head) >> 2;          // (ablation 64: no window store — byte attribution, tools/pmc_bytes.sh)
-        {
-            // a thread's groups of four lie 4 * SCAN_THREADS ints apart: window index and offset inside the window are carried along
-            // (one division per thread instead of one per int); a group that straddles two windows (1 in ~150) takes the general path
-            constexpr int STEP = 4 * SCAN_THREADS, KSTEP = STEP / WIN, OSTEP = STEP % WIN;
-            int g = head + 4 * tid;
-            int k = g / WIN, oo = g - k * WIN;
-            for (int c4 = tid; c4 < n4; c4 += SCAN_THREADS, g += STEP) {
-                int4 v;
-                if (oo + 3 < WIN) {
-                    const int32_t *src = &M.cnt[((int)M.amb[k] - C3R_FLANK) * C + oo];
-                    v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
-                    const int dep = M.evfill[k];
-                    if (2 * (long long)dep > (long long)resc_thr) {
-                        const double sf = (double)dep / (double)f.max_depth;
-                        v.x = (int32_t)((double)v.x / sf); v.y = (int32_t)((double)v.y / sf); v.z = (int32_t)((double)v.z / sf); v.w = (int32_t)((double)v.w / sf);
-                    }
-                } else {
-                    v.x = fetch(g); v.y = fetch(g + 1); v.z = fetch(g + 2); v.w = fetch(g + 3);
-                }
-                *reinterpret_cast<int4 *>(out + g) = v;
-                oo += OSTEP; k += KSTEP;
-                if (oo >= WIN) { oo -= WIN; ++k; }
-            }
-        }
-        const int gt = head + 4 * n4 + tid;
-        if (gt < total && !(C3R_ABL(a) & 64)) out[gt] = fetch(gt);
-        }
-        }
-        // ---- the next span: its ticket has long arrived; three lanes of the first wavefront fetch its record now (the round trip runs
-        // under the token pass; the list position travels from lane 0 by a cross-lane read, no barrier)
+        // a deep span (ScanArgs::deep_min records or more in its range) is left to k_fused_deep, which runs behind this kernel with workgroups of
+        // sixteen wavefronts: the span would keep these four for milliseconds
+        const bool deep = rng.w - rng.z >= a.deep_min;
+        if (tid == 0) t_next = atomicAdd(&f.ticket[q_next * TICKET_STRIDE], 1);
         int b_next = 0;
         int4 nrec = make_int4(0, 0, 0, 0);
-        if (tid < 64) {
-            if (tid == 0) b_next = t_next < queue_len(q_next) ? list_pos(q_next, t_next) : take();
-            b_next = __shfl(b_next, 0, 64);
-            if (b_next < n && tid < 3) nrec = reinterpret_cast<const int4 *>(f.span_rec + b_next)[tid];
-        }
-        if (nc > 0 && fits) {
-        // ---- the candidates' tokens, while the span's records are still in the cache (k_tile_tokens walked the op table a second time:
-        // 0.29 ms and 291 MB per chr20 pass).  The accumulators are dead once the windows are out: their LDS holds the token pass's tables
-        if (f.tok && !(C3R_ABL(a) & 128)) {                                   // (ablation 128: no token pass)
-            if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[7], now_ - t_tail); t_tail = now_; dbg_slot = 8; }
-            TokLds &K = *reinterpret_cast<TokLds *>(M.cnt);
-            const int lost = tile_tokens<true>(a, K, x0, x1, tg.region, rng.z, rng.w, nc, [&](int k, int &lp, int &off, int &cp) {
-                lp = (int)M.amb[k]; off = f.tok_base + tok0 + M.evoff[k];
-                cp = (k + 1 < nc ? M.evoff[k + 1] : nt) - M.evoff[k];
-            }, [&](int k, int n) {
-                f.meta[row0 + k].ncov = n;                                  // (the site's n_tok: what was written, not what was reserved)
-                if (n) atomicAdd(&f.span_info[b].z, n);                     // the span's tokens: k_order_spans sums them into the scan's total
-            }, f.tok, (long long)f.tok_base + (long long)(shard + 1) * f.shard_toks, emit);
-            if (lost && tid == 0) atomicOr(f.overflow, 8);
-        }
-        }
-        if (C3R_DBG(a) && tid == 0) atomicAdd(&C3R_DBG(a)[dbg_slot], wall_clock64() - t_tail);
+        // ---- the next span: three lanes of the first wavefront fetch its record when this span's windows are out (the round trip runs under the
+        // token pass; the list position travels from lane 0 by a cross-lane read, no barrier)
+        auto fetch_next = [&]() __attribute__((always_inline)) {
+            if (tid < 64) {
+                if (tid == 0) b_next = t_next < queue_len(q_next) ? list_pos(q_next, t_next) : take();
+                b_next = __shfl(b_next, 0, 64);
+                if (b_next < n && tid < 3) nrec = reinterpret_cast<const int4 *>(f.span_rec + b_next)[tid];
+            }
+        };
+        if (!deep) fused_span<C, SCAN_THREADS, TileMem<C>::EV_LDS>(f, M, S, b, shard, r0, rng, r2, fetch_next);
+        else fetch_next();
         // ---- hand over: the next span's record and list position into LDS (s_rec was last read at the top of this span, many barriers
         // ago); the barrier also frees this span's LDS
         if (tid < 3) s_rec[tid] = nrec;
         if (tid == 0) s_ticket = b_next;
         __syncthreads();
         b = s_ticket;
+    }
+}
+
+// The deep spans of the list (ScanArgs::deep_min records or more in their range), one at a time per workgroup of DEEP_THREADS = sixteen
+// wavefronts, one workgroup per CU.  Everything a span does record by record, read by read or event by event — the walks, the coverage, the
+// event buckets, the window copy, the token pass — runs on all sixteen; the per-position steps on the first four (tile_columns, `pos_thread`).
+// A span's time at depth is rounds x memory latency while its workgroup has the CU to itself and LDS-atomic throughput once the CU is full (a
+// wavefront's 30 atomic adds per round cost ~9 LDS cycles each on random banks, 3.8 without conflicts: profiles/r6/lds_atomic_probe.txt): four
+// times the wavefronts are a quarter of the rounds.  With one workgroup per CU the LDS holds DEEP_EV_LDS captured events: up to there a span's
+// alleles are counted out of LDS as in the shallow kernel, without the second walk and the global hash table of the deeper ones.
+constexpr int DEEP_THREADS = 1024;
+constexpr int DEEP_EV_LDS = 4096;
+struct DeepArgs { const int32_t *list; const int32_t *n_list; int32_t *ticket; };
+template <int C>
+__global__ __launch_bounds__(DEEP_THREADS, 4) void k_fused_deep(const FusedArgs f, const DeepArgs d) {
+    __shared__ TileMem<C, DEEP_EV_LDS> M;
+    __shared__ int s_b;
+    __shared__ SpanShared S;
+    __shared__ int4 s_rec[3];
+    static_assert(sizeof(TokLds) <= sizeof(M.cnt), "the token pass re-uses the accumulators' LDS");
+    const int shard = (int)(blockIdx.x % (unsigned)f.n_shards);
+    const int tid = (int)threadIdx.x;
+    const int n = *d.n_list;
+    for (;;) {
+        if (tid == 0) { const int i = atomicAdd(d.ticket, 1); s_b = i < n ? d.list[i] : -1; }
+        __syncthreads();
+        const int b = s_b;
+        if (b < 0) return;
+        if (tid < 3) s_rec[tid] = reinterpret_cast<const int4 *>(f.span_rec + b)[tid];
+        __syncthreads();
+        const int4 r0 = s_rec[0], rng = s_rec[1], r2 = s_rec[2];
+        fused_span<C, DEEP_THREADS, DEEP_EV_LDS>(f, M, S, b, shard, r0, rng, r2, [] {});
+        __syncthreads();                      // (s_b, s_rec and the span's LDS are free)
     }
 }
 
