@@ -92,6 +92,36 @@ def k1_algorithmic_bytes(rs, centres, channels, min_mq=5, excl_flags=2316):
     return float(total_in + total_out)
 
 
+def phase1_bytes(rs, channels, min_mq=5, excl_flags=2316):
+    """SURVEY.md 8(d), phase 1 — the column scan the reference runs over EVERY covered position (src/create_tensor_pileup.py:520-560), whether
+    or not a candidate comes of it: the input records (headers + CIGAR ops + packed bases, as handed over) + C * 4 bytes of counts per
+    position that at least one passing read covers (ref-skips included: mpileup prints a row there).  Returns (bytes, covered positions)."""
+    r = rs.reads
+    n = len(r)
+    in_bytes = int(rs.reads.nbytes + rs.cigar.nbytes + rs.seq.nbytes)
+    if n == 0:
+        return float(in_bytes), 0
+    cig = rs.cigar.astype(np.int64)
+    op, ln = cig & 15, cig >> 4
+    ref_len = np.where((op == 0) | (op == 2) | (op == 3) | (op == 7) | (op == 8), ln, 0)
+    csum = np.concatenate([[0], np.cumsum(ref_len)])
+    first = r["cigar_off"].astype(np.int64)
+    span = csum[first + r["n_cigar"].astype(np.int64)] - csum[first]
+    pos = r["pos"].astype(np.int64)
+    end = pos + span
+    flag = r["flag"].astype(np.int64)
+    ok = ((flag & excl_flags) == 0) & ((flag & 4) == 0) & ~(((flag & 1) != 0) & ((flag & 2) == 0)) & (r["mapq"] >= min_mq) & (end > pos)
+    p, e = pos[ok], end[ok]
+    if len(p) == 0:
+        return float(in_bytes), 0
+    o = np.argsort(p, kind="stable")
+    p, e = p[o], e[o]
+    reach = np.maximum.accumulate(e)
+    prev = np.concatenate([[p[0]], reach[:-1]])
+    covered = int(np.sum(np.maximum(e - np.maximum(p, prev), 0)))      # union of the read spans
+    return float(in_bytes + 4 * channels * covered), covered
+
+
 def chunk_list(contig_len, chunk=CHUNK):
     """(ctg_start, ctg_end) per chunk, the arithmetic of src/create_tensor_pileup.py:380-392."""
     n = (contig_len + chunk - 1) // chunk
@@ -207,16 +237,25 @@ def rooflines(kernels, n_prof, rs, site_pos, channels, precision):
                        inference_sites_per_s=round(n_prof / (net_ms * 1e-3), 1) if net_ms else None,
                        tensor_build_algorithmic_GBps=round(tb_gbps, 1) if k1_ms else None,
                        tensor_build_ms=round(k1_ms, 3), read_preparation_ms=round(prep_ms, 3), inference_ms=round(net_ms, 3))
+    p1_bytes, covered = phase1_bytes(rs, channels)
+    p1_gbps = p1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms else 0.0
     if dom not in fps and roofline["bound"] == "hbm" and k1_ms:
-        # the dominant kernel is a tensor-build kernel (deep coverage, few candidates): the whole build's algorithmic bytes over ITS time
-        # would overstate it, so `achieved` stays with the build as a whole (roofline_tensor_build) and this entry names the kernel
-        roofline["note"] = "a tensor-build kernel dominates this workload: see roofline_tensor_build for the build as a whole"
+        # the dominant kernel is a tensor-build kernel (deep coverage, few candidates): it IS the column scan, and the scan's bytes — every input
+        # record once + C * 4 bytes of counts per covered position (phase 1) — over ITS average launch are its rate
+        ach = p1_bytes / (avg_ms * st["launches"] * 1e-3) / 1e9
+        roofline.update(achieved=round(ach, 1), frac=round(ach / PEAK_HBM_GBPS, 4),
+                        note="a tensor-build kernel dominates this workload: phase-1 bytes (input records + C*4 B per covered position, "
+                             "roofline_tensor_build.phase1) over this kernel's time; the build as a whole: roofline_tensor_build")
     # the tensor-build half against ITS roofline (HBM): SURVEY 8(d)'s algorithmic bytes, evaluated on this pass's candidates,
     # over the summed device time of ALL tensor-build kernels of the profiled pass (read preparation included)
     roofline_tb = dict(kernels=sorted(k for k in kernels if k not in NET_KERNELS), bound="hbm",
                        achieved=round(tb_gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(tb_gbps / PEAK_HBM_GBPS, 4),
                        bytes_per_site=round(k1_bytes / n_prof, 1) if n_prof else None, bytes_per_pass=int(k1_bytes), ms=round(k1_ms, 3),
                        note="bytes: SURVEY 8(d) formula evaluated on the pass's own candidates and reads (bench.k1_algorithmic_bytes)")
+    roofline_tb["phase1"] = dict(bytes=int(p1_bytes), covered_positions=covered, achieved=round(p1_gbps, 1), unit="GB/s", frac=round(p1_gbps / PEAK_HBM_GBPS, 4),
+                                 ms=round(k1_ms, 3), bytes_per_covered_position=round(p1_bytes / covered, 1) if covered else None,
+                                 note="SURVEY 8(d) phase 1, the column scan over every covered position: input records (headers + CIGAR ops + packed bases) + "
+                                      "C*4 B of counts per covered position, over the summed device time of all tensor-build kernels (bench.phase1_bytes)")
     h2d_bytes = int(rs.reads.nbytes + rs.cigar.nbytes + rs.seq.nbytes)
     roofline_tb["h2d"] = dict(bytes=h2d_bytes, ms=round(h2d_ms, 3), GBps=round(h2d_bytes / (h2d_ms * 1e-3) / 1e9, 1) if h2d_ms else None, included_in_ms=False,
                               frac_with_h2d=round(k1_bytes / ((k1_ms + h2d_ms) * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if k1_ms else None,
@@ -265,25 +304,33 @@ def extra_config(name, workload, gen, channels, precision, local_rank, steps=4, 
         try:
             e2.set_params(channels=channels, **(params or {}))
             e2.set_reference(1, ref); e2.load_weights(w, channels); e2.set_precision(precision)
-            pair, pending = (e, e2), [0, 0]
+            pair = (e, e2)
 
             def run2(k):
-                tot = 0
-                for i in range(k):
-                    x = pair[i % 2]
-                    if pending[i % 2]:
-                        x.fetch_probs(pending[i % 2])
-                    x.load_reads(rsh)
-                    x.begin_batch(); n = x.scan_regions(chunks); x.end_batch()
-                    if n:
-                        x.infer(fetch=False)
-                    pending[i % 2] = n
-                    tot += n
-                for j in range(2):
-                    if pending[j]:
-                        pair[j].fetch_probs(pending[j])
-                    pending[j] = 0
-                return tot
+                # one host thread per context (the library calls release the GIL): c3r_load_reads and the scan block their caller on read-backs,
+                # so a single thread would serialise one context's upload behind the other's scan
+                import threading
+                tots, errs = [0, 0], []
+
+                def drive(j):
+                    try:
+                        x = pair[j]
+                        for _ in range(k // 2):
+                            x.load_reads(rsh)
+                            x.begin_batch(); n = x.scan_regions(chunks); x.end_batch()
+                            if n:
+                                x.infer()
+                            tots[j] += n
+                    except Exception as ex:          # noqa: BLE001
+                        errs.append(ex)
+                th = [threading.Thread(target=drive, args=(j,)) for j in range(2)]
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+                if errs:
+                    raise errs[0]
+                return sum(tots)
             run2(2)
             e.synchronize(); e2.synchronize(); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -291,7 +338,8 @@ def extra_config(name, workload, gen, channels, precision, local_rank, steps=4, 
             e.synchronize(); e2.synchronize(); torch.cuda.synchronize()
             el2 = time.perf_counter() - t0
             two = dict(value=round(s2 / el2, 1), ms_per_step=round(1e3 * el2 / (2 * steps), 3), steps=2 * steps,
-                       reads_per_s=round(info["n_reads"] * 2 * steps / el2, 1))
+                       reads_per_s=round(info["n_reads"] * 2 * steps / el2, 1), vs_one_context=round((s2 / el2) / (sites / el), 3) if sites else None,
+                       host_threads=2)
         except Exception as ex:                       # (an additional figure: never loses the one above)
             two = dict(error=repr(ex)[:200])
         finally:
@@ -667,10 +715,13 @@ def main():
         deep = dict(contig_len=400000, seed=synth.SEED + 5, depth=20000.0, expressed_frac=0.01, intron_lo=100.0, intron_hi=800.0)
         capped = guarded(lambda: extra_config("depth_cap_20000x", "one 400-kb contig with loci at ~20,000x: mpileup's depth cap -d 8000 in force", deep, 18, args.precision, local_rank, steps=3))
         nocap = guarded(lambda: extra_config("depth_cap_20000x_off", "the same reads with max_depth = 0 (no cap)", deep, 18, args.precision, local_rank, steps=3, params=dict(max_depth=0)))
-        if isinstance(capped, dict) and "error" not in capped and isinstance(nocap, dict) and "error" not in nocap:
-            capped["without_cap"] = dict(ms_per_step=nocap["ms_per_step"], sites_per_step=nocap["sites_per_step"], value=nocap["value"],
-                                         kernels_ms_per_step=nocap["kernels_ms_per_step"])
-            capped["cap_cost_ms_per_step"] = round(capped["ms_per_step"] - nocap["ms_per_step"], 3)
+        if isinstance(capped, dict) and "error" not in capped:
+            if isinstance(nocap, dict) and "error" not in nocap:
+                capped["without_cap"] = dict(ms_per_step=nocap["ms_per_step"], sites_per_step=nocap["sites_per_step"], value=nocap["value"],
+                                             kernels_ms_per_step=nocap["kernels_ms_per_step"])
+                capped["cap_cost_ms_per_step"] = round(capped["ms_per_step"] - nocap["ms_per_step"], 3)
+            else:                                     # (a failed control is part of the record, not a missing key)
+                capped["without_cap"] = nocap if isinstance(nocap, dict) else dict(error="no result")
 
     if rank == 0:
         out = {

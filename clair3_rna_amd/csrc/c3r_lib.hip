@@ -64,6 +64,9 @@ struct c3r_ctx {
     std::map<std::string, KStat> kstats;
     std::vector<std::string> kstat_names;   // stable storage for c3r_get_kernel_stats
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // k_fused_deep runs BESIDE k_fused_tiles on its own stream (created at the first fused scan), forked and joined by two events
+    hipStream_t deep_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // ---- inputs: the device holds the read tables; host copies are fetched on demand (depth cap, decode)
     int32_t n_reads = 0;                   // of the loaded contig
@@ -113,6 +116,8 @@ struct c3r_ctx {
     bool last_scan_pruned = false;
     // the fused path (k_fused_tiles): look-back words and counters, region bounds, what the last scan covered
     DevBuf d_lb, d_regb, d_span, d_spanbase, d_meta, d_spanrec, d_deep;       // (d_deep: list positions of the deep spans, k_fused_deep)
+    DevBuf d_evwg;                         // k_fused_deep: an arrival-order event buffer per workgroup (DEEP_EVG_CAP records each), allocated once a scan has met a deep span
+    bool seen_deep = false;
     int n_cu = 0;                          // compute units of the device (k_fused_deep: one workgroup each)
     DevBuf d_winidx;                       // [resident candidates] row of the i-th site's window in d_tensors (the fused path writes windows as they arrive)
     DevBuf d_rawidx, d_export;             // c3r_get_tensors: index of a raw re-run, windows gathered into position order
@@ -664,11 +669,12 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->net_stream) (void)hipStreamSynchronize(ctx->net_stream);
+    if (ctx->deep_stream) (void)hipStreamSynchronize(ctx->deep_stream);
     (void)hipStreamSynchronize(ctx->stream);
     const bool timing = getenv("C3R_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     DevBuf *bufs[] = {&ctx->d_wgtab, &ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_binoff, &ctx->d_rtab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
-                      &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_deep, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+                      &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_deep, &ctx->d_evwg, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff, &ctx->d_padins, &ctx->d_aftab, &ctx->d_keep, &ctx->d_sites_c, &ctx->d_probs_c};
     int n_dev = 0; size_t b_dev = 0, b_pin = 0;
@@ -685,6 +691,9 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
     for (auto &rb : ctx->refbuf) { if (rb.p) { (void)hipHostFree(rb.p); b_pin += rb.cap; } if (rb.ev) (void)hipEventDestroy(rb.ev); }
     const auto t3 = std::chrono::steady_clock::now();
+    if (ctx->deep_stream) (void)hipStreamDestroy(ctx->deep_stream);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->net_stream) (void)hipStreamDestroy(ctx->net_stream);
@@ -1182,8 +1191,8 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
     a.tile_list2 = (int32_t *)ctx->d_tile_list2.p; a.n_tile_list2 = (int32_t *)((char *)ctx->d_small.p + 24);
     a.dbg = nullptr;
     if (getenv("C3R_SCAN_DBG")) {
-        if ((rc = ensure(ctx, ctx->d_dbg, 16 * 8))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg.p, 0, 16 * 8, ctx->stream));
+        if ((rc = ensure(ctx, ctx->d_dbg, 32 * 8))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg.p, 0, 32 * 8, ctx->stream));
         a.dbg = (unsigned long long *)ctx->d_dbg.p;
     }
     a.cols = (int32_t *)ctx->d_cols.p; a.depth = (int32_t *)ctx->d_depth.p; a.ncov = (int32_t *)ctx->d_ncov.p; a.flags = (uint8_t *)ctx->d_flags.p;
@@ -1360,11 +1369,19 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     a.tile_rng = (int4 *)ctx->d_tile_rng.p; a.tile_list = (int32_t *)ctx->d_tile_list.p; a.n_tile_list = (int32_t *)(lb + 20);
     a.ev = (EvRec *)ctx->d_ev.p; a.ev_cursor = (unsigned long long *)(lb + 24); a.ev_cap = (unsigned long long)ev_cap; a.ev_overflow = (int32_t *)(lb + 32);
     if (getenv("C3R_SCAN_DBG")) {          // phase clocks of tile_columns (timing aid, off in production)
-        if ((rc = ensure(ctx, ctx->d_dbg, 16 * 8))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg.p, 0, 16 * 8, ctx->stream));
+        if ((rc = ensure(ctx, ctx->d_dbg, 32 * 8))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg.p, 0, 32 * 8, ctx->stream));
         a.dbg = (unsigned long long *)ctx->d_dbg.p;
     }
     f.span_rec = (const SpanRec *)ctx->d_spanrec.p;
+    // the deep kernel's per-workgroup event buffers (every event of a span in arrival order: a span that outgrows the LDS store is bucketed from there
+    // instead of walking its records again): 300 MB, so only for a context that has met a deep span (its first such scan walks twice)
+    const int deep_grid = std::min(n_tiles, ctx->n_cu > 0 ? ctx->n_cu : 256);
+    const char *evwg_env = getenv("C3R_EVWG");          // (tests) 0: never, 1: from the first scan on
+    if ((ctx->seen_deep || (evwg_env && *evwg_env == '1')) && !(evwg_env && *evwg_env == '0')) {
+        if ((rc = ensure(ctx, ctx->d_evwg, (size_t)deep_grid * DEEP_EVG_CAP * sizeof(EvRec)))) return rc;
+        a.ev_wg = (EvRec *)ctx->d_evwg.p; a.ev_wg_cap = DEEP_EVG_CAP;
+    }
     f.ticket = (int32_t *)(lb + 64); f.alloc = (unsigned long long *)(lb + lb_alloc); f.overflow = (int32_t *)(lb + 16);
     f.rescale = raw_rerun ? 0 : 1; f.max_depth = ctx->prm.max_depth_rescale;
     f.span_info = (int4 *)ctx->d_span.p;
@@ -1426,19 +1443,36 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             hipLaunchKernelGGL(k_tile_ranges_fused, dim3(nblk), dim3(256), 0, ctx->stream, a, (int32_t *)lb, (unsigned long long *)(lb + lb_head), nblk, (const int2 *)ctx->d_regb.p,
                                (SpanRec *)ctx->d_spanrec.p, (int32_t *)ctx->d_deep.p, (int32_t *)(lb + 44));
         }
+        // the deep spans k_fused_tiles leaves out go to k_fused_deep: one workgroup of sixteen wavefronts per CU, spans by ticket (no deep span: the
+        // workgroups leave at once).  The two kernels share nothing but the allocators and run side by side, the deep one on its own stream; under
+        // the profiler (one kernel at a time, each timed on the context's stream) they run one after the other.
+        const bool side = !ctx->profiling && !getenv("C3R_DEEP_SERIAL");
+        auto launch_deep = [&](hipStream_t st) {
+            DeepArgs d{(const int32_t *)ctx->d_deep.p, (const int32_t *)(lb + 44), (int32_t *)(lb + 48)};
+            if (C == C3R_CH) hipLaunchKernelGGL(k_fused_deep<C3R_CH>, dim3(deep_grid), dim3(DEEP_THREADS), 0, st, f, d);
+            else hipLaunchKernelGGL(k_fused_deep<C3R_CH_PHASED>, dim3(deep_grid), dim3(DEEP_THREADS), 0, st, f, d);
+        };
+        if (side) {
+            if (!ctx->deep_stream) {
+                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->deep_stream, hipStreamNonBlocking));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            }
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->deep_stream, ctx->ev_fork, 0));
+            launch_deep(ctx->deep_stream);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->deep_stream));
+        }
         {
             Launch L(ctx, "k_fused_tiles");
             const int grid = std::min(n_tiles, 2048);
             if (C == C3R_CH) hipLaunchKernelGGL(k_fused_tiles<C3R_CH>, dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, f);
             else hipLaunchKernelGGL(k_fused_tiles<C3R_CH_PHASED>, dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, f);
         }
-        {
-            // the deep spans k_fused_tiles has left out: one workgroup of sixteen wavefronts per CU, spans by ticket (no deep span: the workgroups leave at once)
+        if (side) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        else {
             Launch L(ctx, "k_fused_deep");
-            DeepArgs d{(const int32_t *)ctx->d_deep.p, (const int32_t *)(lb + 44), (int32_t *)(lb + 48)};
-            const int grid = std::min(n_tiles, ctx->n_cu > 0 ? ctx->n_cu : 256);
-            if (C == C3R_CH) hipLaunchKernelGGL(k_fused_deep<C3R_CH>, dim3(grid), dim3(DEEP_THREADS), 0, ctx->stream, f, d);
-            else hipLaunchKernelGGL(k_fused_deep<C3R_CH_PHASED>, dim3(grid), dim3(DEEP_THREADS), 0, ctx->stream, f, d);
+            launch_deep(ctx->stream);
         }
         {
             Launch L(ctx, "k_order_sites");
@@ -1446,23 +1480,25 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
                                (unsigned long long *)(lb + lb_head + (size_t)nblk * 8), (int32_t *)ctx->d_spanbase.p, (int32_t *)(lb + 8));
             hipLaunchKernelGGL(k_finalize_sites, dim3((unsigned)std::min<int64_t>((rows + 15) / 16 + 1, 8192)), dim3(256), 0, ctx->stream, z);
         }
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan, lb + 8, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan, lb + 8, 48, hipMemcpyDeviceToHost, ctx->stream));          // (.. [9]: deep spans listed)
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_scan + 16, lb + lb_alloc, (size_t)ALLOC_SHARDS * ALLOC_STRIDE * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         n_cand = ctx->h_scan[0]; n_tok = ctx->h_scan[1];
+        if (ctx->h_scan[9] > 0) ctx->seen_deep = true;
         int64_t need_c = 0, need_t = 0;          // the fullest shard
         for (int sh = 0; sh < nsh; ++sh) {
             const unsigned long long v = ((const unsigned long long *)(ctx->h_scan + 16))[(size_t)sh * ALLOC_STRIDE];
             need_c = std::max<int64_t>(need_c, (int64_t)(uint32_t)v); need_t = std::max<int64_t>(need_t, (int64_t)(v >> 32));
         }
         if (a.dbg) {
-            unsigned long long d[16];
+            unsigned long long d[32];
             HIPCHK(ctx, hipMemcpy(d, ctx->d_dbg.p, sizeof d, hipMemcpyDeviceToHost));
             const double nt = d[15] ? (double)d[15] : 1.0;
-            fprintf(stderr, "[k_fused_tiles] %llu spans; per span: reads in range %.1f, records in range %.1f, indel events %.1f; us per span: zero %.2f | cover+walk %.2f | scans %.2f | events %.2f | gates %.2f | first-seen %.2f | select+store %.2f | tokens %.2f\n",
-                    d[15], d[13] / nt, d[14] / nt, d[12] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[6] / nt / 100, d[7] / nt / 100, d[8] / nt / 100);
+            fprintf(stderr, "[k_fused_tiles] %llu spans; per span: reads in range %.1f, records in range %.1f, indel events %.1f; us per span: zero %.2f | cover+walk %.2f | scans %.2f | event buckets (LDS store) %.2f | events %.2f | gates %.2f | first-seen %.2f | select+store %.2f | tokens %.2f\n",
+                    d[15], d[13] / nt, d[14] / nt, d[12] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[5] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[6] / nt / 100, d[7] / nt / 100, d[8] / nt / 100);
             fprintf(stderr, "   tail: row mask %.2f | scan %.2f | allocator atomic %.2f us\n", d[9] / nt / 100, d[10] / nt / 100, d[11] / nt / 100);
+            fprintf(stderr, "   LDS event store: leader search (thread 0) %.2f | wait for the others %.2f us\n", d[16] / nt / 100, d[17] / nt / 100);
         }
         if ((ctx->h_scan[2] & 4) && !f.ph.rsegs) {
             // a flagged column and no tables yet: build them (this context keeps doing so from now on) and run the scan again

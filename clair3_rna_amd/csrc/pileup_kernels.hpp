@@ -179,6 +179,8 @@ struct ScanArgs {
     EvRec *ev;                    // scratch: ev_cap records, bump-allocated per tile through ev_cursor
     unsigned long long *ev_cursor;
     unsigned long long ev_cap;    // a reservation past it is refused: the tile skips its events and raises *ev_overflow
+    EvRec *ev_wg;                 // k_fused_deep: per-workgroup arrival-order event buffers, ev_wg_cap records each (null: none — deep tiles walk twice)
+    int32_t ev_wg_cap;
     int32_t *ev_overflow;         // bit 0: the event scratch; bit 1: a position covered by 32768 reads or more — its counts may not fit the 16-bit windows
     int32_t *last_row;            // [n_regions] atomicMax of the last SLOT (index into the position arrays) with a row
     const uint32_t *drop;         // mpileup depth cap: [n_regions][drop_words] bit per read = discarded in that region; null: none
@@ -307,7 +309,7 @@ __device__ __forceinline__ bool sorted_contains(const int32_t *a, int n, int v) 
 
 constexpr int AF_TAB = 8192;
 constexpr int EV_HASH_MIN = 1024;      // indel events of a tile from which their alleles are counted through a hash table (tile_columns)
-constexpr int DEEP_MIN_RECORDS = 1536; // records in a tile's range from which it takes the position-major walk (walk_columns); ScanArgs::deep_min
+constexpr int DEEP_MIN_RECORDS = 2048; // records in a tile's range from which it takes the position-major walk (walk_columns); ScanArgs::deep_min
 enum WalkMode { ACCUM = 0, SCATTER = 1, FIRSTSEEN = 2 };
 constexpr int FS_CAP = 32;     // positions per batch of the first-seen (tie-break) pass
 
@@ -323,6 +325,8 @@ struct TileLds {
     EvRec *evq;        // [evq_cap] the tile's indel events in arrival order, captured by the ACCUM pass (null / 0: not captured)
     int32_t *evn;      // events met so far
     int32_t evq_cap;
+    EvRec *evg;        // k_fused_deep: the workgroup's own event buffer in global memory — every event of the tile in arrival order, beside the LDS store
+    int32_t evg_cap;   //   (a span whose events outgrow the LDS store is then bucketed from there, without a second walk over its records)
 };
 
 // Coverage of the tile from whole-read spans (incl. introns): header-only, one lane per read.  A read that starts at or before the tile's
@@ -425,6 +429,7 @@ __device__ __forceinline__ void walk_event(const ScanArgs &a, const TileLds &s, 
         if (s.evq_cap > 0) {
             const int at = atomicAdd(s.evn, 1);
             if (at < s.evq_cap) s.evq[at] = e;
+            if (at < s.evg_cap) s.evg[at] = e;
         }
     } else {  // SCATTER
         const int slot = s.evoff[pl] + atomicAdd(&s.evfill[pl], 1);
@@ -492,6 +497,10 @@ __device__ __forceinline__ void walk_rec(const ScanArgs &a, const TileLds &s, co
 #define C3R_WALK_UNR 1
 #endif
 constexpr int WALK_UNR = C3R_WALK_UNR;
+#ifndef C3R_DEEP_WALK_UNR
+#define C3R_DEEP_WALK_UNR 1
+#endif
+constexpr int DEEP_WALK_UNR = C3R_DEEP_WALK_UNR;        // k_fused_deep's first walk, records per lane and round (2 and 4 measured no faster at 500x: the LDS atomics bound it)
 template <int C, int MODE, int NT = SCAN_THREADS, int WALK_UNR = c3r::WALK_UNR>
 __device__ __forceinline__ void walk_records(const ScanArgs &a, const TileLds &s, int rlo, int rhi, int t0, int t1, int region, EvRec *ev) {
     const int tid = (int)threadIdx.x;
@@ -553,6 +562,14 @@ __device__ __forceinline__ bool ev_equal(const ScanArgs &a, const EvRec &x, cons
         }
     }
     return !((x.kind ^ y.kind) & 1) || caseless;
+}
+
+// equal alleles (ev_equal) hash alike: kind, length, the first 16 bases, and the strand unless the insertion may be the '='-only kind that has none
+__device__ __forceinline__ uint64_t ev_hash(const EvRec &me) {
+    const bool maybe_caseless = (me.kind & 2) && me.key == 0;
+    uint64_t h = me.key * 0x9E3779B97F4A7C15ull + (uint64_t)me.len * 0xC2B2AE3D27D4EB4Full + (uint64_t)((me.kind & 6) | (maybe_caseless ? 0 : (me.kind & 1)));
+    h ^= h >> 29;
+    return h * 0xBF58476D1CE4E5B9ull;
 }
 
 // One thread per tile: the reads and records that can touch it (span_ranges: four table entries), thousands at a time instead of by
@@ -726,8 +743,12 @@ struct alignas(16) TileMem {
     unsigned long long rowmask[WAVES];          // k_fused_tiles: which positions hold a pileup row, one bit each
     unsigned long long ambmask[WAVES];          // k_fused_tiles: positions with a tie at the top of the allele counts (first-seen pass)
     unsigned long long evbase;
-    EvRec ev[EV_LDS > 0 ? EV_LDS : 1];
+    alignas(16) EvRec ev[EV_LDS > 0 ? EV_LDS : 1];
     evord_t evord[EV_LDS > 0 ? EV_LDS : 4];     // the captured events' indices, bucketed by position
+    // the deep kernel's event store (EV_LDS > 256): per bucket slot the event's allele hash and, for the first event of an allele, its multiplicity
+    alignas(16) uint32_t esig[EV_LDS > 256 ? EV_LDS : 1];
+    int32_t ecnt[EV_LDS > 256 ? EV_LDS : 1];
+    evord_t elead[EV_LDS > 256 ? EV_LDS : 4];   // per bucket slot: the slot that stands for its allele
 };
 struct TileOut { bool is_row, cand; int depth, cov; };     // cov: the token slots the position needs if it becomes a candidate — an upper bound of the reads that show
                                                            // something other than the reference base or a ref-skip there (tile_tokens)
@@ -738,6 +759,30 @@ struct TileOut { bool is_row, cand; int depth, cov; };     // cov: the token slo
 // recompute, and the thread its position's verdict.  Positions below pmin hold no rows (they lie before the region).
 // Used by the column-store kernel (k_scan_tiles) and by the fused kernel (k_fused_tiles), whose "tile" is a window-complete span.
 // FUSED (k_fused_tiles): the row mask of the window rule is published with the ambiguity votes (one barrier instead of two).
+// The first slot in [b, i] whose event is slot i's allele (i itself when none before it is): the slots' 32-bit allele hashes four at a time — one
+// 16-byte LDS read per step, the next one issued before this one is looked at —, `same(j)` (ev_equal) only where the hashes agree.
+template <class Same>
+__device__ __forceinline__ int first_of_allele(const uint32_t *sig, int b, int i, Same &&same) {
+    const uint32_t mine = sig[i];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    int j = b & ~3;
+    u32x4 cur = *reinterpret_cast<const u32x4 *>(sig + j);
+#pragma unroll 1
+    for (; j < i; j += 4) {
+        const u32x4 nxt = *reinterpret_cast<const u32x4 *>(sig + min(j + 4, i & ~3));
+        uint32_t hit = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hit |= (j + q >= b && j + q < i && cur[q] == mine) ? (1u << q) : 0u;
+        while (hit) {
+            const int q = __builtin_ctz(hit);
+            hit &= hit - 1u;
+            if (same(j + q)) return j + q;
+        }
+        cur = nxt;
+    }
+    return i;
+}
+
 template <int C, int NT, int EVL>
 __device__ __forceinline__ void tile_zero(TileMem<C, EVL> &M) {
     const int tid = threadIdx.x;
@@ -756,7 +801,9 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EV
     constexpr int EV_LDS = EVL;
     const int tid = threadIdx.x;
     const bool pos_thread = NT == SCAN_THREADS || tid < TILE;
-    TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, M.ev, &M.misc[0], EV_LDS};
+    // (k_fused_deep: workgroup blockIdx.x owns a.ev_wg_cap event slots of a.ev_wg)
+    EvRec *const evg = (NT > SCAN_THREADS && a.ev_wg) ? a.ev_wg + (size_t)blockIdx.x * (size_t)a.ev_wg_cap : nullptr;
+    TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, M.ev, &M.misc[0], EV_LDS, evg, evg ? a.ev_wg_cap : 0};
     unsigned long long tprev = C3R_DBG(a) ? wall_clock64() : 0ull;
 #define C3R_PHASE(K) do { if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[K], now_ - tprev); tprev = now_; } } while (0)
     tile_zero<C, NT, EVL>(M);
@@ -775,7 +822,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EV
     __syncthreads();
 
     C3R_PHASE(0);
-    if (!(C3R_ABL(a) & 1)) walk_records<C, ACCUM, NT>(a, s, slo, shi, t0, t1, region, nullptr);
+    if (!(C3R_ABL(a) & 1)) walk_records<C, ACCUM, NT, (NT > SCAN_THREADS ? DEEP_WALK_UNR : c3r::WALK_UNR)>(a, s, slo, shi, t0, t1, region, nullptr);
     if (!(C3R_ABL(a) & 4)) {
         cover_span(s, rd_end > t0 && rd_pos < t1, rd_pos, rd_end, t0, t1);
         cover_reads<NT>(a, s, lo + NT, hi, t0, t1, region);
@@ -794,17 +841,41 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EV
     if (pos_thread && my_cov >= 32768) atomicOr(a.ev_overflow, 2);          // (every count of a column is a count of reads that cover it: below this, the windows fit int16)
     if (pos_thread) M.evoff[tid] = ex.y;
     C3R_PHASE(2);
+    if (C3R_ABL(a) & 524288) { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }
     if (ev_total > 0 && !(C3R_ABL(a) & 2)) {
         // the tile's indel events, bucketed by position (counting sort through evoff / evfill), then the max multiplicity of one
         // allele per (position, channel): I1 / i1 / D1 / d1
         __syncthreads();                       // (evoff of every position is in place)
         if (ev_total <= EV_LDS) {
             // the usual case: the first walk has captured every event (ev_total of them, in arrival order); bucket their indices
-            for (int e = tid; e < ev_total; e += NT) {
+            for (int e = (C3R_ABL(a) & 262144) ? ev_total : tid; e < ev_total; e += NT) {
                 const int pl = M.ev[e].pl;
-                M.evord[M.evoff[pl] + atomicAdd(&M.evfill[pl], 1)] = (typename TileMem<C, EVL>::evord_t)e;
+                const int slot = M.evoff[pl] + atomicAdd(&M.evfill[pl], 1);
+                M.evord[slot] = (typename TileMem<C, EVL>::evord_t)e;
+                if (EV_LDS > 256 && !(C3R_ABL(a) & 32768)) { M.esig[slot] = (uint32_t)(ev_hash(M.ev[e]) >> 32); M.ecnt[slot] = 0; }
             }
             __syncthreads();
+            C3R_PHASE(5);
+            if (EV_LDS > 256) {
+                // The deep kernel's store holds thousands of events and a true indel at 500x puts hundreds of them into ONE bucket, whose threads would
+                // each compare with all of it.  Instead an allele is stood for by its FIRST event in the bucket: an event looks for the first slot before
+                // its own that holds its allele (the 32-bit hashes first, ev_equal — an equivalence — on a match), adds one to that slot's count, and
+                // reads the count back after the barrier.  Members of a frequent allele stop after a few slots, the stragglers only compare hashes.
+                // (loops kept rolled and ev_equal at ONE call site: a span runs this code once, and its size is instruction-cache misses)
+#pragma unroll 1
+                for (int i = (C3R_ABL(a) & 131072) ? ev_total : tid; i < ev_total; i += NT) {
+                    const EvRec me = M.ev[M.evord[i]];
+                    const int L = (C3R_ABL(a) & 16384) ? i : first_of_allele(M.esig, M.evoff[me.pl], i, [&](int j) { return ev_equal(a, me, M.ev[M.evord[j]]); });
+                    atomicAdd(&M.ecnt[L], 1);
+                    M.elead[i] = (typename TileMem<C, EVL>::evord_t)L;
+                }
+                __syncthreads();
+#pragma unroll 1
+                for (int i = (C3R_ABL(a) & 65536) ? ev_total : tid; i < ev_total; i += NT) {
+                    const EvRec &me = M.ev[M.evord[i]];
+                    atomicMax(&M.cnt[(int)me.pl * C + me.ch], M.ecnt[M.elead[i]]);
+                }
+            } else
             for (int e = tid; e < ev_total; e += NT) {
                 const EvRec me = M.ev[e];
                 const int pl = me.pl;
@@ -821,15 +892,58 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EV
             // every event of the same allele (ev_equal against the slot's representative — an equivalence: kind, length, bases, pads and, but
             // for the '='-only insertions, strand) adds one.  The all-pairs count below is quadratic in the depth: at mpileup's cap of 8000
             // reads a span spent 14 of its 22 ms there (profiles/r5/deep_locus_phases.txt); it stays for the shallow tiles, where it is cheaper.
-            const bool hashed = ev_total > EV_HASH_MIN;
+            // (k_fused_deep) up to LEAD_CAP events the alleles are counted as in the LDS store above — first event of an allele in its bucket stands for
+            // it — with the events themselves in the global buckets and their hashes / counts where the (outgrown) LDS store lay
+            constexpr int LEAD_CAP = EV_LDS > 256 ? (int)(sizeof(M.ev) / 8) : 0;
+            const bool lead = EV_LDS > 256 && ev_total <= LEAD_CAP;
+            const bool hashed = !lead && ev_total > EV_HASH_MIN;
             const unsigned long long ev_units = (unsigned long long)((ev_total + 15) & ~15);
             const unsigned long long tab_units = hashed ? ((unsigned long long)ev_total * 2ull * sizeof(uint2) + sizeof(EvRec) - 1) / sizeof(EvRec) : 0ull;
             auto events = [&](EvRec *ev) __attribute__((always_inline)) {
-                walk_records<C, SCATTER, NT>(a, s, slo, shi, t0, t1, region, ev);
+                if (s.evg && ev_total <= s.evg_cap) {
+                    // every event of the tile lies in the workgroup's buffer in arrival order (walk_event): into the buckets from there
+                    __threadfence_block();
+#pragma unroll 1
+                    for (int e = tid; e < ev_total; e += NT) {
+                        // (the buffer is re-used span after span by this CU: read past its L1, which may hold the last span's lines)
+                        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(s.evg + e);
+                        unsigned long long w3[3];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) w3[q] = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        EvRec me;
+                        __builtin_memcpy(&me, w3, sizeof me);
+                        ev[M.evoff[me.pl] + atomicAdd(&M.evfill[me.pl], 1)] = me;
+                    }
+                } else walk_records<C, SCATTER, NT>(a, s, slo, shi, t0, t1, region, ev);
                 uint2 *tab = reinterpret_cast<uint2 *>(ev + ev_units);
                 if (hashed) for (int i = tid; i < 2 * ev_total; i += NT) tab[i] = make_uint2(0xffffffffu, 0u);
                 __threadfence_block();
                 __syncthreads();
+                if (lead) {
+                    // per bucket slot: the event's hash and its count where the events of the LDS store lay, the slot that stands for its allele where that
+                    // store's own tables lay (evord, esig, ecnt, elead: contiguous, 12 bytes per event of the store)
+                    uint32_t *gsig = reinterpret_cast<uint32_t *>(M.ev), *gcnt = gsig + LEAD_CAP, *glead = reinterpret_cast<uint32_t *>(M.evord);
+                    typedef TileMem<C, EVL> TM;
+                    static_assert(offsetof(TM, elead) + sizeof(M.elead) - offsetof(TM, evord) >= (EV_LDS > 256 ? LEAD_CAP : 0) * sizeof(uint32_t) &&
+                                  sizeof(M.ev) >= 2 * (EV_LDS > 256 ? LEAD_CAP : 0) * sizeof(uint32_t), "the leader words alias the LDS event store");
+#pragma unroll 1
+                    for (int i = tid; i < ev_total; i += NT) { gsig[i] = (uint32_t)(ev_hash(ev[i]) >> 32); gcnt[i] = 0; }
+                    __syncthreads();
+#pragma unroll 1
+                    for (int i = tid; i < ev_total; i += NT) {
+                        const EvRec me = ev[i];
+                        const int L = first_of_allele(gsig, M.evoff[me.pl], i, [&](int j) { return ev_equal(a, me, ev[j]); });
+                        atomicAdd(&gcnt[L], 1u);
+                        glead[i] = (uint32_t)L;
+                    }
+                    __syncthreads();
+#pragma unroll 1
+                    for (int i = tid; i < ev_total; i += NT) {
+                        const EvRec me = ev[i];
+                        atomicMax(&M.cnt[(int)me.pl * C + me.ch], (int)gcnt[glead[i]]);
+                    }
+                    return;
+                }
                 if (!hashed) {
                     for (int e = tid; e < ev_total; e += NT) {
                         const EvRec me = ev[e];
@@ -843,13 +957,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EV
                     }
                     return;
                 }
-                auto slot_of = [&](const EvRec &me, int n) -> uint32_t {
-                    // equal alleles hash alike: the strand counts unless the insertion may be the '='-only kind that has none
-                    const bool maybe_caseless = (me.kind & 2) && me.key == 0;
-                    uint64_t h = me.key * 0x9E3779B97F4A7C15ull + (uint64_t)me.len * 0xC2B2AE3D27D4EB4Full + (uint64_t)((me.kind & 6) | (maybe_caseless ? 0 : (me.kind & 1)));
-                    h ^= h >> 29;
-                    return (uint32_t)((h * 0xBF58476D1CE4E5B9ull) >> 33) % (uint32_t)(2 * n);
-                };
+                auto slot_of = [&](const EvRec &me, int n) -> uint32_t { return (uint32_t)(ev_hash(me) >> 33) % (uint32_t)(2 * n); };
                 for (int pass = 0; pass < 2; ++pass) {
                     // pass 0: claim or join the allele's slot; pass 1: every event reads its allele's count
                     for (int e = tid; e < ev_total; e += NT) {
@@ -1018,7 +1126,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs &a, const int tile, Til
     if (slo >= shi) {
         // intron-only tile: rows exist (ref-skip columns) but every count is zero.  Only the flags are written; the
         // gather treats the columns of such a tile as zeros (tile_cols stays 0).
-        TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, nullptr, nullptr, 0};
+        TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, nullptr, nullptr, 0, nullptr, 0};
         M.cov[tid] = 0; if (tid == 0) M.cov[TILE] = 0;
         __syncthreads();
         cover_reads(a, s, lo, hi, t0, t1, tg.region);
@@ -2101,7 +2209,8 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
 // times the wavefronts are a quarter of the rounds.  With one workgroup per CU the LDS holds DEEP_EV_LDS captured events: up to there a span's
 // alleles are counted out of LDS as in the shallow kernel, without the second walk and the global hash table of the deeper ones.
 constexpr int DEEP_THREADS = 1024;
-constexpr int DEEP_EV_LDS = 4096;
+constexpr int DEEP_EV_LDS = 3072;
+constexpr int DEEP_EVG_CAP = 49152;      // events of a span that a workgroup's global buffer holds (ScanArgs::ev_wg): a span at mpileup's depth cap has ~34 k
 struct DeepArgs { const int32_t *list; const int32_t *n_list; int32_t *ticket; };
 template <int C>
 __global__ __launch_bounds__(DEEP_THREADS, 4) void k_fused_deep(const FusedArgs f, const DeepArgs d) {

@@ -69,6 +69,10 @@ typedef struct c3r_synth_params {
     int32_t phased;          // emit HP tags
     double intron_lo, intron_hi;
     int64_t region_start, region_end;   // place genes only inside [region_start, region_end) (0 = whole contig)
+    double expr_sigma;       // sigma of the log-normal per-gene expression level; <= 0: the default 0.4 around `depth`.  Larger values keep the MEAN
+                             // at `depth` (level = depth * exp(sigma * g - sigma^2 / 2)): 2.3 spreads the genes over four to five decades — a few loci at
+                             // 1,000-10,000x, a long tail of one-to-three-read islands (what real RNA-seq looks like)
+    double max_level;        // cap on a gene's level (<= 0: none)
 } c3r_synth_params;
 
 typedef struct c3r_synth_result {
@@ -130,7 +134,8 @@ int c3r_synth_generate(const c3r_synth_params *P, c3r_synth_result *res) {
                 var[i] = Var{4, (float)(0.1 + 0.2 * rng.uni()), (uint8_t)'G'};
             }
         }
-        const double level = P->depth * std::exp(0.4 * rng.gauss());
+        double level = P->expr_sigma > 0 ? P->depth * std::exp(P->expr_sigma * rng.gauss() - 0.5 * P->expr_sigma * P->expr_sigma) : P->depth * std::exp(0.4 * rng.gauss());
+        if (P->max_level > 0 && level > P->max_level) level = P->max_level;
         const int n_reads = std::max(1, (int)(level * tlen / std::min(mean_len, (double)tlen)));
         for (int rix = 0; rix < n_reads; ++rix) {
             int Lr = P->platform == 0 ? (int)std::exp(std::log(900.0) + 0.6 * rng.gauss()) : (int)(2500 + 800 * rng.gauss());

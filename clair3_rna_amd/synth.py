@@ -233,7 +233,7 @@ _SYNTH_LIB = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libc3r
 class _SynthParams(_C.Structure):
     _fields_ = [("contig_len", _C.c_int64), ("seed", _C.c_uint64), ("depth", _C.c_double), ("expressed_frac", _C.c_double),
                 ("platform", _C.c_int32), ("phased", _C.c_int32), ("intron_lo", _C.c_double), ("intron_hi", _C.c_double),
-                ("region_start", _C.c_int64), ("region_end", _C.c_int64)]
+                ("region_start", _C.c_int64), ("region_end", _C.c_int64), ("expr_sigma", _C.c_double), ("max_level", _C.c_double)]
 
 
 class _SynthResult(_C.Structure):
@@ -247,8 +247,10 @@ SEED = 20240422
 
 
 def generate_contig(contig_len=CHR20_LEN, seed=SEED, depth=20.0, expressed_frac=0.03, platform="ont", phased=False,
-                    intron_lo=100.0, intron_hi=100000.0, region=None):
-    """Synthetic contig + alignments at BASELINE.json config scale.  Returns (ref_bytes, ReadSet, info)."""
+                    intron_lo=100.0, intron_hi=100000.0, region=None, expr_sigma=0.0, max_level=0.0):
+    """Synthetic contig + alignments at BASELINE.json config scale.  Returns (ref_bytes, ReadSet, info).
+    expr_sigma > 0: log-normal gene expression with that sigma and mean `depth` (2.3: four to five decades — a few loci in the thousands,
+    a long tail of one-to-three-read islands); max_level caps a gene's level."""
     from .reads import READ_DTYPE
     if not _os.path.exists(_SYNTH_LIB):
         raise ImportError("libc3r_synth.so missing — run __graft_entry__.build()")
@@ -256,7 +258,7 @@ def generate_contig(contig_len=CHR20_LEN, seed=SEED, depth=20.0, expressed_frac=
     L.c3r_synth_generate.argtypes = [_C.POINTER(_SynthParams), _C.POINTER(_SynthResult)]
     L.c3r_synth_free.argtypes = [_C.POINTER(_SynthResult)]
     p = _SynthParams(contig_len, seed, depth, expressed_frac, 0 if platform == "ont" else 1, int(phased), intron_lo, intron_hi,
-                     region[0] if region else 0, region[1] if region else 0)
+                     region[0] if region else 0, region[1] if region else 0, float(expr_sigma), float(max_level))
     r = _SynthResult()
     rc = L.c3r_synth_generate(_C.byref(p), _C.byref(r))
     if rc != 0:
