@@ -93,33 +93,43 @@ def k1_algorithmic_bytes(rs, centres, channels, min_mq=5, excl_flags=2316):
 
 
 def phase1_bytes(rs, channels, min_mq=5, excl_flags=2316):
-    """SURVEY.md 8(d), phase 1 — the column scan the reference runs over EVERY covered position (src/create_tensor_pileup.py:520-560), whether
-    or not a candidate comes of it: the input records (headers + CIGAR ops + packed bases, as handed over) + C * 4 bytes of counts per
-    position that at least one passing read covers (ref-skips included: mpileup prints a row there).  Returns (bytes, covered positions)."""
+    """SURVEY.md 8(d), phase 1 — the column scan the reference runs over every position of the pileup stream (src/create_tensor_pileup.py:520-560),
+    whether or not a candidate comes of it: the input records (headers + CIGAR ops + packed bases, as handed over) + C * 4 bytes of counts per
+    position.  Two position counts: `aligned` — positions where at least one passing read has an aligned base or a deletion (the only ones whose
+    counts can be non-zero; what `achieved` is priced on: the smaller, stricter figure) — and `covered`, which adds the positions that reads only
+    span with a ref-skip (mpileup prints a row of '>' / '<' there and the reference parses it).  Returns (bytes on aligned, aligned, covered)."""
     r = rs.reads
     n = len(r)
     in_bytes = int(rs.reads.nbytes + rs.cigar.nbytes + rs.seq.nbytes)
     if n == 0:
-        return float(in_bytes), 0
+        return float(in_bytes), 0, 0
     cig = rs.cigar.astype(np.int64)
     op, ln = cig & 15, cig >> 4
     ref_len = np.where((op == 0) | (op == 2) | (op == 3) | (op == 7) | (op == 8), ln, 0)
     csum = np.concatenate([[0], np.cumsum(ref_len)])
     first = r["cigar_off"].astype(np.int64)
-    span = csum[first + r["n_cigar"].astype(np.int64)] - csum[first]
+    ncig = r["n_cigar"].astype(np.int64)
+    span = csum[first + ncig] - csum[first]
     pos = r["pos"].astype(np.int64)
     end = pos + span
     flag = r["flag"].astype(np.int64)
     ok = ((flag & excl_flags) == 0) & ((flag & 4) == 0) & ~(((flag & 1) != 0) & ((flag & 2) == 0)) & (r["mapq"] >= min_mq) & (end > pos)
-    p, e = pos[ok], end[ok]
-    if len(p) == 0:
-        return float(in_bytes), 0
-    o = np.argsort(p, kind="stable")
-    p, e = p[o], e[o]
-    reach = np.maximum.accumulate(e)
-    prev = np.concatenate([[p[0]], reach[:-1]])
-    covered = int(np.sum(np.maximum(e - np.maximum(p, prev), 0)))      # union of the read spans
-    return float(in_bytes + 4 * channels * covered), covered
+
+    def union(p, e):
+        if len(p) == 0:
+            return 0
+        o = np.argsort(p, kind="stable")
+        p, e = p[o], e[o]
+        reach = np.maximum.accumulate(e)
+        prev = np.concatenate([[p[0]], reach[:-1]])
+        return int(np.sum(np.maximum(e - np.maximum(p, prev), 0)))
+    covered = union(pos[ok], end[ok])
+    # aligned pieces: M / = / X / D ops of the passing reads (the generator lays the CIGARs out back to back in read order)
+    rid = np.repeat(np.arange(n), ncig)
+    start = pos[rid] + (csum[:-1] - csum[first][rid])
+    keep = ok[rid] & ((op == 0) | (op == 2) | (op == 7) | (op == 8)) & (ln > 0)
+    aligned = union(start[keep], start[keep] + ln[keep])
+    return float(in_bytes + 4 * channels * aligned), aligned, covered
 
 
 def chunk_list(contig_len, chunk=CHUNK):
@@ -237,7 +247,7 @@ def rooflines(kernels, n_prof, rs, site_pos, channels, precision):
                        inference_sites_per_s=round(n_prof / (net_ms * 1e-3), 1) if net_ms else None,
                        tensor_build_algorithmic_GBps=round(tb_gbps, 1) if k1_ms else None,
                        tensor_build_ms=round(k1_ms, 3), read_preparation_ms=round(prep_ms, 3), inference_ms=round(net_ms, 3))
-    p1_bytes, covered = phase1_bytes(rs, channels)
+    p1_bytes, aligned, covered = phase1_bytes(rs, channels)
     p1_gbps = p1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms else 0.0
     if dom not in fps and roofline["bound"] == "hbm" and k1_ms:
         # the dominant kernel is a tensor-build kernel (deep coverage, few candidates): it IS the column scan, and the scan's bytes — every input
@@ -252,10 +262,15 @@ def rooflines(kernels, n_prof, rs, site_pos, channels, precision):
                        achieved=round(tb_gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(tb_gbps / PEAK_HBM_GBPS, 4),
                        bytes_per_site=round(k1_bytes / n_prof, 1) if n_prof else None, bytes_per_pass=int(k1_bytes), ms=round(k1_ms, 3),
                        note="bytes: SURVEY 8(d) formula evaluated on the pass's own candidates and reads (bench.k1_algorithmic_bytes)")
-    roofline_tb["phase1"] = dict(bytes=int(p1_bytes), covered_positions=covered, achieved=round(p1_gbps, 1), unit="GB/s", frac=round(p1_gbps / PEAK_HBM_GBPS, 4),
-                                 ms=round(k1_ms, 3), bytes_per_covered_position=round(p1_bytes / covered, 1) if covered else None,
-                                 note="SURVEY 8(d) phase 1, the column scan over every covered position: input records (headers + CIGAR ops + packed bases) + "
-                                      "C*4 B of counts per covered position, over the summed device time of all tensor-build kernels (bench.phase1_bytes)")
+    in_bytes = int(rs.reads.nbytes + rs.cigar.nbytes + rs.seq.nbytes)
+    roofline_tb["phase1"] = dict(bytes=int(p1_bytes), input_record_bytes=in_bytes, aligned_positions=aligned, covered_positions_incl_ref_skips=covered,
+                                 achieved=round(p1_gbps, 1), unit="GB/s", frac=round(p1_gbps / PEAK_HBM_GBPS, 4), ms=round(k1_ms, 3),
+                                 bytes_per_aligned_position=round(p1_bytes / aligned, 1) if aligned else None,
+                                 frac_on_covered_positions=round((in_bytes + 4 * channels * covered) / (k1_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if k1_ms else None,
+                                 note="SURVEY 8(d) phase 1, the column scan: input records (headers + CIGAR ops + packed bases) + C*4 B of counts per position that "
+                                      "holds an aligned base or a deletion of a passing read, over the summed device time of all tensor-build kernels "
+                                      "(bench.phase1_bytes); frac_on_covered_positions prices the ref-skip-only positions too (rows the reference parses, "
+                                      "columns this build never forms)")
     h2d_bytes = int(rs.reads.nbytes + rs.cigar.nbytes + rs.seq.nbytes)
     roofline_tb["h2d"] = dict(bytes=h2d_bytes, ms=round(h2d_ms, 3), GBps=round(h2d_bytes / (h2d_ms * 1e-3) / 1e9, 1) if h2d_ms else None, included_in_ms=False,
                               frac_with_h2d=round(k1_bytes / ((k1_ms + h2d_ms) * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if k1_ms else None,
@@ -427,11 +442,19 @@ def run_strong(args, rank, local_rank, world, one_gpu, emit=True):
     loads = [sum(lens[i] for i in p) for p in plan]
     my_reads = float(sum(info["n_reads"] for (_ci, _r, _rs, _ch, info) in data))
     reads_max, reads_sum = my_reads, my_reads
+    # what this rank keeps resident: device memory in use on ITS device while its contexts are alive (with the one-GPU test hook: of all ranks
+    # together), and the page-locked host bytes of its inputs
+    free_b, total_b = torch.cuda.mem_get_info()
+    hbm_used = float(total_b - free_b)
+    pinned = float(sum(r.nbytes + rs.reads.nbytes + rs.cigar.nbytes + rs.seq.nbytes for (_ci, r, rs, _ch, _info) in data))
+    pinned_max = pinned
     if dist is not None:
         dist.barrier()
         elapsed = shard.reduce_max(dist, elapsed, device=red_dev)
         sites = int(shard.reduce_sum(dist, sites, device=red_dev))
         reads_max, reads_sum = shard.reduce_max(dist, my_reads, device=red_dev), shard.reduce_sum(dist, my_reads, device=red_dev)
+        hbm_used = shard.reduce_max(dist, hbm_used, device=red_dev)
+        pinned_max = shard.reduce_max(dist, pinned, device=red_dev)
     for e in engs:
         e.close()
     if rank == 0:
@@ -444,7 +467,9 @@ def run_strong(args, rank, local_rank, world, one_gpu, emit=True):
                           "parallelism": "contigs dealt largest-first to %d rank(s), no collective" % world, "lpt_imbalance": round(shard.imbalance(lens, plan), 4),
                           "read_imbalance": round(reads_max / (reads_sum / world), 4) if reads_sum else None,      # max / mean READS per rank (the work), not lengths
                           "contigs_per_rank": [len(p) for p in plan], "bp_per_rank": loads, "sites_per_step": round(sites / max(1, args.steps), 1),
-                          "precision": args.precision, "streams": len(engs)},
+                          "precision": args.precision, "streams": len(engs),
+                          "hbm_in_use_bytes_max_rank": int(hbm_used), "pinned_input_bytes_max_rank": int(pinned_max),
+                          "host_threads_per_rank": int(os.environ.get("C3R_THREADS", "0")) or None},
                "roofline": None, "cpu_baseline": None}
         if emit:
             print(json.dumps(out), flush=True)
@@ -468,6 +493,7 @@ def main():
                          "BASELINE.json configs[2] dealt to the ranks largest-first (LPT), total work fixed")
     ap.add_argument("--genome_scale", type=float, default=1.0, help="--scaling strong: shrink every contig by this factor (quick runs)")
     ap.add_argument("--no_resident", action="store_true", help="skip the additional measurement with the read tables already on the device")
+    ap.add_argument("--no_f32", action="store_true", help="skip the three additional steps on the fp32 MFMA path (reported as f32_mfma)")
     ap.add_argument("--no_fast", action="store_true", help="skip the additional measurement in precision 'auto' (reported as fast_precision)")
     ap.add_argument("--no_strong", action="store_true", help="skip the additional N = 1 run of the strong-scaling configuration (BASELINE.json configs[2] at "
                                                              "a quarter of every contig's length), reported as strong_1gpu")
@@ -656,6 +682,45 @@ def main():
         for e in engs:
             e.set_precision(args.precision)
 
+    # ---- three steps in the reference's own arithmetic (clair3_rna/model.py:175-216 runs fp32): the exact-fp32 MFMA path, which is also where the
+    # split-f16 guard sends weights it cannot hold — an ADDITIONAL figure in every line
+    f32 = None
+    if args.precision != "f32" and args.steps > 0 and not args.no_f32:
+        try:
+            for e in engs:
+                e.set_precision("f32")
+            barrier()
+            run_steps(len(engs))                      # (every context once on this path, untimed)
+            barrier()
+            t1 = time.perf_counter()
+            fsites = run_steps(3)
+            for e in engs:
+                e.synchronize()
+            torch.cuda.synchronize()
+            fel = time.perf_counter() - t1
+            if dist is not None:
+                dist.barrier()
+                from clair3_rna_amd import shard
+                fel = shard.reduce_max(dist, fel, device=red_dev)
+                fsites = int(shard.reduce_sum(dist, fsites, device=red_dev))
+            eng.set_profiling(True); eng.reset_kernel_stats()
+            nf = one_step()
+            eng.set_profiling(False)
+            kf = eng.kernel_stats()
+            net_ms = sum(v["total_ms"] for k, v in kf.items() if k in NET_KERNELS)
+            fl = sum(flop_per_site(18).values()) * nf
+            f32 = dict(value=round(fsites / fel, 1), unit="sites/s", ms_per_step=round(1e3 * fel / 3, 3), steps=3, precision="f32",
+                       dtype="f32 (v_mfma_f32_32x32x2_f32), f32 accumulate", network_ms=round(net_ms, 3),
+                       network_tflops=round(fl / (net_ms * 1e-3) / 1e12, 1) if net_ms else None,
+                       network_frac_of_f32_mfma_peak=round(fl / (net_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if net_ms else None,
+                       kernels_ms_per_step={k: round(v["total_ms"], 3) for k, v in sorted(kf.items()) if k != "h2d_reads"},
+                       note="the same passes with c3r_set_precision(0): the reference's own arithmetic; not the headline")
+        except Exception as ex:
+            f32 = dict(error="%s: %s" % (type(ex).__name__, ex))
+        finally:
+            for e in engs:
+                e.set_precision(args.precision)
+
     # ---- per-kernel durations, live, with HIP events on the engine's stream (one extra untimed step)
     roofline, kernels, stage_rates, roofline_tb = None, {}, None, None
     if not args.no_profile:
@@ -683,7 +748,7 @@ def main():
     # ---- BASELINE.json configs[2] on ONE GPU: the 24 GRCh38 contigs (a quarter of each) from host-resident reads AND reference, so that the
     # driver's record carries the configuration `--scaling strong` shards over N ranks — an ADDITIONAL figure, never `value`
     n_streams = len(engs)
-    strong, phased, stress, capped = None, None, None, None
+    strong, phased, stress, capped, real = None, None, None, None, None
     if world == 1 and args.steps > 0 and not (args.no_strong and args.no_extra):
         for e in engs:
             e.close()
@@ -711,6 +776,12 @@ def main():
         stress = guarded(lambda: extra_config(
             "stress_500x", "synthetic ONT dRNA004 windows at ~500x: 16 Mb contig, expressed loci at mean depth 500 (BASELINE.json configs[4])",
             dict(contig_len=16000000, seed=synth.SEED + 4, depth=500.0), 18, args.precision, local_rank))
+        # the shape real RNA-seq has: log-normal gene expression over four to five decades on one chr20-sized contig — a few loci in the thousands,
+        # a long tail of one-to-three-read islands that emit nothing (src/create_tensor_pileup.py:512-516, :551-560), mean ~20x
+        real = guarded(lambda: extra_config(
+            "realistic_expr", "synthetic ONT dRNA004 chr20, log-normal gene expression (sigma 2.3, mean ~20x, capped at 12,000x): a few loci at 1,000-10,000x, "
+            "a long tail of one-to-three-read islands", dict(contig_len=synth.CHR20_LEN, seed=synth.SEED + 6, depth=20.0, expr_sigma=2.3, max_level=12000.0),
+            18, args.precision, local_rank))
         # one locus far beyond samtools mpileup's -d 8000: the depth-cap rule runs (csrc/c3r_lib.hip, depth_cap_mask), with the cap and without it
         deep = dict(contig_len=400000, seed=synth.SEED + 5, depth=20000.0, expressed_frac=0.01, intron_lo=100.0, intron_hi=800.0)
         capped = guarded(lambda: extra_config("depth_cap_20000x", "one 400-kb contig with loci at ~20,000x: mpileup's depth cap -d 8000 in force", deep, 18, args.precision, local_rank, steps=3))
@@ -739,8 +810,8 @@ def main():
                        "parallelism": "chunks sharded by contig, %d rank(s), no collective" % world,
                        "streams": n_streams},
             "roofline": roofline, "roofline_tensor_build": roofline_tb, "cpu_baseline": cpu, "stage_rates": stage_rates,
-            "resident_inputs": resident, "fast_precision": fast, "strong_1gpu": strong, "phased_1gpu": phased, "stress_500x": stress,
-            "depth_cap_20000x": capped,
+            "resident_inputs": resident, "fast_precision": fast, "f32_mfma": f32, "strong_1gpu": strong, "phased_1gpu": phased, "stress_500x": stress,
+            "depth_cap_20000x": capped, "realistic_expr": real,
             "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items())},
         }
         print(json.dumps(out), flush=True)

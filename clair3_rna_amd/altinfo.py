@@ -45,12 +45,18 @@ def inserted_text(readset, read_idx, qpos, n_bases, rev, pads=None):
     return "".join(out)
 
 
-def alt_dict_from_tokens(tokens, readset, ref_seq, ref_start, pos, pads=None, depth=None):
+COUNT_DEPTH = "count"
+
+
+def alt_dict_from_tokens(tokens, readset, ref_seq, ref_start, pos, pads=None, *, depth):
     """tokens: TOKEN_DTYPE slice for one site (BAM order). ref_seq[0] is 1-based ref_start.
-    depth: the site record's depth — the engine writes tokens only for reads that show something other than the reference base or a
-    ref-skip (since round 5), so the column's depth cannot be counted from them; None: one token per covering read, counted here.
+    depth (required): the site record's depth — the engine writes tokens only for reads that show something other than the reference base
+    or a ref-skip (since round 5), so the column's depth cannot be counted from them.  COUNT_DEPTH asks for the legacy stream by name:
+    one token per covering read, the depth counted here.
     Returns (OrderedDict alt, depth)."""
-    site_depth = depth
+    if depth is None:
+        raise TypeError("alt_dict_from_tokens: depth is required (the site record's depth, or altinfo.COUNT_DEPTH for a token per covering read)")
+    site_depth = None if depth == COUNT_DEPTH else depth
     ref_base = evc_base(ref_seq[pos - ref_start])
     alt = OrderedDict()
     depth = alt_count = ins_count = del_count = 0

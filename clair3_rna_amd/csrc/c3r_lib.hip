@@ -118,6 +118,10 @@ struct c3r_ctx {
     DevBuf d_lb, d_regb, d_span, d_spanbase, d_meta, d_spanrec, d_deep;       // (d_deep: list positions of the deep spans, k_fused_deep)
     DevBuf d_evwg;                         // k_fused_deep: an arrival-order event buffer per workgroup (DEEP_EVG_CAP records each), allocated once a scan has met a deep span
     bool seen_deep = false;
+    // the resident windows are int16 unless a scan of this read set has met a position that 32,768 reads or more cover (possible only above mpileup's
+    // default cap, max_depth = 0 or > 32,767): that scan is repeated with int32 windows and the context keeps them from then on (a context that
+    // has met such depth will meet it again: every pass over the same sample would otherwise scan twice)
+    bool win32 = false;
     int n_cu = 0;                          // compute units of the device (k_fused_deep: one workgroup each)
     DevBuf d_winidx;                       // [resident candidates] row of the i-th site's window in d_tensors (the fused path writes windows as they arrive)
     DevBuf d_rawidx, d_export;             // c3r_get_tensors: index of a raw re-run, windows gathered into position order
@@ -256,7 +260,12 @@ int ensure(c3r_ctx *ctx, DevBuf &b, size_t bytes) {
     const auto t0 = std::chrono::steady_clock::now();
     if (b.p) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     const auto t1 = std::chrono::steady_clock::now();
-    HIPCHK(ctx, hipMalloc(&b.p, want));
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        b.p = nullptr;
+        // (which buffer: its offset inside the context says so — a size in the hundreds of GB is a bad count read back from the device, not a full GPU)
+        return fail(ctx, C3R_ENOMEM, "hipMalloc of %zu bytes (asked for: %zu) failed for the device buffer at context offset %zu", want, bytes, (size_t)((char *)&b - (char *)ctx));
+    }
     if (timing) {
         const auto t2 = std::chrono::steady_clock::now();
         const double a = std::chrono::duration<double, std::milli>(t1 - t0).count(), m = std::chrono::duration<double, std::milli>(t2 - t1).count();
@@ -434,7 +443,17 @@ int build_padins(c3r_ctx *ctx, int n) {
     return C3R_OK;
 }
 
-int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
+// Uploads of a contig's records take the device's whole PCIe link for milliseconds.  When several contexts of one process share a device
+// (two pipelined contexts: one uploads while the other computes), two uploads at once halve each other's rate and BOTH contexts then compute
+// at the same time — the link idles while the kernels run and the kernels wait while the link is busy.  One upload at a time per device keeps
+// the contexts out of phase: the gate is taken before the first copy of c3r_load_reads and released at that call's first host wait (the
+// read-back of the table sizes, by which the copies have landed).
+static std::mutex &upload_gate(int device) {
+    static std::mutex gates[64];
+    return gates[(unsigned)device % 64u];
+}
+
+int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing, std::unique_lock<std::mutex> *gate = nullptr) {
     int rc;
     ctx->host_reads_valid = false; ctx->legacy_valid = false;
     if (!ctx->h_stats) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_stats, sizeof(LoadStats), hipHostMallocDefault));
@@ -501,6 +520,7 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
         // ---- the one synchronisation: sizes, errors
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_stats, ctx->d_stats.p, sizeof(LoadStats), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (gate && gate->owns_lock()) gate->unlock();          // (the uploads have landed: the next context's may start)
         HIPCHK(ctx, hipGetLastError());
         hs = *ctx->h_stats;
         if (hs.err != ~0ull) {
@@ -540,6 +560,8 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing) {
     HIPCHK(ctx, hipGetLastError());
     ctx->bins_dirty = false;                                  // (the record counters are back at zero once k_prep<true> is through)
     ctx->n_reads = n; ctx->n_indel_ops = hs.n_indel; ctx->max_cover = hs.max_cover;
+    // (under the profiler: how many workgroups of the second pass counted their records again — no kernel, `launches` is the count)
+    if (ctx->profiling && hs.n_recount > 0) ctx->kstats["k_prep_recount_workgroups"].n += hs.n_recount;
     if (timing) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[c3r_load_reads] %d reads, %d records in %d bins: first pass until the sync %.2f ms, second pass queued in %.2f ms\n", n, hs.n_rec, ctx->bins.nb,
@@ -751,6 +773,7 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     // c3r_host_alloc) and every table the tile kernels need is derived from them on the device
     if ((rc = ensure(ctx, ctx->d_rawreads, std::max<size_t>((size_t)n * sizeof(c3r_read_t), 16))) || (rc = ensure(ctx, ctx->d_rawcig, std::max<size_t>((size_t)n_cigar_ops * 4, 16))) ||
         (rc = ensure(ctx, ctx->d_seq, (size_t)n_seq_bytes + 16))) return rc;
+    std::unique_lock<std::mutex> gate(upload_gate(ctx->device));
     {
         Launch l(ctx, "h2d_reads");           // (profiling: the three uploads as one entry of the kernel statistics — PCIe time, not a kernel)
         if ((rc = upload(ctx, ctx->d_rawreads, reads, (size_t)n)) || (rc = upload(ctx, ctx->d_rawcig, cigars, (size_t)n_cigar_ops))) return rc;
@@ -763,7 +786,7 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     // the last read's position bounds the first guess of the bins (the records are sorted; an unsorted set fails in the first pass)
     const int64_t last_pos = std::max(reads[n - 1].pos, reads[0].pos);
     ctx->last_pos = last_pos;
-    return prepare_tables(ctx, n, last_pos, timing);
+    return prepare_tables(ctx, n, last_pos, timing, &gate);
 }
 
 void *c3r_host_alloc(size_t bytes) {
@@ -1052,6 +1075,9 @@ static int af_table(c3r_ctx *ctx) {
     auto thr = [](int d, double af) -> uint32_t {
         const double denom = d > 0 ? (double)d : 1.0;
         const int top = std::max(d, 1);
+        // an AF no count can reach (well above 65534 / depth: a user's AF > 1 at every depth of the table; NaN) is "never" at once, not after 65 k
+        // divisions (the margin leaves the last ulp to the divisions below)
+        if (!(af * denom <= 65536.0)) return 65535u;
         int c = (int)std::ceil(af * denom);                       // near the answer; settled by the division itself
         c = std::max(1, std::min(c, top + 1));
         while (c > 1 && (double)(c - 1) / denom >= af) --c;
@@ -1252,24 +1278,29 @@ static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg
         fprintf(stderr, "[k_scan_tiles] %llu heavy tiles; per tile: segments in range %.1f, listed %.1f, ops %.1f; us per tile: zero %.2f | cover+list+walk %.2f | scans %.2f | events %.2f | gates %.2f | store %.2f | first-seen %.2f\n",
                 d[15], d[13] / nt, d[12] / nt, d[14] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[5] / nt / 100, d[6] / nt / 100);
     }
-    if (flag_cand[0] & 2) { ctx->last_scan_pruned = false; return fail(ctx, C3R_EOVERFLOW, "a position is covered by more than 32,767 reads (after mpileup's depth cap): lower max_depth"); }
+    if ((flag_cand[0] & 2) && !ctx->win32) {
+        ctx->last_scan_pruned = false;
+        if (columns_only) { /* columns are int32 anyway */ }
+        else if (base_row != 0) return fail(ctx, C3R_EOVERFLOW, "a position is covered by more than 32,767 reads and the batch already holds 16-bit windows: scan this region first, or alone");
+        else { ctx->win32 = true; return scan_column_store(ctx, n_regions, ctg_starts, ctg_ends, n_candidates, columns_only); }
+    }
     if (flag_cand[0] & 1) { ctx->last_scan_pruned = false; return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap); }
     const int32_t n_cand = flag_cand[1];
     ctx->last_cand = n_cand;
     if (n_candidates) *n_candidates = n_cand;
     if (n_cand == 0) return C3R_OK;
-    const size_t tbytes = (size_t)C3R_WINDOW * C * sizeof(int16_t);          // the resident windows are int16 (a caller sees int32: c3r_get_tensors)
+    const size_t tbytes = (size_t)C3R_WINDOW * C * (ctx->win32 ? sizeof(int32_t) : sizeof(int16_t));          // the resident windows are int16 (a caller sees int32: c3r_get_tensors)
     if ((rc = ensure(ctx, ctx->d_cand, (size_t)n_cand * 4))) return rc;
     if ((rc = ensure_keep(ctx, ctx->d_tensors, (size_t)(base_row + n_cand) * tbytes, (size_t)base_row * tbytes))) return rc;
     if ((rc = ensure_keep(ctx, ctx->d_sites_out, (size_t)(base_cand + n_cand) * sizeof(c3r_site_t), (size_t)base_cand * sizeof(c3r_site_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_tokcnt, (size_t)(n_cand + 1) * 4))) return rc;
-    if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_raw, (size_t)n_cand * 2 * tbytes))) return rc;      // (raw windows: int32)
+    if (ctx->prm.splice_padding && (rc = ensure(ctx, ctx->d_raw, (size_t)n_cand * C3R_WINDOW * C * sizeof(int32_t)))) return rc;      // (raw windows: int32)
     {
         Launch L(ctx, "k_compact_write");
         hipLaunchKernelGGL(k_compact_write, dim3(n_cblocks), dim3(CMP_THREADS), 0, ctx->stream, (const uint8_t *)ctx->d_flags.p, (int)n_pos,
                            (const int32_t *)ctx->d_blockcnt.p, (int32_t *)ctx->d_cand.p, heavy, (int2 *)ctx->d_tile_cand.p);
     }
-    if ((rc = run_gather(ctx, 1, (char *)ctx->d_tensors.p + (size_t)base_row * tbytes, true, true))) return rc;
+    if ((rc = run_gather(ctx, 1, (char *)ctx->d_tensors.p + (size_t)base_row * tbytes, true, !ctx->win32))) return rc;
     if ((rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + n_cand) * 4, (size_t)base_cand * 4))) return rc;
     hipLaunchKernelGGL(k_iota, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, ctx->stream, (int32_t *)ctx->d_winidx.p + base_cand, (int)n_cand, (int)base_row);      // (windows in site order)
     {
@@ -1394,7 +1425,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     f.ph.reads = a.reads; f.ph.rsegs = have_tables ? (const DevSeg *)ctx->d_rsegs.p : nullptr; f.ph.rseg_first = have_tables ? (const uint32_t *)ctx->d_rseg_first.p : nullptr;
     f.ph.cigar = (const uint32_t *)ctx->d_cigar.p; f.ph.seq = a.seq;
     f.ph.min_mq = a.min_mq; f.ph.excl_flags = a.excl_flags; f.ph.drop = a.drop; f.ph.drop_words = a.drop_words;
-    const size_t tbytes = (size_t)C3R_WINDOW * C * sizeof(int16_t);          // the resident windows are int16 (a caller sees int32: c3r_get_tensors)
+    const size_t tbytes = (size_t)C3R_WINDOW * C * (ctx->win32 ? sizeof(int32_t) : sizeof(int16_t));          // the resident windows are int16 (a caller sees int32: c3r_get_tensors)
     // What this scan may write.  A small scan has one allocator and dense output: whatever the buffers can take beyond what the batch
     // already holds.  A large one hands rows and token slots out through ALLOC_SHARDS sub-allocators of equal size, sized from what the
     // previous large scan needed; when a shard runs over, the scan is repeated with what the counters say it needs.
@@ -1416,7 +1447,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         const int64_t rows = want_c * nsh, toks = want_t * nsh;
         if ((rc = ensure(ctx, ctx->d_meta, std::max<size_t>((size_t)rows * sizeof(CandMeta), 16)))) return rc;
         if (raw_rerun) {
-            if ((rc = ensure(ctx, ctx->d_raw, std::max<size_t>((size_t)rows * 2 * tbytes, 16))) || (rc = ensure(ctx, ctx->d_rawidx, std::max<size_t>((size_t)rows * 4, 16)))) return rc;
+            if ((rc = ensure(ctx, ctx->d_raw, std::max<size_t>((size_t)rows * C3R_WINDOW * C * sizeof(int32_t), 16))) || (rc = ensure(ctx, ctx->d_rawidx, std::max<size_t>((size_t)rows * 4, 16)))) return rc;
             f.tensors = ctx->d_raw.p; f.x16 = 0;
             z.win_idx = (int32_t *)ctx->d_rawidx.p; z.row_base = 0;
         } else {
@@ -1426,7 +1457,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
                 (rc = ensure_keep(ctx, ctx->d_winidx, (size_t)(base_cand + rows) * 4, (size_t)base_cand * 4)) ||
                 (rc = ensure_keep(ctx, ctx->d_tok, (size_t)(base_tok + toks) * sizeof(c3r_token_t), (size_t)base_tok * sizeof(c3r_token_t))))
                 return rc;
-            f.tensors = (char *)ctx->d_tensors.p + (size_t)base_row * tbytes; f.x16 = 1;
+            f.tensors = (char *)ctx->d_tensors.p + (size_t)base_row * tbytes; f.x16 = ctx->win32 ? 0 : 1;
             z.sites = (c3r_site_t *)ctx->d_sites_out.p + base_cand;
             z.cand_idx = (int32_t *)ctx->d_cand.p;
             z.win_idx = (int32_t *)ctx->d_winidx.p + base_cand; z.row_base = (int32_t)base_row; z.tok_base = (int32_t)base_tok;
@@ -1508,7 +1539,11 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             --attempt;
             continue;
         }
-        if (ctx->h_scan[6] & 2) return fail(ctx, C3R_EOVERFLOW, "a position is covered by more than 32,767 reads (after mpileup's depth cap): lower max_depth");
+        if ((ctx->h_scan[6] & 2) && !ctx->win32 && !raw_rerun) {
+            if (base_row != 0) return fail(ctx, C3R_EOVERFLOW, "a position is covered by more than 32,767 reads and the batch already holds 16-bit windows: scan this region first, or alone");
+            ctx->win32 = true;                 // (16-bit windows cannot hold this scan's counts: once more, with int32 windows)
+            return scan_fused(ctx, n_regions, ctg_starts, ctg_ends, n_candidates, false);
+        }
         if (ctx->h_scan[6] & 1) return fail(ctx, C3R_EOVERFLOW, "internal: indel-event scratch too small (%zu records) — nothing was written past it", ev_cap);
         if (ctx->h_scan[2] & 8) return fail(ctx, C3R_EOVERFLOW, "internal: tokens found no slot (the gates' bound of a site's tokens was too small)");
         if (n_cand < 0 || n_tok < 0) return fail(ctx, C3R_EOVERFLOW, "too many candidates or tokens for one scan");
@@ -1595,7 +1630,7 @@ int c3r_get_tensors(c3r_ctx *ctx, int rescaled, int32_t *tensors, int64_t cap_si
         if (rc) return rc;
         // (the resident windows are int16 rows in arrival order: gathered into position order and widened; a raw re-run's are int32)
         hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)std::min<int64_t>((ctx->n_cand + 3) / 4, 8192)), dim3(256), 0, ctx->stream, src, idx, (int)ctx->n_cand, row_ints,
-                           (int32_t *)ctx->d_export.p, rescaled ? 1 : 0);
+                           (int32_t *)ctx->d_export.p, (rescaled && !ctx->win32) ? 1 : 0);
         src = ctx->d_export.p;
     }
     HIPCHK(ctx, hipMemcpyAsync(tensors, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1852,7 +1887,7 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
     const int C = ctx->net.channels;
     const void *d_x = nullptr;
     const int32_t *d_rows = nullptr;
-    const bool x16 = tensors == nullptr;                 // the resident windows are int16, a caller's batch int32
+    const bool x16 = tensors == nullptr && !ctx->win32;  // the resident windows are int16 (unless the read set needed int32), a caller's batch int32
     if (tensors == nullptr) {
         if (C != ctx->prm.channels) return fail(ctx, C3R_EINVAL, "weights are for %d channels, scan produced %d", C, ctx->prm.channels);
         if (n != ctx->n_cand) return fail(ctx, C3R_EINVAL, "n=%lld but %lld candidates are resident", (long long)n, (long long)ctx->n_cand);
@@ -1972,9 +2007,14 @@ int c3r_rows_begin_ex(c3r_ctx *ctx, int drop_ref_calls, const c3r_read_t *host_r
         hipLaunchKernelGGL(k_row_keep, dim3((unsigned)(n_all / 256 + 1)), dim3(256), 0, ctx->stream, d_sites_src, d_probs_src, (int)n_all, (int32_t *)ctx->d_keep.p);
         if ((rc0 = device_excl_scan(ctx, (int32_t *)ctx->d_keep.p, (int)n_all + 1, (int32_t *)((char *)ctx->d_small.p + 52)))) { delete r; return rc0; }
         int32_t n_keep = 0;
+        // (the keep decision reads the probabilities: the layer-2 time-out word is checked with the same wait, before the count is acted on —
+        // a timed-out batch whose garbage looks like RefCalls must fail, not come back as an empty snapshot)
+        int32_t *lstm_st0 = nullptr;
+        if ((rc0 = queue_lstm_status(ctx, &lstm_st0))) { delete r; return rc0; }
         if (hipMemcpyAsync(&n_keep, (char *)ctx->d_small.p + 52, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
             delete r; return fail(ctx, C3R_EHIP, "reading the number of kept sites failed");
         }
+        if ((rc0 = check_lstm_status(ctx, lstm_st0))) { delete r; return rc0; }
         n = n_keep; r->n = n;
         if (n == 0) { r->n_tok = 0; *out = r; return C3R_OK; }
         if ((rc0 = ensure(ctx, ctx->d_sites_c, (size_t)n * sizeof(c3r_site_t))) || (rc0 = ensure(ctx, ctx->d_probs_c, (size_t)n * C3R_NPROB * sizeof(float)))) { delete r; return rc0; }
@@ -2040,7 +2080,8 @@ int c3r_rows_begin_ex(c3r_ctx *ctx, int drop_ref_calls, const c3r_read_t *host_r
         if (bytes >= PIN_MIN && pin_ring_on()) return big_d2h(ctx, dst, src, bytes) == C3R_OK;
         return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
     };
-    if (!d2h(ctx->h_pack, d_counter, 16) || hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(fail(ctx, C3R_EHIP, "copying the token counters to the host failed"));
+    // (only the packed snapshot sizes its token copy from the counters: the plain one keeps the single wait at the end)
+    if (!d2h(ctx->h_pack, d_counter, 16) || (packed && hipStreamSynchronize(ctx->stream) != hipSuccess)) return bail(fail(ctx, C3R_EHIP, "copying the token counters to the host failed"));
     if (packed) n_tok = (int64_t)((unsigned long long *)ctx->h_pack)[1];          // (the kept sites' token bytes lie back to back)
     if (!d2h(r->sites, d_sites_src, (size_t)n * sizeof(c3r_site_t)) || !d2h(r->tokb, ctx->d_tokb.p, (size_t)n_tok) ||
         !d2h(r->rec_off, ctx->d_recoff.p, (size_t)n * 4) ||

@@ -84,11 +84,13 @@ struct PadView {
         return (lo < n && p[lo].read_idx == r && p[lo].qpos == q) ? &p[lo] : nullptr;
     }
 };
+constexpr int COUNT_DEPTH = -1;
 template <typename NextTok, typename GetRead>
-// site_depth >= 0: the tokens are only those of reads that show something other than the reference base or a ref-skip (what the kernels
-// write since round 5) and the column's depth comes from the site record; < 0: one token per covering read, the depth is counted here.
+// site_depth >= 0 (what every caller passes): the tokens are only those of reads that show something other than the reference base or a ref-skip
+// (what the kernels write since round 5) and the column's depth comes from the site record.  COUNT_DEPTH: one token per covering read, the
+// depth is counted here (the legacy token stream; asked for by name, never by leaving the argument out).
 inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
-                            AltDict &alt, int &depth_out, const PadView pads = PadView{nullptr, 0}, int site_depth = -1) {
+                            AltDict &alt, int &depth_out, const PadView pads, int site_depth) {
     alt.clear();
     const int64_t ri = pos1 - ref_start1;
     char rb = (ri >= 0 && ri < (int64_t)ref.size()) ? ref[(size_t)ri] : 'N';
@@ -136,8 +138,9 @@ inline void alt_from_stream(int n, NextTok next, GetRead get_read, const RefView
 }
 template <typename GetRead>
 inline void alt_from_tokens(const c3r_token_t *tk, int n, GetRead get_read, const RefView &ref, int64_t ref_start1, int64_t pos1,
-                            AltDict &alt, int &depth_out) {
-    alt_from_stream(n, [tk](int i) { return TokView{tk[i].base, tk[i].indel, tk[i].read_idx, tk[i].qpos, tk[i].del_after, tk[i].rev != 0}; }, get_read, ref, ref_start1, pos1, alt, depth_out);
+                            AltDict &alt, int &depth_out, int site_depth) {
+    alt_from_stream(n, [tk](int i) { return TokView{tk[i].base, tk[i].indel, tk[i].read_idx, tk[i].qpos, tk[i].del_after, tk[i].rev != 0}; }, get_read, ref, ref_start1, pos1, alt, depth_out,
+                    PadView{nullptr, 0}, site_depth);
 }
 
 // ---------------------------------------------------------------------------------------------- call_site

@@ -2191,7 +2191,12 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
             }
         };
         if (!deep) fused_span<C, SCAN_THREADS, TileMem<C>::EV_LDS>(f, M, S, b, shard, r0, rng, r2, fetch_next);
-        else fetch_next();
+        else {
+            // (every wavefront has read THIS span's record out of s_rec before the hand-over below overwrites it: a span that is worked on passes
+            // a dozen barriers in between, a skipped one none — without this one a late wavefront took the next span's record for the current)
+            __syncthreads();
+            fetch_next();
+        }
         // ---- hand over: the next span's record and list position into LDS (s_rec was last read at the top of this span, many barriers
         // ago); the barrier also frees this span's LDS
         if (tid < 3) s_rec[tid] = nrec;

@@ -32,7 +32,7 @@ struct LoadStats {
     int32_t n_rec;            // records of the pile table
     int32_t n_indel;          // I + D ops of the passing reads (bounds the indel-event scratch of a scan)
     int32_t n_padreads;       // mpileup_compat = 1: reads with a pad inside a run of I ops (the host then builds the c3r_padins_t table)
-    int32_t pad;
+    int32_t n_recount;        // workgroups of k_prep<false> whose bin table held more occupied slots than their slab of wg_tab takes (k_prep<true> counts theirs again)
 };
 static_assert(sizeof(LoadStats) == 32, "LoadStats layout");
 enum { LD_OK = 0, LD_UNSORTED = 1, LD_CIGAR_RANGE, LD_SEQ_RANGE, LD_BAD_OP, LD_OP_LONG, LD_END_2G, LD_SEG_OPS, LD_RECORDS, LD_PAD_INS };
@@ -429,7 +429,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(const PrepArgs a) {
             for (int h = tid; h < HB; h += PREP_THREADS)
                 if (T.key[h]) { const uint32_t k = atomicAdd(&s_ntab, 1u); if (k < (uint32_t)WG_TAB_PAIRS) reinterpret_cast<uint2 *>(tab + 4)[k] = make_uint2(T.key[h], T.val[h]); }
             __syncthreads();
-            if (tid == 0) tab[0] = s_ntab <= (uint32_t)WG_TAB_PAIRS ? s_ntab : ~0u;
+            if (tid == 0) {
+                tab[0] = s_ntab <= (uint32_t)WG_TAB_PAIRS ? s_ntab : ~0u;
+                if (s_ntab > (uint32_t)WG_TAB_PAIRS) __hip_atomic_fetch_add(&a.st->n_recount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     } else {
         bool pass = false, serial = false;

@@ -102,7 +102,8 @@ int c3r_set_sites(c3r_ctx *ctx, const int32_t *sites, int64_t n);
  * site records stay resident on the device.  Returns the number of emitted candidates.
  * max_depth (samtools mpileup -d, default 8000): htslib's rule — a read that is not the first one pushed for its start
  * position is discarded while more than max_depth reads are live — is applied per region before the walk.
- * C3R_EOVERFLOW when more than 32,767 kept reads cover one position (only with the cap off or raised: the resident windows are int16). */
+ * A scan that meets a position covered by more than 32,767 kept reads (only with the cap off or raised) is repeated with 32-bit resident windows,
+ * which the context keeps from then on; C3R_EOVERFLOW only when the batch already holds 16-bit windows. */
 int c3r_pileup_scan(c3r_ctx *ctx, int64_t ctg_start, int64_t ctg_end, int64_t *n_candidates);
 /* The same for several regions (the chunks of one contig) in ONE set of kernel launches: results are exactly those of
  * n_regions successive c3r_pileup_scan calls in batch mode — candidates of region 0 first, each region with its own

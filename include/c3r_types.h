@@ -63,8 +63,10 @@ typedef struct c3r_params {
     int32_t  max_depth;       /* samtools mpileup -d: reads beyond this many live reads are discarded (htslib's
                                  rule, see c3r_pileup_scan); default 8000 = mpileup's own default, which the reference
                                  leaves in force (src/create_tensor_pileup.py:442); 0 = no cap.  The resident windows are
-                                 16-bit: a scan in which more than 32,767 kept reads cover one position fails with
-                                 C3R_EOVERFLOW (cannot happen at the default cap)                                 */
+                                 16-bit until a scan meets a position that more than 32,767 kept reads cover (cannot
+                                 happen at the default cap): that scan is repeated with 32-bit windows, which the context
+                                 keeps from then on; only a BATCH that already holds 16-bit windows fails there
+                                 (C3R_EOVERFLOW: scan the deep region first, or alone)                              */
     int32_t  mpileup_compat;  /* which samtools the column text is restated from (run_clair3_rna:159,166 only sets a floor of 1.10):
                                  0 = samtools <= 1.10 (default): an I immediately followed by a D shows the insertion only (`C+2TT`);
                                  1 = samtools >= 1.11 (bam_plp_insertion): it shows both (`C+2TT-1N`), which the reference's parser

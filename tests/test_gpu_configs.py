@@ -187,31 +187,66 @@ def test_phased_scan_builds_the_ordered_recompute_tables_only_when_a_column_need
         e.close()
 
 
-def test_a_position_covered_by_more_than_32767_reads_is_refused_not_wrapped(eng):
+def test_a_position_covered_by_more_than_32767_reads_takes_32_bit_windows():
     """The resident windows are int16 (a count never exceeds the reads that cover its position).  Without mpileup's depth cap a locus can be
-    covered by more reads than that: the scan fails with a message instead of wrapping a count; with the cap in force (the reference's own
-    configuration, 8000) the same reads go through."""
-    from clair3_rna_amd import capi
+    covered by more reads than that: the scan is repeated with int32 windows (the context keeps them), lines, tensors and probabilities
+    equal the oracle's; a BATCH that already holds 16-bit windows refuses such a scan instead of wrapping a count; with the cap in force
+    (the reference's own configuration, 8000) the same reads stay on 16-bit windows."""
+    from clair3_rna_amd import capi, synth
     from clair3_rna_amd.reads import ReadSet
+    from oracle import oracle as orc
     import random
     rng = random.Random(5)
     ref = "".join(rng.choice("ACGT") for _ in range(400))
     seq = ref[100:160]
     recs = [dict(pos=100, cigar="60M", seq=seq[:30] + ("T" if seq[30] != "T" else "G") + seq[31:] if i % 3 == 0 else seq, flag=16 * (i % 2)) for i in range(33000)]
     rs = ReadSet.from_records(recs)
-    eng.params = capi.default_params()
-    eng.set_bed(0, None); eng.set_bed(1, None)
-    eng.set_params(max_depth=0)
-    eng.load_reads(rs)
-    eng.set_reference(1, ref)
-    with pytest.raises(capi.C3RError, match="32,767 reads"):
-        eng.scan(1, len(ref))
-    eng.set_params(max_depth=8000)
-    eng.load_reads(rs)
-    n = eng.scan(1, len(ref))
-    s = eng.sites()
-    assert n >= 1 and 131 in s["pos"].tolist()
-    X = eng.tensors()
-    assert X.dtype == np.int32 and np.abs(X).max() <= 216 and int(s["depth"][s["pos"].tolist().index(131)]) == 8000
-    eng.params = capi.default_params()
-    eng.set_params()
+    shallow = ReadSet.from_records([dict(pos=250, cigar="60M", seq=ref[250:280] + ("A" if ref[280] != "A" else "C") + ref[281:310], flag=16 * (i % 2)) for i in range(12)])
+    w = synth.random_weights(18)
+    e = capi.Engine(0)
+    try:
+        e.set_params(max_depth=8000)
+        got = H.engine_chunk(e, rs, ref, 1, 1, len(ref))
+        s = got["sites"]
+        assert got["n"] >= 1 and 131 in s["pos"].tolist() and int(s["depth"][s["pos"].tolist().index(131)]) == 8000 and np.abs(got["X"]).max() <= 216
+        # a batch that holds 16-bit windows cannot take the deep scan behind them
+        e.set_params(max_depth=0)
+        both = H.merge_readsets(rs, shallow)
+        e.load_reads(both)
+        e.begin_batch()
+        assert e.scan(240, 330) >= 1
+        with pytest.raises(capi.C3RError, match="32,767 reads"):
+            e.scan(90, 170)
+        e.end_batch()
+        # alone, the scan goes through on 32-bit windows
+        got = H.engine_chunk(e, rs, ref, 1, 1, len(ref))
+        exp = H.oracle_chunk(rs, ref, 1, 1, len(ref), max_depth=0)
+        assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
+        assert np.array_equal(got["X"], exp["X"])
+        assert got["raw"].min() < -16000 and int(exp["depth"].max()) == 33000
+        e.load_weights(w, 18)
+        probs = e.infer()
+        assert float(np.abs(probs - orc.forward(w, exp["X"])).max()) < 1e-4
+        # ... and the context stays on them: a shallow scan afterwards is still exact
+        got2 = H.engine_chunk(e, shallow, ref, 1, 1, len(ref))
+        exp2 = H.oracle_chunk(shallow, ref, 1, 1, len(ref), max_depth=0)
+        assert got2["lines"] == exp2["lines"] and np.array_equal(got2["X"], exp2["X"])
+    finally:
+        e.close()
+
+
+def test_realistic_expression_slice_matches_the_oracle(eng):
+    """bench.py's `realistic_expr` workload on a 3-Mb slice: log-normal gene expression over four to five decades — loci in the thousands
+    (k_fused_deep's spans) beside one-to-three-read islands that emit nothing (src/create_tensor_pileup.py:512-516, :551-560) — bit-exact
+    against the oracle."""
+    from clair3_rna_amd import synth
+    L = 3000000               # (this seed puts a locus in the thousands into the slice)
+    ref, rs, info = synth.generate_contig(contig_len=L, seed=synth.SEED + 16, depth=20.0, expr_sigma=2.3, max_level=12000.0)
+    ref = ref.decode()
+    _fresh(eng)
+    got = H.engine_chunk(eng, rs, ref, 1, 1, L)
+    exp = H.oracle_chunk(rs, ref, 1, 1, L)
+    d = exp["depth"]
+    assert len(exp["lines"]) > 500 and d.max() > 1000 and (d < 8).any(), (len(exp["lines"]), int(d.max()), int(d.min()))
+    assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
+    assert np.array_equal(got["X"], exp["X"])

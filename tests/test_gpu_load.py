@@ -271,3 +271,44 @@ def test_a_two_stream_context_computes_the_same(eng, monkeypatch):
         assert res[0][0] > 100 and res[0] == res[1]
     finally:
         two.close()
+
+
+def test_long_reads_far_apart_take_the_recount_path_of_the_second_pass(eng):
+    """k_prep<false> hands each workgroup's bin table to k_prep<true> through a 4-KB slab (510 bins); sixteen long reads that share no bin
+    need more (16 x 41 bins), so the second pass counts theirs again.  The profiler's statistics say that the path ran; lines and tensors
+    equal the oracle's."""
+    import random
+    from clair3_rna_amd import capi
+    from clair3_rna_amd.reads import ReadSet
+    from tests import helpers as H
+    rng = random.Random(11)
+    pitch, rlen, n_loci, n_lone = 4000, 1300, 12, 48
+    L = (n_loci + n_lone) * pitch + 3000
+    ref = "".join(rng.choice("ACGT") for _ in range(L))
+    recs = []
+    for i in range(n_loci):                          # loci of five reads with the same mismatches: candidates above the coverage gate
+        for rep in range(5):
+            p0 = 500 + i * pitch + rep * 3
+            seq = list(ref[p0:p0 + rlen])
+            for q in range(60 - rep * 3, rlen, 97):
+                seq[q] = "A" if ref[p0 + q] != "A" else "C"
+            recs.append(dict(pos=p0, cigar="%dM" % rlen, seq="".join(seq), flag=16 * (rep % 2)))
+    for i in range(n_lone):                          # ... and lone long reads, one per 4 kb: sixteen of them make a workgroup of 16 x 41 bins
+        p0 = 500 + (n_loci + i) * pitch
+        recs.append(dict(pos=p0, cigar="%dM" % rlen, seq=ref[p0:p0 + rlen], flag=0))
+    recs.sort(key=lambda r: r["pos"])
+    rs = ReadSet.from_records(recs)
+    eng.params = capi.default_params()
+    eng.set_bed(0, None); eng.set_bed(1, None)
+    eng.set_params(min_coverage=2)
+    eng.set_profiling(True); eng.reset_kernel_stats()
+    got = H.engine_chunk(eng, rs, ref, 1, 1, len(ref))
+    ks = eng.kernel_stats()
+    eng.set_profiling(False)
+    assert ks.get("k_prep_recount_workgroups", {}).get("launches", 0) >= 2, sorted(ks)
+    exp = H.oracle_chunk(rs, ref, 1, 1, len(ref), min_coverage=2)
+    assert len(exp["lines"]) > 100
+    assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
+    assert np.array_equal(got["X"], exp["X"])
+    eng.params = capi.default_params()
+    eng.set_params()

@@ -351,3 +351,39 @@ def test_depth_cap_between_separate_deep_loci(eng):
     assert n_changed == 2                                  # the cap bit at both settings
     eng.params = capi.default_params()
     eng.set_params()
+
+
+def test_bench_eight_ranks_strong_scaling_on_one_gpu():
+    """`bench.py --gpus 8 --scaling strong` as the driver would launch it on an 8-GPU node, with the one-GPU test hook (eight gloo ranks share
+    the box's device): the 24 contigs are dealt to eight ranks without loss or overlap, the summed sites equal the N = 1 run's over the
+    same contigs, and eight ranks' resident contexts together stay far below one device's memory (each rank of a real node has a device
+    to itself).  Readiness for the 8-GPU curve nobody has been able to measure (run_clair3_rna:441-449,681-706)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(n):
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, C3R_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        tail = ["bench.py", "--gpus", str(n), "--scaling", "strong", "--genome_scale", "0.02", "--steps", "1", "--warmup", "0"]
+        cmd = ([sys.executable] if n == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                                                "--master-port", str(port)]) + tail
+        r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+    j8, j1 = run(8), run(1)
+    c8, c1 = j8["config"], j1["config"]
+    assert j8["n_gpus"] == 8 and j8["scaling"] == "strong" and j1["n_gpus"] == 1
+    assert sum(c8["contigs_per_rank"]) == 24 and min(c8["contigs_per_rank"]) >= 1 and len(c8["contigs_per_rank"]) == 8
+    assert sum(c8["bp_per_rank"]) == c8["genome_bp"] == c1["genome_bp"]
+    assert c8["sites_per_step"] == c1["sites_per_step"] > 0                   # the same contigs, whoever holds them
+    assert c8["lpt_imbalance"] < 1.35 and c8["read_imbalance"] < 1.5
+    assert 0 < c8["hbm_in_use_bytes_max_rank"] < 64e9                         # eight ranks' contexts on ONE device
+    assert c8["pinned_input_bytes_max_rank"] > 0

@@ -91,7 +91,7 @@ def test_alt_info_from_tokens_matches_oracle_columns():
         if tok:
             toks[k] = tok
             k += 1
-    alt, depth = altinfo.alt_dict_from_tokens(toks[:k], rs, ref, 1, pos)
+    alt, depth = altinfo.alt_dict_from_tokens(toks[:k], rs, ref, 1, pos, depth=altinfo.COUNT_DEPTH)
     o = orc.generate_tensor(rows[pos], ref[pos - 1], pos, ref, 1)
     assert [[a, b] for a, b in alt.items()] == o["alt"] and depth == o["depth"]
 

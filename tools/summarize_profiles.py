@@ -53,6 +53,12 @@ def main():
     tag = sys.argv[2] if len(sys.argv) > 2 else "r1_end"
     src = os.path.join(ROOT, "gpurun_out", "prof", prec)
     out = os.path.join(ROOT, "profiles")
+    # which build the run was: the commit the profiles were taken at (argv[3]; default: HEAD of this checkout — the box runs a snapshot of the tree)
+    commit = sys.argv[3] if len(sys.argv) > 3 else os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "unknown"
+    dirty = os.popen("git -C %s status --porcelain -- clair3_rna_amd bench.py 2>/dev/null" % ROOT).read().strip()
+    stamp = "# build: commit %s%s\n" % (commit, " + uncommitted changes" if dirty else "")
+    cal = ("# (the --stats averages of the network kernels include ONE 2,048-window calibration launch each, made by c3r_load_weights' precision guard before the passes:\n"
+           "#  read MaxNs for a full launch, or %s_last_pass_%s.csv, which holds one pass without it)\n" % (tag, prec))
     # 1. kernel stats
     st = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if st:
@@ -60,13 +66,13 @@ def main():
         open(os.path.join(out, "%s_kernel_stats_%s.csv" % (tag, prec)), "w").write(
             "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
             "--no_fast --no_resident --no_overlap --no_strong --precision %s   (MI355X; durations in ns; one context: 1 priming + 1 warm-up + 2 timed passes, "
-            "c3r_load_reads inside every pass)\n" % prec + text)
+            "c3r_load_reads inside every pass)\n" % prec + stamp + cal + text)
     sx = sorted(glob.glob(os.path.join(src, "stats_extra", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if sx:
         open(os.path.join(out, "%s_kernel_stats_extra_%s.csv" % (tag, prec)), "w").write(
             "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
             "--no_fast --no_resident --no_overlap --no_strong --precision %s   (MI355X; ns): the chr20 passes AND the additional configurations "
-            "(phased_1gpu: the <30> instantiations; stress_500x; depth_cap_20000x), one context each\n" % prec + open(sx[-1]).read())
+            "(phased_1gpu: the <30> instantiations; stress_500x; depth_cap_20000x; realistic_expr), one context each\n" % prec + stamp + cal + open(sx[-1]).read())
     # 1b. the LAST pass of the same trace, kernel by kernel (the --stats averages above include the first pass, which sizes the buffers
     # with a tile kernel that stops early and then repeats it): a pass starts at its k_prep<false> launch
     tr = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
@@ -81,7 +87,7 @@ def main():
                 per[k] = (n + 1, t + b - a)
             net = ("k_lstm1", "k_lstm2", "k_heads_mfma", "k_heads", "k_fc4")
             with open(os.path.join(out, "%s_last_pass_%s.csv" % (tag, prec)), "w") as f:
-                f.write("# the last timed pass of the trace behind %s_kernel_stats_%s.csv: every launch from its k_prep<false> on (ns)\n" % (tag, prec))
+                f.write("# the last timed pass of the trace behind %s_kernel_stats_%s.csv: every launch from its k_prep<false> on (ns)\n" % (tag, prec) + stamp)
                 f.write("kernel,launches,total_ns\n")
                 for k, (n, t) in per.items():
                     f.write("%s,%d,%d\n" % (k, n, t))
@@ -97,7 +103,7 @@ def main():
     hdr = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]
     traffic = {}
     with open(os.path.join(out, "%s_pmc_%s.csv" % (tag, prec)), "w") as f:
-        f.write("# rocprofv3 --pmc <set> --kernel-trace, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), same bench command; per-launch medians.\n"
+        f.write(stamp + "# rocprofv3 --pmc <set> --kernel-trace, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), same bench command; per-launch medians.\n"
                 "# hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024: FETCH_SIZE reports half of the bytes fetched on gfx950 (MI355X_MICROARCH.md; calibrated on this path's own access patterns by tools/hbm_calib.hip, profiles/r4/hbm_counter_calibration.txt); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                 "(1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); clock_GHz needs the kernel duration and is quoted in DESIGN.md.\n")
         f.write("kernel,launches," + ",".join(hdr) + ",hbm_bytes_per_launch,mfma_busy\n")
