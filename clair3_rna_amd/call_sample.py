@@ -398,37 +398,49 @@ def Run(args, log=None):
 
     weights = io.load_weights(model, channels)
     n_ctx = max(1, args.contexts)
-    engines = []
+    engines = [None] * n_ctx
+    engine_ready = [threading.Event() for _ in range(n_ctx)]
+    engine_errs = []
+    engine_threads = []
 
     def make_engines():
-        """The GPU contexts: created, given the weights and the arithmetic once the first fetches are under way (0.1-0.2 s that
-        used to come before the first BAM byte was read)."""
-        for _ in range(n_ctx):
-            t0_ = time()
-            engines.append(capi.Engine(args.gpu_id))
-            mark("ctx%d" % (len(engines) - 1), "create", t0_)
-        errs = []
-
-        def prepare(e):
+        """The GPU contexts: created, given the weights and the arithmetic once the first fetches are under way (0.1-0.2 s that used to come
+        before the first BAM byte was read).  Each context on a thread of its own: context 0 takes the first contig the moment IT is ready
+        — HIP start-up and its own weights, 0.2 s in a fresh process — while the others' weights are still being packed (they are not needed
+        before the second contig has been fetched).  Returns at once; context_worker waits for its engine."""
+        def bring_up(k):
             try:
+                if k > 0:
+                    # (the process' first c3r_create starts HIP, and two contexts that pack and calibrate their weights at once take twice as long
+                    # each: context 0 first — it is the one the first contig waits for —, the others are ready long before their contig is fetched)
+                    engine_ready[0].wait()
+                t0_ = time()
+                e = capi.Engine(args.gpu_id)
+                engines[k] = e
+                mark("ctx%d" % k, "create", t0_)
                 t0_ = time()
                 e.load_weights(weights, channels)             # (packing the weights into the kernels' layouts is host work: side by side)
-                mark("ctx%d" % engines.index(e), "weights", t0_)
+                mark("ctx%d" % k, "weights", t0_)
                 t0_ = time()
                 e.set_precision(args.gpu_precision)
-                mark("ctx%d" % engines.index(e), "precision", t0_)
+                mark("ctx%d" % k, "precision", t0_)
+                if k == 0 and args.gpu_precision != "f16x3":
+                    log("[INFO] network arithmetic: %s -> %s (calibration max |dP| %s)" % ((args.gpu_precision,) + tuple(e.precision())))
             except BaseException as ex:
-                errs.append(ex)
-        th = [threading.Thread(target=prepare, args=(e,)) for e in engines[1:]]
-        for t_ in th:
+                engine_errs.append(ex)
+            finally:
+                engine_ready[k].set()
+        for k in range(n_ctx):
+            t_ = threading.Thread(target=bring_up, args=(k,), name="c3r-bringup%d" % k, daemon=True)
+            engine_threads.append(t_)
             t_.start()
-        prepare(engines[0])
-        for t_ in th:
-            t_.join()
-        if errs:
-            raise errs[0]
-        if args.gpu_precision != "f16x3":
-            log("[INFO] network arithmetic: %s -> %s (calibration max |dP| %s)" % ((args.gpu_precision,) + tuple(engines[0].precision())))
+
+    def engine_of(k):
+        """Context k's engine, once it is up (raises what its bring-up raised)."""
+        engine_ready[k].wait()
+        if engine_errs:
+            raise engine_errs[0]
+        return engines[k]
     qual_rows = args.qual if args.qual is not None else 2              # call_variants.py:1827 (STEP 1 never passes --qual)
     qual_merge = args.qual if args.qual is not None else 2             # sort_vcf's own default
     header = vcf.header(args.ref_fn, cmd_fn, args.sample_name) + "\n"
@@ -642,7 +654,15 @@ def Run(args, log=None):
         """Thread of context k: contigs from the shared queue until the end marker, then — once the decodes that still read this
         context's snapshots are through — the context is released: device and page-locked memory go back while the last contigs
         are still being decoded and written."""
-        eng = engines[k]
+        try:
+            eng = engine_of(k)
+        except BaseException as e:           # the bring-up failed: every contig this worker takes fails with that
+            while True:
+                item = ctx_queue.get()
+                if item is None:
+                    return
+                if item[2].set_running_or_notify_cancel():
+                    item[2].set_exception(e)
         if reserve_sites and hasattr(eng, "reserve"):
             # the network's buffers (8.9 GB for a full slice: 0.25-0.4 s of a first hipMalloc) while the first fetch is under way
             t0 = time()
@@ -804,11 +824,17 @@ def Run(args, log=None):
         if merger is not None:
             merger.discard()             # no truncated output.vcf.gz (without EOF block) beside a stale .tbi
         if world == 1:
+            for t_ in engine_threads:
+                t_.join()
             for e_ in engines:
-                e_.close()
+                if e_ is not None:
+                    e_.close()
             raise
+    for t_ in engine_threads:
+        t_.join()
     for e in engines:
-        e.close()
+        if e is not None:
+            e.close()
     if world > 1:
         import json
         with open(os.path.join(parts_dir, "rank%d.json" % rank), "w") as f:

@@ -67,6 +67,7 @@ struct c3r_ctx {
     // k_fused_deep runs BESIDE k_fused_tiles on its own stream (created at the first fused scan), forked and joined by two events
     hipStream_t deep_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_up = nullptr;            // c3r_load_reads: "my uploads have landed" (the per-device upload gate)
 
     // ---- inputs: the device holds the read tables; host copies are fetched on demand (depth cap, decode)
     int32_t n_reads = 0;                   // of the loaded contig
@@ -452,6 +453,10 @@ static std::mutex &upload_gate(int device) {
     static std::mutex gates[64];
     return gates[(unsigned)device % 64u];
 }
+static std::atomic<int> &upload_waiters(int device) {          // contexts parked at the gate: whoever holds it lets go as soon as its copies have landed
+    static std::atomic<int> w[64];
+    return w[(unsigned)device % 64u];
+}
 
 int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing, std::unique_lock<std::mutex> *gate = nullptr) {
     int rc;
@@ -716,6 +721,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     if (ctx->deep_stream) (void)hipStreamDestroy(ctx->deep_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_up) (void)hipEventDestroy(ctx->ev_up);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->net_stream) (void)hipStreamDestroy(ctx->net_stream);
@@ -773,13 +779,22 @@ int c3r_load_reads(c3r_ctx *ctx, const c3r_read_t *reads, int64_t n_reads, const
     // c3r_host_alloc) and every table the tile kernels need is derived from them on the device
     if ((rc = ensure(ctx, ctx->d_rawreads, std::max<size_t>((size_t)n * sizeof(c3r_read_t), 16))) || (rc = ensure(ctx, ctx->d_rawcig, std::max<size_t>((size_t)n_cigar_ops * 4, 16))) ||
         (rc = ensure(ctx, ctx->d_seq, (size_t)n_seq_bytes + 16))) return rc;
+    upload_waiters(ctx->device).fetch_add(1);
     std::unique_lock<std::mutex> gate(upload_gate(ctx->device));
+    upload_waiters(ctx->device).fetch_sub(1);
     {
         Launch l(ctx, "h2d_reads");           // (profiling: the three uploads as one entry of the kernel statistics — PCIe time, not a kernel)
         if ((rc = upload(ctx, ctx->d_rawreads, reads, (size_t)n)) || (rc = upload(ctx, ctx->d_rawcig, cigars, (size_t)n_cigar_ops))) return rc;
         if (n_seq_bytes && (rc = big_h2d(ctx, ctx->d_seq.p, seq4, (size_t)n_seq_bytes))) return rc;
     }
     HIPCHK(ctx, hipMemsetAsync((char *)ctx->d_seq.p + n_seq_bytes, 0, 16, ctx->stream));        // (the walk reads the packed bases 16 bytes at a time)
+    if (upload_waiters(ctx->device).load() > 0) {
+        // another context is waiting to upload: the link is handed over when THESE copies are through, not a first table pass later
+        if (!ctx->ev_up) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_up, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_up, ctx->stream));
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev_up));
+        gate.unlock();
+    }
     ctx->n_seq_bytes = n_seq_bytes; ctx->n_cigar_ops = n_cigar_ops;
     if (n == 0) return C3R_OK;
     ctx->first_pos = std::max(reads[0].pos, 0);
