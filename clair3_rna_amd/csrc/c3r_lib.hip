@@ -1916,6 +1916,13 @@ int c3r_infer(c3r_ctx *ctx, const int32_t *tensors, int64_t n, float *probs) {
         d_x = ctx->d_raw.p;
     }
     if (n == 0) return C3R_OK;
+    {
+        // layer 1 addresses a window by a 32-bit element index (k_lstm1_rs): the rows it can be asked for — the resident windows' row space, or the
+        // caller's batch — must stay below 2^32 / (33 * channels) = 7.2 M rows at 18 channels (a GRCh38 chromosome holds one to two million candidates)
+        const int64_t rows = tensors == nullptr ? std::max<int64_t>(ctx->n_rows, n) : n;
+        if ((uint64_t)rows * (uint64_t)(C3R_WINDOW * C) >= (1ull << 32))
+            return fail(ctx, C3R_EINVAL, "%lld window rows of %d channels exceed the network's 32-bit row addressing: call c3r_infer on smaller batches", (long long)rows, C);
+    }
     std::string e;
     if (ctx->net.d_tmo) HIPCHK(ctx, hipMemsetAsync(ctx->net.d_tmo, 0, 4, ctx->stream));     // (a time-out fails the batch it happened in, not the ones after it)
     // the network's kernels go to the context's default-priority stream, behind everything queued on `stream` so far (the tensors, an

@@ -1083,17 +1083,17 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const void *__restrict__ xin_
     typedef int int2v __attribute__((ext_vector_type(2)));
     int2v xr = {0, 0};
     const bool xmine = tid < WG_SITES * NPC;
-    size_t xrow = 0;
+    uint32_t xrow = 0;          // (element index: n * 33 * CIN < 2^32 — the host checks)
     if (xmine) {
         int sj = site0 + tid / NPC;
         if (sj >= n) sj = n - 1;
         if (row_idx) sj = row_idx[sj];
-        xrow = (size_t)sj * NET_T * CIN + 2 * (tid % NPC);
+        xrow = (uint32_t)sj * (uint32_t)(NET_T * CIN) + 2u * (uint32_t)(tid % NPC);
     }
     auto x_fetch = [&](int tt_) {
         if (xmine) {
-            if (x16) { const int pr = *(const int *)(xin16 + xrow + (size_t)tt_ * CIN); xr[0] = (int)(int16_t)(pr & 0xffff); xr[1] = pr >> 16; }
-            else xr = *(const int2v *)(xin + xrow + (size_t)tt_ * CIN);
+            if (x16) { const int pr = *(const int *)(xin16 + (size_t)(xrow + (uint32_t)(tt_ * CIN))); xr[0] = (int)(int16_t)(pr & 0xffff); xr[1] = pr >> 16; }
+            else xr = *(const int2v *)(xin + (size_t)(xrow + (uint32_t)(tt_ * CIN)));
         }
     };
     auto x_store = [&](int buf) {
@@ -1119,9 +1119,10 @@ __global__ __launch_bounds__(1024) void k_lstm1_rs(const void *__restrict__ xin_
     for (int step = 0; step < NET_T; ++step) {
         const int t = dir ? NET_T - 1 - step : step;
         const int cur = step & 1, nxt = cur ^ 1;
-        if (step + 1 < NET_T) x_fetch(dir ? NET_T - 2 - step : step + 1);       // lands under the K loops
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
+            // x_{t+1}: requested when the second block starts — it lands under that block's K loop, and its two registers are not alive under the first
+            if (sb == 1 && step + 1 < NET_T) x_fetch(dir ? NET_T - 2 - step : step + 1);
             floatx16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
