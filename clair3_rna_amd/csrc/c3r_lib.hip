@@ -1127,6 +1127,7 @@ static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int d
     if (ctx->padins && !ctx->padins->empty()) { a.padins = (const c3r_padins_t *)ctx->d_padins.p; a.n_padins = (int32_t)ctx->padins->size(); }
     { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
     { const char *e = getenv("C3R_DEEP_MIN"); a.deep_min = e ? std::max(1, atoi(e)) : DEEP_MIN_RECORDS; }
+    { const char *e = getenv("C3R_NO_SHIFT"); a.no_shift = (e && *e == '1') ? 1 : 0; }
 }
 
 static int scan_column_store(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts, const int64_t *ctg_ends, int64_t *n_candidates, bool columns_only);
@@ -1397,7 +1398,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     // rows), 256 bytes apart; then look-back words: one per block of 256 spans for k_tile_ranges_fused, then the same for k_order_spans
     const size_t lb_alloc = 64 + (size_t)TICKET_Q * TICKET_STRIDE * 4;
     const size_t lb_head = lb_alloc + (size_t)ALLOC_SHARDS * ALLOC_STRIDE * 8;
-    const size_t lb_bytes = lb_head + (size_t)nblk * 16;
+    const size_t lb_bytes = lb_head + (size_t)nblk * 24;         // (look-back words: k_tile_ranges_fused' sums, k_order_spans', k_tile_ranges_fused' run starts)
     if ((rc = ensure(ctx, ctx->d_ev, ev_cap * sizeof(EvRec))) || (rc = ensure(ctx, ctx->d_lb, lb_bytes)) || (rc = ensure(ctx, ctx->d_tile_rng, (size_t)n_tiles * 16 + 16)) ||
         (rc = ensure(ctx, ctx->d_tile_list, (size_t)n_tiles * 4 + 16)) ||
         (rc = ensure(ctx, ctx->d_span, (size_t)n_tiles * sizeof(int4) + 16)) || (rc = ensure(ctx, ctx->d_spanbase, (size_t)n_tiles * 4 + 16)) ||
@@ -1487,7 +1488,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         {
             Launch L(ctx, "k_tile_ranges");
             hipLaunchKernelGGL(k_tile_ranges_fused, dim3(nblk), dim3(256), 0, ctx->stream, a, (int32_t *)lb, (unsigned long long *)(lb + lb_head), nblk, (const int2 *)ctx->d_regb.p,
-                               (SpanRec *)ctx->d_spanrec.p, (int32_t *)ctx->d_deep.p, (int32_t *)(lb + 44));
+                               (SpanRec *)ctx->d_spanrec.p, (int32_t *)ctx->d_deep.p, (int32_t *)(lb + 44), (unsigned long long *)(lb + lb_head + (size_t)nblk * 16));
         }
         // the deep spans k_fused_tiles leaves out go to k_fused_deep: one workgroup of sixteen wavefronts per CU, spans by ticket (no deep span: the
         // workgroups leave at once).  The two kernels share nothing but the allocators and run side by side, the deep one on its own stream; under

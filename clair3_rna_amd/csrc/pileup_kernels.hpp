@@ -27,6 +27,7 @@
 namespace c3r {
 
 constexpr int TILE = 256;      // reference positions per workgroup
+constexpr int FUSE_IN = TILE - 2 * C3R_FLANK;     // 224: the positions of a fused span that can be candidates (k_fused_tiles)
 constexpr int SCAN_THREADS = 256;
 constexpr int WAVES = SCAN_THREADS / 64;
 
@@ -157,7 +158,8 @@ struct ScanArgs {
     int32_t n_tiles;
     int32_t head_tail;            // last_row (end of the row stream) is only needed for the head/tail flush rule
     int32_t abl;                  // timing-only ablation bits (env C3R_SCAN_ABL, 0 in production)
-    int32_t deep_min;             // a tile whose record range holds at least this many records takes the position-major walk (walk_columns); env C3R_DEEP_MIN
+    int32_t deep_min;             // a span whose record range holds at least this many records is left to k_fused_deep; env C3R_DEEP_MIN
+    int32_t no_shift;             // env C3R_NO_SHIFT: spans stay on the regions' fixed grid (k_tile_ranges_fused)
     unsigned long long *dbg;      // null in production; env C3R_SCAN_DBG: per-phase wall-clock sums of k_scan_tiles' heavy tiles (100 MHz ticks)
     const uint8_t *ref;           // upper-cased reference slice
     int32_t ref_beg0;             // 0-based position of ref[0]
@@ -649,6 +651,35 @@ __device__ __forceinline__ unsigned long long lb_lookback(unsigned long long *st
     return excl;
 }
 
+// The same look-back with MAX for +: the largest payload among the entries before b (0: none).
+__device__ __forceinline__ unsigned long long lb_lookback_max(unsigned long long *state, int b, unsigned long long mine) {
+    const int lane = (int)(threadIdx.x & 63);
+    constexpr unsigned long long PAY = 0x3fffffffffffffffull;
+    unsigned long long excl = 0;
+    if (b > 0) {
+        if (lane == 0) lb_store(&state[b], (1ull << 62) | mine);
+        for (int top = b - 1; top >= 0; top -= 64) {
+            const int i = top - lane;
+            unsigned long long w = 0;
+            bool incl_found = false;
+            for (;;) {
+                w = i >= 0 ? lb_load(&state[i]) : (2ull << 62);
+                const unsigned long long not_ready = __ballot((w >> 62) == 0), incl = __ballot((w >> 62) == 2);
+                const int first_incl = incl ? __ffsll((long long)incl) - 1 : 64;
+                const unsigned long long need = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
+                if (!(not_ready & need)) { incl_found = incl != 0; w = (lane <= first_incl) ? (w & PAY) : 0ull; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(w, off, 64); w = o > w ? o : w; }
+            excl = w > excl ? w : excl;
+            if (incl_found) break;
+        }
+    }
+    if (lane == 0) lb_store(&state[b], (2ull << 62) | ((excl > mine ? excl : mine) & PAY));
+    return excl;
+}
+
 // The fused path's list of spans (k_fused_tiles): only spans that hold aligned bases, in ASCENDING order (= output order), with the
 // read / record ranges of the span plus C3R_FLANK on either side.  Workgroups take blocks of 256 spans by ticket and place their
 // listed spans behind those of the blocks before them (decoupled look-back over one word per block, as in k_fused_tiles).
@@ -659,8 +690,9 @@ struct SpanRec { int32_t tile, p0, p1, region; int4 rng; int32_t reg_lo, reg_hi,
 static_assert(sizeof(SpanRec) == 48, "SpanRec must be 48 bytes");
 
 __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int32_t *ticket, unsigned long long *rstate, int nblk, const int2 *reg_bounds,
-                                                           SpanRec *span_rec, int32_t *deep_list, int32_t *n_deep) {
+                                                           SpanRec *span_rec, int32_t *deep_list, int32_t *n_deep, unsigned long long *mstate) {
     __shared__ int s_b, s_base, s_cnt[4];
+    __shared__ unsigned s_kmax[4], s_kexcl;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_b = atomicAdd(ticket, 1);
     __syncthreads();
@@ -668,10 +700,55 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
     const int t = b * 256 + tid;
     bool listed = false;
     SpanRec rec;
-    rec.tile = 0;
+    rec.tile = 0; rec.rng = make_int4(0, 0, 0, 0);
+    // ---- spans follow the reads, not a grid.  The tiles of a region are a fixed grid of FUSE_IN positions, and an exon of 150 bp that straddles a
+    // grid line costs two spans (chr20: 20.3 k spans for 12.4 k runs of aligned bases).  So a RUN of tiles — consecutive tiles of a region whose
+    // own record ranges are not empty — is shifted as a whole to the first bin that holds one of its records: every tile of the run starts `shift`
+    // positions later (0 .. FUSE_IN - 1), the run's spans still lie back to back, every covered position still lies in exactly one of them, and the
+    // run's last tile often covers nothing any more (15.3 k spans).  The shift of a tile's run = that of the most recent run start at or before it:
+    // a max-scan over (tile + 1) << 8 | shift of the run starts (block scan + decoupled look-back).
+    TileGeo tg; tg.p0 = 0; tg.p1 = 0; tg.region = 0; tg.pad = 0;
+    bool nonempty = false;
+    unsigned key = 0;
     if (t < a.n_tiles) {
-        const TileGeo tg = a.geo[t];
-        const int t0 = tg.p0, t1 = tg.p1;
+        tg = a.geo[t];
+        if (tg.p1 > tg.p0) {
+            const int4 own0 = span_ranges(a.rec_off, a.rtab, a.bins, tg.p0, tg.p1);
+            nonempty = own0.z < own0.w;
+            if (nonempty && !a.no_shift) {
+                bool prev = false;
+                if (t > 0) {
+                    const TileGeo pg = a.geo[t - 1];
+                    if (pg.region == tg.region && pg.p1 > pg.p0) { const int4 po = span_ranges(a.rec_off, a.rtab, a.bins, pg.p0, pg.p1); prev = po.z < po.w; }
+                }
+                if (!prev) {
+                    int shift = 0;
+                    const int bl = bin_edge(a.bins, (long long)tg.p0 - (OP_CHOP - 1)), bh = bin_edge(a.bins, (long long)tg.p1 - 1);
+                    for (int bb = bl; bb <= bh && bb < a.bins.nb; ++bb)
+                        if (a.rec_off[bb + 1] > a.rec_off[bb]) { shift = min(max(((bb + a.bins.base) << BIN_SHIFT) - tg.p0, 0), FUSE_IN - 1); break; }
+                    key = ((unsigned)(t + 1) << 8) | (unsigned)shift;
+                }
+            }
+        }
+    }
+    // inclusive max over the tiles up to mine
+    unsigned kin = key;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned o = (unsigned)__shfl_up((int)kin, off, 64); if (lane >= off && o > kin) kin = o; }
+    if (lane == 63) s_kmax[wave] = kin;
+    __syncthreads();
+    if (wave == 0) {
+        const unsigned bm = max(max(s_kmax[0], s_kmax[1]), max(s_kmax[2], s_kmax[3]));
+        const unsigned long long ex = lb_lookback_max(mstate, b, (unsigned long long)bm);
+        if (lane == 0) s_kexcl = (unsigned)ex;
+    }
+    __syncthreads();
+    unsigned run = max(kin, s_kexcl);
+    for (int w = 0; w < wave; ++w) run = max(run, s_kmax[w]);
+    if (nonempty) {
+        const int shift = a.no_shift ? 0 : (int)(run & 255u);
+        const int2 rb = reg_bounds[tg.region];
+        const int t0 = tg.p0 + shift, t1 = min(t0 + FUSE_IN, rb.y);
         if (t1 > t0) {
             // a candidate needs aligned bases on its own position, min_cov of them: spans whose own range meets no record — or fewer records than
             // the coverage gate asks reads for (a read shows at most one piece on a position) — are not listed.  Real RNA-seq is full of
@@ -682,7 +759,6 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
                 a.tile_rng[t] = r;
                 listed = r.x < r.y;
                 rec.tile = t; rec.p0 = t0; rec.p1 = t1; rec.region = tg.region; rec.rng = r;
-                const int2 rb = reg_bounds[tg.region];
                 rec.reg_lo = rb.x; rec.reg_hi = rb.y; rec.pad0 = 0; rec.pad1 = 0;
             }
         }
@@ -1918,7 +1994,6 @@ __global__ __launch_bounds__(TILE) void k_phase_recompute(const PhaseArgs a) {
 // token array needs no global order either; c3r_get_tokens exports it in site order.  No count -> scan -> write over flag arrays, no host
 // round trip for sizes: outputs are bounds-checked against the buffers' capacity, and the host learns the totals (and whether
 // anything did not fit: then it grows the buffers and repeats the scan) from the single read-back at the end of the scan.
-constexpr int FUSE_IN = TILE - 2 * C3R_FLANK;     // 224
 #ifndef C3R_TICKET_RUN
 #define C3R_TICKET_RUN 4
 #endif
