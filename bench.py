@@ -188,7 +188,9 @@ def cpu_baseline(rs, ref, weights, contig_len):
         return None
     per_site = (t1 - t0) / n_cpu + (t2 - t1) / n_net                     # seconds per site through both stages
     return dict(value=round(1.0 / per_site, 1), unit="sites/s", cores=cores, kind="port",
-                note="a port of the reference pipeline, not a tuned CPU code: the network leg is a scalar fp32 triple loop "
+                note="(the sample is bounded to ~10 s of text stages + ~5 s of network since round 5 — 256 short regions instead of whole chunks —, so the "
+                     "figure is not comparable with rounds 1-4's 5.5 k) "
+                     "a port of the reference pipeline, not a tuned CPU code: the network leg is a scalar fp32 triple loop "
                      "(%.1f GFLOP/s per core here; TensorFlow/Eigen reach 10-100x that), so this is a baseline to read beside the "
                      "number, never a speed-up denominator" % (47.8e6 * n_net / max(t2 - t1, 1e-9) / cores / 1e9),
                 sample="chr20:1-%d of the same synthetic contig: text mpileup + parse + window driver in %d worker processes, one 125-kb "
