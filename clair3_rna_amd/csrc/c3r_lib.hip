@@ -1501,7 +1501,11 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         };
         if (side) {
             if (!ctx->deep_stream) {
-                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->deep_stream, hipStreamNonBlocking));
+                // (the device's highest priority: the deep spans are the long ones — their sixteen-wavefront workgroups should get their CUs before
+                // k_fused_tiles' small workgroups have filled every CU's LDS, not after)
+                int least = 0, greatest = 0;
+                if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); greatest = 0; }
+                HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->deep_stream, hipStreamNonBlocking, greatest));
                 HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
                 HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
             }

@@ -162,3 +162,44 @@ def test_c_abi_from_plain_c(tmp_path):
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert out.stdout.startswith("ok c3r")
+
+
+def test_phase1_bytes_counts_aligned_and_covered_positions():
+    """bench.phase1_bytes (SURVEY 8d, phase 1): input records + C * 4 B per position with an aligned base or a deletion of a passing read;
+    positions that reads only span with a ref-skip are counted apart; filtered reads count for the input bytes only."""
+    import bench
+    from clair3_rna_amd.reads import ReadSet
+    recs = [dict(pos=100, cigar="10M5D10M100N20M", seq="A" * 40, flag=0, mapq=60),          # aligned 100..124 and 225..244, spans 100..244
+            dict(pos=110, cigar="30M", seq="C" * 30, flag=16, mapq=60),                       # aligned 110..139
+            dict(pos=300, cigar="50M", seq="G" * 50, flag=256, mapq=60),                      # secondary: filtered
+            dict(pos=400, cigar="50M", seq="T" * 50, flag=0, mapq=3)]                         # MAPQ below 5: filtered
+    rs = ReadSet.from_records(recs)
+    b, aligned, covered = bench.phase1_bytes(rs, 18)
+    assert aligned == (140 - 100) + 20 and covered == 245 - 100
+    assert b == rs.reads.nbytes + rs.cigar.nbytes + rs.seq.nbytes + 4 * 18 * aligned
+    empty = ReadSet.from_records([])
+    assert bench.phase1_bytes(empty, 18)[1:] == (0, 0)
+
+
+def test_synth_expression_spread_is_opt_in_and_deterministic():
+    from clair3_rna_amd import synth
+    a = synth.generate_contig(contig_len=400000, seed=11, depth=20.0)
+    b = synth.generate_contig(contig_len=400000, seed=11, depth=20.0, expr_sigma=0.0)
+    assert a[0] == b[0] and np.array_equal(a[1].reads, b[1].reads) and np.array_equal(a[1].cigar, b[1].cigar)      # the default stream is untouched
+    c = synth.generate_contig(contig_len=400000, seed=11, depth=20.0, expr_sigma=2.3, max_level=12000.0)
+    d = synth.generate_contig(contig_len=400000, seed=11, depth=20.0, expr_sigma=2.3, max_level=12000.0)
+    assert np.array_equal(c[1].reads, d[1].reads) and c[2]["n_reads"] != a[2]["n_reads"]
+
+
+def test_third_party_pin_script_harvests_the_known_answer_cases():
+    """tools/pin_third_party.py re-uses the inputs of tests/test_oracle_mpileup.py (and adds the depth-cap case): the harvest needs neither tool."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pin_third_party", os.path.join(root, "tools", "pin_third_party.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    cases = m.harvest_cases()
+    assert len(cases) >= 60 and all(len(c[0]) >= 1 for c in cases)
+    caps = m.cap_cases()
+    assert [len(c[0]) for c in caps] == [8005, 8006] and caps[0][3] == dict(max_depth=8000)

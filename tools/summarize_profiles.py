@@ -57,6 +57,8 @@ def main():
     commit = sys.argv[3] if len(sys.argv) > 3 else os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "unknown"
     dirty = os.popen("git -C %s status --porcelain -- clair3_rna_amd bench.py 2>/dev/null" % ROOT).read().strip()
     stamp = "# build: commit %s%s\n" % (commit, " + uncommitted changes" if dirty else "")
+    stamp += ("# C3R_DEEP_SERIAL=1: k_fused_deep BEHIND k_fused_tiles, so that every traced duration is the kernel's own (in production the two run side by side on two\n"
+              "# streams and a trace shows the deep kernel with the duration of the kernel it waits beside)\n")
     cal = ("# (the --stats averages of the network kernels include ONE 2,048-window calibration launch each, made by c3r_load_weights' precision guard before the passes:\n"
            "#  read MaxNs for a full launch, or %s_last_pass_%s.csv, which holds one pass without it)\n" % (tag, prec))
     # 1. kernel stats
@@ -65,13 +67,13 @@ def main():
         text = open(st[-1]).read()
         open(os.path.join(out, "%s_kernel_stats_%s.csv" % (tag, prec)), "w").write(
             "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
-            "--no_fast --no_resident --no_overlap --no_strong --precision %s   (MI355X; durations in ns; one context: 1 priming + 1 warm-up + 2 timed passes, "
+            "--no_fast --no_f32 --no_resident --no_overlap --no_strong --precision %s   (MI355X; durations in ns; one context: 1 priming + 1 warm-up + 2 timed passes, "
             "c3r_load_reads inside every pass)\n" % prec + stamp + cal + text)
     sx = sorted(glob.glob(os.path.join(src, "stats_extra", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if sx:
         open(os.path.join(out, "%s_kernel_stats_extra_%s.csv" % (tag, prec)), "w").write(
             "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile "
-            "--no_fast --no_resident --no_overlap --no_strong --precision %s   (MI355X; ns): the chr20 passes AND the additional configurations "
+            "--no_fast --no_f32 --no_resident --no_overlap --no_strong --precision %s   (MI355X; ns): the chr20 passes AND the additional configurations "
             "(phased_1gpu: the <30> instantiations; stress_500x; depth_cap_20000x; realistic_expr), one context each\n" % prec + stamp + cal + open(sx[-1]).read())
     # 1b. the LAST pass of the same trace, kernel by kernel (the --stats averages above include the first pass, which sizes the buffers
     # with a tile kernel that stops early and then repeats it): a pass starts at its k_prep<false> launch
