@@ -801,7 +801,8 @@ constexpr int LIST_GRID = 8192;
 
 // LDS of one tile workgroup.  Indel events of a tile stay in LDS when there are at most EV_LDS of them (a 20x ONT tile holds ~100): the
 // first walk captures them as it meets them, and they are bucketed by position without a second walk over the records; deeper tiles
-// walk again and bump-allocate global scratch.  (30 channels: the accumulators leave no room at four workgroups per CU.)
+// walk again and bump-allocate global scratch.  (30 channels: the accumulators leave no room at four workgroups per CU; a store of 96 events fits and
+// was measured: no faster on the MAS-Seq contig, whose spans hold a dozen events — the second walk is not what its time is.)
 template <int C, int EVL = (C == C3R_CH ? 192 : 0)>
 struct alignas(16) TileMem {
     static constexpr int EV_LDS = EVL;
@@ -869,8 +870,8 @@ __device__ __forceinline__ void tile_zero(TileMem<C, EVL> &M) {
         if (tid == 0) M.misc[0] = 0;
     }
 }
-// NT: threads of the workgroup.  SCAN_THREADS everywhere but in k_fused_deep, whose workgroups of 1024 keep thread tid <-> position t0 + tid for the
-// first TILE threads (`pos_thread`) and put all sixteen wavefronts on everything that goes record by record, read by read or event by event.
+// NT: threads of the workgroup.  SCAN_THREADS everywhere but in k_fused_deep, whose workgroups of DEEP_THREADS keep thread tid <-> position t0 + tid for the
+// first TILE threads (`pos_thread`) and put all twelve wavefronts on everything that goes record by record, read by read or event by event.
 template <int C, bool FUSED = false, int NT = SCAN_THREADS, int EVL = TileMem<C>::EV_LDS>
 __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EVL> &M, int t0, int t1, int pmin, int region, int lo, int hi, int slo, int shi,
                                                 int cand_lo, int cand_hi) {
@@ -2251,7 +2252,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         const int q_next = home;
         const int4 r0 = s_rec[0], rng = s_rec[1], r2 = s_rec[2];
         // a deep span (ScanArgs::deep_min records or more in its range) is left to k_fused_deep, which runs behind this kernel with workgroups of
-        // sixteen wavefronts: the span would keep these four for milliseconds
+        // twelve wavefronts: the span would keep these four for milliseconds
         const bool deep = rng.w - rng.z >= a.deep_min;
         if (tid == 0) t_next = atomicAdd(&f.ticket[q_next * TICKET_STRIDE], 1);
         int b_next = 0;
@@ -2281,19 +2282,24 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
     }
 }
 
-// The deep spans of the list (ScanArgs::deep_min records or more in their range), one at a time per workgroup of DEEP_THREADS = sixteen
-// wavefronts, one workgroup per CU.  Everything a span does record by record, read by read or event by event — the walks, the coverage, the
-// event buckets, the window copy, the token pass — runs on all sixteen; the per-position steps on the first four (tile_columns, `pos_thread`).
+// The deep spans of the list (ScanArgs::deep_min records or more in their range), one at a time per workgroup of DEEP_THREADS = 768 threads =
+// twelve wavefronts, one workgroup per CU.  Everything a span does record by record, read by read or event by event — the walks, the coverage, the
+// event buckets, the window copy, the token pass — runs on all twelve; the per-position steps on the first four (tile_columns, `pos_thread`).
 // A span's time at depth is rounds x memory latency while its workgroup has the CU to itself and LDS-atomic throughput once the CU is full (a
-// wavefront's 30 atomic adds per round cost ~9 LDS cycles each on random banks, 3.8 without conflicts: profiles/r6/lds_atomic_probe.txt): four
-// times the wavefronts are a quarter of the rounds.  With one workgroup per CU the LDS holds DEEP_EV_LDS captured events: up to there a span's
+// wavefront's 30 atomic adds per round cost ~9 LDS cycles each on random banks, 3.8 without conflicts: profiles/r6/lds_atomic_probe.txt): three
+// times the wavefronts are a third of the rounds.  (Sixteen wavefronts are 8-12 % faster still at depth but leave the span body 128 registers, which
+// it overruns by 20 bytes of scratch per lane; with twelve it has 168 and no kernel of the tensor build touches scratch.)
+// With one workgroup per CU the LDS holds DEEP_EV_LDS captured events: up to there a span's
 // alleles are counted out of LDS as in the shallow kernel, without the second walk and the global hash table of the deeper ones.
-constexpr int DEEP_THREADS = 1024;
+#ifndef C3R_DEEP_THREADS
+#define C3R_DEEP_THREADS 768
+#endif
+constexpr int DEEP_THREADS = C3R_DEEP_THREADS;      // 768 = twelve wavefronts, three per SIMD: 168 registers each, which the span body fits without scratch (1024: 128 + 20 B)
 constexpr int DEEP_EV_LDS = 3072;
 constexpr int DEEP_EVG_CAP = 49152;      // events of a span that a workgroup's global buffer holds (ScanArgs::ev_wg): a span at mpileup's depth cap has ~34 k
 struct DeepArgs { const int32_t *list; const int32_t *n_list; int32_t *ticket; };
 template <int C>
-__global__ __launch_bounds__(DEEP_THREADS, 4) void k_fused_deep(const FusedArgs f, const DeepArgs d) {
+__global__ __launch_bounds__(DEEP_THREADS, DEEP_THREADS / 256) void k_fused_deep(const FusedArgs f, const DeepArgs d) {
     __shared__ TileMem<C, DEEP_EV_LDS> M;
     __shared__ int s_b;
     __shared__ SpanShared S;

@@ -8,8 +8,11 @@
  * Conventions: plain C, no exceptions across the boundary.  Every call returns 0 on success or a
  * negative C3R_E* code; c3r_last_error(ctx) returns a human-readable message.  The caller owns all
  * host buffers; the library owns all device memory inside the opaque c3r_ctx.  One context = one
- * GPU = one HIP stream; contexts are independent (one process or thread per GPU, no collectives:
- * chunks are independent work items, run_clair3_rna:681-706).
+ * GPU = one HIP stream (plus, inside the library, a second one on which the tensor build's deep-span kernel runs beside the
+ * other); contexts are independent (one process or thread per GPU, no collectives: chunks are independent work items,
+ * run_clair3_rna:681-706).  Several contexts of one process may share a device, each driven by its own host thread (two
+ * pipelined contexts: one uploads while the other computes): c3r_load_reads lets only one of them upload at a time per device, so
+ * that they stay out of phase on the PCIe link.  A single context is not re-entrant.
  *
  * There is NO CPU fallback: every compute entry point fails with C3R_ENODEVICE when no gfx950 device
  * is usable.

@@ -11,6 +11,9 @@ if which == "chr20":
     L, gen = synth.CHR20_LEN, dict(seed=synth.SEED, depth=20.0)
 elif which == "stress":
     L, gen = 16000000, dict(seed=synth.SEED + 4, depth=500.0)
+elif which == "phased":
+    L, gen = synth.CHR20_LEN, dict(seed=synth.SEED + 3, depth=30.0, platform="hifi", phased=True)
+    params = dict(channels=30)
 elif which in ("cap", "nocap"):
     L, gen = 400000, dict(seed=synth.SEED + 5, depth=20000.0, expressed_frac=0.01, intron_lo=100.0, intron_hi=800.0)
     if which == "nocap":
@@ -19,7 +22,7 @@ else:
     L, gen = synth.CHR20_LEN, dict(seed=synth.SEED + 6, depth=20.0, expr_sigma=2.3, max_level=12000.0)
 ref, rs, info = synth.generate_contig(contig_len=L, **gen)
 chunks = bench.chunk_list(L)
-rsh = capi.pinned_readset(rs)
+rsh = rs if os.environ.get("STEP_UNPINNED") == "1" else capi.pinned_readset(rs)      # (STEP_UNPINNED=1: pageable arrays, the staging path of c3r_load_reads)
 eng = capi.Engine(0); eng.set_params(**params); eng.load_reads(rsh); eng.set_reference(1, ref)
 def scan():
     eng.begin_batch(); n = eng.scan_regions(chunks); eng.end_batch(); return n
