@@ -1490,7 +1490,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             hipLaunchKernelGGL(k_tile_ranges_fused, dim3(nblk), dim3(256), 0, ctx->stream, a, (int32_t *)lb, (unsigned long long *)(lb + lb_head), nblk, (const int2 *)ctx->d_regb.p,
                                (SpanRec *)ctx->d_spanrec.p, (int32_t *)ctx->d_deep.p, (int32_t *)(lb + 44), (unsigned long long *)(lb + lb_head + (size_t)nblk * 16));
         }
-        // the deep spans k_fused_tiles leaves out go to k_fused_deep: one workgroup of twelve wavefronts per CU, spans by ticket (no deep span: the
+        // the deep spans k_fused_tiles leaves out go to k_fused_deep: one workgroup of sixteen wavefronts per CU, spans by ticket (no deep span: the
         // workgroups leave at once).  The two kernels share nothing but the allocators and run side by side, the deep one on its own stream; under
         // the profiler (one kernel at a time, each timed on the context's stream) they run one after the other.
         const bool side = !ctx->profiling && !getenv("C3R_DEEP_SERIAL");
@@ -1501,7 +1501,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         };
         if (side) {
             if (!ctx->deep_stream) {
-                // (the device's highest priority: the deep spans are the long ones — their twelve-wavefront workgroups should get their CUs before
+                // (the device's highest priority: the deep spans are the long ones — their sixteen-wavefront workgroups should get their CUs before
                 // k_fused_tiles' small workgroups have filled every CU's LDS, not after)
                 int least = 0, greatest = 0;
                 if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); greatest = 0; }

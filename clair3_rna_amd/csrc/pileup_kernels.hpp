@@ -871,7 +871,7 @@ __device__ __forceinline__ void tile_zero(TileMem<C, EVL> &M) {
     }
 }
 // NT: threads of the workgroup.  SCAN_THREADS everywhere but in k_fused_deep, whose workgroups of DEEP_THREADS keep thread tid <-> position t0 + tid for the
-// first TILE threads (`pos_thread`) and put all twelve wavefronts on everything that goes record by record, read by read or event by event.
+// first TILE threads (`pos_thread`) and put all sixteen wavefronts on everything that goes record by record, read by read or event by event.
 template <int C, bool FUSED = false, int NT = SCAN_THREADS, int EVL = TileMem<C>::EV_LDS>
 __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EVL> &M, int t0, int t1, int pmin, int region, int lo, int hi, int slo, int shi,
                                                 int cand_lo, int cand_hi) {
@@ -2252,7 +2252,7 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
         const int q_next = home;
         const int4 r0 = s_rec[0], rng = s_rec[1], r2 = s_rec[2];
         // a deep span (ScanArgs::deep_min records or more in its range) is left to k_fused_deep, which runs behind this kernel with workgroups of
-        // twelve wavefronts: the span would keep these four for milliseconds
+        // sixteen wavefronts: the span would keep these four for milliseconds
         const bool deep = rng.w - rng.z >= a.deep_min;
         if (tid == 0) t_next = atomicAdd(&f.ticket[q_next * TICKET_STRIDE], 1);
         int b_next = 0;
@@ -2282,19 +2282,21 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
     }
 }
 
-// The deep spans of the list (ScanArgs::deep_min records or more in their range), one at a time per workgroup of DEEP_THREADS = 768 threads =
-// twelve wavefronts, one workgroup per CU.  Everything a span does record by record, read by read or event by event — the walks, the coverage, the
-// event buckets, the window copy, the token pass — runs on all twelve; the per-position steps on the first four (tile_columns, `pos_thread`).
+// The deep spans of the list (ScanArgs::deep_min records or more in their range), one at a time per workgroup of DEEP_THREADS = 1024 threads =
+// sixteen wavefronts, one workgroup per CU.  Everything a span does record by record, read by read or event by event — the walks, the coverage, the
+// event buckets, the window copy, the token pass — runs on all sixteen; the per-position steps on the first four (tile_columns, `pos_thread`).
 // A span's time at depth is rounds x memory latency while its workgroup has the CU to itself and LDS-atomic throughput once the CU is full (a
-// wavefront's 30 atomic adds per round cost ~9 LDS cycles each on random banks, 3.8 without conflicts: profiles/r6/lds_atomic_probe.txt): three
-// times the wavefronts are a third of the rounds.  (Sixteen wavefronts are 8-12 % faster still at depth but leave the span body 128 registers, which
-// it overruns by 20 bytes of scratch per lane; with twelve it has 168 and no kernel of the tensor build touches scratch.)
+// wavefront's 30 atomic adds per round cost ~9 LDS cycles each on random banks, 3.8 without conflicts: profiles/r6/lds_atomic_probe.txt): four
+// times the wavefronts are a quarter of the rounds.  (Sixteen wavefronts leave the span body 128 registers, which it overruns by 12 / 20 bytes of scratch
+// per lane at 18 / 30 channels — the ISA shows one 64-bit address hoisted out of the span loop, stored once and reloaded once per span, and the rest
+// of the pressure taken by scalar spills into lanes of a vector register.  -DC3R_DEEP_THREADS=768, twelve wavefronts at 168 registers, has no scratch
+// and is 8-10 % slower at depth: scan of bench.py's stress_500x 1.25 against 1.14 ms, capped locus 4.9 against 4.3 ms.)
 // With one workgroup per CU the LDS holds DEEP_EV_LDS captured events: up to there a span's
 // alleles are counted out of LDS as in the shallow kernel, without the second walk and the global hash table of the deeper ones.
 #ifndef C3R_DEEP_THREADS
-#define C3R_DEEP_THREADS 768
+#define C3R_DEEP_THREADS 1024
 #endif
-constexpr int DEEP_THREADS = C3R_DEEP_THREADS;      // 768 = twelve wavefronts, three per SIMD: 168 registers each, which the span body fits without scratch (1024: 128 + 20 B)
+constexpr int DEEP_THREADS = C3R_DEEP_THREADS;      // sixteen wavefronts, four per SIMD: 128 registers each
 constexpr int DEEP_EV_LDS = 3072;
 constexpr int DEEP_EVG_CAP = 49152;      // events of a span that a workgroup's global buffer holds (ScanArgs::ev_wg): a span at mpileup's depth cap has ~34 k
 struct DeepArgs { const int32_t *list; const int32_t *n_list; int32_t *ticket; };
@@ -2315,8 +2317,11 @@ __global__ __launch_bounds__(DEEP_THREADS, DEEP_THREADS / 256) void k_fused_deep
         if (b < 0) return;
         if (tid < 3) s_rec[tid] = reinterpret_cast<const int4 *>(f.span_rec + b)[tid];
         __syncthreads();
-        const int4 r0 = s_rec[0], rng = s_rec[1], r2 = s_rec[2];
-        fused_span<C, DEEP_THREADS, DEEP_EV_LDS>(f, M, S, b, shard, r0, rng, r2, [] {});
+        // the span's record is the same in every lane: say so, and its twelve words live in scalar registers for the length of the span
+        auto uni = [](const int4 v) { return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                                                       __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w)); };
+        const int4 r0 = uni(s_rec[0]), rng = uni(s_rec[1]), r2 = uni(s_rec[2]);
+        fused_span<C, DEEP_THREADS, DEEP_EV_LDS>(f, M, S, __builtin_amdgcn_readfirstlane(b), shard, r0, rng, r2, [] {});
         __syncthreads();                      // (s_b, s_rec and the span's LDS are free)
     }
 }

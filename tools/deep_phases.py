@@ -1,12 +1,10 @@
 # Where a deep locus' tile-kernel time goes (per-phase clocks of k_fused_tiles, diag build):
 #   python tools/deep_phases.py [depth] [max_depth]          one 400-kb contig with loci at `depth` (default 20,000x, cap 8000)
 #   python tools/deep_phases.py stress [abl bits]            bench.py's stress_500x contig (16 Mb, loci at ~500x)
-#   bash tools/build_variant.sh diag -DC3R_SCAN_DIAG=1 first; the script picks gpurun_variants/libc3r_diag.so up by itself
+#   the per-phase clocks need a diag build:  bash tools/build_variant.sh diag -DC3R_SCAN_DIAG=1, then C3R_LIB=gpurun_variants/libc3r_diag.so python tools/…
+#   (the library is only ever taken from C3R_LIB: an earlier version picked a diag build up by itself, and a stale one — built before the barrier fix of
+#   8c264b3 — made this tool, and only this tool, fail 7 times in 330 for two hours)
 import os, sys
-if "C3R_LIB" not in os.environ:
-    _d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_variants", "libc3r_diag.so")
-    if os.path.exists(_d):
-        os.environ["C3R_LIB"] = _d
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 stress = len(sys.argv) > 1 and sys.argv[1] == "stress"
 if stress and len(sys.argv) > 2:

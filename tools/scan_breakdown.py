@@ -7,6 +7,8 @@ if "C3R_LIB" not in os.environ:
     _d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_variants", "libc3r_diag.so")
     if os.path.exists(_d):
         os.environ["C3R_LIB"] = _d
+        sys.stderr.write("using %s (built %s) — rebuild it after every change of csrc/: a stale one measures, and fails, like the code it was built from\n"
+                         % (_d, __import__("time").strftime("%Y-%m-%d %H:%M", __import__("time").gmtime(os.path.getmtime(_d)))))
     else:
         sys.stderr.write("no gpurun_variants/libc3r_diag.so: C3R_SCAN_ABL / C3R_SCAN_DBG have no effect on the product build\n")
 sys.path.insert(0, '.')
