@@ -119,6 +119,8 @@ struct c3r_ctx {
     DevBuf d_lb, d_regb, d_span, d_spanbase, d_meta, d_spanrec, d_deep;       // (d_deep: list positions of the deep spans, k_fused_deep)
     DevBuf d_evwg;                         // k_fused_deep: an arrival-order event buffer per workgroup (DEEP_EVG_CAP records each), allocated once a scan has met a deep span
     bool seen_deep = false;
+    DevBuf d_giant, d_giant_ev, d_giant_tab;            // k_deep_walk: the giant spans' accumulator slots (+ the slice list) and event buffers, allocated once a scan has met a giant span
+    bool seen_giant = false;
     // the resident windows are int16 unless a scan of this read set has met a position that 32,768 reads or more cover (possible only above mpileup's
     // default cap, max_depth = 0 or > 32,767): that scan is repeated with int32 windows and the context keeps them from then on (a context that
     // has met such depth will meet it again: every pass over the same sample would otherwise scan twice)
@@ -701,7 +703,7 @@ void c3r_destroy(c3r_ctx *ctx) {
     const bool timing = getenv("C3R_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     DevBuf *bufs[] = {&ctx->d_wgtab, &ctx->d_rawreads, &ctx->d_rawcig, &ctx->d_bincnt, &ctx->d_binoff, &ctx->d_rtab, &ctx->d_recs, &ctx->d_serial, &ctx->d_nind, &ctx->d_lbk, &ctx->d_lcnt, &ctx->d_tokexp, &ctx->d_tokoff,
-                      &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_deep, &ctx->d_evwg, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
+                      &ctx->d_stats, &ctx->d_lb, &ctx->d_regb, &ctx->d_span, &ctx->d_spanbase, &ctx->d_meta, &ctx->d_spanrec, &ctx->d_deep, &ctx->d_evwg, &ctx->d_giant, &ctx->d_giant_ev, &ctx->d_giant_tab, &ctx->d_winidx, &ctx->d_rawidx, &ctx->d_export, &ctx->d_dbg, &ctx->d_tile_cand, &ctx->d_reads, &ctx->d_cigar, &ctx->d_seq, &ctx->d_prefmax, &ctx->d_tile_cols, &ctx->d_tile_rng, &ctx->d_tile_list, &ctx->d_tile_list2, &ctx->d_rsegs, &ctx->d_rseg_first, &ctx->d_ref, &ctx->d_bed[0], &ctx->d_bed[1],
                       &ctx->d_sites, &ctx->d_cols, &ctx->d_depth, &ctx->d_ncov, &ctx->d_flags, &ctx->d_skipmax, &ctx->d_geo, &ctx->d_lastrow, &ctx->d_drop, &ctx->d_ev, &ctx->d_small,
                       &ctx->d_blockcnt, &ctx->d_scan_tops, &ctx->d_cand, &ctx->d_tensors, &ctx->d_raw, &ctx->d_sites_out, &ctx->d_tokcnt, &ctx->d_tok, &ctx->d_tokb, &ctx->d_tokrec, &ctx->d_recoff, &ctx->d_padins, &ctx->d_aftab, &ctx->d_keep, &ctx->d_sites_c, &ctx->d_probs_c};
     int n_dev = 0; size_t b_dev = 0, b_pin = 0;
@@ -1127,6 +1129,8 @@ static void scan_inputs(c3r_ctx *ctx, ScanArgs &a, const uint32_t *d_drop, int d
     if (ctx->padins && !ctx->padins->empty()) { a.padins = (const c3r_padins_t *)ctx->d_padins.p; a.n_padins = (int32_t)ctx->padins->size(); }
     { const char *e = getenv("C3R_SCAN_ABL"); a.abl = e ? atoi(e) : 0; }
     { const char *e = getenv("C3R_DEEP_MIN"); a.deep_min = e ? std::max(1, atoi(e)) : DEEP_MIN_RECORDS; }
+    { const char *e = getenv("C3R_SPLIT_MIN"); a.split_min = e ? std::max(1, atoi(e)) : SPLIT_MIN_RECORDS; }
+    { const char *e = getenv("C3R_SPLIT_SLICE"); a.split_slice = e ? std::max(1, atoi(e)) : GIANT_SLICE; }
     { const char *e = getenv("C3R_NO_SHIFT"); a.no_shift = (e && *e == '1') ? 1 : 0; }
 }
 
@@ -1392,9 +1396,9 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     if (ctx->n_reads == 0 || n_tiles == 0) return C3R_OK;
     const size_t ev_cap = event_capacity(ctx, n_regions, ctg_starts, ctg_ends, n_tiles, 2);
     const int nblk = (n_tiles + 255) / 256;
-    // d_lb: [0] ticket of k_tile_ranges_fused, [4] ticket of k_fused_tiles, [8] candidates, [12] tokens (k_order_spans), [16] overflow
+    // d_lb: [0] ticket of k_tile_ranges_fused, [4] ticket of k_deep_alleles, [8] candidates, [12] tokens (k_order_spans), [16] overflow
     // bits, [20] listed spans, [24..31] event-scratch cursor, [32] event-scratch overflow, [36] rows handed out, [40] ticket of
-    // k_order_spans, [44] deep spans listed, [48] ticket of k_fused_deep, [64..] the TICKET_Q ticket words of k_fused_tiles, 256 bytes apart, then the ALLOC_SHARDS allocator words (tokens << 32 |
+    // k_order_spans, [44] deep spans listed, [48] ticket of k_fused_deep, [52] giant spans met, [56] their slices listed, [60] ticket of k_deep_walk, [64..] the TICKET_Q ticket words of k_fused_tiles, 256 bytes apart, then the ALLOC_SHARDS allocator words (tokens << 32 |
     // rows), 256 bytes apart; then look-back words: one per block of 256 spans for k_tile_ranges_fused, then the same for k_order_spans
     const size_t lb_alloc = 64 + (size_t)TICKET_Q * TICKET_STRIDE * 4;
     const size_t lb_head = lb_alloc + (size_t)ALLOC_SHARDS * ALLOC_STRIDE * 8;
@@ -1428,6 +1432,27 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
     if ((ctx->seen_deep || (evwg_env && *evwg_env == '1')) && !(evwg_env && *evwg_env == '0')) {
         if ((rc = ensure(ctx, ctx->d_evwg, (size_t)deep_grid * DEEP_EVG_CAP * sizeof(EvRec)))) return rc;
         a.ev_wg = (EvRec *)ctx->d_evwg.p; a.ev_wg_cap = DEEP_EVG_CAP;
+    }
+    // giant spans (k_deep_walk, k_deep_alleles): 64 accumulator slots + the slice list (2 MB), a pool of 12 M events (288 MB) and their allele table
+    // (192 MB), for a context that has met one
+    const char *giant_env = getenv("C3R_GIANT");        // (tests) 0: never, 1: from the first scan on
+    const size_t giant_acc_bytes = (size_t)GIANT_SLOTS * GIANT_STRIDE * 4 + 16;          // (+ the pool's cursor: cleared with the slots)
+    a.n_giant = (int32_t *)(lb + 52); a.n_help = (int32_t *)(lb + 56);
+    if ((ctx->seen_giant || (giant_env && *giant_env == '1')) && !(giant_env && *giant_env == '0')) {
+        if ((rc = ensure(ctx, ctx->d_giant, giant_acc_bytes + (size_t)GIANT_SLOTS * GIANT_MAX_HELP * sizeof(int4))) ||
+            (rc = ensure(ctx, ctx->d_giant_ev, (size_t)GIANT_POOL_EVENTS * sizeof(EvRec)))) return rc;
+        a.giant_acc = (int32_t *)ctx->d_giant.p; a.help_list = (int4 *)((char *)ctx->d_giant.p + giant_acc_bytes); a.giant_ev = (EvRec *)ctx->d_giant_ev.p;
+        a.giant_pool = GIANT_POOL_EVENTS; a.n_giant_ev = (int32_t *)((char *)ctx->d_giant.p + giant_acc_bytes - 16);
+        a.deep_recs = (unsigned long long *)((char *)ctx->d_giant.p + giant_acc_bytes - 8);
+        { const char *e = getenv("C3R_SPLIT_CUS"); a.split_cus = e ? std::max(1, atoi(e)) : (ctx->n_cu > 0 ? ctx->n_cu : 256); }
+        if (!getenv("C3R_NO_GIANT_TAB")) {
+            // (the allele table is all-zero between scans: cleared here when it is new, by k_fused_deep as it reads afterwards)
+            const size_t tab_bytes = (size_t)GIANT_POOL_EVENTS * 2 * sizeof(uint2);
+            const bool fresh = ctx->d_giant_tab.cap < tab_bytes;
+            if ((rc = ensure(ctx, ctx->d_giant_tab, tab_bytes))) return rc;
+            if (fresh) HIPCHK(ctx, hipMemsetAsync(ctx->d_giant_tab.p, 0, tab_bytes, ctx->stream));
+            a.giant_tab = (uint2 *)ctx->d_giant_tab.p;
+        }
     }
     f.ticket = (int32_t *)(lb + 64); f.alloc = (unsigned long long *)(lb + lb_alloc); f.overflow = (int32_t *)(lb + 16);
     f.rescale = raw_rerun ? 0 : 1; f.max_depth = ctx->prm.max_depth_rescale;
@@ -1485,6 +1510,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         z.meta = f.meta; z.span_info = f.span_info; z.span_base = (const int32_t *)ctx->d_spanbase.p; z.alloc = f.alloc; z.n_shards = nsh; z.shard_rows = f.shard_rows; z.overflow = f.overflow;
         z.ref = a.ref; z.ref_beg0 = a.ref_beg0; z.ref_len = a.ref_len;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_lb.p, 0, lb_bytes, ctx->stream));
+        if (a.giant_acc) HIPCHK(ctx, hipMemsetAsync(a.giant_acc, 0, giant_acc_bytes, ctx->stream));
         {
             Launch L(ctx, "k_tile_ranges");
             hipLaunchKernelGGL(k_tile_ranges_fused, dim3(nblk), dim3(256), 0, ctx->stream, a, (int32_t *)lb, (unsigned long long *)(lb + lb_head), nblk, (const int2 *)ctx->d_regb.p,
@@ -1494,6 +1520,19 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         // workgroups leave at once).  The two kernels share nothing but the allocators and run side by side, the deep one on its own stream; under
         // the profiler (one kernel at a time, each timed on the context's stream) they run one after the other.
         const bool side = !ctx->profiling && !getenv("C3R_DEEP_SERIAL");
+        // the giant spans' walks and allele counts, slice by slice on every CU (two workgroups each: the allele pass is round trips), before the deep
+        // kernel takes the spans
+        static const int wg_mul = [] { const char *e = getenv("C3R_GIANT_WGS"); return e ? std::max(1, atoi(e)) : 2; }();
+        const int help_grid = (ctx->n_cu > 0 ? ctx->n_cu : 256) * wg_mul;
+        auto launch_walk = [&](hipStream_t st) {
+            WalkArgs w{(const SpanRec *)ctx->d_spanrec.p, (int32_t *)(lb + 60)};
+            if (C == C3R_CH) hipLaunchKernelGGL(k_deep_walk<C3R_CH>, dim3(help_grid), dim3(DEEP_THREADS), 0, st, a, w);
+            else hipLaunchKernelGGL(k_deep_walk<C3R_CH_PHASED>, dim3(help_grid), dim3(DEEP_THREADS), 0, st, a, w);
+        };
+        auto launch_alleles = [&](hipStream_t st) {
+            if (C == C3R_CH) hipLaunchKernelGGL(k_deep_alleles<C3R_CH>, dim3(help_grid), dim3(DEEP_THREADS), 0, st, a, (int32_t *)(lb + 4));
+            else hipLaunchKernelGGL(k_deep_alleles<C3R_CH_PHASED>, dim3(help_grid), dim3(DEEP_THREADS), 0, st, a, (int32_t *)(lb + 4));
+        };
         auto launch_deep = [&](hipStream_t st) {
             DeepArgs d{(const int32_t *)ctx->d_deep.p, (const int32_t *)(lb + 44), (int32_t *)(lb + 48)};
             if (C == C3R_CH) hipLaunchKernelGGL(k_fused_deep<C3R_CH>, dim3(deep_grid), dim3(DEEP_THREADS), 0, st, f, d);
@@ -1511,6 +1550,8 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
             }
             HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->deep_stream, ctx->ev_fork, 0));
+            if (a.giant_acc) launch_walk(ctx->deep_stream);
+            if (a.giant_tab) launch_alleles(ctx->deep_stream);
             launch_deep(ctx->deep_stream);
             HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->deep_stream));
         }
@@ -1522,6 +1563,8 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         }
         if (side) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         else {
+            if (a.giant_acc) { Launch L(ctx, "k_deep_walk"); launch_walk(ctx->stream); }
+            if (a.giant_tab) { Launch L(ctx, "k_deep_alleles"); launch_alleles(ctx->stream); }
             Launch L(ctx, "k_fused_deep");
             launch_deep(ctx->stream);
         }
@@ -1537,10 +1580,21 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
         HIPCHK(ctx, hipGetLastError());
         n_cand = ctx->h_scan[0]; n_tok = ctx->h_scan[1];
         if (ctx->h_scan[9] > 0) ctx->seen_deep = true;
+        if (ctx->h_scan[9] > 0 && ctx->h_scan[11] != 0) ctx->seen_giant = true;
         int64_t need_c = 0, need_t = 0;          // the fullest shard
         for (int sh = 0; sh < nsh; ++sh) {
             const unsigned long long v = ((const unsigned long long *)(ctx->h_scan + 16))[(size_t)sh * ALLOC_STRIDE];
             need_c = std::max<int64_t>(need_c, (int64_t)(uint32_t)v); need_t = std::max<int64_t>(need_t, (int64_t)(v >> 32));
+        }
+        if (a.dbg && a.giant_acc) {
+            // events met by the giant spans' walks, slot by slot
+            std::vector<int32_t> evn(GIANT_SLOTS, 0);
+            for (int g = 0; g < GIANT_SLOTS; ++g)
+                HIPCHK(ctx, hipMemcpy(&evn[g], a.giant_acc + (size_t)g * GIANT_STRIDE + GIANT_META, 4, hipMemcpyDeviceToHost));
+            std::sort(evn.begin(), evn.end(), std::greater<int32_t>());
+            fprintf(stderr, "[giant spans] %d met; events per slot, largest first:", ctx->h_scan[11]);
+            for (int g = 0; g < GIANT_SLOTS && evn[g] > 0; ++g) fprintf(stderr, " %d", evn[g]);
+            fprintf(stderr, "\n");
         }
         if (a.dbg) {
             unsigned long long d[32];

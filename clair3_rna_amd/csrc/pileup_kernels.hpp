@@ -183,6 +183,24 @@ struct ScanArgs {
     unsigned long long ev_cap;    // a reservation past it is refused: the tile skips its events and raises *ev_overflow
     EvRec *ev_wg;                 // k_fused_deep: per-workgroup arrival-order event buffers, ev_wg_cap records each (null: none — deep tiles walk twice)
     int32_t ev_wg_cap;
+    // giant spans (split_min records or more in range): their walk is done ahead of k_fused_deep by several workgroups of k_deep_walk, each over a
+    // slice of the span's records, into one of GIANT_SLOTS global accumulators (null: no pool yet — the span is walked by its own workgroup)
+    int32_t split_min;            // env C3R_SPLIT_MIN
+    int32_t split_slice;          // records per slice (GIANT_SLICE; env C3R_SPLIT_SLICE: tests cut small spans into many slices)
+    int32_t *giant_acc;           // [GIANT_SLOTS][GIANT_STRIDE] counts, max deletion, order flags, {events met, first event in giant_ev, events it may hold}; zeroed before every scan
+    EvRec *giant_ev;              // [giant_pool] the giant spans' events in arrival order: a span reserves as many as it has records in range (a record shows at most one)
+    int32_t giant_pool;           //   (no room left: the span is walked by its own workgroup); *n_giant_ev: reserved so far
+    int32_t *n_giant_ev;
+    int4 *help_list;              // [GIANT_SLOTS * GIANT_MAX_HELP] {span's list position, slice, slices, slot}
+    uint2 *giant_tab;             // [2 * giant_pool] {1 + first event of an allele, its channel << 30 | its multiplicity}: the giant spans' allele counts (k_deep_alleles);
+                                  // all-zero between scans — k_fused_deep clears what it reads
+    int32_t *n_giant, *n_help;
+    // ... and only where it pays: splitting a span helps when CUs would idle beside it, not when thousands of deep spans keep them all busy (the
+    // slices' kernels run before k_fused_deep and delay it).  A listed giant span is split iff its records x split_cus >= the records of all deep
+    // spans of the scan (*deep_recs, summed by the list kernel): it alone is more than a CU's share.  k_deep_walk, k_deep_alleles and k_fused_deep
+    // all decide by this after the list kernel has finished (giant_on).
+    unsigned long long *deep_recs;
+    int32_t split_cus;            // compute units (env C3R_SPLIT_CUS)
     int32_t *ev_overflow;         // bit 0: the event scratch; bit 1: a position covered by 32768 reads or more — its counts may not fit the 16-bit windows
     int32_t *last_row;            // [n_regions] atomicMax of the last SLOT (index into the position arrays) with a row
     const uint32_t *drop;         // mpileup depth cap: [n_regions][drop_words] bit per read = discarded in that region; null: none
@@ -192,6 +210,9 @@ struct ScanArgs {
     const c3r_padins_t *padins;   // mpileup_compat = 1: insertions with pads, sorted by (read_idx, qpos); null / 0 for every CIGAR an aligner emits
     int32_t n_padins;
 };
+__device__ __forceinline__ bool giant_on(const ScanArgs &a, int nrec) {
+    return (unsigned long long)(unsigned)nrec * (unsigned long long)(unsigned)a.split_cus >= *a.deep_recs;
+}
 // the table entry of the insertion of read r at query offset q, or null
 __device__ __forceinline__ const c3r_padins_t *padins_find(const c3r_padins_t *tab, int n, uint32_t r, uint32_t q) {
     int lo = 0, hi = n;
@@ -311,9 +332,18 @@ __device__ __forceinline__ bool sorted_contains(const int32_t *a, int n, int v) 
 
 constexpr int AF_TAB = 8192;
 constexpr int EV_HASH_MIN = 1024;      // indel events of a tile from which their alleles are counted through a hash table (tile_columns)
-constexpr int DEEP_MIN_RECORDS = 2048; // records in a tile's range from which it takes the position-major walk (walk_columns); ScanArgs::deep_min
+constexpr int DEEP_MIN_RECORDS = 2048; // records in a span's range from which it is left to k_fused_deep; ScanArgs::deep_min
 enum WalkMode { ACCUM = 0, SCATTER = 1, FIRSTSEEN = 2 };
 constexpr int FS_CAP = 32;     // positions per batch of the first-seen (tie-break) pass
+// giant spans: tens of thousands of records in range (a locus at mpileup's depth cap: 270 k) — one CU walks those for a millisecond while the others idle
+constexpr int SPLIT_MIN_RECORDS = 8192;    // ScanArgs::split_min
+constexpr int GIANT_SLOTS = 256;           // giant spans of one scan that are split (the others are walked by their own workgroup)
+constexpr int GIANT_SLICE = 4096;          // records per slice,
+constexpr int GIANT_MAX_HELP = 32;         //   at most this many slices per span (longer slices beyond)
+constexpr int GIANT_STRIDE = TILE * C3R_CH_PHASED + 2 * TILE + 16;     // int32 words per slot: cnt[TILE][C <= 30], maxdel[TILE], odd[TILE], GIANT_META..
+constexpr int GIANT_META = TILE * C3R_CH_PHASED + 2 * TILE;            //   {events met, the span's first event in the pool, events reserved}
+constexpr int GIANT_POOL_EVENTS = 12 << 20;                            // 40 bytes each (event + two table slots): 480 MB, allocated by a context that has met a giant span
+constexpr int DEEP_EVG_CAP = 49152;      // events of a span that a workgroup's global buffer holds (ScanArgs::ev_wg, ::giant_ev): a span at mpileup's depth cap has ~34 k
 
 struct TileLds {
     int32_t *cnt;      // [TILE][C]
@@ -431,6 +461,16 @@ __device__ __forceinline__ void walk_event(const ScanArgs &a, const TileLds &s, 
         if (s.evq_cap > 0) {
             const int at = atomicAdd(s.evn, 1);
             if (at < s.evq_cap) s.evq[at] = e;
+            if (at < s.evg_cap) s.evg[at] = e;
+        } else if (s.evq_cap < 0) {
+            // k_deep_walk: a slice of a giant span — the span's buffer and its cursor are global and shared with the other slices' workgroups: one
+            // returning atomic per wavefront for the lanes that are here
+            const unsigned long long m = __ballot(1);
+            const int lane = (int)(threadIdx.x & 63), lead = __builtin_ctzll(m);
+            int base = 0;
+            if (lane == lead) base = atomicAdd(s.evn, __popcll(m));
+            base = __builtin_amdgcn_readlane(base, lead);
+            const int at = base + __popcll(m & ((1ull << lane) - 1ull));
             if (at < s.evg_cap) s.evg[at] = e;
         }
     } else {  // SCATTER
@@ -780,11 +820,27 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
     if (listed) {
         const int at2 = at + __popcll(m & ((1ull << lane) - 1ull));
         a.tile_list[at2] = t;
+        // a giant span takes one of the GIANT_SLOTS accumulators and lists its slices for k_deep_walk (no slot left: it is walked by its own workgroup)
+        int gslot = 0;
+        const int nrec = rec.rng.w - rec.rng.z;
+        if (nrec >= a.split_min && nrec >= a.deep_min) {
+            const int g = atomicAdd(a.n_giant, 1);          // (counted with or without a pool: the host allocates one after the first scan that met any)
+            const int ev0 = (a.giant_acc && g < GIANT_SLOTS) ? atomicAdd(a.n_giant_ev, nrec) : a.giant_pool;
+            if (a.giant_acc && g < GIANT_SLOTS && ev0 <= a.giant_pool - nrec) {
+                gslot = g + 1;
+                int32_t *meta = a.giant_acc + (size_t)g * GIANT_STRIDE + GIANT_META;
+                meta[1] = ev0; meta[2] = nrec;
+                const int G = min(GIANT_MAX_HELP, (nrec + a.split_slice - 1) / a.split_slice);
+                const int h0 = atomicAdd(a.n_help, G);
+                for (int k = 0; k < G; ++k) a.help_list[h0 + k] = make_int4(at2, k, G, g);
+            }
+        }
         int4 *dst = reinterpret_cast<int4 *>(span_rec + at2);
-        dst[0] = make_int4(rec.tile, rec.p0, rec.p1, rec.region); dst[1] = rec.rng; dst[2] = make_int4(rec.reg_lo, rec.reg_hi, 0, 0);
+        dst[0] = make_int4(rec.tile, rec.p0, rec.p1, rec.region); dst[1] = rec.rng; dst[2] = make_int4(rec.reg_lo, rec.reg_hi, gslot, 0);
     }
     // the deep spans' list positions, in any order, for k_fused_deep (one atomic per wavefront that holds any)
     const bool deep = listed && rec.rng.w - rec.rng.z >= a.deep_min;
+    if (deep && a.giant_acc) atomicAdd(a.deep_recs, (unsigned long long)(rec.rng.w - rec.rng.z));
     const unsigned long long md = __ballot(deep);
     if (md) {
         int base = 0;
@@ -874,13 +930,17 @@ __device__ __forceinline__ void tile_zero(TileMem<C, EVL> &M) {
 // first TILE threads (`pos_thread`) and put all sixteen wavefronts on everything that goes record by record, read by read or event by event.
 template <int C, bool FUSED = false, int NT = SCAN_THREADS, int EVL = TileMem<C>::EV_LDS>
 __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EVL> &M, int t0, int t1, int pmin, int region, int lo, int hi, int slo, int shi,
-                                                int cand_lo, int cand_hi) {
+                                                int cand_lo, int cand_hi, const int giant = 0) {
     constexpr int EV_LDS = EVL;
     const int tid = threadIdx.x;
     const bool pos_thread = NT == SCAN_THREADS || tid < TILE;
+    // giant (k_fused_deep, 1 + slot): the span's records were walked by k_deep_walk — counts, deletion lengths, order flags and events lie in its slot
+    const bool split = NT > SCAN_THREADS && giant > 0;
     // (k_fused_deep: workgroup blockIdx.x owns a.ev_wg_cap event slots of a.ev_wg)
-    EvRec *const evg = (NT > SCAN_THREADS && a.ev_wg) ? a.ev_wg + (size_t)blockIdx.x * (size_t)a.ev_wg_cap : nullptr;
-    TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, M.ev, &M.misc[0], EV_LDS, evg, evg ? a.ev_wg_cap : 0};
+    const int32_t *const gmeta = split ? a.giant_acc + (size_t)(giant - 1) * GIANT_STRIDE + GIANT_META : nullptr;
+    const int g_ev0 = split ? gmeta[1] : 0;
+    EvRec *const evg = split ? a.giant_ev + g_ev0 : (NT > SCAN_THREADS && a.ev_wg) ? a.ev_wg + (size_t)blockIdx.x * (size_t)a.ev_wg_cap : nullptr;
+    TileLds s{M.cnt, M.cov, M.evoff, M.evfill, M.maxdel, M.first, M.amb, M.odd, M.ev, &M.misc[0], EV_LDS, evg, split ? gmeta[2] : evg ? a.ev_wg_cap : 0};
     unsigned long long tprev = C3R_DBG(a) ? wall_clock64() : 0ull;
 #define C3R_PHASE(K) do { if (C3R_DBG(a) && tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&C3R_DBG(a)[K], now_ - tprev); tprev = now_; } } while (0)
     tile_zero<C, NT, EVL>(M);
@@ -899,6 +959,11 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EV
     __syncthreads();
 
     C3R_PHASE(0);
+    if (split) {
+        const int32_t *acc = a.giant_acc + (size_t)(giant - 1) * GIANT_STRIDE;
+        for (int i = tid; i < TILE * C; i += NT) M.cnt[i] = acc[i];
+        if (tid < TILE) { M.maxdel[tid] = acc[TILE * C3R_CH_PHASED + tid]; M.odd[tid] = (uint8_t)(acc[TILE * C3R_CH_PHASED + TILE + tid] != 0); }
+    } else
     if (!(C3R_ABL(a) & 1)) walk_records<C, ACCUM, NT, (NT > SCAN_THREADS ? DEEP_WALK_UNR : c3r::WALK_UNR)>(a, s, slo, shi, t0, t1, region, nullptr);
     if (!(C3R_ABL(a) & 4)) {
         cover_span(s, rd_end > t0 && rd_pos < t1, rd_pos, rd_end, t0, t1);
@@ -923,6 +988,28 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EV
         // the tile's indel events, bucketed by position (counting sort through evoff / evfill), then the max multiplicity of one
         // allele per (position, channel): I1 / i1 / D1 / d1
         __syncthreads();                       // (evoff of every position is in place)
+        if (split && a.giant_tab) {
+            // k_deep_alleles has counted the span's alleles: per position a region of 2 n slots behind those of the positions before it, a used slot =
+            // {1 + the allele's first event, which of I1 / i1 / D1 / d1 it counts for << 30 | how many events show it}.  The slot's position: the last
+            // one whose region starts at or before it (evoff is non-decreasing; positions without events have empty regions)
+            uint2 *tab = a.giant_tab + 2 * (size_t)g_ev0;
+#pragma unroll 4
+            for (int i = tid; i < 2 * ev_total; i += NT) {
+                const uint2 v = tab[i];
+                if (v.x) {
+                    tab[i] = make_uint2(0u, 0u);
+                    int pl = 0;
+#pragma unroll
+                    for (int st = TILE / 2; st > 0; st >>= 1) if (2 * M.evoff[pl + st] <= i) pl += st;
+                    constexpr int CH1[4] = {C3R_I1, C3R_i1, C3R_D1, C3R_d1};
+                    atomicMax(&M.cnt[pl * C + CH1[v.y >> 30]], (int)(v.y & 0x3fffffffu));
+                }
+            }
+        } else {
+        if (split && ev_total <= EV_LDS) {
+            for (int e = tid; e < ev_total; e += NT) M.ev[e] = evg[e];
+            __syncthreads();
+        }
         if (ev_total <= EV_LDS) {
             // the usual case: the first walk has captured every event (ev_total of them, in arrival order); bucket their indices
             for (int e = (C3R_ABL(a) & 262144) ? ev_total : tid; e < ev_total; e += NT) {
@@ -1072,6 +1159,7 @@ __device__ __forceinline__ TileOut tile_columns(const ScanArgs &a, TileMem<C, EV
             } else {
                 events(a.ev + evb);
             }
+        }
         }
         __syncthreads();
     }
@@ -2043,7 +2131,8 @@ __device__ __forceinline__ void fused_span(const FusedArgs &f, TileMem<C, EVL> &
         TileGeo tg; tg.p0 = r0.y; tg.p1 = r0.z; tg.region = r0.w; tg.pad = 0;
         const int2 rb = make_int2(r2.x, r2.y);
         const int x0 = tg.p0 - C3R_FLANK, x1 = min(tg.p1 + C3R_FLANK, rb.y);       // thread tid <-> position x0 + tid
-        const TileOut o = tile_columns<C, true, NT, EVL>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1);
+        const TileOut o = tile_columns<C, true, NT, EVL>(a, M, x0, x1, rb.x, tg.region, rng.x, rng.y, rng.z, rng.w, tg.p0, tg.p1,
+                                                         (NT > SCAN_THREADS && r2.z > 0 && giant_on(a, rng.w - rng.z)) ? r2.z : 0);
         unsigned long long t_tail = C3R_DBG(a) ? wall_clock64() : 0ull;
         int dbg_slot = 7;
         if (C == C3R_CH_PHASED) {
@@ -2298,7 +2387,6 @@ __global__ __launch_bounds__(SCAN_THREADS, (C == C3R_CH ? C3R_FUSED_OCC : C3R_SC
 #endif
 constexpr int DEEP_THREADS = C3R_DEEP_THREADS;      // sixteen wavefronts, four per SIMD: 128 registers each
 constexpr int DEEP_EV_LDS = 3072;
-constexpr int DEEP_EVG_CAP = 49152;      // events of a span that a workgroup's global buffer holds (ScanArgs::ev_wg): a span at mpileup's depth cap has ~34 k
 struct DeepArgs { const int32_t *list; const int32_t *n_list; int32_t *ticket; };
 template <int C>
 __global__ __launch_bounds__(DEEP_THREADS, DEEP_THREADS / 256) void k_fused_deep(const FusedArgs f, const DeepArgs d) {
@@ -2323,6 +2411,96 @@ __global__ __launch_bounds__(DEEP_THREADS, DEEP_THREADS / 256) void k_fused_deep
         const int4 r0 = uni(s_rec[0]), rng = uni(s_rec[1]), r2 = uni(s_rec[2]);
         fused_span<C, DEEP_THREADS, DEEP_EV_LDS>(f, M, S, __builtin_amdgcn_readfirstlane(b), shard, r0, rng, r2, [] {});
         __syncthreads();                      // (s_b, s_rec and the span's LDS are free)
+    }
+}
+
+// The walk of the giant spans (ScanArgs::split_min records or more in range), ahead of k_fused_deep: a workgroup takes one slice of one span's records
+// by ticket, walks it into LDS exactly as the span's own workgroup would (walk_records, ACCUM), and adds what it found to the span's slot — counts by
+// global adds (a slot is 4.6 k words; a slice leaves most of them non-zero once), the longest deletion per position by max, the order flags of the
+// 30-channel mode by store, the indel events into the slot's buffer behind a global cursor.  Every one of these is a sum, a max or a set: the order
+// of the slices does not show.  k_fused_deep then starts such a span from its slot instead of walking (tile_columns, `giant`).
+struct WalkArgs { const SpanRec *span_rec; int32_t *ticket; };
+template <int C>
+__global__ __launch_bounds__(DEEP_THREADS, DEEP_THREADS / 256) void k_deep_walk(const ScanArgs a, const WalkArgs d) {
+    __shared__ int32_t s_cnt[TILE * C];
+    __shared__ int32_t s_maxdel[TILE];
+    __shared__ uint8_t s_odd[TILE];
+    __shared__ int s_i;
+    const int tid = (int)threadIdx.x;
+    const int n = min(*a.n_help, GIANT_SLOTS * GIANT_MAX_HELP);
+    for (;;) {
+        if (tid == 0) s_i = atomicAdd(d.ticket, 1);
+        __syncthreads();
+        const int i = s_i;
+        if (i >= n) return;
+        const int4 h = a.help_list[i];                       // {span, slice, slices, slot}
+        const int4 *rec = reinterpret_cast<const int4 *>(d.span_rec + h.x);
+        const int4 r0 = rec[0], rng = rec[1], r2 = rec[2];
+        if (!giant_on(a, rng.w - rng.z)) { __syncthreads(); continue; }
+        for (int j = tid; j < TILE * C; j += DEEP_THREADS) s_cnt[j] = 0;
+        if (tid < TILE) { s_maxdel[tid] = 0; s_odd[tid] = 0; }
+        __syncthreads();
+        const int t0 = r0.y - C3R_FLANK, t1 = min(r0.z + C3R_FLANK, r2.y);
+        const int per = (rng.w - rng.z + h.z - 1) / h.z;
+        const int lo = rng.z + h.y * per, hi = min(lo + per, rng.w);
+        int32_t *acc = a.giant_acc + (size_t)h.w * GIANT_STRIDE;
+        TileLds s{s_cnt, nullptr, nullptr, nullptr, s_maxdel, nullptr, nullptr, s_odd, nullptr, acc + GIANT_META, -1, a.giant_ev + acc[GIANT_META + 1], acc[GIANT_META + 2]};
+        walk_records<C, ACCUM, DEEP_THREADS, DEEP_WALK_UNR>(a, s, lo, hi, t0, t1, r0.w, nullptr);
+        __syncthreads();
+        for (int j = tid; j < TILE * C; j += DEEP_THREADS) { const int v = s_cnt[j]; if (v) atomicAdd(&acc[j], v); }
+        if (tid < TILE) {
+            if (s_maxdel[tid]) atomicMax(&acc[TILE * C3R_CH_PHASED + tid], s_maxdel[tid]);
+            if (s_odd[tid]) acc[TILE * C3R_CH_PHASED + TILE + tid] = 1;
+        }
+        __syncthreads();
+    }
+}
+
+// The allele counts of the giant spans, between k_deep_walk and k_fused_deep: the slices of a span's EVENTS (in the slot's buffer, arrival order) go to
+// workgroups by ticket; an event claims or joins its allele's slot in the span's table — per position a region of 2 n slots, n the position's events,
+// at twice the exclusive sum of the positions before it (the very offsets tile_columns derives from the merged counts) — and adds one.  One workgroup
+// took 0.6 ms per span at mpileup's cap for this (34 k events, four dependent round trips each, on sixteen wavefronts).
+template <int C>
+__global__ __launch_bounds__(DEEP_THREADS, DEEP_THREADS / 256) void k_deep_alleles(const ScanArgs a, int32_t *ticket) {
+    __shared__ int s_evoff[TILE], s_nev[TILE], s_wt[WAVES], s_i;
+    const int tid = (int)threadIdx.x;
+    const int n = min(*a.n_help, GIANT_SLOTS * GIANT_MAX_HELP);
+    for (;;) {
+        if (tid == 0) s_i = atomicAdd(ticket, 1);
+        __syncthreads();
+        const int i = s_i;
+        if (i >= n) return;
+        const int4 h = a.help_list[i];                       // {span, slice, slices, slot}
+        const int32_t *acc = a.giant_acc + (size_t)h.w * GIANT_STRIDE;
+        if (!giant_on(a, acc[GIANT_META + 2])) { __syncthreads(); continue; }          // ([2]: the events reserved = the span's records)
+        int nev = 0;
+        if (tid < TILE) { const int32_t *row = acc + tid * C; nev = row[C3R_I] + row[C3R_i] + row[C3R_D] + row[C3R_d]; }
+        int n_ev;
+        const int off = block_excl_scan<DEEP_THREADS>(nev, s_wt, &n_ev);
+        if (tid < TILE) { s_evoff[tid] = off; s_nev[tid] = nev; }
+        __syncthreads();
+        {
+            const int ev0 = acc[GIANT_META + 1];
+            const EvRec *ev = a.giant_ev + ev0;
+            uint2 *tab = a.giant_tab + 2 * (size_t)ev0;
+            const int per = (n_ev + h.z - 1) / h.z;
+            const int e1 = min(n_ev, (h.y + 1) * per);
+#pragma unroll 1
+            for (int e = h.y * per + tid; e < e1; e += DEEP_THREADS) {
+                const EvRec me = ev[e];
+                const int nn = 2 * s_nev[me.pl];
+                uint2 *reg = tab + 2 * s_evoff[me.pl];
+                uint32_t hs = (uint32_t)(ev_hash(me) >> 33) % (uint32_t)nn;
+                for (int probe = 0; probe < nn; ++probe) {
+                    const uint32_t rep = atomicCAS(&reg[hs].x, 0u, (uint32_t)e + 1u);
+                    // (the allele's first event also says which channel the count is for)
+                    if (rep == 0u) { atomicAdd(&reg[hs].y, 1u | ((me.ch == C3R_I1 ? 0u : me.ch == C3R_i1 ? 1u : me.ch == C3R_D1 ? 2u : 3u) << 30)); break; }
+                    if (ev_equal(a, me, ev[rep - 1u])) { atomicAdd(&reg[hs].y, 1u); break; }
+                    hs = hs + 1u == (uint32_t)nn ? 0u : hs + 1u;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

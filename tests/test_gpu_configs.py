@@ -237,16 +237,29 @@ def test_a_position_covered_by_more_than_32767_reads_takes_32_bit_windows():
 
 def test_realistic_expression_slice_matches_the_oracle(eng):
     """bench.py's `realistic_expr` workload on a 3-Mb slice: log-normal gene expression over four to five decades — loci in the thousands
-    (k_fused_deep's spans) beside one-to-three-read islands that emit nothing (src/create_tensor_pileup.py:512-516, :551-560) — bit-exact
-    against the oracle."""
+    (k_fused_deep's spans, the deepest of them split over k_deep_walk's workgroups) beside one-to-three-read islands that emit nothing
+    (src/create_tensor_pileup.py:512-516, :551-560) — bit-exact against the oracle."""
     from clair3_rna_amd import synth
     L = 3000000               # (this seed puts a locus in the thousands into the slice)
     ref, rs, info = synth.generate_contig(contig_len=L, seed=synth.SEED + 16, depth=20.0, expr_sigma=2.3, max_level=12000.0)
     ref = ref.decode()
-    _fresh(eng)
-    got = H.engine_chunk(eng, rs, ref, 1, 1, L)
     exp = H.oracle_chunk(rs, ref, 1, 1, L)
     d = exp["depth"]
     assert len(exp["lines"]) > 500 and d.max() > 1000 and (d < 8).any(), (len(exp["lines"]), int(d.max()), int(d.min()))
-    assert got["lines"] == exp["lines"], H.first_diff(got["lines"], exp["lines"])
-    assert np.array_equal(got["X"], exp["X"])
+    # A context of its own: its first scan meets the locus' giant spans (8192 records or more in range) without a pool and walks each with its
+    # own workgroup; from the second scan on their records are walked slice by slice by k_deep_walk and their alleles counted by k_deep_alleles.
+    from clair3_rna_amd import capi
+    e = capi.Engine(0)
+    try:
+        e.set_params()
+        for scan in range(2):
+            if scan == 1:
+                e.set_profiling(True)
+                e.reset_kernel_stats()
+            got = H.engine_chunk(e, rs, ref, 1, 1, L)
+            assert got["lines"] == exp["lines"], (scan, H.first_diff(got["lines"], exp["lines"]))
+            assert np.array_equal(got["X"], exp["X"]), scan
+        ks = e.kernel_stats()
+        assert ks.get("k_deep_walk", {}).get("launches", 0) >= 1 and ks.get("k_deep_alleles", {}).get("launches", 0) >= 1, sorted(ks)
+    finally:
+        e.close()
