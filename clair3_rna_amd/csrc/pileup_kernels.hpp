@@ -373,16 +373,18 @@ __device__ __forceinline__ void cover_span(const TileLds &s, bool covers, int po
 }
 template <int NT = SCAN_THREADS>
 __device__ __forceinline__ void cover_reads(const ScanArgs &a, const TileLds &s, int lo, int hi, int t0, int t1, int region) {
-    for (int base = lo; base < hi; base += NT) {              // (uniform trip count: the ballot sees whole wavefronts)
-        const int r = base + (int)threadIdx.x;
-        bool covers = false;
-        int pos = 0, end = 0;
-        if (r < hi) {
-            const DevRead rd = a.reads[r];
-            pos = rd.pos; end = rd.end;
-            covers = read_passes(rd, a.min_mq, a.excl_flags) && rd.end > t0 && rd.pos < t1 && !read_dropped(a.drop, a.drop_words, region, r);
+    // (k_fused_deep: a span at mpileup's cap has 28 k reads in range — four headers per lane and round, their loads issued together)
+    constexpr int U = NT > SCAN_THREADS ? 4 : 1;
+    for (int base = lo; base < hi; base += NT * U) {          // (uniform trip count: the ballot sees whole wavefronts)
+        DevRead rd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rd[u] = a.reads[min(base + u * NT + (int)threadIdx.x, hi - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = base + u * NT + (int)threadIdx.x;
+            const bool covers = r < hi && read_passes(rd[u], a.min_mq, a.excl_flags) && rd[u].end > t0 && rd[u].pos < t1 && !read_dropped(a.drop, a.drop_words, region, r);
+            cover_span(s, covers, rd[u].pos, rd[u].end, t0, t1);
         }
-        cover_span(s, covers, pos, end, t0, t1);
     }
 }
 
@@ -1918,6 +1920,43 @@ __device__ __forceinline__ int tile_tokens(const ScanArgs &a, TokLds &K, int t0,
     __syncthreads();
     // a record matters only if its piece covers a candidate (or, an indel behind a ref-skip, sits on one): the candidates' bit mask says
     // so from the record's first half alone, before its second half or any base is fetched
+    if (NT > SCAN_THREADS) {
+        // k_fused_deep: tens or hundreds of thousands of records, of which the few that cover a candidate matter — the walk is round trips (a giant
+        // span with one candidate: 260 rounds, 0.5 ms).  Four first halves per lane and round, the second half and the bases only for a record that counts.
+        constexpr int U = 4;
+#pragma unroll 1
+        for (int base = rlo; base < rhi; base += NT * U) {
+            int4 ra[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ra[u] = *reinterpret_cast<const int4 *>(a.recs + min(base + u * NT + tid, rhi - 1));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (base + u * NT + tid >= rhi) continue;
+                const uint32_t w = (uint32_t)ra[u].y;
+                const int op = (int)(w & 3u), len = (int)((w >> 9) & 31u), avail = (int)((w >> 14) & 31u);
+                const int b0 = max(ra[u].x, t0), b1 = min(ra[u].x + len, t1);
+                unsigned long long bits = 0ull;
+                if (op != C3R_CIG_I && b0 < b1) bits = tok_cand_bits(K, b0 - t0, b1 - b0);
+                const int ax = ra[u].x - 1 - t0;
+                const bool anchored = op != C3R_CIG_M && ((w >> 2) & 15u) == (uint32_t)C3R_CIG_N && ax >= 0 && ax < t1 - t0 && ((K.cmask[ax >> 6] >> (ax & 63)) & 1ull);
+                if (!(bits || anchored)) continue;
+                const int4 rb = reinterpret_cast<const int4 *>(a.recs + (base + u * NT + tid))[1];
+                if (a.drop && read_dropped(a.drop, a.drop_words, region, rb.y)) continue;
+                uint64_t w0 = 0, w1 = 0;
+                int boff = 0;
+                if (op == C3R_CIG_M && bits) {
+                    boff = b0 - ra[u].x;
+                    if (boff < avail) {
+                        const uint64_t na = ((uint64_t)(uint32_t)ra[u].z | ((uint64_t)(uint32_t)ra[u].w << 32)) + (uint64_t)boff;
+                        u64x2 ww;
+                        __builtin_memcpy(&ww, a.seq + (na >> 1), 16);
+                        w0 = ww[0]; w1 = ww[1];
+                    }
+                }
+                tok_rec(K, tok, tok_cap, ra[u], rb, w0, w1, boff, t0, t1, bits);
+            }
+        }
+    } else
     for (int base = rlo; base < rhi; base += NT * WALK_UNR) {
         int4 ra[WALK_UNR], rb[WALK_UNR];
         bool have[WALK_UNR];
