@@ -476,7 +476,8 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing, std::uniq
         const int32_t base = ctx->first_pos >> BIN_SHIFT;
         want_end = std::min<int64_t>(want_end, (int64_t)INT32_MAX);
         const int32_t nb = (int32_t)((want_end >> BIN_SHIFT) - base + 2), nbc = (nb >> CBIN_SHIFT) + 2;
-        const size_t cnt_bytes = ((size_t)nb + 3 * (size_t)nbc) * 4;          // records per bin | reads started | ended | prefix-max histogram per coarse bin
+        const int32_t nb_pad = (nb + 1023) & ~1023;                           // (the bin counters are laid out in whole blocks of 1024: cnt_at)
+        const size_t cnt_bytes = ((size_t)nb_pad + 3 * (size_t)nbc) * 4;      // records per bin | reads started | ended | prefix-max histogram per coarse bin
         if (ctx->d_bincnt.cap < cnt_bytes || !ctx->d_bincnt.p) ctx->bins_zeroed = 0;                                    // (a fresh block)
         if ((rc = ensure(ctx, ctx->d_bincnt, cnt_bytes)) || (rc = ensure(ctx, ctx->d_binoff, (size_t)(nb + 1) * 4 + 16)) || (rc = ensure(ctx, ctx->d_rtab, (size_t)(nbc + 1) * sizeof(int4)))) return rc;
         ctx->bins = BinGeo{base, nb, nbc, 0};
@@ -502,7 +503,7 @@ int prepare_tables(c3r_ctx *ctx, int n, int64_t last_pos, bool timing, std::uniq
         a.n_cigar_ops = ctx->n_cigar_ops; a.n_seq_bytes = ctx->n_seq_bytes; a.min_mq = ctx->prm.min_mq; a.excl_flags = ctx->prm.excl_flags; a.compat = ctx->prm.mpileup_compat;
         a.geo = ctx->bins;
         uint32_t *cnt = (uint32_t *)ctx->d_bincnt.p;
-        a.cnt = cnt; a.sc = cnt + nb; a.ec = a.sc + nbc; uint32_t *pc = a.ec + nbc;
+        a.cnt = cnt; a.sc = cnt + nb_pad; a.ec = a.sc + nbc; uint32_t *pc = a.ec + nbc;
         a.rec_off = (const uint32_t *)ctx->d_binoff.p; a.out = (DevRead *)ctx->d_reads.p; a.serial = (uint8_t *)ctx->d_serial.p; a.nind = (int32_t *)ctx->d_nind.p;
         a.st = (LoadStats *)ctx->d_stats.p;
         char *lbk = (char *)ctx->d_lbk.p;
