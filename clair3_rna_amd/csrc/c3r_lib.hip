@@ -1605,6 +1605,7 @@ static int scan_fused(c3r_ctx *ctx, int32_t n_regions, const int64_t *ctg_starts
                     d[15], d[13] / nt, d[14] / nt, d[12] / nt, d[0] / nt / 100, d[1] / nt / 100, d[2] / nt / 100, d[5] / nt / 100, d[3] / nt / 100, d[4] / nt / 100, d[6] / nt / 100, d[7] / nt / 100, d[8] / nt / 100);
             fprintf(stderr, "   tail: row mask %.2f | scan %.2f | allocator atomic %.2f us\n", d[9] / nt / 100, d[10] / nt / 100, d[11] / nt / 100);
             fprintf(stderr, "   LDS event store: leader search (thread 0) %.2f | wait for the others %.2f us\n", d[16] / nt / 100, d[17] / nt / 100);
+            if (d[18]) fprintf(stderr, "   k_fused_deep: the longest span took %.1f us (%llu records in range)\n", (double)(d[18] >> 24) / 100.0, (d[18] & 0xffffffull) << 4);
         }
         if ((ctx->h_scan[2] & 4) && !f.ph.rsegs) {
             // a flagged column and no tables yet: build them (this context keeps doing so from now on) and run the scan again

@@ -401,7 +401,7 @@ __device__ __forceinline__ int nibble_at(uint64_t w0, uint64_t w1, int ni) {    
 }
 
 // The indel a record attaches to the column BEFORE its op (htslib: the next op is peeked at on the last position of the current one): the second
-// half of a record's walk, shared by the record-major walk (walk_rec) and the position-major one (walk_columns).
+// half of a record's walk (walk_rec).
 template <int C, int MODE>
 __device__ __forceinline__ void walk_event(const ScanArgs &a, const TileLds &s, const int4 ra, const int4 rb, uint64_t w0, uint64_t w1, int t0, int t1,
                                            EvRec *ev) {
@@ -2448,8 +2448,11 @@ __global__ __launch_bounds__(DEEP_THREADS, DEEP_THREADS / 256) void k_fused_deep
         auto uni = [](const int4 v) { return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
                                                        __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w)); };
         const int4 r0 = uni(s_rec[0]), rng = uni(s_rec[1]), r2 = uni(s_rec[2]);
+        const unsigned long long t_span = C3R_DBG(f.a) ? wall_clock64() : 0ull;
         fused_span<C, DEEP_THREADS, DEEP_EV_LDS>(f, M, S, __builtin_amdgcn_readfirstlane(b), shard, r0, rng, r2, [] {});
         __syncthreads();                      // (s_b, s_rec and the span's LDS are free)
+        // (diag build: the longest span of the launch, in ticks << 24 | its records in range >> 4)
+        if (C3R_DBG(f.a) && tid == 0) atomicMax(&C3R_DBG(f.a)[18], ((wall_clock64() - t_span) << 24) | (unsigned long long)((unsigned)(rng.w - rng.z) >> 4));
     }
 }
 
