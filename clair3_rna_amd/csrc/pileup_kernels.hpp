@@ -827,8 +827,10 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
         const int nrec = rec.rng.w - rec.rng.z;
         if (nrec >= a.split_min && nrec >= a.deep_min) {
             const int g = atomicAdd(a.n_giant, 1);          // (counted with or without a pool: the host allocates one after the first scan that met any)
-            const int ev0 = (a.giant_acc && g < GIANT_SLOTS) ? atomicAdd(a.n_giant_ev, nrec) : a.giant_pool;
-            if (a.giant_acc && g < GIANT_SLOTS && ev0 <= a.giant_pool - nrec) {
+            // (the pool's cursor: at most GIANT_SLOTS reservations of at most giant_pool events each — below 2^32, read as unsigned)
+            const bool may = a.giant_acc && g < GIANT_SLOTS && nrec <= a.giant_pool;
+            const int ev0 = may ? atomicAdd(a.n_giant_ev, nrec) : a.giant_pool;
+            if (may && (unsigned)ev0 <= (unsigned)(a.giant_pool - nrec)) {
                 gslot = g + 1;
                 int32_t *meta = a.giant_acc + (size_t)g * GIANT_STRIDE + GIANT_META;
                 meta[1] = ev0; meta[2] = nrec;
