@@ -345,7 +345,7 @@ struct BinHash { uint32_t key[HB], val[HB]; };              // key = bin + 1, 0 
 #ifndef C3R_CNT_SWZ
 #define C3R_CNT_SWZ 1
 #endif
-__device__ __forceinline__ uint32_t cnt_at(uint32_t b) {
+__host__ __device__ __forceinline__ uint32_t cnt_at(uint32_t b) {          // (__host__: tests/c/layout_check.hip)
     if (!C3R_CNT_SWZ) return b;
     const uint32_t g = (b >> 2) & 255u;
     return (b & ~1023u) | ((((g & 31u) << 3) | (g >> 5)) << 2) | (b & 3u);

@@ -164,6 +164,22 @@ def test_c_abi_from_plain_c(tmp_path):
     assert out.stdout.startswith("ok c3r")
 
 
+def test_bin_counter_layout_is_a_permutation_that_keeps_groups_and_separates_neighbours(tmp_path):
+    """K0's record counters (csrc/reads_kernels.hpp, cnt_at) are laid out so that the bins of one locus do not share cache lines: the layout must be
+    a permutation of every block of 1024 bins, keep a group of four bins in four consecutive words (k_bin_scan's 16-byte load), and put neighbouring
+    groups at least 128 bytes apart.  Host-side check of the very function the kernels use (hipcc, no GPU)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "layout_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-Wno-unused-function",
+                           os.path.join(ROOT, "tests", "c", "layout_check.hip"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("cnt_at ok"), out.stdout + out.stderr
+
+
 def test_phase1_bytes_counts_aligned_and_covered_positions():
     """bench.phase1_bytes (SURVEY 8d, phase 1): input records + C * 4 B per position with an aligned base or a deletion of a passing read;
     positions that reads only span with a ref-skip are counted apart; filtered reads count for the input bytes only."""
