@@ -342,6 +342,14 @@ constexpr int GIANT_SLICE = 4096;          // records per slice,
 constexpr int GIANT_MAX_HELP = 32;         //   at most this many slices per span (longer slices beyond)
 constexpr int GIANT_STRIDE = TILE * C3R_CH_PHASED + 2 * TILE + 16;     // int32 words per slot: cnt[TILE][C <= 30], maxdel[TILE], odd[TILE], GIANT_META..
 constexpr int GIANT_META = TILE * C3R_CH_PHASED + 2 * TILE;            //   {events met, the span's first event in the pool, events reserved}
+// slices of a giant span with n records (n >= 1) at `slice` records each: 1 .. GIANT_MAX_HELP; slice k of G over n items = [lo, hi), the G of them a
+// partition of [0, n) (the last ones may be empty).  (__host__: tests/c/layout_check.hip)
+__host__ __device__ __forceinline__ int giant_slices(int n, int slice) { const int g = n / slice + (n % slice != 0); return g < GIANT_MAX_HELP ? g : GIANT_MAX_HELP; }
+__host__ __device__ __forceinline__ void giant_slice(int n, int k, int G, int &lo, int &hi) {
+    const long long per = n / G + (n % G != 0), l = (long long)k * per, h = l + per;          // (n may be close to 2^31)
+    lo = (int)(l < n ? l : n);
+    hi = (int)(h < n ? h : n);
+}
 constexpr int GIANT_POOL_EVENTS = 12 << 20;                            // 40 bytes each (event + two table slots): 480 MB, allocated by a context that has met a giant span
 constexpr int DEEP_EVG_CAP = 49152;      // events of a span that a workgroup's global buffer holds (ScanArgs::ev_wg, ::giant_ev): a span at mpileup's depth cap has ~34 k
 
@@ -834,7 +842,7 @@ __global__ __launch_bounds__(256) void k_tile_ranges_fused(const ScanArgs a, int
                 gslot = g + 1;
                 int32_t *meta = a.giant_acc + (size_t)g * GIANT_STRIDE + GIANT_META;
                 meta[1] = ev0; meta[2] = nrec;
-                const int G = min(GIANT_MAX_HELP, (nrec + a.split_slice - 1) / a.split_slice);
+                const int G = giant_slices(nrec, a.split_slice);
                 const int h0 = atomicAdd(a.n_help, G);
                 for (int k = 0; k < G; ++k) a.help_list[h0 + k] = make_int4(at2, k, G, g);
             }
@@ -2485,8 +2493,9 @@ __global__ __launch_bounds__(DEEP_THREADS, DEEP_THREADS / 256) void k_deep_walk(
         if (tid < TILE) { s_maxdel[tid] = 0; s_odd[tid] = 0; }
         __syncthreads();
         const int t0 = r0.y - C3R_FLANK, t1 = min(r0.z + C3R_FLANK, r2.y);
-        const int per = (rng.w - rng.z + h.z - 1) / h.z;
-        const int lo = rng.z + h.y * per, hi = min(lo + per, rng.w);
+        int lo, hi;
+        giant_slice(rng.w - rng.z, h.y, h.z, lo, hi);
+        lo += rng.z; hi += rng.z;
         int32_t *acc = a.giant_acc + (size_t)h.w * GIANT_STRIDE;
         TileLds s{s_cnt, nullptr, nullptr, nullptr, s_maxdel, nullptr, nullptr, s_odd, nullptr, acc + GIANT_META, -1, a.giant_ev + acc[GIANT_META + 1], acc[GIANT_META + 2]};
         walk_records<C, ACCUM, DEEP_THREADS, DEEP_WALK_UNR>(a, s, lo, hi, t0, t1, r0.w, nullptr);
@@ -2527,10 +2536,10 @@ __global__ __launch_bounds__(DEEP_THREADS, DEEP_THREADS / 256) void k_deep_allel
             const int ev0 = acc[GIANT_META + 1];
             const EvRec *ev = a.giant_ev + ev0;
             uint2 *tab = a.giant_tab + 2 * (size_t)ev0;
-            const int per = (n_ev + h.z - 1) / h.z;
-            const int e1 = min(n_ev, (h.y + 1) * per);
+            int e0, e1;
+            giant_slice(n_ev, h.y, h.z, e0, e1);
 #pragma unroll 1
-            for (int e = h.y * per + tid; e < e1; e += DEEP_THREADS) {
+            for (int e = e0 + tid; e < e1; e += DEEP_THREADS) {
                 const EvRec me = ev[e];
                 const int nn = 2 * s_nev[me.pl];
                 uint2 *reg = tab + 2 * s_evoff[me.pl];

@@ -1,4 +1,5 @@
-// Host-side check of K0's counter layout (clair3_rna_amd/csrc/reads_kernels.hpp, cnt_at): compiled by hipcc, runs without a GPU.
+// Host-side checks of K0's counter layout (clair3_rna_amd/csrc/reads_kernels.hpp, cnt_at) and of the giant spans' slice arithmetic
+// (pileup_kernels.hpp, giant_slices / giant_slice): compiled by hipcc, runs without a GPU.
 //   * a permutation of every block of 1024 bins (no two bins share a counter, none leaves its block: the host sizes the array in whole blocks)
 //   * a group of four bins stays four consecutive, 16-byte-aligned words in bin order (k_bin_scan reads it with one load per thread)
 //   * neighbouring groups lie at least a cache line (128 bytes) apart — the point of the layout: the bins of one locus are neighbours
@@ -22,6 +23,22 @@ int main() {
             const long d = (long)c3r::cnt_at(b + 4) - (long)c3r::cnt_at(b);
             if ((d < 0 ? -d : d) * 4 < 128) { printf("groups %u and %u share a cache line\n", b / 4, b / 4 + 1); return 1; }
         }
-    printf("cnt_at ok (swizzle %d)\n", (int)C3R_CNT_SWZ);
+    // the slices of a giant span's records (k_deep_walk) and events (k_deep_alleles): 1 .. GIANT_MAX_HELP of them, a partition of [0, n) in order
+    const int ns[] = {1, 2, 63, 64, 65, 4095, 4096, 4097, 8192, 131071, 131072, 131073, 264960, 655904, 12582912, 2147483000, 2147483646};
+    const int slices[] = {1, 64, 4096, 16384};
+    for (int n : ns)
+        for (int sl : slices) {
+            const int G = c3r::giant_slices(n, sl);
+            if (G < 1 || G > c3r::GIANT_MAX_HELP || (G < c3r::GIANT_MAX_HELP && (long long)G * sl < n)) { printf("n %d slice %d: %d slices\n", n, sl, G); return 1; }
+            int at = 0;
+            for (int k = 0; k < G; ++k) {
+                int lo, hi;
+                c3r::giant_slice(n, k, G, lo, hi);
+                if (lo < hi) { if (lo != at) { printf("n %d G %d: slice %d starts at %d, not %d\n", n, G, k, lo, at); return 1; } at = hi; }
+                else if (lo < at) { printf("n %d G %d: empty slice %d before the end\n", n, G, k); return 1; }
+            }
+            if (at != n) { printf("n %d G %d: the slices end at %d\n", n, G, at); return 1; }
+        }
+    printf("cnt_at ok (swizzle %d), giant slices ok\n", (int)C3R_CNT_SWZ);
     return 0;
 }
