@@ -167,7 +167,8 @@ def test_c_abi_from_plain_c(tmp_path):
 def test_bin_counter_layout_is_a_permutation_that_keeps_groups_and_separates_neighbours(tmp_path):
     """K0's record counters (csrc/reads_kernels.hpp, cnt_at) are laid out so that the bins of one locus do not share cache lines: the layout must be
     a permutation of every block of 1024 bins, keep a group of four bins in four consecutive words (k_bin_scan's 16-byte load), and put neighbouring
-    groups at least 128 bytes apart.  Host-side check of the very function the kernels use (hipcc, no GPU)."""
+    groups at least 128 bytes apart.  The same program checks the giant spans' slice arithmetic (giant_slices / giant_slice: 1..32 slices, a partition
+    of the span's records in order, also for counts near 2^31).  Host-side checks of the very functions the kernels use (hipcc, no GPU)."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -177,7 +178,7 @@ def test_bin_counter_layout_is_a_permutation_that_keeps_groups_and_separates_nei
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-Wno-unused-function",
                            os.path.join(ROOT, "tests", "c", "layout_check.hip"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0 and out.stdout.startswith("cnt_at ok"), out.stdout + out.stderr
+    assert out.returncode == 0 and out.stdout.startswith("cnt_at ok") and "giant slices ok" in out.stdout, out.stdout + out.stderr
 
 
 def test_phase1_bytes_counts_aligned_and_covered_positions():
